@@ -1,0 +1,137 @@
+"""Deterministic synthetic inputs for tests and bench.
+
+libm-free: only +, -, *, compares and IEEE sqrt are used, so any re-implementation
+(C++/numpy) produces identical bits.  RNG: counter-based splitmix64,
+    base(seed, stream) = splitmix64(seed ^ splitmix64(stream))
+    U(seed, stream, i) = (splitmix64(base + i) >> 11) * 2**-53        in [0, 1)
+There is no reference counterpart: the reference ships no synthetic generator and its real
+point files are missing blobs (.MISSING_LARGE_BLOBS:2-14).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def splitmix64(x):
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = x + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+
+def _base(seed: int, stream) -> np.ndarray:
+    return splitmix64(np.uint64(seed) ^ splitmix64(np.asarray(stream, dtype=np.uint64)))
+
+
+def uniform(seed: int, stream, count: int, offset: int = 0) -> np.ndarray:
+    """U[0,1) doubles.  `stream` scalar -> shape (count,); array of S streams -> shape (S, count)."""
+    ctr = np.arange(offset, offset + count, dtype=np.uint64)
+    b = _base(seed, stream)
+    with np.errstate(over="ignore"):
+        h = splitmix64(b[..., None] + ctr) if np.ndim(b) else splitmix64(b + ctr)
+    return (h >> np.uint64(11)).astype(np.float64) * (2.0 ** -53)
+
+
+# ----------------------------------------------------------------------------- point clouds
+def scene_cloud(seed: int, cloud: int, P: int, max_rho: float = 45.0):
+    """Scene sampler of §8-d config 2: 32 boxes + 30 % ground plane, exactly P accepted points with
+    ||p|| < max_rho.  Returns (xyz float64 [P,3] camera frame, intensity float32 [P])."""
+    bx = uniform(seed, cloud * 4 + 0, 32 * 7).reshape(32, 7)
+    centre = np.stack([-38 + 76 * bx[:, 0], -4 + 5 * bx[:, 1], -24 + 48 * bx[:, 2]], 1)
+    half = np.stack([0.5 + 3.5 * bx[:, 3], 0.5 + 2.5 * bx[:, 4], 0.5 + 3.5 * bx[:, 5]], 1)
+    base_i = 20 + 215 * bx[:, 6]
+    out_xyz = np.empty((0, 3)); out_i = np.empty((0,))
+    off = 0
+    while out_xyz.shape[0] < P:
+        n = int((P - out_xyz.shape[0]) * 1.3) + 64
+        u = uniform(seed, cloud * 4 + 1, n * 6, off * 6).reshape(n, 6)
+        off += n
+        ground = u[:, 0] < 0.3
+        box = np.minimum((u[:, 1] * 32).astype(np.int64), 31)
+        pg = np.stack([-42 + 84 * u[:, 2], 1.6 + (-0.05 + 0.1 * u[:, 3]), -28 + 56 * u[:, 4]], 1)
+        pb = centre[box] + half[box] * (2 * u[:, 2:5] - 1)
+        p = np.where(ground[:, None], pg, pb)
+        it = np.where(ground, 60.0, base_i[box]) + (-20 + 40 * u[:, 5])
+        ok = (p * p).sum(1) < max_rho * max_rho
+        out_xyz = np.concatenate([out_xyz, p[ok]]); out_i = np.concatenate([out_i, it[ok]])
+    return np.ascontiguousarray(out_xyz[:P]), out_i[:P].astype(np.float32)
+
+
+def scene_clouds(seed: int, N: int, P: int, max_rho: float = 45.0, first: int = 0):
+    """N clouds in CSR layout: (xyz [N*P,3] f64, inten [N*P] f32, offs [N+1] i64)."""
+    xyz = np.empty((N * P, 3)); it = np.empty((N * P,), np.float32)
+    for c in range(N):
+        xyz[c * P:(c + 1) * P], it[c * P:(c + 1) * P] = scene_cloud(seed, first + c, P, max_rho)
+    return xyz, it, np.arange(N + 1, dtype=np.int64) * P
+
+
+# ----------------------------------------------------------------------------- SC signatures
+def sc_database(seed: int, n: int, first: int = 0, chunk: int = 4096) -> np.ndarray:
+    """SC signature sampler (§8-d metric config): [n, 2400] float64, row = [structure 1200 | intensity 1200],
+    bin = sector*20 + ring.  Structure bin occupied w.p. 0.6 with height U[0,8]; intensity bit
+    Bernoulli(0.45) on occupied bins."""
+    out = np.empty((n, 2400))
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        u = uniform(seed, np.arange(first + s, first + e, dtype=np.uint64), 3600).reshape(e - s, 3, 1200)
+        occ = u[:, 0] < 0.6
+        out[s:e, :1200] = np.where(occ, 8.0 * u[:, 1], 0.0)
+        out[s:e, 1200:] = np.where(occ & (u[:, 2] < 0.45), 1.0, 0.0)
+    return out
+
+
+def sc_queries(seed: int, db: np.ndarray, m: int, db_first: int = 0, n_global: int | None = None):
+    """Queries planted on DB entries: query t copies entry e_t = floor(U*n), rotated by floor(U*60) sectors,
+    mirrored w.p. 1/2, 3 % of bins re-drawn.  Returns (queries [m,2400], planted index [m] int64).
+    `db` may be a shard starting at global row db_first of an n_global-row DB; only queries whose planted
+    entry lies inside the shard are copied from it (the others are drawn from the sampler directly)."""
+    n = db.shape[0] if n_global is None else n_global
+    u = uniform(seed, np.arange(m, dtype=np.uint64), 3 + 3600)
+    et = np.minimum((u[:, 0] * n).astype(np.int64), n - 1)
+    shift = np.minimum((u[:, 1] * 60).astype(np.int64), 59)
+    mirror = u[:, 2] < 0.5
+    q = np.empty((m, 2400))
+    for t in range(m):
+        g = et[t] - db_first
+        src = db[g] if 0 <= g < db.shape[0] else sc_database(seed - 1, 1, first=int(et[t]))[0]
+        for ch in range(2):
+            img = src[ch * 1200:(ch + 1) * 1200].reshape(60, 20)
+            if mirror[t]:
+                img = img[(-np.arange(60)) % 60]
+            q[t, ch * 1200:(ch + 1) * 1200] = np.roll(img, shift[t], axis=0).reshape(-1)
+        r = u[t, 3:].reshape(3, 1200)
+        redo = r[0] < 0.03
+        occ = r[1] < 0.6
+        q[t, :1200] = np.where(redo, np.where(occ, 8.0 * r[2], 0.0), q[t, :1200])
+        q[t, 1200:] = np.where(redo, np.where(occ & (r[2] < 0.45), 1.0, 0.0), q[t, 1200:])
+    return q, et
+
+
+# ----------------------------------------------------------------------------- M2DP signatures
+def m2dp_database(seed: int, n: int, first: int = 0, chunk: int = 4096) -> np.ndarray:
+    """M2DP signature sampler (§8-d config 3): [4n, 384] float64; per entry/variant/channel
+    w = 0.3 + U(entry) + 0.15*(U(variant)-0.5); row = [u|v | u|v] with u = w[:64]/||.||, v = w[64:]/||.||."""
+    out = np.empty((4 * n, 384))
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        u = uniform(seed, np.arange(first + s, first + e, dtype=np.uint64), 384 * 5).reshape(e - s, 5, 2, 192)
+        w = 0.3 + u[:, :1] + 0.15 * (u[:, 1:] - 0.5)                      # [e, 4 variants, 2 ch, 192]
+        uu = w[..., :64] / np.sqrt((w[..., :64] ** 2).sum(-1, keepdims=True))
+        vv = w[..., 64:] / np.sqrt((w[..., 64:] ** 2).sum(-1, keepdims=True))
+        out[4 * s:4 * e] = np.concatenate([uu, vv], -1).reshape(4 * (e - s), 384)
+    return out
+
+
+def m2dp_queries(seed: int, db: np.ndarray, m: int):
+    """Query t copies DB entry e_t (all 4 variant rows), adds 0.05*(U-0.5) per element, renormalises u and v."""
+    n = db.shape[0] // 4
+    u = uniform(seed, np.arange(m, dtype=np.uint64), 1 + 4 * 384)
+    et = np.minimum((u[:, 0] * n).astype(np.int64), n - 1)
+    rows = db.reshape(n, 4, 2, 192)[et] + 0.05 * (u[:, 1:].reshape(m, 4, 2, 192) - 0.5)
+    uu = rows[..., :64] / np.sqrt((rows[..., :64] ** 2).sum(-1, keepdims=True))
+    vv = rows[..., 64:] / np.sqrt((rows[..., 64:] ** 2).sum(-1, keepdims=True))
+    return np.concatenate([uu, vv], -1).reshape(4 * m, 384), et

@@ -1,0 +1,36 @@
+"""The one reference-pinned known-answer test: incoming_id_file.txt is a function of
+poses_history_file.txt alone (pts_preprocess.h:187-215).  Checked for the oracle and the numpy checker."""
+import os
+
+import numpy as np
+import pytest
+
+import np_checker
+import oracle_lib
+
+SEQS = ["kitti_seq06", "kitti_seq07"]
+
+
+@pytest.mark.parametrize("seq", SEQS)
+def test_numpy_checker_reproduces_incoming_ids(golden_dir, seq):
+    d = os.path.join(golden_dir, seq)
+    want = [int(x) for x in open(os.path.join(d, "incoming_id_file.txt")).read().split()]
+    assert np_checker.incoming_ids(os.path.join(d, "poses_history_file.txt")) == want
+
+
+@pytest.mark.parametrize("seq", SEQS)
+def test_oracle_incoming_id_file_is_byte_identical(golden_dir, seq, tmp_path):
+    d = os.path.join(golden_dir, seq)
+    empty_pts = tmp_path / "pts.txt"
+    empty_pts.write_text("")
+    out = tmp_path / "ids.txt"
+    xyz, it, offs, ids = oracle_lib.pts_preprocess(os.path.join(d, "poses_history_file.txt"), str(empty_pts), str(out))
+    assert out.read_bytes() == open(os.path.join(d, "incoming_id_file.txt"), "rb").read()
+    assert len(ids) == len(offs) - 1 and offs[-1] == 0
+
+
+def test_reference_sizes_from_survey(golden_dir):
+    # seq06 -> 880 signatures, seq07 -> 693
+    for seq, n in (("kitti_seq06", 880), ("kitti_seq07", 693)):
+        ids = open(os.path.join(golden_dir, seq, "incoming_id_file.txt")).read().split()
+        assert len(ids) == n
