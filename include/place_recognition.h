@@ -1,0 +1,102 @@
+/* place_recognition.h — C ABI of libpr_amd.so, the MI355X (gfx950) implementation of the
+ * so_dso_place_recognition hot path: generate_signatures (Scan-Context + M2DP) and match_signatures.
+ *
+ * The reference has no FFI; its boundary is two C++ classes, two executables and three MATLAB functions
+ * (SURVEY.md §8-b).  Every entry point below names the reference interface it replaces (file:line under
+ * /root/reference/place_recognition/).  Conventions: flat arrays, caller-owned buffers, int status
+ * (0 = PR_OK, <0 = error, text via pr_last_error), no exceptions across the boundary, one host thread per
+ * context, one HIP device + one HIP stream per context.  There is NO CPU fallback: every call fails with
+ * PR_EHIP when no gfx950 device is usable.
+ */
+#ifndef PLACE_RECOGNITION_H
+#define PLACE_RECOGNITION_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pr_ctx pr_ctx;
+typedef struct pr_sigset pr_sigset;
+
+enum { PR_OK = 0, PR_EINVAL = -1, PR_ENOMEM = -2, PR_EHIP = -3, PR_EIO = -4, PR_ENAN = -5 };
+enum { PR_TYPE_SC = 0, PR_TYPE_M2DP = 1 };          /* run_test.m:27-30 `type` */
+enum { PR_ROLE_QUERY = 0, PR_ROLE_DB = 1 };         /* hist1 / hist2 of run_test.m:1 */
+enum { PR_F64 = 0, PR_F32 = 1 };
+enum { PR_HOST = 0, PR_DEVICE = 1 };
+
+#define PR_SC_SIG_LEN 2400    /* 2 x numS*numR = 2 x 60*20, SC/SC.h:7-8, test_sc.cpp:37-38 */
+#define PR_M2DP_SIG_LEN 384   /* 2 x (numP*numQ + numS*numR) = 2 x 192, M2DP/M2DP.h:7-10, test_m2dp.cpp:37-39 */
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int pr_create(int device_id, pr_ctx** out);
+void pr_destroy(pr_ctx* ctx);
+const char* pr_last_error(const pr_ctx* ctx);        /* valid until the next call on ctx; ctx may be NULL */
+const char* pr_version(void);
+int pr_sync(pr_ctx* ctx);                            /* waits for the context's stream; reports deferred errors */
+void* pr_stream(pr_ctx* ctx);                        /* the context's hipStream_t (for event timing by the caller) */
+
+/* ---- host-buffer entry points = the reference's own call boundary --------------------------------- */
+
+/* Replaces SC::getSignature looped as in SC/test_sc.cpp:40-56 (SC/SC.h:10-23, SC/SC.cpp:12-76; PCA alignment
+ * utils/pts_align.h:7-46 happens inside, as in SC.cpp:17).  Clouds in CSR layout: xyz[offs[N]][3] f64 camera
+ * frame, inten[offs[N]] f32, offs[N+1].  out[N][2400] = [structure | intensity], bin = sector*20 + ring. */
+int pr_sc_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
+                   double max_rho, double* out);
+
+/* Replaces the per-cloud body of M2DP/test_m2dp.cpp:41-68: align_points_PCA once, 4 sign variants,
+ * M2DP::getSignature (M2DP/M2DP.h:12-30, M2DP/M2DP.cpp:38-109) each.  out[4N][384]. */
+int pr_m2dp_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
+                     double max_rho, double* out);
+
+/* Replaces processSC(hist1, hist2) (match_signatures/processSC.m:1-45).  h1[m][2400], h2[n][2400] host f64;
+ * d_struct / d_int: host f32 [m][n], either may be NULL.  PR_ENAN if a row has zero norm (MATLAB: NaN row). */
+int pr_sc_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n,
+                   float* d_struct, float* d_int);
+
+/* Replaces processM2DP(hist1, hist2) (match_signatures/processM2DP.m:1-22).  h1[4m][384], h2[4n][384]. */
+int pr_m2dp_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n,
+                     float* d_cnt, float* d_int);
+
+/* Replaces run_test.m:26-57 (distance matrices, 2:1 z-score fusion :38-41, mask :47-53, row min :57),
+ * generalised to top-k; k = 1 is the reference.  Ties -> lower index (MATLAB min).  idx[m][k] (0-based,
+ * -1 when fewer than k candidates), score[m][k] fused z-score. */
+int pr_match_topk(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n,
+                  int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score);
+
+/* ---- device-resident entry points (inputs already in HBM; what bench.py and the multi-GPU layer call) -- *
+ * All are asynchronous on the context's stream; pr_sync() surfaces deferred errors (e.g. PR_ENAN).         */
+
+/* A packed signature set: rows normalised as processSC.m:15-20 and stored as the per-ring sector spectra
+ * (SC), or the 4-variant rows as-is (M2DP, processM2DP.m:15), in the MFMA operand layout of its role. */
+int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigset** out);
+void pr_sigset_destroy(pr_ctx* ctx, pr_sigset* s);
+int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int where, int32_t n_sigs);
+int32_t pr_sigset_count(const pr_sigset* s);
+
+/* processSC.m:22-33 / processM2DP.m:15-21 on packed sets.  d_p, d_i: DEVICE f32 [m][n] (row stride n). */
+int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float* d_p, float* d_i);
+
+/* Per-row two-pass moments of a distance shard (first half of MATLAB normalize(.,2), run_test.m:40):
+ * mom: DEVICE f64 [m][2][3] = (count, mean, M2 = sum (x-mean)^2) for channel 0 = d_p, 1 = d_i. */
+int pr_row_moments_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n, double* mom);
+
+/* run_test.m:38-41 + :47-53 + :57 on a DB shard.  mom_all: DEVICE f64 [G][m][2][3] moments of ALL G shards
+ * (combined in rank order, N-1 std); the shard's DB rows are global rows db_row0..db_row0+n-1 and its query
+ * rows global q_row0..; mask is |i-j| < mask_width on GLOBAL indices.  idx: DEVICE i32 [m][k] GLOBAL DB
+ * indices (-1 = none), score: DEVICE f32 [m][k]. */
+int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n,
+                       const double* mom_all, int32_t G, int32_t q_row0, int32_t db_row0, int32_t mask_width,
+                       double p_weight, int32_t k, int32_t* idx, float* score);
+
+/* Device-buffer variants of the generators (same layouts as the host versions, pointers in HBM). */
+int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
+                       double max_rho, double* out);
+int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
+                         double max_rho, double* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLACE_RECOGNITION_H */

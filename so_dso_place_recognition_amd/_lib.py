@@ -1,0 +1,74 @@
+"""ctypes loader of libpr_amd.so (the C ABI of include/place_recognition.h).
+
+There is no fallback: if the shared library is missing this raises, and every entry point of the library
+itself fails with PR_EHIP when no gfx950 device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+PR_OK, PR_EINVAL, PR_ENOMEM, PR_EHIP, PR_EIO, PR_ENAN = 0, -1, -2, -3, -4, -5
+TYPE_SC, TYPE_M2DP = 0, 1
+ROLE_QUERY, ROLE_DB = 0, 1
+F64, F32 = 0, 1
+HOST, DEVICE = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpr_amd.so")
+
+# every symbol include/place_recognition.h declares: (name, restype, argtypes)
+_vp, _i32, _dbl = C.c_void_p, C.c_int32, C.c_double
+SYMBOLS = {
+    "pr_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "pr_destroy": (None, [_vp]),
+    "pr_last_error": (C.c_char_p, [_vp]),
+    "pr_version": (C.c_char_p, []),
+    "pr_sync": (C.c_int, [_vp]),
+    "pr_stream": (_vp, [_vp]),
+    "pr_sc_generate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
+    "pr_m2dp_generate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
+    "pr_sc_distance": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp]),
+    "pr_m2dp_distance": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp]),
+    "pr_match_topk": (C.c_int, [_vp, C.c_int, _vp, _i32, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
+    "pr_sigset_create": (C.c_int, [_vp, C.c_int, C.c_int, _i32, C.POINTER(_vp)]),
+    "pr_sigset_destroy": (None, [_vp, _vp]),
+    "pr_sigset_pack": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _i32]),
+    "pr_sigset_count": (_i32, [_vp]),
+    "pr_distances_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "pr_row_moments_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "pr_fuse_select_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp]),
+    "pr_sc_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
+    "pr_m2dp_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
+}
+
+_lib = None
+
+
+class PRError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"libpr_amd error {code}: {msg}")
+        self.code = code
+
+
+def load() -> C.CDLL:
+    """Loads libpr_amd.so and binds every declared symbol (raises if the library or a symbol is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} not found: build it with `make -C so_dso_place_recognition_amd/csrc` "
+                      "(or __graft_entry__.build()); there is no CPU fallback")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(ctx, rc: int):
+    if rc != PR_OK:
+        msg = load().pr_last_error(ctx)
+        raise PRError(rc, msg.decode() if msg else "")

@@ -1,0 +1,185 @@
+"""Host-side mirror of the reference's interface for the hot path, on top of the C ABI (libpr_amd.so).
+
+Same names, argument meaning and error behaviour as the reference:
+  SC / M2DP classes            SC/SC.h:10-23, M2DP/M2DP.h:12-30  (getSignatureSize / getSignature)
+  processSC / processM2DP      match_signatures/processSC.m:1, processM2DP.m:1
+  run_test                     match_signatures/run_test.m:1  (fusion, mask, top-1; PR/AUC evaluation in eval.py)
+Arrays are numpy on the host; the device-resident path used by bench.py / dist.py is `Matcher`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import PRError, TYPE_M2DP, TYPE_SC  # noqa: F401
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Context:
+    """One HIP device + stream (pr_ctx)."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.pr_create(device, C.byref(h))
+        if rc != 0:
+            raise PRError(rc, self.lib.pr_last_error(None).decode())
+        self.h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pr_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        _lib.check(self.h, rc)
+
+    def sync(self):
+        self.check(self.lib.pr_sync(self.h))
+
+    @property
+    def stream(self) -> int:
+        return int(self.lib.pr_stream(self.h) or 0)
+
+
+_default_ctx = None
+
+
+def default_context() -> Context:
+    global _default_ctx
+    if _default_ctx is None:
+        _default_ctx = Context(0)
+    return _default_ctx
+
+
+def _csr(pts_list):
+    """list of (xyz [P,3], intensity [P]) -> CSR arrays."""
+    offs = np.zeros(len(pts_list) + 1, np.int64)
+    for i, (p, _) in enumerate(pts_list):
+        offs[i + 1] = offs[i] + len(p)
+    xyz = np.ascontiguousarray(np.concatenate([np.asarray(p, np.float64).reshape(-1, 3) for p, _ in pts_list])
+                               if pts_list else np.zeros((0, 3)))
+    it = np.ascontiguousarray(np.concatenate([np.asarray(i, np.float32).reshape(-1) for _, i in pts_list])
+                              if pts_list else np.zeros((0,), np.float32))
+    return xyz, it, offs
+
+
+def sc_generate(xyz, inten, offs, max_rho=45.0, ctx: Context | None = None) -> np.ndarray:
+    """test_sc.cpp:40-56 over clouds in CSR layout -> [N, 2400]."""
+    ctx = ctx or default_context()
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    inten = np.ascontiguousarray(inten, np.float32)
+    offs = np.ascontiguousarray(offs, np.int64)
+    N = len(offs) - 1
+    out = np.empty((N, 2400))
+    ctx.check(ctx.lib.pr_sc_generate(ctx.h, _ptr(xyz), _ptr(inten), _ptr(offs), N, float(max_rho), _ptr(out)))
+    return out
+
+
+def m2dp_generate(xyz, inten, offs, max_rho=45.0, ctx: Context | None = None) -> np.ndarray:
+    """test_m2dp.cpp:41-68 over clouds in CSR layout -> [4N, 384]."""
+    ctx = ctx or default_context()
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    inten = np.ascontiguousarray(inten, np.float32)
+    offs = np.ascontiguousarray(offs, np.int64)
+    N = len(offs) - 1
+    out = np.empty((4 * N, 384))
+    ctx.check(ctx.lib.pr_m2dp_generate(ctx.h, _ptr(xyz), _ptr(inten), _ptr(offs), N, float(max_rho), _ptr(out)))
+    return out
+
+
+class SC:
+    """SC/SC.h:10-23."""
+
+    def __init__(self, max_rho: float, ctx: Context | None = None):
+        self.max_rho = float(max_rho)
+        self.ctx = ctx
+
+    def getSignatureSize(self) -> int:
+        return 1200
+
+    def getSignature(self, pts, intensity):
+        """pts [P,3] camera frame (PCA alignment happens inside, SC.cpp:17) -> (structure[1200], intensity[1200])."""
+        xyz, it, offs = _csr([(pts, intensity)])
+        row = sc_generate(xyz, it, offs, self.max_rho, self.ctx)[0]
+        return row[:1200].copy(), row[1200:].copy()
+
+
+class M2DP:
+    """M2DP/M2DP.h:12-30.  The reference driver aligns once and loops the 4 sign variants (test_m2dp.cpp:44-68);
+    getSignatures returns all 4 rows of that loop."""
+
+    def __init__(self, max_rho: float, ctx: Context | None = None):
+        self.max_rho = float(max_rho)
+        self.ctx = ctx
+
+    def getSignatureSize(self) -> int:
+        return 192
+
+    def getSignatures(self, pts, intensity):
+        xyz, it, offs = _csr([(pts, intensity)])
+        return m2dp_generate(xyz, it, offs, self.max_rho, self.ctx)
+
+
+def _distance(fn_name, div, width, hist1, hist2, ctx):
+    ctx = ctx or default_context()
+    h1 = np.ascontiguousarray(hist1, np.float64)
+    h2 = np.ascontiguousarray(hist2, np.float64)
+    if h1.ndim != 2 or h2.ndim != 2 or h1.shape[1] != width or h2.shape[1] != width or h1.shape[0] % div or h2.shape[0] % div:
+        raise ValueError(f"expected [{div}*m, {width}] and [{div}*n, {width}] signature matrices")
+    m, n = h1.shape[0] // div, h2.shape[0] // div
+    dp = np.empty((m, n), np.float32)
+    di = np.empty((m, n), np.float32)
+    ctx.check(getattr(ctx.lib, fn_name)(ctx.h, _ptr(h1), m, _ptr(h2), n, _ptr(dp), _ptr(di)))
+    return dp, di
+
+
+def processSC(hist1, hist2, ctx: Context | None = None):
+    """[diff_m_p, diff_m_i] = processSC(hist1, hist2)  (processSC.m:1); float32 [m, n] each."""
+    return _distance("pr_sc_distance", 1, 2400, hist1, hist2, ctx)
+
+
+def processM2DP(hist1, hist2, ctx: Context | None = None):
+    """[diff_m_p, diff_m_i] = processM2DP(hist1, hist2)  (processM2DP.m:1); hist rows come in groups of 4 variants."""
+    return _distance("pr_m2dp_distance", 4, 384, hist1, hist2, ctx)
+
+
+def match_topk(type_, hist1, hist2, mask_width=0, p_weight=2.0, k=1, ctx: Context | None = None):
+    """run_test.m:26-57 generalised to top-k: returns (idx int32 [m,k] 0-based, score float32 [m,k])."""
+    ctx = ctx or default_context()
+    t = {"sc": TYPE_SC, "m2dp": TYPE_M2DP}.get(type_, type_)
+    if t not in (TYPE_SC, TYPE_M2DP):
+        raise ValueError("type must be 'sc' or 'm2dp'")
+    div, width = (1, 2400) if t == TYPE_SC else (4, 384)
+    h1 = np.ascontiguousarray(hist1, np.float64)
+    h2 = np.ascontiguousarray(hist2, np.float64)
+    if h1.shape[1] != width or h2.shape[1] != width:
+        raise ValueError(f"signature width must be {width}")
+    m, n = h1.shape[0] // div, h2.shape[0] // div
+    idx = np.empty((m, k), np.int32)
+    sc = np.empty((m, k), np.float32)
+    ctx.check(ctx.lib.pr_match_topk(ctx.h, t, _ptr(h1), m, _ptr(h2), n, int(mask_width), float(p_weight), int(k),
+                                    _ptr(idx), _ptr(sc)))
+    return idx, sc
+
+
+def run_test(type_, hist1, hist2, gt1=None, gt2=None, loop_diff=None, mask_width=0, ctx: Context | None = None):
+    """run_test.m:1.  Without ground truth: returns (diff_v, diff_idx) of run_test.m:57 (0-based indices).
+    With gt1/gt2/loop_diff: returns (AUC, top_recall, lp_detected) through eval.precision_recall."""
+    idx, sc = match_topk(type_, hist1, hist2, mask_width, 2.0, 1, ctx)
+    if gt1 is None:
+        return sc[:, 0], idx[:, 0]
+    from . import eval as _eval
+    return _eval.precision_recall(sc[:, 0], idx[:, 0], np.asarray(gt1), np.asarray(gt2), loop_diff, mask_width)

@@ -1,0 +1,146 @@
+// fuse_select.hip — z-score fusion, mask and top-k of run_test.m:38-41, :47-53, :57 on gfx950.
+//
+// MATLAB normalize(d,2) = (d - mean)/std per row with the N-1 standard deviation, computed over the WHOLE row
+// including entries that the mask will later discard (mask is applied after normalisation).  Two kernels:
+//   row_moments : per query row and channel, two-pass (count, mean, M2) in fp64 with a fixed reduction tree
+//                 (deterministic).  One workgroup per row; the row (n x 4 B per channel) is read twice, the
+//                 second time from L2.  HBM-bound: 8 B per (query, entry) pair.
+//   fuse_select : combines the moments of G DB shards in rank order (Chan), then
+//                 fused = p_weight*(d_p-mean_p)/std_p + (d_i-mean_i)/std_i  (run_test.m:40), +Inf where
+//                 |i-j| < mask_width on GLOBAL indices (:47-53), and selects the k smallest (value, index)
+//                 pairs in lexicographic order, i.e. ties go to the lower index like MATLAB min (:57).
+#include "kernels.hpp"
+
+namespace pr {
+namespace {
+
+__device__ __forceinline__ double block_sum(double v, double* red, int tid) {
+  red[tid] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void row_moments_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i,
+                                                           int n, double* __restrict__ mom) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x, q = blockIdx.x;
+  for (int ch = 0; ch < 2; ch++) {
+    const float* row = (ch ? d_i : d_p) + (size_t)q * n;
+    double s = 0.0;
+    for (int j = tid; j < n; j += 256) s += (double)row[j];
+    const double mean = block_sum(s, red, tid) / (double)n;
+    double v = 0.0;
+    for (int j = tid; j < n; j += 256) {
+      const double d = (double)row[j] - mean;
+      v += d * d;
+    }
+    const double m2 = block_sum(v, red, tid);
+    if (tid == 0) {
+      double* o = mom + ((size_t)q * 2 + ch) * 3;
+      o[0] = (double)n;
+      o[1] = mean;
+      o[2] = m2;
+    }
+  }
+}
+
+struct Cand {
+  double v;
+  int j;
+};
+__device__ __forceinline__ bool cand_less(double av, int aj, double bv, int bj) {   // (a) < (b) lexicographic
+  return av < bv || (av == bv && aj < bj);
+}
+
+__global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i,
+                                                           int m, int n, const double* __restrict__ mom_all, int G,
+                                                           int q_row0, int db_row0, int mask_width, double p_weight,
+                                                           int k, int32_t* __restrict__ idx, float* __restrict__ score) {
+  __shared__ double st[4];
+  __shared__ double rv[256];
+  __shared__ int rj[256];
+  const int tid = threadIdx.x, q = blockIdx.x;
+  if (tid < 2) {  // Chan's parallel combination of the shard moments, fixed (rank) order
+    double cn = 0.0, mean = 0.0, m2 = 0.0;
+    for (int g = 0; g < G; g++) {
+      const double* o = mom_all + (((size_t)g * m + q) * 2 + tid) * 3;
+      const double nb = o[0], mb = o[1], m2b = o[2];
+      if (nb <= 0.0) continue;
+      const double tot = cn + nb, delta = mb - mean;
+      mean += delta * (nb / tot);
+      m2 += m2b + delta * delta * (cn * nb / tot);
+      cn = tot;
+    }
+    st[tid * 2] = mean;
+    st[tid * 2 + 1] = sqrt(m2 / (cn - 1.0));
+  }
+  __syncthreads();
+  const double mp = st[0], sp = st[1], mi = st[2], si = st[3];
+  const float* rp = d_p + (size_t)q * n;
+  const float* ri = d_i + (size_t)q * n;
+  const int ig = q_row0 + q;
+  double pv = -__builtin_inf();
+  int pj = -1;
+  for (int t = 0; t < k; t++) {
+    double bv = 0.0;
+    int bj = -1;
+    for (int j = tid; j < n; j += 256) {
+      const int jg = db_row0 + j;
+      double f = p_weight * (((double)rp[j] - mp) / sp) + ((double)ri[j] - mi) / si;   // run_test.m:40
+      int dij = ig - jg;
+      if (dij < 0) dij = -dij;
+      if (dij < mask_width) f = __builtin_inf();                                      // run_test.m:47-53
+      if (f != f) continue;                                                            // NaN never wins (MATLAB min)
+      if (!cand_less(pv, pj, f, jg)) continue;                                         // already selected
+      if (bj < 0 || cand_less(f, jg, bv, bj)) { bv = f; bj = jg; }
+    }
+    rv[tid] = bv;
+    rj[tid] = bj;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) {
+        const int oj = rj[tid + s];
+        if (oj >= 0 && (rj[tid] < 0 || cand_less(rv[tid + s], oj, rv[tid], rj[tid]))) {
+          rv[tid] = rv[tid + s];
+          rj[tid] = oj;
+        }
+      }
+      __syncthreads();
+    }
+    pv = rv[0];
+    pj = rj[0];
+    __syncthreads();
+    if (tid == 0) {
+      idx[(size_t)q * k + t] = pj;
+      score[(size_t)q * k + t] = (pj >= 0) ? (float)pv : __builtin_nanf("");
+    }
+    if (pj < 0) {  // fewer than k candidates: fill the rest
+      if (tid == 0)
+        for (int u = t + 1; u < k; u++) { idx[(size_t)q * k + u] = -1; score[(size_t)q * k + u] = __builtin_nanf(""); }
+      break;
+    }
+  }
+}
+
+}  // namespace
+
+void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(row_moments_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, n, mom);
+}
+
+void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int m, int n, const double* mom_all,
+                        int G, int q_row0, int db_row0, int mask_width, double p_weight, int k, int32_t* idx,
+                        float* score) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(fuse_select_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, m, n, mom_all, G, q_row0, db_row0,
+                     mask_width, p_weight, k, idx, score);
+}
+
+}  // namespace pr

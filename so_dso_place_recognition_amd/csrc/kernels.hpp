@@ -1,0 +1,46 @@
+// kernels.hpp — launch wrappers of the gfx950 kernels (internal to libpr_amd.so).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pr {
+
+// ------------------------------------------------------------------ packed layouts
+constexpr int SC_NF = 31;                       // rfft bins of the 60 sectors
+constexpr int SC_QIMG = SC_NF * 320;            // floats per (channel, 8-query group): [f][s(5)][lane(64)]
+constexpr int SC_DSTEP = 640;                   // floats per (channel, 16-entry DB group, f)
+constexpr int SC_DIMG = SC_NF * SC_DSTEP;       // floats per (channel, 16-entry DB group)
+constexpr int M2_TILE = 96 * 64;                // floats per (channel, 32-row tile): [kq(24)][lane(64)][4]
+
+inline int sc_qgroups8(int m) { return ((m + 31) / 32) * 4; }
+inline int sc_dgroups(int n) { return (n + 15) / 16; }
+inline int m2_tiles(int sigs) { return (sigs + 7) / 8; }      // 8 signatures x 4 variants = 32 rows
+
+// sc_pack.hip — processSC.m:15-20 (row L2 normalisation) + per-ring rfft over the 60 sectors, written in the
+// MFMA operand layout of `role`.  sig: device [rows][2400] of T.  flags[0] |= 1 if a row has zero norm.
+void launch_sc_pack(hipStream_t st, const void* sig, int dtype, int rows, int role, float* packed, int groups,
+                    const double* twiddle, int* flags);
+// sc_match.hip — processSC.m:22-33 for both channels.  Writes d_p, d_i device [m][n].
+void launch_sc_match(hipStream_t st, const float* qpk, int m, const float* dpk, int n, const float* cst,
+                     float* d_p, float* d_i, int nsplit_override);
+size_t sc_match_lds_bytes();
+
+// m2dp_match.hip — processM2DP.m:12-22 for both channels.
+void launch_m2dp_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed, int tiles);
+void launch_m2dp_match(hipStream_t st, const float* qpk, int m, const float* dpk, int n, float* d_p, float* d_i);
+
+// fuse_select.hip — run_test.m:38-41,47-53,57
+void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom);
+void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int m, int n, const double* mom_all,
+                        int G, int q_row0, int db_row0, int mask_width, double p_weight, int k, int32_t* idx,
+                        float* score);
+
+// sc_gen.hip / m2dp_gen.hip — pts_align.h:7-46 + SC.cpp:12-76 / M2DP.cpp:38-109 (+ test_m2dp.cpp:44-68)
+void launch_cloud_frames(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double* frames);
+void launch_sc_generate(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
+                        double max_rho, double* out, double* frames);
+void launch_m2dp_generate(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
+                          double max_rho, double* out, const double* planes, void* scratch, size_t scratch_bytes);
+size_t m2dp_generate_scratch_bytes(int N);
+
+}  // namespace pr

@@ -1,0 +1,221 @@
+// m2dp_gen.hip — M2DP signature (M2DP/M2DP.cpp:38-109 + the 4-variant loop of test_m2dp.cpp:44-68) on gfx950.
+//
+// After cloud_frames (sc_gen.hip; PCA frame + float average, once per cloud as test_m2dp.cpp:45):
+//   m2dp_bin  : grid (cloud, variant, group of 16 planes).  Each thread centres + rotates its points, applies the
+//               variant signs pt' = (dx x, dy y, dx dy z) (test_m2dp.cpp:52-56), and for each of the group's planes
+//               xp = xProj.pt', yp = yProj.pt' evaluated as a0*b0 + (a1*b1 + a2*b2) with NO zero seed so that the
+//               degenerate plane 32 (xProj = yProj = +0) keeps its signed-zero behaviour;
+//               si = floor((atan2(yp,xp)+pi)*16/2pi), ri = floor(sqrt(xp^2+yp^2)*8/max_rho), idx = ri*16+si,
+//               dropped iff idx >= 128 (M2DP.cpp:66-68).  LDS-resident 16x128 count (u32) and intensity (f64) grids,
+//               LDS atomics; then mean > ave ? 1 : 0 (M2DP.cpp:84-91) and both 16x128 slabs go to the scratch
+//               matrices [cloud][variant][{count,intensity}][64][128] (f64).
+//   m2dp_svd  : grid (cloud, variant, channel): leading singular pair of the 64x128 matrix (JacobiSVD U.col(0),
+//               V.col(0), M2DP.cpp:94-103) in fp64: G = A A^T (64x64) in LDS, 8 normalised squarings (G^256),
+//               u = dominant column, then polished with u <- A(A^T u)/||.|| on the original matrix until the
+//               update is below 4e-15; v = A^T u / sigma.  Sign: sum(u) >= 0 (N6).  Zero matrix -> (e0, e0).
+// Bound: fp64 VALU / transcendental (256 P atan2 per cloud), not HBM and not MFMA.
+#include "kernels.hpp"
+
+namespace pr {
+namespace {
+
+constexpr int MAT = 64 * 128;
+
+__global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict__ xyz, const float* __restrict__ inten,
+                                                        const int64_t* __restrict__ offs, const double* __restrict__ frames,
+                                                        const double* __restrict__ planes, double max_rho, int c0,
+                                                        double* __restrict__ mats) {
+  __shared__ unsigned int cnt[16 * 128];
+  __shared__ double isum[16 * 128];
+  __shared__ double pl[16][6];
+  const int tid = threadIdx.x;
+  const int pg = blockIdx.x & 3, var = (blockIdx.x >> 2) & 3, cl = blockIdx.x >> 4;
+  const int c = c0 + cl;
+  const int64_t o0 = offs[c];
+  const int64_t P = offs[c + 1] - o0;
+  for (int b = tid; b < 16 * 128; b += 256) { cnt[b] = 0u; isum[b] = 0.0; }
+  if (tid < 96) {
+    const int k = tid / 6, a = tid % 6;
+    pl[k][a] = (a < 3) ? planes[(pg * 16 + k) * 3 + a] : planes[64 * 3 + (pg * 16 + k) * 3 + (a - 3)];
+  }
+  __syncthreads();
+  const double* f = frames + (size_t)c * 16;
+  const double mx = f[0], my = f[1], mz = f[2];
+  const double e00 = f[3], e01 = f[4], e02 = f[5], e10 = f[6], e11 = f[7], e12 = f[8], e20 = f[9], e21 = f[10], e22 = f[11];
+  // variants in the order (-,-), (-,+), (+,-), (+,+)  (test_m2dp.cpp:47-48)
+  const double dx = (var & 2) ? 1.0 : -1.0, dy = (var & 1) ? 1.0 : -1.0, dz = dx * dy;
+  const double S_res_inv = 16 / (2.0 * M_PI), R_res_inv = 8 / max_rho;   // M2DP.cpp:32-33
+  const double* p = xyz + 3 * o0;
+  const float* it = inten + o0;
+  for (int64_t i = tid; i < P; i += 256) {
+    const double x = p[3 * i] - mx, y = p[3 * i + 1] - my, z = p[3 * i + 2] - mz;
+    const double q0 = dx * ((x * e00 + y * e01) + z * e02);
+    const double q1 = dy * ((x * e10 + y * e11) + z * e12);
+    const double q2 = dz * ((x * e20 + y * e21) + z * e22);
+    const double iv = (double)it[i];
+#pragma unroll 4
+    for (int k = 0; k < 16; k++) {
+      const double xp = pl[k][0] * q0 + (pl[k][1] * q1 + pl[k][2] * q2);   // M2DP.cpp:56
+      const double yp = pl[k][3] * q0 + (pl[k][4] * q1 + pl[k][5] * q2);   // :57
+      const int si = (int)floor((atan2(yp, xp) + M_PI) * S_res_inv);
+      const int ri = (int)floor(sqrt(xp * xp + yp * yp) * R_res_inv);
+      const int idx = ri * 16 + si;
+      if (idx >= 128 || idx < 0) continue;
+      atomicAdd(&cnt[k * 128 + idx], 1u);
+      atomicAdd(&isum[k * 128 + idx], iv);
+    }
+  }
+  __syncthreads();
+  const double ave = f[12];
+  double* mc = mats + (((size_t)cl * 4 + var) * 2) * MAT + (size_t)pg * 16 * 128;
+  double* mi = mc + MAT;
+  for (int b = tid; b < 16 * 128; b += 256) {
+    const unsigned int n = cnt[b];
+    mc[b] = (double)n;
+    mi[b] = n ? ((isum[b] / (double)n) > ave ? 1.0 : 0.0) : 0.0;
+  }
+}
+
+__device__ __forceinline__ double block_sum256(double v, double* red, int tid) {
+  red[tid] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict__ mats, int c0, double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  double* A = sm;               // 64 x 129 (padded rows)
+  double* G = A + 64 * 129;     // 64 x 65
+  double* H = G + 64 * 65;      // 64 x 65
+  double* u = H + 64 * 65;      // 64
+  double* v = u + 64;           // 128
+  double* red = v + 128;        // 256
+  const int tid = threadIdx.x;
+  const int ch = blockIdx.x & 1, var = (blockIdx.x >> 1) & 3, cl = blockIdx.x >> 3;
+  const double* src = mats + (((size_t)cl * 4 + var) * 2 + ch) * MAT;
+  double fro = 0.0;
+  for (int e = tid; e < MAT; e += 256) {
+    const double a = src[e];
+    A[(e >> 7) * 129 + (e & 127)] = a;
+    fro += a * a;
+  }
+  fro = block_sum256(fro, red, tid);   // also orders the A stores
+  double* o = out + ((size_t)(c0 + cl) * 4 + var) * 384 + ch * 192;
+  if (!(fro > 0.0)) {                  // JacobiSVD of a zero matrix: identity factors
+    for (int e = tid; e < 192; e += 256) o[e] = (e == 0 || e == 64) ? 1.0 : 0.0;
+    return;
+  }
+  // G = A A^T / fro
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int i = e >> 6, j = e & 63;
+    double s = 0.0;
+    for (int k = 0; k < 128; k++) s += A[i * 129 + k] * A[j * 129 + k];
+    G[i * 65 + j] = s / fro;
+  }
+  __syncthreads();
+  for (int it = 0; it < 8; it++) {     // G <- G*G / ||G*G||_F   (G symmetric)
+    double part = 0.0;
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int i = e >> 6, j = e & 63;
+      double s = 0.0;
+      for (int k = 0; k < 64; k++) s += G[i * 65 + k] * G[j * 65 + k];
+      H[i * 65 + j] = s;
+      part += s * s;
+    }
+    const double nf = sqrt(block_sum256(part, red, tid));
+    for (int e = tid; e < 64 * 64; e += 256) {
+      const int i = e >> 6, j = e & 63;
+      G[i * 65 + j] = H[i * 65 + j] / nf;
+    }
+    __syncthreads();
+  }
+  // start vector: G * ones (non-negative matrices keep it in the Perron cone), normalised
+  if (tid < 64) {
+    double s = 0.0;
+    for (int k = 0; k < 64; k++) s += G[tid * 65 + k];
+    u[tid] = s;
+  }
+  __syncthreads();
+  {
+    const double nn = sqrt(block_sum256(tid < 64 ? u[tid] * u[tid] : 0.0, red, tid));
+    if (tid < 64) u[tid] = u[tid] / nn;
+    __syncthreads();
+  }
+  double sigma = 0.0;
+  for (int it = 0; it < 400; it++) {   // polish on the original matrix: u <- A (A^T u)
+    if (tid < 128) {
+      double s = 0.0;
+      for (int i = 0; i < 64; i++) s += A[i * 129 + tid] * u[i];
+      v[tid] = s;
+    }
+    __syncthreads();
+    double un = 0.0;
+    if (tid < 64) {
+      double s = 0.0;
+      for (int k = 0; k < 128; k++) s += A[tid * 129 + k] * v[k];
+      un = s;
+    }
+    const double nn = sqrt(block_sum256(tid < 64 ? un * un : 0.0, red, tid));   // = sigma^2 at convergence
+    double diff = 0.0;
+    if (tid < 64) {
+      un = un / nn;
+      diff = fabs(un - u[tid]);
+    }
+    red[tid] = diff;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
+      __syncthreads();
+    }
+    const double dmax = red[0];
+    __syncthreads();
+    if (tid < 64) u[tid] = un;
+    sigma = sqrt(nn);
+    __syncthreads();
+    if (dmax < 4e-15 && it >= 1) break;
+  }
+  // v = A^T u / sigma, sign so that sum(u) >= 0
+  if (tid < 128) {
+    double s = 0.0;
+    for (int i = 0; i < 64; i++) s += A[i * 129 + tid] * u[i];
+    v[tid] = s / sigma;
+  }
+  const double su = block_sum256(tid < 64 ? u[tid] : 0.0, red, tid);
+  const double sg = (su < 0.0) ? -1.0 : 1.0;
+  if (tid < 64) o[tid] = sg * u[tid];
+  if (tid < 128) o[64 + tid] = sg * v[tid];
+}
+
+constexpr size_t SVD_LDS = (size_t)(64 * 129 + 2 * 64 * 65 + 64 + 128 + 256) * sizeof(double);
+constexpr int GEN_BATCH = 256;   // clouds per scratch batch (256 * 4 * 2 * 64 KiB = 128 MiB)
+
+}  // namespace
+
+size_t m2dp_generate_scratch_bytes(int N) {
+  const int nb = N < GEN_BATCH ? N : GEN_BATCH;
+  return (size_t)N * 16 * sizeof(double) + (size_t)nb * 4 * 2 * MAT * sizeof(double);
+}
+
+void launch_m2dp_generate(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
+                          double max_rho, double* out, const double* planes, void* scratch, size_t scratch_bytes) {
+  if (N <= 0) return;
+  (void)scratch_bytes;
+  double* frames = static_cast<double*>(scratch);
+  double* mats = frames + (size_t)N * 16;
+  launch_cloud_frames(st, xyz, inten, offs, N, frames);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(m2dp_svd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)SVD_LDS);
+  for (int c0 = 0; c0 < N; c0 += GEN_BATCH) {
+    const int nc = (N - c0) < GEN_BATCH ? (N - c0) : GEN_BATCH;
+    hipLaunchKernelGGL(m2dp_bin_kernel, dim3(nc * 16), dim3(256), 0, st, xyz, inten, offs, frames, planes, max_rho, c0, mats);
+    hipLaunchKernelGGL(m2dp_svd_kernel, dim3(nc * 8), dim3(256), SVD_LDS, st, mats, c0, out);
+  }
+}
+
+}  // namespace pr

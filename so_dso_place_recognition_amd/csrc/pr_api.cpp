@@ -1,0 +1,398 @@
+// pr_api.cpp — host side of libpr_amd.so: context, packed signature sets and the C ABI declared in
+// include/place_recognition.h.  No CPU fallback anywhere: without a usable gfx950 device every call fails.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/place_recognition.h"
+#include "../../include/pr_m2dp_table.h"
+#include "kernels.hpp"
+
+struct pr_ctx {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  std::string err;
+  int* d_flags = nullptr;        // [4] deferred error bits (bit0: zero-norm row at pack time)
+  double* d_twiddle = nullptr;   // cos[60], sin[60] of 2*pi*t/60
+  float* d_cst = nullptr;        // SC stage-2 constants [31][2][64]
+  double* d_planes = nullptr;    // M2DP xProj[64][3], yProj[64][3]
+  int sc_nsplit = 0;             // PR_SC_NSPLIT override (experiments)
+};
+
+struct pr_sigset {
+  int type = 0, role = 0;
+  int32_t max_sigs = 0, count = 0;
+  int groups = 0;                // SC: 8-query or 16-entry groups; M2DP: 32-row tiles (channel stride)
+  float* packed = nullptr;
+  size_t floats = 0;
+};
+
+static thread_local std::string g_err;   // errors without a context
+
+#define PR_FAIL(ctx, code, ...)                                   \
+  do {                                                            \
+    char _b[512];                                                 \
+    snprintf(_b, sizeof _b, __VA_ARGS__);                         \
+    if (ctx) (ctx)->err = _b; else g_err = _b;                    \
+    return (code);                                                \
+  } while (0)
+
+#define PR_HIP(ctx, call)                                                                     \
+  do {                                                                                        \
+    hipError_t _e = (call);                                                                   \
+    if (_e != hipSuccess) PR_FAIL(ctx, (_e == hipErrorOutOfMemory ? PR_ENOMEM : PR_EHIP),     \
+                                  "%s failed: %s", #call, hipGetErrorString(_e));            \
+  } while (0)
+
+namespace {
+
+struct DevBuf {   // RAII device scratch for the host-buffer entry points
+  void* p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
+  template <typename T> T* as() { return static_cast<T*>(p); }
+};
+
+int set_device(pr_ctx* ctx) {
+  PR_HIP(ctx, hipSetDevice(ctx->device));
+  return PR_OK;
+}
+
+size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups) {
+  if (type == PR_TYPE_SC) {
+    if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SC_QIMG; }
+    *groups = pr::sc_dgroups(max_sigs);
+    return (size_t)2 * *groups * pr::SC_DIMG + 4 * pr::SC_DSTEP;   // + prefetch tail (sc_match.hip)
+  }
+  if (role == PR_ROLE_QUERY) { *groups = ((pr::m2_tiles(max_sigs) + 3) / 4) * 4; return (size_t)2 * *groups * pr::M2_TILE; }
+  *groups = pr::m2_tiles(max_sigs);
+  return (size_t)(2 * *groups + 8) * pr::M2_TILE;                  // + tail tiles read by the last sweep step
+}
+
+int check_flags(pr_ctx* ctx) {
+  int h[4];
+  PR_HIP(ctx, hipMemcpyAsync(h, ctx->d_flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h[0]) {
+    PR_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof h, ctx->stream));
+    PR_FAIL(ctx, PR_ENAN, "a signature row has zero L2 norm (MATLAB would produce NaN distances, processSC.m:16,19)");
+  }
+  return PR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* pr_version(void) { return "so_dso_place_recognition_amd 0.1 (gfx950)"; }
+
+const char* pr_last_error(const pr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+int pr_create(int device_id, pr_ctx** out) {
+  if (!out) PR_FAIL((pr_ctx*)nullptr, PR_EINVAL, "pr_create: out is NULL");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0)
+    PR_FAIL((pr_ctx*)nullptr, PR_EHIP, "pr_create: no HIP device available (%s); this library has no CPU fallback",
+            e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  if (device_id < 0 || device_id >= ndev) PR_FAIL((pr_ctx*)nullptr, PR_EINVAL, "pr_create: device %d out of range [0,%d)", device_id, ndev);
+  hipDeviceProp_t prop;
+  PR_HIP((pr_ctx*)nullptr, hipGetDeviceProperties(&prop, device_id));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    PR_FAIL((pr_ctx*)nullptr, PR_EHIP, "pr_create: device %d is %s, this library is built for gfx950 only", device_id, prop.gcnArchName);
+  pr_ctx* ctx = new (std::nothrow) pr_ctx;
+  if (!ctx) PR_FAIL((pr_ctx*)nullptr, PR_ENOMEM, "pr_create: out of host memory");
+  ctx->device = device_id;
+  int rc = PR_OK;
+  do {
+#define TRY(call) if ((call) != hipSuccess) { g_err = std::string(#call) + " failed"; rc = PR_EHIP; break; }
+    TRY(hipSetDevice(device_id));
+    TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    TRY(hipMalloc((void**)&ctx->d_flags, 4 * sizeof(int)));
+    TRY(hipMemset(ctx->d_flags, 0, 4 * sizeof(int)));
+    double tw[120];
+    for (int t = 0; t < 60; t++) { tw[t] = std::cos(2.0 * M_PI * t / 60.0); tw[60 + t] = std::sin(2.0 * M_PI * t / 60.0); }
+    // exact values at the multiples of 90 degrees
+    tw[0] = 1; tw[15] = 0; tw[30] = -1; tw[45] = 0; tw[60] = 0; tw[75] = 1; tw[90] = 0; tw[105] = -1;
+    TRY(hipMalloc((void**)&ctx->d_twiddle, sizeof tw));
+    TRY(hipMemcpy(ctx->d_twiddle, tw, sizeof tw, hipMemcpyHostToDevice));
+    // stage-2 constants: lane l of tile st -> shift k = st*32 + (l&31) (k >= 60 repeats shift 0, harmless for the max),
+    // l < 32: w_f cos(2 pi f k/60), l >= 32: -w_f sin(2 pi f k/60); w_0 = w_30 = 1, else 2.
+    std::vector<float> cst((size_t)pr::SC_NF * 128);
+    for (int f = 0; f < pr::SC_NF; f++)
+      for (int st = 0; st < 2; st++)
+        for (int l = 0; l < 64; l++) {
+          int k = st * 32 + (l & 31); if (k >= 60) k = 0;
+          const int t = (f * k) % 60;
+          const double w = (f == 0 || f == 30) ? 1.0 : 2.0;
+          cst[(size_t)f * 128 + st * 64 + l] = (float)((l < 32) ? w * tw[t] : -w * tw[60 + t]);
+        }
+    TRY(hipMalloc((void**)&ctx->d_cst, cst.size() * sizeof(float)));
+    TRY(hipMemcpy(ctx->d_cst, cst.data(), cst.size() * sizeof(float), hipMemcpyHostToDevice));
+    // M2DP plane table from the frozen float normals (M2DP/M2DP.cpp:9-30)
+    double pl[2][64][3];
+    for (int k = 0; k < 64; k++) {
+      float nf[3]; memcpy(nf, PR_M2DP_VECN_BITS[k], 12);
+      const double n[3] = {nf[0], nf[1], nf[2]};
+      const double d = (1.0 * n[0] + 0.0 * n[1]) + 0.0 * n[2];
+      const double xa[3] = {1.0, 0.0, 0.0};
+      for (int a = 0; a < 3; a++) pl[0][k][a] = xa[a] - d * n[a];
+      pl[1][k][0] = n[1] * pl[0][k][2] - n[2] * pl[0][k][1];
+      pl[1][k][1] = n[2] * pl[0][k][0] - n[0] * pl[0][k][2];
+      pl[1][k][2] = n[0] * pl[0][k][1] - n[1] * pl[0][k][0];
+    }
+    TRY(hipMalloc((void**)&ctx->d_planes, sizeof pl));
+    TRY(hipMemcpy(ctx->d_planes, pl, sizeof pl, hipMemcpyHostToDevice));
+#undef TRY
+  } while (0);
+  if (rc != PR_OK) { pr_destroy(ctx); return rc; }
+  if (const char* s = getenv("PR_SC_NSPLIT")) ctx->sc_nsplit = atoi(s);
+  *out = ctx;
+  return PR_OK;
+}
+
+void pr_destroy(pr_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+  if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+  if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
+  if (ctx->d_cst) (void)hipFree(ctx->d_cst);
+  if (ctx->d_planes) (void)hipFree(ctx->d_planes);
+  delete ctx;
+}
+
+void* pr_stream(pr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+int pr_sync(pr_ctx* ctx) {
+  if (!ctx) return PR_EINVAL;
+  if (int rc = set_device(ctx)) return rc;
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  PR_HIP(ctx, hipGetLastError());
+  return check_flags(ctx);
+}
+
+// ------------------------------------------------------------------------------------------- signature sets
+int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigset** out) {
+  if (!ctx || !out) return PR_EINVAL;
+  if ((type != PR_TYPE_SC && type != PR_TYPE_M2DP) || (role != PR_ROLE_QUERY && role != PR_ROLE_DB) || max_sigs < 0)
+    PR_FAIL(ctx, PR_EINVAL, "pr_sigset_create: bad type/role/max_sigs");
+  if (int rc = set_device(ctx)) return rc;
+  pr_sigset* s = new (std::nothrow) pr_sigset;
+  if (!s) PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: out of host memory");
+  s->type = type; s->role = role; s->max_sigs = max_sigs;
+  s->floats = sigset_floats(type, role, max_sigs, &s->groups);
+  hipError_t e = hipMalloc((void**)&s->packed, s->floats * sizeof(float) + 16);
+  if (e != hipSuccess) { delete s; PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: hipMalloc(%zu B) failed: %s", s->floats * 4, hipGetErrorString(e)); }
+  *out = s;
+  return PR_OK;
+}
+
+void pr_sigset_destroy(pr_ctx* ctx, pr_sigset* s) {
+  if (!s) return;
+  if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
+  if (s->packed) (void)hipFree(s->packed);
+  delete s;
+}
+
+int32_t pr_sigset_count(const pr_sigset* s) { return s ? s->count : 0; }
+
+int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int where, int32_t n_sigs) {
+  if (!ctx || !s) return PR_EINVAL;
+  if (n_sigs < 0 || n_sigs > s->max_sigs || (n_sigs > 0 && !sig) || (dtype != PR_F64 && dtype != PR_F32) ||
+      (where != PR_HOST && where != PR_DEVICE))
+    PR_FAIL(ctx, PR_EINVAL, "pr_sigset_pack: bad arguments (n_sigs=%d, capacity=%d)", n_sigs, s->max_sigs);
+  if (int rc = set_device(ctx)) return rc;
+  const size_t rows = (s->type == PR_TYPE_SC) ? (size_t)n_sigs : (size_t)4 * n_sigs;
+  const size_t cols = (s->type == PR_TYPE_SC) ? PR_SC_SIG_LEN : PR_M2DP_SIG_LEN;
+  const size_t esz = (dtype == PR_F64) ? 8 : 4;
+  DevBuf stage;
+  const void* dsig = sig;
+  if (where == PR_HOST && n_sigs > 0) {
+    PR_HIP(ctx, stage.alloc(rows * cols * esz));
+    PR_HIP(ctx, hipMemcpyAsync(stage.p, sig, rows * cols * esz, hipMemcpyHostToDevice, ctx->stream));
+    dsig = stage.p;
+  }
+  // padding rows/tiles must be zero: they yield dot = 0 and are masked on store
+  PR_HIP(ctx, hipMemsetAsync(s->packed, 0, s->floats * sizeof(float), ctx->stream));
+  // the channel stride must match the matcher's view of THIS count (not the capacity)
+  int groups;
+  (void)sigset_floats(s->type, s->role, n_sigs, &groups);
+  s->groups = groups;
+  if (s->type == PR_TYPE_SC)
+    pr::launch_sc_pack(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags);
+  else
+    pr::launch_m2dp_pack(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
+  PR_HIP(ctx, hipGetLastError());
+  s->count = n_sigs;
+  if (stage.p) PR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging buffer is freed on return
+  return PR_OK;
+}
+
+// ------------------------------------------------------------------------------------------- device path
+int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float* d_p, float* d_i) {
+  if (!ctx || !q || !db || !d_p || !d_i) return PR_EINVAL;
+  if (q->type != db->type || q->role != PR_ROLE_QUERY || db->role != PR_ROLE_DB)
+    PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: q must be a QUERY set and db a DB set of the same type");
+  if (int rc = set_device(ctx)) return rc;
+  if (q->type == PR_TYPE_SC)
+    pr::launch_sc_match(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst, d_p, d_i, ctx->sc_nsplit);
+  else
+    pr::launch_m2dp_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+int pr_row_moments_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n, double* mom) {
+  if (!ctx || !d_p || !d_i || !mom || m < 0 || n < 1) return PR_EINVAL;
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_row_moments(ctx->stream, d_p, d_i, m, n, mom);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n, const double* mom_all,
+                       int32_t G, int32_t q_row0, int32_t db_row0, int32_t mask_width, double p_weight, int32_t k,
+                       int32_t* idx, float* score) {
+  if (!ctx || !d_p || !d_i || !mom_all || !idx || !score || m < 0 || n < 1 || G < 1 || k < 1)
+    return PR_EINVAL;
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_fuse_select(ctx->stream, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+// ------------------------------------------------------------------------------------------- host-buffer path
+static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n,
+                         float* out_p, float* out_i, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,
+                         float* score, bool want_topk) {
+  if (!ctx) return PR_EINVAL;
+  if (m < 0 || n < 0 || (m > 0 && !h1) || (n > 0 && !h2)) PR_FAIL(ctx, PR_EINVAL, "bad signature buffers (m=%d, n=%d)", m, n);
+  if (want_topk && (n < 2 || k < 1 || !idx || !score))
+    PR_FAIL(ctx, PR_EINVAL, "pr_match_topk needs n >= 2 (N-1 standard deviation), k >= 1 and output buffers");
+  if (m == 0 || n == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  pr_sigset *q = nullptr, *d = nullptr;
+  int rc = pr_sigset_create(ctx, type, PR_ROLE_QUERY, m, &q);
+  if (rc == PR_OK) rc = pr_sigset_create(ctx, type, PR_ROLE_DB, n, &d);
+  DevBuf dp, di, mom, didx, dsc;
+  do {
+    if (rc) break;
+    if ((rc = pr_sigset_pack(ctx, q, h1, PR_F64, PR_HOST, m))) break;
+    if ((rc = pr_sigset_pack(ctx, d, h2, PR_F64, PR_HOST, n))) break;
+    const size_t mn = (size_t)m * n;
+    if (dp.alloc(mn * 4) != hipSuccess || di.alloc(mn * 4) != hipSuccess) { ctx->err = "out of device memory for the m x n distance matrices"; rc = PR_ENOMEM; break; }
+    if ((rc = pr_distances_dev(ctx, q, d, dp.as<float>(), di.as<float>()))) break;
+    if (want_topk) {
+      if (mom.alloc((size_t)m * 6 * 8) != hipSuccess || didx.alloc((size_t)m * k * 4) != hipSuccess ||
+          dsc.alloc((size_t)m * k * 4) != hipSuccess) { ctx->err = "out of device memory"; rc = PR_ENOMEM; break; }
+      if ((rc = pr_row_moments_dev(ctx, dp.as<float>(), di.as<float>(), m, n, mom.as<double>()))) break;
+      if ((rc = pr_fuse_select_dev(ctx, dp.as<float>(), di.as<float>(), m, n, mom.as<double>(), 1, 0, 0, mask_width,
+                                   p_weight, k, didx.as<int32_t>(), dsc.as<float>()))) break;
+      if (hipMemcpyAsync(idx, didx.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(score, dsc.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
+    }
+    if (out_p && hipMemcpyAsync(out_p, dp.p, mn * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
+    if (out_i && hipMemcpyAsync(out_i, di.p, mn * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
+    rc = pr_sync(ctx);
+  } while (0);
+  if (rc != PR_OK) (void)hipStreamSynchronize(ctx->stream);
+  pr_sigset_destroy(ctx, q);
+  pr_sigset_destroy(ctx, d);
+  return rc;
+}
+
+int pr_sc_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, float* d_struct, float* d_int) {
+  return distance_host(ctx, PR_TYPE_SC, h1, m, h2, n, d_struct, d_int, 0, 0, 0, nullptr, nullptr, false);
+}
+
+int pr_m2dp_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, float* d_cnt, float* d_int) {
+  return distance_host(ctx, PR_TYPE_M2DP, h1, m, h2, n, d_cnt, d_int, 0, 0, 0, nullptr, nullptr, false);
+}
+
+int pr_match_topk(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n, int32_t mask_width,
+                  double p_weight, int32_t k, int32_t* idx, float* score) {
+  if (!ctx) return PR_EINVAL;
+  if (type != PR_TYPE_SC && type != PR_TYPE_M2DP) PR_FAIL(ctx, PR_EINVAL, "pr_match_topk: unknown type %d", type);
+  return distance_host(ctx, type, h1, m, h2, n, nullptr, nullptr, mask_width, p_weight, k, idx, score, true);
+}
+
+// ------------------------------------------------------------------------------------------- generation
+static int check_gen_args(pr_ctx* ctx, const void* xyz, const void* inten, const void* offs, int32_t N, double max_rho, const void* out) {
+  if (!ctx) return PR_EINVAL;
+  if (N < 0 || !offs || (N > 0 && !out) || !(max_rho > 0)) PR_FAIL(ctx, PR_EINVAL, "generate: bad arguments (N=%d, max_rho=%g)", N, max_rho);
+  (void)xyz; (void)inten;
+  return PR_OK;
+}
+
+int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
+  if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
+  if (N == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  DevBuf frames;
+  PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
+  pr::launch_sc_generate(ctx->stream, xyz, inten, offs, N, max_rho, out, frames.as<double>());
+  PR_HIP(ctx, hipGetLastError());
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PR_OK;
+}
+
+int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
+  if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
+  if (N == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  DevBuf scratch;
+  const size_t sb = pr::m2dp_generate_scratch_bytes(N);
+  PR_HIP(ctx, scratch.alloc(sb));
+  pr::launch_m2dp_generate(ctx->stream, xyz, inten, offs, N, max_rho, out, ctx->d_planes, scratch.p, sb);
+  PR_HIP(ctx, hipGetLastError());
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PR_OK;
+}
+
+static int generate_host(pr_ctx* ctx, int type, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
+                         double max_rho, double* out) {
+  if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
+  if (N == 0) return PR_OK;
+  for (int c = 0; c < N; c++)
+    if (offs[c + 1] < offs[c]) PR_FAIL(ctx, PR_EINVAL, "generate: offs must be non-decreasing (cloud %d)", c);
+  if (offs[0] != 0) PR_FAIL(ctx, PR_EINVAL, "generate: offs[0] must be 0");
+  const size_t T = (size_t)offs[N];
+  if (T > 0 && (!xyz || !inten)) PR_FAIL(ctx, PR_EINVAL, "generate: xyz/inten are NULL");
+  if (int rc = set_device(ctx)) return rc;
+  const size_t rowlen = (type == PR_TYPE_SC) ? PR_SC_SIG_LEN : (size_t)4 * PR_M2DP_SIG_LEN;
+  DevBuf dx, di, dof, dout;
+  PR_HIP(ctx, dx.alloc(T * 24));
+  PR_HIP(ctx, di.alloc(T * 4));
+  PR_HIP(ctx, dof.alloc((size_t)(N + 1) * 8));
+  PR_HIP(ctx, dout.alloc((size_t)N * rowlen * 8));
+  if (T) {
+    PR_HIP(ctx, hipMemcpyAsync(dx.p, xyz, T * 24, hipMemcpyHostToDevice, ctx->stream));
+    PR_HIP(ctx, hipMemcpyAsync(di.p, inten, T * 4, hipMemcpyHostToDevice, ctx->stream));
+  }
+  PR_HIP(ctx, hipMemcpyAsync(dof.p, offs, (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
+  int rc = (type == PR_TYPE_SC)
+               ? pr_sc_generate_dev(ctx, dx.as<double>(), di.as<float>(), dof.as<int64_t>(), N, max_rho, dout.as<double>())
+               : pr_m2dp_generate_dev(ctx, dx.as<double>(), di.as<float>(), dof.as<int64_t>(), N, max_rho, dout.as<double>());
+  if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+  PR_HIP(ctx, hipMemcpyAsync(out, dout.p, (size_t)N * rowlen * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PR_OK;
+}
+
+int pr_sc_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
+  return generate_host(ctx, PR_TYPE_SC, xyz, inten, offs, N, max_rho, out);
+}
+
+int pr_m2dp_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
+  return generate_host(ctx, PR_TYPE_M2DP, xyz, inten, offs, N, max_rho, out);
+}
+
+}  // extern "C"

@@ -1,0 +1,85 @@
+// sc_pack.hip — Scan-Context signature packing for the matcher (gfx950).
+//
+// Follows processSC.m:15-20: every 1200-vector (one channel of a signature) is divided by its L2 norm.
+// The matcher (sc_match.hip) evaluates the 120 column-shift / mirror variants of processSC.m:24-32 through a
+// length-60 real DFT over the sector axis, so the normalised rows are stored here as their
+// per-ring sector spectra  X_r[f] = (1/sqrt 60) * sum_s x[s*20+r] * exp(-2 pi i f s / 60),  f = 0..30,
+// computed in fp64 and rounded once to fp32, laid out as the MFMA operand image of the set's role:
+//   query image  [ch][group of 8][f][s=0..4][lane]      lane = (k<<4) | (part<<3) | e   ring = 4s+k
+//   DB image     [ch][group of 16][f]{ q4a[lane][4] (Re, s=0..3) | q4b[lane][4] (Im, s=0..3) | d2[lane][2] (Re,Im of s=4) }
+//                                                       lane = (k<<4) | j               ring = 4s+k
+// One workgroup per (row, channel).  HBM-trivial: 2400 values in, 2480 floats out per row.
+#include "kernels.hpp"
+
+namespace pr {
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void sc_pack_kernel(const T* __restrict__ sig, int rows, int role,
+                                                       float* __restrict__ packed, int groups,
+                                                       const double* __restrict__ tw, int* __restrict__ flags) {
+  __shared__ double x[1200];
+  __shared__ double red[256];
+  __shared__ double tws[120];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x >> 1, ch = blockIdx.x & 1;
+  const T* src = sig + (size_t)row * 2400 + ch * 1200;
+  double part = 0.0;
+  for (int i = tid; i < 1200; i += 256) {
+    double v = (double)src[i];
+    x[i] = v;
+    part += v * v;
+  }
+  if (tid < 120) tws[tid] = tw[tid];
+  red[tid] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const double nr = sqrt(red[0]);
+  if (!(nr > 0.0) && tid == 0) atomicOr(flags, 1);   // MATLAB would produce a NaN row
+  for (int i = tid; i < 1200; i += 256) x[i] = x[i] / nr;   // processSC.m:16,19
+  __syncthreads();
+  const double scale = 0.12909944487358055;  // 1/sqrt(60)
+  for (int o = tid; o < SC_NF * 40; o += 256) {
+    const int f = o / 40, rem = o - f * 40, ring = rem >> 1, im = rem & 1;
+    double acc = 0.0;
+    int t = 0;  // (f*s) mod 60
+    for (int s = 0; s < 60; s++) {
+      const double w = im ? -tws[60 + t] : tws[t];
+      acc += x[s * 20 + ring] * w;
+      t += f;
+      if (t >= 60) t -= 60;
+    }
+    const float val = (float)(acc * scale);
+    const int s4 = ring >> 2, k = ring & 3;
+    size_t dst;
+    if (role == 0) {  // query image
+      const int g = row >> 3, e = row & 7;
+      const int lane = (k << 4) | (im << 3) | e;
+      dst = (((size_t)ch * groups + g) * SC_NF + f) * 320 + s4 * 64 + lane;
+    } else {          // DB image
+      const int g = row >> 4, j = row & 15;
+      const int lane = (k << 4) | j;
+      const size_t base = (((size_t)ch * groups + g) * SC_NF + f) * SC_DSTEP;
+      dst = (s4 < 4) ? base + im * 256 + lane * 4 + s4 : base + 512 + lane * 2 + im;
+    }
+    packed[dst] = val;
+  }
+}
+
+}  // namespace
+
+void launch_sc_pack(hipStream_t st, const void* sig, int dtype, int rows, int role, float* packed, int groups,
+                    const double* twiddle, int* flags) {
+  if (rows <= 0) return;
+  if (dtype == 0)
+    hipLaunchKernelGGL(sc_pack_kernel<double>, dim3(rows * 2), dim3(256), 0, st, (const double*)sig, rows, role,
+                       packed, groups, twiddle, flags);
+  else
+    hipLaunchKernelGGL(sc_pack_kernel<float>, dim3(rows * 2), dim3(256), 0, st, (const float*)sig, rows, role,
+                       packed, groups, twiddle, flags);
+}
+
+}  // namespace pr

@@ -1,0 +1,52 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header declares,
+and fails loudly (no CPU fallback) when no gfx950 device is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from so_dso_place_recognition_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    txt = open(os.path.join(ROOT, "include", "place_recognition.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(pr_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _header_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert sorted(_lib.SYMBOLS) == declared
+    assert b"gfx950" in lib.pr_version()
+
+
+def test_no_silent_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present; the loud-failure path is for CPU-only hosts")
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.pr_create(0, C.byref(h))
+    assert rc == _lib.PR_EHIP and not h
+    assert b"no CPU fallback" in lib.pr_last_error(None)
+    from so_dso_place_recognition_amd import api
+    with pytest.raises(_lib.PRError):
+        api.Context(0)
+
+
+def test_product_does_not_link_the_oracle():
+    so = os.path.join(ROOT, "so_dso_place_recognition_amd", "libpr_amd.so")
+    data = open(so, "rb").read()
+    assert b"pr_ref_" not in data and b"libpr_ref" not in data
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "so_dso_place_recognition_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                src = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_lib" not in src and "libpr_ref" not in src and "np_checker" not in src, f

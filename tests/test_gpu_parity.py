@@ -1,0 +1,161 @@
+"""GPU parity tests proper: the HIP path through the C ABI vs the CPU oracle on the same seeded inputs.
+Tolerances: top-k indices bit-exact; fp32 distances within 1e-5 (BASELINE.json north_star); generated signatures:
+bin occupancy / binary channel exact, fp64 structure within 1e-10, M2DP singular vectors within 1e-9."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+from so_dso_place_recognition_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def api():
+    from so_dso_place_recognition_amd import api as _api
+    return _api
+
+
+# ------------------------------------------------------------------------------------------------ a6
+@pytest.mark.parametrize("m,n", [(1, 2), (8, 16), (37, 101), (64, 333)])
+def test_sc_distance_vs_oracle(api, m, n):
+    db = synth.sc_database(45, n)
+    q, _ = synth.sc_queries(46, db, m)
+    rc, op, oi = oracle_lib.sc_distance(q, db)
+    gp, gi = api.processSC(q, db)
+    assert gp.shape == (m, n) and gp.dtype == np.float32
+    assert np.abs(gp - op).max() < 1e-5 and np.abs(gi - oi).max() < 1e-5
+
+
+def test_sc_distance_golden_and_invariants(api, golden_dir):
+    g = np.load(os.path.join(golden_dir, "synthetic_v1.npz"))
+    db = synth.sc_database(45, 16)
+    q, _ = synth.sc_queries(46, db, 8)
+    gp, gi = api.processSC(q, db)
+    assert np.abs(gp - g["sc_dp"]).max() < 1e-5 and np.abs(gi - g["sc_di"]).max() < 1e-5
+    sp, si = api.processSC(db, db)
+    assert np.abs(np.diag(sp)).max() < 1e-5 and np.abs(np.diag(si)).max() < 1e-5       # self distance 0
+    rot = np.roll(db.reshape(16, 2, 60, 20)[:, :, ::-1], 11, axis=2).reshape(16, 2400)   # mirror + rotate
+    rp, ri = api.processSC(rot, db)
+    assert np.abs(rp - sp).max() < 2e-6 and np.abs(ri - si).max() < 2e-6
+
+
+def test_sc_zero_row_is_reported(api):
+    db = synth.sc_database(45, 20)
+    db[3, :1200] = 0
+    with pytest.raises(api.PRError) as e:
+        api.processSC(db[:2], db)
+    assert e.value.code == -5
+    # the context stays usable afterwards
+    gp, _ = api.processSC(db[:2], db[4:])
+    assert np.isfinite(gp).all()
+
+
+# ------------------------------------------------------------------------------------------------ a7
+@pytest.mark.parametrize("m,n", [(1, 2), (9, 40), (33, 130)])
+def test_m2dp_distance_vs_oracle(api, m, n):
+    db = synth.m2dp_database(43, n)
+    q, _ = synth.m2dp_queries(44, db, m)
+    rc, op, oi = oracle_lib.m2dp_distance(q, db)
+    gp, gi = api.processM2DP(q, db)
+    assert np.abs(gp - op).max() < 1e-5 and np.abs(gi - oi).max() < 1e-5
+    sp, _ = api.processM2DP(db, db)
+    assert np.abs(np.diag(sp) + 0.5).max() < 1e-5                                       # self distance -0.5
+
+
+# ------------------------------------------------------------------------------------------------ a8
+@pytest.mark.parametrize("type_,mask,k", [("sc", 0, 1), ("sc", 5, 4), ("m2dp", 0, 1), ("m2dp", 3, 3)])
+def test_match_topk_vs_oracle(api, type_, mask, k):
+    if type_ == "sc":
+        db = synth.sc_database(45, 150); q = db[:60]
+        t = 0
+    else:
+        db = synth.m2dp_database(43, 150); q = db[:240]
+        t = 1
+    rc, oidx, osc = oracle_lib.match_topk(t, q, db, mask, 2.0, k)
+    gidx, gsc = api.match_topk(type_, q, db, mask, 2.0, k)
+    assert np.array_equal(gidx, oidx)                       # bit-exact indices
+    assert np.abs(gsc - osc).max() < 2e-4                   # fused z-scores (distances 1e-5 / sigma ~ 0.05)
+
+
+def test_match_planted_and_ties(api, golden_dir):
+    g = np.load(os.path.join(golden_dir, "synthetic_v1.npz"))
+    db = synth.sc_database(45, 16); q, et = synth.sc_queries(46, db, 8)
+    idx, sc = api.match_topk("sc", q, db)
+    assert np.array_equal(idx[:, 0], g["sc_top1"]) and np.array_equal(idx[:, 0], et)
+    db = synth.sc_database(45, 40)
+    db[27] = db[9]                                          # duplicate -> exact tie -> lower index first
+    q, _ = synth.sc_queries(46, db[9:10], 1)
+    idx, sc = api.match_topk("sc", q, db, 0, 2.0, 2)
+    assert list(idx[0]) == [9, 27] and sc[0, 0] == sc[0, 1]
+    # k larger than the unmasked candidates -> -1 / NaN padding after the Inf entries in index order
+    idx, sc = api.match_topk("sc", db[:3], db[:6], 100, 2.0, 6)
+    assert np.array_equal(idx, np.tile(np.arange(6, dtype=np.int32), (3, 1))) and np.isinf(sc).all()
+
+
+def test_match_full_size_properties(api):
+    """Size-independent properties at a DB size the oracle cannot brute-force in seconds: planted top-1 recall
+    = 100 % and distance of the planted pair far below the row mean."""
+    n, m = 20000, 256
+    db = synth.sc_database(45, n)
+    q, et = synth.sc_queries(46, db, m)
+    idx, sc = api.match_topk("sc", q, db)
+    assert np.array_equal(idx[:, 0], et)
+    assert (sc[:, 0] < -8).all()
+    rc, oidx, osc = oracle_lib.match_topk(0, q[:2], db, 0)          # two full rows against the oracle
+    assert np.array_equal(oidx[:, 0], idx[:2, 0]) and np.abs(osc[:, 0] - sc[:2, 0]).max() < 5e-4
+
+
+# ------------------------------------------------------------------------------------------------ a3 + a4
+@pytest.mark.parametrize("P", [1500, 20011])
+def test_sc_generate_vs_oracle(api, P):
+    xyz, it, offs = synth.scene_clouds(42, 3, P)
+    o = oracle_lib.sc_generate(xyz, it, offs)
+    g = api.sc_generate(xyz, it, offs)
+    assert np.array_equal(g[:, 1200:], o[:, 1200:])                   # binarised intensity exact
+    assert np.array_equal(g[:, :1200] > 0, o[:, :1200] > 0)
+    assert np.abs(g[:, :1200] - o[:, :1200]).max() < 1e-10
+
+
+def test_sc_generate_ragged_and_empty(api, golden_dir):
+    a, ia = synth.scene_cloud(42, 5, 700)
+    b, ib = synth.scene_cloud(42, 6, 3)
+    c, ic = synth.scene_cloud(42, 7, 1300)
+    xyz = np.concatenate([a, b, c]); it = np.concatenate([ia, ib, ic])
+    offs = np.array([0, 700, 700, 703, 2003], np.int64)               # an empty and a 3-point cloud
+    o = oracle_lib.sc_generate(xyz, it, offs)
+    g = api.sc_generate(xyz, it, offs)
+    assert np.array_equal(g[1], np.zeros(2400))
+    for r in (0, 3):
+        assert np.array_equal(g[r, 1200:], o[r, 1200:]) and np.abs(g[r] - o[r]).max() < 1e-10
+    gold = np.load(os.path.join(golden_dir, "synthetic_v1.npz"))
+    xyz, it, offs = synth.scene_clouds(42, 3, int(gold["cloud_P"][0]))
+    g = api.sc_generate(xyz, it, offs)
+    assert np.array_equal(g[:, 1200:], gold["sc_sig"][:, 1200:]) and np.abs(g - gold["sc_sig"]).max() < 1e-10
+    s = api.SC(45.0)
+    st, iv = s.getSignature(xyz[:offs[1]], it[:offs[1]])
+    assert s.getSignatureSize() == 1200 and np.array_equal(np.concatenate([st, iv]), g[0])
+
+
+# ------------------------------------------------------------------------------------------------ a5
+def test_m2dp_generate_vs_oracle(api, golden_dir):
+    xyz, it, offs = synth.scene_clouds(42, 3, 2000)
+    o = oracle_lib.m2dp_generate(xyz, it, offs)
+    g = api.m2dp_generate(xyz, it, offs)
+    assert g.shape == (12, 384)
+    assert np.abs(g - o).max() < 1e-9
+    gold = np.load(os.path.join(golden_dir, "synthetic_v1.npz"))
+    assert np.abs(g - gold["m2dp_sig"]).max() < 1e-9
+
+
+def test_generate_then_match_end_to_end(api):
+    """config-2 shape at a small size: generate SC signatures on the GPU, match them on the GPU, compare the
+    top-1 with the oracle run on the oracle's own signatures."""
+    xyz, it, offs = synth.scene_clouds(42, 24, 4000)
+    g = api.sc_generate(xyz, it, offs)
+    o = oracle_lib.sc_generate(xyz, it, offs)
+    gi, gs = api.match_topk("sc", g, g, 2)
+    rc, oi, osc = oracle_lib.match_topk(0, o, o, 2)
+    assert np.array_equal(gi, oi)
