@@ -1,0 +1,177 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the place-recognition hot path on MI355X.
+
+Metric (BASELINE.json): queries/sec over a 100k-signature DB, top-1 index parity.
+Workload (`config.workload`): Scan-Context 20x60 matching, m = 4096 synthetic queries planted on an
+n = 100 000-signature synthetic DB (SURVEY.md §8-d "metric config"), mask_width 0, p_weight 2, k = 1.
+One step = the whole match path on inputs already resident in HBM as f64 signatures:
+    pack queries (L2-normalise + sector rfft) -> pack DB shard -> all-pairs SC distance (both channels)
+    -> per-row moments -> [all-gather moments] -> z-score fusion + mask + top-1 -> [all-gather + merge]
+i.e. run_test.m:25-57.  With N > 1 GPUs the SAME 100k DB is row-sharded over the ranks (strong scaling,
+SURVEY.md §8-e); queries are replicated.  value = queries of all steps / max-over-ranks wall time.
+
+Extra objects on the JSON line: `roofline` (the dominant kernel sc_match, timed live with HIP events on the
+stream it runs on; algorithmic FLOPs = 39 680 per (query, entry) pair), `cpu_baseline` (the CPU oracle =
+a port of the reference, timed on this host's cores on a bounded query sample at N = 1), `parity` (GPU top-1 vs
+that oracle on the sample and vs the planted ground truth on all queries).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOP_PER_PAIR = 2 * 31 * (160 + 480)     # 39 680: stage 1 (4 real K=20 dots) + stage 2 (120 shifts x 2 coeff), DESIGN.md
+MFMA_F32_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: Peak FP32 (matrix)
+
+
+class HipEvents:
+    """HIP events on an arbitrary hipStream_t (torch.cuda.Event only sees torch's own streams)."""
+
+    def __init__(self):
+        self.hip = C.CDLL("libamdhip64.so")
+        self.hip.hipEventCreate.argtypes = [C.POINTER(C.c_void_p)]
+        self.hip.hipEventRecord.argtypes = [C.c_void_p, C.c_void_p]
+        self.hip.hipEventSynchronize.argtypes = [C.c_void_p]
+        self.hip.hipEventElapsedTime.argtypes = [C.POINTER(C.c_float), C.c_void_p, C.c_void_p]
+
+    def create(self):
+        e = C.c_void_p()
+        assert self.hip.hipEventCreate(C.byref(e)) == 0
+        return e
+
+    def record(self, e, stream):
+        assert self.hip.hipEventRecord(e, C.c_void_p(stream)) == 0
+
+    def elapsed_ms(self, a, b):
+        assert self.hip.hipEventSynchronize(b) == 0
+        ms = C.c_float()
+        assert self.hip.hipEventElapsedTime(C.byref(ms), a, b) == 0
+        return ms.value
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--db", type=int, default=100_000, help="total DB signatures (sharded over the ranks)")
+    ap.add_argument("--queries", type=int, default=4096)
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="queries for the CPU baseline (-1: one per host core, <= 32)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from so_dso_place_recognition_amd import synth
+    from so_dso_place_recognition_amd.matcher import Matcher
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    n, m = args.db, args.queries
+    lo, hi = (n * rank) // world, (n * (rank + 1)) // world          # this rank's DB rows
+    t0 = time.time()
+    db_host = synth.sc_database(45, hi - lo, first=lo)
+    q_host, planted = synth.sc_queries(46, db_host, m, db_first=lo, n_global=n, db_seed=45)
+    db = torch.from_numpy(db_host).to(dev)                            # f64 [n_local, 2400] resident in HBM
+    q = torch.from_numpy(q_host).to(dev)                              # f64 [m, 2400]
+    gen_s = time.time() - t0
+
+    mt = Matcher("sc", m, hi - lo, device=local)
+    ev = HipEvents()
+    e0, e1 = ev.create(), ev.create()
+    stream = mt.ctx.stream
+    kern_ms = []
+
+    def step(timed_kernel: bool):
+        mt.pack_database(db)
+        if timed_kernel:   # the only launch between the two records is sc_match_kernel, on the stream it runs on
+            mt.pre_distances = lambda: ev.record(e0, stream)
+            mt.post_distances = lambda: ev.record(e1, stream)
+        out = mt.match(q, 0, 2.0, 1, db_row0=lo)
+        if timed_kernel:
+            mt.pre_distances = mt.post_distances = None
+            kern_ms.append(ev.elapsed_ms(e0, e1))
+        return out
+
+    for _ in range(args.warmup):
+        step(False)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx, score = step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    idx_h = idx.cpu().numpy()[:, 0]
+    score_h = score.cpu().numpy()[:, 0]
+    planted_ok = int((idx_h == planted).sum())
+
+    if rank == 0:
+        qps = m * args.steps / dt
+        kms = float(np.mean(kern_ms))
+        pairs = m * (hi - lo)
+        ach = pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12
+        out = {
+            "metric": "queries/sec over 100k-signature DB (SC 20x60, z-score fusion, top-1)",
+            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * dt / args.steps, "ms_per_query": 1e3 * dt / (args.steps * m),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "sc_match_100k", "db_signatures": n, "queries_per_step": m, "descriptor": "SC 20x60 x 2 channels",
+                       "mask_width": 0, "p_weight": 2.0, "k": 1, "db_rows_per_gpu": hi - lo,
+                       "step": "pack(q)+pack(db)+distances+moments+fuse/top-1" + ("+2 all_gathers" if world > 1 else "")},
+            "roofline": {"kernel": "sc_match_kernel", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": pairs, "ms_per_launch": kms,
+                         "dense_equivalent_tflops": pairs * 576000 / (kms * 1e-3) / 1e12},
+            "parity": {"planted_top1_correct": planted_ok, "queries": m},
+            "setup_s": gen_s,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sys.path.insert(0, os.path.join(ROOT, "tests"))
+            import oracle_lib                                           # the checker: CPU port of the reference
+            cores = os.cpu_count() or 1
+            S = args.cpu_sample if args.cpu_sample > 0 else min(cores, 32)
+            os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+            t0 = time.perf_counter()
+            rc, oidx, osc = oracle_lib.match_topk(0, q_host[:S], db_host, 0, 2.0, 1)
+            cdt = time.perf_counter() - t0
+            out["cpu_baseline"] = {"value": S / cdt, "unit": "queries/s", "cores": min(cores, S), "kind": "port",
+                                   "sample": f"{S} queries x full {n}-signature DB, dense 120-variant fp64 (oracle/pr_ref.cpp), {cdt:.1f} s"}
+            out["parity"].update({"oracle_queries": S, "oracle_top1_equal": bool((oidx[:, 0] == idx_h[:S]).all()),
+                                  "oracle_max_abs_score_err": float(np.abs(osc[:, 0] - score_h[:S]).max())})
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -327,23 +327,30 @@ int sc_process(const double* h1, int m, const double* h2, int n, double* res) {
   }
 #pragma omp parallel for schedule(dynamic, 1)
   for (int i = 0; i < m; i++) {                                                  // :22-33
-    std::vector<double> sig((size_t)120 * L);
+    // sigT[c][v] = variant v of query i at column c.  The 120 dot products advance together over c, so the
+    // loop vectorises ACROSS variants while every individual sum keeps the sequential c = 0..1199 order.
+    std::vector<double> sigT((size_t)L * 120);
     const double* row = &a[(size_t)i * L];
     for (int k0 = 0; k0 < 60; k0++)                                              // permute_sc :37-45 (0-based)
       for (int c = 0; c < 60; c++) {
         int sf = (k0 + c) % 60, sm = ((k0 - c) % 60 + 60) % 60;
         for (int r = 0; r < 20; r++) {
-          sig[(size_t)(2 * k0) * L + c * 20 + r] = row[sf * 20 + r];
-          sig[(size_t)(2 * k0 + 1) * L + c * 20 + r] = row[sm * 20 + r];
+          sigT[(size_t)(c * 20 + r) * 120 + 2 * k0] = row[sf * 20 + r];
+          sigT[(size_t)(c * 20 + r) * 120 + 2 * k0 + 1] = row[sm * 20 + r];
         }
       }
     for (int j = 0; j < n; j++) {
       const double* d = &b[(size_t)j * L];
+      double dot[120];
+      for (int v = 0; v < 120; v++) dot[v] = 0.0;
+      for (int c = 0; c < L; c++) {
+        const double dc = d[c];
+        const double* s = &sigT[(size_t)c * 120];
+        for (int v = 0; v < 120; v++) dot[v] += s[v] * dc;
+      }
       double best = std::numeric_limits<double>::quiet_NaN();                    // MATLAB min skips NaN
       for (int v = 0; v < 120; v++) {
-        const double* s = &sig[(size_t)v * L];
-        double dot = 0; for (int c = 0; c < L; c++) dot += s[c] * d[c];
-        double diff = (1 - dot) / 2;                                             // :30
+        double diff = (1 - dot[v]) / 2;                                          // :30
         if (std::isnan(best) || diff < best) best = diff;                        // :31 (min)
       }
       res[(size_t)i * n + j] = best;

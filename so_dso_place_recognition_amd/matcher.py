@@ -45,6 +45,8 @@ class Matcher:
         self.max_queries, self.max_db = max_queries, max_db
         self.n = 0
         self._bufs = {}
+        self.pre_distances = None      # optional callables (e.g. HIP event records) around the distance launch
+        self.post_distances = None
 
     def close(self):
         if self.q:
@@ -86,7 +88,11 @@ class Matcher:
         idx = self._buf("idx", (m, k), torch.int32)
         score = self._buf("score", (m, k), torch.float32)
         lib, h = self.lib, self.ctx.h
+        if self.pre_distances:
+            self.pre_distances()
         self.ctx.check(lib.pr_distances_dev(h, self.q, self.db, _dptr(d_p), _dptr(d_i)))
+        if self.post_distances:
+            self.post_distances()
         self.ctx.check(lib.pr_row_moments_dev(h, _dptr(d_p), _dptr(d_i), m, n, _dptr(mom)))
         if G > 1:
             self.ctx.sync()

@@ -84,11 +84,14 @@ def sc_database(seed: int, n: int, first: int = 0, chunk: int = 4096) -> np.ndar
     return out
 
 
-def sc_queries(seed: int, db: np.ndarray, m: int, db_first: int = 0, n_global: int | None = None):
+def sc_queries(seed: int, db: np.ndarray, m: int, db_first: int = 0, n_global: int | None = None,
+               db_seed: int | None = None):
     """Queries planted on DB entries: query t copies entry e_t = floor(U*n), rotated by floor(U*60) sectors,
     mirrored w.p. 1/2, 3 % of bins re-drawn.  Returns (queries [m,2400], planted index [m] int64).
     `db` may be a shard starting at global row db_first of an n_global-row DB; only queries whose planted
-    entry lies inside the shard are copied from it (the others are drawn from the sampler directly)."""
+    entry lies inside the shard are copied from it (the others are re-drawn from sc_database(db_seed), default
+    db_seed = seed - 1)."""
+    db_seed = seed - 1 if db_seed is None else db_seed
     n = db.shape[0] if n_global is None else n_global
     u = uniform(seed, np.arange(m, dtype=np.uint64), 3 + 3600)
     et = np.minimum((u[:, 0] * n).astype(np.int64), n - 1)
@@ -97,7 +100,7 @@ def sc_queries(seed: int, db: np.ndarray, m: int, db_first: int = 0, n_global: i
     q = np.empty((m, 2400))
     for t in range(m):
         g = et[t] - db_first
-        src = db[g] if 0 <= g < db.shape[0] else sc_database(seed - 1, 1, first=int(et[t]))[0]
+        src = db[g] if 0 <= g < db.shape[0] else sc_database(db_seed, 1, first=int(et[t]))[0]
         for ch in range(2):
             img = src[ch * 1200:(ch + 1) * 1200].reshape(60, 20)
             if mirror[t]:
