@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Summarises rocprofv3 (rocpd sqlite) outputs: per-kernel trace stats and PMC counters.
+usage: python profiles/summarize.py <trace.db> [pmc.db ...] > profiles/rNN_<name>.txt"""
+import sqlite3
+import sys
+
+
+def main():
+    for path in sys.argv[1:]:
+        c = sqlite3.connect(path)
+        print(f"== {path}")
+        n = c.execute("select count(*) from kernels").fetchone()[0]
+        has_pmc = c.execute("select count(*) from counters_collection").fetchone()[0]
+        if n and not has_pmc:
+            print("-- kernel trace (rocprofv3 --kernel-trace --stats): name, calls, avg/min/max ms, total ms, vgpr, agpr, lds")
+            q = ("select name, count(*), avg(end-start)/1e6, min(end-start)/1e6, max(end-start)/1e6, sum(end-start)/1e6,"
+                 " max(vgpr_count), max(accum_vgpr_count), max(lds_size) from kernels group by name order by 6 desc")
+            for r in c.execute(q):
+                print("%-72s n=%-3d avg=%9.3f min=%9.3f max=%9.3f total=%9.1f vgpr=%s agpr=%s lds=%s" % ((r[0][:72],) + r[1:]))
+        if has_pmc:
+            print("-- PMC (rocprofv3 --pmc ...): kernel, counter, sum over dispatches, dispatches")
+            q = ("select kernel_name, counter_name, sum(value), count(*) from counters_collection"
+                 " group by kernel_name, counter_name order by kernel_name, counter_name")
+            for r in c.execute(q):
+                print("%-72s %-28s %.6g (n=%d)" % (r[0][:72], r[1], r[2], r[3]))
+
+
+if __name__ == "__main__":
+    main()
