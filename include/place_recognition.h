@@ -19,6 +19,7 @@ extern "C" {
 
 typedef struct pr_ctx pr_ctx;
 typedef struct pr_sigset pr_sigset;
+typedef struct pr_clouds pr_clouds;
 
 enum { PR_OK = 0, PR_EINVAL = -1, PR_ENOMEM = -2, PR_EHIP = -3, PR_EIO = -4, PR_ENAN = -5 };
 enum { PR_TYPE_SC = 0, PR_TYPE_M2DP = 1 };          /* run_test.m:27-30 `type` */
@@ -95,6 +96,31 @@ int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const
                        double max_rho, double* out);
 int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
                          double max_rho, double* out);
+
+/* ---- host-side rows a1/a2 (CPU in the reference too; no device, no context) ---------------------------- */
+
+/* Replaces pts_preprocess(poses_file, pts_file, incoming_id_file, lidarRange, clouds, polar_filter)
+ * (utils/pts_preprocess.h:169-232, records PosesPts.h:5-40): sliding world-point window per pose, camera-frame
+ * transform, range cut, voxel (polar_filter = 0, SC) or 1-degree polar (polar_filter = 1, M2DP) down-sampling with the
+ * reference's point ORDER, and the incoming_id_file (written when non-NULL).  verbose prints the reference's lines. */
+int pr_pts_preprocess(const char* poses_file, const char* pts_file, const char* incoming_id_file, double lidarRange,
+                      int polar_filter, int verbose, pr_clouds** out);
+int64_t pr_clouds_count(const pr_clouds* c);
+const int64_t* pr_clouds_offs(const pr_clouds* c);      /* [N+1] */
+const double* pr_clouds_xyz(const pr_clouds* c);        /* [offs[N]][3] camera frame */
+const float* pr_clouds_inten(const pr_clouds* c);       /* [offs[N]] */
+const int32_t* pr_clouds_ids(const pr_clouds* c);       /* [N] incoming ids */
+void pr_clouds_free(pr_clouds* c);
+
+/* Signature matrix text I/O: writer = `ofstream << Eigen::MatrixXd` (test_sc.cpp:63-66, test_m2dp.cpp:83-86);
+ * reader = whitespace-tolerant load (test_kitti.m:26); *out is released with pr_free. */
+int pr_write_signatures(const char* path, const double* sig, int64_t rows, int64_t cols);
+int pr_read_signatures(const char* path, double** out, int64_t* rows, int64_t* cols);
+void pr_free(void* p);
+/* PosesPts.h:12-24 / :36-39 record writers (the producer side, OutputWrapperSODSO.cpp:24-31). */
+int pr_write_poses(const char* path, const int32_t* ids, const double* w2c, int64_t n);
+int pr_write_points(const char* path, const int32_t* ids, const double* xyz, const float* inten, int64_t n);
+const char* pr_host_last_error(void);
 
 #ifdef __cplusplus
 }

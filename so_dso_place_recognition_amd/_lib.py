@@ -40,6 +40,19 @@ SYMBOLS = {
     "pr_fuse_select_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_sc_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
     "pr_m2dp_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
+    "pr_pts_preprocess": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _dbl, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "pr_clouds_count": (C.c_int64, [_vp]),
+    "pr_clouds_offs": (C.POINTER(C.c_int64), [_vp]),
+    "pr_clouds_xyz": (C.POINTER(C.c_double), [_vp]),
+    "pr_clouds_inten": (C.POINTER(C.c_float), [_vp]),
+    "pr_clouds_ids": (C.POINTER(C.c_int32), [_vp]),
+    "pr_clouds_free": (None, [_vp]),
+    "pr_write_signatures": (C.c_int, [C.c_char_p, _vp, C.c_int64, C.c_int64]),
+    "pr_read_signatures": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "pr_free": (None, [_vp]),
+    "pr_write_poses": (C.c_int, [C.c_char_p, _vp, _vp, C.c_int64]),
+    "pr_write_points": (C.c_int, [C.c_char_p, _vp, _vp, _vp, C.c_int64]),
+    "pr_host_last_error": (C.c_char_p, []),
 }
 
 _lib = None

@@ -183,3 +183,59 @@ def run_test(type_, hist1, hist2, gt1=None, gt2=None, loop_diff=None, mask_width
         return sc[:, 0], idx[:, 0]
     from . import eval as _eval
     return _eval.precision_recall(sc[:, 0], idx[:, 0], np.asarray(gt1), np.asarray(gt2), loop_diff, mask_width)
+
+
+# ------------------------------------------------------------------------------- host-side rows a1 / a2
+def pts_preprocess(poses_file: str, pts_file: str, incoming_id_file: str | None, lidarRange: float = 45.0,
+                   polar_filter: bool = False, verbose: bool = False):
+    """pts_preprocess(...) of utils/pts_preprocess.h:169-232 -> (xyz [T,3] f64, inten [T] f32, offs [N+1] i64, ids [N] i32)."""
+    lib = _lib.load()
+    h = C.c_void_p()
+    rc = lib.pr_pts_preprocess(poses_file.encode(), pts_file.encode(),
+                               incoming_id_file.encode() if incoming_id_file else None, float(lidarRange),
+                               int(polar_filter), int(verbose), C.byref(h))
+    if rc != 0:
+        raise PRError(rc, lib.pr_host_last_error().decode())
+    try:
+        N = lib.pr_clouds_count(h)
+        offs = np.ctypeslib.as_array(lib.pr_clouds_offs(h), (N + 1,)).copy()
+        T = int(offs[-1])
+        xyz = np.ctypeslib.as_array(lib.pr_clouds_xyz(h), (T, 3)).copy() if T else np.zeros((0, 3))
+        it = np.ctypeslib.as_array(lib.pr_clouds_inten(h), (T,)).copy() if T else np.zeros((0,), np.float32)
+        ids = np.ctypeslib.as_array(lib.pr_clouds_ids(h), (N,)).copy() if N else np.zeros((0,), np.int32)
+    finally:
+        lib.pr_clouds_free(h)
+    return xyz, it, offs, ids
+
+
+def write_signatures(path: str, sig) -> None:
+    """`ofstream << Eigen::MatrixXd` text (test_sc.cpp:63-66)."""
+    sig = np.ascontiguousarray(sig, np.float64)
+    lib = _lib.load()
+    rc = lib.pr_write_signatures(path.encode(), _ptr(sig), sig.shape[0], sig.shape[1])
+    if rc != 0:
+        raise PRError(rc, lib.pr_host_last_error().decode())
+
+
+def read_signatures(path: str) -> np.ndarray:
+    lib = _lib.load()
+    p = C.c_void_p(); r = C.c_int64(); c = C.c_int64()
+    rc = lib.pr_read_signatures(path.encode(), C.byref(p), C.byref(r), C.byref(c))
+    if rc != 0:
+        raise PRError(rc, lib.pr_host_last_error().decode())
+    try:
+        out = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_double)), (r.value, c.value)).copy()
+    finally:
+        lib.pr_free(p)
+    return out
+
+
+def write_poses(path: str, ids, w2c) -> None:
+    ids = np.ascontiguousarray(ids, np.int32); w2c = np.ascontiguousarray(w2c, np.float64).reshape(len(ids), 12)
+    _lib.load().pr_write_poses(path.encode(), _ptr(ids), _ptr(w2c), len(ids))
+
+
+def write_points(path: str, ids, xyz, inten) -> None:
+    ids = np.ascontiguousarray(ids, np.int32); xyz = np.ascontiguousarray(xyz, np.float64)
+    inten = np.ascontiguousarray(inten, np.float32)
+    _lib.load().pr_write_points(path.encode(), _ptr(ids), _ptr(xyz), _ptr(inten), len(ids))

@@ -1,0 +1,43 @@
+// generate_main.hpp — shared body of test_sc / test_m2dp (SC/test_sc.cpp:12-69, M2DP/test_m2dp.cpp:13-89):
+// same parameters, same exit code / message when one is missing, same console lines, same output files.
+#pragma once
+#include <chrono>
+#include <vector>
+
+#include "../../../include/place_recognition.h"
+#include "cli_common.hpp"
+
+inline int generate_main(int argc, char** argv, bool m2dp) {
+  Params prm(argc, argv);
+  const char* out_name = m2dp ? "m2dp_file" : "sc_file";
+  std::string poses, pts, outf, idf;
+  if (!prm.get("poses_history_file", poses) || !prm.get("pts_history_file", pts) || !prm.get(out_name, outf) ||
+      !prm.get("incoming_id_file", idf)) {
+    printf("Fail to get params, exit.\n");            // test_sc.cpp:23-24
+    return 1;
+  }
+  const double lidarRange = prm.num("lidarRange", 45.0);   // :27-28
+  pr_clouds* clouds = nullptr;
+  if (pr_pts_preprocess(poses.c_str(), pts.c_str(), idf.c_str(), lidarRange, m2dp ? 1 : 0, 1, &clouds) != PR_OK) {
+    fprintf(stderr, "pts_preprocess failed: %s\n", pr_host_last_error());
+    return 2;
+  }
+  const int32_t N = (int32_t)pr_clouds_count(clouds);
+  const size_t rows = m2dp ? (size_t)4 * N : (size_t)N, cols = m2dp ? PR_M2DP_SIG_LEN : PR_SC_SIG_LEN;
+  std::vector<double> sig(rows * cols);
+  pr_ctx* ctx = nullptr;
+  int rc = pr_create((int)prm.num("device", 0), &ctx);
+  if (rc != PR_OK) { fprintf(stderr, "%s\n", pr_last_error(nullptr)); pr_clouds_free(clouds); return 3; }
+  const auto t0 = std::chrono::steady_clock::now();
+  rc = m2dp ? pr_m2dp_generate(ctx, pr_clouds_xyz(clouds), pr_clouds_inten(clouds), pr_clouds_offs(clouds), N, lidarRange, sig.data())
+            : pr_sc_generate(ctx, pr_clouds_xyz(clouds), pr_clouds_inten(clouds), pr_clouds_offs(clouds), N, lidarRange, sig.data());
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (rc != PR_OK) { fprintf(stderr, "generate failed: %s\n", pr_last_error(ctx)); pr_destroy(ctx); pr_clouds_free(clouds); return 4; }
+  printProgress(N ? 1.0 : 0.0);
+  printf("\n%s average time: %gms\n", m2dp ? "M2DP" : "SC", N ? 1000.0 * secs / N : 0.0);   // test_sc.cpp:58-61
+  rc = pr_write_signatures(outf.c_str(), sig.data(), (int64_t)rows, (int64_t)cols);         // :63-66
+  if (rc != PR_OK) fprintf(stderr, "%s\n", pr_host_last_error());
+  pr_destroy(ctx);
+  pr_clouds_free(clouds);
+  return rc == PR_OK ? 0 : 5;
+}

@@ -1,0 +1,50 @@
+// match_signatures — executable counterpart of match_signatures/run_test.m:25-57 (the reference runs it from MATLAB:
+// test_kitti.m:18-28).  Options mirror run_test's arguments:
+//   --type sc|m2dp --hist1 F --hist2 F [--mask_width W=0] [--p_weight 2] [--topk K=1] [--one_based 0|1] --out F
+// Output: one line per query: K pairs "index score" (0-based indices unless --one_based 1), and the reference's
+// console lines `type` / `tm` (ms per query, run_test.m:42-44).
+#include <chrono>
+#include <vector>
+
+#include "../../../include/place_recognition.h"
+#include "cli_common.hpp"
+
+int main(int argc, char** argv) {
+  Params prm(argc, argv);
+  std::string type, h1f, h2f, outf;
+  if (!prm.get("type", type) || !prm.get("hist1", h1f) || !prm.get("hist2", h2f) || !prm.get("out", outf) ||
+      (type != "sc" && type != "m2dp")) {
+    printf("usage: match_signatures --type sc|m2dp --hist1 F --hist2 F [--mask_width W] [--p_weight 2] [--topk K] [--one_based 0|1] --out F\n");
+    return 1;
+  }
+  const int t = type == "sc" ? PR_TYPE_SC : PR_TYPE_M2DP, div = t == PR_TYPE_SC ? 1 : 4;
+  const int64_t width = t == PR_TYPE_SC ? PR_SC_SIG_LEN : PR_M2DP_SIG_LEN;
+  double *h1 = nullptr, *h2 = nullptr;
+  int64_t r1, c1, r2, c2;
+  if (pr_read_signatures(h1f.c_str(), &h1, &r1, &c1) != PR_OK || pr_read_signatures(h2f.c_str(), &h2, &r2, &c2) != PR_OK) {
+    fprintf(stderr, "%s\n", pr_host_last_error());
+    return 2;
+  }
+  if (c1 != width || c2 != width || r1 % div || r2 % div) { fprintf(stderr, "signature files must be [%d*m x %ld]\n", div, (long)width); return 2; }
+  const int32_t m = (int32_t)(r1 / div), n = (int32_t)(r2 / div), k = (int32_t)prm.num("topk", 1);
+  std::vector<int32_t> idx((size_t)m * k);
+  std::vector<float> score((size_t)m * k);
+  pr_ctx* ctx = nullptr;
+  if (pr_create((int)prm.num("device", 0), &ctx) != PR_OK) { fprintf(stderr, "%s\n", pr_last_error(nullptr)); return 3; }
+  const auto t0 = std::chrono::steady_clock::now();
+  const int rc = pr_match_topk(ctx, t, h1, m, h2, n, (int32_t)prm.num("mask_width", 0), prm.num("p_weight", 2.0), k, idx.data(), score.data());
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  if (rc != PR_OK) { fprintf(stderr, "match failed (%d): %s\n", rc, pr_last_error(ctx)); pr_destroy(ctx); return 4; }
+  printf("type = %s\ntm = %g\n", type.c_str(), m ? 1000.0 * secs / m : 0.0);
+  FILE* f = fopen(outf.c_str(), "w");
+  if (!f) { fprintf(stderr, "cannot write %s\n", outf.c_str()); pr_destroy(ctx); return 5; }
+  const int base = prm.num("one_based", 0) != 0 ? 1 : 0;
+  for (int32_t i = 0; i < m; i++) {
+    for (int32_t j = 0; j < k; j++) fprintf(f, "%s%d %.9g", j ? " " : "", idx[(size_t)i * k + j] < 0 ? -1 : idx[(size_t)i * k + j] + base, (double)score[(size_t)i * k + j]);
+    fputc('\n', f);
+  }
+  fclose(f);
+  pr_free(h1); pr_free(h2);
+  pr_destroy(ctx);
+  return 0;
+}

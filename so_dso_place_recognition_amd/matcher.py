@@ -93,28 +93,45 @@ class Matcher:
         self.ctx.check(lib.pr_distances_dev(h, self.q, self.db, _dptr(d_p), _dptr(d_i)))
         if self.post_distances:
             self.post_distances()
-        self.ctx.check(lib.pr_row_moments_dev(h, _dptr(d_p), _dptr(d_i), m, n, _dptr(mom)))
-        if G > 1:
+
+        def local_moments():
+            self.ctx.check(lib.pr_row_moments_dev(h, _dptr(d_p), _dptr(d_i), m, n, _dptr(mom)))
+            if G > 1:
+                self.ctx.sync()
+            return mom
+
+        def local_select(mom_all, G_):
+            if G_ > 1:
+                torch.cuda.current_stream(self.dev).synchronize()
+            self.ctx.check(lib.pr_fuse_select_dev(h, _dptr(d_p), _dptr(d_i), m, n, _dptr(mom_all), G_, q_row0, db_row0,
+                                                  int(mask_width), float(p_weight), int(k), _dptr(idx), _dptr(score)))
             self.ctx.sync()
-            mom_all = self._buf("mom_all", (G, m, 2, 3), torch.float64)
-            dist.all_gather_into_tensor(mom_all, mom, group=group)
-            torch.cuda.current_stream(self.dev).synchronize()
-        else:
-            mom_all = mom
-        self.ctx.check(lib.pr_fuse_select_dev(h, _dptr(d_p), _dptr(d_i), m, n, _dptr(mom_all), G, q_row0, db_row0,
-                                              int(mask_width), float(p_weight), int(k), _dptr(idx), _dptr(score)))
-        self.ctx.sync()
-        if G == 1:
             return idx, score
-        idx_all = self._buf("idx_all", (G, m, k), torch.int32)
-        sc_all = self._buf("sc_all", (G, m, k), torch.float32)
-        dist.all_gather_into_tensor(idx_all, idx, group=group)
-        dist.all_gather_into_tensor(sc_all, score, group=group)
-        return merge_topk(idx_all, sc_all, k)
+
+        return sharded_topk(local_moments, local_select, k, group if G > 1 else None, G)
 
     def distances(self):
         """The last distance matrices (device, float32 [m, n_local])."""
         return self._bufs["d_p"], self._bufs["d_i"]
+
+
+def sharded_topk(local_moments, local_select, k: int, group, G: int):
+    """The exchange protocol of SURVEY.md §8-e around two local callables (HIP in production; a numpy stand-in in
+    the gloo CPU tests): moments -> all_gather -> select with the moments of all shards -> all_gather -> merge."""
+    import torch.distributed as dist
+    mom = local_moments()
+    if G == 1:
+        return local_select(mom, 1)
+    def gather(t):   # list form: identical semantics on nccl (RCCL) and gloo
+        t = t.contiguous()
+        outs = [torch.empty_like(t) for _ in range(G)]
+        dist.all_gather(outs, t, group=group)
+        return torch.stack(outs)
+
+    mom_all = gather(mom)
+    idx, score = local_select(mom_all, G)
+    idx_all, sc_all = gather(idx), gather(score)
+    return merge_topk(idx_all, sc_all, k)
 
 
 def merge_topk(idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):

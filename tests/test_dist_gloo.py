@@ -1,0 +1,92 @@
+"""world_size-2 gloo test of the sharded matching protocol on CPU: the two collectives and the
+merge of matcher.sharded_topk around a numpy stand-in for the two local HIP steps (tests only), checked against
+the oracle run on the unsharded DB."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, n, m, k, mask, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    from so_dso_place_recognition_amd import synth
+    from so_dso_place_recognition_amd.matcher import combine_moments, sharded_topk
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lo, hi = n * rank // world, n * (rank + 1) // world
+    db = synth.sc_database(45, hi - lo, first=lo)
+    queries, _ = synth.sc_queries(46, db, m, db_first=lo, n_global=n, db_seed=45)
+    rc, dp, di = oracle_lib.sc_distance(queries, db)              # stand-in for the local HIP distance kernels
+
+    def local_moments():
+        mom = np.empty((m, 2, 3))
+        for ch, d in enumerate((dp, di)):
+            mean = d.mean(1)
+            mom[:, ch, 0] = d.shape[1]; mom[:, ch, 1] = mean; mom[:, ch, 2] = ((d - mean[:, None]) ** 2).sum(1)
+        return torch.from_numpy(mom)
+
+    def local_select(mom_all, G):
+        ma = mom_all.numpy() if G > 1 else mom_all.numpy()[None]
+        mean, std = combine_moments(ma)
+        f = 2.0 * ((dp - mean[:, :1]) / std[:, :1]) + (di - mean[:, 1:]) / std[:, 1:]
+        jg = lo + np.arange(hi - lo)[None, :]
+        f = np.where(np.abs(np.arange(m)[:, None] - jg) < mask, np.inf, f)
+        order = np.argsort(f, axis=1, kind="stable")[:, :k]
+        idx = (order + lo).astype(np.int32)
+        sc = np.take_along_axis(f, order, 1).astype(np.float32)
+        return torch.from_numpy(idx), torch.from_numpy(sc)
+
+    idx, sc = sharded_topk(local_moments, local_select, k, None, world)
+    if rank == 0:
+        q.put((idx.numpy(), sc.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mask,k", [(0, 1), (4, 3)])
+def test_sharded_topk_matches_unsharded_oracle(mask, k):
+    import oracle_lib
+    from so_dso_place_recognition_amd import synth
+    n, m, world = 90, 12, 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + mask
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, m, k, mask, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    import queue as _q
+    res = None
+    for _ in range(120):
+        try:
+            res = q.get(timeout=1)
+            break
+        except _q.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs):
+                break
+    assert res is not None, 'a rank failed'
+    idx, sc = res
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    db = synth.sc_database(45, n)
+    queries, _ = synth.sc_queries(46, db, m)
+    rc, oidx, osc = oracle_lib.match_topk(0, queries, db, mask, 2.0, k)
+    assert np.array_equal(idx, oidx)
+    assert np.abs(sc - osc).max() < 1e-5
+
+
+def test_merge_topk_ties_and_padding():
+    from so_dso_place_recognition_amd.matcher import merge_topk
+    idx = torch.tensor([[[5, 9, -1]], [[2, 7, 11]]], dtype=torch.int32)           # [G=2, m=1, k=3]
+    sc = torch.tensor([[[0.5, 1.0, float("nan")]], [[0.5, 1.0, 3.0]]], dtype=torch.float32)
+    i, s = merge_topk(idx, sc, 3)
+    assert i.tolist() == [[2, 5, 7]] and s.tolist() == [[0.5, 0.5, 1.0]]       # ties -> lower global index
+    i, s = merge_topk(idx, sc, 6)
+    assert i.tolist()[0][:5] == [2, 5, 7, 9, 11] and i.tolist()[0][5] == -1
