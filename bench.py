@@ -11,7 +11,7 @@ i.e. run_test.m:25-57.  With N > 1 GPUs the SAME 100k DB is row-sharded over the
 SURVEY.md §8-e); queries are replicated.  value = queries of all steps / max-over-ranks wall time.
 
 Extra objects on the JSON line: `roofline` (the dominant kernel sc_match, timed live with HIP events on the
-stream it runs on; algorithmic FLOPs = 39 680 per (query, entry) pair), `cpu_baseline` (the CPU oracle =
+stream it runs on; algorithmic FLOPs = 23 856 per (query, entry) pair), `cpu_baseline` (the CPU oracle =
 a port of the reference, timed on this host's cores on a bounded query sample at N = 1), `parity` (GPU top-1 vs
 that oracle on the sample and vs the planted ground truth on all queries).
 """
@@ -27,7 +27,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOP_PER_PAIR = 2 * 31 * (160 + 480)     # 39 680: stage 1 (4 real K=20 dots) + stage 2 (120 shifts x 2 coeff), DESIGN.md
+# algorithmic FLOP per (query, entry) pair of the formulation sc_match.hip runs, per channel:
+#   stage 1: 29 frequencies x 4 real K=20 dots (160) + 2 real-only frequencies x 1 dot (40)            = 4 720
+#   stage 2: {fwd, mir} x ( E: 31 shifts x 31 freqs + O: 29 shifts x 29 freqs ) x 2 FLOP               = 7 208
+FLOP_PER_PAIR = 2 * (29 * 160 + 2 * 40 + 2 * 2 * (31 * 31 + 29 * 29))    # 23 856
 MFMA_F32_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: Peak FP32 (matrix)
 
 

@@ -7,9 +7,12 @@ namespace pr {
 
 // ------------------------------------------------------------------ packed layouts
 constexpr int SC_NF = 31;                       // rfft bins of the 60 sectors
-constexpr int SC_QIMG = SC_NF * 320;            // floats per (channel, 8-query group): [f][s(5)][lane(64)]
-constexpr int SC_DSTEP = 640;                   // floats per (channel, 16-entry DB group, f)
-constexpr int SC_DIMG = SC_NF * SC_DSTEP;       // floats per (channel, 16-entry DB group)
+constexpr int SC_NSLOT = 16;                    // frequency pairs per DB group: (0,30),(1,2),...,(27,28),(29,-)
+constexpr int SC_QIMG = SC_NF * 320;            // floats per (channel, 8-query group): [pos(31)][s(5)][lane(64)]
+constexpr int SC_DSTEP = 640;                   // floats per (channel, 16-entry DB group, frequency position)
+constexpr int SC_DIMG = 2 * SC_NSLOT * SC_DSTEP;  // floats per (channel, 16-entry DB group): 32 positions, the last one zero
+// frequency -> position in the packed images (processing order 0,30,1,2,...,29)
+__host__ __device__ inline int sc_fpos(int f) { return f == 0 ? 0 : (f == 30 ? 1 : f + 1); }
 constexpr int M2_TILE = 96 * 64;                // floats per (channel, 32-row tile): [kq(24)][lane(64)][4]
 
 inline int sc_qgroups8(int m) { return ((m + 31) / 32) * 4; }

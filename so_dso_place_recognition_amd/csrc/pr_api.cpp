@@ -68,7 +68,7 @@ size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups) {
   if (type == PR_TYPE_SC) {
     if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SC_QIMG; }
     *groups = pr::sc_dgroups(max_sigs);
-    return (size_t)2 * *groups * pr::SC_DIMG + 4 * pr::SC_DSTEP;   // + prefetch tail (sc_match.hip)
+    return (size_t)2 * *groups * pr::SC_DIMG + 8 * pr::SC_DSTEP;   // + prefetch tail of 4 slots (sc_match.hip)
   }
   if (role == PR_ROLE_QUERY) { *groups = ((pr::m2_tiles(max_sigs) + 3) / 4) * 4; return (size_t)2 * *groups * pr::M2_TILE; }
   *groups = pr::m2_tiles(max_sigs);
@@ -123,17 +123,26 @@ int pr_create(int device_id, pr_ctx** out) {
     tw[0] = 1; tw[15] = 0; tw[30] = -1; tw[45] = 0; tw[60] = 0; tw[75] = 1; tw[90] = 0; tw[105] = -1;
     TRY(hipMalloc((void**)&ctx->d_twiddle, sizeof tw));
     TRY(hipMemcpy(ctx->d_twiddle, tw, sizeof tw, hipMemcpyHostToDevice));
-    // stage-2 constants: lane l of tile st -> shift k = st*32 + (l&31) (k >= 60 repeats shift 0, harmless for the max),
-    // l < 32: w_f cos(2 pi f k/60), l >= 32: -w_f sin(2 pi f k/60); w_0 = w_30 = 1, else 2.
-    std::vector<float> cst((size_t)pr::SC_NF * 128);
-    for (int f = 0; f < pr::SC_NF; f++)
-      for (int st = 0; st < 2; st++)
-        for (int l = 0; l < 64; l++) {
-          int k = st * 32 + (l & 31); if (k >= 60) k = 0;
+    // stage-2 constants per slot (two frequencies fa | fb in the lane halves): lane l -> shift k = l & 31 (k = 31
+    // repeats shift 0, harmless for the max), f = (l < 32 ? fa : fb);  ce = w_f cos(2 pi f k/60), co = -w_f sin(2 pi f k/60),
+    // w_0 = w_30 = 1, else 2.  Slot order (0,30), (1,2), ..., (27,28), (29,-): the missing partner gets zeros.
+    std::vector<float> cst((size_t)pr::SC_NSLOT * 128);
+    for (int sl = 0; sl < pr::SC_NSLOT; sl++)
+      for (int l = 0; l < 64; l++) {
+        int f;
+        if (sl == 0) f = (l < 32) ? 0 : 30;
+        else f = (sl == pr::SC_NSLOT - 1 && l >= 32) ? 31 : 2 * sl - 1 + (l >> 5);   // slot 15 has no partner
+        int k = l & 31; if (k > 30) k = 0;
+        float ce = 0.f, co = 0.f;
+        if (f <= 30) {
           const int t = (f * k) % 60;
           const double w = (f == 0 || f == 30) ? 1.0 : 2.0;
-          cst[(size_t)f * 128 + st * 64 + l] = (float)((l < 32) ? w * tw[t] : -w * tw[60 + t]);
+          ce = (float)(w * tw[t]);
+          co = (float)(-w * tw[60 + t]);
         }
+        cst[(size_t)sl * 128 + l] = ce;
+        cst[(size_t)sl * 128 + 64 + l] = co;
+      }
     TRY(hipMalloc((void**)&ctx->d_cst, cst.size() * sizeof(float)));
     TRY(hipMemcpy(ctx->d_cst, cst.data(), cst.size() * sizeof(float), hipMemcpyHostToDevice));
     // M2DP plane table from the frozen float normals (M2DP/M2DP.cpp:9-30)

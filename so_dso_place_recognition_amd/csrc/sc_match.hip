@@ -4,24 +4,28 @@
 // permute_sc processSC.m:37-45) of (1 - <variant_k(q_i), d_j>)/2 on L2-normalised 1200-vectors, per channel.
 // The 120 inner products are the circular cross-correlation (forward) and circular convolution (mirror) of
 // the 60 sectors summed over the 20 rings, so with the per-ring sector spectra Q_r[f], D_r[f] (sc_pack.hip)
-//   S_f = sum_r Q_r[f] conj(D_r[f])   (forward)        P_f = sum_r Q_r[f] D_r[f]   (mirror)
-//   dot_fwd[k] = sum_f w_f ( Re S_f cos(2 pi f k/60) - Im S_f sin(2 pi f k/60) ),  same with P_f for the mirror
-// (w_0 = w_30 = 1, else 2; the 1/60 is folded into the packed spectra).  39 680 FLOP per (query, entry) pair
-// instead of the dense 576 000 (SURVEY.md H6/N7).
+//   S_f = sum_r Q_r[f] conj(D_r[f])   (forward)        P_f = sum_r Q_r[f] D_r[f]   (mirror)          f = 0..30
+//   dot_fwd[k] = E[k] + O[k],  dot_fwd[60-k] = E[k] - O[k],   k = 0..30
+//   E[k] = sum_f w_f Re S_f cos(2 pi f k/60)  (even in k)     O[k] = -sum_f w_f Im S_f sin(2 pi f k/60)  (odd in k)
+// hence  max over the 60 shifts = max_{k=0..30} ( E[k] + |O[k]| ), and the same with P_f for the 60 mirrored shifts
+// (w_0 = w_30 = 1, else 2; the 1/60 is folded into the packed spectra).  23 856 FLOP per (query, entry) pair
+// instead of the dense 576 000 (SURVEY.md H6/N7; DESIGN.md §4.1).
 //
-// Mapping to the matrix cores (one wave = 8 queries x 16 DB entries, all 31 frequencies):
-//   stage 1  v_mfma_f32_16x16x4_f32, K = 20 rings:  rows = {Re,Im} x 8 queries, cols = 16 entries
-//            T1 = [Qre;Qim] . Dre^T          = (A | C)
-//            T2 = [Qim;-Qre] . Dim^T         = (B | -E)      (row operand = DPP row_ror:8 of T1's, sign-flipped)
-//            F = T1 + T2 = (Re S_f | Im S_f)    M = T1 - T2 = (Re P_f | Im P_f)        (8 VALU)
-//   stage 2  v_mfma_f32_32x32x2_f32, K = {Re,Im}:  the C/D register r of stage 1 holds, lane for lane, the
-//            B operand (k = lane>>5, pair = lane&31) of a 32x32x2 MFMA whose A operand is the constant
-//            [shift][cos | -sin] tile, so stage 1 feeds stage 2 without any data movement:
-//            acc[r][tile][fwd|mir] (32 shifts x 32 pairs) += C_f[tile] . F[r]   (16 MFMAs per frequency)
-//   epilogue max over the 60 shifts (15 in-lane v_max + one cross-half) -> d = 0.5 - 0.5*max.
+// Mapping to the matrix cores (one wave = 8 queries x 16 DB entries; the 31 frequencies are processed as 16 slots
+// of two frequencies: (0,30), (1,2), ..., (27,28), (29,-)):
+//   stage 1  v_mfma_f32_16x16x4_f32, K = 20 rings, per frequency:  rows = {Re,Im} x 8 queries, cols = 16 entries
+//            T1 = [Qre;Qim] . Dre^T = (A | C)      T2 = [Qim;-Qre] . Dim^T = (B | -E)
+//            (T2's row operand = T1's through DPP row_ror:8 with a sign flip - no second LDS image)
+//            F = T1 + T2 = (Re S_f | Im S_f)       M = T1 - T2 = (Re P_f | Im P_f)              lanes <32 | >=32
+//   swap     v_permlane32_swap(F_fa[r], F_fb[r]) -> (Re S_fa | Re S_fb), (Im S_fa | Im S_fb): each register is now, lane
+//            for lane, the B operand (k = lane>>5, pair = lane&31) of a 32x32x2 MFMA over K = {fa, fb}
+//   stage 2  v_mfma_f32_32x32x2_f32:  E[r][fwd|mir] += Ccos[slot] . Re-tile,  O[r][fwd|mir] += Csin[slot] . Im-tile
+//            (A operand = constant [shift 0..31][fa|fb] tile; 16 MFMAs per slot; 256 accumulator registers)
+//   epilogue max over shifts of E + |O| (in-lane over 16 registers + one cross-half exchange) -> d = 0.5 - 0.5*max.
+// Stage 1 feeds stage 2 through registers only: no LDS or HBM round trip of the m x n x 124 intermediate.
 // A workgroup (4 waves, one per SIMD, <=512 VGPR+AGPR each) keeps the spectra of 32 queries of one channel
 // resident in LDS (158 720 B) and sweeps a range of the DB; the DB operand stream goes HBM/L2 -> VGPR directly
-// (all 4 waves read the same 2.5 KB per frequency, so 3 of 4 hit L1).  Bound: MFMA fp32 (157.3 TFLOP/s).
+// (all 4 waves read the same 5 KB per slot, so 3 of 4 hit L1).  Bound: MFMA fp32 (157.3 TFLOP/s).
 #include "kernels.hpp"
 
 namespace pr {
@@ -29,37 +33,47 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
-struct Ops {        // operands of one frequency step
+struct FreqOps {    // operands of one frequency
   float a[5];       // query rows, K-steps s = 0..4                    (LDS)
   f32x4 bre, bim;   // DB Re / Im, K-steps 0..3                        (global)
   float2 b4;        // DB (Re, Im) of K-step 4                         (global)
-  float c0, c1;     // stage-2 constant tiles (shifts 0..31, 32..63)    (global, L1-resident)
+};
+struct SlotOps {    // operands of one slot = two frequencies + the two stage-2 constant tiles
+  FreqOps f[2];
+  float ce, co;
 };
 
 __device__ __forceinline__ float ror8(float x) {  // DPP row_ror:8 inside each 16-lane row
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));
 }
 
-__device__ __forceinline__ void load_ops(Ops& o, const float* __restrict__ la, const float* __restrict__ db,
-                                         const float* __restrict__ cst, int f, int lane) {
-  const float* a = la + f * 320;
+// slot = 0..15 within a DB group; db points at the slot's first frequency block of the packed DB stream
+__device__ __forceinline__ void load_slot(SlotOps& o, const float* __restrict__ la, const float* __restrict__ db,
+                                          const float* __restrict__ cst, int slot, int lane) {
 #pragma unroll
-  for (int s = 0; s < 5; s++) o.a[s] = a[s * 64];
-  const f32x4* p = reinterpret_cast<const f32x4*>(db);
-  o.bre = p[lane];
-  o.bim = p[64 + lane];
-  o.b4 = reinterpret_cast<const float2*>(db + 512)[lane];
-  o.c0 = cst[f * 128 + lane];
-  o.c1 = cst[f * 128 + 64 + lane];
+  for (int h = 0; h < 2; h++) {
+    int pos = 2 * slot + h;
+    if (pos > SC_NF - 1) pos = SC_NF - 1;          // the 32nd position is all-zero on the DB side: any query rows do
+    const float* a = la + pos * 320;
+#pragma unroll
+    for (int s = 0; s < 5; s++) o.f[h].a[s] = a[s * 64];
+    const f32x4* p = reinterpret_cast<const f32x4*>(db + h * SC_DSTEP);
+    o.f[h].bre = p[lane];
+    o.f[h].bim = p[64 + lane];
+    o.f[h].b4 = reinterpret_cast<const float2*>(db + h * SC_DSTEP + 512)[lane];
+  }
+  o.ce = cst[slot * 128 + lane];
+  o.co = cst[slot * 128 + 64 + lane];
 }
 
-// Stage 1 in VGPR form.  The 256 accumulators of stage 2 fill the whole AccVGPR half of the register file, and
-// hipcc selects one MFMA form per function (AGPR C/D here), so the two small stage-1 accumulators are kept in
-// ArchVGPRs by hand: ONE asm statement with the ten MFMAs, its own wait states inside (cdna_hip_programming.md
-// §5.7): s_nop 1 covers VALU-written A operands (the DPP products), the trailing s_nop 10 covers the 8-pass
-// MFMA D -> VALU read of the add/sub that follows; back-to-back SrcC == vDst chains need none.
-__device__ __forceinline__ void stage1(const Ops& o, float sgn, f32x4& F, f32x4& M) {
+// Stage 1 of one frequency in VGPR form.  The 256 accumulators of stage 2 fill the whole AccVGPR half of the register
+// file and hipcc selects one MFMA form per function (AGPR C/D here), so the small stage-1 accumulators are kept in
+// ArchVGPRs by hand: ONE asm statement with the ten MFMAs and their wait states inside (cdna_hip_programming.md §5.7):
+// s_nop 1 covers the VALU-written A operands (the DPP products), the trailing s_nop 10 covers the 8-pass MFMA D -> VALU
+// read of the add/sub that follows; back-to-back SrcC == vDst chains need none.
+__device__ __forceinline__ void stage1(const FreqOps& o, float sgn, f32x4& F, f32x4& M) {
   f32x4 t1, t2;
   const float r0 = ror8(o.a[0]) * sgn, r1 = ror8(o.a[1]) * sgn, r2 = ror8(o.a[2]) * sgn, r3 = ror8(o.a[3]) * sgn,
               r4 = ror8(o.a[4]) * sgn;
@@ -85,9 +99,41 @@ __device__ __forceinline__ void stage1(const Ops& o, float sgn, f32x4& F, f32x4&
   M = t1 - t2;
 }
 
+struct Tiles {      // stage-2 B operands of one slot: {forward, mirror} x {Re, Im} x 4 registers
+  f32x4 fre, fim, mre, mim;
+};
+
+__device__ __forceinline__ void swap_halves(const f32x4& xa, const f32x4& xb, f32x4& re, f32x4& im) {
+#pragma unroll
+  for (int r = 0; r < 4; r++) {   // lanes 32-63 of xa <-> lanes 0-31 of xb
+    const u32x2 v = __builtin_amdgcn_permlane32_swap(__float_as_uint(xa[r]), __float_as_uint(xb[r]), false, false);
+    re[r] = __uint_as_float(v[0]);
+    im[r] = __uint_as_float(v[1]);
+  }
+}
+
+__device__ __forceinline__ void slot_stage1(const SlotOps& o, float sgn, Tiles& t) {
+  f32x4 Fa, Ma, Fb, Mb;
+  stage1(o.f[0], sgn, Fa, Ma);
+  stage1(o.f[1], sgn, Fb, Mb);
+  swap_halves(Fa, Fb, t.fre, t.fim);
+  swap_halves(Ma, Mb, t.mre, t.mim);
+}
+
+#define SC_STAGE2(CE, CO, T, CIN_E, CIN_O)                                                              \
+  _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                       \
+    accE[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(CE, T.fre[r], CIN_E(r, 0), 0, 0, 0);              \
+    accO[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(CO, T.fim[r], CIN_O(r, 0), 0, 0, 0);              \
+    accE[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(CE, T.mre[r], CIN_E(r, 1), 0, 0, 0);              \
+    accO[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(CO, T.mim[r], CIN_O(r, 1), 0, 0, 0);              \
+  }
+#define SC_ZERO(r, v) zero
+#define SC_ACCE(r, v) accE[r][v]
+#define SC_ACCO(r, v) accO[r][v]
+
 __global__ __launch_bounds__(256, 1) void sc_match_kernel(const float* __restrict__ qpk,  // [2][QG8][31][5][64]
-                                                          const float* __restrict__ dpk,  // [2][DG][31][640]
-                                                          const float* __restrict__ cst,  // [31][2][64]
+                                                          const float* __restrict__ dpk,  // [2][DG][32][640]
+                                                          const float* __restrict__ cst,  // [16][2][64]
                                                           float* __restrict__ dist_p, float* __restrict__ dist_i,
                                                           int m, int n, int QG8, int DG, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -108,60 +154,56 @@ __global__ __launch_bounds__(256, 1) void sc_match_kernel(const float* __restric
   if (g0 >= g1) return;
 
   const float* la = lds + w * SC_QIMG + lane;
-  const float* db = dpk + ((size_t)ch * DG + g0) * SC_DIMG;
+  const float* db = dpk + ((size_t)ch * DG + g0) * SC_DIMG;   // slot stream: SS floats per slot, contiguous over groups
   float* dist = ch ? dist_i : dist_p;
   const float sgn = ((lane & 15) >= 8) ? -1.0f : 1.0f;
-
-  // software pipeline: operands are loaded two steps ahead, stage 1 runs one step ahead of stage 2.
-  // The packed DB buffer carries a readable tail of >= 2 steps, so the prefetch needs no bounds branch.
-  Ops o1, o2;
-  f32x4 F, M, Fn, Mn;
-  float c0, c1;
-  {
-    Ops o0;
-    load_ops(o0, la, db, cst, 0, lane);
-    stage1(o0, sgn, F, M);
-    c0 = o0.c0; c1 = o0.c1;
-  }
-  load_ops(o1, la, db + SC_DSTEP, cst, 1, lane);
-  const float* dbn = db + 2 * SC_DSTEP;      // operands of step t+2
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  constexpr int SS = 2 * SC_DSTEP;
+
+  // Software pipeline over the flat slot sequence i = 0,1,2,... (16 slots per DB group).  While stage 2 of slot i runs:
+  // operands of slot i+3 are being requested, those of i+2 are in flight, stage 1 + swap of slot i+1 are issued.
+  // Three operand buffers rotate with period 3, so the 15 slots after the peeled slot 0 are unrolled by 3 and the
+  // only register copies are two buffer renames per DB group.  The packed DB buffer has a readable tail of >= 3
+  // slots, so the prefetch needs no bounds branch.
+  SlotOps oA, oB, oC;   // at the top of a group: oA = operands(slot 1), oB = operands(slot 2) in flight, oC free
+  Tiles tc, tn;         // tiles of the current / next slot
+  float ce, co;         // constants of the current slot
+  load_slot(oC, la, db, cst, 0, lane);
+  load_slot(oA, la, db + SS, cst, 1, lane);
+  load_slot(oB, la, db + 2 * SS, cst, 2, lane);
+  slot_stage1(oC, sgn, tc);
+  ce = oC.ce; co = oC.co;
+  const float* dbn = db + 3 * SS;                              // next slot to request
 
   for (int g = g0; g < g1; g++) {
-    f32x16 acc[4][2][2];
-    // ---- f = 0: accumulators start from the MFMA's zero C operand (no 256-register clear)
-    load_ops(o2, la, dbn, cst, 2, lane);
-    dbn += SC_DSTEP;
-    stage1(o1, sgn, Fn, Mn);
+    f32x16 accE[4][2], accO[4][2];
+    // ---- slot 0: accumulators start from the MFMA's zero C operand (no 256-register clear)
+    load_slot(oC, la, dbn, cst, 3, lane); dbn += SS;
+    slot_stage1(oA, sgn, tn);
+    SC_STAGE2(ce, co, tc, SC_ZERO, SC_ZERO)
+    tc = tn; ce = oA.ce; co = oA.co;
+    // ---- slots 1..15, three per iteration
+    for (int s = 1; s < SC_NSLOT; s += 3) {
+      load_slot(oA, la, dbn, cst, (s + 3) & 15, lane); dbn += SS;
+      slot_stage1(oB, sgn, tn);
+      SC_STAGE2(ce, co, tc, SC_ACCE, SC_ACCO)
+      tc = tn; ce = oB.ce; co = oB.co;
+
+      load_slot(oB, la, dbn, cst, (s + 4) & 15, lane); dbn += SS;
+      slot_stage1(oC, sgn, tn);
+      SC_STAGE2(ce, co, tc, SC_ACCE, SC_ACCO)
+      tc = tn; ce = oC.ce; co = oC.co;
+
+      load_slot(oC, la, dbn, cst, (s + 5) & 15, lane); dbn += SS;
+      slot_stage1(oA, sgn, tn);
+      SC_STAGE2(ce, co, tc, SC_ACCE, SC_ACCO)
+      tc = tn; ce = oA.ce; co = oA.co;
+    }
+    // ---- end of the DB group: max over the 120 variants = max_k E + |O| over fwd and mir, write 8 x 16 distances
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      acc[r][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, F[r], zero, 0, 0, 0);
-      acc[r][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, M[r], zero, 0, 0, 0);
-      acc[r][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, F[r], zero, 0, 0, 0);
-      acc[r][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, M[r], zero, 0, 0, 0);
-    }
-    F = Fn; M = Mn; c0 = o1.c0; c1 = o1.c1; o1 = o2;
-    // ---- f = 1..30
-    for (int f = 1; f < SC_NF; f++) {
-      int f2 = f + 2;                          // frequency of the step being prefetched
-      if (f2 >= SC_NF) f2 -= SC_NF;
-      load_ops(o2, la, dbn, cst, f2, lane);
-      dbn += SC_DSTEP;
-      stage1(o1, sgn, Fn, Mn);                 // stage 1 of step t+1
-#pragma unroll
-      for (int r = 0; r < 4; r++) {            // stage 2 of step t
-        acc[r][0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, F[r], acc[r][0][0], 0, 0, 0);
-        acc[r][0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, M[r], acc[r][0][1], 0, 0, 0);
-        acc[r][1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, F[r], acc[r][1][0], 0, 0, 0);
-        acc[r][1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, M[r], acc[r][1][1], 0, 0, 0);
-      }
-      F = Fn; M = Mn; c0 = o1.c0; c1 = o1.c1; o1 = o2;
-    }
-    // ---- end of the DB group: max over the 120 variants, write 8 x 16 distances
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      f32x16 v = __builtin_elementwise_max(__builtin_elementwise_max(acc[r][0][0], acc[r][0][1]),
-                                           __builtin_elementwise_max(acc[r][1][0], acc[r][1][1]));
+      f32x16 v = __builtin_elementwise_max(accE[r][0] + __builtin_elementwise_abs(accO[r][0]),
+                                           accE[r][1] + __builtin_elementwise_abs(accO[r][1]));
       float mx = v[0];
 #pragma unroll
       for (int e = 1; e < 16; e++) mx = fmaxf(mx, v[e]);
@@ -172,6 +214,9 @@ __global__ __launch_bounds__(256, 1) void sc_match_kernel(const float* __restric
         if (qrow < m && drow < n) dist[(size_t)qrow * n + drow] = 0.5f - 0.5f * mx;   // processSC.m:30
       }
     }
+    // 16 slots advance the period-3 rotation by one: rename so that the next group starts in the same roles
+    oA = oB;   // operands(slot 1 of the next group)
+    oB = oC;   // operands(slot 2 of the next group), possibly still in flight
   }
 }
 
@@ -188,12 +233,8 @@ void launch_sc_match(hipStream_t st, const float* qpk, int m, const float* dpk, 
   if (nsplit > DG / 8) nsplit = DG / 8;            // keep >= 8 DB groups (128 entries) per workgroup
   if (nsplit < 1) nsplit = 1;
   if (nsplit_override > 0) nsplit = nsplit_override < DG ? nsplit_override : DG;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_match_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_lds_bytes());
-    attr_set = true;
-  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_match_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_lds_bytes());
   hipLaunchKernelGGL(sc_match_kernel, dim3(base * nsplit), dim3(256), sc_match_lds_bytes(), st, qpk, dpk, cst, d_p,
                      d_i, m, n, QG8, DG, nsplit);
 }

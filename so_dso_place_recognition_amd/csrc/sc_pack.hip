@@ -5,8 +5,9 @@
 // length-60 real DFT over the sector axis, so the normalised rows are stored here as their
 // per-ring sector spectra  X_r[f] = (1/sqrt 60) * sum_s x[s*20+r] * exp(-2 pi i f s / 60),  f = 0..30,
 // computed in fp64 and rounded once to fp32, laid out as the MFMA operand image of the set's role:
-//   query image  [ch][group of 8][f][s=0..4][lane]      lane = (k<<4) | (part<<3) | e   ring = 4s+k
-//   DB image     [ch][group of 16][f]{ q4a[lane][4] (Re, s=0..3) | q4b[lane][4] (Im, s=0..3) | d2[lane][2] (Re,Im of s=4) }
+//   query image  [ch][group of 8][pos][s=0..4][lane]    lane = (k<<4) | (part<<3) | e   ring = 4s+k
+//   (pos = processing order of the frequencies: 0,30,1,2,...,29; the DB image has a 32nd, all-zero position)
+//   DB image     [ch][group of 16][pos]{ q4a[lane][4] (Re, s=0..3) | q4b[lane][4] (Im, s=0..3) | d2[lane][2] (Re,Im of s=4) }
 //                                                       lane = (k<<4) | j               ring = 4s+k
 // One workgroup per (row, channel).  HBM-trivial: 2400 values in, 2480 floats out per row.
 #include "kernels.hpp"
@@ -58,11 +59,11 @@ __global__ __launch_bounds__(256) void sc_pack_kernel(const T* __restrict__ sig,
     if (role == 0) {  // query image
       const int g = row >> 3, e = row & 7;
       const int lane = (k << 4) | (im << 3) | e;
-      dst = (((size_t)ch * groups + g) * SC_NF + f) * 320 + s4 * 64 + lane;
+      dst = ((size_t)ch * groups + g) * SC_QIMG + (size_t)sc_fpos(f) * 320 + s4 * 64 + lane;
     } else {          // DB image
       const int g = row >> 4, j = row & 15;
       const int lane = (k << 4) | j;
-      const size_t base = (((size_t)ch * groups + g) * SC_NF + f) * SC_DSTEP;
+      const size_t base = ((size_t)ch * groups + g) * SC_DIMG + (size_t)sc_fpos(f) * SC_DSTEP;
       dst = (s4 < 4) ? base + im * 256 + lane * 4 + s4 : base + 512 + lane * 2 + im;
     }
     packed[dst] = val;
