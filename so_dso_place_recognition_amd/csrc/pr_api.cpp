@@ -123,23 +123,20 @@ int pr_create(int device_id, pr_ctx** out) {
     tw[0] = 1; tw[15] = 0; tw[30] = -1; tw[45] = 0; tw[60] = 0; tw[75] = 1; tw[90] = 0; tw[105] = -1;
     TRY(hipMalloc((void**)&ctx->d_twiddle, sizeof tw));
     TRY(hipMemcpy(ctx->d_twiddle, tw, sizeof tw, hipMemcpyHostToDevice));
-    // stage-2 constants per slot (two frequencies fa | fb in the lane halves): lane l -> shift k = l & 31 (k = 31
-    // repeats shift 0, harmless for the max), f = (l < 32 ? fa : fb);  ce = w_f cos(2 pi f k/60), co = -w_f sin(2 pi f k/60),
-    // w_0 = w_30 = 1, else 2.  Slot order (0,30), (1,2), ..., (27,28), (29,-): the missing partner gets zeros.
+    // stage-2 constants per slot, A operand of v_mfma_f32_32x32x2_f32: lane l -> shift k = l & 31 (k = 31 repeats
+    // shift 0, harmless for the max), K index = l >> 5.  Slots (fa, fb) = (0,30), (1,2), ..., (27,28): K = {fa, fb},
+    // ce = w_f cos(2 pi f k/60), co = -w_f sin(2 pi f k/60), w_0 = w_30 = 1, else 2.  Slot 15 = frequency 29 alone,
+    // applied to the unswapped (Re | Im) tile: ce = (w cos | 0), co = (0 | -w sin).
     std::vector<float> cst((size_t)pr::SC_NSLOT * 128);
     for (int sl = 0; sl < pr::SC_NSLOT; sl++)
       for (int l = 0; l < 64; l++) {
-        int f;
-        if (sl == 0) f = (l < 32) ? 0 : 30;
-        else f = (sl == pr::SC_NSLOT - 1 && l >= 32) ? 31 : 2 * sl - 1 + (l >> 5);   // slot 15 has no partner
+        const int half = l >> 5;
         int k = l & 31; if (k > 30) k = 0;
-        float ce = 0.f, co = 0.f;
-        if (f <= 30) {
-          const int t = (f * k) % 60;
-          const double w = (f == 0 || f == 30) ? 1.0 : 2.0;
-          ce = (float)(w * tw[t]);
-          co = (float)(-w * tw[60 + t]);
-        }
+        const int f = (sl == 0) ? (half ? 30 : 0) : (sl == pr::SC_NSLOT - 1 ? 29 : 2 * sl - 1 + half);
+        const int t = (f * k) % 60;
+        const double w = (f == 0 || f == 30) ? 1.0 : 2.0;
+        float ce = (float)(w * tw[t]), co = (float)(-w * tw[60 + t]);
+        if (sl == pr::SC_NSLOT - 1) { if (half) ce = 0.f; else co = 0.f; }
         cst[(size_t)sl * 128 + l] = ce;
         cst[(size_t)sl * 128 + 64 + l] = co;
       }

@@ -44,37 +44,47 @@ struct SlotOps {    // operands of one slot = two frequencies + the two stage-2 
   FreqOps f[2];
   float ce, co;
 };
+struct Tiles {      // stage-2 B operands of one slot: {forward, mirror} x {Re, Im} x 4 registers
+  f32x4 fre, fim, mre, mim;
+};
+
+constexpr int SS = 2 * SC_DSTEP;   // floats per slot in the packed DB stream
 
 __device__ __forceinline__ float ror8(float x) {  // DPP row_ror:8 inside each 16-lane row
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x128, 0xf, 0xf, false));
 }
 
-// slot = 0..15 within a DB group; db points at the slot's first frequency block of the packed DB stream
+// Slot kinds: slot 0 = (0,30): both spectra are real (no Im loads, no T2 chain, no O accumulation);
+// slot 15 = (29,-): single frequency; every other slot is a full pair.
+template <int SLOT>
 __device__ __forceinline__ void load_slot(SlotOps& o, const float* __restrict__ la, const float* __restrict__ db,
-                                          const float* __restrict__ cst, int slot, int lane) {
+                                          const float* __restrict__ cst, int lane) {
 #pragma unroll
   for (int h = 0; h < 2; h++) {
-    int pos = 2 * slot + h;
-    if (pos > SC_NF - 1) pos = SC_NF - 1;          // the 32nd position is all-zero on the DB side: any query rows do
-    const float* a = la + pos * 320;
+    if (SLOT == SC_NSLOT - 1 && h == 1) break;
+    const float* a = la + (2 * SLOT + h) * 320;
 #pragma unroll
     for (int s = 0; s < 5; s++) o.f[h].a[s] = a[s * 64];
     const f32x4* p = reinterpret_cast<const f32x4*>(db + h * SC_DSTEP);
     o.f[h].bre = p[lane];
-    o.f[h].bim = p[64 + lane];
-    o.f[h].b4 = reinterpret_cast<const float2*>(db + h * SC_DSTEP + 512)[lane];
+    if (SLOT != 0) {
+      o.f[h].bim = p[64 + lane];
+      o.f[h].b4 = reinterpret_cast<const float2*>(db + h * SC_DSTEP + 512)[lane];
+    } else {
+      o.f[h].b4.x = db[h * SC_DSTEP + 512 + 2 * lane];
+    }
   }
-  o.ce = cst[slot * 128 + lane];
-  o.co = cst[slot * 128 + 64 + lane];
+  o.ce = cst[SLOT * 128 + lane];
+  if (SLOT != 0) o.co = cst[SLOT * 128 + 64 + lane];
 }
 
 // Stage 1 of one frequency in VGPR form.  The 256 accumulators of stage 2 fill the whole AccVGPR half of the register
 // file and hipcc selects one MFMA form per function (AGPR C/D here), so the small stage-1 accumulators are kept in
-// ArchVGPRs by hand: ONE asm statement with the ten MFMAs and their wait states inside (cdna_hip_programming.md §5.7):
+// ArchVGPRs by hand: ONE asm statement with the MFMAs and their wait states inside (cdna_hip_programming.md §5.7):
 // s_nop 1 covers the VALU-written A operands (the DPP products), the trailing s_nop 10 covers the 8-pass MFMA D -> VALU
-// read of the add/sub that follows; back-to-back SrcC == vDst chains need none.
-__device__ __forceinline__ void stage1(const FreqOps& o, float sgn, f32x4& F, f32x4& M) {
-  f32x4 t1, t2;
+// read of the add/sub/swap that consumes t1/t2 (placed after a block of stage-2 MFMAs, but never rely on that);
+// back-to-back SrcC == vDst chains need none.
+__device__ __forceinline__ void stage1_full(const FreqOps& o, float sgn, f32x4& t1, f32x4& t2) {
   const float r0 = ror8(o.a[0]) * sgn, r1 = ror8(o.a[1]) * sgn, r2 = ror8(o.a[2]) * sgn, r3 = ror8(o.a[3]) * sgn,
               r4 = ror8(o.a[4]) * sgn;
   asm volatile(
@@ -95,13 +105,23 @@ __device__ __forceinline__ void stage1(const FreqOps& o, float sgn, f32x4& F, f3
         "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4),                              // %7..%11  rotated, sign-flipped rows
         "v"(o.bre[0]), "v"(o.bre[1]), "v"(o.bre[2]), "v"(o.bre[3]), "v"(o.b4.x),  // %12..%16 DB Re
         "v"(o.bim[0]), "v"(o.bim[1]), "v"(o.bim[2]), "v"(o.bim[3]), "v"(o.b4.y)); // %17..%21 DB Im
-  F = t1 + t2;
-  M = t1 - t2;
 }
-
-struct Tiles {      // stage-2 B operands of one slot: {forward, mirror} x {Re, Im} x 4 registers
-  f32x4 fre, fim, mre, mim;
-};
+// Real spectra (f = 0, 30): Im parts are zero, so T2 = 0 and F = M = T1.  Two independent half-chains (K-steps
+// 0,2,4 and 1,3) keep the 40-cycle dependent latency of the 16x16x4 MFMA off the critical path.
+__device__ __forceinline__ void stage1_real(const FreqOps& o, f32x4& t1) {
+  f32x4 u;
+  asm volatile(
+      "v_mfma_f32_16x16x4_f32 %0, %2, %7, 0\n\t"
+      "v_mfma_f32_16x16x4_f32 %1, %3, %8, 0\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, %4, %9, %0\n\t"
+      "v_mfma_f32_16x16x4_f32 %1, %5, %10, %1\n\t"
+      "v_mfma_f32_16x16x4_f32 %0, %6, %11, %0\n\t"
+      "s_nop 10"
+      : "=&v"(t1), "=&v"(u)
+      : "v"(o.a[0]), "v"(o.a[1]), "v"(o.a[2]), "v"(o.a[3]), "v"(o.a[4]),
+        "v"(o.bre[0]), "v"(o.bre[1]), "v"(o.bre[2]), "v"(o.bre[3]), "v"(o.b4.x));
+  t1 = t1 + u;
+}
 
 __device__ __forceinline__ void swap_halves(const f32x4& xa, const f32x4& xb, f32x4& re, f32x4& im) {
 #pragma unroll
@@ -112,24 +132,78 @@ __device__ __forceinline__ void swap_halves(const f32x4& xa, const f32x4& xb, f3
   }
 }
 
-__device__ __forceinline__ void slot_stage1(const SlotOps& o, float sgn, Tiles& t) {
-  f32x4 Fa, Ma, Fb, Mb;
-  stage1(o.f[0], sgn, Fa, Ma);
-  stage1(o.f[1], sgn, Fb, Mb);
-  swap_halves(Fa, Fb, t.fre, t.fim);
-  swap_halves(Ma, Mb, t.mre, t.mim);
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+// stage-2 MFMAs of slot S for stage-1 register r (4 per r; 2 for the real slot 0)
+template <int S>
+__device__ __forceinline__ void stage2_r(int r, const Tiles& t, float ce, float co, f32x16 (&accE)[4][2],
+                                         f32x16 (&accO)[4][2], const f32x16& zero) {
+  if (S == 0) {                    // real pair: forward and mirror get the same E contribution, O stays empty
+    accE[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.fre[r], zero, 0, 0, 0);
+    accE[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.fre[r], zero, 0, 0, 0);
+  } else if (S == 1) {             // first slot with an odd part: O starts from the zero C operand
+    accE[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.fre[r], accE[r][0], 0, 0, 0);
+    accO[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.fim[r], zero, 0, 0, 0);
+    accE[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.mre[r], accE[r][1], 0, 0, 0);
+    accO[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.mim[r], zero, 0, 0, 0);
+  } else if (S == SC_NSLOT - 1) {  // single frequency: unswapped (Re|Im) tiles against (cos|0) and (0|-sin)
+    accE[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.fre[r], accE[r][0], 0, 0, 0);
+    accO[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.fre[r], accO[r][0], 0, 0, 0);
+    accE[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.mre[r], accE[r][1], 0, 0, 0);
+    accO[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.mre[r], accO[r][1], 0, 0, 0);
+  } else {
+    accE[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.fre[r], accE[r][0], 0, 0, 0);
+    accO[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.fim[r], accO[r][0], 0, 0, 0);
+    accE[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.mre[r], accE[r][1], 0, 0, 0);
+    accO[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.mim[r], accO[r][1], 0, 0, 0);
+  }
 }
 
-#define SC_STAGE2(CE, CO, T, CIN_E, CIN_O)                                                              \
-  _Pragma("unroll") for (int r = 0; r < 4; r++) {                                                       \
-    accE[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(CE, T.fre[r], CIN_E(r, 0), 0, 0, 0);              \
-    accO[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(CO, T.fim[r], CIN_O(r, 0), 0, 0, 0);              \
-    accE[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(CE, T.mre[r], CIN_E(r, 1), 0, 0, 0);              \
-    accO[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(CO, T.mim[r], CIN_O(r, 1), 0, 0, 0);              \
+// One pipeline step: stage 2 of slot S (tiles tc), stage 1 + swap of slot S+1 (operands X -> tiles tc for the next
+// step), request of the operands of slot S+3 (into Z).  The schedule is pinned with sched_barrier so that the
+// VALU work that consumes stage-1 results (add/sub, permlane swaps) always issues behind a block of independent
+// stage-2 MFMAs: the matrix pipe never waits for it.
+template <int S>
+__device__ __forceinline__ void slot_step(SlotOps& X, SlotOps& Z, Tiles& tc, float& ce, float& co,
+                                          f32x16 (&accE)[4][2], f32x16 (&accO)[4][2], const f32x16& zero,
+                                          const float* __restrict__ la, const float*& dbn,
+                                          const float* __restrict__ cst, int lane, float sgn) {
+  constexpr int N1 = (S + 1) & (SC_NSLOT - 1);   // slot whose stage 1 runs in this step
+  constexpr int N3 = (S + 3) & (SC_NSLOT - 1);   // slot whose operands are requested in this step
+  load_slot<N3>(Z, la, dbn, cst, lane);
+  dbn += SS;
+  Tiles tn;
+  f32x4 t1a, t2a, t1b, t2b;
+  if (N1 == 0) stage1_real(X.f[0], t1a); else stage1_full(X.f[0], sgn, t1a, t2a);
+  SB();
+  stage2_r<S>(0, tc, ce, co, accE, accO, zero);
+  SB();
+  f32x4 Fa, Ma, Fb, Mb;
+  if (N1 == 0) { Fa = t1a; } else { Fa = t1a + t2a; Ma = t1a - t2a; }
+  if (N1 != SC_NSLOT - 1) {
+    if (N1 == 0) stage1_real(X.f[1], t1b); else stage1_full(X.f[1], sgn, t1b, t2b);
   }
-#define SC_ZERO(r, v) zero
-#define SC_ACCE(r, v) accE[r][v]
-#define SC_ACCO(r, v) accO[r][v]
+  SB();
+  stage2_r<S>(1, tc, ce, co, accE, accO, zero);
+  SB();
+  if (N1 == 0) {
+    Fb = t1b;
+    swap_halves(Fa, Fb, tn.fre, tn.fim);          // (Re_0 | Re_30); the Im tile is identically zero and unused
+  } else if (N1 == SC_NSLOT - 1) {
+    tn.fre = Fa; tn.mre = Ma;                     // single frequency: keep (Re | Im) together
+  } else {
+    Fb = t1b + t2b; Mb = t1b - t2b;
+    swap_halves(Fa, Fb, tn.fre, tn.fim);
+    swap_halves(Ma, Mb, tn.mre, tn.mim);
+  }
+  SB();
+  stage2_r<S>(2, tc, ce, co, accE, accO, zero);
+  stage2_r<S>(3, tc, ce, co, accE, accO, zero);
+  SB();
+  tc = tn;
+  ce = X.ce;
+  co = X.co;
+}
 
 __global__ __launch_bounds__(256, 1) void sc_match_kernel(const float* __restrict__ qpk,  // [2][QG8][31][5][64]
                                                           const float* __restrict__ dpk,  // [2][DG][32][640]
@@ -158,47 +232,36 @@ __global__ __launch_bounds__(256, 1) void sc_match_kernel(const float* __restric
   float* dist = ch ? dist_i : dist_p;
   const float sgn = ((lane & 15) >= 8) ? -1.0f : 1.0f;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  constexpr int SS = 2 * SC_DSTEP;
 
-  // Software pipeline over the flat slot sequence i = 0,1,2,... (16 slots per DB group).  While stage 2 of slot i runs:
-  // operands of slot i+3 are being requested, those of i+2 are in flight, stage 1 + swap of slot i+1 are issued.
-  // Three operand buffers rotate with period 3, so the 15 slots after the peeled slot 0 are unrolled by 3 and the
-  // only register copies are two buffer renames per DB group.  The packed DB buffer has a readable tail of >= 3
-  // slots, so the prefetch needs no bounds branch.
+  // Software pipeline over the flat slot sequence (16 slots per DB group).  While stage 2 of slot i runs: operands of
+  // slot i+3 are being requested, those of i+2 are in flight, stage 1 + swap of slot i+1 are issued.  Three operand
+  // buffers rotate with period 3; the 16 slots of a group are fully unrolled (compile-time slot kinds) and the only
+  // register copies are two buffer renames per group.  The packed DB buffer has a readable tail of >= 3 slots.
   SlotOps oA, oB, oC;   // at the top of a group: oA = operands(slot 1), oB = operands(slot 2) in flight, oC free
-  Tiles tc, tn;         // tiles of the current / next slot
-  float ce, co;         // constants of the current slot
-  load_slot(oC, la, db, cst, 0, lane);
-  load_slot(oA, la, db + SS, cst, 1, lane);
-  load_slot(oB, la, db + 2 * SS, cst, 2, lane);
-  slot_stage1(oC, sgn, tc);
-  ce = oC.ce; co = oC.co;
+  Tiles tc;             // tiles of the current slot
+  float ce, co = 0.f;   // constants of the current slot
+  {
+    f32x4 t1a, t1b;
+    load_slot<0>(oC, la, db, cst, lane);
+    load_slot<1>(oA, la, db + SS, cst, lane);
+    load_slot<2>(oB, la, db + 2 * SS, cst, lane);
+    stage1_real(oC.f[0], t1a);
+    stage1_real(oC.f[1], t1b);
+    swap_halves(t1a, t1b, tc.fre, tc.fim);
+    ce = oC.ce;
+  }
   const float* dbn = db + 3 * SS;                              // next slot to request
 
   for (int g = g0; g < g1; g++) {
     f32x16 accE[4][2], accO[4][2];
-    // ---- slot 0: accumulators start from the MFMA's zero C operand (no 256-register clear)
-    load_slot(oC, la, dbn, cst, 3, lane); dbn += SS;
-    slot_stage1(oA, sgn, tn);
-    SC_STAGE2(ce, co, tc, SC_ZERO, SC_ZERO)
-    tc = tn; ce = oA.ce; co = oA.co;
-    // ---- slots 1..15, three per iteration
-    for (int s = 1; s < SC_NSLOT; s += 3) {
-      load_slot(oA, la, dbn, cst, (s + 3) & 15, lane); dbn += SS;
-      slot_stage1(oB, sgn, tn);
-      SC_STAGE2(ce, co, tc, SC_ACCE, SC_ACCO)
-      tc = tn; ce = oB.ce; co = oB.co;
-
-      load_slot(oB, la, dbn, cst, (s + 4) & 15, lane); dbn += SS;
-      slot_stage1(oC, sgn, tn);
-      SC_STAGE2(ce, co, tc, SC_ACCE, SC_ACCO)
-      tc = tn; ce = oC.ce; co = oC.co;
-
-      load_slot(oC, la, dbn, cst, (s + 5) & 15, lane); dbn += SS;
-      slot_stage1(oA, sgn, tn);
-      SC_STAGE2(ce, co, tc, SC_ACCE, SC_ACCO)
-      tc = tn; ce = oA.ce; co = oA.co;
-    }
+#define STEP(S, X, Z) slot_step<S>(X, Z, tc, ce, co, accE, accO, zero, la, dbn, cst, lane, sgn)
+    STEP(0, oA, oC);  STEP(1, oB, oA);  STEP(2, oC, oB);
+    STEP(3, oA, oC);  STEP(4, oB, oA);  STEP(5, oC, oB);
+    STEP(6, oA, oC);  STEP(7, oB, oA);  STEP(8, oC, oB);
+    STEP(9, oA, oC);  STEP(10, oB, oA); STEP(11, oC, oB);
+    STEP(12, oA, oC); STEP(13, oB, oA); STEP(14, oC, oB);
+    STEP(15, oA, oC);
+#undef STEP
     // ---- end of the DB group: max over the 120 variants = max_k E + |O| over fwd and mir, write 8 x 16 distances
 #pragma unroll
     for (int r = 0; r < 4; r++) {
