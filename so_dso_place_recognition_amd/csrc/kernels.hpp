@@ -39,11 +39,13 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
                         float* score);
 
 // sc_gen.hip / m2dp_gen.hip — pts_align.h:7-46 + SC.cpp:12-76 / M2DP.cpp:38-109 (+ test_m2dp.cpp:44-68)
-void launch_cloud_frames(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double* frames);
-void launch_sc_generate(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
-                        double max_rho, double* out, double* frames);
-void launch_m2dp_generate(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
-                          double max_rho, double* out, const double* planes, void* scratch, size_t scratch_bytes);
+void launch_ave_chain(hipStream_t st, const float* inten, const int64_t* offs, int N, float* ave);
+void launch_cloud_frames(hipStream_t st, const double* xyz, const int64_t* offs, int N, double* frames);
+void launch_sc_bin(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double max_rho,
+                   const double* frames, const float* ave, double* out);
+void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
+                         double max_rho, const double* frames, const float* ave, const double* planes, double* mats,
+                         double* out);
 size_t m2dp_generate_scratch_bytes(int N);
 
 }  // namespace pr

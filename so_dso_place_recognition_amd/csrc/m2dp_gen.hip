@@ -23,6 +23,7 @@ constexpr int MAT = 64 * 128;
 
 __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict__ xyz, const float* __restrict__ inten,
                                                         const int64_t* __restrict__ offs, const double* __restrict__ frames,
+                                                        const float* __restrict__ ave_in,
                                                         const double* __restrict__ planes, double max_rho, int c0,
                                                         double* __restrict__ mats) {
   __shared__ unsigned int cnt[16 * 128];
@@ -66,7 +67,7 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
     }
   }
   __syncthreads();
-  const double ave = f[12];
+  const double ave = (double)ave_in[c];
   double* mc = mats + (((size_t)cl * 4 + var) * 2) * MAT + (size_t)pg * 16 * 128;
   double* mi = mc + MAT;
   for (int b = tid; b < 16 * 128; b += 256) {
@@ -199,21 +200,19 @@ constexpr int GEN_BATCH = 256;   // clouds per scratch batch (256 * 4 * 2 * 64 K
 
 size_t m2dp_generate_scratch_bytes(int N) {
   const int nb = N < GEN_BATCH ? N : GEN_BATCH;
-  return (size_t)N * 16 * sizeof(double) + (size_t)nb * 4 * 2 * MAT * sizeof(double);
+  return (size_t)nb * 4 * 2 * MAT * sizeof(double);
 }
 
-void launch_m2dp_generate(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
-                          double max_rho, double* out, const double* planes, void* scratch, size_t scratch_bytes) {
+void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
+                         double max_rho, const double* frames, const float* ave, const double* planes, double* mats,
+                         double* out) {
   if (N <= 0) return;
-  (void)scratch_bytes;
-  double* frames = static_cast<double*>(scratch);
-  double* mats = frames + (size_t)N * 16;
-  launch_cloud_frames(st, xyz, inten, offs, N, frames);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(m2dp_svd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)SVD_LDS);
   for (int c0 = 0; c0 < N; c0 += GEN_BATCH) {
     const int nc = (N - c0) < GEN_BATCH ? (N - c0) : GEN_BATCH;
-    hipLaunchKernelGGL(m2dp_bin_kernel, dim3(nc * 16), dim3(256), 0, st, xyz, inten, offs, frames, planes, max_rho, c0, mats);
+    hipLaunchKernelGGL(m2dp_bin_kernel, dim3(nc * 16), dim3(256), 0, st, xyz, inten, offs, frames, ave, planes, max_rho,
+                       c0, mats);
     hipLaunchKernelGGL(m2dp_svd_kernel, dim3(nc * 8), dim3(256), SVD_LDS, st, mats, c0, out);
   }
 }

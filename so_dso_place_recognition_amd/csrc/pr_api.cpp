@@ -17,6 +17,8 @@
 struct pr_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t side = nullptr;    // overlaps the sequential float-average chain with the moments pass
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   int* d_flags = nullptr;        // [4] deferred error bits (bit0: zero-norm row at pack time)
   double* d_twiddle = nullptr;   // cos[60], sin[60] of 2*pi*t/60
@@ -115,6 +117,9 @@ int pr_create(int device_id, pr_ctx** out) {
 #define TRY(call) if ((call) != hipSuccess) { g_err = std::string(#call) + " failed"; rc = PR_EHIP; break; }
     TRY(hipSetDevice(device_id));
     TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     TRY(hipMalloc((void**)&ctx->d_flags, 4 * sizeof(int)));
     TRY(hipMemset(ctx->d_flags, 0, 4 * sizeof(int)));
     double tw[120];
@@ -168,6 +173,9 @@ void pr_destroy(pr_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+  if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->d_cst) (void)hipFree(ctx->d_cst);
@@ -338,13 +346,27 @@ static int check_gen_args(pr_ctx* ctx, const void* xyz, const void* inten, const
   return PR_OK;
 }
 
+// frames (moments + eig) on the main stream, the float-average chain on the side stream, joined before binning
+static int launch_frames_and_ave(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
+                                 double* frames, float* ave) {
+  PR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  PR_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  pr::launch_ave_chain(ctx->side, inten, offs, N, ave);
+  PR_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+  pr::launch_cloud_frames(ctx->stream, xyz, offs, N, frames);
+  PR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  return PR_OK;
+}
+
 int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
   if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
   if (N == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
-  DevBuf frames;
+  DevBuf frames, ave;
   PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
-  pr::launch_sc_generate(ctx->stream, xyz, inten, offs, N, max_rho, out, frames.as<double>());
+  PR_HIP(ctx, ave.alloc((size_t)N * 4));
+  if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc;
+  pr::launch_sc_bin(ctx->stream, xyz, inten, offs, N, max_rho, frames.as<double>(), ave.as<float>(), out);
   PR_HIP(ctx, hipGetLastError());
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PR_OK;
@@ -354,10 +376,13 @@ int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, con
   if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
   if (N == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
-  DevBuf scratch;
-  const size_t sb = pr::m2dp_generate_scratch_bytes(N);
-  PR_HIP(ctx, scratch.alloc(sb));
-  pr::launch_m2dp_generate(ctx->stream, xyz, inten, offs, N, max_rho, out, ctx->d_planes, scratch.p, sb);
+  DevBuf frames, ave, mats;
+  PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
+  PR_HIP(ctx, ave.alloc((size_t)N * 4));
+  PR_HIP(ctx, mats.alloc(pr::m2dp_generate_scratch_bytes(N)));
+  if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc;
+  pr::launch_m2dp_bin_svd(ctx->stream, xyz, inten, offs, N, max_rho, frames.as<double>(), ave.as<float>(), ctx->d_planes,
+                          mats.as<double>(), out);
   PR_HIP(ctx, hipGetLastError());
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PR_OK;

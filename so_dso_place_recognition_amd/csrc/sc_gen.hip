@@ -1,13 +1,15 @@
 // sc_gen.hip — PCA alignment (utils/pts_align.h:7-46) and Scan-Context signature (SC/SC.cpp:12-76) on gfx950.
 //
 // Two kernels, one workgroup per cloud each (compiled with -ffp-contract=off so products/sums round as on the CPU):
-//   cloud_frames : one streaming pass over the cloud: fp64 raw moments (sum p, sum p p^T) by waves 0..6 with a
-//                  fixed reduction tree, while wave 7 walks the intensities IN INPUT ORDER accumulating the
-//                  reference's FLOAT sequential average (SC.cpp:60-64; a tree sum differs at ~3e-4 and flips
-//                  bins; the loads are wave-uniform -> scalar loads, the chain is one v_add_f32 per
-//                  point).  Then mean, scatter matrix cov = sum pp^T - P mean mean^T (un-normalised as :30),
-//                  3x3 symmetric Jacobi eigen-solver, eigenvalues ascending, canonical signs (N3)
-//                  -> frames[c] = {mean[3], v0[3], v1[3], v2[3], ave, pad} (16 doubles).
+//   ave_chain    : the reference's FLOAT sequential average of the intensities IN INPUT ORDER (SC.cpp:60-64,
+//                  M2DP.cpp:77-81; a tree sum differs at ~3e-4 and flips bins).  The chain of P
+//                  dependent v_add_f32 cannot be parallelised inside a cloud, so every LANE walks a different
+//                  cloud (8 independent chains per wave, per-lane 16-byte loads, two batches of 8 loads in flight per lane).
+//                  Runs on a side stream, overlapped with cloud_frames.  -> ave[c] (float).
+//   cloud_frames : one streaming pass over the cloud: fp64 raw moments (sum p, sum p p^T), fixed reduction tree;
+//                  mean, scatter matrix cov = sum pp^T - P mean mean^T (un-normalised as :30), 3x3 symmetric Jacobi
+//                  eigen-solver, eigenvalues ascending, canonical signs (N3)
+//                  -> frames[c] = {mean[3], v0[3], v1[3], v2[3], pad} (16 doubles).
 //   sc_bin       : second pass: centre, rotate (same association as the oracle), sector = floor((atan2(z,y)+pi)*60/2pi),
 //                  ring = floor(sqrt(y^2+z^2)*20/max_rho), idx = sector*20 + ring, dropped iff idx >= 1200 (the
 //                  ring-overflow aliasing of SC.cpp:39-44 is kept, H3); LDS-resident 1200-bin grids with LDS
@@ -19,7 +21,8 @@
 namespace pr {
 namespace {
 
-constexpr int FT = 512;   // threads of cloud_frames (8 waves: 7 reduce, 1 walks the float average)
+constexpr int FT = 256;   // threads of cloud_frames
+constexpr int RW = FT / 64;
 
 __device__ void jacobi_eig3(double a[3][3], double v[3][3]) {
   for (int i = 0; i < 3; i++)
@@ -53,25 +56,58 @@ __device__ void jacobi_eig3(double a[3][3], double v[3][3]) {
   }
 }
 
-__global__ __launch_bounds__(FT) void cloud_frames_kernel(const double* __restrict__ xyz, const float* __restrict__ inten,
+// one lane per cloud: lane-private sequential float sum in input order.  Only CPW lanes of a wave are used: a
+// per-lane 16-byte load touches one cache line per active lane, and with 64 different clouds per instruction the
+// texture-address path (one line per cycle or so) was slower than the add chain; 8 clouds per wave keeps the chain
+// (about 5 cycles per dependent v_add_f32) the only limiter, and 5 000 clouds still are only 625 waves.
+constexpr int CPW = 8;
+__global__ __launch_bounds__(64) void ave_chain_kernel(const float* __restrict__ inten, const int64_t* __restrict__ offs,
+                                                        int N, float* __restrict__ ave_out) {
+  const int c = blockIdx.x * CPW + threadIdx.x;
+  const bool live = c < N;
+  const int64_t o0 = live ? offs[c] : 0;
+  const int64_t P = live ? offs[c + 1] - o0 : 0;
+  const float* it = inten + o0;
+  float ave = 0.f;
+  int64_t i = 0;
+  constexpr int U = 8;                       // 16-byte loads per batch and lane; two batches are in flight
+  constexpr int BF = 4 * U;                  // floats per batch
+  typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
+  if (P >= BF) {
+    f4 a[U], b[U];
+#pragma unroll
+    for (int k = 0; k < U; k++) a[k] = *reinterpret_cast<const f4*>(it + 4 * k);
+    i = BF;
+    // invariant: batch [i-BF, i) sits in `a`; the next batch is requested before the current one is summed
+    while (i + 2 * BF <= P) {
+#pragma unroll
+      for (int k = 0; k < U; k++) b[k] = *reinterpret_cast<const f4*>(it + i + 4 * k);
+#pragma unroll
+      for (int k = 0; k < U; k++) { ave += a[k][0]; ave += a[k][1]; ave += a[k][2]; ave += a[k][3]; }
+#pragma unroll
+      for (int k = 0; k < U; k++) a[k] = *reinterpret_cast<const f4*>(it + i + BF + 4 * k);
+#pragma unroll
+      for (int k = 0; k < U; k++) { ave += b[k][0]; ave += b[k][1]; ave += b[k][2]; ave += b[k][3]; }
+      i += 2 * BF;
+    }
+#pragma unroll
+    for (int k = 0; k < U; k++) { ave += a[k][0]; ave += a[k][1]; ave += a[k][2]; ave += a[k][3]; }
+  }
+  for (; i < P; i++) ave += it[i];
+  if (live) ave_out[c] = ave / (float)P;     // SC.cpp:64
+}
+
+__global__ __launch_bounds__(FT) void cloud_frames_kernel(const double* __restrict__ xyz,
                                                            const int64_t* __restrict__ offs, double* __restrict__ frames) {
-  __shared__ double red[7][9];
-  __shared__ float ave_s;
+  __shared__ double red[RW][9];
   const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int w = tid >> 6;
   const int64_t o0 = offs[c];
   const int64_t P = offs[c + 1] - o0;
-  if (w == 7) {
-    // SC.cpp:60-64 / M2DP.cpp:77-81: float accumulator, input order.  Every lane computes the same chain.
-    const float* it = inten + o0;
-    float ave = 0.f;
-    for (int64_t i = 0; i < P; i++) ave += it[i];
-    ave = ave / (float)P;
-    if (lane == 0) ave_s = ave;
-  } else {
+  {
     double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const double* p = xyz + 3 * o0;
-    for (int64_t i = tid; i < P; i += 7 * 64) {
+    for (int64_t i = tid; i < P; i += FT) {
       const double x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
       s[0] += x; s[1] += y; s[2] += z;
       s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;
@@ -88,7 +124,7 @@ __global__ __launch_bounds__(FT) void cloud_frames_kernel(const double* __restri
     double s[9];
     for (int k = 0; k < 9; k++) {
       double v = 0;
-      for (int i = 0; i < 7; i++) v += red[i][k];
+      for (int i = 0; i < RW; i++) v += red[i][k];
       s[k] = v;
     }
     const double n = (double)P;
@@ -117,8 +153,7 @@ __global__ __launch_bounds__(FT) void cloud_frames_kernel(const double* __restri
     f[0] = mx; f[1] = my; f[2] = mz;
     for (int j = 0; j < 3; j++)
       for (int k = 0; k < 3; k++) f[3 + 3 * j + k] = e[j][k];
-    f[12] = (double)ave_s;
-    f[13] = n; f[14] = 0; f[15] = 0;
+    f[12] = 0; f[13] = n; f[14] = 0; f[15] = 0;
   }
 }
 
@@ -133,7 +168,8 @@ __device__ __forceinline__ double dunkey(unsigned long long k) {
 
 __global__ __launch_bounds__(512) void sc_bin_kernel(const double* __restrict__ xyz, const float* __restrict__ inten,
                                                       const int64_t* __restrict__ offs, const double* __restrict__ frames,
-                                                      double max_rho, double* __restrict__ out) {
+                                                      const float* __restrict__ ave_in, double max_rho,
+                                                      double* __restrict__ out) {
   __shared__ unsigned int cnt[1200];
   __shared__ unsigned long long lo[1200], hi[1200];
   __shared__ double sum[1200];
@@ -164,7 +200,7 @@ __global__ __launch_bounds__(512) void sc_bin_kernel(const double* __restrict__ 
     atomicAdd(&sum[idx], (double)it[i]);
   }
   __syncthreads();
-  const double ave = f[12];   // the float average, widened (comparison double > float promotes the float)
+  const double ave = (double)ave_in[c];   // the float average, widened (double > float promotes the float, SC.cpp:70)
   double* o = out + (size_t)c * 2400;
   for (int b = tid; b < 1200; b += 512) {
     const unsigned int n = cnt[b];
@@ -180,16 +216,20 @@ __global__ __launch_bounds__(512) void sc_bin_kernel(const double* __restrict__ 
 
 }  // namespace
 
-void launch_cloud_frames(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double* frames) {
+void launch_ave_chain(hipStream_t st, const float* inten, const int64_t* offs, int N, float* ave) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(cloud_frames_kernel, dim3(N), dim3(FT), 0, st, xyz, inten, offs, frames);
+  hipLaunchKernelGGL(ave_chain_kernel, dim3((N + CPW - 1) / CPW), dim3(CPW), 0, st, inten, offs, N, ave);
 }
 
-void launch_sc_generate(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
-                        double max_rho, double* out, double* frames) {
+void launch_cloud_frames(hipStream_t st, const double* xyz, const int64_t* offs, int N, double* frames) {
   if (N <= 0) return;
-  launch_cloud_frames(st, xyz, inten, offs, N, frames);
-  hipLaunchKernelGGL(sc_bin_kernel, dim3(N), dim3(512), 0, st, xyz, inten, offs, frames, max_rho, out);
+  hipLaunchKernelGGL(cloud_frames_kernel, dim3(N), dim3(FT), 0, st, xyz, offs, frames);
+}
+
+void launch_sc_bin(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double max_rho,
+                   const double* frames, const float* ave, double* out) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(sc_bin_kernel, dim3(N), dim3(512), 0, st, xyz, inten, offs, frames, ave, max_rho, out);
 }
 
 }  // namespace pr
