@@ -56,33 +56,41 @@ __global__ __launch_bounds__(256, 1) void m2dp_match_kernel(const float* __restr
   const f32x4* la0 = reinterpret_cast<const f32x4*>(lds) + (size_t)(wq * 2) * (M2_TILE / 4) + lane;
   const f32x4* la1 = la0 + (M2_TILE / 4);
   float* dist = ch ? dist_i : dist_p;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (s0 >= s1) return;
+  // DB operand stream of this wave: tiles (4 s + 2 wd) and (4 s + 2 wd + 1); per tile 24 x 16-byte loads per lane.
+  // Software pipeline: DB operands two K-quads ahead (3 rotating register pairs), query operands (LDS) one ahead,
+  // loads pinned in front of the 16 MFMAs of the current K-quad with sched_barrier so hipcc cannot sink them next to
+  // their first use; the first two K-quads of the NEXT sweep step are requested before this step's epilogue.
+  const f32x4* pb = reinterpret_cast<const f32x4*>(dpk + ((size_t)ch * DT + (size_t)s0 * 4 + wd * 2) * M2_TILE) + lane;
+  constexpr int TQ = M2_TILE / 4;            // f32x4 per tile
+  f32x4 b0[3], b1[3], a0[2], a1[2];
+  b0[0] = pb[0];  b1[0] = pb[TQ];
+  b0[1] = pb[64]; b1[1] = pb[TQ + 64];
   for (int s = s0; s < s1; s++) {
-    const int dt0 = s * 4 + wd * 2;                                // this wave's two DB tiles (buffer is padded)
-    const f32x4* pb0 = reinterpret_cast<const f32x4*>(dpk + ((size_t)ch * DT + dt0) * M2_TILE) + lane;
-    const f32x4* pb1 = pb0 + (M2_TILE / 4);
+    const int dt0 = s * 4 + wd * 2;
+    const f32x4* pn = pb + 4 * TQ;           // same wave column, next sweep step (the packed buffer has a readable tail)
     f32x16 acc[2][2];
+    a0[0] = la0[0]; a1[0] = la1[0];
 #pragma unroll
-    for (int i = 0; i < 2; i++)
-#pragma unroll
-      for (int j = 0; j < 2; j++)
-#pragma unroll
-        for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
-    f32x4 b0 = pb0[0], b1 = pb1[0];
-#pragma unroll 4
     for (int kq = 0; kq < 24; kq++) {
-      const f32x4 a0 = la0[kq * 64], a1 = la1[kq * 64];
-      const int kn = (kq < 23) ? kq + 1 : 23;
-      const f32x4 nb0 = pb0[kn * 64], nb1 = pb1[kn * 64];
+      const int cb = kq % 3, nb = (kq + 2) % 3, ca = kq & 1, na = (kq + 1) & 1;
+      if (kq + 2 < 24) { b0[nb] = pb[(kq + 2) * 64]; b1[nb] = pb[TQ + (kq + 2) * 64]; }
+      else             { b0[nb] = pn[(kq - 22) * 64]; b1[nb] = pn[TQ + (kq - 22) * 64]; }
+      if (kq + 1 < 24) { a0[na] = la0[(kq + 1) * 64]; a1[na] = la1[(kq + 1) * 64]; }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int c = 0; c < 4; c++) {
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b0[c], acc[0][0], 0, 0, 0);
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[c], b1[c], acc[0][1], 0, 0, 0);
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b0[c], acc[1][0], 0, 0, 0);
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[c], b1[c], acc[1][1], 0, 0, 0);
+        const bool first = (kq == 0 && c == 0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[ca][c], b0[cb][c], first ? zero : acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[ca][c], b1[cb][c], first ? zero : acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[ca][c], b0[cb][c], first ? zero : acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[ca][c], b1[cb][c], first ? zero : acc[1][1], 0, 0, 0);
       }
-      b0 = nb0;
-      b1 = nb1;
+      __builtin_amdgcn_sched_barrier(0);
     }
+    // 24 K-quads advance the period-3 rotation by 0: b0[0], b0[1] already hold K-quads 0, 1 of the next step
+    pb = pn;
     // epilogue: C layout col = lane&31 -> (entry = col>>2, variant = col&3); row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // -> (query = 2*(reg>>2) + (lane>>5), variant = reg&3).  d = min (1-dot)/2 = 0.5 - 0.5*max dot.
 #pragma unroll
