@@ -16,6 +16,7 @@
 //                  atomics: count (u32 add), min/max of x (order-preserving u64 keys), fp64 intensity sum; epilogue
 //                  max-min and mean > ave ? 1 : 0 (:67-75) -> out[c][2400].
 // Bound: HBM (28 B per point per pass); the points are never written back.
+#include "fast_bins.hpp"
 #include "kernels.hpp"
 
 namespace pr {
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(512) void sc_bin_kernel(const double* __restrict__ 
   const double mx = f[0], my = f[1], mz = f[2];
   const double e00 = f[3], e01 = f[4], e02 = f[5], e10 = f[6], e11 = f[7], e12 = f[8], e20 = f[9], e21 = f[10], e22 = f[11];
   const double S_res_inv = 60 / (2.0 * M_PI), R_res_inv = 20 / max_rho;   // SC.cpp:5-8
+  const float S_f = (float)S_res_inv, R_f = (float)R_res_inv;
   const double* p = xyz + 3 * o0;
   const float* it = inten + o0;
   for (int64_t i = tid; i < P; i += 512) {
@@ -189,8 +191,8 @@ __global__ __launch_bounds__(512) void sc_bin_kernel(const double* __restrict__ 
     const double nx = (x * e00 + y * e01) + z * e02;                                // :37-39
     const double yp = (x * e10 + y * e11) + z * e12;
     const double zp = (x * e20 + y * e21) + z * e22;
-    const int si = (int)floor((atan2(zp, yp) + M_PI) * S_res_inv);                  // SC.cpp:37
-    const int ri = (int)floor(sqrt(yp * yp + zp * zp) * R_res_inv);                 // :38
+    const int si = polar_sector(zp, yp, S_res_inv, S_f);    // floor((atan2(zp, yp) + pi) * S_res_inv), SC.cpp:37
+    const int ri = polar_ring(yp, zp, R_res_inv, R_f);      // floor(sqrt(yp^2 + zp^2) * R_res_inv),   SC.cpp:38
     const int idx = si * 20 + ri;                                                   // :39
     if (idx >= 1200 || idx < 0) continue;                                           // :42-44
     atomicAdd(&cnt[idx], 1u);
