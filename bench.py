@@ -142,6 +142,13 @@ def main():
         kms = float(np.mean(kern_ms))
         pairs = m * (hi - lo)
         ach = pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12
+        traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
+        try:
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if tr["workload"] == {"db": n, "queries": m, "n_gpus": world}:
+                traffic = tr["sc_match_kernel"]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "queries/sec over 100k-signature DB (SC 20x60, z-score fusion, top-1)",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -152,7 +159,7 @@ def main():
                        "mask_width": 0, "p_weight": 2.0, "k": 1, "db_rows_per_gpu": hi - lo,
                        "step": "pack(q)+pack(db)+distances+moments+fuse/top-1" + ("+2 all_gathers" if world > 1 else "")},
             "roofline": {"kernel": "sc_match_kernel", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
                          "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": pairs, "ms_per_launch": kms,
                          "dense_equivalent_tflops": pairs * 576000 / (kms * 1e-3) / 1e12},
             "parity": {"planted_top1_correct": planted_ok, "queries": m},
