@@ -70,7 +70,7 @@ size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups) {
   if (type == PR_TYPE_SC) {
     if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SC_QIMG; }
     *groups = pr::sc_dgroups(max_sigs);
-    return (size_t)2 * *groups * pr::SC_DIMG + 8 * pr::SC_DSTEP;   // + prefetch tail of 4 slots (sc_match.hip)
+    return (size_t)2 * *groups * pr::SC_DIMG + 16 * pr::SC_DSTEP;  // + zero tail of 8 slots read past the last group (sc_match.hip)
   }
   if (role == PR_ROLE_QUERY) { *groups = ((pr::m2_tiles(max_sigs) + 3) / 4) * 4; return (size_t)2 * *groups * pr::M2_TILE; }
   *groups = pr::m2_tiles(max_sigs);

@@ -56,26 +56,41 @@ __device__ __forceinline__ float ror8(float x) {  // DPP row_ror:8 inside each 1
 
 // Slot kinds: slot 0 = (0,30): both spectra are real (no Im loads, no T2 chain, no O accumulation);
 // slot 15 = (29,-): single frequency; every other slot is a full pair.
+template <int SLOT, int H>
+__device__ __forceinline__ void load_freq_lds(SlotOps& o, const float* __restrict__ la) {
+  if (SLOT == SC_NSLOT - 1 && H == 1) return;
+  const float* a = la + (2 * SLOT + H) * 320;
+#pragma unroll
+  for (int s = 0; s < 5; s++) o.f[H].a[s] = a[s * 64];
+}
+template <int SLOT, int H>
+__device__ __forceinline__ void load_freq_db(SlotOps& o, const float* __restrict__ db, int lane) {
+  if (SLOT == SC_NSLOT - 1 && H == 1) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(db + H * SC_DSTEP);
+  o.f[H].bre = p[lane];
+  if (SLOT != 0) {
+    o.f[H].bim = p[64 + lane];
+    o.f[H].b4 = reinterpret_cast<const float2*>(db + H * SC_DSTEP + 512)[lane];
+  } else {
+    o.f[H].b4.x = db[H * SC_DSTEP + 512 + 2 * lane];
+  }
+}
+template <int SLOT, int H>
+__device__ __forceinline__ void load_freq(SlotOps& o, const float* __restrict__ la, const float* __restrict__ db, int lane) {
+  load_freq_lds<SLOT, H>(o, la);
+  load_freq_db<SLOT, H>(o, db, lane);
+}
+template <int SLOT>
+__device__ __forceinline__ void load_consts(SlotOps& o, const float* __restrict__ cst, int lane) {
+  o.ce = cst[SLOT * 128 + lane];
+  if (SLOT != 0) o.co = cst[SLOT * 128 + 64 + lane];
+}
 template <int SLOT>
 __device__ __forceinline__ void load_slot(SlotOps& o, const float* __restrict__ la, const float* __restrict__ db,
                                           const float* __restrict__ cst, int lane) {
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    if (SLOT == SC_NSLOT - 1 && h == 1) break;
-    const float* a = la + (2 * SLOT + h) * 320;
-#pragma unroll
-    for (int s = 0; s < 5; s++) o.f[h].a[s] = a[s * 64];
-    const f32x4* p = reinterpret_cast<const f32x4*>(db + h * SC_DSTEP);
-    o.f[h].bre = p[lane];
-    if (SLOT != 0) {
-      o.f[h].bim = p[64 + lane];
-      o.f[h].b4 = reinterpret_cast<const float2*>(db + h * SC_DSTEP + 512)[lane];
-    } else {
-      o.f[h].b4.x = db[h * SC_DSTEP + 512 + 2 * lane];
-    }
-  }
-  o.ce = cst[SLOT * 128 + lane];
-  if (SLOT != 0) o.co = cst[SLOT * 128 + 64 + lane];
+  load_freq<SLOT, 0>(o, la, db, lane);
+  load_freq<SLOT, 1>(o, la, db, lane);
+  load_consts<SLOT>(o, cst, lane);
 }
 
 // Stage 1 of one frequency in VGPR form.  The 256 accumulators of stage 2 fill the whole AccVGPR half of the register
@@ -84,9 +99,12 @@ __device__ __forceinline__ void load_slot(SlotOps& o, const float* __restrict__ 
 // s_nop 1 covers the VALU-written A operands (the DPP products), the trailing s_nop 10 covers the 8-pass MFMA D -> VALU
 // read of the add/sub/swap that consumes t1/t2 (placed after a block of stage-2 MFMAs, but never rely on that);
 // back-to-back SrcC == vDst chains need none.
-__device__ __forceinline__ void stage1_full(const FreqOps& o, float sgn, f32x4& t1, f32x4& t2) {
-  const float r0 = ror8(o.a[0]) * sgn, r1 = ror8(o.a[1]) * sgn, r2 = ror8(o.a[2]) * sgn, r3 = ror8(o.a[3]) * sgn,
-              r4 = ror8(o.a[4]) * sgn;
+struct Rot { float r[5]; };
+__device__ __forceinline__ void make_rot(const FreqOps& o, float sgn, Rot& q) {   // [Qim; -Qre] row operand of T2
+#pragma unroll
+  for (int k = 0; k < 5; k++) q.r[k] = ror8(o.a[k]) * sgn;
+}
+__device__ __forceinline__ void stage1_full(const FreqOps& o, const Rot& q, f32x4& t1, f32x4& t2) {
   asm volatile(
       "s_nop 1\n\t"
       "v_mfma_f32_16x16x4_f32 %0, %2, %12, 0\n\t"
@@ -102,7 +120,7 @@ __device__ __forceinline__ void stage1_full(const FreqOps& o, float sgn, f32x4& 
       "s_nop 10"
       : "=&v"(t1), "=&v"(t2)
       : "v"(o.a[0]), "v"(o.a[1]), "v"(o.a[2]), "v"(o.a[3]), "v"(o.a[4]),          // %2..%6   query rows
-        "v"(r0), "v"(r1), "v"(r2), "v"(r3), "v"(r4),                              // %7..%11  rotated, sign-flipped rows
+        "v"(q.r[0]), "v"(q.r[1]), "v"(q.r[2]), "v"(q.r[3]), "v"(q.r[4]),          // %7..%11  rotated, sign-flipped rows
         "v"(o.bre[0]), "v"(o.bre[1]), "v"(o.bre[2]), "v"(o.bre[3]), "v"(o.b4.x),  // %12..%16 DB Re
         "v"(o.bim[0]), "v"(o.bim[1]), "v"(o.bim[2]), "v"(o.bim[3]), "v"(o.b4.y)); // %17..%21 DB Im
 }
@@ -134,71 +152,186 @@ __device__ __forceinline__ void swap_halves(const f32x4& xa, const f32x4& xb, f3
 
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
-// stage-2 MFMAs of slot S for stage-1 register r (4 per r; 2 for the real slot 0)
+
+// ONE stage-2 MFMA of slot S: accumulator (r, v = forward|mirror, part = E|O)
+template <int S, int V, int PART>
+__device__ __forceinline__ void stage2_one(int r, const Tiles& t, float ce, float co, f32x16 (&accE)[4][2],
+                                           f32x16 (&accO)[4][2], const f32x16& zero) {
+  if (S == 0) {                    // real pair: forward and mirror get the same E contribution, O stays empty
+    if (PART == 0) accE[r][V] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.fre[r], zero, 0, 0, 0);
+    return;
+  }
+  // slot 15 (single frequency): unswapped (Re|Im) tiles against (cos|0) and (0|-sin); slot 1 starts O from zero
+  const f32x4& re = V ? t.mre : t.fre;
+  const f32x4& im = (S == SC_NSLOT - 1) ? (V ? t.mre : t.fre) : (V ? t.mim : t.fim);
+  if (PART == 0) accE[r][V] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, re[r], accE[r][V], 0, 0, 0);
+  else accO[r][V] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, im[r], (S == 1) ? zero : accO[r][V], 0, 0, 0);
+}
 template <int S>
 __device__ __forceinline__ void stage2_r(int r, const Tiles& t, float ce, float co, f32x16 (&accE)[4][2],
                                          f32x16 (&accO)[4][2], const f32x16& zero) {
-  if (S == 0) {                    // real pair: forward and mirror get the same E contribution, O stays empty
-    accE[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.fre[r], zero, 0, 0, 0);
-    accE[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.fre[r], zero, 0, 0, 0);
-  } else if (S == 1) {             // first slot with an odd part: O starts from the zero C operand
-    accE[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.fre[r], accE[r][0], 0, 0, 0);
-    accO[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.fim[r], zero, 0, 0, 0);
-    accE[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.mre[r], accE[r][1], 0, 0, 0);
-    accO[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.mim[r], zero, 0, 0, 0);
-  } else if (S == SC_NSLOT - 1) {  // single frequency: unswapped (Re|Im) tiles against (cos|0) and (0|-sin)
-    accE[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.fre[r], accE[r][0], 0, 0, 0);
-    accO[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.fre[r], accO[r][0], 0, 0, 0);
-    accE[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.mre[r], accE[r][1], 0, 0, 0);
-    accO[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.mre[r], accO[r][1], 0, 0, 0);
-  } else {
-    accE[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.fre[r], accE[r][0], 0, 0, 0);
-    accO[r][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.fim[r], accO[r][0], 0, 0, 0);
-    accE[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(ce, t.mre[r], accE[r][1], 0, 0, 0);
-    accO[r][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(co, t.mim[r], accO[r][1], 0, 0, 0);
+  stage2_one<S, 0, 0>(r, t, ce, co, accE, accO, zero);
+  stage2_one<S, 0, 1>(r, t, ce, co, accE, accO, zero);
+  stage2_one<S, 1, 0>(r, t, ce, co, accE, accO, zero);
+  stage2_one<S, 1, 1>(r, t, ce, co, accE, accO, zero);
+}
+
+// One pipeline step: stage 2 of slot S (tiles tc), stage 1 + swap of slot S+1 (operands X -> tiles for the next
+// step), request of the operands of slot S+3 (into Z).  The wave issues in order, and an MFMA only blocks issue
+// until the matrix pipe accepts it, so the pipe stays busy as long as no more than a handful of other instructions
+// sit between two MFMAs.  The schedule is therefore written out by hand and pinned with sched_barrier: every chunk
+// of loads / VALU (<= 8 instructions) is followed by an MFMA that was independent of it.
+template <int S>
+__device__ __forceinline__ void slot_step(SlotOps& X, const SlotOps& Y, SlotOps& Z, Tiles& tc, float& ce, float& co,
+                                          f32x16 (&accE)[4][2], f32x16 (&accO)[4][2], const f32x16& zero,
+                                          const float* __restrict__ la, const float*& dbn,
+                                          const float* __restrict__ cst, int lane, float sgn, Rot& rotA) {
+  constexpr int N1 = (S + 1) & (SC_NSLOT - 1);   // slot whose stage 1 runs in this step
+  constexpr int N2 = (S + 2) & (SC_NSLOT - 1);
+  constexpr int N3 = (S + 3) & (SC_NSLOT - 1);   // slot whose operands are requested in this step
+  constexpr bool REAL = (N1 == 0), SINGLE = (N1 == SC_NSLOT - 1);
+  Tiles tn;
+  f32x4 t1a, t2a, t1b, t2b, Fa, Ma, Fb, Mb;
+  Rot rotB;
+  SB();
+  if (REAL) stage1_real(X.f[0], t1a); else stage1_full(X.f[0], rotA, t1a, t2a);      // 10 MFMAs (VGPR form)
+  SB();
+  // r = 0: four MFMAs, the VALU consumers of stage 1 (first frequency) in their shadow
+  stage2_one<S, 0, 0>(0, tc, ce, co, accE, accO, zero);
+  SB();
+  if (REAL) Fa = t1a; else Fa = t1a + t2a;
+  SB();
+  stage2_one<S, 0, 1>(0, tc, ce, co, accE, accO, zero);
+  SB();
+  if (!REAL) Ma = t1a - t2a;
+  SB();
+  stage2_one<S, 1, 0>(0, tc, ce, co, accE, accO, zero);
+  SB();
+  if (!REAL && !SINGLE) make_rot(X.f[1], sgn, rotB);
+  SB();
+  stage2_one<S, 1, 1>(0, tc, ce, co, accE, accO, zero);
+  SB();
+  if (!SINGLE) { if (REAL) stage1_real(X.f[1], t1b); else stage1_full(X.f[1], rotB, t1b, t2b); }
+  SB();
+  // r = 1: add/sub and permlane swaps of the second frequency
+  stage2_one<S, 0, 0>(1, tc, ce, co, accE, accO, zero);
+  SB();
+  if (REAL) Fb = t1b; else if (!SINGLE) Fb = t1b + t2b;
+  SB();
+  stage2_one<S, 0, 1>(1, tc, ce, co, accE, accO, zero);
+  SB();
+  if (!REAL && !SINGLE) Mb = t1b - t2b;
+  SB();
+  stage2_one<S, 1, 0>(1, tc, ce, co, accE, accO, zero);
+  SB();
+  if (SINGLE) tn.fre = Fa; else swap_halves(Fa, Fb, tn.fre, tn.fim);   // real pair: (Re_0 | Re_30), Im tile unused
+  SB();
+  stage2_one<S, 1, 1>(1, tc, ce, co, accE, accO, zero);
+  SB();
+  if (SINGLE) tn.mre = Ma; else if (!REAL) swap_halves(Ma, Mb, tn.mre, tn.mim);
+  SB();
+  // r = 2, 3: eight MFMAs; the operand requests of slot S+3 (<= 5 memory instructions per gap) and the row
+  // operand of the next step's first stage 1 go in between
+  stage2_one<S, 0, 0>(2, tc, ce, co, accE, accO, zero);
+  SB();
+  load_freq_db<N3, 0>(Z, dbn, lane);
+  SB();
+  stage2_one<S, 0, 1>(2, tc, ce, co, accE, accO, zero);
+  SB();
+  load_freq_lds<N3, 0>(Z, la);
+  SB();
+  stage2_one<S, 1, 0>(2, tc, ce, co, accE, accO, zero);
+  SB();
+  load_freq_db<N3, 1>(Z, dbn, lane);
+  SB();
+  stage2_one<S, 1, 1>(2, tc, ce, co, accE, accO, zero);
+  SB();
+  load_freq_lds<N3, 1>(Z, la);
+  SB();
+  stage2_one<S, 0, 0>(3, tc, ce, co, accE, accO, zero);
+  SB();
+  load_consts<N3>(Z, cst, lane);
+  dbn += SS;
+  SB();
+  stage2_one<S, 0, 1>(3, tc, ce, co, accE, accO, zero);
+  SB();
+  if (N2 != 0) make_rot(Y.f[0], sgn, rotA);   // row operand of the NEXT step's first stage 1 (Y = operands of slot S+2)
+  SB();
+  stage2_one<S, 1, 0>(3, tc, ce, co, accE, accO, zero);
+  stage2_one<S, 1, 1>(3, tc, ce, co, accE, accO, zero);
+  SB();
+  tc = tn;
+  ce = X.ce;
+  co = X.co;
+}
+
+// Epilogue of one stage-1 register r of a finished DB group: max over the 120 variants = max_k E + |O| over forward
+// and mirror, then d = (1 - max)/2 for 2 queries x 16 entries (lanes 0..31).
+__device__ __forceinline__ void epilogue_r(int r, const f32x16 (&accE)[4][2], const f32x16 (&accO)[4][2],
+                                           float* __restrict__ dist, int qrow0, int drow0, int m, int n, int lane) {
+  f32x16 v = __builtin_elementwise_max(accE[r][0] + __builtin_elementwise_abs(accO[r][0]),
+                                       accE[r][1] + __builtin_elementwise_abs(accO[r][1]));
+  float mx = v[0];
+#pragma unroll
+  for (int e = 1; e < 16; e++) mx = fmaxf(mx, v[e]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  if (lane < 32) {
+    const int qrow = qrow0 + ((lane < 16) ? r : 4 + r);
+    const int drow = drow0 + (lane & 15);
+    if (qrow < m && drow < n) {
+      // The store is issued through inline asm on purpose.  On gfx9-class targets loads and stores share vmcnt but
+      // may retire out of order with respect to each other, so once hipcc sees a store in flight it turns every
+      // later operand wait into s_waitcnt vmcnt(0) and may drain the 3-slot prefetch pipeline.  Hidden from the waitcnt pass, the counted waits stay: they remain sufficient because
+      // loads still return in order among themselves (at worst a wait also covers a few of these stores).  The data
+      // is a single dword, so no store-data hazard; the stores complete before the wave ends.
+      float* ptr = dist + ((size_t)qrow * n + drow);
+      const float val = 0.5f - 0.5f * mx;                                          // processSC.m:30
+      asm volatile("global_store_dword %0, %1, off" : : "v"(ptr), "v"(val) : "memory");
+    }
   }
 }
 
-// One pipeline step: stage 2 of slot S (tiles tc), stage 1 + swap of slot S+1 (operands X -> tiles tc for the next
-// step), request of the operands of slot S+3 (into Z).  The schedule is pinned with sched_barrier so that the
-// VALU work that consumes stage-1 results (add/sub, permlane swaps) always issues behind a block of independent
-// stage-2 MFMAs: the matrix pipe never waits for it.
-template <int S>
-__device__ __forceinline__ void slot_step(SlotOps& X, SlotOps& Z, Tiles& tc, float& ce, float& co,
-                                          f32x16 (&accE)[4][2], f32x16 (&accO)[4][2], const f32x16& zero,
-                                          const float* __restrict__ la, const float*& dbn,
-                                          const float* __restrict__ cst, int lane, float sgn) {
-  constexpr int N1 = (S + 1) & (SC_NSLOT - 1);   // slot whose stage 1 runs in this step
-  constexpr int N3 = (S + 3) & (SC_NSLOT - 1);   // slot whose operands are requested in this step
-  load_slot<N3>(Z, la, dbn, cst, lane);
+// Group boundary: the epilogue of the finished group (VALU: 256 accumulator reads + ~260 ops, no matrix work of its
+// own) is interleaved with pipeline step 0 of the NEXT group, whose MFMAs do not depend on it: stage 1 of slot 1 runs
+// beside epilogue_r(0), and the stage-2 MFMAs of slot 0 that restart accE[r] from zero are issued right after
+// epilogue_r(r) has read it.  After the last group the same step runs once on the zero-padded tail of the DB stream.
+__device__ __forceinline__ void boundary_step(SlotOps& X, const SlotOps& Y, SlotOps& Z, Tiles& tc, float& ce, float& co,
+                                              f32x16 (&accE)[4][2], f32x16 (&accO)[4][2], const f32x16& zero,
+                                              const float* __restrict__ la, const float*& dbn,
+                                              const float* __restrict__ cst, int lane, float sgn,
+                                              float* __restrict__ dist, int qrow0, int drow0, int m, int n,
+                                              Rot& rotA) {
+  SB();
+  load_slot<3>(Z, la, dbn, cst, lane);
   dbn += SS;
   Tiles tn;
   f32x4 t1a, t2a, t1b, t2b;
-  if (N1 == 0) stage1_real(X.f[0], t1a); else stage1_full(X.f[0], sgn, t1a, t2a);
+  stage1_full(X.f[0], rotA, t1a, t2a);
   SB();
-  stage2_r<S>(0, tc, ce, co, accE, accO, zero);
+  epilogue_r(0, accE, accO, dist, qrow0, drow0, m, n, lane);
   SB();
-  f32x4 Fa, Ma, Fb, Mb;
-  if (N1 == 0) { Fa = t1a; } else { Fa = t1a + t2a; Ma = t1a - t2a; }
-  if (N1 != SC_NSLOT - 1) {
-    if (N1 == 0) stage1_real(X.f[1], t1b); else stage1_full(X.f[1], sgn, t1b, t2b);
-  }
+  stage2_r<0>(0, tc, ce, co, accE, accO, zero);
+  const f32x4 Fa = t1a + t2a, Ma = t1a - t2a;
+  Rot rotB;
+  make_rot(X.f[1], sgn, rotB);
+  stage1_full(X.f[1], rotB, t1b, t2b);
   SB();
-  stage2_r<S>(1, tc, ce, co, accE, accO, zero);
+  epilogue_r(1, accE, accO, dist, qrow0, drow0, m, n, lane);
   SB();
-  if (N1 == 0) {
-    Fb = t1b;
-    swap_halves(Fa, Fb, tn.fre, tn.fim);          // (Re_0 | Re_30); the Im tile is identically zero and unused
-  } else if (N1 == SC_NSLOT - 1) {
-    tn.fre = Fa; tn.mre = Ma;                     // single frequency: keep (Re | Im) together
-  } else {
-    Fb = t1b + t2b; Mb = t1b - t2b;
-    swap_halves(Fa, Fb, tn.fre, tn.fim);
-    swap_halves(Ma, Mb, tn.mre, tn.mim);
-  }
+  stage2_r<0>(1, tc, ce, co, accE, accO, zero);
+  const f32x4 Fb = t1b + t2b, Mb = t1b - t2b;
+  swap_halves(Fa, Fb, tn.fre, tn.fim);
+  swap_halves(Ma, Mb, tn.mre, tn.mim);
   SB();
-  stage2_r<S>(2, tc, ce, co, accE, accO, zero);
-  stage2_r<S>(3, tc, ce, co, accE, accO, zero);
+  epilogue_r(2, accE, accO, dist, qrow0, drow0, m, n, lane);
+  SB();
+  stage2_r<0>(2, tc, ce, co, accE, accO, zero);
+  SB();
+  epilogue_r(3, accE, accO, dist, qrow0, drow0, m, n, lane);
+  SB();
+  stage2_r<0>(3, tc, ce, co, accE, accO, zero);
+  SB();
+  make_rot(Y.f[0], sgn, rotA);
   SB();
   tc = tn;
   ce = X.ce;
@@ -252,35 +385,26 @@ __global__ __launch_bounds__(256, 1) void sc_match_kernel(const float* __restric
   }
   const float* dbn = db + 3 * SS;                              // next slot to request
 
+  f32x16 accE[4][2], accO[4][2];
+#define STEP(S, X, Y, Z) slot_step<S>(X, Y, Z, tc, ce, co, accE, accO, zero, la, dbn, cst, lane, sgn, rotA)
+  Rot rotA;
+  make_rot(oA.f[0], sgn, rotA);
+  STEP(0, oA, oB, oC);             // first group: nothing to overlap with
   for (int g = g0; g < g1; g++) {
-    f32x16 accE[4][2], accO[4][2];
-#define STEP(S, X, Z) slot_step<S>(X, Z, tc, ce, co, accE, accO, zero, la, dbn, cst, lane, sgn)
-    STEP(0, oA, oC);  STEP(1, oB, oA);  STEP(2, oC, oB);
-    STEP(3, oA, oC);  STEP(4, oB, oA);  STEP(5, oC, oB);
-    STEP(6, oA, oC);  STEP(7, oB, oA);  STEP(8, oC, oB);
-    STEP(9, oA, oC);  STEP(10, oB, oA); STEP(11, oC, oB);
-    STEP(12, oA, oC); STEP(13, oB, oA); STEP(14, oC, oB);
-    STEP(15, oA, oC);
-#undef STEP
-    // ---- end of the DB group: max over the 120 variants = max_k E + |O| over fwd and mir, write 8 x 16 distances
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      f32x16 v = __builtin_elementwise_max(accE[r][0] + __builtin_elementwise_abs(accO[r][0]),
-                                           accE[r][1] + __builtin_elementwise_abs(accO[r][1]));
-      float mx = v[0];
-#pragma unroll
-      for (int e = 1; e < 16; e++) mx = fmaxf(mx, v[e]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      if (lane < 32) {
-        const int qrow = qg32 * 32 + w * 8 + ((lane < 16) ? r : 4 + r);
-        const int drow = g * 16 + (lane & 15);
-        if (qrow < m && drow < n) dist[(size_t)qrow * n + drow] = 0.5f - 0.5f * mx;   // processSC.m:30
-      }
-    }
+                          STEP(1, oB, oC, oA);  STEP(2, oC, oA, oB);
+    STEP(3, oA, oB, oC);  STEP(4, oB, oC, oA);  STEP(5, oC, oA, oB);
+    STEP(6, oA, oB, oC);  STEP(7, oB, oC, oA);  STEP(8, oC, oA, oB);
+    STEP(9, oA, oB, oC);  STEP(10, oB, oC, oA); STEP(11, oC, oA, oB);
+    STEP(12, oA, oB, oC); STEP(13, oB, oC, oA); STEP(14, oC, oA, oB);
+    STEP(15, oA, oB, oC);
     // 16 slots advance the period-3 rotation by one: rename so that the next group starts in the same roles
     oA = oB;   // operands(slot 1 of the next group)
     oB = oC;   // operands(slot 2 of the next group), possibly still in flight
+    // epilogue of group g fused with step 0 of group g+1
+    boundary_step(oA, oB, oC, tc, ce, co, accE, accO, zero, la, dbn, cst, lane, sgn, dist, qg32 * 32 + w * 8, g * 16, m, n,
+                  rotA);
   }
+#undef STEP
 }
 
 }  // namespace
