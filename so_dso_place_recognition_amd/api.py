@@ -182,7 +182,7 @@ def run_test(type_, hist1, hist2, gt1=None, gt2=None, loop_diff=None, mask_width
     if gt1 is None:
         return sc[:, 0], idx[:, 0]
     from . import eval as _eval
-    return _eval.precision_recall(sc[:, 0], idx[:, 0], np.asarray(gt1), np.asarray(gt2), loop_diff, mask_width)
+    return _eval.precision_recall(sc[:, 0], idx[:, 0], np.asarray(gt1), np.asarray(gt2), loop_diff, mask_width)[:3]
 
 
 # ------------------------------------------------------------------------------- host-side rows a1 / a2
