@@ -122,11 +122,15 @@ def sharded_topk(local_moments, local_select, k: int, group, G: int):
     mom = local_moments()
     if G == 1:
         return local_select(mom, 1)
+    stage_on_host = dist.get_backend(group) == "gloo"   # gloo has no device all_gather: used by the single-GPU tests
+
     def gather(t):   # list form: identical semantics on nccl (RCCL) and gloo
-        t = t.contiguous()
-        outs = [torch.empty_like(t) for _ in range(G)]
-        dist.all_gather(outs, t, group=group)
-        return torch.stack(outs)
+        src = t.contiguous()
+        if stage_on_host and src.is_cuda:
+            src = src.cpu()
+        outs = [torch.empty_like(src) for _ in range(G)]
+        dist.all_gather(outs, src, group=group)
+        return torch.stack(outs).to(t.device)
 
     mom_all = gather(mom)
     idx, score = local_select(mom_all, G)
