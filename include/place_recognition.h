@@ -117,6 +117,10 @@ void pr_clouds_free(pr_clouds* c);
 int pr_write_signatures(const char* path, const double* sig, int64_t rows, int64_t cols);
 int pr_read_signatures(const char* path, double** out, int64_t* rows, int64_t* cols);
 void pr_free(void* p);
+/* Binary side-car of the same matrices (no reference counterpart): 32-byte header + row-major data,
+ * dtype PR_F64 or PR_F32 on disk; the reader always returns f64.  The executables pick it by the ".bin" suffix. */
+int pr_write_signatures_bin(const char* path, const double* sig, int64_t rows, int64_t cols, int dtype);
+int pr_read_signatures_bin(const char* path, double** out, int64_t* rows, int64_t* cols);
 /* PosesPts.h:12-24 / :36-39 record writers (the producer side, OutputWrapperSODSO.cpp:24-31). */
 int pr_write_poses(const char* path, const int32_t* ids, const double* w2c, int64_t n);
 int pr_write_points(const char* path, const int32_t* ids, const double* xyz, const float* inten, int64_t n);

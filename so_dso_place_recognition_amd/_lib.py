@@ -50,6 +50,8 @@ SYMBOLS = {
     "pr_write_signatures": (C.c_int, [C.c_char_p, _vp, C.c_int64, C.c_int64]),
     "pr_read_signatures": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pr_free": (None, [_vp]),
+    "pr_write_signatures_bin": (C.c_int, [C.c_char_p, _vp, C.c_int64, C.c_int64, C.c_int]),
+    "pr_read_signatures_bin": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pr_write_poses": (C.c_int, [C.c_char_p, _vp, _vp, C.c_int64]),
     "pr_write_points": (C.c_int, [C.c_char_p, _vp, _vp, _vp, C.c_int64]),
     "pr_host_last_error": (C.c_char_p, []),

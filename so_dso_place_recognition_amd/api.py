@@ -208,11 +208,15 @@ def pts_preprocess(poses_file: str, pts_file: str, incoming_id_file: str | None,
     return xyz, it, offs, ids
 
 
-def write_signatures(path: str, sig) -> None:
-    """`ofstream << Eigen::MatrixXd` text (test_sc.cpp:63-66)."""
+def write_signatures(path: str, sig, dtype=np.float64) -> None:
+    """`ofstream << Eigen::MatrixXd` text (test_sc.cpp:63-66); a path ending in .bin writes the binary side-car."""
     sig = np.ascontiguousarray(sig, np.float64)
     lib = _lib.load()
-    rc = lib.pr_write_signatures(path.encode(), _ptr(sig), sig.shape[0], sig.shape[1])
+    if path.endswith(".bin"):
+        rc = lib.pr_write_signatures_bin(path.encode(), _ptr(sig), sig.shape[0], sig.shape[1],
+                                         _lib.F32 if dtype == np.float32 else _lib.F64)
+    else:
+        rc = lib.pr_write_signatures(path.encode(), _ptr(sig), sig.shape[0], sig.shape[1])
     if rc != 0:
         raise PRError(rc, lib.pr_host_last_error().decode())
 
@@ -220,7 +224,8 @@ def write_signatures(path: str, sig) -> None:
 def read_signatures(path: str) -> np.ndarray:
     lib = _lib.load()
     p = C.c_void_p(); r = C.c_int64(); c = C.c_int64()
-    rc = lib.pr_read_signatures(path.encode(), C.byref(p), C.byref(r), C.byref(c))
+    fn = lib.pr_read_signatures_bin if path.endswith(".bin") else lib.pr_read_signatures
+    rc = fn(path.encode(), C.byref(p), C.byref(r), C.byref(c))
     if rc != 0:
         raise PRError(rc, lib.pr_host_last_error().decode())
     try:

@@ -35,7 +35,9 @@ inline int generate_main(int argc, char** argv, bool m2dp) {
   if (rc != PR_OK) { fprintf(stderr, "generate failed: %s\n", pr_last_error(ctx)); pr_destroy(ctx); pr_clouds_free(clouds); return 4; }
   printProgress(N ? 1.0 : 0.0);
   printf("\n%s average time: %gms\n", m2dp ? "M2DP" : "SC", N ? 1000.0 * secs / N : 0.0);   // test_sc.cpp:58-61
-  rc = pr_write_signatures(outf.c_str(), sig.data(), (int64_t)rows, (int64_t)cols);         // :63-66
+  const bool bin = outf.size() > 4 && outf.compare(outf.size() - 4, 4, ".bin") == 0;
+  rc = bin ? pr_write_signatures_bin(outf.c_str(), sig.data(), (int64_t)rows, (int64_t)cols, PR_F64)
+           : pr_write_signatures(outf.c_str(), sig.data(), (int64_t)rows, (int64_t)cols);   // :63-66
   if (rc != PR_OK) fprintf(stderr, "%s\n", pr_host_last_error());
   pr_destroy(ctx);
   pr_clouds_free(clouds);

@@ -21,7 +21,11 @@ int main(int argc, char** argv) {
   const int64_t width = t == PR_TYPE_SC ? PR_SC_SIG_LEN : PR_M2DP_SIG_LEN;
   double *h1 = nullptr, *h2 = nullptr;
   int64_t r1, c1, r2, c2;
-  if (pr_read_signatures(h1f.c_str(), &h1, &r1, &c1) != PR_OK || pr_read_signatures(h2f.c_str(), &h2, &r2, &c2) != PR_OK) {
+  auto rd = [](const std::string& f, double** o, int64_t* r, int64_t* c) {
+    const bool bin = f.size() > 4 && f.compare(f.size() - 4, 4, ".bin") == 0;
+    return bin ? pr_read_signatures_bin(f.c_str(), o, r, c) : pr_read_signatures(f.c_str(), o, r, c);
+  };
+  if (rd(h1f, &h1, &r1, &c1) != PR_OK || rd(h2f, &h2, &r2, &c2) != PR_OK) {
     fprintf(stderr, "%s\n", pr_host_last_error());
     return 2;
   }

@@ -108,6 +108,21 @@ def test_match_full_size_properties(api):
     assert np.array_equal(oidx[:, 0], idx[:2, 0]) and np.abs(osc[:, 0] - sc[:2, 0]).max() < 5e-4
 
 
+def test_match_at_baseline_size(api):
+    """BASELINE.json's metric size (100k-signature DB): planted top-1 recall must be 100 %, and one full row is
+    checked against the oracle (index bit-exact, every distance of the row within 1e-5)."""
+    n, m = 100_000, 96
+    db = synth.sc_database(45, n)
+    q, et = synth.sc_queries(46, db, m)
+    idx, sc = api.match_topk("sc", q, db)
+    assert np.array_equal(idx[:, 0], et)
+    rc, oidx, osc = oracle_lib.match_topk(0, q[:1], db, 0)
+    assert oidx[0, 0] == idx[0, 0] and abs(osc[0, 0] - sc[0, 0]) < 5e-4
+    gp, gi = api.processSC(q[:1], db)
+    rc, op, oi = oracle_lib.sc_distance(q[:1], db)
+    assert np.abs(gp - op).max() < 1e-5 and np.abs(gi - oi).max() < 1e-5
+
+
 # ------------------------------------------------------------------------------------------------ a3 + a4
 @pytest.mark.parametrize("P", [1500, 20011])
 def test_sc_generate_vs_oracle(api, P):

@@ -76,3 +76,17 @@ def test_posespts_record_format(tmp_path):
     q = str(tmp_path / "pts.txt")
     api.write_points(q, ids, np.array([[1.5, -2.25, 1e-9], [1 / 3, 2 / 3, 100.0]]), np.array([127.36, 0.5], np.float32))
     assert open(q).read().split("\n")[0] == "3 1.5 -2.25 1e-09 127.36"
+
+
+def test_binary_sidecar_roundtrip(tmp_path):
+    rng = np.random.default_rng(5)
+    m = rng.normal(size=(7, 2400))
+    p = str(tmp_path / "sig.bin")
+    api.write_signatures(p, m)
+    assert np.array_equal(api.read_signatures(p), m)                   # f64 on disk: bit exact
+    assert os.path.getsize(p) == 32 + m.size * 8
+    api.write_signatures(p, m, dtype=np.float32)
+    assert np.array_equal(api.read_signatures(p), m.astype(np.float32).astype(np.float64))
+    (tmp_path / "bad.bin").write_bytes(b"nope")
+    with pytest.raises(api.PRError):
+        api.read_signatures(str(tmp_path / "bad.bin"))
