@@ -22,13 +22,14 @@ typedef struct pr_sigset pr_sigset;
 typedef struct pr_clouds pr_clouds;
 
 enum { PR_OK = 0, PR_EINVAL = -1, PR_ENOMEM = -2, PR_EHIP = -3, PR_EIO = -4, PR_ENAN = -5 };
-enum { PR_TYPE_SC = 0, PR_TYPE_M2DP = 1 };          /* run_test.m:27-30 `type` */
+enum { PR_TYPE_SC = 0, PR_TYPE_M2DP = 1, PR_TYPE_DELIGHT = 2 };   /* run_test.m:26-36 `type` */
 enum { PR_ROLE_QUERY = 0, PR_ROLE_DB = 1 };         /* hist1 / hist2 of run_test.m:1 */
 enum { PR_F64 = 0, PR_F32 = 1 };
 enum { PR_HOST = 0, PR_DEVICE = 1 };
 
 #define PR_SC_SIG_LEN 2400    /* 2 x numS*numR = 2 x 60*20, SC/SC.h:7-8, test_sc.cpp:37-38 */
 #define PR_M2DP_SIG_LEN 384   /* 2 x (numP*numQ + numS*numR) = 2 x 192, M2DP/M2DP.h:7-10, test_m2dp.cpp:37-39 */
+#define PR_DELIGHT_SIG_LEN 256 /* BINS, DELIGHT/DELIGHT.h:9; 16 rows (histograms) per signature, test_delight.cpp:36-37 */
 
 /* ---- context ------------------------------------------------------------------------------------ */
 int pr_create(int device_id, pr_ctx** out);
@@ -51,6 +52,14 @@ int pr_sc_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int
 int pr_m2dp_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
                      double max_rho, double* out);
 
+/* Replaces DELIGHT::getSignature looped as in DELIGHT/test_delight.cpp:41-56 (DELIGHT/DELIGHT.h:11-18, DELIGHT.cpp:8-24;
+ * PCA alignment inside).  out[16N][256]: 16 intensity histograms per cloud. */
+int pr_delight_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double* out);
+
+/* Replaces processDELIGHT(hist1, hist2) (match_signatures/processDELIGHT.m:1-38).  h1[16m][256], h2[16n][256];
+ * dist: host f32 [m][n] (chi-square, min over the 4 octant permutations; +Inf when no bin is occupied). */
+int pr_delight_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, float* dist);
+
 /* Replaces processSC(hist1, hist2) (match_signatures/processSC.m:1-45).  h1[m][2400], h2[n][2400] host f64;
  * d_struct / d_int: host f32 [m][n], either may be NULL.  PR_ENAN if a row has zero norm (MATLAB: NaN row). */
 int pr_sc_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n,
@@ -62,7 +71,8 @@ int pr_m2dp_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2,
 
 /* Replaces run_test.m:26-57 (distance matrices, 2:1 z-score fusion :38-41, mask :47-53, row min :57),
  * generalised to top-k; k = 1 is the reference.  Ties -> lower index (MATLAB min).  idx[m][k] (0-based,
- * -1 when fewer than k candidates), score[m][k] fused z-score. */
+ * -1 when fewer than k candidates), score[m][k] fused z-score.  type = PR_TYPE_DELIGHT: no fusion (run_test.m:26-36),
+ * score = the chi-square distance, h1[16m][256], h2[16n][256], p_weight ignored. */
 int pr_match_topk(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n,
                   int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score);
 
@@ -76,7 +86,8 @@ void pr_sigset_destroy(pr_ctx* ctx, pr_sigset* s);
 int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int where, int32_t n_sigs);
 int32_t pr_sigset_count(const pr_sigset* s);
 
-/* processSC.m:22-33 / processM2DP.m:15-21 on packed sets.  d_p, d_i: DEVICE f32 [m][n] (row stride n). */
+/* processSC.m:22-33 / processM2DP.m:15-21 / processDELIGHT.m:7-37 on packed sets.  d_p, d_i: DEVICE f32 [m][n]
+ * (row stride n); DELIGHT writes d_p only (d_i may be NULL). */
 int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float* d_p, float* d_i);
 
 /* Per-row two-pass moments of a distance shard (first half of MATLAB normalize(.,2), run_test.m:40):
@@ -86,7 +97,7 @@ int pr_row_moments_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
 /* run_test.m:38-41 + :47-53 + :57 on a DB shard.  mom_all: DEVICE f64 [G][m][2][3] moments of ALL G shards
  * (combined in rank order, N-1 std); the shard's DB rows are global rows db_row0..db_row0+n-1 and its query
  * rows global q_row0..; mask is |i-j| < mask_width on GLOBAL indices.  idx: DEVICE i32 [m][k] GLOBAL DB
- * indices (-1 = none), score: DEVICE f32 [m][k]. */
+ * indices (-1 = none), score: DEVICE f32 [m][k].  d_i == NULL: plain selection on d_p without fusion (mom_all unused). */
 int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n,
                        const double* mom_all, int32_t G, int32_t q_row0, int32_t db_row0, int32_t mask_width,
                        double p_weight, int32_t k, int32_t* idx, float* score);
@@ -96,6 +107,7 @@ int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const
                        double max_rho, double* out);
 int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
                          double max_rho, double* out);
+int pr_delight_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double* out);
 
 /* ---- host-side rows a1/a2 (CPU in the reference too; no device, no context) ---------------------------- */
 

@@ -408,6 +408,49 @@ void fuse_topk(const double* dp, const double* di, int m, int n, int mask_width,
   }
 }
 
+// DELIGHT/DELIGHT.cpp:8-24 on one cloud (alignment inside, :12-13): 16 x 256 intensity histograms
+void delight_signature(const double* xyz, const float* inten, int64_t P, double* out /*16*256*/) {
+  std::fill(out, out + 16 * 256, 0.0);
+  if (P <= 0) return;
+  std::vector<double> al(3 * (size_t)P);
+  align_pca(xyz, P, al.data(), nullptr);
+  for (int64_t i = 0; i < P; i++) {
+    const double* p = &al[3 * i];
+    float x = p[0], y = p[1], z = p[2];                                           // :17-19 (double -> float)
+    float d = std::sqrt(p[0] * p[0] + p[1] * p[1] + p[2] * p[2]);                // :20 norm() then float
+    float clr = inten[i];
+    int hist = 8 * (d > 10.0) + 4 * (z > 0) + 2 * (y > 0) + 1 * (x > 0);          // :23, RADIUS 10.0
+    int bin = int(clr);                                                           // :24 truncation
+    if (bin < 0 || bin >= 256) continue;   // out of range is undefined behaviour in the reference; dropped here
+    out[hist * 256 + bin]++;
+  }
+}
+
+// processDELIGHT.m:1-38: chi-square over non-empty bins, min over the 4 octant permutations
+const int DELIGHT_MUT[4][16] = {{0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15},
+                                {5, 4, 7, 6, 1, 0, 3, 2, 13, 12, 15, 14, 9, 8, 11, 10},
+                                {6, 7, 4, 5, 2, 3, 0, 1, 14, 15, 12, 13, 10, 11, 8, 9},
+                                {3, 2, 1, 0, 7, 6, 5, 4, 11, 10, 9, 8, 15, 14, 13, 12}};
+void delight_process(const double* h1, int m, const double* h2, int n, double* res) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < m; i++)
+    for (int j = 0; j < n; j++) {
+      const double* A = h1 + (size_t)i * 4096; const double* B = h2 + (size_t)j * 4096;
+      double best = std::numeric_limits<double>::infinity();
+      for (int k = 0; k < 4; k++) {
+        double ts = 0; double tc = 0;
+        for (int c = 0; c < 256; c++)          // Ak = A(:) is column-major: the order of the terms of the sum
+          for (int r = 0; r < 16; r++) {
+            double a = A[r * 256 + c], b = B[DELIGHT_MUT[k][r] * 256 + c], sum = a + b;
+            if (sum > 0) { ts += 2 * (a - b) * (a - b) / sum; tc += 1; }
+          }
+        ts = ts / tc;
+        if (best > ts) best = ts;                                                 // :31-33 (NaN never wins)
+      }
+      res[(size_t)i * n + j] = best;
+    }
+}
+
 }  // namespace
 
 // =================================================================== C ABI of the oracle
@@ -542,6 +585,42 @@ int pr_ref_m2dp_distance(const double* h1, int32_t m, const double* h2, int32_t 
   return PR_REF_OK;
 }
 
+// DELIGHT/test_delight.cpp:41-56: rows 16c..16c+15 = the 16 histograms of cloud c
+int pr_ref_delight_generate(const double* xyz, const float* inten, const int64_t* offs, int32_t N, double* out) {
+  if (!offs || !out || N < 0) return PR_REF_EINVAL;
+#pragma omp parallel for schedule(dynamic, 1)
+  for (int c = 0; c < N; c++)
+    delight_signature(xyz + 3 * offs[c], inten + offs[c], offs[c + 1] - offs[c], out + (size_t)c * 4096);
+  return PR_REF_OK;
+}
+
+int pr_ref_delight_distance(const double* h1, int32_t m, const double* h2, int32_t n, double* dist) {
+  if (!h1 || !h2 || !dist || m < 0 || n < 0) return PR_REF_EINVAL;
+  delight_process(h1, m, h2, n, dist);
+  return PR_REF_OK;
+}
+
+// run_test.m:47-57 without the z-score fusion (types other than m2dp / sc, run_test.m:26-41)
+int pr_ref_select_topk(const double* d, int32_t m, int32_t n, int32_t mask_width, int32_t k, int32_t* idx, double* score) {
+  if (!d || m < 0 || n < 1 || k < 1) return PR_REF_EINVAL;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < m; i++) {
+    std::vector<double> f(d + (size_t)i * n, d + (size_t)(i + 1) * n);
+    for (int j = 0; j < n; j++) if (std::abs(i - j) < mask_width) f[j] = std::numeric_limits<double>::infinity();
+    std::vector<char> used(n, 0);
+    for (int t = 0; t < k; t++) {
+      int bj = -1; double bv = 0;
+      for (int j = 0; j < n; j++) {
+        if (used[j] || std::isnan(f[j])) continue;
+        if (bj < 0 || f[j] < bv) { bj = j; bv = f[j]; }
+      }
+      if (bj < 0) { idx[(size_t)i * k + t] = -1; score[(size_t)i * k + t] = std::numeric_limits<double>::quiet_NaN(); }
+      else { used[bj] = 1; idx[(size_t)i * k + t] = bj; score[(size_t)i * k + t] = bv; }
+    }
+  }
+  return PR_REF_OK;
+}
+
 int pr_ref_fuse_topk(const double* d_p, const double* d_i, int32_t m, int32_t n, int32_t mask_width, double p_weight,
                      int32_t k, int32_t* idx, double* score) {
   if (!d_p || !d_i || m < 0 || n < 2 || k < 1) return PR_REF_EINVAL;
@@ -552,6 +631,12 @@ int pr_ref_fuse_topk(const double* d_p, const double* d_i, int32_t m, int32_t n,
 // run_test.m:26-57 end to end.  type 0 = SC (m x 2400 / n x 2400), 1 = M2DP (4m x 384 / 4n x 384).
 int pr_ref_match_topk(int type, const double* h1, int32_t m, const double* h2, int32_t n, int32_t mask_width,
                       double p_weight, int32_t k, int32_t* idx, double* score) {
+  if (type == 2) {   // DELIGHT: h1 [16m][256], h2 [16n][256]
+    if (n < 1 || m < 0 || k < 1) return PR_REF_EINVAL;
+    std::vector<double> d((size_t)m * n);
+    delight_process(h1, m, h2, n, d.data());
+    return pr_ref_select_topk(d.data(), m, n, mask_width, k, idx, score);
+  }
   if (n < 2 || m < 0 || k < 1) return PR_REF_EINVAL;
   std::vector<double> dp((size_t)m * n), di((size_t)m * n);
   int rc = type == 0 ? pr_ref_sc_distance(h1, m, h2, n, dp.data(), di.data())

@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import PRError, TYPE_M2DP, TYPE_SC  # noqa: F401
+from ._lib import PRError, TYPE_DELIGHT, TYPE_M2DP, TYPE_SC  # noqa: F401
 
 
 def _ptr(a):
@@ -100,6 +100,32 @@ def m2dp_generate(xyz, inten, offs, max_rho=45.0, ctx: Context | None = None) ->
     return out
 
 
+def delight_generate(xyz, inten, offs, ctx: Context | None = None) -> np.ndarray:
+    """test_delight.cpp:41-56 over clouds in CSR layout -> [16N, 256]."""
+    ctx = ctx or default_context()
+    xyz = np.ascontiguousarray(xyz, np.float64)
+    inten = np.ascontiguousarray(inten, np.float32)
+    offs = np.ascontiguousarray(offs, np.int64)
+    N = len(offs) - 1
+    out = np.empty((16 * N, 256))
+    ctx.check(ctx.lib.pr_delight_generate(ctx.h, _ptr(xyz), _ptr(inten), _ptr(offs), N, _ptr(out)))
+    return out
+
+
+class DELIGHT:
+    """DELIGHT/DELIGHT.h:11-18."""
+
+    def __init__(self, ctx: Context | None = None):
+        self.ctx = ctx
+
+    def getSignatureSize(self) -> int:
+        return 256
+
+    def getSignature(self, pts, intensity):
+        xyz, it, offs = _csr([(pts, intensity)])
+        return delight_generate(xyz, it, offs, self.ctx)
+
+
 class SC:
     """SC/SC.h:10-23."""
 
@@ -156,13 +182,26 @@ def processM2DP(hist1, hist2, ctx: Context | None = None):
     return _distance("pr_m2dp_distance", 4, 384, hist1, hist2, ctx)
 
 
+def processDELIGHT(hist1, hist2, ctx: Context | None = None):
+    """dist = processDELIGHT(hist1, hist2)  (processDELIGHT.m:1); 16 rows per signature; float32 [m, n]."""
+    ctx = ctx or default_context()
+    h1 = np.ascontiguousarray(hist1, np.float64)
+    h2 = np.ascontiguousarray(hist2, np.float64)
+    if h1.ndim != 2 or h2.ndim != 2 or h1.shape[1] != 256 or h2.shape[1] != 256 or h1.shape[0] % 16 or h2.shape[0] % 16:
+        raise ValueError("expected [16*m, 256] and [16*n, 256] histogram matrices")
+    m, n = h1.shape[0] // 16, h2.shape[0] // 16
+    d = np.empty((m, n), np.float32)
+    ctx.check(ctx.lib.pr_delight_distance(ctx.h, _ptr(h1), m, _ptr(h2), n, _ptr(d)))
+    return d
+
+
 def match_topk(type_, hist1, hist2, mask_width=0, p_weight=2.0, k=1, ctx: Context | None = None):
     """run_test.m:26-57 generalised to top-k: returns (idx int32 [m,k] 0-based, score float32 [m,k])."""
     ctx = ctx or default_context()
-    t = {"sc": TYPE_SC, "m2dp": TYPE_M2DP}.get(type_, type_)
-    if t not in (TYPE_SC, TYPE_M2DP):
-        raise ValueError("type must be 'sc' or 'm2dp'")
-    div, width = (1, 2400) if t == TYPE_SC else (4, 384)
+    t = {"sc": TYPE_SC, "m2dp": TYPE_M2DP, "delight": TYPE_DELIGHT}.get(type_, type_)
+    if t not in (TYPE_SC, TYPE_M2DP, TYPE_DELIGHT):
+        raise ValueError("type must be 'sc', 'm2dp' or 'delight'")
+    div, width = {TYPE_SC: (1, 2400), TYPE_M2DP: (4, 384), TYPE_DELIGHT: (16, 256)}[t]
     h1 = np.ascontiguousarray(hist1, np.float64)
     h2 = np.ascontiguousarray(hist2, np.float64)
     if h1.shape[1] != width or h2.shape[1] != width:

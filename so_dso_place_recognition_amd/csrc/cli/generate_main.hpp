@@ -7,9 +7,11 @@
 #include "../../../include/place_recognition.h"
 #include "cli_common.hpp"
 
-inline int generate_main(int argc, char** argv, bool m2dp) {
+// kind: 0 = SC (test_sc.cpp), 1 = M2DP (test_m2dp.cpp), 2 = DELIGHT (DELIGHT/test_delight.cpp:12-68)
+inline int generate_main(int argc, char** argv, int kind) {
   Params prm(argc, argv);
-  const char* out_name = m2dp ? "m2dp_file" : "sc_file";
+  const bool m2dp = kind == 1, delight = kind == 2;
+  const char* out_name = delight ? "delight_file" : (m2dp ? "m2dp_file" : "sc_file");
   std::string poses, pts, outf, idf;
   if (!prm.get("poses_history_file", poses) || !prm.get("pts_history_file", pts) || !prm.get(out_name, outf) ||
       !prm.get("incoming_id_file", idf)) {
@@ -18,23 +20,25 @@ inline int generate_main(int argc, char** argv, bool m2dp) {
   }
   const double lidarRange = prm.num("lidarRange", 45.0);   // :27-28
   pr_clouds* clouds = nullptr;
-  if (pr_pts_preprocess(poses.c_str(), pts.c_str(), idf.c_str(), lidarRange, m2dp ? 1 : 0, 1, &clouds) != PR_OK) {
+  if (pr_pts_preprocess(poses.c_str(), pts.c_str(), idf.c_str(), lidarRange, (m2dp || delight) ? 1 : 0, 1, &clouds) != PR_OK) {
     fprintf(stderr, "pts_preprocess failed: %s\n", pr_host_last_error());
     return 2;
   }
   const int32_t N = (int32_t)pr_clouds_count(clouds);
-  const size_t rows = m2dp ? (size_t)4 * N : (size_t)N, cols = m2dp ? PR_M2DP_SIG_LEN : PR_SC_SIG_LEN;
+  const size_t rows = delight ? (size_t)16 * N : (m2dp ? (size_t)4 * N : (size_t)N);
+  const size_t cols = delight ? PR_DELIGHT_SIG_LEN : (m2dp ? PR_M2DP_SIG_LEN : PR_SC_SIG_LEN);
   std::vector<double> sig(rows * cols);
   pr_ctx* ctx = nullptr;
   int rc = pr_create((int)prm.num("device", 0), &ctx);
   if (rc != PR_OK) { fprintf(stderr, "%s\n", pr_last_error(nullptr)); pr_clouds_free(clouds); return 3; }
   const auto t0 = std::chrono::steady_clock::now();
-  rc = m2dp ? pr_m2dp_generate(ctx, pr_clouds_xyz(clouds), pr_clouds_inten(clouds), pr_clouds_offs(clouds), N, lidarRange, sig.data())
+  rc = delight ? pr_delight_generate(ctx, pr_clouds_xyz(clouds), pr_clouds_inten(clouds), pr_clouds_offs(clouds), N, sig.data())
+     : m2dp ? pr_m2dp_generate(ctx, pr_clouds_xyz(clouds), pr_clouds_inten(clouds), pr_clouds_offs(clouds), N, lidarRange, sig.data())
             : pr_sc_generate(ctx, pr_clouds_xyz(clouds), pr_clouds_inten(clouds), pr_clouds_offs(clouds), N, lidarRange, sig.data());
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (rc != PR_OK) { fprintf(stderr, "generate failed: %s\n", pr_last_error(ctx)); pr_destroy(ctx); pr_clouds_free(clouds); return 4; }
   printProgress(N ? 1.0 : 0.0);
-  printf("\n%s average time: %gms\n", m2dp ? "M2DP" : "SC", N ? 1000.0 * secs / N : 0.0);   // test_sc.cpp:58-61
+  printf("\n%s average time: %gms\n", delight ? "DELIGHT" : (m2dp ? "M2DP" : "SC"), N ? 1000.0 * secs / N : 0.0);   // test_sc.cpp:58-61
   const bool bin = outf.size() > 4 && outf.compare(outf.size() - 4, 4, ".bin") == 0;
   rc = bin ? pr_write_signatures_bin(outf.c_str(), sig.data(), (int64_t)rows, (int64_t)cols, PR_F64)
            : pr_write_signatures(outf.c_str(), sig.data(), (int64_t)rows, (int64_t)cols);   // :63-66

@@ -1,6 +1,6 @@
 // match_signatures — executable counterpart of match_signatures/run_test.m:25-57 (the reference runs it from MATLAB:
 // test_kitti.m:18-28).  Options mirror run_test's arguments:
-//   --type sc|m2dp --hist1 F --hist2 F [--mask_width W=0] [--p_weight 2] [--topk K=1] [--one_based 0|1] --out F
+//   --type sc|m2dp|delight --hist1 F --hist2 F [--mask_width W=0] [--p_weight 2] [--topk K=1] [--one_based 0|1] --out F
 // Output: one line per query: K pairs "index score" (0-based indices unless --one_based 1), and the reference's
 // console lines `type` / `tm` (ms per query, run_test.m:42-44).
 #include <chrono>
@@ -13,12 +13,13 @@ int main(int argc, char** argv) {
   Params prm(argc, argv);
   std::string type, h1f, h2f, outf;
   if (!prm.get("type", type) || !prm.get("hist1", h1f) || !prm.get("hist2", h2f) || !prm.get("out", outf) ||
-      (type != "sc" && type != "m2dp")) {
-    printf("usage: match_signatures --type sc|m2dp --hist1 F --hist2 F [--mask_width W] [--p_weight 2] [--topk K] [--one_based 0|1] --out F\n");
+      (type != "sc" && type != "m2dp" && type != "delight")) {
+    printf("usage: match_signatures --type sc|m2dp|delight --hist1 F --hist2 F [--mask_width W] [--p_weight 2] [--topk K] [--one_based 0|1] --out F\n");
     return 1;
   }
-  const int t = type == "sc" ? PR_TYPE_SC : PR_TYPE_M2DP, div = t == PR_TYPE_SC ? 1 : 4;
-  const int64_t width = t == PR_TYPE_SC ? PR_SC_SIG_LEN : PR_M2DP_SIG_LEN;
+  const int t = type == "sc" ? PR_TYPE_SC : (type == "m2dp" ? PR_TYPE_M2DP : PR_TYPE_DELIGHT);
+  const int div = t == PR_TYPE_SC ? 1 : (t == PR_TYPE_M2DP ? 4 : 16);
+  const int64_t width = t == PR_TYPE_SC ? PR_SC_SIG_LEN : (t == PR_TYPE_M2DP ? PR_M2DP_SIG_LEN : PR_DELIGHT_SIG_LEN);
   double *h1 = nullptr, *h2 = nullptr;
   int64_t r1, c1, r2, c2;
   auto rd = [](const std::string& f, double** o, int64_t* r, int64_t* c) {

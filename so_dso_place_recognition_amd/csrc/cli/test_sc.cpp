@@ -1,2 +1,2 @@
 #include "generate_main.hpp"
-int main(int argc, char** argv) { return generate_main(argc, argv, false); }
+int main(int argc, char** argv) { return generate_main(argc, argv, 0); }

@@ -66,7 +66,8 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   __shared__ double rv[256];
   __shared__ int rj[256];
   const int tid = threadIdx.x, q = blockIdx.x;
-  if (tid < 2) {  // Chan's parallel combination of the shard moments, fixed (rank) order
+  const bool plain = (d_i == nullptr);   // single distance matrix, no z-score fusion (run_test.m types other than m2dp/sc)
+  if (!plain && tid < 2) {  // Chan's parallel combination of the shard moments, fixed (rank) order
     double cn = 0.0, mean = 0.0, m2 = 0.0;
     for (int g = 0; g < G; g++) {
       const double* o = mom_all + (((size_t)g * m + q) * 2 + tid) * 3;
@@ -81,9 +82,9 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
     st[tid * 2 + 1] = sqrt(m2 / (cn - 1.0));
   }
   __syncthreads();
-  const double mp = st[0], sp = st[1], mi = st[2], si = st[3];
+  const double mp = plain ? 0.0 : st[0], sp = plain ? 1.0 : st[1], mi = plain ? 0.0 : st[2], si = plain ? 1.0 : st[3];
   const float* rp = d_p + (size_t)q * n;
-  const float* ri = d_i + (size_t)q * n;
+  const float* ri = plain ? rp : d_i + (size_t)q * n;
   const int ig = q_row0 + q;
   double pv = -__builtin_inf();
   int pj = -1;
@@ -92,7 +93,7 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
     int bj = -1;
     for (int j = tid; j < n; j += 256) {
       const int jg = db_row0 + j;
-      double f = p_weight * (((double)rp[j] - mp) / sp) + ((double)ri[j] - mi) / si;   // run_test.m:40
+      double f = plain ? (double)rp[j] : p_weight * (((double)rp[j] - mp) / sp) + ((double)ri[j] - mi) / si;   // run_test.m:40
       int dij = ig - jg;
       if (dij < 0) dij = -dij;
       if (dij < mask_width) f = __builtin_inf();                                      // run_test.m:47-53

@@ -48,4 +48,10 @@ void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, 
                          double* out);
 size_t m2dp_generate_scratch_bytes(int N);
 
+// delight.hip — DELIGHT.cpp:8-24, processDELIGHT.m:1-38
+void launch_delight_gen(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
+                        const double* frames, double* out);
+void launch_delight_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed);
+void launch_delight_match(hipStream_t st, const float* q, int m, const float* db, int n, float* dist);
+
 }  // namespace pr

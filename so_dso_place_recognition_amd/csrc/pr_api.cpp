@@ -67,6 +67,7 @@ int set_device(pr_ctx* ctx) {
 }
 
 size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups) {
+  if (type == PR_TYPE_DELIGHT) { *groups = max_sigs; return (size_t)max_sigs * 4096 + 16; }
   if (type == PR_TYPE_SC) {
     if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SC_QIMG; }
     *groups = pr::sc_dgroups(max_sigs);
@@ -196,7 +197,7 @@ int pr_sync(pr_ctx* ctx) {
 // ------------------------------------------------------------------------------------------- signature sets
 int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigset** out) {
   if (!ctx || !out) return PR_EINVAL;
-  if ((type != PR_TYPE_SC && type != PR_TYPE_M2DP) || (role != PR_ROLE_QUERY && role != PR_ROLE_DB) || max_sigs < 0)
+  if ((type != PR_TYPE_SC && type != PR_TYPE_M2DP && type != PR_TYPE_DELIGHT) || (role != PR_ROLE_QUERY && role != PR_ROLE_DB) || max_sigs < 0)
     PR_FAIL(ctx, PR_EINVAL, "pr_sigset_create: bad type/role/max_sigs");
   if (int rc = set_device(ctx)) return rc;
   pr_sigset* s = new (std::nothrow) pr_sigset;
@@ -224,8 +225,8 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
       (where != PR_HOST && where != PR_DEVICE))
     PR_FAIL(ctx, PR_EINVAL, "pr_sigset_pack: bad arguments (n_sigs=%d, capacity=%d)", n_sigs, s->max_sigs);
   if (int rc = set_device(ctx)) return rc;
-  const size_t rows = (s->type == PR_TYPE_SC) ? (size_t)n_sigs : (size_t)4 * n_sigs;
-  const size_t cols = (s->type == PR_TYPE_SC) ? PR_SC_SIG_LEN : PR_M2DP_SIG_LEN;
+  const size_t rows = (s->type == PR_TYPE_SC) ? (size_t)n_sigs : (s->type == PR_TYPE_M2DP ? (size_t)4 * n_sigs : (size_t)16 * n_sigs);
+  const size_t cols = (s->type == PR_TYPE_SC) ? PR_SC_SIG_LEN : (s->type == PR_TYPE_M2DP ? PR_M2DP_SIG_LEN : PR_DELIGHT_SIG_LEN);
   const size_t esz = (dtype == PR_F64) ? 8 : 4;
   DevBuf stage;
   const void* dsig = sig;
@@ -242,8 +243,10 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
   s->groups = groups;
   if (s->type == PR_TYPE_SC)
     pr::launch_sc_pack(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags);
-  else
+  else if (s->type == PR_TYPE_M2DP)
     pr::launch_m2dp_pack(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
+  else
+    pr::launch_delight_pack(ctx->stream, dsig, dtype, n_sigs, s->packed);
   PR_HIP(ctx, hipGetLastError());
   s->count = n_sigs;
   if (stage.p) PR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging buffer is freed on return
@@ -252,14 +255,16 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
 
 // ------------------------------------------------------------------------------------------- device path
 int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float* d_p, float* d_i) {
-  if (!ctx || !q || !db || !d_p || !d_i) return PR_EINVAL;
+  if (!ctx || !q || !db || !d_p || (!d_i && q->type != PR_TYPE_DELIGHT)) return PR_EINVAL;
   if (q->type != db->type || q->role != PR_ROLE_QUERY || db->role != PR_ROLE_DB)
     PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: q must be a QUERY set and db a DB set of the same type");
   if (int rc = set_device(ctx)) return rc;
   if (q->type == PR_TYPE_SC)
     pr::launch_sc_match(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst, d_p, d_i, ctx->sc_nsplit);
-  else
+  else if (q->type == PR_TYPE_M2DP)
     pr::launch_m2dp_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
+  else
+    pr::launch_delight_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -275,7 +280,7 @@ int pr_row_moments_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
 int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n, const double* mom_all,
                        int32_t G, int32_t q_row0, int32_t db_row0, int32_t mask_width, double p_weight, int32_t k,
                        int32_t* idx, float* score) {
-  if (!ctx || !d_p || !d_i || !mom_all || !idx || !score || m < 0 || n < 1 || G < 1 || k < 1)
+  if (!ctx || !d_p || (d_i && !mom_all) || !idx || !score || m < 0 || n < 1 || G < 1 || k < 1)
     return PR_EINVAL;
   if (int rc = set_device(ctx)) return rc;
   pr::launch_fuse_select(ctx->stream, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score);
@@ -289,7 +294,8 @@ static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, con
                          float* score, bool want_topk) {
   if (!ctx) return PR_EINVAL;
   if (m < 0 || n < 0 || (m > 0 && !h1) || (n > 0 && !h2)) PR_FAIL(ctx, PR_EINVAL, "bad signature buffers (m=%d, n=%d)", m, n);
-  if (want_topk && (n < 2 || k < 1 || !idx || !score))
+  const bool plain = (type == PR_TYPE_DELIGHT);
+  if (want_topk && ((n < 2 && !plain) || k < 1 || !idx || !score))
     PR_FAIL(ctx, PR_EINVAL, "pr_match_topk needs n >= 2 (N-1 standard deviation), k >= 1 and output buffers");
   if (m == 0 || n == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
@@ -302,19 +308,19 @@ static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, con
     if ((rc = pr_sigset_pack(ctx, q, h1, PR_F64, PR_HOST, m))) break;
     if ((rc = pr_sigset_pack(ctx, d, h2, PR_F64, PR_HOST, n))) break;
     const size_t mn = (size_t)m * n;
-    if (dp.alloc(mn * 4) != hipSuccess || di.alloc(mn * 4) != hipSuccess) { ctx->err = "out of device memory for the m x n distance matrices"; rc = PR_ENOMEM; break; }
-    if ((rc = pr_distances_dev(ctx, q, d, dp.as<float>(), di.as<float>()))) break;
+    if (dp.alloc(mn * 4) != hipSuccess || (!plain && di.alloc(mn * 4) != hipSuccess)) { ctx->err = "out of device memory for the m x n distance matrices"; rc = PR_ENOMEM; break; }
+    if ((rc = pr_distances_dev(ctx, q, d, dp.as<float>(), plain ? nullptr : di.as<float>()))) break;
     if (want_topk) {
       if (mom.alloc((size_t)m * 6 * 8) != hipSuccess || didx.alloc((size_t)m * k * 4) != hipSuccess ||
           dsc.alloc((size_t)m * k * 4) != hipSuccess) { ctx->err = "out of device memory"; rc = PR_ENOMEM; break; }
-      if ((rc = pr_row_moments_dev(ctx, dp.as<float>(), di.as<float>(), m, n, mom.as<double>()))) break;
-      if ((rc = pr_fuse_select_dev(ctx, dp.as<float>(), di.as<float>(), m, n, mom.as<double>(), 1, 0, 0, mask_width,
+      if (!plain && (rc = pr_row_moments_dev(ctx, dp.as<float>(), di.as<float>(), m, n, mom.as<double>()))) break;
+      if ((rc = pr_fuse_select_dev(ctx, dp.as<float>(), plain ? nullptr : di.as<float>(), m, n, mom.as<double>(), 1, 0, 0, mask_width,
                                    p_weight, k, didx.as<int32_t>(), dsc.as<float>()))) break;
       if (hipMemcpyAsync(idx, didx.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
           hipMemcpyAsync(score, dsc.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
     }
     if (out_p && hipMemcpyAsync(out_p, dp.p, mn * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
-    if (out_i && hipMemcpyAsync(out_i, di.p, mn * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
+    if (out_i && !plain && hipMemcpyAsync(out_i, di.p, mn * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
     rc = pr_sync(ctx);
   } while (0);
   if (rc != PR_OK) (void)hipStreamSynchronize(ctx->stream);
@@ -331,10 +337,14 @@ int pr_m2dp_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2,
   return distance_host(ctx, PR_TYPE_M2DP, h1, m, h2, n, d_cnt, d_int, 0, 0, 0, nullptr, nullptr, false);
 }
 
+int pr_delight_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, float* dist) {
+  return distance_host(ctx, PR_TYPE_DELIGHT, h1, m, h2, n, dist, nullptr, 0, 0, 0, nullptr, nullptr, false);
+}
+
 int pr_match_topk(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n, int32_t mask_width,
                   double p_weight, int32_t k, int32_t* idx, float* score) {
   if (!ctx) return PR_EINVAL;
-  if (type != PR_TYPE_SC && type != PR_TYPE_M2DP) PR_FAIL(ctx, PR_EINVAL, "pr_match_topk: unknown type %d", type);
+  if (type != PR_TYPE_SC && type != PR_TYPE_M2DP && type != PR_TYPE_DELIGHT) PR_FAIL(ctx, PR_EINVAL, "pr_match_topk: unknown type %d", type);
   return distance_host(ctx, type, h1, m, h2, n, nullptr, nullptr, mask_width, p_weight, k, idx, score, true);
 }
 
@@ -388,6 +398,19 @@ int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, con
   return PR_OK;
 }
 
+int pr_delight_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double* out) {
+  if (int rc = check_gen_args(ctx, xyz, inten, offs, N, 1.0, out)) return rc;
+  if (N == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  DevBuf frames;
+  PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
+  pr::launch_cloud_frames(ctx->stream, xyz, offs, N, frames.as<double>());
+  pr::launch_delight_gen(ctx->stream, xyz, inten, offs, N, frames.as<double>(), out);
+  PR_HIP(ctx, hipGetLastError());
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PR_OK;
+}
+
 static int generate_host(pr_ctx* ctx, int type, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
                          double max_rho, double* out) {
   if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
@@ -398,7 +421,7 @@ static int generate_host(pr_ctx* ctx, int type, const double* xyz, const float* 
   const size_t T = (size_t)offs[N];
   if (T > 0 && (!xyz || !inten)) PR_FAIL(ctx, PR_EINVAL, "generate: xyz/inten are NULL");
   if (int rc = set_device(ctx)) return rc;
-  const size_t rowlen = (type == PR_TYPE_SC) ? PR_SC_SIG_LEN : (size_t)4 * PR_M2DP_SIG_LEN;
+  const size_t rowlen = (type == PR_TYPE_SC) ? PR_SC_SIG_LEN : (type == PR_TYPE_M2DP ? (size_t)4 * PR_M2DP_SIG_LEN : (size_t)16 * PR_DELIGHT_SIG_LEN);
   DevBuf dx, di, dof, dout;
   PR_HIP(ctx, dx.alloc(T * 24));
   PR_HIP(ctx, di.alloc(T * 4));
@@ -411,7 +434,9 @@ static int generate_host(pr_ctx* ctx, int type, const double* xyz, const float* 
   PR_HIP(ctx, hipMemcpyAsync(dof.p, offs, (size_t)(N + 1) * 8, hipMemcpyHostToDevice, ctx->stream));
   int rc = (type == PR_TYPE_SC)
                ? pr_sc_generate_dev(ctx, dx.as<double>(), di.as<float>(), dof.as<int64_t>(), N, max_rho, dout.as<double>())
-               : pr_m2dp_generate_dev(ctx, dx.as<double>(), di.as<float>(), dof.as<int64_t>(), N, max_rho, dout.as<double>());
+               : (type == PR_TYPE_M2DP
+                      ? pr_m2dp_generate_dev(ctx, dx.as<double>(), di.as<float>(), dof.as<int64_t>(), N, max_rho, dout.as<double>())
+                      : pr_delight_generate_dev(ctx, dx.as<double>(), di.as<float>(), dof.as<int64_t>(), N, dout.as<double>()));
   if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
   PR_HIP(ctx, hipMemcpyAsync(out, dout.p, (size_t)N * rowlen * 8, hipMemcpyDeviceToHost, ctx->stream));
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -424,6 +449,10 @@ int pr_sc_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int
 
 int pr_m2dp_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
   return generate_host(ctx, PR_TYPE_M2DP, xyz, inten, offs, N, max_rho, out);
+}
+
+int pr_delight_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double* out) {
+  return generate_host(ctx, PR_TYPE_DELIGHT, xyz, inten, offs, N, 1.0, out);
 }
 
 }  // extern "C"

@@ -30,9 +30,9 @@ def _dptr(t: torch.Tensor):
 
 class Matcher:
     def __init__(self, type_: str, max_queries: int, max_db: int, ctx: Context | None = None, device: int | None = None):
-        self.type = {"sc": _lib.TYPE_SC, "m2dp": _lib.TYPE_M2DP}[type_]
-        self.sig_len = 2400 if self.type == _lib.TYPE_SC else 384
-        self.rows_per_sig = 1 if self.type == _lib.TYPE_SC else 4
+        self.type = {"sc": _lib.TYPE_SC, "m2dp": _lib.TYPE_M2DP, "delight": _lib.TYPE_DELIGHT}[type_]
+        self.rows_per_sig, self.sig_len = {_lib.TYPE_SC: (1, 2400), _lib.TYPE_M2DP: (4, 384), _lib.TYPE_DELIGHT: (16, 256)}[self.type]
+        self.plain = self.type == _lib.TYPE_DELIGHT      # one distance matrix, no z-score fusion (run_test.m:26-36)
         if device is None:
             device = torch.cuda.current_device()
         self.ctx = ctx or Context(device)
@@ -83,18 +83,23 @@ class Matcher:
         n = self.n
         G = dist.get_world_size(group) if (group is not None or (dist.is_available() and dist.is_initialized())) else 1
         d_p = self._buf("d_p", (m, n), torch.float32)
-        d_i = self._buf("d_i", (m, n), torch.float32)
+        d_i = None if self.plain else self._buf("d_i", (m, n), torch.float32)
         mom = self._buf("mom", (m, 2, 3), torch.float64)
         idx = self._buf("idx", (m, k), torch.int32)
         score = self._buf("score", (m, k), torch.float32)
         lib, h = self.lib, self.ctx.h
         if self.pre_distances:
             self.pre_distances()
-        self.ctx.check(lib.pr_distances_dev(h, self.q, self.db, _dptr(d_p), _dptr(d_i)))
+        p_i = None if self.plain else _dptr(d_i)
+        self.ctx.check(lib.pr_distances_dev(h, self.q, self.db, _dptr(d_p), p_i))
         if self.post_distances:
             self.post_distances()
 
         def local_moments():
+            if self.plain:
+                mom.zero_()
+                torch.cuda.current_stream(self.dev).synchronize()
+                return mom
             self.ctx.check(lib.pr_row_moments_dev(h, _dptr(d_p), _dptr(d_i), m, n, _dptr(mom)))
             if G > 1:
                 self.ctx.sync()
@@ -103,7 +108,7 @@ class Matcher:
         def local_select(mom_all, G_):
             if G_ > 1:
                 torch.cuda.current_stream(self.dev).synchronize()
-            self.ctx.check(lib.pr_fuse_select_dev(h, _dptr(d_p), _dptr(d_i), m, n, _dptr(mom_all), G_, q_row0, db_row0,
+            self.ctx.check(lib.pr_fuse_select_dev(h, _dptr(d_p), p_i, m, n, _dptr(mom_all), G_, q_row0, db_row0,
                                                   int(mask_width), float(p_weight), int(k), _dptr(idx), _dptr(score)))
             self.ctx.sync()
             return idx, score
@@ -112,7 +117,7 @@ class Matcher:
 
     def distances(self):
         """The last distance matrices (device, float32 [m, n_local])."""
-        return self._bufs["d_p"], self._bufs["d_i"]
+        return self._bufs["d_p"], self._bufs.get("d_i")
 
 
 def sharded_topk(local_moments, local_select, k: int, group, G: int):

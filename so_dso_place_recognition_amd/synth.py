@@ -138,3 +138,29 @@ def m2dp_queries(seed: int, db: np.ndarray, m: int):
     uu = rows[..., :64] / np.sqrt((rows[..., :64] ** 2).sum(-1, keepdims=True))
     vv = rows[..., 64:] / np.sqrt((rows[..., 64:] ** 2).sum(-1, keepdims=True))
     return np.concatenate([uu, vv], -1).reshape(4 * m, 384), et
+
+
+# ----------------------------------------------------------------------------- DELIGHT histograms
+def delight_database(seed: int, n: int, first: int = 0) -> np.ndarray:
+    """[16n, 256] float64 histograms: per entry 16 x 256 Poisson-like integer counts around a smooth profile."""
+    u = uniform(seed, np.arange(first, first + n, dtype=np.uint64), 4096 + 16).reshape(n, 4096 + 16)
+    scale = 4.0 + 28.0 * u[:, 4096:]                                          # per-histogram level
+    cnt = np.floor(u[:, :4096].reshape(n, 16, 256) * scale[:, :, None] * (u[:, :4096].reshape(n, 16, 256) < 0.5))
+    return cnt.reshape(16 * n, 256)
+
+
+def delight_queries(seed: int, db: np.ndarray, m: int):
+    """Query t copies entry e_t, applies one of the 4 octant permutations of processDELIGHT.m and perturbs 2 % of the bins."""
+    from numpy import array
+    mut = array([[0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15], [5, 4, 7, 6, 1, 0, 3, 2, 13, 12, 15, 14, 9, 8, 11, 10],
+                 [6, 7, 4, 5, 2, 3, 0, 1, 14, 15, 12, 13, 10, 11, 8, 9], [3, 2, 1, 0, 7, 6, 5, 4, 11, 10, 9, 8, 15, 14, 13, 12]])
+    n = db.shape[0] // 16
+    u = uniform(seed, np.arange(m, dtype=np.uint64), 2 + 2 * 4096)
+    et = np.minimum((u[:, 0] * n).astype(np.int64), n - 1)
+    k = np.minimum((u[:, 1] * 4).astype(np.int64), 3)
+    q = np.empty((m, 16, 256))
+    for t in range(m):
+        src = db.reshape(n, 16, 256)[et[t]][mut[k[t]]]
+        r = u[t, 2:].reshape(2, 16, 256)
+        q[t] = np.where(r[0] < 0.02, np.floor(r[1] * 8), src)
+    return q.reshape(16 * m, 256), et

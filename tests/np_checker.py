@@ -177,3 +177,40 @@ def incoming_ids(poses_file):
             continue
         ids.append(int(t[0]))
     return ids
+
+
+DELIGHT_MUT = np.array([[1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16],
+                        [6, 5, 8, 7, 2, 1, 4, 3, 14, 13, 16, 15, 10, 9, 12, 11],
+                        [7, 8, 5, 6, 3, 4, 1, 2, 15, 16, 13, 14, 11, 12, 9, 10],
+                        [4, 3, 2, 1, 8, 7, 6, 5, 12, 11, 10, 9, 16, 15, 14, 13]]) - 1   # processDELIGHT.m:2-5
+
+
+def delight_signature(xyz, inten):
+    """DELIGHT.cpp:8-24"""
+    al, _ = align_pca(xyz)
+    f = al.astype(np.float32)
+    d = np.sqrt((al * al).sum(1)).astype(np.float32)
+    hist = 8 * (d.astype(np.float64) > 10.0) + 4 * (f[:, 2] > 0) + 2 * (f[:, 1] > 0) + 1 * (f[:, 0] > 0)
+    b = np.asarray(inten, np.float32).astype(np.int64)
+    ok = (b >= 0) & (b < 256)
+    out = np.zeros((16, 256))
+    np.add.at(out, (hist[ok], b[ok]), 1)
+    return out
+
+
+def delight_distance(h1, h2):
+    """processDELIGHT.m:7-37"""
+    m, n = h1.shape[0] // 16, h2.shape[0] // 16
+    A = h1.reshape(m, 16, 256)
+    B = h2.reshape(n, 16, 256)
+    out = np.empty((m, n))
+    for i in range(m):
+        best = np.full(n, np.inf)
+        for k in range(4):
+            Bk = B[:, DELIGHT_MUT[k], :]
+            s = A[i][None] + Bk
+            with np.errstate(divide="ignore", invalid="ignore"):
+                t = np.where(s > 0, 2 * (A[i][None] - Bk) ** 2 / s, 0.0).sum((1, 2)) / (s > 0).sum((1, 2))
+            best = np.where(best > t, t, best)
+        out[i] = best
+    return out

@@ -43,6 +43,9 @@ def lib():
     L.pr_ref_top_singular_pair.argtypes = [_dp, _dp]
     L.pr_ref_sc_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, _dp, _dp]
     L.pr_ref_m2dp_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, _dp, _dp]
+    L.pr_ref_delight_generate.argtypes = [_dp, _fp, _lp, C.c_int32, _dp]
+    L.pr_ref_delight_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, _dp]
+    L.pr_ref_select_topk.argtypes = [_dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _dp]
     L.pr_ref_fuse_topk.argtypes = [_dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, _ip, _dp]
     L.pr_ref_match_topk.argtypes = [C.c_int, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_double, C.c_int32, _ip, _dp]
     _lib = L
@@ -150,9 +153,28 @@ def fuse_topk(dp, di, mask_width, p_weight=2.0, k=1):
 def match_topk(type_, h1, h2, mask_width, p_weight=2.0, k=1):
     h1 = np.ascontiguousarray(h1, np.float64)
     h2 = np.ascontiguousarray(h2, np.float64)
-    div = 1 if type_ == 0 else 4
+    div = {0: 1, 1: 4, 2: 16}[type_]
     m, n = h1.shape[0] // div, h2.shape[0] // div
     idx = np.empty((m, k), np.int32)
     sc = np.empty((m, k))
     rc = lib().pr_ref_match_topk(type_, h1, m, h2, n, mask_width, p_weight, k, idx, sc)
     return rc, idx, sc
+
+
+def delight_generate(xyz, inten, offs):
+    N = len(offs) - 1
+    out = np.empty((16 * N, 256))
+    rc = lib().pr_ref_delight_generate(np.ascontiguousarray(xyz, np.float64), np.ascontiguousarray(inten, np.float32),
+                                       np.ascontiguousarray(offs, np.int64), N, out)
+    assert rc == 0
+    return out
+
+
+def delight_distance(h1, h2):
+    h1 = np.ascontiguousarray(h1, np.float64)
+    h2 = np.ascontiguousarray(h2, np.float64)
+    m, n = h1.shape[0] // 16, h2.shape[0] // 16
+    d = np.empty((m, n))
+    rc = lib().pr_ref_delight_distance(h1, m, h2, n, d)
+    assert rc == 0
+    return d

@@ -15,7 +15,7 @@ BIN = os.path.join(ROOT, "so_dso_place_recognition_amd", "bin")
 
 
 def test_missing_params_exit_code_and_message():
-    for exe in ("test_sc", "test_m2dp"):
+    for exe in ("test_sc", "test_m2dp", "test_delight"):
         r = subprocess.run([os.path.join(BIN, exe), "_poses_history_file:=x"], capture_output=True, text=True)
         assert r.returncode == 1 and "Fail to get params, exit." in r.stdout      # test_sc.cpp:19-25
     r = subprocess.run([os.path.join(BIN, "match_signatures"), "--type", "gist"], capture_output=True, text=True)
@@ -32,7 +32,8 @@ def test_config1_end_to_end(golden_dir, tmp_path):
     pts = str(tmp_path / "pts_history_file.txt")
     helpers.write_synthetic_points(poses, pts, per_pose=80)
     out = {}
-    for exe, key, polar in (("test_sc", "sc_file", False), ("test_m2dp", "m2dp_file", True)):
+    for exe, key, polar in (("test_sc", "sc_file", False), ("test_m2dp", "m2dp_file", True),
+                            ("test_delight", "delight_file", True)):
         sig = str(tmp_path / f"history_{exe}.txt"); ids = str(tmp_path / f"ids_{exe}.txt")
         r = subprocess.run([os.path.join(BIN, exe), f"_poses_history_file:={poses}", f"_pts_history_file:={pts}",
                             f"_{key}:={sig}", f"_incoming_id_file:={ids}", "_lidarRange:=45.0"],
@@ -42,11 +43,12 @@ def test_config1_end_to_end(golden_dir, tmp_path):
         x, it, offs, oid = oracle_lib.pts_preprocess(poses, pts, None, 45.0, polar)
         assert [int(v) for v in open(ids).read().split()] == list(oid)
         got = np.loadtxt(sig)
-        want = oracle_lib.m2dp_generate(x, it, offs) if polar else oracle_lib.sc_generate(x, it, offs)
+        want = (oracle_lib.delight_generate(x, it, offs) if exe == "test_delight" else
+                oracle_lib.m2dp_generate(x, it, offs) if polar else oracle_lib.sc_generate(x, it, offs))
         assert got.shape == want.shape
         assert np.allclose(got, want, rtol=2e-5, atol=1e-12)                   # 6 significant digits in the text
         out[exe] = (sig, got)
-    for type_, exe, t in (("sc", "test_sc", 0), ("m2dp", "test_m2dp", 1)):
+    for type_, exe, t in (("sc", "test_sc", 0), ("m2dp", "test_m2dp", 1), ("delight", "test_delight", 2)):
         sig, got = out[exe]
         res = str(tmp_path / f"match_{type_}.txt")
         r = subprocess.run([os.path.join(BIN, "match_signatures"), "--type", type_, "--hist1", sig, "--hist2", sig,

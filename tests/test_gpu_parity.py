@@ -174,3 +174,55 @@ def test_generate_then_match_end_to_end(api):
     gi, gs = api.match_topk("sc", g, g, 2)
     rc, oi, osc = oracle_lib.match_topk(0, o, o, 2)
     assert np.array_equal(gi, oi)
+
+
+# ------------------------------------------------------------------------------------------------ f3 (DELIGHT)
+@pytest.mark.parametrize("P", [1200, 30011])
+def test_delight_generate_vs_oracle(api, P):
+    xyz, it, offs = synth.scene_clouds(61, 5, P)
+    it = (it * 1.5).astype(np.float32)
+    offs = np.concatenate([offs[:3], offs[2:]])              # one empty cloud in the middle
+    got = api.delight_generate(xyz, it, offs)
+    want = oracle_lib.delight_generate(xyz, it, offs)
+    assert got.shape == (16 * 6, 256)
+    # integer counts; a point within 1 ulp(float) of an octant plane or of the 10 m sphere may land in the sibling histogram
+    assert np.abs(got - want).sum() <= 4
+    assert np.array_equal(got.reshape(6, 16, 256).sum(1), want.reshape(6, 16, 256).sum(1))
+
+
+@pytest.mark.parametrize("m,n", [(1, 1), (7, 33), (40, 257)])
+def test_delight_distance_vs_oracle(api, m, n):
+    db = synth.delight_database(51, n)
+    q, _ = synth.delight_queries(52, db, m)
+    want = oracle_lib.delight_distance(q, db)
+    got = api.processDELIGHT(q, db)
+    assert got.shape == (m, n) and got.dtype == np.float32
+    assert (np.abs(got - want) <= 1e-5 * np.maximum(1.0, np.abs(want))).all()
+    z = np.zeros((16, 256))
+    assert np.isinf(api.processDELIGHT(z, np.zeros((32, 256)))).all()
+
+
+@pytest.mark.parametrize("mask,k", [(0, 1), (4, 3)])
+def test_delight_match_topk_vs_oracle(api, mask, k):
+    db = synth.delight_database(51, 300)
+    q, et = synth.delight_queries(52, db, 64)
+    rc, oidx, osc = oracle_lib.match_topk(2, q, db, mask, 2.0, k)
+    idx, sc = api.match_topk("delight", q, db, mask_width=mask, k=k)
+    assert np.array_equal(idx, oidx)
+    assert (np.abs(sc - osc) <= 1e-5 * np.maximum(1.0, np.abs(osc))).all()
+    if mask == 0:
+        assert np.array_equal(idx[:, 0], et)
+
+
+def test_delight_matcher_device_path(api):
+    import torch
+    from so_dso_place_recognition_amd.matcher import Matcher
+    db = synth.delight_database(51, 500)
+    q, et = synth.delight_queries(52, db, 48)
+    mt = Matcher("delight", 48, 500)
+    mt.pack_database(torch.from_numpy(db).cuda())
+    idx, sc = mt.match(torch.from_numpy(q).cuda(), mask_width=0, k=2)
+    rc, oidx, osc = oracle_lib.match_topk(2, q, db, 0, 2.0, 2)
+    assert np.array_equal(idx.cpu().numpy(), oidx)
+    assert (np.abs(sc.cpu().numpy() - osc) <= 1e-5 * np.maximum(1.0, np.abs(osc))).all()
+    mt.close()

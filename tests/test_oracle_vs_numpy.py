@@ -170,3 +170,42 @@ def test_fusion_tie_breaks_to_first_index():
     q, _ = synth.sc_queries(46, db[3:4], 1)
     rc, idx, sc = oracle_lib.match_topk(0, q, db, 0, 2.0, 2)
     assert list(idx[0]) == [3, 7] and sc[0, 0] == sc[0, 1]
+
+
+# ------------------------------------------------------------------------------------------------ f3 (DELIGHT)
+@pytest.mark.parametrize("c", [0, 1])
+def test_delight_signature(c):
+    xyz, it = _cloud(c, 4000)
+    it = (it * 1.7).astype(np.float32)                       # some intensities beyond 255 are dropped, DELIGHT.cpp:24
+    got = oracle_lib.delight_generate(xyz, it, np.array([0, len(it)], np.int64))
+    want = np_checker.delight_signature(xyz, it)
+    assert got.shape == (16, 256)
+    assert np.array_equal(got, want)
+    assert got.sum() == ((it.astype(np.int64) >= 0) & (it.astype(np.int64) < 256)).sum()
+
+
+def test_delight_distance_and_permutation_invariance():
+    db = synth.delight_database(51, 12)
+    q, et = synth.delight_queries(52, db, 5)
+    got = oracle_lib.delight_distance(q, db)
+    want = np_checker.delight_distance(q, db)
+    assert np.abs(got - want).max() < 1e-12
+    assert np.array_equal(got.argmin(1), et)
+    # the distance is invariant to applying any of the 4 octant permutations to the query (processDELIGHT.m:2-5 is a group)
+    qp = q.reshape(5, 16, 256)[:, np_checker.DELIGHT_MUT[2]].reshape(80, 256)
+    assert np.abs(oracle_lib.delight_distance(qp, db) - got).max() < 1e-12
+    # all-empty histograms never match: +Inf
+    z = np.zeros((16, 256))
+    assert np.isinf(oracle_lib.delight_distance(z, np.zeros((32, 256)))).all()
+
+
+def test_delight_topk_plain_selection():
+    db = synth.delight_database(51, 30)
+    rc, idx, sc = oracle_lib.match_topk(2, db, db, 4, 2.0, 3)
+    assert rc == 0
+    d = np_checker.delight_distance(db, db)
+    i, j = np.indices(d.shape)
+    d = np.where(np.abs(i - j) < 4, np.inf, d)
+    order = np.argsort(d, axis=1, kind="stable")[:, :3]
+    assert np.array_equal(idx, order)
+    assert np.abs(sc - np.take_along_axis(d, order, 1)).max() < 1e-12
