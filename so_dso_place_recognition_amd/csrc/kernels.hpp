@@ -13,6 +13,12 @@ constexpr int SC_DSTEP = 640;                   // floats per (channel, 16-entry
 constexpr int SC_DIMG = 2 * SC_NSLOT * SC_DSTEP;  // floats per (channel, 16-entry DB group): 32 positions, the last one zero
 // frequency -> position in the packed images (processing order 0,30,1,2,...,29)
 __host__ __device__ inline int sc_fpos(int f) { return f == 0 ? 0 : (f == 30 ? 1 : f + 1); }
+// split-f16 images (sc_match_h.hip), sizes in BYTES
+constexpr int SCH_QBLK = 1288;                  // (8-query group, frequency): 16 rows x 80 B (Q hi | Q lo), rows 8..15 shifted by 8 B
+constexpr int SCH_QIMG = SC_NF * SCH_QBLK;      // 39 928 per (channel, 8-query group)
+constexpr int SCH_DTILE = 768;                  // one 16x16x32 column operand: 48 lanes x 16 B
+constexpr int SCH_DFREQ = 4 * SCH_DTILE;        // Re hi, Re lo, Im hi, Im lo
+constexpr int SCH_DIMG = SC_NF * SCH_DFREQ;     // 95 232 per (channel, 16-entry DB group)
 constexpr int M2_TILE = 96 * 64;                // floats per (channel, 32-row tile): [kq(24)][lane(64)][4]
 
 inline int sc_qgroups8(int m) { return ((m + 31) / 32) * 4; }
@@ -27,6 +33,12 @@ void launch_sc_pack(hipStream_t st, const void* sig, int dtype, int rows, int ro
 void launch_sc_match(hipStream_t st, const float* qpk, int m, const float* dpk, int n, const float* cst,
                      float* d_p, float* d_i, int nsplit_override);
 size_t sc_match_lds_bytes();
+// sc_match_h.hip — the same on the f16 matrix cores with split (hi + lo) operands; packed images from launch_sc_pack_h
+void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
+                      const double* twiddle, int* flags);
+void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p,
+                       float* d_i, int nsplit_override);
+size_t sc_match_h_lds_bytes();
 
 // m2dp_match.hip — processM2DP.m:12-22 for both channels.
 void launch_m2dp_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed, int tiles);

@@ -23,6 +23,8 @@ struct pr_ctx {
   int* d_flags = nullptr;        // [4] deferred error bits (bit0: zero-norm row at pack time)
   double* d_twiddle = nullptr;   // cos[60], sin[60] of 2*pi*t/60
   float* d_cst = nullptr;        // SC stage-2 constants [31][2][64]
+  void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16]
+  int sc_mode = 0;               // 0: split-f16 MFMA (sc_match_h.hip), 1: fp32 MFMA (sc_match.hip); PR_SC_MATCH=f32 selects 1
   double* d_planes = nullptr;    // M2DP xProj[64][3], yProj[64][3]
   int sc_nsplit = 0;             // PR_SC_NSPLIT override (experiments)
 };
@@ -31,6 +33,7 @@ struct pr_sigset {
   int type = 0, role = 0;
   int32_t max_sigs = 0, count = 0;
   int groups = 0;                // SC: 8-query or 16-entry groups; M2DP: 32-row tiles (channel stride)
+  int sc_mode = 0;               // SC: arithmetic the image was packed for (pr_ctx::sc_mode at creation)
   float* packed = nullptr;
   size_t floats = 0;
 };
@@ -66,8 +69,13 @@ int set_device(pr_ctx* ctx) {
   return PR_OK;
 }
 
-size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups) {
+size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups, int sc_mode) {
   if (type == PR_TYPE_DELIGHT) { *groups = max_sigs; return (size_t)max_sigs * 4096 + 16; }
+  if (type == PR_TYPE_SC && sc_mode == 0) {   // split-f16 images, sizes in bytes / 4
+    if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SCH_QIMG / 4; }
+    *groups = pr::sc_dgroups(max_sigs);
+    return (size_t)(2 * *groups + 1) * pr::SCH_DIMG / 4;   // + one all-zero group: the pipeline requests one pair past the end
+  }
   if (type == PR_TYPE_SC) {
     if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SC_QIMG; }
     *groups = pr::sc_dgroups(max_sigs);
@@ -148,6 +156,31 @@ int pr_create(int device_id, pr_ctx** out) {
       }
     TRY(hipMalloc((void**)&ctx->d_cst, cst.size() * sizeof(float)));
     TRY(hipMemcpy(ctx->d_cst, cst.data(), cst.size() * sizeof(float), hipMemcpyHostToDevice));
+    // split-f16 stage-2 constants (sc_match_h.hip): A operand of v_mfma_f32_32x32x16_f16, lane l -> shift k = min(l & 31, 30)
+    // (row 31 repeats shift 30, harmless for the max), K index = 8*(l >> 5) + e -> frequency f = 16*half + K (f = 31: 0),
+    // value = w_f cos(2 pi f k/60) (E) or -w_f sin(2 pi f k/60) (O), scaled by 2^10 and split into hi + lo
+    {
+      std::vector<_Float16> ch((size_t)8 * 64 * 8);
+      for (int eo = 0; eo < 2; eo++)
+        for (int half = 0; half < 2; half++)
+          for (int l = 0; l < 64; l++)
+            for (int e = 0; e < 8; e++) {
+              int k = l & 31; if (k > 30) k = 30;
+              const int f = 16 * half + 8 * (l >> 5) + e;
+              double v = 0.0;
+              if (f < pr::SC_NF) {
+                const int t = (f * k) % 60;
+                const double w = (f == 0 || f == 30) ? 1.0 : 2.0;
+                v = (eo == 0 ? w * tw[t] : -w * tw[60 + t]) * 1024.0;
+              }
+              const _Float16 hi = (_Float16)v;
+              const _Float16 lo = (_Float16)(v - (double)hi);
+              ch[((((size_t)eo * 2 + half) * 2 + 0) * 64 + l) * 8 + e] = hi;
+              ch[((((size_t)eo * 2 + half) * 2 + 1) * 64 + l) * 8 + e] = lo;
+            }
+      TRY(hipMalloc(&ctx->d_cst_h, ch.size() * sizeof(_Float16)));
+      TRY(hipMemcpy(ctx->d_cst_h, ch.data(), ch.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+    }
     // M2DP plane table from the frozen float normals (M2DP/M2DP.cpp:9-30)
     double pl[2][64][3];
     for (int k = 0; k < 64; k++) {
@@ -166,6 +199,7 @@ int pr_create(int device_id, pr_ctx** out) {
   } while (0);
   if (rc != PR_OK) { pr_destroy(ctx); return rc; }
   if (const char* s = getenv("PR_SC_NSPLIT")) ctx->sc_nsplit = atoi(s);
+  if (const char* s = getenv("PR_SC_MATCH")) ctx->sc_mode = (strcmp(s, "f32") == 0) ? 1 : 0;
   *out = ctx;
   return PR_OK;
 }
@@ -180,6 +214,7 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->d_cst) (void)hipFree(ctx->d_cst);
+  if (ctx->d_cst_h) (void)hipFree(ctx->d_cst_h);
   if (ctx->d_planes) (void)hipFree(ctx->d_planes);
   delete ctx;
 }
@@ -203,7 +238,8 @@ int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigse
   pr_sigset* s = new (std::nothrow) pr_sigset;
   if (!s) PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: out of host memory");
   s->type = type; s->role = role; s->max_sigs = max_sigs;
-  s->floats = sigset_floats(type, role, max_sigs, &s->groups);
+  s->sc_mode = ctx->sc_mode;
+  s->floats = sigset_floats(type, role, max_sigs, &s->groups, s->sc_mode);
   hipError_t e = hipMalloc((void**)&s->packed, s->floats * sizeof(float) + 16);
   if (e != hipSuccess) { delete s; PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: hipMalloc(%zu B) failed: %s", s->floats * 4, hipGetErrorString(e)); }
   *out = s;
@@ -239,9 +275,11 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
   PR_HIP(ctx, hipMemsetAsync(s->packed, 0, s->floats * sizeof(float), ctx->stream));
   // the channel stride must match the matcher's view of THIS count (not the capacity)
   int groups;
-  (void)sigset_floats(s->type, s->role, n_sigs, &groups);
+  (void)sigset_floats(s->type, s->role, n_sigs, &groups, s->sc_mode);
   s->groups = groups;
-  if (s->type == PR_TYPE_SC)
+  if (s->type == PR_TYPE_SC && s->sc_mode == 0)
+    pr::launch_sc_pack_h(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags);
+  else if (s->type == PR_TYPE_SC)
     pr::launch_sc_pack(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags);
   else if (s->type == PR_TYPE_M2DP)
     pr::launch_m2dp_pack(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
@@ -259,7 +297,11 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
   if (q->type != db->type || q->role != PR_ROLE_QUERY || db->role != PR_ROLE_DB)
     PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: q must be a QUERY set and db a DB set of the same type");
   if (int rc = set_device(ctx)) return rc;
-  if (q->type == PR_TYPE_SC)
+  if (q->type == PR_TYPE_SC && q->sc_mode != db->sc_mode)
+    PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: the two SC sets were packed for different arithmetic modes");
+  if (q->type == PR_TYPE_SC && q->sc_mode == 0)
+    pr::launch_sc_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit);
+  else if (q->type == PR_TYPE_SC)
     pr::launch_sc_match(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst, d_p, d_i, ctx->sc_nsplit);
   else if (q->type == PR_TYPE_M2DP)
     pr::launch_m2dp_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);

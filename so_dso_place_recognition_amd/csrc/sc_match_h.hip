@@ -1,0 +1,336 @@
+// sc_match_h.hip — all-pairs Scan-Context distance on the gfx950 f16 matrix cores with split-f16 ("hi + lo") operands
+// (processSC.m:22-33).  Same mathematics as sc_match.hip (per-ring sector spectra, S_f / P_f, even/odd split of the
+// inverse transform, max over the 60 + 60 shifts), different arithmetic:
+//
+//   every fp32 factor x is carried as  x = hi + lo,  hi = f16(x), lo = f16(x - hi)  (22 significand bits), and every
+//   product as the three f16 MFMAs  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  accumulated in fp32 (the dropped lo*lo term is
+//   2^-22 relative).  On MI355X the f16 MFMA rate is 16x the fp32 MFMA rate, so the 3x is still a 5x gain in matrix
+//   time, and — unlike v_mfma_f32_*_f32, which occupies the SIMD's fp32 VALU datapath — the f16 MFMAs run beside the
+//   wave's own VALU work (tools/ubench/f16_feed.hip).  Measured distance error vs fp64: same order as the fp32 kernel
+//   (tools/experiments/split_f16_error.py; tests/test_gpu_parity.py).
+//
+// One wave = 8 queries x 16 DB entries of one channel; spectra are pre-scaled (queries 2^8, DB 2^7, constants 2^10) so
+// that hi and lo stay in the normal f16 range; the final correlation is rescaled by 2^-25.
+//   stage 1  v_mfma_f32_16x16x32_f16, K = 20 rings (+12 zero), per frequency f:
+//            rows = {Re,Im} x 8 queries, cols = 16 entries
+//            T1 = [Qr;Qi].Dr^T = (QrDr | QiDr)       T2 = [Qi;Qr].Di^T = (QiDi | QrDi)     lanes <32 | >=32
+//            (T2's row operand = the same LDS image read with row ^ 8)
+//            F = T1 + s T2 = (Re S_f | Im S_f)       M = T1 - s T2 = (Re P_f | Im P_f)     s = +1 | -1
+//   split    F, M of two consecutive frequencies -> v_cvt_pk_f16_f32 (hi), v_fma_mixlo/hi_f16 (lo = F - hi)
+//   swap     v_permlane32_swap(pair j, pair j+4): (Re | Im) x 2 -> (Re, Re') , (Im, Im'): four such registers are, lane
+//            for lane, the B operand of a 32x32x16 MFMA over 16 frequencies (k = 8*(lane>>5) + 0..7, pair = lane&31)
+//   stage 2  v_mfma_f32_32x32x16_f16 per half (16 frequencies):  E[r][F|M] += Ccos . Re-operand, O[r][F|M] += Csin . Im-operand
+//            (A operand = constant [shift 0..31][16 frequencies] tile, hi and lo; 3 MFMAs per chain; 256 accumulators)
+//   epilogue max over shifts of E + |O|, max(forward, mirror), d = 0.5 - 0.5 * 2^-25 * max           (processSC.m:30)
+// A workgroup (4 waves, one per SIMD) keeps the split spectra of 32 queries of one channel in LDS (159 712 B) and
+// sweeps a range of the DB; DB operands stream L2 -> L1 -> VGPR with raw buffer loads (lanes 48-63 are out of range
+// and read zeros: that is the K padding 24..31; K = 20..23 is stored as zeros in the packed image).
+#include "kernels.hpp"
+
+namespace pr {
+namespace {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
+
+struct AOps { u32x4 h, l, rh, rl; };          // query row operands: Q hi, Q lo, and the same with Re/Im rows exchanged
+struct BOps { u32x4 reh, rel, imh, iml; };    // DB column operands: Re hi, Re lo, Im hi, Im lo
+
+// one operand tile (4 registers) per call, so that every request can be placed in its own MFMA gap
+enum { A_H = 0, A_L = 1, A_RH = 2, A_RL = 3 };
+enum { B_REH = 0, B_REL = 1, B_IMH = 2, B_IML = 3 };
+template <int P, int T>
+__device__ __forceinline__ void load_a(AOps& a, const char* __restrict__ nat, const char* __restrict__ rot) {
+  const char* src = ((T & 2) ? rot : nat) + P * SCH_QBLK + (T & 1) * 40;
+  const u32x4 v = *reinterpret_cast<const u32x4_a8*>(src);
+  if (T == A_H) a.h = v; else if (T == A_L) a.l = v; else if (T == A_RH) a.rh = v; else a.rl = v;
+}
+template <int P, int T>
+__device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int voff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, P * SCH_DFREQ + T * SCH_DTILE, 0);
+  if (T == B_REH) b.reh = v; else if (T == B_REL) b.rel = v; else if (T == B_IMH) b.imh = v; else b.iml = v;
+}
+
+// Stage-1 MFMAs in VGPR form, ONE instruction per asm statement so that VALU work can be placed between them by hand
+// (the wave issues in order: back-to-back MFMAs would block it).  The 256 stage-2 accumulators own the AccVGPR half and
+// hipcc picks one MFMA register form per function, hence asm.  hipcc pads nothing around asm (cdna_hip_programming.md
+// §5.7): an accumulate chain on the same vDst needs no wait states; every VALU reader of t1/t2 below sits at least two
+// MFMAs + their fillers behind the last write, except the one after DRAIN().
+#define MF0(d, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b))
+#define MFA(d, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b))
+#define DRAIN() asm volatile("s_nop 9")
+#define SB() __builtin_amdgcn_sched_barrier(0)
+
+// (hi, lo) split of two fp32 values into packed f16 pairs: lo = x - hi exactly (fp32), rounded to f16
+__device__ __forceinline__ void split2(float x, float y, unsigned& hi, unsigned& lo) {
+  const f32x2 v = {x, y};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(lo)
+      : "v"(hi), "v"(x), "v"(y));
+}
+
+// Packed results of 16 frequencies (one half) for the 4 stage-1 registers r: [kind][r] is a 4-register MFMA operand
+// whose element j holds pair j (lanes 0-31) / pair j+4 (lanes 32-63) after the swap.
+struct Half {
+  u32x4 reFh[4], reFl[4], imFh[4], imFl[4];   // forward (S): Re / Im operands, hi / lo
+  u32x4 reMh[4], reMl[4], imMh[4], imMl[4];   // mirror (P)
+};
+
+__device__ __forceinline__ void swap32(u32x4& a, u32x4& b, int e) {   // lanes 32-63 of a[e] <-> lanes 0-31 of b[e]
+  const u32x2 v = __builtin_amdgcn_permlane32_swap(a[e], b[e], false, false);
+  a[e] = v[0];
+  b[e] = v[1];
+}
+
+// frequencies (2J, 2J+1) of the half -> element J&3 of the "re" (J < 4) or "im" (J >= 4) registers, still as (Re | Im)
+template <int J, int R>
+__device__ __forceinline__ void pack_F(Half& hb, const f32x4& Fa, const f32x4& Fb) {
+  unsigned h, l;
+  split2(Fa[R], Fb[R], h, l);
+  if (J < 4) { hb.reFh[R][J & 3] = h; hb.reFl[R][J & 3] = l; } else { hb.imFh[R][J & 3] = h; hb.imFl[R][J & 3] = l; }
+}
+template <int J, int R>
+__device__ __forceinline__ void pack_M(Half& hb, const f32x4& Ma, const f32x4& Mb) {
+  unsigned h, l;
+  split2(Ma[R], Mb[R], h, l);
+  if (J < 4) { hb.reMh[R][J & 3] = h; hb.reMl[R][J & 3] = l; } else { hb.imMh[R][J & 3] = h; hb.imMl[R][J & 3] = l; }
+}
+template <int R>
+__device__ __forceinline__ void swap_r(Half& hb, int e0, int e1) {   // elements e0..e1-1 of the 8 operands of register R
+  for (int e = e0; e < e1; e++) {
+    swap32(hb.reFh[R], hb.imFh[R], e);
+    swap32(hb.reFl[R], hb.imFl[R], e);
+    swap32(hb.reMh[R], hb.imMh[R], e);
+    swap32(hb.reMl[R], hb.imMl[R], e);
+  }
+}
+
+__device__ __forceinline__ f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+struct Consts { u32x4 ch, cl, sh, sl; };   // A operands of one half: cos hi/lo, -sin hi/lo
+template <int HALF>
+__device__ __forceinline__ void load_consts(Consts& c, __amdgpu_buffer_rsrc_t rc, int lane16) {   // [E|O][half][hi|lo][64] x 16 B
+  c.ch = __builtin_amdgcn_raw_buffer_load_b128(rc, lane16, ((0 * 2 + HALF) * 2 + 0) * 1024, 0);
+  c.cl = __builtin_amdgcn_raw_buffer_load_b128(rc, lane16, ((0 * 2 + HALF) * 2 + 1) * 1024, 0);
+  c.sh = __builtin_amdgcn_raw_buffer_load_b128(rc, lane16, ((1 * 2 + HALF) * 2 + 0) * 1024, 0);
+  c.sl = __builtin_amdgcn_raw_buffer_load_b128(rc, lane16, ((1 * 2 + HALF) * 2 + 1) * 1024, 0);
+}
+
+// One of the 12 stage-2 MFMAs of stage-1 register R: I = 0..3 hi x hi (starts the chain in the first half),
+// 4..7 lo(constants) x hi, 8..11 hi x lo; within each four: E forward, O forward, E mirror, O mirror.
+template <bool FIRST, int R, int I>
+__device__ __forceinline__ void stage2_one(const Half& hb, const Consts& c, f32x16 (&accE)[4][2], f32x16 (&accO)[4][2],
+                                           const f32x16& zero) {
+  constexpr int V = (I >> 1) & 1, PART = I & 1, T = I >> 2;
+  const u32x4& ca = PART ? (T == 1 ? c.sl : c.sh) : (T == 1 ? c.cl : c.ch);
+  const u32x4& op = PART ? (V ? (T == 2 ? hb.imMl[R] : hb.imMh[R]) : (T == 2 ? hb.imFl[R] : hb.imFh[R]))
+                         : (V ? (T == 2 ? hb.reMl[R] : hb.reMh[R]) : (T == 2 ? hb.reFl[R] : hb.reFh[R]));
+  f32x16& acc = PART ? accO[R][V] : accE[R][V];
+  acc = mfma32(ca, op, (FIRST && T == 0) ? zero : acc);
+}
+
+// epilogue piece: shift rows e of register R -> running max over E + |O| of forward and mirror
+template <int R>
+__device__ __forceinline__ void ep_elem(float& mx, const f32x16 (&accE)[4][2], const f32x16 (&accO)[4][2], int e) {
+  const float vf = accE[R][0][e] + __builtin_fabsf(accO[R][0][e]);
+  const float vm = accE[R][1][e] + __builtin_fabsf(accO[R][1][e]);
+  mx = fmaxf(fmaxf(mx, vf), vm);
+}
+// 2 queries x 16 entries (lanes 0..31): d = (1 - max)/2 with the 2^-25 operand scaling folded in   (processSC.m:30)
+template <int R>
+__device__ __forceinline__ void ep_store(float mx, float* __restrict__ dist, int qrow0, int drow0, int m, int n, int lane) {
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  if (lane < 32) {
+    const int qrow = qrow0 + ((lane < 16) ? R : 4 + R);
+    const int drow = drow0 + (lane & 15);
+    if (qrow < m && drow < n) dist[(size_t)qrow * n + drow] = __builtin_fmaf(mx, -0x1p-26f, 0.5f);
+  }
+}
+
+#define FM2(F, M, t1, t2, r0)                                                        \
+  {                                                                                  \
+    F[r0] = __builtin_fmaf(t2[r0], sg, t1[r0]);         M[r0] = __builtin_fmaf(t2[r0], -sg, t1[r0]);         \
+    F[r0 + 1] = __builtin_fmaf(t2[r0 + 1], sg, t1[r0 + 1]); M[r0 + 1] = __builtin_fmaf(t2[r0 + 1], -sg, t1[r0 + 1]); \
+  }
+
+__global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restrict__ qpk,   // [2][QG32][4][31][1288 B]
+                                                            const char* __restrict__ dpk,   // [2][DG][31][4][768 B] + one zero group
+                                                            const u32x4* __restrict__ cst,  // [2][2][2][64] x 16 B
+                                                            float* __restrict__ dist_p, float* __restrict__ dist_i,
+                                                            int m, int n, int QG8, int DG, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int split = b % nsplit;
+  b /= nsplit;
+  const int ch = b & 1, qg32 = b >> 1;
+  const int g0 = (int)((long long)DG * split / nsplit), g1 = (int)((long long)DG * (split + 1) / nsplit);
+
+  {  // the 4 query groups of this workgroup -> LDS (linear copy; the packed image IS the LDS image) + zeroed tail
+    const u32x4* src = reinterpret_cast<const u32x4*>(qpk + ((size_t)ch * QG8 + (size_t)qg32 * 4) * SCH_QIMG);
+    u32x4* dst = reinterpret_cast<u32x4*>(lds);
+    constexpr int NV = 4 * SCH_QIMG / 16;
+    for (int i = tid; i < NV + 4; i += 256) dst[i] = (i < NV) ? src[i] : u32x4{0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+  if (g0 >= g1) return;
+
+  const int row = lane & 15, kg = lane >> 4;
+  const char* nat = lds + w * SCH_QIMG + row * 80 + (row >= 8 ? 8 : 0) + kg * 16;
+  const char* rot = lds + w * SCH_QIMG + (row ^ 8) * 80 + (row >= 8 ? 0 : 8) + kg * 16;
+  const int voff = (lane < 48) ? lane * 16 : (int)0x80000000;     // lanes 48-63: out of range -> zeros (K = 24..31)
+  const float sg = (lane < 32) ? 1.0f : -1.0f;
+  float* dist = ch ? dist_i : dist_p;
+  const char* dbase = dpk + ((size_t)ch * DG) * SCH_DIMG;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const int qrow0 = qg32 * 32 + w * 8;
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(cst), 0, 8192, 0x00020000);
+
+  // Software pipeline over the slot sequence (6 stage-1 MFMAs per frequency), per operand TILE: the DB tiles of frequency
+  // q are requested 8-12 MFMA slots ahead (Re hi, Im hi, Re lo during frequency q-2, Im lo during q-1), the query tiles 4
+  // slots ahead (during q-1); buffers rotate with period 4 (DB) and 2 (queries) over 32 positions per group, position 31
+  // being a ghost whose requests are issued by hand at the start of the stage-2 phase.  hipcc counts all these loads, so
+  // every MFMA waits with the exact vmcnt / lgkmcnt for its own operands only.  The wave issues in order, so the VALU
+  // work is placed by hand into the gaps between MFMAs and pinned with sched_barrier: the F/M combination of a
+  // frequency runs two MFMAs after its last stage-1 MFMA, the split/pack of pair J-1 under the stage-1 MFMAs of pair J,
+  // the permlane swaps of register r+1 and the epilogue of register r-1 under the 12 stage-2 MFMAs of register r.
+  AOps At[2];
+  BOps Bt[4];
+  __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)g0 * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
+  load_b<0, B_REH>(Bt[0], rs, voff); load_b<0, B_IMH>(Bt[0], rs, voff); load_b<0, B_REL>(Bt[0], rs, voff); load_b<0, B_IML>(Bt[0], rs, voff);
+  load_a<0, A_H>(At[0], nat, rot); load_a<0, A_RH>(At[0], nat, rot); load_a<0, A_L>(At[0], nat, rot); load_a<0, A_RL>(At[0], nat, rot);
+  load_b<1, B_REH>(Bt[1], rs, voff); load_b<1, B_IMH>(Bt[1], rs, voff); load_b<1, B_REL>(Bt[1], rs, voff);
+  for (int g = g0; g < g1; g++) {
+    const __amdgpu_buffer_rsrc_t rsn =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g + 1) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
+    f32x16 accE[4][2], accO[4][2];
+    Half hb;
+    Consts c;
+    f32x4 Fa, Ma, Fb, Mb, t1a, t2a, t1b, t2b;
+    float mx0, mx1, mx2, mx3;
+// request tile T of frequency Q of this group (Q >= 31: nothing - the first requests of the next group are issued by
+// hand late in the stage-2 phase, when half of the packed registers are free again)
+#define LDB(Q, T) { if ((Q) < SC_NF) load_b<((Q) < SC_NF ? (Q) : 0), T>(Bt[(Q) & 3], rs, voff); }
+#define LDA(Q, T) { if ((Q) < SC_NF) load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 1], nat, rot); }
+#define FREQ(P, t1, t2, W0, W1, W2, W3, W4, W5)                                                   \
+  {                                                                                               \
+    SB(); MF0(t1, At[(P) & 1].h, Bt[(P) & 3].reh);  SB(); LDB((P) + 1, B_IML); W0;                \
+    SB(); MF0(t2, At[(P) & 1].rh, Bt[(P) & 3].imh); SB(); LDB((P) + 2, B_REH); W1;                \
+    SB(); MFA(t1, At[(P) & 1].l, Bt[(P) & 3].reh);  SB(); LDB((P) + 2, B_IMH); LDA((P) + 1, A_H); W2;  \
+    SB(); MFA(t2, At[(P) & 1].rl, Bt[(P) & 3].imh); SB(); LDA((P) + 1, A_RH); W3;                 \
+    SB(); MFA(t1, At[(P) & 1].h, Bt[(P) & 3].rel);  SB(); LDA((P) + 1, A_L); W4;                  \
+    SB(); MFA(t2, At[(P) & 1].rh, Bt[(P) & 3].iml); SB(); LDB((P) + 2, B_REL); LDA((P) + 1, A_RL); W5; \
+    SB();                                                                                         \
+  }
+#define PK(J, R) { pack_F<J, R>(hb, Fa, Fb); pack_M<J, R>(hb, Ma, Mb); }
+#define NONE ((void)0)
+// pair J of half H with the pending work of pair J-1: F/M of its second frequency, its four split/pack pieces
+#define PAIR0(H)                                                                                  \
+  FREQ(16 * (H), t1a, t2a, NONE, NONE, NONE, NONE, NONE, NONE)                                    \
+  FREQ(16 * (H) + 1, t1b, t2b, NONE, NONE, FM2(Fa, Ma, t1a, t2a, 0), FM2(Fa, Ma, t1a, t2a, 2), NONE, NONE)
+#define PAIR(H, J)                                                                                \
+  FREQ(16 * (H) + 2 * (J), t1a, t2a, NONE, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PK((J) - 1, 0), PK((J) - 1, 1)) \
+  FREQ(16 * (H) + 2 * (J) + 1, t1b, t2b, PK((J) - 1, 2), PK((J) - 1, 3), FM2(Fa, Ma, t1a, t2a, 0), FM2(Fa, Ma, t1a, t2a, 2), NONE, NONE)
+// the 12 stage-2 MFMAs of register R with the VALU pieces W0..W11 in their gaps
+#define S2(FIRST, R, W0, W1, W2, W3, W4, W5, W6, W7, W8, W9, W10, W11)                             \
+  { stage2_one<FIRST, R, 0>(hb, c, accE, accO, zero); SB(); W0; SB();                             \
+    stage2_one<FIRST, R, 1>(hb, c, accE, accO, zero); SB(); W1; SB();                             \
+    stage2_one<FIRST, R, 2>(hb, c, accE, accO, zero); SB(); W2; SB();                             \
+    stage2_one<FIRST, R, 3>(hb, c, accE, accO, zero); SB(); W3; SB();                             \
+    stage2_one<FIRST, R, 4>(hb, c, accE, accO, zero); SB(); W4; SB();                             \
+    stage2_one<FIRST, R, 5>(hb, c, accE, accO, zero); SB(); W5; SB();                             \
+    stage2_one<FIRST, R, 6>(hb, c, accE, accO, zero); SB(); W6; SB();                             \
+    stage2_one<FIRST, R, 7>(hb, c, accE, accO, zero); SB(); W7; SB();                             \
+    stage2_one<FIRST, R, 8>(hb, c, accE, accO, zero); SB(); W8; SB();                             \
+    stage2_one<FIRST, R, 9>(hb, c, accE, accO, zero); SB(); W9; SB();                             \
+    stage2_one<FIRST, R, 10>(hb, c, accE, accO, zero); SB(); W10; SB();                           \
+    stage2_one<FIRST, R, 11>(hb, c, accE, accO, zero); SB(); W11; SB(); }
+
+    // ---------------------------------------------------------------- first half: frequencies 0..15
+    PAIR0(0) PAIR(0, 1) PAIR(0, 2) PAIR(0, 3) PAIR(0, 4) PAIR(0, 5) PAIR(0, 6) PAIR(0, 7)
+    DRAIN();
+    SB();
+    FM2(Fb, Mb, t1b, t2b, 0); FM2(Fb, Mb, t1b, t2b, 2);
+    PK(7, 0) PK(7, 1) PK(7, 2) PK(7, 3)
+    SB();
+    load_consts<0>(c, rc, lane * 16);
+    swap_r<0>(hb, 0, 4);
+    SB();
+    S2(true, 0, swap_r<1>(hb, 0, 1), NONE, swap_r<1>(hb, 1, 2), NONE, swap_r<1>(hb, 2, 3), NONE, swap_r<1>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
+    S2(true, 1, swap_r<2>(hb, 0, 1), NONE, swap_r<2>(hb, 1, 2), NONE, swap_r<2>(hb, 2, 3), NONE, swap_r<2>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
+    S2(true, 2, swap_r<3>(hb, 0, 1), NONE, swap_r<3>(hb, 1, 2), NONE, swap_r<3>(hb, 2, 3), NONE, swap_r<3>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
+    S2(true, 3, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE)
+    // ---------------------------------------------------------------- second half: frequencies 16..30
+    PAIR0(1) PAIR(1, 1) PAIR(1, 2) PAIR(1, 3) PAIR(1, 4) PAIR(1, 5) PAIR(1, 6)
+    FREQ(30, t1a, t2a, NONE, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PK(6, 0), PK(6, 1))
+    PK(6, 2) PK(6, 3)
+    DRAIN();
+    SB();
+    FM2(Fa, Ma, t1a, t2a, 0); FM2(Fa, Ma, t1a, t2a, 2);
+    Fb = f32x4{0.f, 0.f, 0.f, 0.f}; Mb = Fb;
+    PK(7, 0) PK(7, 1) PK(7, 2) PK(7, 3)
+    SB();
+    load_consts<1>(c, rc, lane * 16);
+    swap_r<0>(hb, 0, 4);
+    SB();
+    S2(false, 0, swap_r<1>(hb, 0, 1), NONE, swap_r<1>(hb, 1, 2), NONE, swap_r<1>(hb, 2, 3), NONE, swap_r<1>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
+    mx0 = -__builtin_inff();
+#define EP(R, mx, e) ep_elem<R>(mx, accE, accO, e)
+    S2(false, 1, swap_r<2>(hb, 0, 1), EP(0, mx0, 0), swap_r<2>(hb, 1, 2), EP(0, mx0, 1), swap_r<2>(hb, 2, 3), EP(0, mx0, 2), swap_r<2>(hb, 3, 4),
+       (EP(0, mx0, 3), EP(0, mx0, 4)), (EP(0, mx0, 5), EP(0, mx0, 6), EP(0, mx0, 7)), (EP(0, mx0, 8), EP(0, mx0, 9), EP(0, mx0, 10)),
+       (EP(0, mx0, 11), EP(0, mx0, 12), EP(0, mx0, 13)), (EP(0, mx0, 14), EP(0, mx0, 15)))
+    ep_store<0>(mx0, dist, qrow0, g * 16, m, n, lane);
+    mx1 = -__builtin_inff();
+    S2(false, 2, swap_r<3>(hb, 0, 1), EP(1, mx1, 0), swap_r<3>(hb, 1, 2), EP(1, mx1, 1), swap_r<3>(hb, 2, 3), EP(1, mx1, 2), swap_r<3>(hb, 3, 4),
+       (EP(1, mx1, 3), EP(1, mx1, 4)), (EP(1, mx1, 5), EP(1, mx1, 6), EP(1, mx1, 7)), (EP(1, mx1, 8), EP(1, mx1, 9), EP(1, mx1, 10)),
+       (EP(1, mx1, 11), EP(1, mx1, 12), EP(1, mx1, 13)), (EP(1, mx1, 14), EP(1, mx1, 15)))
+    // first requests of the next group (what the frequencies "-2" and "-1" would have issued)
+#define NB(P, T) load_b<P, T>(Bt[P], rsn, voff)
+#define NA(T) load_a<0, T>(At[0], nat, rot)
+    ep_store<1>(mx1, dist, qrow0, g * 16, m, n, lane);
+    mx2 = -__builtin_inff();
+    S2(false, 3, (NB(0, B_REH), EP(2, mx2, 0)), (NB(0, B_IMH), EP(2, mx2, 1)), (NB(0, B_REL), EP(2, mx2, 2)), (NB(0, B_IML), EP(2, mx2, 3)),
+       (NB(1, B_REH), EP(2, mx2, 4), EP(2, mx2, 5)), (NB(1, B_IMH), EP(2, mx2, 6), EP(2, mx2, 7)), (NB(1, B_REL), EP(2, mx2, 8), EP(2, mx2, 9)),
+       (NA(A_H), EP(2, mx2, 10), EP(2, mx2, 11)), (NA(A_RH), EP(2, mx2, 12), EP(2, mx2, 13)), (NA(A_L), EP(2, mx2, 14), EP(2, mx2, 15)), NA(A_RL), NONE)
+    ep_store<2>(mx2, dist, qrow0, g * 16, m, n, lane);
+    mx3 = -__builtin_inff();
+#pragma unroll
+    for (int e = 0; e < 16; e++) EP(3, mx3, e);
+    ep_store<3>(mx3, dist, qrow0, g * 16, m, n, lane);
+    rs = rsn;
+  }
+}
+
+}  // namespace
+
+size_t sc_match_h_lds_bytes() { return (size_t)4 * SCH_QIMG + 64; }
+
+void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p,
+                       float* d_i, int nsplit_override) {
+  if (m <= 0 || n <= 0) return;
+  const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n);
+  const int base = (QG8 / 4) * 2;
+  int nsplit = (1024 + base - 1) / base;           // >= ~4 workgroups per CU in total, for tail balance
+  if (nsplit > DG / 8) nsplit = DG / 8;            // keep >= 8 DB groups (128 entries) per workgroup
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit_override > 0) nsplit = nsplit_override < DG ? nsplit_override : DG;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_match_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sc_match_h_lds_bytes());
+  hipLaunchKernelGGL(sc_match_h_kernel, dim3(base * nsplit), dim3(256), sc_match_h_lds_bytes(), st,
+                     static_cast<const char*>(qpk), static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i,
+                     m, n, QG8, DG, nsplit);
+}
+
+}  // namespace pr

@@ -70,7 +70,84 @@ __global__ __launch_bounds__(256) void sc_pack_kernel(const T* __restrict__ sig,
   }
 }
 
+
+// Split-f16 images for sc_match_h.hip: every spectrum value x (queries scaled by 2^8, DB by 2^7) is stored as
+// hi = f16(x), lo = f16(x - hi).
+//   query image  [ch][group of 8][f = 0..30]{ 16 rows x 80 B: Qhi ring 0..19 | Qlo ring 0..19 }, row = (Im<<3) | e,
+//                rows 8..15 shifted by 8 B (LDS bank spread), 1288 B per frequency
+//   DB image     [ch][group of 16][f = 0..30][Re hi | Re lo | Im hi | Im lo]{ 768 B: lane = (ring>>3)<<4 | j, 16 B per
+//                lane = rings 8g..8g+7; rings 20..23 stay zero }
+template <typename T>
+__global__ __launch_bounds__(256) void sc_pack_h_kernel(const T* __restrict__ sig, int rows, int role,
+                                                         unsigned short* __restrict__ packed, int groups,
+                                                         const double* __restrict__ tw, int* __restrict__ flags) {
+  __shared__ double x[1200];
+  __shared__ double red[256];
+  __shared__ double tws[120];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x >> 1, ch = blockIdx.x & 1;
+  const T* src = sig + (size_t)row * 2400 + ch * 1200;
+  double part = 0.0;
+  for (int i = tid; i < 1200; i += 256) {
+    double v = (double)src[i];
+    x[i] = v;
+    part += v * v;
+  }
+  if (tid < 120) tws[tid] = tw[tid];
+  red[tid] = part;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const double nr = sqrt(red[0]);
+  if (!(nr > 0.0) && tid == 0) atomicOr(flags, 1);   // MATLAB would produce a NaN row
+  for (int i = tid; i < 1200; i += 256) x[i] = x[i] / nr;   // processSC.m:16,19
+  __syncthreads();
+  const double scale = 0.12909944487358055 * (role == 0 ? 256.0 : 128.0);  // 1/sqrt(60) x 2^8 | 2^7
+  for (int o = tid; o < SC_NF * 40; o += 256) {
+    const int f = o / 40, rem = o - f * 40, ring = rem >> 1, im = rem & 1;
+    double acc = 0.0;
+    int t = 0;  // (f*s) mod 60
+    for (int s = 0; s < 60; s++) {
+      const double w = im ? -tws[60 + t] : tws[t];
+      acc += x[s * 20 + ring] * w;
+      t += f;
+      if (t >= 60) t -= 60;
+    }
+    const double val = acc * scale;
+    const _Float16 hi = (_Float16)val;
+    const _Float16 lo = (_Float16)(val - (double)hi);
+    size_t bh, bl;   // byte offsets of hi and lo
+    if (role == 0) {
+      const int g = row >> 3, rr = (im << 3) | (row & 7);
+      const size_t base = ((size_t)ch * groups + g) * SCH_QIMG + (size_t)f * SCH_QBLK + rr * 80 + (rr >= 8 ? 8 : 0);
+      bh = base + ring * 2;
+      bl = base + 40 + ring * 2;
+    } else {
+      const int g = row >> 4, j = row & 15;
+      const size_t base = ((size_t)ch * groups + g) * SCH_DIMG + (size_t)f * SCH_DFREQ + (size_t)im * 2 * SCH_DTILE +
+                          (((ring >> 3) << 4) | j) * 16 + (ring & 7) * 2;
+      bh = base;
+      bl = base + SCH_DTILE;
+    }
+    packed[bh >> 1] = __builtin_bit_cast(unsigned short, hi);
+    packed[bl >> 1] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
 }  // namespace
+
+void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
+                      const double* twiddle, int* flags) {
+  if (rows <= 0) return;
+  if (dtype == 0)
+    hipLaunchKernelGGL(sc_pack_h_kernel<double>, dim3(rows * 2), dim3(256), 0, st, (const double*)sig, rows, role,
+                       (unsigned short*)packed, groups, twiddle, flags);
+  else
+    hipLaunchKernelGGL(sc_pack_h_kernel<float>, dim3(rows * 2), dim3(256), 0, st, (const float*)sig, rows, role,
+                       (unsigned short*)packed, groups, twiddle, flags);
+}
 
 void launch_sc_pack(hipStream_t st, const void* sig, int dtype, int rows, int role, float* packed, int groups,
                     const double* twiddle, int* flags) {

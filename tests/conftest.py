@@ -16,3 +16,16 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _torch_first():
+    """On a GPU box bring torch's HIP runtime up before libpr_amd.so loads its own copy (the documented order:
+    torch owns device memory and streams, the library is loaded next to it)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
+    yield
