@@ -45,15 +45,18 @@ struct BOps { u32x4 reh, rel, imh, iml; };    // DB column operands: Re hi, Re l
 // one operand tile (4 registers) per call, so that every request can be placed in its own MFMA gap
 enum { A_H = 0, A_L = 1, A_RH = 2, A_RL = 3 };
 enum { B_REH = 0, B_REL = 1, B_IMH = 2, B_IML = 3 };
+// nat / rot: 32-bit LDS byte addresses of this lane's 16 B in the block of frequency (P & ~1); the odd frequency of the
+// pair and the lo tile are immediate offsets of the ds_read2_b64 (8-bit, in units of 8 B: 1288 + 40 + 8 < 2048)
+typedef const u32x4_a8 __attribute__((address_space(3))) * lds_tile_p;
 template <int P, int T>
-__device__ __forceinline__ void load_a(AOps& a, const char* __restrict__ nat, const char* __restrict__ rot) {
-  const char* src = ((T & 2) ? rot : nat) + P * SCH_QBLK + (T & 1) * 40;
-  const u32x4 v = *reinterpret_cast<const u32x4_a8*>(src);
+__device__ __forceinline__ void load_a(AOps& a, unsigned nat, unsigned rot) {
+  const unsigned addr = ((T & 2) ? rot : nat) + (P & 1) * SCH_QBLK + (T & 1) * 40;
+  const u32x4 v = *reinterpret_cast<lds_tile_p>(addr);
   if (T == A_H) a.h = v; else if (T == A_L) a.l = v; else if (T == A_RH) a.rh = v; else a.rl = v;
 }
 template <int P, int T>
 __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int voff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, P * SCH_DFREQ + T * SCH_DTILE, 0);
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + T * SCH_DTILE, P * SCH_DFREQ, 0);   // tile offset folds into the instruction
   if (T == B_REH) b.reh = v; else if (T == B_REL) b.rel = v; else if (T == B_IMH) b.imh = v; else b.iml = v;
 }
 
@@ -66,6 +69,11 @@ __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int v
 #define MFA(d, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b))
 #define DRAIN() asm volatile("s_nop 9")
 #define SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef PR_SCH_TIMING
+#define TICK(i) { SB(); unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)); tacc[i] += _t - tprev; tprev = _t; SB(); }
+#else
+#define TICK(i)
+#endif
 
 // (hi, lo) split of two fp32 values into packed f16 pairs: lo = x - hi exactly (fp32), rounded to f16
 __device__ __forceinline__ void split2(float x, float y, unsigned& hi, unsigned& lo) {
@@ -146,21 +154,22 @@ __device__ __forceinline__ void ep_elem(float& mx, const f32x16 (&accE)[4][2], c
   const float vm = accE[R][1][e] + __builtin_fabsf(accO[R][1][e]);
   mx = fmaxf(fmaxf(mx, vf), vm);
 }
-// 2 queries x 16 entries (lanes 0..31): d = (1 - max)/2 with the 2^-25 operand scaling folded in   (processSC.m:30)
+// 2 queries x 16 entries (lanes 0..31): d = (1 - max)/2 with the 2^-25 operand scaling folded in   (processSC.m:30).
+// Branch-free (a buffer store whose invalid lanes are out of range), so that the whole group body stays ONE basic block
+// and the hand-placed order survives the compiler's sinking passes.
 template <int R>
-__device__ __forceinline__ void ep_store(float mx, float* __restrict__ dist, int qrow0, int drow0, int m, int n, int lane) {
-  mx = fmaxf(mx, __shfl_xor(mx, 32));
-  if (lane < 32) {
-    const int qrow = qrow0 + ((lane < 16) ? R : 4 + R);
-    const int drow = drow0 + (lane & 15);
-    if (qrow < m && drow < n) dist[(size_t)qrow * n + drow] = __builtin_fmaf(mx, -0x1p-26f, 0.5f);
-  }
+__device__ __forceinline__ void ep_store(float mx, __amdgpu_buffer_rsrc_t rd, int st_off) {
+  const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+  mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));     // max over the two lane halves (shift rows +0..3 | +4..7)
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(mx, -0x1p-26f, 0.5f)), rd, st_off, R * 0, 0);
 }
 
+// F = T1 + s T2, M = T1 - s T2 for registers r0, r0+1: two v_pk_fma_f32
 #define FM2(F, M, t1, t2, r0)                                                        \
   {                                                                                  \
-    F[r0] = __builtin_fmaf(t2[r0], sg, t1[r0]);         M[r0] = __builtin_fmaf(t2[r0], -sg, t1[r0]);         \
-    F[r0 + 1] = __builtin_fmaf(t2[r0 + 1], sg, t1[r0 + 1]); M[r0 + 1] = __builtin_fmaf(t2[r0 + 1], -sg, t1[r0 + 1]); \
+    const f32x2 _a = {t1[r0], t1[r0 + 1]}, _b = {t2[r0], t2[r0 + 1]};                \
+    const f32x2 _f = __builtin_elementwise_fma(_b, sg2, _a), _m = __builtin_elementwise_fma(_b, -sg2, _a); \
+    F[r0] = _f[0]; F[r0 + 1] = _f[1]; M[r0] = _m[0]; M[r0 + 1] = _m[1];             \
   }
 
 __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restrict__ qpk,   // [2][QG32][4][31][1288 B]
@@ -171,11 +180,14 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  int b = blockIdx.x;
-  const int split = b % nsplit;
-  b /= nsplit;
-  const int ch = b & 1, qg32 = b >> 1;
-  const int g0 = (int)((long long)DG * split / nsplit), g1 = (int)((long long)DG * (split + 1) / nsplit);
+  // XCD-aware mapping (workgroups go round-robin to the 8 XCDs, each with its own L2): all workgroups of one XCD work
+  // on ONE channel and on the same quarter of the DB ranges, consecutive workgroups of an XCD on consecutive 32-query
+  // blocks - so the ~32 resident workgroups of an XCD sweep the same DB range together and share it through that L2.
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int ch = xcd & 1;
+  const int range = (xcd >> 1) + 4 * (idx % nsplit), qg32 = idx / nsplit;      // nsplit = ranges per XCD slice
+  const int nrange = 4 * nsplit;
+  const int g0 = (int)((long long)DG * range / nrange), g1 = (int)((long long)DG * (range + 1) / nrange);
 
   {  // the 4 query groups of this workgroup -> LDS (linear copy; the packed image IS the LDS image) + zeroed tail
     const u32x4* src = reinterpret_cast<const u32x4*>(qpk + ((size_t)ch * QG8 + (size_t)qg32 * 4) * SCH_QIMG);
@@ -187,14 +199,23 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   if (g0 >= g1) return;
 
   const int row = lane & 15, kg = lane >> 4;
-  const char* nat = lds + w * SCH_QIMG + row * 80 + (row >= 8 ? 8 : 0) + kg * 16;
-  const char* rot = lds + w * SCH_QIMG + (row ^ 8) * 80 + (row >= 8 ? 0 : 8) + kg * 16;
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds;
+  const unsigned nat0 = lds0 + w * SCH_QIMG + row * 80 + (row >= 8 ? 8 : 0) + kg * 16;
+  const unsigned rot0 = lds0 + w * SCH_QIMG + (row ^ 8) * 80 + (row >= 8 ? 0 : 8) + kg * 16;
   const int voff = (lane < 48) ? lane * 16 : (int)0x80000000;     // lanes 48-63: out of range -> zeros (K = 24..31)
   const float sg = (lane < 32) ? 1.0f : -1.0f;
+  const f32x2 sg2 = {sg, sg};
   float* dist = ch ? dist_i : dist_p;
   const char* dbase = dpk + ((size_t)ch * DG) * SCH_DIMG;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const int qrow0 = qg32 * 32 + w * 8;
+  // distances of this wave's 8 query rows: byte offset = ((local row) * n + entry) * 4; local row = R (lanes 0-15) or 4 + R (16-31)
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+      dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 8 ? m - qrow0 : 8) : 0) * n * 4, 0x00020000);
+  const int st_lane = ((lane & 16) ? 4 * n : 0) * 4 + (lane & 15) * 4;
+  const int pf_slot = (qg32 & 31) * 4 + w;                                  // 0..127
+  const int pf_off = (lane < 6) ? (pf_slot * 6 + lane) * 128 : (int)0x80000000;   // lines past the group are out of range
+  unsigned pf_sink = 0;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(cst), 0, 8192, 0x00020000);
 
   // Software pipeline over the slot sequence (6 stage-1 MFMAs per frequency), per operand TILE: the DB tiles of frequency
@@ -205,13 +226,18 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   // work is placed by hand into the gaps between MFMAs and pinned with sched_barrier: the F/M combination of a
   // frequency runs two MFMAs after its last stage-1 MFMA, the split/pack of pair J-1 under the stage-1 MFMAs of pair J,
   // the permlane swaps of register r+1 and the epilogue of register r-1 under the 12 stage-2 MFMAs of register r.
-  AOps At[2];
+  AOps At[4];
   BOps Bt[4];
   __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)g0 * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
   load_b<0, B_REH>(Bt[0], rs, voff); load_b<0, B_IMH>(Bt[0], rs, voff); load_b<0, B_REL>(Bt[0], rs, voff); load_b<0, B_IML>(Bt[0], rs, voff);
-  load_a<0, A_H>(At[0], nat, rot); load_a<0, A_RH>(At[0], nat, rot); load_a<0, A_L>(At[0], nat, rot); load_a<0, A_RL>(At[0], nat, rot);
+  load_a<0, A_H>(At[0], nat0, rot0); load_a<0, A_RH>(At[0], nat0, rot0); load_a<0, A_L>(At[0], nat0, rot0); load_a<0, A_RL>(At[0], nat0, rot0);
   load_b<1, B_REH>(Bt[1], rs, voff); load_b<1, B_IMH>(Bt[1], rs, voff); load_b<1, B_REL>(Bt[1], rs, voff);
+  load_a<1, A_H>(At[1], nat0, rot0); load_a<1, A_RH>(At[1], nat0, rot0);
+#ifdef PR_SCH_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev));
+#endif
   for (int g = g0; g < g1; g++) {
     const __amdgpu_buffer_rsrc_t rsn =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g + 1) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
@@ -219,28 +245,34 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
     Half hb;
     Consts c;
     f32x4 Fa, Ma, Fb, Mb, t1a, t2a, t1b, t2b;
-    float mx0, mx1, mx2, mx3;
+    unsigned ncur, rcur, nnxt = nat0, rnxt = rot0;
+    TICK(7)
 // request tile T of frequency Q of this group (Q >= 31: nothing - the first requests of the next group are issued by
 // hand late in the stage-2 phase, when half of the packed registers are free again)
 #define LDB(Q, T) { if ((Q) < SC_NF) load_b<((Q) < SC_NF ? (Q) : 0), T>(Bt[(Q) & 3], rs, voff); }
-#define LDA(Q, T) { if ((Q) < SC_NF) load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 1], nat, rot); }
+#define LDA(P, Q, T) { if ((Q) < SC_NF) { if (((Q) >> 1) == ((P) >> 1)) load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], ncur, rcur); \
+                                        else load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], nnxt, rnxt); } }
 #define FREQ(P, t1, t2, W0, W1, W2, W3, W4, W5)                                                   \
   {                                                                                               \
-    SB(); MF0(t1, At[(P) & 1].h, Bt[(P) & 3].reh);  SB(); LDB((P) + 1, B_IML); W0;                \
-    SB(); MF0(t2, At[(P) & 1].rh, Bt[(P) & 3].imh); SB(); LDB((P) + 2, B_REH); W1;                \
-    SB(); MFA(t1, At[(P) & 1].l, Bt[(P) & 3].reh);  SB(); LDB((P) + 2, B_IMH); LDA((P) + 1, A_H); W2;  \
-    SB(); MFA(t2, At[(P) & 1].rl, Bt[(P) & 3].imh); SB(); LDA((P) + 1, A_RH); W3;                 \
-    SB(); MFA(t1, At[(P) & 1].h, Bt[(P) & 3].rel);  SB(); LDA((P) + 1, A_L); W4;                  \
-    SB(); MFA(t2, At[(P) & 1].rh, Bt[(P) & 3].iml); SB(); LDB((P) + 2, B_REL); LDA((P) + 1, A_RL); W5; \
+    SB(); MF0(t1, At[(P) & 3].h, Bt[(P) & 3].reh);  SB(); LDB((P) + 1, B_IML); LDA(P, (P) + 1, A_L); W0;   \
+    SB(); MF0(t2, At[(P) & 3].rh, Bt[(P) & 3].imh); SB(); LDB((P) + 2, B_REH); LDA(P, (P) + 1, A_RL); W1;  \
+    SB(); MFA(t1, At[(P) & 3].l, Bt[(P) & 3].reh);  SB(); LDB((P) + 2, B_IMH); W2;                \
+    SB(); MFA(t2, At[(P) & 3].rl, Bt[(P) & 3].imh); SB(); W3;                                     \
+    SB(); MFA(t1, At[(P) & 3].h, Bt[(P) & 3].rel);  SB(); LDA(P, (P) + 2, A_H); W4;                  \
+    SB(); MFA(t2, At[(P) & 3].rh, Bt[(P) & 3].iml); SB(); LDB((P) + 2, B_REL); LDA(P, (P) + 2, A_RH); W5;  \
     SB();                                                                                         \
   }
 #define PK(J, R) { pack_F<J, R>(hb, Fa, Fb); pack_M<J, R>(hb, Ma, Mb); }
 #define NONE ((void)0)
 // pair J of half H with the pending work of pair J-1: F/M of its second frequency, its four split/pack pieces
+// LDS bases of this lane's tiles: current pair and next pair (one opaque add per pair and operand kind)
+#define ADV() { ncur = nnxt; rcur = rnxt; nnxt = ncur + 2 * SCH_QBLK; rnxt = rcur + 2 * SCH_QBLK; asm("" : "+v"(nnxt)); asm("" : "+v"(rnxt)); }
 #define PAIR0(H)                                                                                  \
+  ADV()                                                                                           \
   FREQ(16 * (H), t1a, t2a, NONE, NONE, NONE, NONE, NONE, NONE)                                    \
   FREQ(16 * (H) + 1, t1b, t2b, NONE, NONE, FM2(Fa, Ma, t1a, t2a, 0), FM2(Fa, Ma, t1a, t2a, 2), NONE, NONE)
 #define PAIR(H, J)                                                                                \
+  ADV()                                                                                           \
   FREQ(16 * (H) + 2 * (J), t1a, t2a, NONE, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PK((J) - 1, 0), PK((J) - 1, 1)) \
   FREQ(16 * (H) + 2 * (J) + 1, t1b, t2b, PK((J) - 1, 2), PK((J) - 1, 3), FM2(Fa, Ma, t1a, t2a, 0), FM2(Fa, Ma, t1a, t2a, 2), NONE, NONE)
 // the 12 stage-2 MFMAs of register R with the VALU pieces W0..W11 in their gaps
@@ -260,6 +292,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
 
     // ---------------------------------------------------------------- first half: frequencies 0..15
     PAIR0(0) PAIR(0, 1) PAIR(0, 2) PAIR(0, 3) PAIR(0, 4) PAIR(0, 5) PAIR(0, 6) PAIR(0, 7)
+    TICK(0)
     DRAIN();
     SB();
     FM2(Fb, Mb, t1b, t2b, 0); FM2(Fb, Mb, t1b, t2b, 2);
@@ -268,14 +301,18 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
     load_consts<0>(c, rc, lane * 16);
     swap_r<0>(hb, 0, 4);
     SB();
+    TICK(1)
     S2(true, 0, swap_r<1>(hb, 0, 1), NONE, swap_r<1>(hb, 1, 2), NONE, swap_r<1>(hb, 2, 3), NONE, swap_r<1>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
     S2(true, 1, swap_r<2>(hb, 0, 1), NONE, swap_r<2>(hb, 1, 2), NONE, swap_r<2>(hb, 2, 3), NONE, swap_r<2>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
     S2(true, 2, swap_r<3>(hb, 0, 1), NONE, swap_r<3>(hb, 1, 2), NONE, swap_r<3>(hb, 2, 3), NONE, swap_r<3>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
     S2(true, 3, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE)
+    TICK(2)
     // ---------------------------------------------------------------- second half: frequencies 16..30
     PAIR0(1) PAIR(1, 1) PAIR(1, 2) PAIR(1, 3) PAIR(1, 4) PAIR(1, 5) PAIR(1, 6)
+    ADV()
     FREQ(30, t1a, t2a, NONE, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PK(6, 0), PK(6, 1))
     PK(6, 2) PK(6, 3)
+    TICK(3)
     DRAIN();
     SB();
     FM2(Fa, Ma, t1a, t2a, 0); FM2(Fa, Ma, t1a, t2a, 2);
@@ -283,34 +320,41 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
     PK(7, 0) PK(7, 1) PK(7, 2) PK(7, 3)
     SB();
     load_consts<1>(c, rc, lane * 16);
+    {  // L2 prefetch of group g + 2 for the whole XCD: this wave's 6 of its 744 cache lines (1/128 of the group), one
+       // dword per line into a register nobody reads before the same point of the next group.  The ~128 waves that sweep
+       // this range on this XCD cover the group between them, so the demand loads two groups later hit the L2 instead of
+       // paying HBM latency in the middle of the in-order load queue.
+      asm volatile("" : : "v"(pf_sink));
+      const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(dbase + (size_t)(g + 2) * SCH_DIMG), 0, (g + 2 < DG) ? SCH_DIMG : 0, 0x00020000);
+      pf_sink = __builtin_amdgcn_raw_buffer_load_b32(rp, pf_off, 0, 0);
+    }
     swap_r<0>(hb, 0, 4);
     SB();
-    S2(false, 0, swap_r<1>(hb, 0, 1), NONE, swap_r<1>(hb, 1, 2), NONE, swap_r<1>(hb, 2, 3), NONE, swap_r<1>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
-    mx0 = -__builtin_inff();
-#define EP(R, mx, e) ep_elem<R>(mx, accE, accO, e)
-    S2(false, 1, swap_r<2>(hb, 0, 1), EP(0, mx0, 0), swap_r<2>(hb, 1, 2), EP(0, mx0, 1), swap_r<2>(hb, 2, 3), EP(0, mx0, 2), swap_r<2>(hb, 3, 4),
-       (EP(0, mx0, 3), EP(0, mx0, 4)), (EP(0, mx0, 5), EP(0, mx0, 6), EP(0, mx0, 7)), (EP(0, mx0, 8), EP(0, mx0, 9), EP(0, mx0, 10)),
-       (EP(0, mx0, 11), EP(0, mx0, 12), EP(0, mx0, 13)), (EP(0, mx0, 14), EP(0, mx0, 15)))
-    ep_store<0>(mx0, dist, qrow0, g * 16, m, n, lane);
-    mx1 = -__builtin_inff();
-    S2(false, 2, swap_r<3>(hb, 0, 1), EP(1, mx1, 0), swap_r<3>(hb, 1, 2), EP(1, mx1, 1), swap_r<3>(hb, 2, 3), EP(1, mx1, 2), swap_r<3>(hb, 3, 4),
-       (EP(1, mx1, 3), EP(1, mx1, 4)), (EP(1, mx1, 5), EP(1, mx1, 6), EP(1, mx1, 7)), (EP(1, mx1, 8), EP(1, mx1, 9), EP(1, mx1, 10)),
-       (EP(1, mx1, 11), EP(1, mx1, 12), EP(1, mx1, 13)), (EP(1, mx1, 14), EP(1, mx1, 15)))
-    // first requests of the next group (what the frequencies "-2" and "-1" would have issued)
+    TICK(4)
+    // (v_accvgpr_read next to in-flight MFMAs costs ~25 cycles each, so the epilogue is NOT interleaved with stage 2)
 #define NB(P, T) load_b<P, T>(Bt[P], rsn, voff)
-#define NA(T) load_a<0, T>(At[0], nat, rot)
-    ep_store<1>(mx1, dist, qrow0, g * 16, m, n, lane);
-    mx2 = -__builtin_inff();
-    S2(false, 3, (NB(0, B_REH), EP(2, mx2, 0)), (NB(0, B_IMH), EP(2, mx2, 1)), (NB(0, B_REL), EP(2, mx2, 2)), (NB(0, B_IML), EP(2, mx2, 3)),
-       (NB(1, B_REH), EP(2, mx2, 4), EP(2, mx2, 5)), (NB(1, B_IMH), EP(2, mx2, 6), EP(2, mx2, 7)), (NB(1, B_REL), EP(2, mx2, 8), EP(2, mx2, 9)),
-       (NA(A_H), EP(2, mx2, 10), EP(2, mx2, 11)), (NA(A_RH), EP(2, mx2, 12), EP(2, mx2, 13)), (NA(A_L), EP(2, mx2, 14), EP(2, mx2, 15)), NA(A_RL), NONE)
-    ep_store<2>(mx2, dist, qrow0, g * 16, m, n, lane);
-    mx3 = -__builtin_inff();
-#pragma unroll
-    for (int e = 0; e < 16; e++) EP(3, mx3, e);
-    ep_store<3>(mx3, dist, qrow0, g * 16, m, n, lane);
+#define NA(P, T) load_a<P, T>(At[P], nat0, rot0)
+    S2(false, 0, swap_r<1>(hb, 0, 1), NONE, swap_r<1>(hb, 1, 2), NONE, swap_r<1>(hb, 2, 3), NONE, swap_r<1>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
+    S2(false, 1, swap_r<2>(hb, 0, 1), NONE, swap_r<2>(hb, 1, 2), NONE, swap_r<2>(hb, 2, 3), NONE, swap_r<2>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
+    S2(false, 2, swap_r<3>(hb, 0, 1), NONE, swap_r<3>(hb, 1, 2), NONE, swap_r<3>(hb, 2, 3), NONE, swap_r<3>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
+    // first requests of the next group (what its frequencies "-2" and "-1" would have issued)
+    S2(false, 3, NB(0, B_REH), NB(0, B_IMH), NB(0, B_REL), NB(0, B_IML), NB(1, B_REH), NB(1, B_IMH), NB(1, B_REL),
+       NA(0, A_H), NA(0, A_RH), NA(0, A_L), (NA(0, A_RL), NA(1, A_H)), NA(1, A_RH))
+    TICK(5)
+#define EPILOGUE(R)                                                                               \
+  { const int st_base = (lane < 32 && g * 16 + (lane & 15) < n) ? st_lane : (int)0x80000000;      \
+    float mx = -__builtin_inff();                                                                 \
+    _Pragma("unroll") for (int e = 0; e < 16; e++) ep_elem<R>(mx, accE, accO, e);                 \
+    ep_store<R>(mx, rd, st_base + (R) * 4 * n + g * 64); }
+    EPILOGUE(0) EPILOGUE(1) EPILOGUE(2) EPILOGUE(3)
+    TICK(6)
     rs = rsn;
   }
+#ifdef PR_SCH_TIMING
+  if (blockIdx.x == 8 * 40 && tid == 0)   // one wave somewhere in the middle of the grid; written over the first distances
+    for (int i = 0; i < 8; i++) reinterpret_cast<unsigned long long*>(dist_p)[i] = tacc[i] / (unsigned long long)(g1 - g0);
+#endif
 }
 
 }  // namespace
@@ -321,14 +365,15 @@ void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, 
                        float* d_i, int nsplit_override) {
   if (m <= 0 || n <= 0) return;
   const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n);
-  const int base = (QG8 / 4) * 2;
-  int nsplit = (1024 + base - 1) / base;           // >= ~4 workgroups per CU in total, for tail balance
-  if (nsplit > DG / 8) nsplit = DG / 8;            // keep >= 8 DB groups (128 entries) per workgroup
+  const int QG32 = QG8 / 4;
+  // grid = 8 XCD slices (channel x quarter of the ranges) x QG32 query blocks x nsplit ranges per slice
+  int nsplit = (128 + QG32 - 1) / QG32;            // >= ~4 workgroups per CU in total, for tail balance
+  if (nsplit > DG / 32) nsplit = DG / 32;          // keep >= 8 DB groups (128 entries) per workgroup
   if (nsplit < 1) nsplit = 1;
-  if (nsplit_override > 0) nsplit = nsplit_override < DG ? nsplit_override : DG;
+  if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_match_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sc_match_h_lds_bytes());
-  hipLaunchKernelGGL(sc_match_h_kernel, dim3(base * nsplit), dim3(256), sc_match_h_lds_bytes(), st,
+  hipLaunchKernelGGL(sc_match_h_kernel, dim3(8 * QG32 * nsplit), dim3(256), sc_match_h_lds_bytes(), st,
                      static_cast<const char*>(qpk), static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i,
                      m, n, QG8, DG, nsplit);
 }
