@@ -15,7 +15,7 @@ F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpr_amd.so")
+LIB_PATH = os.environ.get("PR_AMD_LIB") or os.path.join(_HERE, "libpr_amd.so")   # PR_AMD_LIB: experiment builds only
 
 # every symbol include/place_recognition.h declares: (name, restype, argtypes)
 _vp, _i32, _dbl = C.c_void_p, C.c_int32, C.c_double

@@ -75,14 +75,18 @@ __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int v
 #define TICK(i)
 #endif
 
-// (hi, lo) split of two fp32 values into packed f16 pairs: lo = x - hi exactly (fp32), rounded to f16
+// (hi, lo) split of two fp32 values into packed f16 pairs: hi = f16(x) (v_cvt_pk_f16_f32), lo = f16(x - hi) with the
+// residual formed exactly in fp32 by v_fma_mix_f32 (f16 operand x -1 + f32 operand) - the mixlo/mixhi forms that write a
+// 16-bit half directly cost ~2x the issue time of a full-register VALU op on gfx950 (tools/ubench/valu_rate.hip).
 __device__ __forceinline__ void split2(float x, float y, unsigned& hi, unsigned& lo) {
   const f32x2 v = {x, y};
   hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
-  asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]\n\t"
-      "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
-      : "=&v"(lo)
+  f32x2 r;
+  asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(r[0]), "=&v"(r[1])
       : "v"(hi), "v"(x), "v"(y));
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
 }
 
 // Packed results of 16 frequencies (one half) for the 4 stage-1 registers r: [kind][r] is a 4-register MFMA operand
@@ -249,32 +253,51 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
     TICK(7)
 // request tile T of frequency Q of this group (Q >= 31: nothing - the first requests of the next group are issued by
 // hand late in the stage-2 phase, when half of the packed registers are free again)
+#if defined(EXP_NOLOADB)
+#define LDB(Q, T) {}
+#else
 #define LDB(Q, T) { if ((Q) < SC_NF) load_b<((Q) < SC_NF ? (Q) : 0), T>(Bt[(Q) & 3], rs, voff); }
+#endif
+#if defined(EXP_NOLOADA)
+#define LDA(P, Q, T) {}
+#else
 #define LDA(P, Q, T) { if ((Q) < SC_NF) { if (((Q) >> 1) == ((P) >> 1)) load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], ncur, rcur); \
                                         else load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], nnxt, rnxt); } }
+#endif
 #define FREQ(P, t1, t2, W0, W1, W2, W3, W4, W5)                                                   \
   {                                                                                               \
     SB(); MF0(t1, At[(P) & 3].h, Bt[(P) & 3].reh);  SB(); LDB((P) + 1, B_IML); LDA(P, (P) + 1, A_L); W0;   \
-    SB(); MF0(t2, At[(P) & 3].rh, Bt[(P) & 3].imh); SB(); LDB((P) + 2, B_REH); LDA(P, (P) + 1, A_RL); W1;  \
-    SB(); MFA(t1, At[(P) & 3].l, Bt[(P) & 3].reh);  SB(); LDB((P) + 2, B_IMH); W2;                \
-    SB(); MFA(t2, At[(P) & 3].rl, Bt[(P) & 3].imh); SB(); W3;                                     \
-    SB(); MFA(t1, At[(P) & 3].h, Bt[(P) & 3].rel);  SB(); LDA(P, (P) + 2, A_H); W4;                  \
-    SB(); MFA(t2, At[(P) & 3].rh, Bt[(P) & 3].iml); SB(); LDB((P) + 2, B_REL); LDA(P, (P) + 2, A_RH); W5;  \
+    SB(); MF0(t2, At[(P) & 3].rh, Bt[(P) & 3].imh); SB(); LDB((P) + 2, B_REH); W1;                \
+    SB(); MFA(t1, At[(P) & 3].l, Bt[(P) & 3].reh);  SB(); LDB((P) + 2, B_IMH); LDA(P, (P) + 1, A_RL); W2;  \
+    SB(); MFA(t2, At[(P) & 3].rl, Bt[(P) & 3].imh); SB(); LDA(P, (P) + 2, A_H); W3;               \
+    SB(); MFA(t1, At[(P) & 3].h, Bt[(P) & 3].rel);  SB(); LDB((P) + 2, B_REL); W4;                \
+    SB(); MFA(t2, At[(P) & 3].rh, Bt[(P) & 3].iml); SB(); LDA(P, (P) + 2, A_RH); W5;              \
     SB();                                                                                         \
   }
-#define PK(J, R) { pack_F<J, R>(hb, Fa, Fb); pack_M<J, R>(hb, Ma, Mb); }
+#ifdef EXP_NOPACK
+#define PKF(J, R) { if ((J) == 7 || (J) == 3) pack_F<J, R>(hb, Fa, Fb); }
+#define PKM(J, R) { if ((J) == 7 || (J) == 3) pack_M<J, R>(hb, Ma, Mb); }
+#else
+#define PKF(J, R) pack_F<J, R>(hb, Fa, Fb)
+#define PKM(J, R) pack_M<J, R>(hb, Ma, Mb)
+#endif
+#define PK(J, R) { PKF(J, R); PKM(J, R); }
 #define NONE ((void)0)
-// pair J of half H with the pending work of pair J-1: F/M of its second frequency, its four split/pack pieces
 // LDS bases of this lane's tiles: current pair and next pair (one opaque add per pair and operand kind)
 #define ADV() { ncur = nnxt; rcur = rnxt; nnxt = ncur + 2 * SCH_QBLK; rnxt = rcur + 2 * SCH_QBLK; asm("" : "+v"(nnxt)); asm("" : "+v"(rnxt)); }
+// Pair J of half H.  The VALU work is spread as evenly as the dependences allow, ~3 instructions per MFMA gap (a
+// 16x16x32 MFMA hides two or three; a gap with six costs ~34 cycles instead of ~18): the F/M combination of the previous
+// pair's second frequency (its last MFMA is two slots back), the eight split/pack pieces of the previous pair, and in
+// the last gap the F/M combination of this pair's first frequency (after the last reader of the old Fa/Ma).
+#define FMA_ALL(F, M, t1, t2) { FM2(F, M, t1, t2, 0); FM2(F, M, t1, t2, 2); }
 #define PAIR0(H)                                                                                  \
   ADV()                                                                                           \
   FREQ(16 * (H), t1a, t2a, NONE, NONE, NONE, NONE, NONE, NONE)                                    \
-  FREQ(16 * (H) + 1, t1b, t2b, NONE, NONE, FM2(Fa, Ma, t1a, t2a, 0), FM2(Fa, Ma, t1a, t2a, 2), NONE, NONE)
+  FREQ(16 * (H) + 1, t1b, t2b, NONE, NONE, NONE, NONE, NONE, FMA_ALL(Fa, Ma, t1a, t2a))
 #define PAIR(H, J)                                                                                \
   ADV()                                                                                           \
-  FREQ(16 * (H) + 2 * (J), t1a, t2a, NONE, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PK((J) - 1, 0), PK((J) - 1, 1)) \
-  FREQ(16 * (H) + 2 * (J) + 1, t1b, t2b, PK((J) - 1, 2), PK((J) - 1, 3), FM2(Fa, Ma, t1a, t2a, 0), FM2(Fa, Ma, t1a, t2a, 2), NONE, NONE)
+  FREQ(16 * (H) + 2 * (J), t1a, t2a, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PKF((J) - 1, 0), PKM((J) - 1, 0), PKF((J) - 1, 1)) \
+  FREQ(16 * (H) + 2 * (J) + 1, t1b, t2b, PKM((J) - 1, 1), PKF((J) - 1, 2), PKM((J) - 1, 2), PKF((J) - 1, 3), PKM((J) - 1, 3), FMA_ALL(Fa, Ma, t1a, t2a))
 // the 12 stage-2 MFMAs of register R with the VALU pieces W0..W11 in their gaps
 #define S2(FIRST, R, W0, W1, W2, W3, W4, W5, W6, W7, W8, W9, W10, W11)                             \
   { stage2_one<FIRST, R, 0>(hb, c, accE, accO, zero); SB(); W0; SB();                             \
@@ -310,8 +333,8 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
     // ---------------------------------------------------------------- second half: frequencies 16..30
     PAIR0(1) PAIR(1, 1) PAIR(1, 2) PAIR(1, 3) PAIR(1, 4) PAIR(1, 5) PAIR(1, 6)
     ADV()
-    FREQ(30, t1a, t2a, NONE, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PK(6, 0), PK(6, 1))
-    PK(6, 2) PK(6, 3)
+    FREQ(30, t1a, t2a, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PK(6, 0), PK(6, 1), PK(6, 2))
+    PK(6, 3)
     TICK(3)
     DRAIN();
     SB();
