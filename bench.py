@@ -10,8 +10,9 @@ One step = the whole match path on inputs already resident in HBM as f64 signatu
 i.e. run_test.m:25-57.  With N > 1 GPUs the SAME 100k DB is row-sharded over the ranks (strong scaling,
 SURVEY.md §8-e); queries are replicated.  value = queries of all steps / max-over-ranks wall time.
 
-Extra objects on the JSON line: `roofline` (the dominant kernel sc_match, timed live with HIP events on the
-stream it runs on; algorithmic FLOPs = 23 856 per (query, entry) pair), `cpu_baseline` (the CPU oracle =
+Extra objects on the JSON line: `roofline` (the dominant kernel - sc_match_h_kernel, split-f16 MFMA, by default;
+sc_match_kernel, fp32 MFMA, with --sc-arith f32 - timed live with HIP events on the stream it runs on; algorithmic
+FLOPs = 23 856 fp32 FLOP per (query, entry) pair = 71 568 f16 FLOP in the split form), `cpu_baseline` (the CPU oracle =
 a port of the reference, timed on this host's cores on a bounded query sample at N = 1), `parity` (GPU top-1 vs
 that oracle on the sample and vs the planted ground truth on all queries).
 """
@@ -32,6 +33,10 @@ sys.path.insert(0, ROOT)
 #   stage 2: {fwd, mir} x ( E: 31 shifts x 31 freqs + O: 29 shifts x 29 freqs ) x 2 FLOP               = 7 208
 FLOP_PER_PAIR = 2 * (29 * 160 + 2 * 40 + 2 * 2 * (31 * 31 + 29 * 29))    # 23 856
 MFMA_F32_PEAK_TFLOPS = 157.3             # MI355X_MICROARCH.md: Peak FP32 (matrix)
+# split-f16 arithmetic (sc_match_h.hip): the same formulation with every fp32 product carried as three f16 products
+# (hi*hi + hi*lo + lo*hi, fp32 accumulate) on the f16 matrix cores
+FLOP_PER_PAIR_F16X2 = 3 * FLOP_PER_PAIR  # 71 568
+MFMA_F16_PEAK_TFLOPS = 2500.0            # MI355X_MICROARCH.md: BF16/F16 ~2.5 PF dense
 
 
 class HipEvents:
@@ -68,6 +73,8 @@ def main():
     ap.add_argument("--queries", type=int, default=4096)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="queries for the CPU baseline (-1: one per host core, <= 32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sc-arith", default=None, choices=["f16x2", "f32"],
+                    help="SC matcher arithmetic (default: the library's, split-f16 MFMA; f32 = the fp32-MFMA kernel)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: several ranks on ONE GPU, tests only)")
     args = ap.parse_args()
 
@@ -103,7 +110,9 @@ def main():
     q = torch.from_numpy(q_host).to(dev)                              # f64 [m, 2400]
     gen_s = time.time() - t0
 
-    mt = Matcher("sc", m, hi - lo, device=local)
+    from so_dso_place_recognition_amd.api import Context
+    mt = Matcher("sc", m, hi - lo, ctx=Context(local, sc_arith=args.sc_arith))
+    arith = mt.ctx.sc_arith
     ev = HipEvents()
     e0, e1 = ev.create(), ev.create()
     stream = mt.ctx.stream
@@ -147,26 +156,33 @@ def main():
         qps = m * args.steps / dt
         kms = float(np.mean(kern_ms))
         pairs = m * (hi - lo)
-        ach = pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12
+        f16 = arith == "f16x2"
+        kname = "sc_match_h_kernel" if f16 else "sc_match_kernel"
+        fpp, peak = (FLOP_PER_PAIR_F16X2, MFMA_F16_PEAK_TFLOPS) if f16 else (FLOP_PER_PAIR, MFMA_F32_PEAK_TFLOPS)
+        ach = pairs * fpp / (kms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
         try:
             tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
             if tr["workload"] == {"db": n, "queries": m, "n_gpus": world}:
-                traffic = tr["sc_match_kernel"]["hbm_bytes_per_launch"]
+                traffic = tr[kname]["hbm_bytes_per_launch"]
         except Exception:
             pass
         out = {
             "metric": "queries/sec over 100k-signature DB (SC 20x60, z-score fusion, top-1)",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "ms_per_query": 1e3 * dt / (args.steps * m),
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f16x2 (fp32 carried as f16 hi + lo, fp32 accumulate)" if f16 else "f32",
             "data": "synthetic",
             "config": {"workload": "sc_match_100k", "db_signatures": n, "queries_per_step": m, "descriptor": "SC 20x60 x 2 channels",
                        "mask_width": 0, "p_weight": 2.0, "k": 1, "db_rows_per_gpu": hi - lo,
                        "step": "pack(q)+pack(db)+distances+moments+fuse/top-1" + ("+2 all_gathers" if world > 1 else "")},
-            "roofline": {"kernel": "sc_match_kernel", "bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": ach / MFMA_F32_PEAK_TFLOPS, "traffic": traffic,
-                         "flop_per_pair": FLOP_PER_PAIR, "pairs_per_launch": pairs, "ms_per_launch": kms,
+            "roofline": {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak,
+                         "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                         "flop_per_pair": fpp, "pairs_per_launch": pairs, "ms_per_launch": kms,
+                         # the same launch priced as the fp32 formulation it replaces (what an fp32-MFMA kernel would need)
+                         "fp32_formulation_tflops": pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12,
+                         "fp32_formulation_frac_of_157.3": pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          "dense_equivalent_tflops": pairs * 576000 / (kms * 1e-3) / 1e12},
             "parity": {"planted_top1_correct": planted_ok, "queries": m},
             "setup_s": gen_s,

@@ -10,6 +10,7 @@ import os
 
 PR_OK, PR_EINVAL, PR_ENOMEM, PR_EHIP, PR_EIO, PR_ENAN = 0, -1, -2, -3, -4, -5
 TYPE_SC, TYPE_M2DP, TYPE_DELIGHT = 0, 1, 2
+SC_ARITH_F16X2, SC_ARITH_F32 = 0, 1
 ROLE_QUERY, ROLE_DB = 0, 1
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
@@ -24,6 +25,8 @@ SYMBOLS = {
     "pr_destroy": (None, [_vp]),
     "pr_last_error": (C.c_char_p, [_vp]),
     "pr_version": (C.c_char_p, []),
+    "pr_set_sc_arith": (C.c_int, [_vp, C.c_int]),
+    "pr_get_sc_arith": (C.c_int, [_vp]),
     "pr_sync": (C.c_int, [_vp]),
     "pr_stream": (_vp, [_vp]),
     "pr_sc_generate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),

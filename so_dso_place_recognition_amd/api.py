@@ -23,7 +23,8 @@ def _ptr(a):
 class Context:
     """One HIP device + stream (pr_ctx)."""
 
-    def __init__(self, device: int = 0):
+    def __init__(self, device: int = 0, sc_arith: str | None = None):
+        """sc_arith: None (library default: "f16x2", or PR_SC_MATCH=f32 from the environment), "f16x2" or "f32"."""
         self.lib = _lib.load()
         h = C.c_void_p()
         rc = self.lib.pr_create(device, C.byref(h))
@@ -31,6 +32,12 @@ class Context:
             raise PRError(rc, self.lib.pr_last_error(None).decode())
         self.h = h
         self.device = device
+        if sc_arith is not None:
+            self.check(self.lib.pr_set_sc_arith(h, {"f16x2": _lib.SC_ARITH_F16X2, "f32": _lib.SC_ARITH_F32}[sc_arith]))
+
+    @property
+    def sc_arith(self) -> str:
+        return "f32" if self.lib.pr_get_sc_arith(self.h) == _lib.SC_ARITH_F32 else "f16x2"
 
     def close(self):
         if getattr(self, "h", None):

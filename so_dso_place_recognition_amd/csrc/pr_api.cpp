@@ -23,8 +23,8 @@ struct pr_ctx {
   int* d_flags = nullptr;        // [4] deferred error bits (bit0: zero-norm row at pack time)
   double* d_twiddle = nullptr;   // cos[60], sin[60] of 2*pi*t/60
   float* d_cst = nullptr;        // SC stage-2 constants [31][2][64]
-  void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16]
-  int sc_mode = 0;               // 0: split-f16 MFMA (sc_match_h.hip), 1: fp32 MFMA (sc_match.hip); PR_SC_MATCH=f32 selects 1
+  void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16] (sc_match_h.hip)
+  int sc_mode = PR_SC_ARITH_F16X2;   // PR_SC_ARITH_*: split-f16 MFMA (sc_match_h.hip) | fp32 MFMA (sc_match.hip); PR_SC_MATCH=f32 selects the latter
   double* d_planes = nullptr;    // M2DP xProj[64][3], yProj[64][3]
   int sc_nsplit = 0;             // PR_SC_NSPLIT override (experiments)
 };
@@ -74,7 +74,7 @@ size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups, int sc_m
   if (type == PR_TYPE_SC && sc_mode == 0) {   // split-f16 images, sizes in bytes / 4
     if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SCH_QIMG / 4; }
     *groups = pr::sc_dgroups(max_sigs);
-    return (size_t)(2 * *groups + 1) * pr::SCH_DIMG / 4;   // + one all-zero group: the pipeline requests one pair past the end
+    return (size_t)(2 * *groups + 2) * pr::SCH_DIMG / 4;   // + two all-zero groups: the pipeline runs one group past the end
   }
   if (type == PR_TYPE_SC) {
     if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SC_QIMG; }
@@ -218,6 +218,15 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->d_planes) (void)hipFree(ctx->d_planes);
   delete ctx;
 }
+
+int pr_set_sc_arith(pr_ctx* ctx, int arith) {
+  if (!ctx) return PR_EINVAL;
+  if (arith != PR_SC_ARITH_F16X2 && arith != PR_SC_ARITH_F32) PR_FAIL(ctx, PR_EINVAL, "pr_set_sc_arith: unknown arithmetic %d", arith);
+  ctx->sc_mode = arith;
+  return PR_OK;
+}
+
+int pr_get_sc_arith(const pr_ctx* ctx) { return ctx ? ctx->sc_mode : PR_EINVAL; }
 
 void* pr_stream(pr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 

@@ -226,3 +226,41 @@ def test_delight_matcher_device_path(api):
     assert np.array_equal(idx.cpu().numpy(), oidx)
     assert (np.abs(sc.cpu().numpy() - osc) <= 1e-5 * np.maximum(1.0, np.abs(osc))).all()
     mt.close()
+
+
+# ------------------------------------------------------------------------------------------------ a6, both arithmetics
+def test_sc_both_arithmetics_vs_oracle(api):
+    """The SC matcher ships in two arithmetics (include/place_recognition.h PR_SC_ARITH_*): split-f16 MFMA (default) and
+    fp32 MFMA.  Both must meet the 1e-5 distance tolerance and give the same top-k as the oracle; measured error of
+    either is ~1e-7."""
+    db = synth.sc_database(45, 333)
+    q, _ = synth.sc_queries(46, db, 64)
+    rc, op, oi = oracle_lib.sc_distance(q, db)
+    rc, oidx, osc = oracle_lib.match_topk(0, q, db, 3, 2.0, 4)
+    errs = {}
+    for arith in ("f16x2", "f32"):
+        ctx = api.Context(0, sc_arith=arith)
+        assert ctx.sc_arith == arith
+        gp, gi = api.processSC(q, db, ctx)
+        errs[arith] = max(np.abs(gp - op).max(), np.abs(gi - oi).max())
+        assert errs[arith] < 2e-6                                   # well inside the 1e-5 of BASELINE.json
+        idx, sc = api.match_topk("sc", q, db, 3, 2.0, 4, ctx=ctx)
+        assert np.array_equal(idx, oidx)
+        ctx.close()
+    print("max |d - oracle|:", errs)
+
+
+def test_sc_mixed_arithmetic_sets_are_rejected(api):
+    import ctypes as C
+    from so_dso_place_recognition_amd import _lib
+    ctx = api.Context(0, sc_arith="f32")
+    q = C.c_void_p(); d = C.c_void_p()
+    assert ctx.lib.pr_sigset_create(ctx.h, _lib.TYPE_SC, _lib.ROLE_QUERY, 8, C.byref(q)) == 0
+    assert ctx.lib.pr_set_sc_arith(ctx.h, _lib.SC_ARITH_F16X2) == 0
+    assert ctx.lib.pr_sigset_create(ctx.h, _lib.TYPE_SC, _lib.ROLE_DB, 16, C.byref(d)) == 0
+    dummy = C.c_void_p(16)
+    assert ctx.lib.pr_distances_dev(ctx.h, q, d, dummy, dummy) == -1        # PR_EINVAL, nothing launched
+    assert b"different arithmetic" in ctx.lib.pr_last_error(ctx.h)
+    assert ctx.lib.pr_set_sc_arith(ctx.h, 7) == -1
+    ctx.lib.pr_sigset_destroy(ctx.h, q); ctx.lib.pr_sigset_destroy(ctx.h, d)
+    ctx.close()
