@@ -78,17 +78,17 @@ __global__ __launch_bounds__(256) void sc_pack_kernel(const T* __restrict__ sig,
 //   DB image     [ch][group of 16][f = 0..30][Re hi | Re lo | Im hi | Im lo]{ 768 B: lane = (ring>>3)<<4 | j, 16 B per
 //                lane = rings 8g..8g+7; rings 20..23 stay zero }
 template <typename T>
-__global__ __launch_bounds__(256) void sc_pack_h_kernel(const T* __restrict__ sig, int rows, int role,
+__global__ __launch_bounds__(320) void sc_pack_h_kernel(const T* __restrict__ sig, int rows, int role,
                                                          unsigned short* __restrict__ packed, int groups,
                                                          const double* __restrict__ tw, int* __restrict__ flags) {
   __shared__ double x[1200];
-  __shared__ double red[256];
+  __shared__ double red[320];
   __shared__ double tws[120];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x;                            // 320 threads = one per (ring, frequency <= 15)
   const int row = blockIdx.x >> 1, ch = blockIdx.x & 1;
   const T* src = sig + (size_t)row * 2400 + ch * 1200;
   double part = 0.0;
-  for (int i = tid; i < 1200; i += 256) {
+  for (int i = tid; i < 1200; i += 320) {
     double v = (double)src[i];
     x[i] = v;
     part += v * v;
@@ -96,43 +96,61 @@ __global__ __launch_bounds__(256) void sc_pack_h_kernel(const T* __restrict__ si
   if (tid < 120) tws[tid] = tw[tid];
   red[tid] = part;
   __syncthreads();
+  if (tid < 64) red[tid] += red[tid + 256];
+  __syncthreads();
   for (int s = 128; s > 0; s >>= 1) {
     if (tid < s) red[tid] += red[tid + s];
     __syncthreads();
   }
   const double nr = sqrt(red[0]);
   if (!(nr > 0.0) && tid == 0) atomicOr(flags, 1);   // MATLAB would produce a NaN row
-  for (int i = tid; i < 1200; i += 256) x[i] = x[i] / nr;   // processSC.m:16,19
+  for (int i = tid; i < 1200; i += 320) x[i] = x[i] / nr;   // processSC.m:16,19
   __syncthreads();
   const double scale = 0.12909944487358055 * (role == 0 ? 256.0 : 128.0);  // 1/sqrt(60) x 2^8 | 2^7
-  for (int o = tid; o < SC_NF * 40; o += 256) {
-    const int f = o / 40, rem = o - f * 40, ring = rem >> 1, im = rem & 1;
-    double acc = 0.0;
+  // One thread per (ring, frequency f <= 15): the bins f and 30 - f share every product, because
+  // cos(2 pi (30-f) s/60) = (-1)^s cos(2 pi f s/60) and sin(2 pi (30-f) s/60) = -(-1)^s sin(2 pi f s/60): with the sums over
+  // even and odd sectors kept apart, X_f = (Ce + Co) - i (Se + So) and X_{30-f} = (Ce - Co) + i (Se - So).
+  {
+    const int o = tid;
+    const int f = o / 20, ring = o - f * 20;
+    double ce = 0.0, co = 0.0, se = 0.0, so = 0.0;
     int t = 0;  // (f*s) mod 60
-    for (int s = 0; s < 60; s++) {
-      const double w = im ? -tws[60 + t] : tws[t];
-      acc += x[s * 20 + ring] * w;
-      t += f;
-      if (t >= 60) t -= 60;
+#pragma unroll 3
+    for (int s2 = 0; s2 < 60; s2 += 2) {
+      const double x0 = x[s2 * 20 + ring];
+      ce += x0 * tws[t];
+      se += x0 * tws[60 + t];
+      t += f; if (t >= 60) t -= 60;
+      const double x1 = x[(s2 + 1) * 20 + ring];
+      co += x1 * tws[t];
+      so += x1 * tws[60 + t];
+      t += f; if (t >= 60) t -= 60;
     }
-    const double val = acc * scale;
-    const _Float16 hi = (_Float16)val;
-    const _Float16 lo = (_Float16)(val - (double)hi);
-    size_t bh, bl;   // byte offsets of hi and lo
-    if (role == 0) {
-      const int g = row >> 3, rr = (im << 3) | (row & 7);
-      const size_t base = ((size_t)ch * groups + g) * SCH_QIMG + (size_t)f * SCH_QBLK + rr * 80 + (rr >= 8 ? 8 : 0);
-      bh = base + ring * 2;
-      bl = base + 40 + ring * 2;
-    } else {
-      const int g = row >> 4, j = row & 15;
-      const size_t base = ((size_t)ch * groups + g) * SCH_DIMG + (size_t)f * SCH_DFREQ + (size_t)im * 2 * SCH_DTILE +
-                          (((ring >> 3) << 4) | j) * 16 + (ring & 7) * 2;
-      bh = base;
-      bl = base + SCH_DTILE;
+    auto put = [&](double val, int ff, int im) {
+      const _Float16 hi = (_Float16)val;
+      const _Float16 lo = (_Float16)(val - (double)hi);
+      size_t bh, bl;   // byte offsets of hi and lo
+      if (role == 0) {
+        const int g = row >> 3, rr = (im << 3) | (row & 7);
+        const size_t base = ((size_t)ch * groups + g) * SCH_QIMG + (size_t)ff * SCH_QBLK + rr * 80 + (rr >= 8 ? 8 : 0);
+        bh = base + ring * 2;
+        bl = base + 40 + ring * 2;
+      } else {
+        const int g = row >> 4, j = row & 15;
+        const size_t base = ((size_t)ch * groups + g) * SCH_DIMG + (size_t)ff * SCH_DFREQ + (size_t)im * 2 * SCH_DTILE +
+                            (((ring >> 3) << 4) | j) * 16 + (ring & 7) * 2;
+        bh = base;
+        bl = base + SCH_DTILE;
+      }
+      packed[bh >> 1] = __builtin_bit_cast(unsigned short, hi);
+      packed[bl >> 1] = __builtin_bit_cast(unsigned short, lo);
+    };
+    put((ce + co) * scale, f, 0);
+    put(-(se + so) * scale, f, 1);
+    if (f != 15) {                                      // 30 - 15 = 15: the same bin
+      put((ce - co) * scale, 30 - f, 0);
+      put((se - so) * scale, 30 - f, 1);
     }
-    packed[bh >> 1] = __builtin_bit_cast(unsigned short, hi);
-    packed[bl >> 1] = __builtin_bit_cast(unsigned short, lo);
   }
 }
 
@@ -142,10 +160,10 @@ void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int 
                       const double* twiddle, int* flags) {
   if (rows <= 0) return;
   if (dtype == 0)
-    hipLaunchKernelGGL(sc_pack_h_kernel<double>, dim3(rows * 2), dim3(256), 0, st, (const double*)sig, rows, role,
+    hipLaunchKernelGGL(sc_pack_h_kernel<double>, dim3(rows * 2), dim3(320), 0, st, (const double*)sig, rows, role,
                        (unsigned short*)packed, groups, twiddle, flags);
   else
-    hipLaunchKernelGGL(sc_pack_h_kernel<float>, dim3(rows * 2), dim3(256), 0, st, (const float*)sig, rows, role,
+    hipLaunchKernelGGL(sc_pack_h_kernel<float>, dim3(rows * 2), dim3(320), 0, st, (const float*)sig, rows, role,
                        (unsigned short*)packed, groups, twiddle, flags);
 }
 
