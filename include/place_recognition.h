@@ -125,11 +125,20 @@ int pr_delight_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, 
  * reference's point ORDER, and the incoming_id_file (written when non-NULL).  verbose prints the reference's lines. */
 int pr_pts_preprocess(const char* poses_file, const char* pts_file, const char* incoming_id_file, double lidarRange,
                       int polar_filter, int verbose, pr_clouds** out);
+/* The same on the GPU: identical clouds in identical point order (the order of libstdc++'s
+ * std::unordered_map iteration, reproduced from the key insertion sequence), files parsed on the host.  Needs a context. */
+int pr_pts_preprocess_gpu(pr_ctx* ctx, const char* poses_file, const char* pts_file, const char* incoming_id_file,
+                          double lidarRange, int polar, int verbose, pr_clouds** out);
+/* Iteration order of a std::unordered_map<int,...> after inserting the K distinct non-negative keys in this order
+ * (order[t] = index of the t-th element); the host build of the routine the GPU pre-stage runs per cloud. */
+int pr_hash_order(const int32_t* keys, int32_t K, int32_t* order);
 int64_t pr_clouds_count(const pr_clouds* c);
 const int64_t* pr_clouds_offs(const pr_clouds* c);      /* [N+1] */
 const double* pr_clouds_xyz(const pr_clouds* c);        /* [offs[N]][3] camera frame */
 const float* pr_clouds_inten(const pr_clouds* c);       /* [offs[N]] */
 const int32_t* pr_clouds_ids(const pr_clouds* c);       /* [N] incoming ids */
+double pr_clouds_avg_ms(const pr_clouds* c);           /* the reference's "average time" of pts_preprocess.h:221-225 (files already parsed) */
+double pr_clouds_avg_pts(const pr_clouds* c);
 void pr_clouds_free(pr_clouds* c);
 
 /* Signature matrix text I/O: writer = `ofstream << Eigen::MatrixXd` (test_sc.cpp:63-66, test_m2dp.cpp:83-86);

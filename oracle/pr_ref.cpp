@@ -601,6 +601,16 @@ int pr_ref_delight_distance(const double* h1, int32_t m, const double* h2, int32
 }
 
 // run_test.m:47-57 without the z-score fusion (types other than m2dp / sc, run_test.m:26-41)
+// iteration order of the real std::unordered_map after inserting the K keys in this order (what the reference's
+// filterPoints / filterPointsPolar emit: pts_preprocess.h:85-89, :124-128); order[t] = index of the t-th element
+int pr_ref_unordered_order(const int32_t* keys, int32_t K, int32_t* order) {
+  std::unordered_map<int, int> m;
+  for (int k = 0; k < K; k++) m[keys[k]] = k;
+  int t = 0;
+  for (const auto& kv : m) order[t++] = kv.second;
+  return t == K ? 0 : -1;
+}
+
 int pr_ref_select_topk(const double* d, int32_t m, int32_t n, int32_t mask_width, int32_t k, int32_t* idx, double* score) {
   if (!d || m < 0 || n < 1 || k < 1) return PR_REF_EINVAL;
 #pragma omp parallel for schedule(static)

@@ -47,6 +47,10 @@ SYMBOLS = {
     "pr_sc_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
     "pr_m2dp_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
     "pr_pts_preprocess": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _dbl, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "pr_pts_preprocess_gpu": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, _dbl, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "pr_hash_order": (C.c_int, [_vp, _i32, _vp]),
+    "pr_clouds_avg_ms": (C.c_double, [_vp]),
+    "pr_clouds_avg_pts": (C.c_double, [_vp]),
     "pr_clouds_count": (C.c_int64, [_vp]),
     "pr_clouds_offs": (C.POINTER(C.c_int64), [_vp]),
     "pr_clouds_xyz": (C.POINTER(C.c_double), [_vp]),

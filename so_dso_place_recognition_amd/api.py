@@ -233,15 +233,20 @@ def run_test(type_, hist1, hist2, gt1=None, gt2=None, loop_diff=None, mask_width
 
 # ------------------------------------------------------------------------------- host-side rows a1 / a2
 def pts_preprocess(poses_file: str, pts_file: str, incoming_id_file: str | None, lidarRange: float = 45.0,
-                   polar_filter: bool = False, verbose: bool = False):
-    """pts_preprocess(...) of utils/pts_preprocess.h:169-232 -> (xyz [T,3] f64, inten [T] f32, offs [N+1] i64, ids [N] i32)."""
+                   polar_filter: bool = False, verbose: bool = False, gpu: bool = False, ctx: Context | None = None):
+    """pts_preprocess(...) of utils/pts_preprocess.h:169-232 -> (xyz [T,3] f64, inten [T] f32, offs [N+1] i64, ids [N] i32).
+    gpu=True runs the sliding-window / best-point-per-cell work on the device (same clouds, same point order)."""
     lib = _lib.load()
     h = C.c_void_p()
-    rc = lib.pr_pts_preprocess(poses_file.encode(), pts_file.encode(),
-                               incoming_id_file.encode() if incoming_id_file else None, float(lidarRange),
-                               int(polar_filter), int(verbose), C.byref(h))
-    if rc != 0:
-        raise PRError(rc, lib.pr_host_last_error().decode())
+    args = (poses_file.encode(), pts_file.encode(), incoming_id_file.encode() if incoming_id_file else None,
+            float(lidarRange), int(polar_filter), int(verbose), C.byref(h))
+    if gpu:
+        ctx = ctx or default_context()
+        ctx.check(lib.pr_pts_preprocess_gpu(ctx.h, *args))
+    else:
+        rc = lib.pr_pts_preprocess(*args)
+        if rc != 0:
+            raise PRError(rc, lib.pr_host_last_error().decode())
     try:
         N = lib.pr_clouds_count(h)
         offs = np.ctypeslib.as_array(lib.pr_clouds_offs(h), (N + 1,)).copy()
@@ -249,9 +254,20 @@ def pts_preprocess(poses_file: str, pts_file: str, incoming_id_file: str | None,
         xyz = np.ctypeslib.as_array(lib.pr_clouds_xyz(h), (T, 3)).copy() if T else np.zeros((0, 3))
         it = np.ctypeslib.as_array(lib.pr_clouds_inten(h), (T,)).copy() if T else np.zeros((0,), np.float32)
         ids = np.ctypeslib.as_array(lib.pr_clouds_ids(h), (N,)).copy() if N else np.zeros((0,), np.int32)
+        pts_preprocess.last_avg_ms = float(lib.pr_clouds_avg_ms(h))     # "generate_spherical_points average time"
     finally:
         lib.pr_clouds_free(h)
     return xyz, it, offs, ids
+
+
+def hash_order(keys) -> np.ndarray:
+    """Iteration order of a libstdc++ unordered_map<int,...> after inserting these distinct keys in this order."""
+    k = np.ascontiguousarray(keys, np.int32)
+    out = np.empty(len(k), np.int32)
+    rc = _lib.load().pr_hash_order(_ptr(k), len(k), _ptr(out))
+    if rc != 0:
+        raise PRError(rc, "pr_hash_order")
+    return out
 
 
 def write_signatures(path: str, sig, dtype=np.float64) -> None:

@@ -20,17 +20,21 @@ inline int generate_main(int argc, char** argv, int kind) {
   }
   const double lidarRange = prm.num("lidarRange", 45.0);   // :27-28
   pr_clouds* clouds = nullptr;
-  if (pr_pts_preprocess(poses.c_str(), pts.c_str(), idf.c_str(), lidarRange, (m2dp || delight) ? 1 : 0, 1, &clouds) != PR_OK) {
-    fprintf(stderr, "pts_preprocess failed: %s\n", pr_host_last_error());
+  pr_ctx* ctx = nullptr;
+  int rc = pr_create((int)prm.num("device", 0), &ctx);
+  if (rc != PR_OK) { fprintf(stderr, "%s\n", pr_last_error(nullptr)); return 3; }
+  const bool gpu_pre = prm.num("gpu_prestage", 0.0) != 0.0;   // _gpu_prestage:=1: pts_preprocess on the device (same clouds)
+  rc = gpu_pre ? pr_pts_preprocess_gpu(ctx, poses.c_str(), pts.c_str(), idf.c_str(), lidarRange, (m2dp || delight) ? 1 : 0, 1, &clouds)
+               : pr_pts_preprocess(poses.c_str(), pts.c_str(), idf.c_str(), lidarRange, (m2dp || delight) ? 1 : 0, 1, &clouds);
+  if (rc != PR_OK) {
+    fprintf(stderr, "pts_preprocess failed: %s\n", gpu_pre ? pr_last_error(ctx) : pr_host_last_error());
+    pr_destroy(ctx);
     return 2;
   }
   const int32_t N = (int32_t)pr_clouds_count(clouds);
   const size_t rows = delight ? (size_t)16 * N : (m2dp ? (size_t)4 * N : (size_t)N);
   const size_t cols = delight ? PR_DELIGHT_SIG_LEN : (m2dp ? PR_M2DP_SIG_LEN : PR_SC_SIG_LEN);
   std::vector<double> sig(rows * cols);
-  pr_ctx* ctx = nullptr;
-  int rc = pr_create((int)prm.num("device", 0), &ctx);
-  if (rc != PR_OK) { fprintf(stderr, "%s\n", pr_last_error(nullptr)); pr_clouds_free(clouds); return 3; }
   const auto t0 = std::chrono::steady_clock::now();
   rc = delight ? pr_delight_generate(ctx, pr_clouds_xyz(clouds), pr_clouds_inten(clouds), pr_clouds_offs(clouds), N, sig.data())
      : m2dp ? pr_m2dp_generate(ctx, pr_clouds_xyz(clouds), pr_clouds_inten(clouds), pr_clouds_offs(clouds), N, lidarRange, sig.data())

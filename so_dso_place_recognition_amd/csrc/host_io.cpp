@@ -21,68 +21,10 @@
 #include <vector>
 
 #include "../../include/place_recognition.h"
-
-struct pr_clouds {
-  std::vector<int64_t> offs;
-  std::vector<double> xyz;
-  std::vector<float> inten;
-  std::vector<int32_t> ids;
-  double avg_ms = 0, avg_pts = 0;
-};
+#include "records.hpp"
 
 namespace {
-
-bool slurp(const char* path, std::string& buf) {
-  FILE* f = fopen(path, "rb");
-  if (!f) return false;
-  fseek(f, 0, SEEK_END);
-  long n = ftell(f);
-  fseek(f, 0, SEEK_SET);
-  buf.resize(n > 0 ? (size_t)n : 0);
-  size_t got = n > 0 ? fread(&buf[0], 1, (size_t)n, f) : 0;
-  fclose(f);
-  buf.resize(got);
-  return true;
-}
-
-struct Cursor {
-  const char* p;
-  bool next_int(int& v) { char* e; long x = strtol(p, &e, 10); if (e == p) return false; v = (int)x; p = e; return true; }
-  bool next_double(double& v) { char* e; v = strtod(p, &e); if (e == p) return false; p = e; return true; }
-  bool next_float(float& v) { char* e; v = strtof(p, &e); if (e == p) return false; p = e; return true; }
-};
-
-struct PoseRec { int id; double w[12]; };
-struct History { std::vector<int> id; std::vector<double> xyz; std::vector<float> it; };
-
-// pts_preprocess.h:17-49
-void read_records(const char* poses_file, const char* pts_file, std::vector<PoseRec>& poses, History& h) {
-  std::string buf;
-  if (slurp(poses_file, buf)) {
-    Cursor c{buf.c_str()};
-    while (true) {
-      PoseRec r;
-      memset(&r, 0, sizeof r);
-      if (!c.next_int(r.id)) break;
-      bool ok = true;
-      for (int k = 0; k < 12 && ok; k++) ok = c.next_double(r.w[k]);   // a short line still yields a pose (:28-34)
-      poses.push_back(r);
-      if (!ok) {   // the stream is now in a failed state in the reference: every later extraction fails
-        break;
-      }
-    }
-  }
-  if (slurp(pts_file, buf)) {
-    Cursor c{buf.c_str()};
-    while (true) {
-      int id; double x, y, z; float it;
-      if (!c.next_int(id) || !c.next_double(x) || !c.next_double(y) || !c.next_double(z) || !c.next_float(it)) break;
-      h.id.push_back(id);
-      h.xyz.push_back(x); h.xyz.push_back(y); h.xyz.push_back(z);
-      h.it.push_back(it);
-    }
-  }
-}
+using namespace pr_rec;
 
 struct Scratch { std::vector<double> p; std::vector<int> src; };   // camera-frame points of the current pose
 
@@ -219,6 +161,8 @@ const int64_t* pr_clouds_offs(const pr_clouds* c) { return c->offs.data(); }
 const double* pr_clouds_xyz(const pr_clouds* c) { return c->xyz.data(); }
 const float* pr_clouds_inten(const pr_clouds* c) { return c->inten.data(); }
 const int32_t* pr_clouds_ids(const pr_clouds* c) { return c->ids.data(); }
+double pr_clouds_avg_ms(const pr_clouds* c) { return c ? c->avg_ms : 0.0; }
+double pr_clouds_avg_pts(const pr_clouds* c) { return c ? c->avg_pts : 0.0; }
 void pr_clouds_free(pr_clouds* c) { delete c; }
 
 // Text format of `ofstream << Eigen::MatrixXd` (test_sc.cpp:63-66): default IOFormat = stream precision (6 significant

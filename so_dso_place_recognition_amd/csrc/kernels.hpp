@@ -66,4 +66,20 @@ void launch_delight_gen(hipStream_t st, const double* xyz, const float* inten, c
 void launch_delight_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed);
 void launch_delight_match(hipStream_t st, const float* q, int m, const float* db, int n, float* dist);
 
+// prestage.hip — utils/pts_preprocess.h:135-232 on the GPU (see the file header); all pointers are device pointers
+int64_t prestage_cells(double range, int polar);          // dense cell-table length per pose
+void launch_death(hipStream_t st, const double* xyz, const int* birth, int64_t T, const double* W, const unsigned char* emit,
+                  const int* next_reset, double range, int* death);
+void launch_members(hipStream_t st, int E, const int* death, const int* pose_of, const int64_t* first_alive, const int64_t* cursor,
+                    const int64_t* off, int* cnt, int* list);
+void launch_cells(hipStream_t st, const double* xyz, const int* list, const int64_t* off, const int* pose_of, int e0, int e1,
+                  int64_t s0, int64_t s1, const double* W, double range, int polar, int64_t C, int* cell, unsigned long long* val,
+                  unsigned long long* tval, unsigned* tfirst, unsigned* tbest);
+void launch_keys(hipStream_t st, const int64_t* off, int e0, int e1, int64_t C, const int* cell, const int* list, const unsigned* tfirst,
+                 const unsigned* tbest, int* keys, int* win, int* nkeys);
+void launch_order(hipStream_t st, int E, const int64_t* off, const int* nkeys, const int* keys, const int* sched_cnt, const int* sched_nb,
+                  int nsched, int* next, const int64_t* boff, int* bkt, int* order);
+void launch_gather(hipStream_t st, int E, int64_t total, const int64_t* off, const int64_t* ooff, const int* pose_of, const int* order,
+                   const int* win, const double* xyz, const float* inten, const double* W, double range, double* oxyz, float* oint);
+
 }  // namespace pr

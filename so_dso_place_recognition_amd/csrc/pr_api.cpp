@@ -13,6 +13,10 @@
 #include "../../include/place_recognition.h"
 #include "../../include/pr_m2dp_table.h"
 #include "kernels.hpp"
+#include "hash_order.hpp"
+#include "records.hpp"
+#include <chrono>
+#include <unordered_map>
 
 struct pr_ctx {
   int device = -1;
@@ -236,6 +240,187 @@ int pr_sync(pr_ctx* ctx) {
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   PR_HIP(ctx, hipGetLastError());
   return check_flags(ctx);
+}
+
+
+// ------------------------------------------------------------------------------------------- GPU pre-stage (row f1)
+// The bucket count libstdc++ picks when the element count crosses each threshold, read off the real container (it
+// depends on counts only, never on keys): the table is rehashed to nb[i] buckets when a key is inserted while cnt[i]
+// elements exist.
+static void probe_bucket_schedule(int kmax, std::vector<int>& cnt, std::vector<int>& nb) {
+  std::unordered_map<int, int> m;
+  size_t last = m.bucket_count();
+  for (int k = 0; k < kmax; k++) {
+    m[k] = k;
+    if (m.bucket_count() != last) { cnt.push_back(k); nb.push_back((int)m.bucket_count()); last = m.bucket_count(); }
+  }
+}
+
+int pr_hash_order(const int32_t* keys, int32_t K, int32_t* order) {   // host build of hash_order.hpp (tests; not a hot path)
+  if (K < 0 || (K > 0 && (!keys || !order))) return PR_EINVAL;
+  std::vector<int> cnt, nb;
+  probe_bucket_schedule(K, cnt, nb);
+  std::vector<int> next((size_t)K + 1), bkt(nb.empty() ? 1 : (size_t)nb.back());
+  pr::hash_order(keys, K, cnt.data(), nb.data(), (int)cnt.size(), next.data(), bkt.data(), order);
+  return PR_OK;
+}
+
+int pr_pts_preprocess_gpu(pr_ctx* ctx, const char* poses_file, const char* pts_file, const char* incoming_id_file,
+                          double lidarRange, int polar, int verbose, pr_clouds** out) {
+  if (!ctx) return PR_EINVAL;
+  if (!poses_file || !pts_file || !out || !(lidarRange > 0)) PR_FAIL(ctx, PR_EINVAL, "pr_pts_preprocess_gpu: bad arguments");
+  if (int rc = set_device(ctx)) return rc;
+  std::vector<pr_rec::PoseRec> poses;
+  pr_rec::History h;
+  pr_rec::read_records(poses_file, pts_file, poses, h);
+  FILE* idf = nullptr;
+  if (incoming_id_file) {
+    idf = fopen(incoming_id_file, "w");
+    if (!idf) PR_FAIL(ctx, PR_EIO, "cannot write %s", incoming_id_file);
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  const int M = (int)poses.size();
+  const int64_t T = (int64_t)h.id.size();
+  // host bookkeeping of the pose loop (pts_preprocess.h:187-215): resets, the 30 skipped frames, which point is appended
+  // at which pose
+  std::vector<unsigned char> emit(M ? M : 1, 0);
+  std::vector<int> next_reset(M ? M : 1, M), birth((size_t)(T ? T : 1), -1), pose_of;
+  std::vector<int64_t> cur_after(M ? M : 1, 0);
+  std::vector<double> W((size_t)(M ? M : 1) * 12);
+  {
+    size_t cursor = 0;
+    int since_reset = 0;
+    std::vector<int> resets;
+    for (int p = 0; p < M; p++) {
+      const double* w = poses[p].w;
+      memcpy(&W[(size_t)p * 12], w, 12 * sizeof(double));
+      if (std::sqrt(w[3] * w[3] + w[7] * w[7] + w[11] * w[11]) < 1.0) {
+        if (verbose) printf("\nReset at id: %d\n", poses[p].id);
+        since_reset = 0;
+        resets.push_back(p);
+      }
+      while (cursor < (size_t)T && h.id[cursor] <= poses[p].id) birth[cursor++] = p;
+      cur_after[p] = (int64_t)cursor;
+      if (since_reset < 30) { since_reset++; continue; }
+      emit[p] = 1;
+      pose_of.push_back(p);
+    }
+    size_t ri = 0;
+    for (int p = 0; p < M; p++) {          // first reset pose strictly after p
+      while (ri < resets.size() && resets[ri] <= p) ri++;
+      next_reset[p] = ri < resets.size() ? resets[ri] : M;
+    }
+  }
+  const int E = (int)pose_of.size();
+  pr_clouds* res = new (std::nothrow) pr_clouds;
+  if (!res) { if (idf) fclose(idf); PR_FAIL(ctx, PR_ENOMEM, "out of host memory"); }
+  res->offs.assign(1, 0);
+  int rc = PR_OK;
+  DevBuf dxyz, dint, dbirth, dW, demit, dnr, ddeath, dpose, dfa, dcur, doff, dcnt, dlist, dcell, dval, dtv, dtf, dtb, dkeys, dwin,
+      dnk, dscnt, dsnb, dnext, dboff, dbkt, dord, dooff, doxyz, doint;
+#define PRE_HIP(call) { hipError_t _e = (call); if (_e != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(_e); \
+                        rc = (_e == hipErrorOutOfMemory) ? PR_ENOMEM : PR_EHIP; break; } }
+#define UP(buf, vec) { PRE_HIP((buf).alloc((vec).size() * sizeof((vec)[0]))); \
+                       PRE_HIP(hipMemcpyAsync((buf).p, (vec).data(), (vec).size() * sizeof((vec)[0]), hipMemcpyHostToDevice, ctx->stream)); }
+  do {
+    if (E == 0 || T == 0) break;           // every emitting pose gets an empty cloud below
+    UP(dxyz, h.xyz); UP(dint, h.it); UP(dbirth, birth); UP(dW, W); UP(demit, emit); UP(dnr, next_reset); UP(dpose, pose_of);
+    PRE_HIP(ddeath.alloc((size_t)T * 4));
+    pr::launch_death(ctx->stream, dxyz.as<double>(), dbirth.as<int>(), T, dW.as<double>(), demit.as<unsigned char>(), dnr.as<int>(),
+                     lidarRange, ddeath.as<int>());
+    std::vector<int> death((size_t)T);
+    PRE_HIP(hipMemcpyAsync(death.data(), ddeath.p, (size_t)T * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PRE_HIP(hipStreamSynchronize(ctx->stream));
+    // candidate range of every emitting pose: [first alive point, points appended so far); dead is for good, so the lower
+    // end only moves forward
+    std::vector<int64_t> fa(E), cur(E), off((size_t)E + 1, 0);
+    {
+      int64_t ptr = 0;
+      for (int e = 0; e < E; e++) {
+        const int p = pose_of[e];
+        cur[e] = cur_after[p];
+        while (ptr < cur[e] && death[ptr] <= p) ptr++;
+        fa[e] = ptr;
+      }
+    }
+    UP(dfa, fa); UP(dcur, cur);
+    PRE_HIP(dcnt.alloc((size_t)E * 4));
+    pr::launch_members(ctx->stream, E, ddeath.as<int>(), dpose.as<int>(), dfa.as<int64_t>(), dcur.as<int64_t>(), nullptr, dcnt.as<int>(), nullptr);
+    std::vector<int> cnt(E);
+    PRE_HIP(hipMemcpyAsync(cnt.data(), dcnt.p, (size_t)E * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PRE_HIP(hipStreamSynchronize(ctx->stream));
+    for (int e = 0; e < E; e++) off[e + 1] = off[e] + cnt[e];
+    const int64_t S = off[E];
+    UP(doff, off);
+    PRE_HIP(dlist.alloc((size_t)S * 4)); PRE_HIP(dcell.alloc((size_t)S * 4)); PRE_HIP(dval.alloc((size_t)S * 8));
+    PRE_HIP(dkeys.alloc((size_t)S * 4)); PRE_HIP(dwin.alloc((size_t)S * 4)); PRE_HIP(dnk.alloc((size_t)E * 4));
+    pr::launch_members(ctx->stream, E, ddeath.as<int>(), dpose.as<int>(), dfa.as<int64_t>(), dcur.as<int64_t>(), doff.as<int64_t>(),
+                       dcnt.as<int>(), dlist.as<int>());
+    // dense (pose, cell) tables, a batch of poses at a time (16 B per cell)
+    const int64_t C = pr::prestage_cells(lidarRange, polar);
+    int PB = (int)std::max<int64_t>(1, std::min<int64_t>(E, ((int64_t)4 << 30) / (16 * C)));
+    PRE_HIP(dtv.alloc((size_t)PB * C * 8)); PRE_HIP(dtf.alloc((size_t)PB * C * 4)); PRE_HIP(dtb.alloc((size_t)PB * C * 4));
+    bool fail = false;
+    for (int e0 = 0; e0 < E && !fail; e0 += PB) {
+      const int e1 = std::min(E, e0 + PB);
+      if (hipMemsetAsync(dtv.p, 0xFF, (size_t)(e1 - e0) * C * 8, ctx->stream) != hipSuccess ||
+          hipMemsetAsync(dtf.p, 0xFF, (size_t)(e1 - e0) * C * 4, ctx->stream) != hipSuccess ||
+          hipMemsetAsync(dtb.p, 0xFF, (size_t)(e1 - e0) * C * 4, ctx->stream) != hipSuccess) { fail = true; break; }
+      pr::launch_cells(ctx->stream, dxyz.as<double>(), dlist.as<int>(), doff.as<int64_t>(), dpose.as<int>(), e0, e1, off[e0], off[e1],
+                       dW.as<double>(), lidarRange, polar, C, dcell.as<int>(), dval.as<unsigned long long>(),
+                       dtv.as<unsigned long long>(), dtf.as<unsigned>(), dtb.as<unsigned>());
+      pr::launch_keys(ctx->stream, doff.as<int64_t>(), e0, e1, C, dcell.as<int>(), dlist.as<int>(), dtf.as<unsigned>(), dtb.as<unsigned>(),
+                      dkeys.as<int>(), dwin.as<int>(), dnk.as<int>());
+    }
+    if (fail) { ctx->err = "hipMemsetAsync failed"; rc = PR_EHIP; break; }
+    std::vector<int> nk(E);
+    PRE_HIP(hipMemcpyAsync(nk.data(), dnk.p, (size_t)E * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PRE_HIP(hipStreamSynchronize(ctx->stream));
+    PRE_HIP(hipGetLastError());
+    int kmax = 0;
+    for (int e = 0; e < E; e++) kmax = std::max(kmax, nk[e]);
+    std::vector<int> scnt, snb;
+    probe_bucket_schedule(kmax, scnt, snb);
+    if (scnt.empty()) { scnt.push_back(0); snb.push_back(1); }
+    std::vector<int64_t> boff((size_t)E + 1, 0), ooff((size_t)E + 1, 0);
+    for (int e = 0; e < E; e++) {
+      int nbk = 1;
+      for (size_t i = 0; i < scnt.size() && scnt[i] < std::max(nk[e], 1); i++) nbk = snb[i];
+      boff[e + 1] = boff[e] + nbk;
+      ooff[e + 1] = ooff[e] + nk[e];
+    }
+    const int64_t TOT = ooff[E];
+    UP(dscnt, scnt); UP(dsnb, snb); UP(dboff, boff); UP(dooff, ooff);
+    PRE_HIP(dnext.alloc((size_t)S * 4)); PRE_HIP(dord.alloc((size_t)S * 4)); PRE_HIP(dbkt.alloc((size_t)boff[E] * 4));
+    PRE_HIP(doxyz.alloc((size_t)TOT * 24)); PRE_HIP(doint.alloc((size_t)TOT * 4));
+    pr::launch_order(ctx->stream, E, doff.as<int64_t>(), dnk.as<int>(), dkeys.as<int>(), dscnt.as<int>(), dsnb.as<int>(), (int)scnt.size(),
+                     dnext.as<int>(), dboff.as<int64_t>(), dbkt.as<int>(), dord.as<int>());
+    pr::launch_gather(ctx->stream, E, TOT, doff.as<int64_t>(), dooff.as<int64_t>(), dpose.as<int>(), dord.as<int>(), dwin.as<int>(),
+                      dxyz.as<double>(), dint.as<float>(), dW.as<double>(), lidarRange, doxyz.as<double>(), doint.as<float>());
+    res->xyz.resize((size_t)TOT * 3);
+    res->inten.resize((size_t)TOT);
+    PRE_HIP(hipMemcpyAsync(res->xyz.data(), doxyz.p, (size_t)TOT * 24, hipMemcpyDeviceToHost, ctx->stream));
+    PRE_HIP(hipMemcpyAsync(res->inten.data(), doint.p, (size_t)TOT * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PRE_HIP(hipStreamSynchronize(ctx->stream));
+    PRE_HIP(hipGetLastError());
+    for (int e = 0; e < E; e++) res->offs.push_back(ooff[e + 1]);
+  } while (0);
+#undef UP
+#undef PRE_HIP
+  if (rc != PR_OK) { (void)hipStreamSynchronize(ctx->stream); delete res; if (idf) fclose(idf); return rc; }
+  if (res->offs.size() == 1) res->offs.resize((size_t)E + 1, 0);
+  for (int e = 0; e < E; e++) {
+    res->ids.push_back(poses[pose_of[e]].id);
+    if (idf) fprintf(idf, "%d\n", poses[pose_of[e]].id);
+  }
+  if (idf) fclose(idf);
+  const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  res->avg_ms = E ? 1000.0 * secs / E : NAN;
+  res->avg_pts = E ? (double)res->inten.size() / E : NAN;
+  if (verbose)
+    printf("\ngenerate_spherical_points average time: %gms average points: %g\n", (double)(float)res->avg_ms, (double)(float)res->avg_pts);
+  *out = res;
+  return PR_OK;
 }
 
 // ------------------------------------------------------------------------------------------- signature sets

@@ -45,6 +45,7 @@ def lib():
     L.pr_ref_m2dp_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, _dp, _dp]
     L.pr_ref_delight_generate.argtypes = [_dp, _fp, _lp, C.c_int32, _dp]
     L.pr_ref_delight_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, _dp]
+    L.pr_ref_unordered_order.argtypes = [_ip, C.c_int32, _ip]
     L.pr_ref_select_topk.argtypes = [_dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _dp]
     L.pr_ref_fuse_topk.argtypes = [_dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, _ip, _dp]
     L.pr_ref_match_topk.argtypes = [C.c_int, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_double, C.c_int32, _ip, _dp]
@@ -178,3 +179,10 @@ def delight_distance(h1, h2):
     rc = lib().pr_ref_delight_distance(h1, m, h2, n, d)
     assert rc == 0
     return d
+
+
+def unordered_order(keys):
+    k = np.ascontiguousarray(keys, np.int32)
+    out = np.empty(len(k), np.int32)
+    assert lib().pr_ref_unordered_order(k, len(k), out) == 0
+    return out

@@ -59,3 +59,22 @@ def test_config1_end_to_end(golden_dir, tmp_path):
         rc, oidx, osc = oracle_lib.match_topk(t, got, got, 10, 2.0, 2)         # same (text-rounded) inputs on both sides
         assert np.array_equal(m[:, [0, 2]].astype(np.int32), oidx)
         assert np.abs(m[:, [1, 3]] - osc).max() < 5e-4
+
+
+@pytest.mark.gpu
+def test_gpu_prestage_option_gives_the_same_files(golden_dir, tmp_path):
+    """`_gpu_prestage:=1` (row f1): same incoming ids and the same signature file as the host pre-stage."""
+    full = open(os.path.join(golden_dir, "kitti_seq07", "poses_history_file.txt")).read().split("\n")
+    poses = str(tmp_path / "poses_history_file.txt")
+    open(poses, "w").write("\n".join(full[:90]) + "\n")
+    pts = str(tmp_path / "pts_history_file.txt")
+    helpers.write_synthetic_points(poses, pts, per_pose=60)
+    outs = []
+    for g in (0, 1):
+        sig = str(tmp_path / f"sc_{g}.txt"); ids = str(tmp_path / f"ids_{g}.txt")
+        r = subprocess.run([os.path.join(BIN, "test_sc"), f"_poses_history_file:={poses}", f"_pts_history_file:={pts}",
+                            f"_sc_file:={sig}", f"_incoming_id_file:={ids}", f"_gpu_prestage:={g}"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert "generate_spherical_points average time" in r.stdout
+        outs.append((open(sig, "rb").read(), open(ids, "rb").read()))
+    assert outs[0] == outs[1]

@@ -90,3 +90,60 @@ def test_binary_sidecar_roundtrip(tmp_path):
     (tmp_path / "bad.bin").write_bytes(b"nope")
     with pytest.raises(api.PRError):
         api.read_signatures(str(tmp_path / "bad.bin"))
+
+
+# ------------------------------------------------------------------------------------------------ f1 (GPU pre-stage)
+@pytest.mark.parametrize("K", [0, 1, 2, 12, 13, 14, 29, 30, 59, 60, 61, 1000, 5003, 70000])
+def test_hash_order_emulation_matches_libstdcxx(K):
+    """csrc/hash_order.hpp (what the GPU pre-stage runs per cloud) vs the real std::unordered_map in the oracle: the
+    iteration order for distinct keys in a given insertion order, across every rehash threshold."""
+    rng = np.random.default_rng(K)
+    for trial, hi in enumerate((K + 1, 65341, 450241)):
+        keys = rng.permutation(max(hi, K))[:K].astype(np.int32)
+        got = api.hash_order(keys)
+        want = oracle_lib.unordered_order(keys)
+        assert np.array_equal(got, want), (K, trial)
+    seq = np.arange(K, dtype=np.int32)[::-1].copy()               # descending keys: collision chains in every bucket
+    assert np.array_equal(api.hash_order(seq), oracle_lib.unordered_order(seq))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("polar", [False, True])
+def test_gpu_prestage_equals_host_prestage(seq07, polar):
+    poses, pts, d = seq07
+    idh = str(d / f"ids_host_{polar}.txt"); idg = str(d / f"ids_gpu_{polar}.txt")
+    hx, hi, ho, hid = api.pts_preprocess(poses, pts, idh, 45.0, polar)
+    gx, gi, go, gid = api.pts_preprocess(poses, pts, idg, 45.0, polar, gpu=True)
+    assert np.array_equal(go, ho) and np.array_equal(gid, hid)
+    assert ho[-1] > 10000
+    assert np.array_equal(gx.view(np.uint64), hx.view(np.uint64))  # same points, same ORDER, same bits
+    assert np.array_equal(gi.view(np.uint32), hi.view(np.uint32))
+    assert open(idg, "rb").read() == open(idh, "rb").read()
+
+
+@pytest.mark.gpu
+def test_gpu_prestage_resets_ranges_and_empty_inputs(golden_dir, tmp_path):
+    """Two sequences back to back (a second reset in the middle), a shorter lidar range, unsorted point ids, and the
+    degenerate inputs."""
+    full = open(os.path.join(golden_dir, "kitti_seq07", "poses_history_file.txt")).read().split("\n")
+    lines = [l for l in full[:90] if l.strip()]
+    second = []
+    for k, l in enumerate(lines[:70]):                             # same trajectory again with later ids: |t| < 1 -> reset
+        t = l.split(); t[0] = str(int(lines[-1].split()[0]) + 1 + k); second.append(" ".join(t) + " ")
+    poses = str(tmp_path / "poses.txt"); open(poses, "w").write("\n".join(lines + second) + "\n")
+    pts = str(tmp_path / "pts.txt")
+    helpers.write_synthetic_points(poses, pts, per_pose=50)
+    rows = open(pts).read().strip().split("\n")
+    rows[100], rows[4000] = rows[4000], rows[100]                  # an out-of-order id: the cursor waits behind it
+    open(pts, "w").write("\n".join(rows) + "\n")
+    for polar, rng_ in ((False, 45.0), (True, 45.0), (False, 20.0), (True, 12.5)):
+        h = api.pts_preprocess(poses, pts, None, rng_, polar)
+        g = api.pts_preprocess(poses, pts, None, rng_, polar, gpu=True)
+        assert np.array_equal(g[2], h[2]) and np.array_equal(g[3], h[3])
+        assert np.array_equal(g[0].view(np.uint64), h[0].view(np.uint64)) and np.array_equal(g[1].view(np.uint32), h[1].view(np.uint32))
+    empty = str(tmp_path / "empty.txt"); open(empty, "w").write("")
+    g = api.pts_preprocess(poses, empty, None, 45.0, False, gpu=True)
+    h = api.pts_preprocess(poses, empty, None, 45.0, False)
+    assert np.array_equal(g[2], h[2]) and np.array_equal(g[3], h[3]) and g[0].shape == (0, 3)
+    g = api.pts_preprocess(empty, empty, None, 45.0, True, gpu=True)
+    assert len(g[3]) == 0 and len(g[2]) == 1
