@@ -12,7 +12,7 @@ for grp in "$@"; do
   i=$((i+1))
   d=$out/${tag}_p$i
   rm -rf $d
-  rocprofv3 --pmc $grp -d $d -o sc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline > $d.log 2>&1
+  rocprofv3 --pmc $grp -d $d -o sc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline ${PMC_BENCH_ARGS:-} > $d.log 2>&1
   python $root/profiles/summarize.py $(find $d -name "*_results.db") | grep -E "^==|sc_match" >> $out/$tag.txt
 done
 cat $out/$tag.txt
