@@ -26,8 +26,8 @@ enum { PR_TYPE_SC = 0, PR_TYPE_M2DP = 1, PR_TYPE_DELIGHT = 2 };   /* run_test.m:
 enum { PR_ROLE_QUERY = 0, PR_ROLE_DB = 1 };         /* hist1 / hist2 of run_test.m:1 */
 enum { PR_F64 = 0, PR_F32 = 1 };
 enum { PR_HOST = 0, PR_DEVICE = 1 };
-/* arithmetic of the SC matcher (processSC.m:22-33 on the GPU): split-f16 (hi + lo operands, three f16 MFMAs per product,
- * fp32 accumulate; default, ~2x faster, same error as fp32) or plain fp32 MFMA */
+/* arithmetic of the SC and M2DP matchers (processSC.m:22-33, processM2DP.m:12-22 on the GPU): split-f16 (fp32 operands carried
+ * as f16 hi + lo, three f16 MFMAs per product, fp32 accumulate; default, 2-3x faster, same 1e-7 error as fp32) or plain fp32 MFMA */
 enum { PR_SC_ARITH_F16X2 = 0, PR_SC_ARITH_F32 = 1 };
 
 #define PR_SC_SIG_LEN 2400    /* 2 x numS*numR = 2 x 60*20, SC/SC.h:7-8, test_sc.cpp:37-38 */
@@ -39,7 +39,7 @@ int pr_create(int device_id, pr_ctx** out);
 void pr_destroy(pr_ctx* ctx);
 const char* pr_last_error(const pr_ctx* ctx);        /* valid until the next call on ctx; ctx may be NULL */
 const char* pr_version(void);
-/* Selects the SC matcher arithmetic for signature sets created AFTERWARDS (a set is packed for one arithmetic; matching two
+/* Selects the matcher arithmetic (SC and M2DP) for signature sets created AFTERWARDS (a set is packed for one arithmetic; matching two
  * sets packed differently is PR_EINVAL).  Initial value: PR_SC_ARITH_F16X2, or PR_SC_ARITH_F32 if the environment has
  * PR_SC_MATCH=f32. */
 int pr_set_sc_arith(pr_ctx* ctx, int arith);

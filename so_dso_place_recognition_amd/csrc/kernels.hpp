@@ -43,6 +43,9 @@ size_t sc_match_h_lds_bytes();
 // m2dp_match.hip — processM2DP.m:12-22 for both channels.
 void launch_m2dp_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed, int tiles);
 void launch_m2dp_match(hipStream_t st, const float* qpk, int m, const float* dpk, int n, float* d_p, float* d_i);
+// m2dp_match_h.hip — the same with split-f16 operands on the f16 matrix cores (tiles of the same size, packed by launch_m2dp_pack_h)
+void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, void* packed, int tiles);
+void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i);
 
 // fuse_select.hip — run_test.m:38-41,47-53,57
 void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom);

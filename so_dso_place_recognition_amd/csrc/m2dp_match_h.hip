@@ -1,0 +1,162 @@
+// m2dp_match_h.hip — all-pairs M2DP distance on the gfx950 f16 matrix cores with split-f16 operands (processM2DP.m:12-22).
+//
+// Same GEMM and fused 4x4 block-min epilogue as m2dp_match.hip ([4m x 192] . [192 x 4n] per channel), same arithmetic
+// idea as sc_match_h.hip: every fp32 entry x (scaled by 2^8) is carried as hi = f16(x), lo = f16(x - hi), every product as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (16x the fp32 MFMA rate for 3x the products).
+// Both operands are inputs, so the split happens once at pack time; the kernel is a plain tiled GEMM.
+//
+// Layout (m2dp_pack_h): per channel, per tile of 32 rows (8 signatures x 4 variants): [K-step 0..11][hi | lo][lane][8 f16],
+// lane l holds row l & 31 at k = 16*step + 8*(l >> 5) + 0..7: exactly the A (or B) operand registers of one 32x32x16 MFMA,
+// one 16-byte load per operand and K-step; 24 576 B per tile and channel (the size of the fp32 tile).
+// A workgroup (4 waves) owns 4 query tiles (32 queries) resident in LDS (96 KB) and sweeps the DB 8 tiles at a time; each
+// wave computes all 4 query tiles x its own 2 DB tiles per step (24 MFMAs per K-step and 4 DB operand loads: half the
+// L1 traffic per MFMA of a 2x2 wave tile), DB operands straight from L2/L1 into VGPRs.
+#include "kernels.hpp"
+
+namespace pr {
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TB = M2_TILE * 4;            // bytes per (channel, tile)
+constexpr int TV = TB / 16;                // 16-byte vectors per tile: [step 12][hi|lo][64]
+
+template <typename T>
+__global__ __launch_bounds__(256) void m2dp_pack_h_kernel(const T* __restrict__ sig, int sigs, unsigned short* __restrict__ packed,
+                                                           int tiles) {
+  const int sg = blockIdx.x, tid = threadIdx.x;      // one workgroup per signature (4 variant rows x 384)
+  const int tile = sg >> 3, e = sg & 7;
+  for (int o = tid; o < 4 * 384; o += 256) {
+    const int var = o / 384, c = o - var * 384, ch = c / 192, k = c - ch * 192;
+    const double v = (double)sig[((size_t)sg * 4 + var) * 384 + c] * 256.0;
+    const _Float16 hi = (_Float16)v;
+    const _Float16 lo = (_Float16)(v - (double)hi);
+    const int row = e * 4 + var, step = k >> 4, lane = (((k >> 3) & 1) << 5) | row;
+    const size_t base = ((size_t)ch * tiles + tile) * (TB / 2) + ((size_t)(step * 2) * 64 + lane) * 8 + (k & 7);
+    packed[base] = __builtin_bit_cast(unsigned short, hi);
+    packed[base + 64 * 8] = __builtin_bit_cast(unsigned short, lo);
+  }
+}
+
+struct HL { u32x4 h, l; };
+
+__global__ __launch_bounds__(256, 1) void m2dp_match_h_kernel(const u32x4* __restrict__ qpk, const u32x4* __restrict__ dpk,
+                                                              float* __restrict__ dist_p, float* __restrict__ dist_i,
+                                                              int m, int n, int QT, int DT, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) u32x4 ldsv[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int b = blockIdx.x;
+  const int split = b % nsplit;
+  b /= nsplit;
+  const int ch = b & 1, qt4 = b >> 1;               // 4 query tiles per workgroup
+  const int DT8 = (DT + 7) / 8;                     // DB swept in steps of 8 tiles (2 per wave)
+  const int s0 = (int)((long long)DT8 * split / nsplit), s1 = (int)((long long)DT8 * (split + 1) / nsplit);
+  {
+    const u32x4* src = qpk + ((size_t)ch * QT + (size_t)qt4 * 4) * TV;
+    for (int i = tid; i < 4 * TV; i += 256) ldsv[i] = src[i];
+  }
+  __syncthreads();
+  const u32x4* la = ldsv + lane;
+  float* dist = ch ? dist_i : dist_p;
+  // distances of this workgroup's 32 query rows: invalid rows fall outside the descriptor's range
+  const int qrow0 = qt4 * 32;
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+      dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 32 ? m - qrow0 : 32) : 0) * n * 4, 0x00020000);
+  const unsigned st_lane = (unsigned)((lane >> 5) * n + ((lane & 31) >> 2)) * 4u;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (s0 >= s1) return;
+  // DB operand stream of this wave: tiles (8 s + 2 w) and (8 s + 2 w + 1).  Software pipeline: DB operands two K-steps
+  // ahead (3 rotating register sets), query operands (LDS) one ahead, loads pinned in front of the 24 MFMAs of the current
+  // K-step; the first two K-steps of the NEXT sweep step are requested before this step's epilogue (the packed buffer has
+  // a readable tail).
+  const u32x4* pb = dpk + ((size_t)ch * DT + (size_t)s0 * 8 + w * 2) * TV + lane;
+  HL b0[3], b1[3], a[2][4];
+#define LDB(dst0, dst1, p, st) { dst0.h = (p)[(st) * 128]; dst0.l = (p)[(st) * 128 + 64]; dst1.h = (p)[TV + (st) * 128]; dst1.l = (p)[TV + (st) * 128 + 64]; }
+#define LDA(dst, st) { _Pragma("unroll") for (int t = 0; t < 4; t++) { dst[t].h = la[t * TV + (st) * 128]; dst[t].l = la[t * TV + (st) * 128 + 64]; } }
+#define MF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
+  LDB(b0[0], b1[0], pb, 0)
+  LDB(b0[1], b1[1], pb, 1)
+  for (int s = s0; s < s1; s++) {
+    const int dt0 = s * 8 + w * 2;
+    const u32x4* pn = pb + 8 * TV;           // same wave column, next sweep step
+    f32x16 acc[4][2];
+    LDA(a[0], 0)
+#pragma unroll
+    for (int st = 0; st < 12; st++) {
+      const int cb = st % 3, nb = (st + 2) % 3, ca = st & 1, na = (st + 1) & 1;
+      if (st + 2 < 12) LDB(b0[nb], b1[nb], pb, st + 2)
+      else             LDB(b0[nb], b1[nb], pn, st - 10)
+      if (st + 1 < 12) LDA(a[na], st + 1)
+      __builtin_amdgcn_sched_barrier(0);
+      const bool first = st == 0;
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        acc[t][0] = MF(a[ca][t].h, b0[cb].h, first ? zero : acc[t][0]);
+        acc[t][1] = MF(a[ca][t].h, b1[cb].h, first ? zero : acc[t][1]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        acc[t][0] = MF(a[ca][t].h, b0[cb].l, acc[t][0]);
+        acc[t][1] = MF(a[ca][t].h, b1[cb].l, acc[t][1]);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        acc[t][0] = MF(a[ca][t].l, b0[cb].h, acc[t][0]);
+        acc[t][1] = MF(a[ca][t].l, b1[cb].h, acc[t][1]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // 12 K-steps advance the period-3 rotation by 0: b0[0], b0[1] already hold K-steps 0, 1 of the next sweep step
+    pb = pn;
+    // epilogue: C layout col = lane&31 -> (entry = col>>2, variant = col&3); row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+    // -> (query = 2*(reg>>2) + (lane>>5), variant = reg&3).  d = min (1-dot)/2 = 0.5 - 0.5 * 2^-16 * max dot.
+    // Branch-free: quad reductions as DPP-source v_max, one buffer store per (query tile, DB tile, query pair) whose
+    // invalid lanes are out of range.
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+      for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++) {
+          float mx = fmaxf(fmaxf(acc[i][j][gq * 4], acc[i][j][gq * 4 + 1]),
+                           fmaxf(acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]));
+          mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
+          mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
+          // query row (local to the workgroup's 32) = 8 i + 2 gq + (lane >> 5), entry = 8 (dt0 + j) + ((lane & 31) >> 2)
+          const int drow = (dt0 + j) * 8 + ((lane & 31) >> 2);
+          const unsigned off = ((lane & 3) == 0 && drow < n) ? st_lane + (unsigned)((8 * i + 2 * gq) * n + (dt0 + j) * 8) * 4u : 0x80000000u;
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(mx, -0x1p-17f, 0.5f)), rd, (int)off, 0, 0);   // processM2DP.m:15,19
+        }
+  }
+#undef LDB
+#undef LDA
+#undef MF
+}
+
+}  // namespace
+
+void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, void* packed, int tiles) {
+  if (sigs <= 0) return;
+  if (dtype == 0)
+    hipLaunchKernelGGL(m2dp_pack_h_kernel<double>, dim3(sigs), dim3(256), 0, st, (const double*)sig, sigs, (unsigned short*)packed, tiles);
+  else
+    hipLaunchKernelGGL(m2dp_pack_h_kernel<float>, dim3(sigs), dim3(256), 0, st, (const float*)sig, sigs, (unsigned short*)packed, tiles);
+}
+
+void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i) {
+  if (m <= 0 || n <= 0) return;
+  const int QT = ((m2_tiles(m) + 3) / 4) * 4, DT = m2_tiles(n);
+  const int base = (QT / 4) * 2, DT8 = (DT + 7) / 8;
+  int nsplit = (1024 + base - 1) / base;
+  if (nsplit > DT8 / 4) nsplit = DT8 / 4;
+  if (nsplit < 1) nsplit = 1;
+  const size_t lds = (size_t)4 * TB;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(m2dp_match_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(m2dp_match_h_kernel, dim3(base * nsplit), dim3(256), lds, st, static_cast<const u32x4*>(qpk),
+                     static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
+}
+
+}  // namespace pr

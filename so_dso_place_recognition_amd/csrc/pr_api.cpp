@@ -87,7 +87,7 @@ size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups, int sc_m
   }
   if (role == PR_ROLE_QUERY) { *groups = ((pr::m2_tiles(max_sigs) + 3) / 4) * 4; return (size_t)2 * *groups * pr::M2_TILE; }
   *groups = pr::m2_tiles(max_sigs);
-  return (size_t)(2 * *groups + 8) * pr::M2_TILE;                  // + tail tiles read by the last sweep step
+  return (size_t)(2 * *groups + 16) * pr::M2_TILE;                 // + tail tiles read by the last sweep step (8 tiles per step + prefetch)
 }
 
 int check_flags(pr_ctx* ctx) {
@@ -476,7 +476,8 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
   else if (s->type == PR_TYPE_SC)
     pr::launch_sc_pack(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags);
   else if (s->type == PR_TYPE_M2DP)
-    pr::launch_m2dp_pack(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
+    if (s->sc_mode == PR_SC_ARITH_F16X2) pr::launch_m2dp_pack_h(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
+    else pr::launch_m2dp_pack(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
   else
     pr::launch_delight_pack(ctx->stream, dsig, dtype, n_sigs, s->packed);
   PR_HIP(ctx, hipGetLastError());
@@ -491,14 +492,15 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
   if (q->type != db->type || q->role != PR_ROLE_QUERY || db->role != PR_ROLE_DB)
     PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: q must be a QUERY set and db a DB set of the same type");
   if (int rc = set_device(ctx)) return rc;
-  if (q->type == PR_TYPE_SC && q->sc_mode != db->sc_mode)
-    PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: the two SC sets were packed for different arithmetic modes");
+  if (q->type != PR_TYPE_DELIGHT && q->sc_mode != db->sc_mode)
+    PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: the two sets were packed for different arithmetic modes");
   if (q->type == PR_TYPE_SC && q->sc_mode == 0)
     pr::launch_sc_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit);
   else if (q->type == PR_TYPE_SC)
     pr::launch_sc_match(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst, d_p, d_i, ctx->sc_nsplit);
   else if (q->type == PR_TYPE_M2DP)
-    pr::launch_m2dp_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
+    if (q->sc_mode == PR_SC_ARITH_F16X2) pr::launch_m2dp_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
+    else pr::launch_m2dp_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
   else
     pr::launch_delight_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p);
   PR_HIP(ctx, hipGetLastError());

@@ -264,3 +264,18 @@ def test_sc_mixed_arithmetic_sets_are_rejected(api):
     assert ctx.lib.pr_set_sc_arith(ctx.h, 7) == -1
     ctx.lib.pr_sigset_destroy(ctx.h, q); ctx.lib.pr_sigset_destroy(ctx.h, d)
     ctx.close()
+
+
+def test_m2dp_both_arithmetics_vs_oracle(api):
+    """The arithmetic switch covers the M2DP matcher too (split-f16 GEMM by default, fp32 MFMA with PR_SC_ARITH_F32)."""
+    db = synth.m2dp_database(43, 130)
+    q, _ = synth.m2dp_queries(44, db, 33)
+    rc, oc, oi = oracle_lib.m2dp_distance(q, db)
+    rc, oidx, osc = oracle_lib.match_topk(1, q, db, 2, 2.0, 3)
+    for arith in ("f16x2", "f32"):
+        ctx = api.Context(0, sc_arith=arith)
+        gc, gi = api.processM2DP(q, db, ctx)
+        assert max(np.abs(gc - oc).max(), np.abs(gi - oi).max()) < 2e-6
+        idx, sc = api.match_topk("m2dp", q, db, 2, 2.0, 3, ctx=ctx)
+        assert np.array_equal(idx, oidx)
+        ctx.close()
