@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void m2dp_pack_h_kernel(const T* __restrict__ 
 
 struct HL { u32x4 h, l; };
 
-__global__ __launch_bounds__(256, 1) void m2dp_match_h_kernel(const u32x4* __restrict__ qpk, const u32x4* __restrict__ dpk,
+__global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __restrict__ qpk, const u32x4* __restrict__ dpk,
                                                               float* __restrict__ dist_p, float* __restrict__ dist_i,
                                                               int m, int n, int QT, int DT, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) u32x4 ldsv[];
@@ -68,17 +68,16 @@ __global__ __launch_bounds__(256, 1) void m2dp_match_h_kernel(const u32x4* __res
   const unsigned st_lane = (unsigned)((lane >> 5) * n + ((lane & 31) >> 2)) * 4u;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (s0 >= s1) return;
-  // DB operand stream of this wave: tiles (8 s + 2 w) and (8 s + 2 w + 1).  Software pipeline: DB operands two K-steps
-  // ahead (3 rotating register sets), query operands (LDS) one ahead, loads pinned in front of the 24 MFMAs of the current
-  // K-step; the first two K-steps of the NEXT sweep step are requested before this step's epilogue (the packed buffer has
-  // a readable tail).
+  // DB operand stream of this wave: tiles (8 s + 2 w) and (8 s + 2 w + 1).  Software pipeline: DB and query operands one
+  // K-step (24 MFMAs = 768 cycles) ahead, loads pinned in front of the MFMAs of the current K-step; the first K-step of the
+  // NEXT sweep step is requested before this step's epilogue (the packed buffer has a readable tail).  launch_bounds(256, 2)
+  // caps the wave at 256 unified registers, which keeps the 128 accumulators in ArchVGPRs (no v_accvgpr_read in the epilogue).
   const u32x4* pb = dpk + ((size_t)ch * DT + (size_t)s0 * 8 + w * 2) * TV + lane;
-  HL b0[3], b1[3], a[2][4];
+  HL b0[2], b1[2], a[2][4];
 #define LDB(dst0, dst1, p, st) { dst0.h = (p)[(st) * 128]; dst0.l = (p)[(st) * 128 + 64]; dst1.h = (p)[TV + (st) * 128]; dst1.l = (p)[TV + (st) * 128 + 64]; }
 #define LDA(dst, st) { _Pragma("unroll") for (int t = 0; t < 4; t++) { dst[t].h = la[t * TV + (st) * 128]; dst[t].l = la[t * TV + (st) * 128 + 64]; } }
 #define MF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
   LDB(b0[0], b1[0], pb, 0)
-  LDB(b0[1], b1[1], pb, 1)
   for (int s = s0; s < s1; s++) {
     const int dt0 = s * 8 + w * 2;
     const u32x4* pn = pb + 8 * TV;           // same wave column, next sweep step
@@ -86,9 +85,9 @@ __global__ __launch_bounds__(256, 1) void m2dp_match_h_kernel(const u32x4* __res
     LDA(a[0], 0)
 #pragma unroll
     for (int st = 0; st < 12; st++) {
-      const int cb = st % 3, nb = (st + 2) % 3, ca = st & 1, na = (st + 1) & 1;
-      if (st + 2 < 12) LDB(b0[nb], b1[nb], pb, st + 2)
-      else             LDB(b0[nb], b1[nb], pn, st - 10)
+      const int cb = st & 1, nb = (st + 1) & 1, ca = st & 1, na = (st + 1) & 1;
+      if (st + 1 < 12) LDB(b0[nb], b1[nb], pb, st + 1)
+      else             LDB(b0[nb], b1[nb], pn, 0)
       if (st + 1 < 12) LDA(a[na], st + 1)
       __builtin_amdgcn_sched_barrier(0);
       const bool first = st == 0;
@@ -109,7 +108,7 @@ __global__ __launch_bounds__(256, 1) void m2dp_match_h_kernel(const u32x4* __res
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    // 12 K-steps advance the period-3 rotation by 0: b0[0], b0[1] already hold K-steps 0, 1 of the next sweep step
+    // 12 K-steps advance the period-2 rotation by 0: b0[0] already holds K-step 0 of the next sweep step
     pb = pn;
     // epilogue: C layout col = lane&31 -> (entry = col>>2, variant = col&3); row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // -> (query = 2*(reg>>2) + (lane>>5), variant = reg&3).  d = min (1-dot)/2 = 0.5 - 0.5 * 2^-16 * max dot.
