@@ -98,7 +98,7 @@ int32_t pr_sigset_count(const pr_sigset* s);
  * (row stride n); DELIGHT writes d_p only (d_i may be NULL). */
 int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float* d_p, float* d_i);
 
-/* Per-row two-pass moments of a distance shard (first half of MATLAB normalize(.,2), run_test.m:40):
+/* Per-row moments (one fp64 pass of shifted sums) of a distance shard (first half of MATLAB normalize(.,2), run_test.m:40):
  * mom: DEVICE f64 [m][2][3] = (count, mean, M2 = sum (x-mean)^2) for channel 0 = d_p, 1 = d_i. */
 int pr_row_moments_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n, double* mom);
 

@@ -5,7 +5,7 @@ PyTorch is plumbing here (device buffers, streams, the two small collectives); a
 libpr_amd.so through the C ABI (plain device pointers).
 
 Sharding: every rank holds the DB rows [db_row0, db_row0 + n_local) and ALL queries.
-  1. local: pack, distances (m x n_local), per-row two-pass moments (count, mean, M2) per channel   [HIP]
+  1. local: pack, distances (m x n_local), per-row fp64 moments (count, mean, M2) per channel   [HIP]
   2. all_gather of the moments  (m x 2 x 3 f64 per rank = 48 B per query)                             [RCCL]
   3. local: Chan-combine in rank order -> global mean/std, fused score, mask on GLOBAL indices,
      per-shard top-k (ties -> lower global index)                                                    [HIP]
