@@ -50,3 +50,16 @@ def test_product_does_not_link_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
                 src = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_lib" not in src and "libpr_ref" not in src and "np_checker" not in src, f
+
+
+def test_inline_asm_mfma_operands_are_not_written_right_before_use():
+    """hipcc pads nothing for inline asm: a compiler-generated VALU write (spill reload, copy) of an operand within two
+    instructions of a hand-written MFMA is silent corruption (seen once during development).  tools/audit_asm_hazards.py
+    scans the gfx950 assembly of both SC matchers for it."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = [os.path.join(root, "so_dso_place_recognition_amd", "csrc", f) for f in ("sc_match_h.hip", "sc_match.hip")]
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_asm_hazards.py")] + src, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "186 inline-asm MFMAs checked, 0 finding" in r.stdout
