@@ -63,3 +63,11 @@ def test_inline_asm_mfma_operands_are_not_written_right_before_use():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_asm_hazards.py")] + src, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "186 inline-asm MFMAs checked, 0 finding" in r.stdout
+    # the audit itself: a reload in front of an asm MFMA and a copy of its result right behind it are both reported
+    sys.path.insert(0, os.path.join(root, "tools"))
+    import audit_asm_hazards as aud
+    bad_before = ["v_accvgpr_read_b32 v5, a7", ";;#ASMSTART", "v_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[8:11], 0", ";;#ASMEND"]
+    bad_after = [";;#ASMSTART", "v_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[8:11], 0", ";;#ASMEND", "v_mov_b32_e32 v20, v2"]
+    good = ["v_mov_b32_e32 v5, v30", "s_nop 1", ";;#ASMSTART", "v_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[8:11], 0", ";;#ASMEND",
+            ";;#ASMSTART", "v_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[12:15], v[0:3]", ";;#ASMEND", "s_nop 9", "v_add_f32_e32 v20, v2, v3"]
+    assert aud.audit_lines("x", bad_before) == 1 and aud.audit_lines("x", bad_after) == 1 and aud.audit_lines("x", good) == 0
