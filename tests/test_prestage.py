@@ -48,6 +48,49 @@ def test_missing_files_yield_zero_clouds_like_the_reference(tmp_path):
     assert len(ids) == 0 and list(offs) == [0]
 
 
+# `ifstream >> id >> x >> y >> z >> intensity` (pts_preprocess.h:36-47) is a TOKEN stream that ends at the first failed
+# extraction; what fails is decided by libstdc++'s num_get grammar, not by strtod.  Each case replaces one line in the
+# middle of the points file; the oracle parses with the real ifstream, the product with its sequential parser
+# (PR_PARSE_THREADS=1) and with the chunked multi-threaded one (which must notice the odd line and defer to the former).
+_ODD_LINES = ["{id} nan {y} {z} {it}", "{id} inf {y} {z} {it}", "{id} 0x10 {y} {z} {it}", "{id} +1.5 {y} {z} {it}",
+              "{id} 1e {y} {z} {it}", "{id} 1e+ {y} {z} {it}", "{id} 1ex {y} {z} {it}", "{id} 1e400 {y} {z} {it}",
+              "{id} 1e-400 {y} {z} {it}", "{id} 1.2.3 {y} {z} {it}", "{id} {x} {y} {z}", "{id} {x} {y} {z} {it} 7",
+              "", "   \t ", "{id}.5 {x} {y} {z} {it}", "99999999999 {x} {y} {z} {it}", "{id} - {y} {z} {it}",
+              "{id} 5. .5 -.5e+1 1E0", "{id} {x} {y} {z} 1e39", "{id} {x} {y} {z} {it}\r", "{id}\t{x}  {y}\v{z}\f{it}",
+              "-{id} {x} {y} {z} {it}", "{id} {x},{y} {z} {it}", "# comment"]
+
+
+@pytest.mark.parametrize("case", range(len(_ODD_LINES)))
+def test_points_parser_follows_istream_token_rules(seq07, case, monkeypatch, tmp_path):
+    poses, pts, _ = seq07
+    lines = open(pts).read().split("\n")
+    k = len(lines) // 2
+    f = lines[k].split()
+    lines[k] = _ODD_LINES[case].format(id=f[0], x=f[1], y=f[2], z=f[3], it=f[4])
+    odd = str(tmp_path / "odd.txt")
+    open(odd, "w").write("\n".join(lines))
+    ox, oi, oo, oid = oracle_lib.pts_preprocess(poses, odd, None, 45.0, False)
+    assert oo[-1] > 1000
+    for env in ({"PR_PARSE_THREADS": "1"}, {"PR_PARSE_THREADS": "4", "PR_PARSE_MIN_BYTES": "0"}):
+        for kk, v in env.items():
+            monkeypatch.setenv(kk, v)
+        px, pi, po, pid = api.pts_preprocess(poses, odd, None, 45.0, False)
+        assert np.array_equal(po, oo) and np.array_equal(pid, oid), env
+        assert np.array_equal(px.view(np.uint64), ox.view(np.uint64)), env
+        assert np.array_equal(pi.view(np.uint32), oi.view(np.uint32)), env
+
+
+def test_parallel_points_parser_same_clouds(seq07, monkeypatch):
+    poses, pts, _ = seq07
+    monkeypatch.setenv("PR_PARSE_THREADS", "1")
+    a = api.pts_preprocess(poses, pts, None, 45.0, True)
+    for th in ("2", "3", "8", "32"):
+        monkeypatch.setenv("PR_PARSE_THREADS", th)
+        monkeypatch.setenv("PR_PARSE_MIN_BYTES", "0")
+        b = api.pts_preprocess(poses, pts, None, 45.0, True)
+        assert all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(a, b))
+
+
 def test_signature_text_format_roundtrip(tmp_path):
     rng = np.random.default_rng(3)
     m = rng.normal(size=(5, 7)) * np.array([1, 10, 1e-3, 1e5, 1, 1, 1e-7])
