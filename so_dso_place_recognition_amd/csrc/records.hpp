@@ -84,6 +84,24 @@ struct Cursor {
   bool next_float(float& v) { return next_fp(v, strtof); }
 };
 
+// Host threads for the text formats: PR_PARSE_THREADS overrides (1 = everything on the calling thread), at most 32, and no
+// more than `units` (callers pass the amount of work in units that are worth a thread each).
+inline unsigned host_threads(size_t units) {
+  unsigned T = std::thread::hardware_concurrency();
+  if (const char* e = getenv("PR_PARSE_THREADS")) T = (unsigned)atoi(e);
+  if (T > 32) T = 32;
+  if (T > units) T = (unsigned)units;
+  return T < 1 ? 1 : T;
+}
+
+template <typename F>
+inline void run_threads(unsigned T, F&& body) {
+  std::vector<std::thread> th;
+  for (unsigned t = 1; t < T; t++) th.emplace_back([&body, t] { body(t); });
+  body(0);
+  for (auto& x : th) x.join();
+}
+
 struct PoseRec { int id; double w[12]; };
 struct History { std::vector<int> id; std::vector<double> xyz; std::vector<float> it; };
 
@@ -95,9 +113,7 @@ struct History { std::vector<int> id; std::vector<double> xyz; std::vector<float
 // parses the whole file sequentially with the reference's stop-at-first-failure semantics.
 inline bool parse_points_parallel(const std::string& buf, History& h) {
   const size_t n = buf.size();
-  unsigned T = std::thread::hardware_concurrency();
-  if (const char* e = getenv("PR_PARSE_THREADS")) T = (unsigned)atoi(e);   // 1 = the sequential parser
-  if (T > 32) T = 32;
+  const unsigned T = host_threads(n);
   size_t min_bytes = (size_t)4 << 20;   // below this the thread start-up costs more than the parse
   if (const char* e = getenv("PR_PARSE_MIN_BYTES")) min_bytes = (size_t)atoll(e);
   if (T < 2 || n < min_bytes || n < T) return false;
@@ -139,10 +155,7 @@ inline bool parse_points_parallel(const std::string& buf, History& h) {
       p = eol + 1;
     }
   };
-  std::vector<std::thread> th;
-  for (unsigned t = 1; t < T; t++) th.emplace_back(work, t);
-  work(0);
-  for (auto& x : th) x.join();
+  run_threads(T, work);
   for (unsigned t = 0; t < T; t++)
     if (bad[t]) return false;
   size_t tot = 0;

@@ -109,6 +109,45 @@ def test_signature_text_format_roundtrip(tmp_path):
     assert np.array_equal(np.loadtxt(p), back)
 
 
+@pytest.mark.parametrize("rows,cols", [(1, 1), (3, 2400), (257, 192), (700, 2400)])
+def test_signature_text_threads_do_not_change_a_byte(tmp_path, monkeypatch, rows, cols):
+    rng = np.random.default_rng(rows)
+    m = rng.normal(size=(rows, cols)) * 10.0 ** rng.integers(-8, 6, size=(rows, cols))
+    m[0, 0] = np.nan; m[-1, -1] = -np.inf                                    # Eigen prints them, MATLAB load reads them
+    files, backs = [], []
+    for th in ("1", "2", "7", "32"):
+        monkeypatch.setenv("PR_PARSE_THREADS", th)
+        p = str(tmp_path / f"sig_{th}.txt")
+        api.write_signatures(p, m)
+        files.append(open(p, "rb").read())
+        backs.append(api.read_signatures(p))
+    assert all(f == files[0] for f in files)
+    w = max(len("%g" % v) for v in m.ravel())
+    assert files[0].decode().split("\n")[-1] == " ".join(("%g" % v).rjust(w) for v in m[-1])
+    assert all(b.shape == (rows, cols) and np.array_equal(b, backs[0], equal_nan=True) for b in backs)
+    assert np.array_equal(backs[0], np.array([[float("%g" % v) for v in r] for r in m]), equal_nan=True)
+
+
+def test_signature_reader_stops_at_junk_like_one_thread(tmp_path, monkeypatch):
+    rows = ["%d %d %d" % (3 * i, 3 * i + 1, 3 * i + 2) for i in range(400000)]      # 6 MB: one chunk per MB
+    rows[1500] = "4500 oops 4502"
+    p = str(tmp_path / "junk.txt"); open(p, "w").write("  \n" + " \n".join(rows) + "\n\n")
+    res = []
+    for th in ("1", "8"):
+        monkeypatch.setenv("PR_PARSE_THREADS", th)
+        try:
+            res.append(api.read_signatures(p))
+        except api.PRError as e:
+            res.append(str(e))
+    assert isinstance(res[0], str) and "ragged" in res[0] and res[1] == res[0]   # 4501 numbers before the junk: not k * 3
+    rows[1500] = "4500 4501 4502 oops"
+    open(p, "w").write("\n".join(rows))
+    for th in ("1", "8"):
+        monkeypatch.setenv("PR_PARSE_THREADS", th)
+        b = api.read_signatures(p)
+        assert b.shape == (1501, 3) and b[-1, -1] == 4502
+
+
 def test_posespts_record_format(tmp_path):
     ids = np.array([3, 9], np.int32)
     w = np.arange(24, dtype=np.float64).reshape(2, 12) / 7
