@@ -5,15 +5,16 @@
 //                   float casts: hist = 8*(|p| > 10) + 4*(z > 0) + 2*(y > 0) + (x > 0), bin = int(intensity); 16 x 256 u32
 //                   LDS histogram with LDS atomics -> counts as f64.  HBM-bound (28 B per point).
 //   delight_match : d(i,j) = min over the 4 octant permutations of mean over non-empty bins of 2 (a-b)^2 / (a+b).
-//                   One wave per (query, entry) pair stream: every lane owns 4 histogram columns x 16 rows of the query in
-//                   registers (64 floats) and loads the same columns of the entry with 16 coalesced 16-byte loads; the row
-//                   permutations are register renames.  VALU-bound: 4 x 4096 terms per pair, v_rcp_f32 for the division.
+//                   One wave per query (every lane owns 4 histogram columns x 16 rows = 64 floats in registers), 4 queries
+//                   per workgroup, the entry rows staged through LDS; the row permutations are register renames.
+//                   VALU-bound (4 x 4096 terms per pair): packed fp32, no compares, one v_rcp_f32 per two terms.
 #include "kernels.hpp"
 
 namespace pr {
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 __global__ __launch_bounds__(256) void delight_gen_kernel(const double* __restrict__ xyz, const float* __restrict__ inten,
                                                            const int64_t* __restrict__ offs, const double* __restrict__ frames,
@@ -52,52 +53,131 @@ __global__ __launch_bounds__(256) void delight_pack_kernel(const T* __restrict__
   if (i < n) packed[i] = (float)sig[i];
 }
 
-__device__ __forceinline__ void chi2_perm(const f32x4 (&A)[16], const f32x4 (&B)[16], const int (&mut)[16], float& ts, float& tc) {
-  ts = 0.f; tc = 0.f;
+// Empty-bin masks of the packed histograms: word (r >> 3) of lane l of a signature has bit 4 (r & 7) + c set iff element
+// (row r, column 4 l + c) is zero - the lane layout of the matcher.  One thread per (signature, lane).
+__global__ __launch_bounds__(256) void delight_mask_kernel(const float* __restrict__ packed, int sigs, unsigned* __restrict__ mask) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (size_t)sigs * 64) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(packed) + (t >> 6) * 1024 + (t & 63);
+  unsigned w[2] = {0u, 0u};
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    const f32x4 v = p[r * 64];
+#pragma unroll
+    for (int c = 0; c < 4; c++) w[r >> 3] |= (v[c] == 0.f ? 1u : 0u) << (4 * (r & 7) + c);
+  }
+  mask[2 * t] = w[0];
+  mask[2 * t + 1] = w[1];
+}
+
+// nibble r of the result = nibble r ^ X of v (X = 0, 5, 6, 3: the four octant permutations are XORs of the row index)
+template <int X>
+__device__ __forceinline__ unsigned nibble_xor(unsigned v) {
+  if (X & 1) v = ((v & 0x0f0f0f0fu) << 4) | ((v >> 4) & 0x0f0f0f0fu);
+  if (X & 2) v = ((v & 0x00ff00ffu) << 8) | ((v >> 8) & 0x00ff00ffu);
+  if (X & 4) v = (v << 16) | (v >> 16);
+  return v;
+}
+
+// Two permutations at a time: rows r of the query against rows r ^ X and r ^ Y of the entry (processDELIGHT.m:2-5:
+// {0..15}, {5,4,7,6,1,0,3,2,..}, {6,7,4,5,2,3,0,1,..}, {3,2,1,0,7,6,5,4,..}, the second eight likewise + 8).  A holds
+// a + 2^-60, so that s = a + b and d = a - b are the exact float sums wherever a or b is non-zero and (2^-60, 2^-60) - a
+// term of 2^-60, invisible next to 1 - where both are empty: no compare, no select, packed fp32 adds / multiplies.
+// v_rcp_f32 runs at a quarter of the packed rate and is what bounds the kernel, so the two divisions of an (X, Y) pair
+// share ONE reciprocal: R = 1 / (s_x s_y), 1/s_x = R s_y, 1/s_y = R s_x (three packed multiplies; 2^-120 <= s_x s_y stays
+// normal for histogram counts and for anything else in [1e-15, 1e15]).
+template <int X, int Y>
+__device__ __forceinline__ void chi2_perm2(const f32x4 (&A)[16], const f32x4 (&B)[16], f32x2& accx, f32x2& accy) {
 #pragma unroll
   for (int r = 0; r < 16; r++) {
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const float a = A[r][c], b = B[mut[r]][c], s = a + b, d = a - b;
-      const float t = 2.f * d * d * __builtin_amdgcn_rcpf(s);
-      if (s > 0.f) { ts += t; tc += 1.f; }                                         // processDELIGHT.m:24-28
+    for (int h = 0; h < 2; h++) {
+      const f32x2 a = {A[r][2 * h], A[r][2 * h + 1]};
+      const f32x2 bx = {B[r ^ X][2 * h], B[r ^ X][2 * h + 1]}, by = {B[r ^ Y][2 * h], B[r ^ Y][2 * h + 1]};
+      const f32x2 sx = a + bx, dx = a - bx, sy = a + by, dy = a - by;
+      const f32x2 p = sx * sy;
+      const f32x2 R = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
+      accx = __builtin_elementwise_fma(dx * dx, R * sy, accx);                         // processDELIGHT.m:24-28 (x 2 at the end)
+      accy = __builtin_elementwise_fma(dy * dy, R * sx, accy);
     }
   }
 }
 
-__global__ __launch_bounds__(256) void delight_match_kernel(const float* __restrict__ q, const float* __restrict__ db,
-                                                             float* __restrict__ dist, int m, int n, int nsplit) {
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int i = blockIdx.x / nsplit, split = blockIdx.x % nsplit;
+// Workgroup = 4 queries (one per wave, 64 floats per lane in registers) x a range of entries; the entry rows go through a
+// double-buffered 16 KB LDS tile (one global read per workgroup instead of one per wave, requested one row ahead).
+__global__ __launch_bounds__(256, 2) void delight_match_kernel(const float* __restrict__ q, const float* __restrict__ db,
+                                                                const unsigned* __restrict__ dbmask, float* __restrict__ dist,
+                                                                int m, int n, int nsplit) {
+  __shared__ f32x4 rowbuf[2][1024];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int i = (blockIdx.x / nsplit) * 4 + w, split = blockIdx.x % nsplit;
   const int j0 = (int)((long long)n * split / nsplit), j1 = (int)((long long)n * (split + 1) / nsplit);
+  if (j0 >= j1) return;
+  const bool valid = i < m;
   f32x4 A[16];
-  const f32x4* pa = reinterpret_cast<const f32x4*>(q + (size_t)i * 4096) + lane;
+  unsigned za0 = 0u, za1 = 0u;
+  {
+    const f32x4* pa = reinterpret_cast<const f32x4*>(q + (size_t)(valid ? i : 0) * 4096) + lane;
 #pragma unroll
-  for (int r = 0; r < 16; r++) A[r] = pa[r * 64];
-  constexpr int M0[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};       // processDELIGHT.m:2-5 (0-based)
-  constexpr int M1[16] = {5, 4, 7, 6, 1, 0, 3, 2, 13, 12, 15, 14, 9, 8, 11, 10};
-  constexpr int M2[16] = {6, 7, 4, 5, 2, 3, 0, 1, 14, 15, 12, 13, 10, 11, 8, 9};
-  constexpr int M3[16] = {3, 2, 1, 0, 7, 6, 5, 4, 11, 10, 9, 8, 15, 14, 13, 12};
-  for (int j = j0 + w; j < j1; j += 4) {
+    for (int r = 0; r < 16; r++) {
+      A[r] = pa[r * 64];
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        (r < 8 ? za0 : za1) |= (A[r][c] == 0.f ? 1u : 0u) << (4 * (r & 7) + c);
+        A[r][c] += 0x1p-60f;
+      }
+    }
+  }
+  f32x4 st[4];
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(db + (size_t)j0 * 4096) + tid;
+#pragma unroll
+    for (int k = 0; k < 4; k++) rowbuf[0][tid + 256 * k] = src[256 * k];
+  }
+  __syncthreads();
+  for (int j = j0; j < j1; j++) {
+    const int cur = (j - j0) & 1;
+    if (j + 1 < j1) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(db + (size_t)(j + 1) * 4096) + tid;
+#pragma unroll
+      for (int k = 0; k < 4; k++) st[k] = src[256 * k];
+    }
+    const unsigned zb0 = dbmask[(size_t)j * 128 + 2 * lane], zb1 = dbmask[(size_t)j * 128 + 2 * lane + 1];
     f32x4 B[16];
-    const f32x4* pb = reinterpret_cast<const f32x4*>(db + (size_t)j * 4096) + lane;
 #pragma unroll
-    for (int r = 0; r < 16; r++) B[r] = pb[r * 64];
-    float ts[4], tc[4];
-    chi2_perm(A, B, M0, ts[0], tc[0]);
-    chi2_perm(A, B, M1, ts[1], tc[1]);
-    chi2_perm(A, B, M2, ts[2], tc[2]);
-    chi2_perm(A, B, M3, ts[3], tc[3]);
+    for (int r = 0; r < 16; r++) B[r] = rowbuf[cur][r * 64 + lane];
+    f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+    chi2_perm2<0, 5>(A, B, acc[0], acc[1]);
+    chi2_perm2<6, 3>(A, B, acc[2], acc[3]);
+    float ts[4];
+    // bins empty in both histograms do not count (:25-28): two 13-bit totals per word
+    unsigned e01 = (unsigned)(__builtin_popcount(za0 & zb0) + __builtin_popcount(za1 & zb1)) |
+                   (unsigned)(__builtin_popcount(za0 & nibble_xor<5>(zb0)) + __builtin_popcount(za1 & nibble_xor<5>(zb1))) << 16;
+    unsigned e23 = (unsigned)(__builtin_popcount(za0 & nibble_xor<6>(zb0)) + __builtin_popcount(za1 & nibble_xor<6>(zb1))) |
+                   (unsigned)(__builtin_popcount(za0 & nibble_xor<3>(zb0)) + __builtin_popcount(za1 & nibble_xor<3>(zb1))) << 16;
 #pragma unroll
-    for (int k = 0; k < 4; k++)
-      for (int d = 32; d > 0; d >>= 1) { ts[k] += __shfl_xor(ts[k], d); tc[k] += __shfl_xor(tc[k], d); }
+    for (int k = 0; k < 4; k++) ts[k] = acc[k][0] + acc[k][1];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) ts[k] += __shfl_xor(ts[k], d);
+      e01 += (unsigned)__shfl_xor((int)e01, d);
+      e23 += (unsigned)__shfl_xor((int)e23, d);
+    }
+    const float tc[4] = {4096.f - (float)(e01 & 0xffffu), 4096.f - (float)(e01 >> 16), 4096.f - (float)(e23 & 0xffffu),
+                         4096.f - (float)(e23 >> 16)};
     float best = __builtin_inff();
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-      const float v = ts[k] / tc[k];                                               // :30 (0/0 = NaN never wins, :31)
+      const float v = 2.f * ts[k] / tc[k];                                         // :30 (0/0 = NaN never wins, :31)
       if (best > v) best = v;
     }
-    if (lane == 0) dist[(size_t)i * n + j] = best;
+    if (lane == 0 && valid) dist[(size_t)i * n + j] = best;
+    if (j + 1 < j1) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) rowbuf[cur ^ 1][tid + 256 * k] = st[k];
+    }
+    __syncthreads();
   }
 }
 
@@ -109,20 +189,22 @@ void launch_delight_gen(hipStream_t st, const double* xyz, const float* inten, c
   hipLaunchKernelGGL(delight_gen_kernel, dim3(N), dim3(256), 0, st, xyz, inten, offs, frames, out);
 }
 
-void launch_delight_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed) {
+void launch_delight_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed, unsigned* mask) {
   if (sigs <= 0) return;
   const size_t n = (size_t)sigs * 4096;
   const unsigned blocks = (unsigned)((n + 255) / 256);
   if (dtype == 0) hipLaunchKernelGGL(delight_pack_kernel<double>, dim3(blocks), dim3(256), 0, st, (const double*)sig, n, packed);
   else hipLaunchKernelGGL(delight_pack_kernel<float>, dim3(blocks), dim3(256), 0, st, (const float*)sig, n, packed);
+  hipLaunchKernelGGL(delight_mask_kernel, dim3((unsigned)(((size_t)sigs * 64 + 255) / 256)), dim3(256), 0, st, packed, sigs, mask);
 }
 
-void launch_delight_match(hipStream_t st, const float* q, int m, const float* db, int n, float* dist) {
+void launch_delight_match(hipStream_t st, const float* q, int m, const float* db, const unsigned* dbmask, int n, float* dist) {
   if (m <= 0 || n <= 0) return;
-  int nsplit = (4096 + m - 1) / m;
-  if (nsplit > (n + 3) / 4) nsplit = (n + 3) / 4;
+  const int qb = (m + 3) / 4;
+  int nsplit = (2048 + qb - 1) / qb;                  // >= 4 rounds of 2 workgroups per CU
+  if (nsplit > (n + 7) / 8) nsplit = (n + 7) / 8;     // >= 8 entries per workgroup
   if (nsplit < 1) nsplit = 1;
-  hipLaunchKernelGGL(delight_match_kernel, dim3((unsigned)m * nsplit), dim3(256), 0, st, q, db, dist, m, n, nsplit);
+  hipLaunchKernelGGL(delight_match_kernel, dim3((unsigned)qb * nsplit), dim3(256), 0, st, q, db, dbmask, dist, m, n, nsplit);
 }
 
 }  // namespace pr

@@ -11,14 +11,36 @@
 
 namespace pr {
 
-__device__ __forceinline__ int polar_sector(double y, double x, double S_res_inv, float S_f) {
-  const float t = (atan2f((float)y, (float)x) + 3.14159274f) * S_f;
+__host__ __device__ __forceinline__ int polar_sector(double y, double x, double S_res_inv, float S_f) {
+  const float xf = (float)x, yf = (float)y;
+  const float t = (atan2f(yf, xf) + 3.14159274f) * S_f;
   const float fl = floorf(t), fr = t - fl;
-  if (fr > 1e-3f && fr < 0.999f) return (int)fl;
+  const float mx = fmaxf(fabsf(xf), fabsf(yf));          // the casts must neither overflow nor lose bits to denormals
+  if (fr > 1e-3f && fr < 0.999f && mx > 1e-30f && mx < 3.0e38f) return (int)fl;
   return (int)floor((atan2(y, x) + M_PI) * S_res_inv);
 }
 
-__device__ __forceinline__ int polar_ring(double x, double y, double R_res_inv, float R_f) {
+// 16 sectors (M2DP.cpp:59, S = 16 / 2pi): the sector is decided by the signs of x, y, by |y| > |x| and by
+// min(|x|,|y|) > max(|x|,|y|) tan(pi/8) - no arctangent.  Accepted when the point is at least 1e-3 (relative to
+// max(|x|,|y|), i.e. >= 1e-3 rad) away from all three kinds of boundary (axis, 22.5 deg, diagonal); everything else -
+// boundaries, zeros of either sign, NaN, float overflow / underflow - takes the reference's fp64 expression.
+__host__ __device__ __forceinline__ int polar_sector16(double y, double x, double S_res_inv) {
+  const float xf = (float)x, yf = (float)y;
+  const float a = fabsf(xf), b = fabsf(yf);
+  const float mn = fminf(a, b), mx = fmaxf(a, b);
+  const float e = 1e-3f * mx, t = 0.414213568f * mx;                       // tan(pi/8)
+  if (mn > e && fabsf(mn - t) > e && (mx - mn) > e && mx > 1e-30f && mx < 3.0e38f) {
+    // quadrant of theta + pi: (x<0,y<0) 0, (x>0,y<0) 1, (x>0,y>0) 2, (x<0,y>0) 3; inside it the angle grows from the
+    // negative x axis (even quadrants: tan = |y|/|x|) or from the y axis (odd quadrants: tan = |x|/|y|)
+    const int q = (yf < 0.f) ? (xf < 0.f ? 0 : 1) : (xf < 0.f ? 3 : 2);
+    const bool big = (q & 1) ? (a > b) : (b > a);                         // tangent above 1
+    const bool h = mn > t;                                                // more than 22.5 deg from the nearer axis
+    return q * 4 + (big ? (h ? 2 : 3) : (h ? 1 : 0));
+  }
+  return (int)floor((atan2(y, x) + M_PI) * S_res_inv);
+}
+
+__host__ __device__ __forceinline__ int polar_ring(double x, double y, double R_res_inv, float R_f) {
   const float xf = (float)x, yf = (float)y;
   const float t = sqrtf(xf * xf + yf * yf) * R_f;
   const float fl = floorf(t), fr = t - fl;

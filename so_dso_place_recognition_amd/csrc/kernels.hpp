@@ -66,8 +66,8 @@ size_t m2dp_generate_scratch_bytes(int N);
 // delight.hip — DELIGHT.cpp:8-24, processDELIGHT.m:1-38
 void launch_delight_gen(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
                         const double* frames, double* out);
-void launch_delight_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed);
-void launch_delight_match(hipStream_t st, const float* q, int m, const float* db, int n, float* dist);
+void launch_delight_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed, unsigned* mask);
+void launch_delight_match(hipStream_t st, const float* q, int m, const float* db, const unsigned* dbmask, int n, float* dist);
 
 // prestage.hip — utils/pts_preprocess.h:135-232 on the GPU (see the file header); all pointers are device pointers
 int64_t prestage_cells(double range, int polar);          // dense cell-table length per pose

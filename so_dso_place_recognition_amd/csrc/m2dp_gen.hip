@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
   // variants in the order (-,-), (-,+), (+,-), (+,+)  (test_m2dp.cpp:47-48)
   const double dx = (var & 2) ? 1.0 : -1.0, dy = (var & 1) ? 1.0 : -1.0, dz = dx * dy;
   const double S_res_inv = 16 / (2.0 * M_PI), R_res_inv = 8 / max_rho;   // M2DP.cpp:32-33
-  const float S_f = (float)S_res_inv, R_f = (float)R_res_inv;
+  const float R_f = (float)R_res_inv;
   const double* p = xyz + 3 * o0;
   const float* it = inten + o0;
   for (int64_t i = tid; i < P; i += 256) {
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
     for (int k = 0; k < 16; k++) {
       const double xp = pl[k][0] * q0 + (pl[k][1] * q1 + pl[k][2] * q2);   // M2DP.cpp:56
       const double yp = pl[k][3] * q0 + (pl[k][4] * q1 + pl[k][5] * q2);   // :57
-      const int si = polar_sector(yp, xp, S_res_inv, S_f);   // floor((atan2(yp, xp) + pi) * S_res_inv), M2DP.cpp:59
+      const int si = polar_sector16(yp, xp, S_res_inv);      // floor((atan2(yp, xp) + pi) * S_res_inv), M2DP.cpp:59
       const int ri = polar_ring(xp, yp, R_res_inv, R_f);     // floor(sqrt(xp^2 + yp^2) * R_res_inv),   M2DP.cpp:60-61
       const int idx = ri * 16 + si;
       if (idx >= 128 || idx < 0) continue;

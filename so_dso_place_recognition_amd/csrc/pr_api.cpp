@@ -74,7 +74,7 @@ int set_device(pr_ctx* ctx) {
 }
 
 size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups, int sc_mode) {
-  if (type == PR_TYPE_DELIGHT) { *groups = max_sigs; return (size_t)max_sigs * 4096 + 16; }
+  if (type == PR_TYPE_DELIGHT) { *groups = max_sigs; return (size_t)max_sigs * (4096 + 128) + 16; }   // histograms + empty-bin masks
   if (type == PR_TYPE_SC && sc_mode == 0) {   // split-f16 images, sizes in bytes / 4
     if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SCH_QIMG / 4; }
     *groups = pr::sc_dgroups(max_sigs);
@@ -424,6 +424,8 @@ int pr_pts_preprocess_gpu(pr_ctx* ctx, const char* poses_file, const char* pts_f
 }
 
 // ------------------------------------------------------------------------------------------- signature sets
+// DELIGHT sets: [capacity][4096] f32 histograms, then [capacity][64 lanes][2] u32 empty-bin masks
+static unsigned* delight_masks(const pr_sigset* s) { return reinterpret_cast<unsigned*>(s->packed + (size_t)s->max_sigs * 4096); }
 int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigset** out) {
   if (!ctx || !out) return PR_EINVAL;
   if ((type != PR_TYPE_SC && type != PR_TYPE_M2DP && type != PR_TYPE_DELIGHT) || (role != PR_ROLE_QUERY && role != PR_ROLE_DB) || max_sigs < 0)
@@ -479,7 +481,7 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
     if (s->sc_mode == PR_SC_ARITH_F16X2) pr::launch_m2dp_pack_h(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
     else pr::launch_m2dp_pack(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
   else
-    pr::launch_delight_pack(ctx->stream, dsig, dtype, n_sigs, s->packed);
+    pr::launch_delight_pack(ctx->stream, dsig, dtype, n_sigs, s->packed, delight_masks(s));
   PR_HIP(ctx, hipGetLastError());
   s->count = n_sigs;
   if (stage.p) PR_HIP(ctx, hipStreamSynchronize(ctx->stream));   // staging buffer is freed on return
@@ -502,7 +504,7 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
     if (q->sc_mode == PR_SC_ARITH_F16X2) pr::launch_m2dp_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
     else pr::launch_m2dp_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
   else
-    pr::launch_delight_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p);
+    pr::launch_delight_match(ctx->stream, q->packed, q->count, db->packed, delight_masks(db), db->count, d_p);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
