@@ -135,10 +135,19 @@ int pr_create(int device_id, pr_ctx** out) {
     TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     TRY(hipMalloc((void**)&ctx->d_flags, 4 * sizeof(int)));
     TRY(hipMemset(ctx->d_flags, 0, 4 * sizeof(int)));
-    double tw[120];
+    double tw[120 + 4 * 60 * 8];
     for (int t = 0; t < 60; t++) { tw[t] = std::cos(2.0 * M_PI * t / 60.0); tw[60 + t] = std::sin(2.0 * M_PI * t / 60.0); }
     // exact values at the multiples of 90 degrees
     tw[0] = 1; tw[15] = 0; tw[30] = -1; tw[45] = 0; tw[60] = 0; tw[75] = 1; tw[90] = 0; tw[105] = -1;
+    // + the same values regrouped for sc_pack_h_col_kernel: [f block 0..3][sector 0..59][j 0..3]{cos, sin} of f = 4 fb + j
+    // (64 contiguous bytes per sector: one scalar load brings the 8 twiddles a workgroup needs for it)
+    for (int fb = 0; fb < 4; fb++)
+      for (int sct = 0; sct < 60; sct++)
+        for (int j = 0; j < 4; j++) {
+          const int t = ((4 * fb + j) * sct) % 60;
+          tw[120 + ((fb * 60 + sct) * 4 + j) * 2] = tw[t];
+          tw[120 + ((fb * 60 + sct) * 4 + j) * 2 + 1] = tw[60 + t];
+        }
     TRY(hipMalloc((void**)&ctx->d_twiddle, sizeof tw));
     TRY(hipMemcpy(ctx->d_twiddle, tw, sizeof tw, hipMemcpyHostToDevice));
     // stage-2 constants per slot, A operand of v_mfma_f32_32x32x2_f32: lane l -> shift k = l & 31 (k = 31 repeats

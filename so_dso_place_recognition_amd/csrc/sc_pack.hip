@@ -10,6 +10,9 @@
 //   DB image     [ch][group of 16][pos]{ q4a[lane][4] (Re, s=0..3) | q4b[lane][4] (Im, s=0..3) | d2[lane][2] (Re,Im of s=4) }
 //                                                       lane = (k<<4) | j               ring = 4s+k
 // One workgroup per (row, channel).  HBM-trivial: 2400 values in, 2480 floats out per row.
+#include <cstdlib>
+#include <cstring>
+
 #include "kernels.hpp"
 
 namespace pr {
@@ -154,17 +157,142 @@ __global__ __launch_bounds__(320) void sc_pack_h_kernel(const T* __restrict__ si
   }
 }
 
+// The shipped split-f16 pack.  What bounded the kernel above: 1.5 LDS reads per multiply-add and 2-byte global stores.
+// (The fp64 matrix cores are no way out: v_mfma_f64_16x16x4_f64 issues every ~156 cycles on gfx950 = 32 TFLOP/s, against
+// 78 TFLOP/s of plain v_fma_f64 - tools/ubench/mfma_f64_rate.hip; a version of this kernel built on it ran at 1.85 ms.)
+//   lane      = one ring column of one signature: 16 signatures x 20 rings = 320 threads; the lane walks its 60 sectors
+//               straight from global memory (8 B per sector, 160-byte runs per signature) - no staging, no LDS reads
+//   workgroup = 16 signatures x one channel x 4 frequencies f = 4 fb .. 4 fb + 3 and their partners 30 - f (even / odd
+//               sector sums kept apart as above): 16 accumulators per lane
+//   twiddles  = wave-uniform (every lane of the workgroup works on the same f), so they come through the scalar cache
+//               into SGPRs and cost no vector or LDS bandwidth: 16 v_fma_f64 per 8-byte load, nothing else in the loop
+//   norm      = every lane sums the squares of its column, the 20 partial sums of a signature are added in ring order
+//   output    = hi / lo halves scattered into an LDS copy of the workgroup's 8 frequency slices of the group image
+//               (a slice is contiguous: 3072 B per DB group, 1288 B per query group), then copied out linearly.
+template <typename T, int ROLE>
+__global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict__ sig, int rows,
+                                                             unsigned short* __restrict__ packed, int groups,
+                                                             const double* __restrict__ tw, int* __restrict__ flags) {
+  constexpr int SL = ROLE == 0 ? SCH_QBLK : SCH_DFREQ;          // bytes of one (group, frequency) slice
+  constexpr int NG = ROLE == 0 ? 2 : 1;                         // groups per 16 signatures
+  constexpr int IMGB = ROLE == 0 ? SCH_QIMG : SCH_DIMG;
+  __shared__ __attribute__((aligned(16))) char img[NG * 8 * SL];
+  __shared__ double part[16 * 20];
+  const int tid = threadIdx.x, lrow = tid / 20, ring = tid - 20 * lrow;
+  // workgroups go round-robin to the 8 XCDs (each with its own L2): the four frequency blocks of the same 16 signatures -
+  // which read the same input - are consecutive workgroups of ONE XCD, so HBM sees the input once
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int fb = idx & 3, ch = (idx >> 2) & 1, blk = (idx >> 3) * 8 + xcd;
+  if (blk * 16 >= rows) return;
+  const int row = blk * 16 + lrow;
+  const bool valid = row < rows;
+  for (int i = tid; i < NG * 8 * SL / 8; i += 320) reinterpret_cast<unsigned long long*>(img)[i] = 0ull;   // padding stays zero
+  const T* src = sig + (size_t)(valid ? row : 0) * 2400 + ch * 1200 + ring;   // lanes past the end redo signature 0 and drop it
+  double ce[4] = {0, 0, 0, 0}, co[4] = {0, 0, 0, 0}, se[4] = {0, 0, 0, 0}, so[4] = {0, 0, 0, 0};
+  double nsq = 0.0;
+  const double* twc = tw + 120 + (size_t)fb * 60 * 8;           // [sector][j]{cos, sin}, wave-uniform
+  // rolled loop over 4 sectors at a time, the column values requested two rounds (8 sectors) ahead of their use
+  T xq[3][4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) { xq[0][k] = src[k * 20]; xq[1][k] = src[(4 + k) * 20]; }
+#pragma unroll 3
+  for (int it = 0; it < 15; it++) {
+    if (it + 2 < 15) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) xq[(it + 2) % 3][k] = src[((it + 2) * 4 + k) * 20];
+    }
+    const double* tp = twc + it * 32;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const double x0 = (double)xq[it % 3][2 * h], x1 = (double)xq[it % 3][2 * h + 1];
+      nsq += x0 * x0;
+      nsq += x1 * x1;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        ce[j] += x0 * tp[h * 16 + 2 * j];
+        se[j] += x0 * tp[h * 16 + 2 * j + 1];
+        co[j] += x1 * tp[h * 16 + 8 + 2 * j];
+        so[j] += x1 * tp[h * 16 + 8 + 2 * j + 1];
+      }
+    }
+  }
+  part[tid] = nsq;
+  __syncthreads();
+  double n2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 20; r++) n2 += part[lrow * 20 + r];
+  const double nr = sqrt(n2);
+  if (valid && ring == 0 && fb == 0 && !(nr > 0.0)) atomicOr(flags, 1);   // MATLAB would produce a NaN row
+  const double sc = 0.12909944487358055 * (ROLE == 0 ? 256.0 : 128.0) / nr;   // 1/sqrt(60) x 2^8 | 2^7, over the norm (processSC.m:16,19)
+  auto put = [&](double val, int slice, int im) {
+    // through fp32: two hardware converts instead of ~80 instructions of software f64 -> f16; the double rounding can
+    // move hi by one f16 ulp in rare halfway cases, and lo = f16(val - hi) takes up the difference either way
+    // (the empty asm keeps the compiler from folding the two casts back into its software f64 -> f16 sequence)
+    float vf = (float)val;
+    asm volatile("" : "+v"(vf));
+    const _Float16 hi = (_Float16)vf;
+    float rf = (float)(val - (double)hi);
+    asm volatile("" : "+v"(rf));
+    const _Float16 lo = (_Float16)rf;
+    int bh, bl;   // byte offsets of hi and lo in the LDS copy
+    if (ROLE == 0) {
+      const int rr = (im << 3) | (lrow & 7);
+      bh = ((lrow >> 3) * 8 + slice) * SL + rr * 80 + (rr >= 8 ? 8 : 0) + ring * 2;
+      bl = bh + 40;
+    } else {
+      bh = slice * SL + im * 2 * SCH_DTILE + (((ring >> 3) << 4) | lrow) * 16 + (ring & 7) * 2;
+      bl = bh + SCH_DTILE;
+    }
+    *reinterpret_cast<_Float16*>(img + bh) = hi;
+    *reinterpret_cast<_Float16*>(img + bl) = lo;
+  };
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {                         // slices 0..3: f = 4 fb + j, slices 4..7: 30 - f
+      put((ce[j] + co[j]) * sc, j, 0);
+      put(-(se[j] + so[j]) * sc, j, 1);
+      if (4 * fb + j != 15) {                             // 30 - 15 = 15: the same bin
+        put((ce[j] - co[j]) * sc, 4 + j, 0);
+        put((se[j] - so[j]) * sc, 4 + j, 1);
+      }
+    }
+  }
+  __syncthreads();
+  // slice (group gg, k) -> frequency (k < 4 ? 4 fb + k : 30 - 4 fb - (k - 4)) of group NG blk + gg
+  constexpr int W = SL / 8;                               // 8-byte words per slice
+  for (int i = tid; i < NG * 8 * W; i += 320) {
+    const int sl = i / W, wd = i - sl * W, gg = sl >> 3, k = sl & 7;
+    const int f = k < 4 ? 4 * fb + k : 30 - 4 * fb - (k - 4);
+    if (k >= 4 && f == 15) continue;
+    const int g = NG * blk + gg;
+    if (g >= groups) continue;
+    reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(packed) + ((size_t)ch * groups + g) * IMGB + (size_t)f * SL)[wd] =
+        reinterpret_cast<const unsigned long long*>(img)[i];
+  }
+}
+
+template <typename T, int ROLE>
+void launch_pack_col(hipStream_t st, const T* sig, int rows, unsigned short* packed, int groups, const double* tw, int* flags) {
+  hipLaunchKernelGGL((sc_pack_h_col_kernel<T, ROLE>), dim3((unsigned)(((rows + 15) / 16 + 7) / 8) * 64), dim3(320), 0, st, sig, rows, packed,
+                     groups, tw, flags);
+}
+
 }  // namespace
 
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
                       const double* twiddle, int* flags) {
   if (rows <= 0) return;
-  if (dtype == 0)
+  static const bool valu = getenv("PR_SC_PACK") && !strcmp(getenv("PR_SC_PACK"), "valu");   // the per-thread DFT, kept for A/B runs
+  if (valu && dtype == 0)
     hipLaunchKernelGGL(sc_pack_h_kernel<double>, dim3(rows * 2), dim3(320), 0, st, (const double*)sig, rows, role,
                        (unsigned short*)packed, groups, twiddle, flags);
-  else
+  else if (valu)
     hipLaunchKernelGGL(sc_pack_h_kernel<float>, dim3(rows * 2), dim3(320), 0, st, (const float*)sig, rows, role,
                        (unsigned short*)packed, groups, twiddle, flags);
+  else if (dtype == 0 && role == 0) launch_pack_col<double, 0>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags);
+  else if (dtype == 0) launch_pack_col<double, 1>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags);
+  else if (role == 0) launch_pack_col<float, 0>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags);
+  else launch_pack_col<float, 1>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags);
 }
 
 void launch_sc_pack(hipStream_t st, const void* sig, int dtype, int rows, int role, float* packed, int groups,
