@@ -89,6 +89,7 @@ int pr_match_topk(pr_ctx* ctx, int type, const double* h1, int32_t m, const doub
 
 /* A packed signature set: rows normalised as processSC.m:15-20 and stored as the per-ring sector spectra
  * (SC), or the 4-variant rows as-is (M2DP, processM2DP.m:15), in the MFMA operand layout of its role. */
+#define PR_MAX_SIGS 4000000          /* capacity limit of one signature set (32-bit offsets inside the matchers) */
 int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigset** out);
 void pr_sigset_destroy(pr_ctx* ctx, pr_sigset* s);
 int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int where, int32_t n_sigs);

@@ -8,10 +8,13 @@
 //                 fused = p_weight*(d_p-mean_p)/std_p + (d_i-mean_i)/std_i  (run_test.m:40), +Inf where
 //                 |i-j| < mask_width on GLOBAL indices (:47-53), and selects the k smallest (value, index)
 //                 pairs in lexicographic order, i.e. ties go to the lower index like MATLAB min (:57).
+#include "div_rn.hpp"
 #include "kernels.hpp"
 
 namespace pr {
 namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ double block_sum(double v, double* red, int tid) {
   red[tid] = v;
@@ -36,11 +39,23 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restric
     const float* row = (ch ? d_i : d_p) + (size_t)q * n;
     const double c = (double)row[0];
     double s1 = 0.0, s2 = 0.0;
-    for (int j = tid; j < n; j += 256) {
-      const double d = (double)row[j] - c;
-      s1 += d;
-      s2 += d * d;
+    auto acc = [&](float v) { const double d = (double)v - c; s1 += d; s2 += d * d; };
+    // 16-byte loads over the aligned body of the row (4 of them in flight per thread), scalars on the ragged ends
+    int head = (int)((4 - ((reinterpret_cast<size_t>(row) >> 2) & 3)) & 3);
+    if (head > n) head = n;
+    const int nv = (n - head) >> 2;
+    if (tid < head) acc(row[tid]);
+    const f32x4* rv4 = reinterpret_cast<const f32x4*>(row + head);
+    int j = tid;
+    for (; j + 768 < nv; j += 1024) {
+      const f32x4 a = rv4[j], b = rv4[j + 256], c4 = rv4[j + 512], d4 = rv4[j + 768];
+      acc(a[0]); acc(a[1]); acc(a[2]); acc(a[3]);
+      acc(b[0]); acc(b[1]); acc(b[2]); acc(b[3]);
+      acc(c4[0]); acc(c4[1]); acc(c4[2]); acc(c4[3]);
+      acc(d4[0]); acc(d4[1]); acc(d4[2]); acc(d4[3]);
     }
+    for (; j < nv; j += 256) { const f32x4 a = rv4[j]; acc(a[0]); acc(a[1]); acc(a[2]); acc(a[3]); }
+    for (int t = head + 4 * nv + tid; t < n; t += 256) acc(row[t]);
     const double S1 = block_sum(s1, red, tid);
     const double S2 = block_sum(s2, red, tid);
     if (tid == 0) {
@@ -88,21 +103,42 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   const float* rp = d_p + (size_t)q * n;
   const float* ri = plain ? rp : d_i + (size_t)q * n;
   const int ig = q_row0 + q;
+  // (d - mean) / std is a correctly rounded fp64 division in the reference (MATLAB normalize).  Markstein's sequence gives
+  // the same correctly rounded quotient from the row's reciprocal r = RN(1/s): q = x r, e = fma(-q, s, x), fma(e, r, q) -
+  // 3 instructions instead of the ~30 of a software fp64 division, which made this kernel VALU-bound.  Rows whose std is
+  // zero, denormal or not finite keep the plain division (uniform per workgroup).
+  const bool fastdiv = !plain && sp > 1e-290 && sp < 1e290 && si > 1e-290 && si < 1e290;
+  const double rsp = 1.0 / sp, rsi = 1.0 / si;
+  int head = (int)((4 - ((reinterpret_cast<size_t>(rp) >> 2) & 3)) & 3);
+  if (head > n || ((reinterpret_cast<size_t>(rp) ^ reinterpret_cast<size_t>(ri)) & 15)) head = n;   // rows not co-aligned: scalar loads
+  const int nv = (n - head) >> 2;
+  const f32x4* rp4 = reinterpret_cast<const f32x4*>(rp + head);
+  const f32x4* ri4 = reinterpret_cast<const f32x4*>(ri + head);
   double pv = -__builtin_inf();
   int pj = -1;
   for (int t = 0; t < k; t++) {
     double bv = 0.0;
     int bj = -1;
-    for (int j = tid; j < n; j += 256) {
+    auto consider = [&](float vp, float vi, int j) {
       const int jg = db_row0 + j;
-      double f = plain ? (double)rp[j] : p_weight * (((double)rp[j] - mp) / sp) + ((double)ri[j] - mi) / si;   // run_test.m:40
+      double f;
+      if (plain) f = (double)vp;
+      else if (fastdiv) f = p_weight * div_rn((double)vp - mp, sp, rsp) + div_rn((double)vi - mi, si, rsi);        // run_test.m:40
+      else f = p_weight * (((double)vp - mp) / sp) + ((double)vi - mi) / si;
       int dij = ig - jg;
       if (dij < 0) dij = -dij;
       if (dij < mask_width) f = __builtin_inf();                                      // run_test.m:47-53
-      if (f != f) continue;                                                            // NaN never wins (MATLAB min)
-      if (!cand_less(pv, pj, f, jg)) continue;                                         // already selected
+      if (f != f) return;                                                              // NaN never wins (MATLAB min)
+      if (!cand_less(pv, pj, f, jg)) return;                                           // already selected
       if (bj < 0 || cand_less(f, jg, bv, bj)) { bv = f; bj = jg; }
+    };
+    if (tid < head) consider(rp[tid], ri[tid], tid);
+    for (int j = tid; j < nv; j += 256) {
+      const f32x4 a = rp4[j], b = ri4[j];
+      const int j0 = head + 4 * j;
+      consider(a[0], b[0], j0); consider(a[1], b[1], j0 + 1); consider(a[2], b[2], j0 + 2); consider(a[3], b[3], j0 + 3);
     }
+    for (int j = head + 4 * nv + tid; j < n; j += 256) consider(rp[j], ri[j], j);
     rv[tid] = bv;
     rj[tid] = bj;
     __syncthreads();

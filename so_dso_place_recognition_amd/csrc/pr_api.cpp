@@ -439,6 +439,9 @@ int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigse
   if (!ctx || !out) return PR_EINVAL;
   if ((type != PR_TYPE_SC && type != PR_TYPE_M2DP && type != PR_TYPE_DELIGHT) || (role != PR_ROLE_QUERY && role != PR_ROLE_DB) || max_sigs < 0)
     PR_FAIL(ctx, PR_EINVAL, "pr_sigset_create: bad type/role/max_sigs");
+  // the matchers address one 8/32-row band of the [m][n] distance matrix with 32-bit byte offsets (raw buffer stores):
+  // 32 rows x n x 4 B < 2^31 with n = 4 rows per M2DP signature caps a set at 4 M signatures (77 GB of SC signatures)
+  if (max_sigs > PR_MAX_SIGS) PR_FAIL(ctx, PR_EINVAL, "pr_sigset_create: max_sigs %d exceeds PR_MAX_SIGS = %d", max_sigs, PR_MAX_SIGS);
   if (int rc = set_device(ctx)) return rc;
   pr_sigset* s = new (std::nothrow) pr_sigset;
   if (!s) PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: out of host memory");

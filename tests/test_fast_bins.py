@@ -20,3 +20,17 @@ def test_fast_bin_classifiers_equal_the_fp64_expressions(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]
+
+
+def test_markstein_division_equals_ieee_division(tmp_path):
+    """fuse_select divides by the row's standard deviation with csrc/div_rn.hpp (3 instructions); the reference
+    (MATLAB normalize, run_test.m:40) uses a correctly rounded division - they must agree to the last bit."""
+    gxx = shutil.which("g++")
+    if not gxx:
+        pytest.skip("g++ not available")
+    exe = str(tmp_path / "div_rn_check")
+    r = subprocess.run([gxx, "-O2", "-std=c++17", os.path.join(ROOT, "tests", "native", "div_rn_check.cpp"), "-o", exe],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and " 0 mismatches" in r.stdout, r.stdout[-2000:]

@@ -266,6 +266,16 @@ def test_sc_mixed_arithmetic_sets_are_rejected(api):
     ctx.close()
 
 
+def test_sigset_capacity_limit_is_an_error_not_an_overflow(api):
+    import ctypes as C
+    from so_dso_place_recognition_amd import _lib
+    ctx = api.Context(0)
+    q = C.c_void_p()
+    assert ctx.lib.pr_sigset_create(ctx.h, _lib.TYPE_M2DP, _lib.ROLE_DB, 4_000_001, C.byref(q)) == -1   # PR_EINVAL
+    assert b"PR_MAX_SIGS" in ctx.lib.pr_last_error(ctx.h) and not q.value
+    ctx.close()
+
+
 def test_m2dp_both_arithmetics_vs_oracle(api):
     """The arithmetic switch covers the M2DP matcher too (split-f16 GEMM by default, fp32 MFMA with PR_SC_ARITH_F32)."""
     db = synth.m2dp_database(43, 130)
