@@ -65,73 +65,89 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
   const int qrow0 = qt4 * 32;
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
       dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 32 ? m - qrow0 : 32) : 0) * n * 4, 0x00020000);
-  const unsigned st_lane = (unsigned)((lane >> 5) * n + ((lane & 31) >> 2)) * 4u;
+  const unsigned st_lane = (unsigned)((2 * (lane & 3) + (lane >> 5)) * n + ((lane & 31) >> 2)) * 4u;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (s0 >= s1) return;
-  // DB operand stream of this wave: tiles (8 s + 2 w) and (8 s + 2 w + 1).  Software pipeline: DB and query operands one
-  // K-step (24 MFMAs = 768 cycles) ahead, loads pinned in front of the MFMAs of the current K-step; the first K-step of the
-  // NEXT sweep step is requested before this step's epilogue (the packed buffer has a readable tail).  launch_bounds(256, 2)
-  // caps the wave at 256 unified registers, which keeps the 128 accumulators in ArchVGPRs (no v_accvgpr_read in the epilogue).
+  // DB operand stream of this wave: tiles (8 s + 2 w) and (8 s + 2 w + 1), requested two K-steps ahead (three register sets);
+  // the query tiles come from LDS one tile at a time, each reloaded for the next K-step right behind its own six MFMAs.
+  // launch_bounds(256, 2) caps the wave at 256 unified registers, which keeps the 128 accumulators in ArchVGPRs (no
+  // v_accvgpr_read in the epilogue).  The packed buffer has a readable tail for the requests past the last sweep step.
   const u32x4* pb = dpk + ((size_t)ch * DT + (size_t)s0 * 8 + w * 2) * TV + lane;
-  HL b0[2], b1[2], a[2][4];
-#define LDB(dst0, dst1, p, st) { dst0.h = (p)[(st) * 128]; dst0.l = (p)[(st) * 128 + 64]; dst1.h = (p)[TV + (st) * 128]; dst1.l = (p)[TV + (st) * 128 + 64]; }
-#define LDA(dst, st) { _Pragma("unroll") for (int t = 0; t < 4; t++) { dst[t].h = la[t * TV + (st) * 128]; dst[t].l = la[t * TV + (st) * 128 + 64]; } }
+  struct BSet { HL b0, b1; };
+  BSet bs[3];               // K-steps st, st + 1, st + 2 (period 3 divides the 12 K-steps of a sweep step)
+  HL a[4];                  // the 4 query tiles of the current K-step; tile t is reloaded for the next K-step behind its own MFMAs
+#define LDB(dst, p, st) { dst.b0.h = (p)[(st) * 128]; dst.b0.l = (p)[(st) * 128 + 64]; dst.b1.h = (p)[TV + (st) * 128]; dst.b1.l = (p)[TV + (st) * 128 + 64]; }
+#define LDA1(t, st) { a[t].h = la[(t) * TV + (st) * 128]; a[t].l = la[(t) * TV + (st) * 128 + 64]; }
 #define MF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
-  LDB(b0[0], b1[0], pb, 0)
+  LDB(bs[0], pb, 0)
+  LDB(bs[1], pb, 1)
+#pragma unroll
+  for (int t = 0; t < 4; t++) LDA1(t, 0)
   for (int s = s0; s < s1; s++) {
     const int dt0 = s * 8 + w * 2;
     const u32x4* pn = pb + 8 * TV;           // same wave column, next sweep step
     f32x16 acc[4][2];
-    LDA(a[0], 0)
+#define SBAR() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
     for (int st = 0; st < 12; st++) {
-      const int cb = st & 1, nb = (st + 1) & 1, ca = st & 1, na = (st + 1) & 1;
-      if (st + 1 < 12) LDB(b0[nb], b1[nb], pb, st + 1)
-      else             LDB(b0[nb], b1[nb], pn, 0)
-      if (st + 1 < 12) LDA(a[na], st + 1)
-      __builtin_amdgcn_sched_barrier(0);
+      // Every request sits alone in the gap behind one MFMA (a 32x32x16 MFMA occupies the pipe for 32 cycles, a request
+      // issues in 5-20): batched at the top of the K-step the 12 requests left the matrix pipe idle for ~160 of 930 cycles.
+      // DB operands two K-steps ahead, one 16-byte piece behind the first MFMA of each query tile; query tile t is
+      // reloaded for the next K-step behind the last MFMAs that read it.
+      const BSet& c = bs[st % 3];
+      BSet& nx = bs[(st + 2) % 3];
+      const u32x4* pq = (st + 2 < 12) ? pb + (st + 2) * 128 : pn + (st + 2 - 12) * 128;
       const bool first = st == 0;
 #pragma unroll
       for (int t = 0; t < 4; t++) {
-        acc[t][0] = MF(a[ca][t].h, b0[cb].h, first ? zero : acc[t][0]);
-        acc[t][1] = MF(a[ca][t].h, b1[cb].h, first ? zero : acc[t][1]);
+        SBAR();
+        acc[t][0] = MF(a[t].h, c.b0.h, first ? zero : acc[t][0]);
+        SBAR();
+        if (t == 0) nx.b0.h = pq[0]; else if (t == 1) nx.b0.l = pq[64]; else if (t == 2) nx.b1.h = pq[TV]; else nx.b1.l = pq[TV + 64];
+        SBAR();
+        acc[t][1] = MF(a[t].h, c.b1.h, first ? zero : acc[t][1]);
+        acc[t][0] = MF(a[t].h, c.b0.l, acc[t][0]);
+        acc[t][1] = MF(a[t].h, c.b1.l, acc[t][1]);
+        SBAR();
+        a[t].h = la[t * TV + ((st + 1) % 12) * 128];              // the query tiles do not depend on the sweep step
+        SBAR();
+        acc[t][0] = MF(a[t].l, c.b0.h, acc[t][0]);
+        acc[t][1] = MF(a[t].l, c.b1.h, acc[t][1]);
+        SBAR();
+        a[t].l = la[t * TV + ((st + 1) % 12) * 128 + 64];
+        SBAR();
       }
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        acc[t][0] = MF(a[ca][t].h, b0[cb].l, acc[t][0]);
-        acc[t][1] = MF(a[ca][t].h, b1[cb].l, acc[t][1]);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; t++) {
-        acc[t][0] = MF(a[ca][t].l, b0[cb].h, acc[t][0]);
-        acc[t][1] = MF(a[ca][t].l, b1[cb].h, acc[t][1]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
-    // 12 K-steps advance the period-2 rotation by 0: b0[0] already holds K-step 0 of the next sweep step
+#undef SBAR
+    // 12 K-steps advance the period-3 rotation by 0: bs[0], bs[1] already hold K-steps 0, 1 of the next sweep step
     pb = pn;
     // epilogue: C layout col = lane&31 -> (entry = col>>2, variant = col&3); row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
     // -> (query = 2*(reg>>2) + (lane>>5), variant = reg&3).  d = min (1-dot)/2 = 0.5 - 0.5 * 2^-16 * max dot.
     // Branch-free: quad reductions as DPP-source v_max, one buffer store per (query tile, DB tile, query pair) whose
     // invalid lanes are out of range.
+    // After the quad reduction all four lanes of a quad hold the block maximum, so lane (lane & 3) = gq keeps the value
+    // of query pair gq: ONE store per (query tile, DB tile) with all 64 lanes active instead of four with 16.
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-      for (int j = 0; j < 2; j++)
+      for (int j = 0; j < 2; j++) {
+        float sel = 0.f;
 #pragma unroll
         for (int gq = 0; gq < 4; gq++) {
           float mx = fmaxf(fmaxf(acc[i][j][gq * 4], acc[i][j][gq * 4 + 1]),
                            fmaxf(acc[i][j][gq * 4 + 2], acc[i][j][gq * 4 + 3]));
           mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
           mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
-          // query row (local to the workgroup's 32) = 8 i + 2 gq + (lane >> 5), entry = 8 (dt0 + j) + ((lane & 31) >> 2)
-          const int drow = (dt0 + j) * 8 + ((lane & 31) >> 2);
-          const unsigned off = ((lane & 3) == 0 && drow < n) ? st_lane + (unsigned)((8 * i + 2 * gq) * n + (dt0 + j) * 8) * 4u : 0x80000000u;
-          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(mx, -0x1p-17f, 0.5f)), rd, (int)off, 0, 0);   // processM2DP.m:15,19
+          sel = ((lane & 3) == gq) ? mx : sel;
         }
+        // query row (local to the workgroup's 32) = 8 i + 2 (lane & 3) + (lane >> 5), entry = 8 (dt0 + j) + ((lane & 31) >> 2)
+        const int drow = (dt0 + j) * 8 + ((lane & 31) >> 2);
+        const unsigned off = (drow < n) ? st_lane + (unsigned)((8 * i) * n + (dt0 + j) * 8) * 4u : 0x80000000u;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(sel, -0x1p-17f, 0.5f)), rd, (int)off, 0, 0);   // processM2DP.m:15,19
+      }
   }
 #undef LDB
-#undef LDA
+#undef LDA1
 #undef MF
 }
 
