@@ -22,23 +22,28 @@ namespace {
 
 constexpr int MAT = 64 * 128;
 
+// PPB planes per workgroup: 16 for throughput (every point is read by 16 workgroups of its cloud), 4 when there are few
+// clouds - a workgroup is ~100 instructions per (point, plane) on one wave per SIMD, 1.4 ms for 50k points x 16 planes,
+// and a small batch has nothing else to hide that behind.
+template <int PPB>
 __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict__ xyz, const float* __restrict__ inten,
                                                         const int64_t* __restrict__ offs, const double* __restrict__ frames,
                                                         const float* __restrict__ ave_in,
                                                         const double* __restrict__ planes, double max_rho, int c0,
                                                         double* __restrict__ mats) {
-  __shared__ unsigned int cnt[16 * 128];
-  __shared__ double isum[16 * 128];
-  __shared__ double pl[16][6];
+  __shared__ unsigned int cnt[PPB * 128];
+  __shared__ double isum[PPB * 128];
+  __shared__ double pl[PPB][6];
+  constexpr int NPG = 64 / PPB;              // plane groups per (cloud, variant)
   const int tid = threadIdx.x;
-  const int pg = blockIdx.x & 3, var = (blockIdx.x >> 2) & 3, cl = blockIdx.x >> 4;
+  const int pg = blockIdx.x % NPG, var = (blockIdx.x / NPG) & 3, cl = blockIdx.x / (4 * NPG);
   const int c = c0 + cl;
   const int64_t o0 = offs[c];
   const int64_t P = offs[c + 1] - o0;
-  for (int b = tid; b < 16 * 128; b += 256) { cnt[b] = 0u; isum[b] = 0.0; }
-  if (tid < 96) {
+  for (int b = tid; b < PPB * 128; b += 256) { cnt[b] = 0u; isum[b] = 0.0; }
+  if (tid < PPB * 6) {
     const int k = tid / 6, a = tid % 6;
-    pl[k][a] = (a < 3) ? planes[(pg * 16 + k) * 3 + a] : planes[64 * 3 + (pg * 16 + k) * 3 + (a - 3)];
+    pl[k][a] = (a < 3) ? planes[(pg * PPB + k) * 3 + a] : planes[64 * 3 + (pg * PPB + k) * 3 + (a - 3)];
   }
   __syncthreads();
   const double* f = frames + (size_t)c * 16;
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
     const double q2 = dz * ((x * e20 + y * e21) + z * e22);
     const double iv = (double)it[i];
 #pragma unroll 4
-    for (int k = 0; k < 16; k++) {
+    for (int k = 0; k < PPB; k++) {
       const double xp = pl[k][0] * q0 + (pl[k][1] * q1 + pl[k][2] * q2);   // M2DP.cpp:56
       const double yp = pl[k][3] * q0 + (pl[k][4] * q1 + pl[k][5] * q2);   // :57
       const int si = polar_sector16(yp, xp, S_res_inv);      // floor((atan2(yp, xp) + pi) * S_res_inv), M2DP.cpp:59
@@ -70,9 +75,9 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
   }
   __syncthreads();
   const double ave = (double)ave_in[c];
-  double* mc = mats + (((size_t)cl * 4 + var) * 2) * MAT + (size_t)pg * 16 * 128;
+  double* mc = mats + (((size_t)cl * 4 + var) * 2) * MAT + (size_t)pg * PPB * 128;
   double* mi = mc + MAT;
-  for (int b = tid; b < 16 * 128; b += 256) {
+  for (int b = tid; b < PPB * 128; b += 256) {
     const unsigned int n = cnt[b];
     mc[b] = (double)n;
     mi[b] = n ? ((isum[b] / (double)n) > ave ? 1.0 : 0.0) : 0.0;
@@ -213,8 +218,12 @@ void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, 
                             (int)SVD_LDS);
   for (int c0 = 0; c0 < N; c0 += GEN_BATCH) {
     const int nc = (N - c0) < GEN_BATCH ? (N - c0) : GEN_BATCH;
-    hipLaunchKernelGGL(m2dp_bin_kernel, dim3(nc * 16), dim3(256), 0, st, xyz, inten, offs, frames, ave, planes, max_rho,
-                       c0, mats);
+    if (nc * 16 >= 4096)
+      hipLaunchKernelGGL(m2dp_bin_kernel<16>, dim3(nc * 16), dim3(256), 0, st, xyz, inten, offs, frames, ave, planes, max_rho,
+                         c0, mats);
+    else
+      hipLaunchKernelGGL(m2dp_bin_kernel<4>, dim3(nc * 64), dim3(256), 0, st, xyz, inten, offs, frames, ave, planes, max_rho,
+                         c0, mats);
     hipLaunchKernelGGL(m2dp_svd_kernel, dim3(nc * 8), dim3(256), SVD_LDS, st, mats, c0, out);
   }
 }

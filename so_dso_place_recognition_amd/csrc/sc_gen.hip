@@ -57,45 +57,73 @@ __device__ void jacobi_eig3(double a[3][3], double v[3][3]) {
   }
 }
 
-// one lane per cloud: lane-private sequential float sum in input order.  Only CPW lanes of a wave are used: a
-// per-lane 16-byte load touches one cache line per active lane, and with 64 different clouds per instruction the
-// texture-address path (one line per cycle or so) was slower than the add chain; 8 clouds per wave keeps the chain
-// (about 5 cycles per dependent v_add_f32) the only limiter, and 5 000 clouds still are only 625 waves.
+// The float average of the reference is a sequential sum in input order (SC.cpp:60-64, M2DP.cpp:77-81): one dependent
+// v_add_f32 per point, ~5 cycles each - 0.1 ms for 50k points whatever the number of clouds.  One wave per CPW = 8
+// clouds: all 64 lanes stream the next CH = 512 floats of each of the 8 clouds (coalesced 16-byte loads, requested one
+// round = 512 adds ahead) into LDS, then lane k < 8 adds cloud k's chunk in order out of LDS.  (Lane-private loads - one
+// cache line per lane and instruction, 64 floats in flight - left the chain waiting on memory: 32 cycles per point.)
 constexpr int CPW = 8;
+constexpr int ACH = 512;                     // floats per cloud and round
 __global__ __launch_bounds__(64) void ave_chain_kernel(const float* __restrict__ inten, const int64_t* __restrict__ offs,
                                                         int N, float* __restrict__ ave_out) {
-  const int c = blockIdx.x * CPW + threadIdx.x;
-  const bool live = c < N;
-  const int64_t o0 = live ? offs[c] : 0;
-  const int64_t P = live ? offs[c + 1] - o0 : 0;
-  const float* it = inten + o0;
-  float ave = 0.f;
-  int64_t i = 0;
-  constexpr int U = 8;                       // 16-byte loads per batch and lane; two batches are in flight
-  constexpr int BF = 4 * U;                  // floats per batch
+  __shared__ __attribute__((aligned(16))) float buf[CPW][ACH];
   typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
-  if (P >= BF) {
-    f4 a[U], b[U];
+  typedef float f4a __attribute__((ext_vector_type(4)));
+  const int lane = threadIdx.x;
+  const int cb = blockIdx.x * CPW;
+  const float* base[CPW];
+  int64_t Pk[CPW];
+  int64_t Pmax = 0;
 #pragma unroll
-    for (int k = 0; k < U; k++) a[k] = *reinterpret_cast<const f4*>(it + 4 * k);
-    i = BF;
-    // invariant: batch [i-BF, i) sits in `a`; the next batch is requested before the current one is summed
-    while (i + 2 * BF <= P) {
-#pragma unroll
-      for (int k = 0; k < U; k++) b[k] = *reinterpret_cast<const f4*>(it + i + 4 * k);
-#pragma unroll
-      for (int k = 0; k < U; k++) { ave += a[k][0]; ave += a[k][1]; ave += a[k][2]; ave += a[k][3]; }
-#pragma unroll
-      for (int k = 0; k < U; k++) a[k] = *reinterpret_cast<const f4*>(it + i + BF + 4 * k);
-#pragma unroll
-      for (int k = 0; k < U; k++) { ave += b[k][0]; ave += b[k][1]; ave += b[k][2]; ave += b[k][3]; }
-      i += 2 * BF;
-    }
-#pragma unroll
-    for (int k = 0; k < U; k++) { ave += a[k][0]; ave += a[k][1]; ave += a[k][2]; ave += a[k][3]; }
+  for (int k = 0; k < CPW; k++) {
+    const bool live = cb + k < N;
+    const int64_t o0 = live ? offs[cb + k] : 0;
+    Pk[k] = live ? offs[cb + k + 1] - o0 : 0;
+    base[k] = inten + o0;
+    Pmax = Pk[k] > Pmax ? Pk[k] : Pmax;
   }
-  for (; i < P; i++) ave += it[i];
-  if (live) ave_out[c] = ave / (float)P;     // SC.cpp:64
+  f4 nx[CPW][2];
+  auto request = [&](int64_t r0) {            // floats [r0 + 8 lane, + 8) of every cloud; zeros past the end (x + 0 = x)
+#pragma unroll
+    for (int k = 0; k < CPW; k++) {
+      const int64_t i = r0 + 8 * lane;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int64_t j = i + 4 * h;
+        if (j + 4 <= Pk[k]) nx[k][h] = *reinterpret_cast<const f4*>(base[k] + j);
+        else {
+          f4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int e = 0; e < 4; e++) if (j + e < Pk[k]) v[e] = base[k][j + e];
+          nx[k][h] = v;
+        }
+      }
+    }
+  };
+  float ave = 0.f;
+  request(0);
+  for (int64_t r0 = 0; r0 < Pmax; r0 += ACH) {
+#pragma unroll
+    for (int k = 0; k < CPW; k++) {
+      *reinterpret_cast<f4a*>(&buf[k][8 * lane]) = nx[k][0];
+      *reinterpret_cast<f4a*>(&buf[k][8 * lane + 4]) = nx[k][1];
+    }
+    if (r0 + ACH < Pmax) request(r0 + ACH);
+    __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes of this wave are done (one wave per workgroup)
+    if (lane < CPW) {
+#pragma unroll 8
+      for (int j = 0; j < ACH; j += 4) {
+        const f4a v = *reinterpret_cast<const f4a*>(&buf[lane][j]);
+        ave += v[0]; ave += v[1]; ave += v[2]; ave += v[3];
+      }
+    }
+  }
+  if (lane < CPW && cb + lane < N) {
+    int64_t P = 0;
+#pragma unroll
+    for (int k = 0; k < CPW; k++) P = (lane == k) ? Pk[k] : P;
+    ave_out[cb + lane] = ave / (float)P;     // SC.cpp:64
+  }
 }
 
 __global__ __launch_bounds__(FT) void cloud_frames_kernel(const double* __restrict__ xyz,
@@ -220,7 +248,7 @@ __global__ __launch_bounds__(512) void sc_bin_kernel(const double* __restrict__ 
 
 void launch_ave_chain(hipStream_t st, const float* inten, const int64_t* offs, int N, float* ave) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(ave_chain_kernel, dim3((N + CPW - 1) / CPW), dim3(CPW), 0, st, inten, offs, N, ave);
+  hipLaunchKernelGGL(ave_chain_kernel, dim3((N + CPW - 1) / CPW), dim3(64), 0, st, inten, offs, N, ave);
 }
 
 void launch_cloud_frames(hipStream_t st, const double* xyz, const int64_t* offs, int N, double* frames) {

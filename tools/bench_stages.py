@@ -46,6 +46,7 @@ def main():
         return float(np.min(ts[1:])), float(np.mean(ts[1:]))
 
     N, P = args.clouds, args.points
+    assert args.m2dp_clouds <= N, "--m2dp-clouds uses the first clouds of --clouds: raise --clouds"
     t0 = time.time()
     base = 64                                  # distinct clouds; the rest are rigidly moved copies (cheap to generate)
     xyz, it, offs = synth.scene_clouds(42, min(N, base), P)
