@@ -48,4 +48,38 @@ __host__ __device__ __forceinline__ int polar_ring(double x, double y, double R_
   return (int)floor(sqrt(x * x + y * y) * R_res_inv);
 }
 
+// Both bin indices of one M2DP projection (M2DP.cpp:59-62) with ONE accept test and no control flow in the fast path:
+// hipcc turns the short-circuit conditions of the two functions above into a chain of exec-mask branches (~100 issue
+// slots per projection, most of them not arithmetic).  Sector: four sign / order bits -> a 16-entry nibble table; ring:
+// the raw v_sqrt_f32 (1 ulp; sqrtf() is a 16-instruction correctly rounded sequence) - the 1e-3-bin margins cover both.
+// Everything the fast path cannot vouch for falls back to the reference's fp64 expressions, as above.
+__host__ __device__ __forceinline__ void polar_bins16(double y, double x, double S_res_inv, double R_res_inv, float R_f,
+                                                     int& si, int& ri) {
+  const float xf = (float)x, yf = (float)y;
+  const float a = fabsf(xf), b = fabsf(yf);
+  const float mn = fminf(a, b), mx = fmaxf(a, b);
+  const float e = 1e-3f * mx, t = 0.414213568f * mx;                       // tan(pi/8)
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float r = __builtin_amdgcn_sqrtf(xf * xf + yf * yf);
+#else
+  const float r = sqrtf(xf * xf + yf * yf);
+#endif
+  const float tt = r * R_f, fl = floorf(tt), fr = tt - fl;
+  const bool ok = (mn > e) & (fabsf(mn - t) > e) & ((mx - mn) > e) & (mx > 1e-30f) & (mx < 3.0e38f) &
+                  (fr > 1e-3f) & (fr < 0.999f) & (tt < 1e6f);
+  if (ok) {
+    // index = 8 (y < 0) + 4 (x < 0) + 2 (|y| > |x|) + (min > max tan(pi/8)); entries: quadrant of theta + pi (see polar_sector16)
+    // q0 (y<0,x<0): tan = |y|/|x|; q1 (y<0,x>0): tan = |x|/|y|; q2 (y>0,x>0): |y|/|x|; q3 (y>0,x<0): |x|/|y|
+    const unsigned idx = ((yf < 0.f) ? 8u : 0u) | ((xf < 0.f) ? 4u : 0u) | ((b > a) ? 2u : 0u) | ((mn > t) ? 1u : 0u);
+    // y>=0,x>=0 (q2: 8..11): 8, 9, 11, 10 | y>=0,x<0 (q3: 12..15; big = |x|>|y| = !(b>a)): 15, 14, 12, 13
+    // y<0,x>=0 (q1: 4..7; big = !(b>a)): 7, 6, 4, 5 | y<0,x<0 (q0: 0..3): 0, 1, 3, 2
+    constexpr unsigned long long TAB = 0x2310ull << 48 | 0x5467ull << 32 | 0xDCEFull << 16 | 0xAB98ull;
+    si = (int)((TAB >> (4 * idx)) & 15ull);
+    ri = (int)fl;
+    return;
+  }
+  si = (int)floor((atan2(y, x) + M_PI) * S_res_inv);
+  ri = (int)floor(sqrt(x * x + y * y) * R_res_inv);
+}
+
 }  // namespace pr

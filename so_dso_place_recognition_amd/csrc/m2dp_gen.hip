@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
     for (int k = 0; k < PPB; k++) {
       const double xp = pl[k][0] * q0 + (pl[k][1] * q1 + pl[k][2] * q2);   // M2DP.cpp:56
       const double yp = pl[k][3] * q0 + (pl[k][4] * q1 + pl[k][5] * q2);   // :57
-      const int si = polar_sector16(yp, xp, S_res_inv);      // floor((atan2(yp, xp) + pi) * S_res_inv), M2DP.cpp:59
-      const int ri = polar_ring(xp, yp, R_res_inv, R_f);     // floor(sqrt(xp^2 + yp^2) * R_res_inv),   M2DP.cpp:60-61
+      int si, ri;   // floor((atan2(yp, xp) + pi) * S_res_inv), floor(sqrt(xp^2 + yp^2) * R_res_inv): M2DP.cpp:59-61
+      polar_bins16(yp, xp, S_res_inv, R_res_inv, R_f, si, ri);
       const int idx = ri * 16 + si;
       if (idx >= 128 || idx < 0) continue;
       atomicAdd(&cnt[k * 128 + idx], 1u);
@@ -100,8 +100,7 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* A = sm;               // 64 x 129 (padded rows)
   double* G = A + 64 * 129;     // 64 x 65
-  double* H = G + 64 * 65;      // 64 x 65
-  double* u = H + 64 * 65;      // 64
+  double* u = G + 64 * 65;      // 64
   double* v = u + 64;           // 128
   double* red = v + 128;        // 256
   const int tid = threadIdx.x;
@@ -119,28 +118,49 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
     for (int e = tid; e < 192; e += 256) o[e] = (e == 0 || e == 64) ? 1.0 : 0.0;
     return;
   }
-  // G = A A^T / fro
-  for (int e = tid; e < 64 * 64; e += 256) {
-    const int i = e >> 6, j = e & 63;
-    double s = 0.0;
-    for (int k = 0; k < 128; k++) s += A[i * 129 + k] * A[j * 129 + k];
-    G[i * 65 + j] = s / fro;
+  // G = A A^T / fro.  Every thread owns a 4 x 4 block of the 64 x 64 result: 8 LDS reads per 16 multiply-adds instead
+  // of 32 (the kernel is LDS-bound); every entry is still summed over k in ascending order, so the values do not change.
+  const int i0 = (tid >> 4) * 4, j0 = (tid & 15) * 4;
+  {
+    double acc[4][4] = {};
+    for (int k = 0; k < 128; k++) {
+      double ai[4], aj[4];
+#pragma unroll
+      for (int a = 0; a < 4; a++) { ai[a] = A[(i0 + a) * 129 + k]; aj[a] = A[(j0 + a) * 129 + k]; }
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] += ai[a] * aj[b];
+    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) G[(i0 + a) * 65 + j0 + b] = acc[a][b] / fro;
   }
   __syncthreads();
   for (int it = 0; it < 8; it++) {     // G <- G*G / ||G*G||_F   (G symmetric)
+    double acc[4][4] = {};
+    for (int k = 0; k < 64; k++) {
+      double gi[4], gj[4];
+#pragma unroll
+      for (int a = 0; a < 4; a++) { gi[a] = G[(i0 + a) * 65 + k]; gj[a] = G[(j0 + a) * 65 + k]; }
+#pragma unroll
+      for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] += gi[a] * gj[b];
+    }
+    // Frobenius norm: the per-thread partial sums run over the thread's entries in the order e = tid, tid + 256, ... of
+    // the first version of this kernel is NOT kept (another fixed order); the norm only scales G, u is renormalised below
     double part = 0.0;
-    for (int e = tid; e < 64 * 64; e += 256) {
-      const int i = e >> 6, j = e & 63;
-      double s = 0.0;
-      for (int k = 0; k < 64; k++) s += G[i * 65 + k] * G[j * 65 + k];
-      H[i * 65 + j] = s;
-      part += s * s;
-    }
-    const double nf = sqrt(block_sum256(part, red, tid));
-    for (int e = tid; e < 64 * 64; e += 256) {
-      const int i = e >> 6, j = e & 63;
-      G[i * 65 + j] = H[i * 65 + j] / nf;
-    }
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) part += acc[a][b] * acc[a][b];
+    const double nf = sqrt(block_sum256(part, red, tid));   // (its barriers also order the reads of G before the writes)
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+      for (int b = 0; b < 4; b++) G[(i0 + a) * 65 + j0 + b] = acc[a][b] / nf;
     __syncthreads();
   }
   // start vector: G * ones (non-negative matrices keep it in the Perron cone), normalised
@@ -200,7 +220,7 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
   if (tid < 128) o[64 + tid] = sg * v[tid];
 }
 
-constexpr size_t SVD_LDS = (size_t)(64 * 129 + 2 * 64 * 65 + 64 + 128 + 256) * sizeof(double);
+constexpr size_t SVD_LDS = (size_t)(64 * 129 + 64 * 65 + 64 + 128 + 256) * sizeof(double);
 constexpr int GEN_BATCH = 256;   // clouds per scratch batch (256 * 4 * 2 * 64 KiB = 128 MiB)
 
 }  // namespace

@@ -18,7 +18,13 @@ static void check(double y, double x) {
   const int f16 = pr::polar_sector16(y, x, S16);
   const int f60 = pr::polar_sector(y, x, S60, (float)S60);
   const int fr = pr::polar_ring(x, y, R, (float)R);
+  int c16, cr;
+  pr::polar_bins16(y, x, S16, R, (float)R, c16, cr);   // the combined classifier of m2dp_bin_kernel
   total++;
+  if (c16 != r16 || cr != rr) {
+    if (bad < 10) printf("MISMATCH (combined) y=%a x=%a: sector16 %d/%d ring %d/%d\n", y, x, c16, r16, cr, rr);
+    bad++;
+  }
   if (f16 != r16 || f60 != r60 || fr != rr) {
     if (bad < 10) printf("MISMATCH y=%a x=%a: sector16 %d/%d sector60 %d/%d ring %d/%d\n", y, x, f16, r16, f60, r60, fr, rr);
     bad++;
