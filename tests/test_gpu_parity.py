@@ -165,6 +165,26 @@ def test_m2dp_generate_vs_oracle(api, golden_dir):
     assert np.abs(g - gold["m2dp_sig"]).max() < 1e-9
 
 
+def test_generators_large_ragged_batch_vs_oracle(api):
+    """300 clouds of 1..1100 points (a batch large enough for the 16-plane M2DP workgroups and several rounds of the
+    float-average chain, sizes that are not multiples of its 512-float chunks, an empty cloud in the middle)."""
+    rng = np.random.default_rng(5)
+    sizes = rng.integers(1, 1100, size=300); sizes[17] = 0; sizes[123] = 512; sizes[124] = 513; sizes[299] = 1
+    parts = [synth.scene_cloud(77, 10 + i, int(n)) if n else (np.zeros((0, 3)), np.zeros((0,), np.float32)) for i, n in enumerate(sizes)]
+    xyz = np.concatenate([p[0] for p in parts]); it = np.concatenate([p[1] for p in parts]).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    live = sizes > 8                                                   # PCA / leading singular pair of a handful of points are degenerate (N3, N6): not compared
+    o = oracle_lib.sc_generate(xyz, it, offs); g = api.sc_generate(xyz, it, offs)
+    assert np.array_equal(g[live][:, 1200:], o[live][:, 1200:]) and np.abs(g[live] - o[live]).max() < 1e-10
+    assert np.array_equal(g[17], np.zeros(2400))
+    o = oracle_lib.m2dp_generate(xyz, it, offs); g = api.m2dp_generate(xyz, it, offs)
+    rows = np.repeat(live, 4)
+    assert np.abs(g[rows] - o[rows]).max() < 1e-9
+    o = oracle_lib.delight_generate(xyz, it, offs); g = api.delight_generate(xyz, it, offs)
+    rows = np.repeat(live, 16)
+    assert np.abs(g[rows] - o[rows]).sum() <= 4 * live.sum()           # float-cast boundary points may move between two bins
+
+
 def test_generate_then_match_end_to_end(api):
     """config-2 shape at a small size: generate SC signatures on the GPU, match them on the GPU, compare the
     top-1 with the oracle run on the oracle's own signatures."""
