@@ -79,26 +79,30 @@ __device__ __forceinline__ unsigned nibble_xor(unsigned v) {
   return v;
 }
 
-// Two permutations at a time: rows r of the query against rows r ^ X and r ^ Y of the entry (processDELIGHT.m:2-5:
-// {0..15}, {5,4,7,6,1,0,3,2,..}, {6,7,4,5,2,3,0,1,..}, {3,2,1,0,7,6,5,4,..}, the second eight likewise + 8).  A holds
-// a + 2^-60, so that s = a + b and d = a - b are the exact float sums wherever a or b is non-zero and (2^-60, 2^-60) - a
-// term of 2^-60, invisible next to 1 - where both are empty: no compare, no select, packed fp32 adds / multiplies.
-// v_rcp_f32 runs at a quarter of the packed rate and is what bounds the kernel, so the two divisions of an (X, Y) pair
-// share ONE reciprocal: R = 1 / (s_x s_y), 1/s_x = R s_y, 1/s_y = R s_x (three packed multiplies; 2^-120 <= s_x s_y stays
-// normal for histogram counts and for anything else in [1e-15, 1e15]).
-template <int X, int Y>
-__device__ __forceinline__ void chi2_perm2(const f32x4 (&A)[16], const f32x4 (&B)[16], f32x2& accx, f32x2& accy) {
+// All four permutations of one query term at a time: rows r of the query against rows r ^ 0, r ^ 5, r ^ 6, r ^ 3 of the
+// entry (processDELIGHT.m:2-5: {0..15}, {5,4,7,6,1,0,3,2,..}, {6,7,4,5,2,3,0,1,..}, {3,2,1,0,7,6,5,4,..}, the second eight
+// likewise + 8).  A holds a + 2^-30, so that s = a + b and d = a - b are the exact float sums wherever a or b is a count >= 1
+// and (2^-30, 2^-30) - a term of 2^-30, invisible next to 1 - where both are empty: no compare, no select, packed fp32
+// adds / multiplies.  v_rcp_f32 runs at a quarter of the packed rate, so the four divisions share ONE reciprocal
+// (Montgomery's trick): R = 1 / (s0 s1 s2 s3), 1/s0 = (R s2 s3) s1, ... - 9 packed multiplies instead of 3 reciprocals.
+// 2^-120 <= s0 s1 s2 s3 <= 2^72 for histogram counts: no underflow, no overflow.
+__device__ __forceinline__ void chi2_perm4(const f32x4 (&A)[16], const f32x4 (&B)[16], f32x2 (&acc)[4]) {
 #pragma unroll
   for (int r = 0; r < 16; r++) {
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const f32x2 a = {A[r][2 * h], A[r][2 * h + 1]};
-      const f32x2 bx = {B[r ^ X][2 * h], B[r ^ X][2 * h + 1]}, by = {B[r ^ Y][2 * h], B[r ^ Y][2 * h + 1]};
-      const f32x2 sx = a + bx, dx = a - bx, sy = a + by, dy = a - by;
-      const f32x2 p = sx * sy;
-      const f32x2 R = {__builtin_amdgcn_rcpf(p[0]), __builtin_amdgcn_rcpf(p[1])};
-      accx = __builtin_elementwise_fma(dx * dx, R * sy, accx);                         // processDELIGHT.m:24-28 (x 2 at the end)
-      accy = __builtin_elementwise_fma(dy * dy, R * sx, accy);
+      const f32x2 b0 = {B[r][2 * h], B[r][2 * h + 1]}, b1 = {B[r ^ 5][2 * h], B[r ^ 5][2 * h + 1]};
+      const f32x2 b2 = {B[r ^ 6][2 * h], B[r ^ 6][2 * h + 1]}, b3 = {B[r ^ 3][2 * h], B[r ^ 3][2 * h + 1]};
+      const f32x2 s0 = a + b0, s1 = a + b1, s2 = a + b2, s3 = a + b3;
+      const f32x2 d0 = a - b0, d1 = a - b1, d2 = a - b2, d3 = a - b3;
+      const f32x2 p01 = s0 * s1, p23 = s2 * s3, P = p01 * p23;
+      const f32x2 R = {__builtin_amdgcn_rcpf(P[0]), __builtin_amdgcn_rcpf(P[1])};
+      const f32x2 q23 = R * p23, q01 = R * p01;                                        // 1 / (s0 s1), 1 / (s2 s3)
+      acc[0] = __builtin_elementwise_fma(d0 * d0, q23 * s1, acc[0]);                   // processDELIGHT.m:24-28 (x 2 at the end)
+      acc[1] = __builtin_elementwise_fma(d1 * d1, q23 * s0, acc[1]);
+      acc[2] = __builtin_elementwise_fma(d2 * d2, q01 * s3, acc[2]);
+      acc[3] = __builtin_elementwise_fma(d3 * d3, q01 * s2, acc[3]);
     }
   }
 }
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256, 2) void delight_match_kernel(const float* __re
 #pragma unroll
       for (int c = 0; c < 4; c++) {
         (r < 8 ? za0 : za1) |= (A[r][c] == 0.f ? 1u : 0u) << (4 * (r & 7) + c);
-        A[r][c] += 0x1p-60f;
+        A[r][c] += 0x1p-30f;
       }
     }
   }
@@ -147,8 +151,7 @@ __global__ __launch_bounds__(256, 2) void delight_match_kernel(const float* __re
 #pragma unroll
     for (int r = 0; r < 16; r++) B[r] = rowbuf[cur][r * 64 + lane];
     f32x2 acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-    chi2_perm2<0, 5>(A, B, acc[0], acc[1]);
-    chi2_perm2<6, 3>(A, B, acc[2], acc[3]);
+    chi2_perm4(A, B, acc);
     float ts[4];
     // bins empty in both histograms do not count (:25-28): two 13-bit totals per word
     unsigned e01 = (unsigned)(__builtin_popcount(za0 & zb0) + __builtin_popcount(za1 & zb1)) |
