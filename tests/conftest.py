@@ -29,3 +29,31 @@ def _torch_first():
     except Exception:
         pass
     yield
+
+
+def _ref_sequence_names():
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_sequences")
+    return sorted(n for n in os.listdir(d) if os.path.isdir(os.path.join(d, n))) if os.path.isdir(d) else []
+
+
+REF_SEQUENCES = _ref_sequence_names()
+
+
+@pytest.fixture(scope="session")
+def ref_sequence(tmp_path_factory):
+    """name -> (poses_history_file.txt, incoming_id_file.txt) of one of the 13 sequences the reference holds
+    (tests/golden/ref_sequences, written by tests/make_ref_sequences.py; the pose files are stored gzip-compressed)."""
+    import gzip
+    import shutil
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_sequences")
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            d = tmp_path_factory.mktemp("ref_" + name.replace("-", "_"))
+            poses = str(d / "poses_history_file.txt")
+            with gzip.open(os.path.join(root, name, "poses_history_file.txt.gz"), "rb") as f, open(poses, "wb") as g:
+                shutil.copyfileobj(f, g)
+            cache[name] = (poses, os.path.join(root, name, "incoming_id_file.txt"))
+        return cache[name]
+    return get

@@ -1,5 +1,6 @@
-"""The one reference-pinned known-answer test: incoming_id_file.txt is a function of
-poses_history_file.txt alone (pts_preprocess.h:187-215).  Checked for the oracle and the numpy checker."""
+"""The reference-pinned known-answer test: incoming_id_file.txt is a function of poses_history_file.txt
+alone (pts_preprocess.h:187-215).  Checked for the oracle, the numpy checker and the product's host pre-stage on ALL 13
+sequences the reference holds (5 KITTI, 8 RobotCar: the RobotCar runs have up to five tracking resets each)."""
 import os
 
 import numpy as np
@@ -7,6 +8,7 @@ import pytest
 
 import np_checker
 import oracle_lib
+from conftest import REF_SEQUENCES
 
 SEQS = ["kitti_seq06", "kitti_seq07"]
 
@@ -34,3 +36,23 @@ def test_reference_sizes_from_survey(golden_dir):
     for seq, n in (("kitti_seq06", 880), ("kitti_seq07", 693)):
         ids = open(os.path.join(golden_dir, seq, "incoming_id_file.txt")).read().split()
         assert len(ids) == n
+
+
+@pytest.mark.parametrize("name", REF_SEQUENCES)
+def test_all_reference_sequences_byte_identical(ref_sequence, name, tmp_path):
+    from so_dso_place_recognition_amd import api
+    poses, ids_file = ref_sequence(name)
+    want = open(ids_file, "rb").read()
+    empty_pts = tmp_path / "pts.txt"
+    empty_pts.write_text("")
+    assert np_checker.incoming_ids(poses) == [int(x) for x in want.split()]
+    o = tmp_path / "oracle.txt"
+    oracle_lib.pts_preprocess(poses, str(empty_pts), str(o))
+    assert o.read_bytes() == want
+    g = tmp_path / "product.txt"
+    api.pts_preprocess(poses, str(empty_pts), str(g))                 # host pre-stage of libpr_amd.so (no GPU involved)
+    assert g.read_bytes() == want
+
+
+def test_there_are_thirteen_reference_sequences():
+    assert len(REF_SEQUENCES) == 13

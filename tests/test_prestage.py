@@ -7,6 +7,7 @@ import pytest
 
 import helpers
 import oracle_lib
+from conftest import REF_SEQUENCES
 from so_dso_place_recognition_amd import api
 
 
@@ -229,3 +230,18 @@ def test_gpu_prestage_resets_ranges_and_empty_inputs(golden_dir, tmp_path):
     assert np.array_equal(g[2], h[2]) and np.array_equal(g[3], h[3]) and g[0].shape == (0, 3)
     g = api.pts_preprocess(empty, empty, None, 45.0, True, gpu=True)
     assert len(g[3]) == 0 and len(g[2]) == 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", REF_SEQUENCES)
+def test_gpu_prestage_reproduces_every_reference_id_file(ref_sequence, name, tmp_path):
+    """The device pre-stage on the reference's own pose files (RobotCar: several resets per run) + synthetic points: the
+    id file must be the reference's, byte for byte, and the clouds the host pre-stage's."""
+    poses, ids_file = ref_sequence(name)
+    pts = str(tmp_path / "pts.txt")
+    helpers.write_synthetic_points(poses, pts, per_pose=12)
+    out = str(tmp_path / "ids.txt")
+    g = api.pts_preprocess(poses, pts, out, 45.0, False, gpu=True)
+    assert open(out, "rb").read() == open(ids_file, "rb").read()
+    h = api.pts_preprocess(poses, pts, None, 45.0, False)
+    assert all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(g, h))
