@@ -22,7 +22,7 @@ typedef struct pr_sigset pr_sigset;
 typedef struct pr_clouds pr_clouds;
 
 enum { PR_OK = 0, PR_EINVAL = -1, PR_ENOMEM = -2, PR_EHIP = -3, PR_EIO = -4, PR_ENAN = -5 };
-enum { PR_TYPE_SC = 0, PR_TYPE_M2DP = 1, PR_TYPE_DELIGHT = 2 };   /* run_test.m:26-36 `type` */
+enum { PR_TYPE_SC = 0, PR_TYPE_M2DP = 1, PR_TYPE_DELIGHT = 2, PR_TYPE_GIST = 3, PR_TYPE_BOW = 4 };   /* run_test.m:26-36 `type` */
 enum { PR_ROLE_QUERY = 0, PR_ROLE_DB = 1 };         /* hist1 / hist2 of run_test.m:1 */
 enum { PR_F64 = 0, PR_F32 = 1 };
 enum { PR_HOST = 0, PR_DEVICE = 1 };
@@ -83,6 +83,16 @@ int pr_m2dp_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2,
  * score = the chi-square distance, h1[16m][256], h2[16n][256], p_weight ignored. */
 int pr_match_topk(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n,
                   int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score);
+
+/* The two remaining `type`s of run_test.m:32-35, whose signatures have no fixed length (`cols` columns per row):
+ *   gist: h [m][cols];            dist(i,j) = sum_c (h1[i,c] - h2[j,c])^2                    (processGIST.m:1-10)
+ *   bow:  h [2 m][cols], rows alternate word ids | weights, padded with -1 (test_bow.cpp:147-162);
+ *         dist(i,j) = 1 - DBoW2 L1 score                                                    (processBoW.m:1-38)
+ * pr_match_topk_cols: mask + row minimum without fusion (run_test.m:47-57), type = PR_TYPE_GIST | PR_TYPE_BOW. */
+int pr_gist_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, int32_t cols, float* dist);
+int pr_bow_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, int32_t cols, float* dist);
+int pr_match_topk_cols(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n, int32_t cols,
+                       int32_t mask_width, int32_t k, int32_t* idx, float* score);
 
 /* ---- device-resident entry points (inputs already in HBM; what bench.py and the multi-GPU layer call) -- *
  * All are asynchronous on the context's stream; pr_sync() surfaces deferred errors (e.g. PR_ENAN).         */

@@ -600,6 +600,40 @@ int pr_ref_delight_distance(const double* h1, int32_t m, const double* h2, int32
   return PR_REF_OK;
 }
 
+// processGIST.m:1-10 - squared Euclidean distance of every row pair
+int pr_ref_gist_distance(const double* h1, int32_t m, const double* h2, int32_t n, int32_t cols, double* dist) {
+  if (!h1 || !h2 || !dist || m < 0 || n < 0 || cols < 0) return PR_REF_EINVAL;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < m; i++)
+    for (int j = 0; j < n; j++) {
+      double s = 0.0;
+      for (int c = 0; c < cols; c++) { const double d = h1[(size_t)i * cols + c] - h2[(size_t)j * cols + c]; s += d * d; }   // :7
+      dist[(size_t)i * n + j] = s;
+    }
+  return PR_REF_OK;
+}
+
+// processBoW.m:1-38 - rows alternate (word ids | word weights), both padded with -1 (test_bow.cpp:147-162); DBoW2's L1 score
+// by a merge of the two sorted id lists.  The loop guards are `ii < length(list)` with 1-based ii (processBoW.m:23): the
+// LAST column is never looked at - kept.
+int pr_ref_bow_distance(const double* h1, int32_t m, const double* h2, int32_t n, int32_t cols, double* dist) {
+  if (!h1 || !h2 || !dist || m < 0 || n < 0 || cols < 0) return PR_REF_EINVAL;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < m; i++)
+    for (int j = 0; j < n; j++) {
+      const double *i1 = h1 + (size_t)(2 * i) * cols, *v1 = i1 + cols, *i2 = h2 + (size_t)(2 * j) * cols, *v2 = i2 + cols;
+      int a = 1, b = 1;                                  // 1-based like the reference
+      double score = 0.0;
+      while (a < cols && i1[a - 1] > -1 && b < cols && i2[b - 1] > -1) {                                       // :23
+        if (i1[a - 1] == i2[b - 1]) { score = score + std::fabs(v1[a - 1] - v2[b - 1]) - std::fabs(v1[a - 1]) - std::fabs(v2[b - 1]); a++; b++; }   // :25
+        else if (i1[a - 1] < i2[b - 1]) a++;
+        else b++;
+      }
+      dist[(size_t)i * n + j] = 1.0 - (-score / 2.0);                                                          // :37, :14
+    }
+  return PR_REF_OK;
+}
+
 // run_test.m:47-57 without the z-score fusion (types other than m2dp / sc, run_test.m:26-41)
 // iteration order of the real std::unordered_map after inserting the K keys in this order (what the reference's
 // filterPoints / filterPointsPolar emit: pts_preprocess.h:85-89, :124-128); order[t] = index of the t-th element

@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 PR_OK, PR_EINVAL, PR_ENOMEM, PR_EHIP, PR_EIO, PR_ENAN = 0, -1, -2, -3, -4, -5
-TYPE_SC, TYPE_M2DP, TYPE_DELIGHT = 0, 1, 2
+TYPE_SC, TYPE_M2DP, TYPE_DELIGHT, TYPE_GIST, TYPE_BOW = 0, 1, 2, 3, 4
 SC_ARITH_F16X2, SC_ARITH_F32 = 0, 1
 ROLE_QUERY, ROLE_DB = 0, 1
 F64, F32 = 0, 1
@@ -33,6 +33,9 @@ SYMBOLS = {
     "pr_m2dp_generate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
     "pr_delight_generate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "pr_delight_distance": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
+    "pr_gist_distance": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "pr_bow_distance": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
+    "pr_match_topk_cols": (C.c_int, [_vp, C.c_int, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pr_delight_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "pr_sc_distance": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp]),
     "pr_m2dp_distance": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp]),

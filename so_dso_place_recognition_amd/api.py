@@ -13,7 +13,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import PRError, TYPE_DELIGHT, TYPE_M2DP, TYPE_SC  # noqa: F401
+from ._lib import PRError, TYPE_BOW, TYPE_DELIGHT, TYPE_GIST, TYPE_M2DP, TYPE_SC  # noqa: F401
 
 
 def _ptr(a):
@@ -202,12 +202,44 @@ def processDELIGHT(hist1, hist2, ctx: Context | None = None):
     return d
 
 
+def processGIST(hist1, hist2, ctx: Context | None = None):
+    """diff_m = processGIST(hist1, hist2)  (processGIST.m:1): squared Euclidean distances, float32 [m, n]."""
+    ctx = ctx or default_context()
+    h1 = np.ascontiguousarray(hist1, np.float64); h2 = np.ascontiguousarray(hist2, np.float64)
+    if h1.shape[1] != h2.shape[1]:
+        raise ValueError("hist1 and hist2 must have the same number of columns")
+    d = np.empty((h1.shape[0], h2.shape[0]), np.float32)
+    ctx.check(ctx.lib.pr_gist_distance(ctx.h, _ptr(h1), h1.shape[0], _ptr(h2), h2.shape[0], h1.shape[1], _ptr(d)))
+    return d
+
+
+def processBoW(hist1, hist2, ctx: Context | None = None):
+    """diff_m = processBoW(hist1, hist2)  (processBoW.m:1): rows alternate word ids / weights (padded with -1); float32 [m, n]."""
+    ctx = ctx or default_context()
+    h1 = np.ascontiguousarray(hist1, np.float64); h2 = np.ascontiguousarray(hist2, np.float64)
+    if h1.shape[1] != h2.shape[1] or h1.shape[0] % 2 or h2.shape[0] % 2:
+        raise ValueError("BoW files hold two rows of the same width per image")
+    m, n = h1.shape[0] // 2, h2.shape[0] // 2
+    d = np.empty((m, n), np.float32)
+    ctx.check(ctx.lib.pr_bow_distance(ctx.h, _ptr(h1), m, _ptr(h2), n, h1.shape[1], _ptr(d)))
+    return d
+
+
 def match_topk(type_, hist1, hist2, mask_width=0, p_weight=2.0, k=1, ctx: Context | None = None):
     """run_test.m:26-57 generalised to top-k: returns (idx int32 [m,k] 0-based, score float32 [m,k])."""
     ctx = ctx or default_context()
-    t = {"sc": TYPE_SC, "m2dp": TYPE_M2DP, "delight": TYPE_DELIGHT}.get(type_, type_)
+    t = {"sc": TYPE_SC, "m2dp": TYPE_M2DP, "delight": TYPE_DELIGHT, "gist": TYPE_GIST, "bow": TYPE_BOW}.get(type_, type_)
+    if t in (TYPE_GIST, TYPE_BOW):
+        h1 = np.ascontiguousarray(hist1, np.float64); h2 = np.ascontiguousarray(hist2, np.float64)
+        div = 2 if t == TYPE_BOW else 1
+        if h1.shape[1] != h2.shape[1] or h1.shape[0] % div or h2.shape[0] % div:
+            raise ValueError("hist1 / hist2 shapes do not fit the type")
+        m, n = h1.shape[0] // div, h2.shape[0] // div
+        idx = np.empty((m, k), np.int32); sc = np.empty((m, k), np.float32)
+        ctx.check(ctx.lib.pr_match_topk_cols(ctx.h, t, _ptr(h1), m, _ptr(h2), n, h1.shape[1], int(mask_width), int(k), _ptr(idx), _ptr(sc)))
+        return idx, sc
     if t not in (TYPE_SC, TYPE_M2DP, TYPE_DELIGHT):
-        raise ValueError("type must be 'sc', 'm2dp' or 'delight'")
+        raise ValueError("type must be 'sc', 'm2dp', 'delight', 'gist' or 'bow'")
     div, width = {TYPE_SC: (1, 2400), TYPE_M2DP: (4, 384), TYPE_DELIGHT: (16, 256)}[t]
     h1 = np.ascontiguousarray(hist1, np.float64)
     h2 = np.ascontiguousarray(hist2, np.float64)

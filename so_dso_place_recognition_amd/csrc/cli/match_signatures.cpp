@@ -1,6 +1,6 @@
 // match_signatures — executable counterpart of match_signatures/run_test.m:25-57 (the reference runs it from MATLAB:
 // test_kitti.m:18-28).  Options mirror run_test's arguments:
-//   --type sc|m2dp|delight --hist1 F --hist2 F [--mask_width W=0] [--p_weight 2] [--topk K=1] [--one_based 0|1] --out F
+//   --type sc|m2dp|delight|gist|bow --hist1 F --hist2 F [--mask_width W=0] [--p_weight 2] [--topk K=1] [--one_based 0|1] --out F
 // Output: one line per query: K pairs "index score" (0-based indices unless --one_based 1), and the reference's
 // console lines `type` / `tm` (ms per query, run_test.m:42-44).
 #include <chrono>
@@ -13,13 +13,14 @@ int main(int argc, char** argv) {
   Params prm(argc, argv);
   std::string type, h1f, h2f, outf;
   if (!prm.get("type", type) || !prm.get("hist1", h1f) || !prm.get("hist2", h2f) || !prm.get("out", outf) ||
-      (type != "sc" && type != "m2dp" && type != "delight")) {
-    printf("usage: match_signatures --type sc|m2dp|delight --hist1 F --hist2 F [--mask_width W] [--p_weight 2] [--topk K] [--one_based 0|1] --out F\n");
+      (type != "sc" && type != "m2dp" && type != "delight" && type != "gist" && type != "bow")) {
+    printf("usage: match_signatures --type sc|m2dp|delight|gist|bow --hist1 F --hist2 F [--mask_width W] [--p_weight 2] [--topk K] [--one_based 0|1] --out F\n");
     return 1;
   }
-  const int t = type == "sc" ? PR_TYPE_SC : (type == "m2dp" ? PR_TYPE_M2DP : PR_TYPE_DELIGHT);
-  const int div = t == PR_TYPE_SC ? 1 : (t == PR_TYPE_M2DP ? 4 : 16);
-  const int64_t width = t == PR_TYPE_SC ? PR_SC_SIG_LEN : (t == PR_TYPE_M2DP ? PR_M2DP_SIG_LEN : PR_DELIGHT_SIG_LEN);
+  const int t = type == "sc" ? PR_TYPE_SC : type == "m2dp" ? PR_TYPE_M2DP : type == "delight" ? PR_TYPE_DELIGHT : type == "gist" ? PR_TYPE_GIST : PR_TYPE_BOW;
+  const bool cols_type = t == PR_TYPE_GIST || t == PR_TYPE_BOW;        // no fixed signature length
+  const int div = t == PR_TYPE_SC ? 1 : t == PR_TYPE_M2DP ? 4 : t == PR_TYPE_DELIGHT ? 16 : t == PR_TYPE_BOW ? 2 : 1;
+  int64_t width = t == PR_TYPE_SC ? PR_SC_SIG_LEN : (t == PR_TYPE_M2DP ? PR_M2DP_SIG_LEN : PR_DELIGHT_SIG_LEN);
   double *h1 = nullptr, *h2 = nullptr;
   int64_t r1, c1, r2, c2;
   auto rd = [](const std::string& f, double** o, int64_t* r, int64_t* c) {
@@ -30,6 +31,7 @@ int main(int argc, char** argv) {
     fprintf(stderr, "%s\n", pr_host_last_error());
     return 2;
   }
+  if (cols_type) width = c1;
   if (c1 != width || c2 != width || r1 % div || r2 % div) { fprintf(stderr, "signature files must be [%d*m x %ld]\n", div, (long)width); return 2; }
   const int32_t m = (int32_t)(r1 / div), n = (int32_t)(r2 / div), k = (int32_t)prm.num("topk", 1);
   std::vector<int32_t> idx((size_t)m * k);
@@ -37,7 +39,8 @@ int main(int argc, char** argv) {
   pr_ctx* ctx = nullptr;
   if (pr_create((int)prm.num("device", 0), &ctx) != PR_OK) { fprintf(stderr, "%s\n", pr_last_error(nullptr)); return 3; }
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = pr_match_topk(ctx, t, h1, m, h2, n, (int32_t)prm.num("mask_width", 0), prm.num("p_weight", 2.0), k, idx.data(), score.data());
+  const int rc = cols_type ? pr_match_topk_cols(ctx, t, h1, m, h2, n, (int32_t)width, (int32_t)prm.num("mask_width", 0), k, idx.data(), score.data())
+                           : pr_match_topk(ctx, t, h1, m, h2, n, (int32_t)prm.num("mask_width", 0), prm.num("p_weight", 2.0), k, idx.data(), score.data());
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (rc != PR_OK) { fprintf(stderr, "match failed (%d): %s\n", rc, pr_last_error(ctx)); pr_destroy(ctx); return 4; }
   printf("type = %s\ntm = %g\n", type.c_str(), m ? 1000.0 * secs / m : 0.0);

@@ -63,6 +63,9 @@ void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, 
                          double* out);
 size_t m2dp_generate_scratch_bytes(int N);
 
+// plain_match.hip — processGIST.m:1-10, processBoW.m:1-38 (h1, h2: device, row-major doubles; BoW rows alternate ids | weights)
+void launch_gist_distance(hipStream_t st, const double* h1, int m, const double* h2, int n, int cols, float* dist);
+void launch_bow_distance(hipStream_t st, const double* h1, int m, const double* h2, int n, int cols, float* dist);
 // delight.hip — DELIGHT.cpp:8-24, processDELIGHT.m:1-38
 void launch_delight_gen(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
                         const double* frames, double* out);

@@ -600,6 +600,55 @@ int pr_match_topk(pr_ctx* ctx, int type, const double* h1, int32_t m, const doub
   return distance_host(ctx, type, h1, m, h2, n, nullptr, nullptr, mask_width, p_weight, k, idx, score, true);
 }
 
+// GIST / BoW (run_test.m:32-35): one distance matrix from raw f64 rows of `cols` columns, no packing, no fusion
+static int plain_cols_host(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n, int32_t cols,
+                           float* out, int32_t mask_width, int32_t k, int32_t* idx, float* score, bool want_topk) {
+  if (!ctx) return PR_EINVAL;
+  if (type != PR_TYPE_GIST && type != PR_TYPE_BOW) PR_FAIL(ctx, PR_EINVAL, "unknown plain type %d", type);
+  if (m < 0 || n < 0 || cols < 1 || (m > 0 && !h1) || (n > 0 && !h2) || m > PR_MAX_SIGS || n > PR_MAX_SIGS)
+    PR_FAIL(ctx, PR_EINVAL, "bad signature buffers (m=%d, n=%d, cols=%d)", m, n, cols);
+  if (type == PR_TYPE_BOW && (size_t)cols * 16 > 160 * 1024) PR_FAIL(ctx, PR_EINVAL, "BoW rows of %d columns do not fit the LDS", cols);
+  if (want_topk && (k < 1 || !idx || !score)) PR_FAIL(ctx, PR_EINVAL, "top-k needs k >= 1 and output buffers");
+  if (m == 0 || n == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  const size_t rows1 = (type == PR_TYPE_BOW ? 2 : 1) * (size_t)m, rows2 = (type == PR_TYPE_BOW ? 2 : 1) * (size_t)n;
+  const size_t mn = (size_t)m * n;
+  DevBuf d1, d2, dd, didx, dsc;
+  if (d1.alloc(rows1 * cols * 8) != hipSuccess || d2.alloc(rows2 * cols * 8) != hipSuccess || dd.alloc(mn * 4) != hipSuccess)
+    PR_FAIL(ctx, PR_ENOMEM, "out of device memory for %d x %d %s signatures", m, n, type == PR_TYPE_BOW ? "BoW" : "GIST");
+  int rc = PR_OK;
+  do {
+    if (hipMemcpyAsync(d1.p, h1, rows1 * cols * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(d2.p, h2, rows2 * cols * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D copy failed"; rc = PR_EHIP; break; }
+    if (type == PR_TYPE_GIST) pr::launch_gist_distance(ctx->stream, d1.as<double>(), m, d2.as<double>(), n, cols, dd.as<float>());
+    else pr::launch_bow_distance(ctx->stream, d1.as<double>(), m, d2.as<double>(), n, cols, dd.as<float>());
+    if (hipGetLastError() != hipSuccess) { ctx->err = "kernel launch failed"; rc = PR_EHIP; break; }
+    if (want_topk) {
+      if (didx.alloc((size_t)m * k * 4) != hipSuccess || dsc.alloc((size_t)m * k * 4) != hipSuccess) { ctx->err = "out of device memory"; rc = PR_ENOMEM; break; }
+      if ((rc = pr_fuse_select_dev(ctx, dd.as<float>(), nullptr, m, n, nullptr, 1, 0, 0, mask_width, 0.0, k, didx.as<int32_t>(), dsc.as<float>()))) break;
+      if (hipMemcpyAsync(idx, didx.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(score, dsc.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
+    }
+    if (out && hipMemcpyAsync(out, dd.p, mn * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
+    rc = pr_sync(ctx);
+  } while (0);
+  if (rc != PR_OK) (void)hipStreamSynchronize(ctx->stream);
+  return rc;
+}
+
+int pr_gist_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, int32_t cols, float* dist) {
+  return plain_cols_host(ctx, PR_TYPE_GIST, h1, m, h2, n, cols, dist, 0, 0, nullptr, nullptr, false);
+}
+
+int pr_bow_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, int32_t cols, float* dist) {
+  return plain_cols_host(ctx, PR_TYPE_BOW, h1, m, h2, n, cols, dist, 0, 0, nullptr, nullptr, false);
+}
+
+int pr_match_topk_cols(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n, int32_t cols,
+                       int32_t mask_width, int32_t k, int32_t* idx, float* score) {
+  return plain_cols_host(ctx, type, h1, m, h2, n, cols, nullptr, mask_width, k, idx, score, true);
+}
+
 // ------------------------------------------------------------------------------------------- generation
 static int check_gen_args(pr_ctx* ctx, const void* xyz, const void* inten, const void* offs, int32_t N, double max_rho, const void* out) {
   if (!ctx) return PR_EINVAL;

@@ -57,3 +57,89 @@ def precision_recall(diff_v, diff_idx, gt1, gt2, loop_diff: float, mask_width: i
     auc = float(trapz(precision, recall))              # trapz(recall, precision)
     lp_detected = np.stack([rank[:top_count], diff_idx[rank[:top_count]]], 1)
     return auc, float(top_recall), lp_detected, precision, recall
+
+
+# ------------------------------------------------------------------ the drivers: test_kitti.m, test_robotcar.m
+KITTI_SEQS = ("seq00", "seq02", "seq05", "seq06", "seq07")                                  # test_kitti.m:5
+ROBOTCAR_DATES = ("2014-07-14-14-49-50", "2014-11-28-12-07-13", "2014-12-12-10-45-15", "2015-02-10-11-58-05",
+                  "2015-05-19-14-06-38", "2015-05-22-11-14-30", "2015-08-13-16-02-58", "2015-10-30-13-52-14")   # test_robotcar.m:4-6
+ROBOTCAR_PAIRS = ((5, 6), (5, 7), (5, 8), (5, 4), (7, 1), (7, 8), (7, 4), (8, 2), (8, 4), (4, 3))              # :9, 1-based
+TYPES = ("delight", "m2dp", "sc", "bow", "gist")                                            # :8
+
+
+def _load(path):
+    """MATLAB `load` of a numeric text file (optionally gzip-compressed, as the test fixtures are)."""
+    import gzip
+    import os
+    if not os.path.exists(path) and os.path.exists(path + ".gz"):
+        path += ".gz"
+    with (gzip.open(path, "rt") if path.endswith(".gz") else open(path)) as f:
+        return np.loadtxt(f, ndmin=2)
+
+
+def load_kitti_ground_truth(seq_dir: str) -> np.ndarray:
+    """test_kitti.m:23-25: positions of the poses that became clouds - gt.txt rows `incoming_id + 1` (0-based ids in the
+    file), columns 4, 8, 12 of the row-major 3 x 4 pose."""
+    import os
+    ids = _load(os.path.join(seq_dir, "incoming_id_file.txt")).astype(np.int64).ravel()
+    return _load(os.path.join(seq_dir, "gt.txt"))[ids][:, [3, 7, 11]]
+
+
+def load_robotcar_ground_truth(run_dir: str) -> np.ndarray:
+    """test_robotcar.m:31-36: gps.txt rows of the poses that became clouds (all three columns)."""
+    import os
+    ids = _load(os.path.join(run_dir, "incoming_id_file.txt")).astype(np.int64).ravel()
+    return _load(os.path.join(run_dir, "gps.txt"))[ids]
+
+
+def run_kitti(seq_dir: str, type_: str, hist=None, ctx=None):
+    """run_kitti of test_kitti.m:17-29: a sequence against itself, mask_width 100, loop_diff 10 m.  `hist` defaults to
+    `<seq_dir>/history_<type>.txt` (or .bin).  Returns (AUC, top_recall, lp_detected)."""
+    from . import api
+    gt = load_kitti_ground_truth(seq_dir)
+    h = _history(seq_dir, type_) if hist is None else hist
+    return api.run_test(type_, h, h, gt, gt, 10.0, 100, ctx)
+
+
+def run_robotcar(run1_dir: str, run2_dir: str, type_: str, hist1=None, hist2=None, ctx=None):
+    """run_robotcar of test_robotcar.m:26-41: run 1 against run 2, no mask, loop_diff 25 m."""
+    from . import api
+    gt1, gt2 = load_robotcar_ground_truth(run1_dir), load_robotcar_ground_truth(run2_dir)
+    h1 = _history(run1_dir, type_) if hist1 is None else hist1
+    h2 = _history(run2_dir, type_) if hist2 is None else hist2
+    return api.run_test(type_, h1, h2, gt1, gt2, 25.0, 0, ctx)
+
+
+def _history(d: str, type_: str):
+    import os
+    from . import api
+    for ext in (".bin", ".txt"):
+        p = os.path.join(d, "history_" + type_ + ext)
+        if os.path.exists(p):
+            return api.read_signatures(p)
+    raise FileNotFoundError(os.path.join(d, "history_" + type_ + ".txt"))
+
+
+def test_kitti(results_dir: str, types=TYPES, seqs=KITTI_SEQS, ctx=None):
+    """test_kitti.m:1-15: (AUCs, TRs), each [len(types), len(seqs)]."""
+    import os
+    auc = np.zeros((len(types), len(seqs))); tr = np.zeros_like(auc)
+    for ti, t in enumerate(types):
+        for si, s in enumerate(seqs):
+            auc[ti, si], tr[ti, si] = run_kitti(os.path.join(results_dir, "KITTI", s), t, ctx=ctx)[:2]
+    return auc, tr
+
+
+def test_robotcar(results_dir: str, types=TYPES, pairs=ROBOTCAR_PAIRS, ctx=None):
+    """test_robotcar.m:1-24: (AUCs, TRs), each [len(types), len(pairs)]; pairs are 1-based indices into ROBOTCAR_DATES."""
+    import os
+    auc = np.zeros((len(types), len(pairs))); tr = np.zeros_like(auc)
+    for ti, t in enumerate(types):
+        for si, (a, b) in enumerate(pairs):
+            auc[ti, si], tr[ti, si] = run_robotcar(os.path.join(results_dir, "RobotCar", ROBOTCAR_DATES[a - 1]),
+                                                   os.path.join(results_dir, "RobotCar", ROBOTCAR_DATES[b - 1]), t, ctx=ctx)[:2]
+    return auc, tr
+
+
+test_kitti.__test__ = False       # (names of the reference's scripts, not pytest tests)
+test_robotcar.__test__ = False

@@ -164,3 +164,21 @@ def delight_queries(seed: int, db: np.ndarray, m: int):
         r = u[t, 2:].reshape(2, 16, 256)
         q[t] = np.where(r[0] < 0.02, np.floor(r[1] * 8), src)
     return q.reshape(16 * m, 256), et
+
+
+def bow_signatures(seed: int, n: int, cols: int = 120, vocab: int = 400, fill=(20, 90)):
+    """[2 n][cols] BoW rows as test_bow.cpp:147-162 writes them: sorted word ids / L1-normalised weights, both padded with -1."""
+    rng = np.random.default_rng(seed)
+    out = -np.ones((2 * n, cols))
+    for i in range(n):
+        k = int(rng.integers(fill[0], min(fill[1], cols) + 1))
+        ids = np.sort(rng.choice(vocab, size=k, replace=False))
+        w = rng.random(k) + 0.05
+        out[2 * i, :k] = ids
+        out[2 * i + 1, :k] = w / w.sum()
+    return out
+
+
+def gist_signatures(seed: int, n: int, cols: int = 96):
+    rng = np.random.default_rng(seed)
+    return np.abs(rng.normal(0.1, 0.05, size=(n, cols)))

@@ -20,4 +20,12 @@ for d in sorted(glob.glob(REF + "/*/*")):
     with open(poses, "rb") as f, gzip.GzipFile(os.path.join(o, "poses_history_file.txt.gz"), "wb", mtime=0) as g:
         shutil.copyfileobj(f, g)
     shutil.copyfile(ids, os.path.join(o, "incoming_id_file.txt"))
+    # ground truth of the evaluation drivers (test_kitti.m:24-25 gt.txt, test_robotcar.m:33-36 gps.txt) for the sequences
+    # tests/test_eval.py runs them on
+    if name in ("kitti_seq06", "kitti_seq07", "robotcar_2015-05-19-14-06-38", "robotcar_2015-05-22-11-14-30"):
+        for gname in ("gt.txt", "gps.txt"):
+            src = os.path.join(d, gname)
+            if os.path.exists(src):
+                with open(src, "rb") as f, gzip.GzipFile(os.path.join(o, gname + ".gz"), "wb", mtime=0) as g:
+                    shutil.copyfileobj(f, g)
     print(name, os.path.getsize(os.path.join(o, "poses_history_file.txt.gz")))

@@ -214,3 +214,31 @@ def delight_distance(h1, h2):
             best = np.where(best > t, t, best)
         out[i] = best
     return out
+
+
+def gist_distance(h1, h2):
+    """processGIST.m:1-10"""
+    h1 = np.asarray(h1, np.float64); h2 = np.asarray(h2, np.float64)
+    return ((h1[:, None, :] - h2[None, :, :]) ** 2).sum(2)
+
+
+def bow_distance(h1, h2):
+    """processBoW.m:1-38, literally (1-based cursors; the strict `<` of the guards skips the last column)"""
+    h1 = np.asarray(h1, np.float64); h2 = np.asarray(h2, np.float64)
+    i1s, v1s, i2s, v2s = h1[0::2], h1[1::2], h2[0::2], h2[1::2]
+    out = np.ones((i1s.shape[0], i2s.shape[0]))
+    for i in range(i1s.shape[0]):
+        for j in range(i2s.shape[0]):
+            i1, v1, i2, v2 = i1s[i], v1s[i], i2s[j], v2s[j]
+            a = b = 1
+            score = 0.0
+            while a < len(i1) and i1[a - 1] > -1 and b < len(i2) and i2[b - 1] > -1:
+                if i1[a - 1] == i2[b - 1]:
+                    score = score + abs(v1[a - 1] - v2[b - 1]) - abs(v1[a - 1]) - abs(v2[b - 1])
+                    a += 1; b += 1
+                elif i1[a - 1] < i2[b - 1]:
+                    a += 1
+                else:
+                    b += 1
+            out[i, j] = 1 - (-score / 2.0)
+    return out

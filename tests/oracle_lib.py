@@ -45,6 +45,8 @@ def lib():
     L.pr_ref_m2dp_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, _dp, _dp]
     L.pr_ref_delight_generate.argtypes = [_dp, _fp, _lp, C.c_int32, _dp]
     L.pr_ref_delight_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, _dp]
+    L.pr_ref_gist_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, C.c_int32, _dp]
+    L.pr_ref_bow_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, C.c_int32, _dp]
     L.pr_ref_unordered_order.argtypes = [_ip, C.c_int32, _ip]
     L.pr_ref_select_topk.argtypes = [_dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _dp]
     L.pr_ref_fuse_topk.argtypes = [_dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, _ip, _dp]
@@ -162,6 +164,16 @@ def match_topk(type_, h1, h2, mask_width, p_weight=2.0, k=1):
     return rc, idx, sc
 
 
+def select_topk(d, mask_width, k=1):
+    """run_test.m:47-57 on one distance matrix (no fusion): (rc, idx int32 [m,k], score f64 [m,k])."""
+    d = np.ascontiguousarray(d, np.float64)
+    m, n = d.shape
+    idx = np.empty((m, k), np.int32)
+    sc = np.empty((m, k))
+    rc = lib().pr_ref_select_topk(d, m, n, mask_width, k, idx, sc)
+    return rc, idx, sc
+
+
 def delight_generate(xyz, inten, offs):
     N = len(offs) - 1
     out = np.empty((16 * N, 256))
@@ -178,6 +190,21 @@ def delight_distance(h1, h2):
     d = np.empty((m, n))
     rc = lib().pr_ref_delight_distance(h1, m, h2, n, d)
     assert rc == 0
+    return d
+
+
+def gist_distance(h1, h2):
+    h1 = np.ascontiguousarray(h1, np.float64); h2 = np.ascontiguousarray(h2, np.float64)
+    d = np.empty((h1.shape[0], h2.shape[0]))
+    assert lib().pr_ref_gist_distance(h1, h1.shape[0], h2, h2.shape[0], h1.shape[1], d) == 0
+    return d
+
+
+def bow_distance(h1, h2):
+    h1 = np.ascontiguousarray(h1, np.float64); h2 = np.ascontiguousarray(h2, np.float64)
+    m, n = h1.shape[0] // 2, h2.shape[0] // 2
+    d = np.empty((m, n))
+    assert lib().pr_ref_bow_distance(h1, m, h2, n, h1.shape[1], d) == 0
     return d
 
 

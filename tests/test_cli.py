@@ -19,6 +19,9 @@ def test_missing_params_exit_code_and_message():
         r = subprocess.run([os.path.join(BIN, exe), "_poses_history_file:=x"], capture_output=True, text=True)
         assert r.returncode == 1 and "Fail to get params, exit." in r.stdout      # test_sc.cpp:19-25
     r = subprocess.run([os.path.join(BIN, "match_signatures"), "--type", "gist"], capture_output=True, text=True)
+    assert r.returncode == 1 and "usage" in r.stdout                              # --hist1 / --hist2 / --out missing
+    r = subprocess.run([os.path.join(BIN, "match_signatures"), "--type", "orb", "--hist1", "a", "--hist2", "b", "--out", "c"],
+                       capture_output=True, text=True)
     assert r.returncode == 1 and "usage" in r.stdout
 
 
@@ -78,3 +81,28 @@ def test_gpu_prestage_option_gives_the_same_files(golden_dir, tmp_path):
         assert "generate_spherical_points average time" in r.stdout
         outs.append((open(sig, "rb").read(), open(ids, "rb").read()))
     assert outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_match_signatures_gist_and_bow(tmp_path):
+    """run_test.m:32-35 through the executable: text files in the reference's formats (BoW: two padded rows per image,
+    test_bow.cpp:147-162), plain row minimum with mask."""
+    from so_dso_place_recognition_amd import api, synth
+    for type_, h1, h2 in (("gist", synth.gist_signatures(5, 23), synth.gist_signatures(6, 57)),
+                          ("bow", synth.bow_signatures(7, 19), synth.bow_signatures(8, 41))):
+        f1, f2, res = str(tmp_path / f"{type_}1.txt"), str(tmp_path / f"{type_}2.txt"), str(tmp_path / f"{type_}.out")
+        if type_ == "bow":                                                        # the reference's writer: "v " per entry, endl per row
+            for f, h in ((f1, h1), (f2, h2)):
+                open(f, "w").write("".join("".join(("%d " % v) if r % 2 == 0 or v == -1 else ("%.9g " % v) for v in row) + "\n"
+                                           for r, row in enumerate(h)))
+        else:
+            api.write_signatures(f1, h1); api.write_signatures(f2, h2)
+        r = subprocess.run([os.path.join(BIN, "match_signatures"), "--type", type_, "--hist1", f1, "--hist2", f2,
+                            "--mask_width", "3", "--topk", "2", "--out", res], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        a, b = np.loadtxt(f1), np.loadtxt(f2)                                     # the text-rounded values both sides see
+        d = oracle_lib.gist_distance(a, b) if type_ == "gist" else oracle_lib.bow_distance(a, b)
+        rc, oidx, osc = oracle_lib.select_topk(d, 3, 2)
+        m = np.loadtxt(res)
+        assert np.array_equal(m[:, [0, 2]].astype(np.int32), oidx)
+        assert np.abs(m[:, [1, 3]] - osc).max() < 1e-5 * max(1.0, np.abs(osc).max())

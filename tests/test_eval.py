@@ -53,3 +53,51 @@ def test_precision_recall_sweep():
         p2.append(tp / (i + 1))
     assert np.allclose(prec, p2)
     assert 0 < auc <= 1
+
+
+# ------------------------------------------------------------------ the drivers (test_kitti.m, test_robotcar.m) on reference data
+import gzip
+import os
+
+import pytest
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_sequences")
+
+
+def _rff(pos, dim=96, scale=15.0, seed=3):
+    """A stand-in descriptor that is a smooth function of position (random Fourier features): near places, near vectors."""
+    rng = np.random.default_rng(seed)
+    w = rng.normal(0, 1.0 / scale, size=(pos.shape[1], dim)); b = rng.uniform(0, 2 * np.pi, dim)
+    return np.cos((pos - pos.mean(0)) @ w + b) * np.sqrt(2.0 / dim)
+
+
+def test_ground_truth_loaders_on_the_reference_files():
+    d = os.path.join(GOLD, "kitti_seq06")
+    ids = np.loadtxt(os.path.join(d, "incoming_id_file.txt")).astype(int)
+    full = np.loadtxt(gzip.open(os.path.join(d, "gt.txt.gz"), "rt"))
+    gt = ev.load_kitti_ground_truth(d)
+    assert gt.shape == (880, 3) and np.array_equal(gt, full[ids][:, [3, 7, 11]])      # test_kitti.m:23-25 (1-based there)
+    assert np.array_equal(gt[0], full[ids[0], [3, 7, 11]]) and ids[0] >= 30          # 30 warm-up poses after a reset (pts_preprocess.h:203)
+    d = os.path.join(GOLD, "robotcar_2015-05-19-14-06-38")
+    ids = np.loadtxt(os.path.join(d, "incoming_id_file.txt")).astype(int)
+    gps = ev.load_robotcar_ground_truth(d)
+    assert gps.shape == (len(ids), 3) and np.array_equal(gps, np.loadtxt(gzip.open(os.path.join(d, "gps.txt.gz"), "rt"))[ids])
+    assert ev.ROBOTCAR_DATES[5 - 1] == "2015-05-19-14-06-38" and ev.ROBOTCAR_PAIRS[0] == (5, 6) and len(ev.ROBOTCAR_PAIRS) == 10
+
+
+@pytest.mark.gpu
+def test_drivers_run_kitti_and_run_robotcar():
+    """run_kitti / run_robotcar with the reference's ground truth, ids, masks and thresholds; the signatures are stand-ins
+    (the reference's own are missing blobs), matched as type 'gist'.  The harness must find the loops the positions imply."""
+    d = os.path.join(GOLD, "kitti_seq06")
+    gt = ev.load_kitti_ground_truth(d)
+    auc, top_recall, det = ev.run_kitti(d, "gist", hist=_rff(gt))
+    lp = ev.ground_truth_pairs(gt, gt, 10.0, 100)
+    assert len(lp) > 50 and auc > 0.9 and top_recall > 0.5                            # seq06 closes its loop
+    assert all(((gt[a] - gt[b]) ** 2).sum() < 100.0 and abs(a - b) >= 100 for a, b in det)
+    d1, d2 = (os.path.join(GOLD, "robotcar_" + ev.ROBOTCAR_DATES[i - 1]) for i in ev.ROBOTCAR_PAIRS[0])
+    g1, g2 = ev.load_robotcar_ground_truth(d1), ev.load_robotcar_ground_truth(d2)
+    both = np.concatenate([g1, g2])
+    f = _rff(both, scale=40.0)
+    auc, top_recall, det = ev.run_robotcar(d1, d2, "gist", hist1=f[: len(g1)], hist2=f[len(g1):])
+    assert auc > 0.9 and top_recall > 0.3 and all(((g1[a] - g2[b]) ** 2).sum() < 625.0 for a, b in det)

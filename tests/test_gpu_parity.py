@@ -286,6 +286,36 @@ def test_sc_mixed_arithmetic_sets_are_rejected(api):
     ctx.close()
 
 
+@pytest.mark.parametrize("m,n,cols", [(1, 1, 1), (5, 70, 33), (65, 130, 96), (130, 64, 512)])
+def test_gist_distance_vs_oracle(api, m, n, cols):
+    a, b = synth.gist_signatures(11, m, cols), synth.gist_signatures(12, n, cols)
+    d = api.processGIST(a, b); o = oracle_lib.gist_distance(a, b)
+    assert d.shape == (m, n) and np.abs(d - o).max() <= 1e-6 * max(1e-3, o.max())
+
+
+@pytest.mark.parametrize("m,n,cols,fill", [(1, 1, 8, (1, 8)), (6, 300, 60, (10, 50)), (40, 257, 30, (30, 30)), (3, 9, 4000, (50, 400))])
+def test_bow_distance_vs_oracle(api, m, n, cols, fill):
+    a = synth.bow_signatures(21, m, cols=cols, vocab=max(500, cols), fill=fill)
+    b = synth.bow_signatures(22, n, cols=cols, vocab=max(500, cols), fill=fill)
+    d = api.processBoW(a, b); o = oracle_lib.bow_distance(a, b)
+    assert d.shape == (m, n) and np.abs(d - o).max() < 2e-7
+
+
+@pytest.mark.parametrize("type_", ["gist", "bow"])
+def test_plain_types_match_topk_vs_oracle(api, type_):
+    if type_ == "gist":
+        a, b = synth.gist_signatures(31, 37), synth.gist_signatures(32, 120)
+        d = oracle_lib.gist_distance(a, b)
+    else:
+        a, b = synth.bow_signatures(33, 37), synth.bow_signatures(34, 120)
+        d = oracle_lib.bow_distance(a, b)
+    rc, oidx, osc = oracle_lib.select_topk(d, 4, 3)
+    idx, sc = api.match_topk(type_, a, b, mask_width=4, k=3)
+    assert np.array_equal(idx, oidx) and np.abs(sc - osc).max() <= 1e-6 * max(1.0, np.abs(osc).max())
+    v, i = api.run_test(type_, a, b, mask_width=4)
+    assert np.array_equal(i, oidx[:, 0])
+
+
 def test_sigset_capacity_limit_is_an_error_not_an_overflow(api):
     import ctypes as C
     from so_dso_place_recognition_amd import _lib

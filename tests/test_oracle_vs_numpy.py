@@ -209,3 +209,18 @@ def test_delight_topk_plain_selection():
     order = np.argsort(d, axis=1, kind="stable")[:, :3]
     assert np.array_equal(idx, order)
     assert np.abs(sc - np.take_along_axis(d, order, 1)).max() < 1e-12
+
+
+def test_gist_and_bow_distances_vs_numpy():
+    """processGIST.m / processBoW.m: the C restatement against the literal numpy one (incl. the never-read last column
+    of full BoW rows and rows without padding)."""
+    from so_dso_place_recognition_amd import synth
+    g1, g2 = synth.gist_signatures(3, 9), synth.gist_signatures(4, 11)
+    assert np.abs(oracle_lib.gist_distance(g1, g2) - np_checker.gist_distance(g1, g2)).max() < 1e-14
+    for cols, fill in ((40, (5, 30)), (30, (30, 30)), (6, (1, 6))):
+        a = synth.bow_signatures(1, 7, cols=cols, vocab=60, fill=fill); b = synth.bow_signatures(2, 9, cols=cols, vocab=60, fill=fill)
+        d = oracle_lib.bow_distance(a, b)
+        assert np.abs(d - np_checker.bow_distance(a, b)).max() < 1e-15
+        assert d.min() >= -1e-12 and d.max() <= 1 + 1e-12
+    a = synth.bow_signatures(5, 4, cols=20, vocab=30, fill=(8, 12))
+    assert np.abs(np.diag(oracle_lib.bow_distance(a, a))).max() < 1e-12          # identical vectors: L1 score 1
