@@ -94,6 +94,16 @@ int pr_bow_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, 
 int pr_match_topk_cols(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n, int32_t cols,
                        int32_t mask_width, int32_t k, int32_t* idx, float* score);
 
+/* BASELINE.json config 5, "fused SC + M2DP scoring" - NO reference counterpart (run_test.m handles one type per run);
+ * build-defined as in SURVEY.md §6: score = [p z(sc_struct) + z(sc_int)] + [p z(m2dp_count) + z(m2dp_int)] with the row
+ * z-scores of run_test.m:40, then mask and row minimum (run_test.m:47-57).  sc: [m][2400], m2dp: [4 m][384] of the same places.
+ * pr_fuse_select2_dev is the device-level step (two channel pairs over the same grid, moments as pr_row_moments_dev). */
+int pr_match_topk_fused(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32_t m, const double* sc2, const double* m2dp2,
+                        int32_t n, int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score);
+int pr_fuse_select2_dev(pr_ctx* ctx, const float* d_p, const float* d_i, const float* e_p, const float* e_i, int32_t m, int32_t n,
+                        const double* mom_all, const double* mom2_all, int32_t G, int32_t q_row0, int32_t db_row0,
+                        int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score);
+
 /* ---- device-resident entry points (inputs already in HBM; what bench.py and the multi-GPU layer call) -- *
  * All are asynchronous on the context's stream; pr_sync() surfaces deferred errors (e.g. PR_ENAN).         */
 

@@ -689,4 +689,31 @@ int pr_ref_match_topk(int type, const double* h1, int32_t m, const double* h2, i
   return pr_ref_fuse_topk(dp.data(), di.data(), m, n, mask_width, p_weight, k, idx, score);
 }
 
+// BASELINE.json config 5 ("fused SC + M2DP scoring"), which has NO reference counterpart (run_test.m handles one type per
+// run): the build-defined score of SURVEY.md §6 - fused = [p z(sc_struct) + z(sc_int)] + [p z(m2dp_count) + z(m2dp_int)],
+// every z a MATLAB normalize(.,2) row z-score (N-1) as in run_test.m:40 - then mask and row minimum as run_test.m:47-57.
+int pr_ref_match_topk_fused(const double* sc1, const double* m2dp1, int32_t m, const double* sc2, const double* m2dp2, int32_t n,
+                            int32_t mask_width, double p_weight, int32_t k, int32_t* idx, double* score) {
+  if (n < 2 || m < 0 || k < 1) return PR_REF_EINVAL;
+  const size_t mn = (size_t)m * n;
+  std::vector<double> d[4];
+  for (auto& v : d) v.resize(mn);
+  int rc = pr_ref_sc_distance(sc1, m, sc2, n, d[0].data(), d[1].data());
+  if (!rc) rc = pr_ref_m2dp_distance(m2dp1, m, m2dp2, n, d[2].data(), d[3].data());
+  if (rc) return rc;
+  std::vector<double> f(mn, 0.0);
+  for (int c = 0; c < 4; c++)
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < m; i++) {
+      const double* a = d[c].data() + (size_t)i * n;
+      double mu = 0, va = 0;
+      for (int j = 0; j < n; j++) mu += a[j];
+      mu /= n;
+      for (int j = 0; j < n; j++) va += (a[j] - mu) * (a[j] - mu);
+      const double sd = std::sqrt(va / (n - 1)), wt = (c % 2 == 0) ? p_weight : 1.0;
+      for (int j = 0; j < n; j++) f[(size_t)i * n + j] += wt * ((a[j] - mu) / sd);
+    }
+  return pr_ref_select_topk(f.data(), m, n, mask_width, k, idx, score);
+}
+
 }  // extern "C"

@@ -253,6 +253,21 @@ def match_topk(type_, hist1, hist2, mask_width=0, p_weight=2.0, k=1, ctx: Contex
     return idx, sc
 
 
+def match_topk_fused(sc1, m2dp1, sc2, m2dp2, mask_width=0, p_weight=2.0, k=1, ctx: Context | None = None):
+    """BASELINE config 5 (build-defined, no reference counterpart): SC [m, 2400] and M2DP [4 m, 384] signatures of the same
+    places scored together - the four row z-scores added with weights p, 1, p, 1.  Returns (idx int32 [m,k], score float32)."""
+    ctx = ctx or default_context()
+    a1 = np.ascontiguousarray(sc1, np.float64); a2 = np.ascontiguousarray(sc2, np.float64)
+    b1 = np.ascontiguousarray(m2dp1, np.float64); b2 = np.ascontiguousarray(m2dp2, np.float64)
+    m, n = a1.shape[0], a2.shape[0]
+    if b1.shape != (4 * m, 384) or b2.shape != (4 * n, 384) or a1.shape[1] != 2400 or a2.shape[1] != 2400:
+        raise ValueError("need SC [m, 2400] and M2DP [4 m, 384] signatures of the same m (n) places")
+    idx = np.empty((m, k), np.int32); sc = np.empty((m, k), np.float32)
+    ctx.check(ctx.lib.pr_match_topk_fused(ctx.h, _ptr(a1), _ptr(b1), m, _ptr(a2), _ptr(b2), n, int(mask_width), float(p_weight),
+                                          int(k), _ptr(idx), _ptr(sc)))
+    return idx, sc
+
+
 def run_test(type_, hist1, hist2, gt1=None, gt2=None, loop_diff=None, mask_width=0, ctx: Context | None = None):
     """run_test.m:1.  Without ground truth: returns (diff_v, diff_idx) of run_test.m:57 (0-based indices).
     With gt1/gt2/loop_diff: returns (AUC, top_recall, lp_detected) through eval.precision_recall."""

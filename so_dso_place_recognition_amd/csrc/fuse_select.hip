@@ -75,19 +75,24 @@ __device__ __forceinline__ bool cand_less(double av, int aj, double bv, int bj) 
   return av < bv || (av == bv && aj < bj);
 }
 
+// e_p / e_i / mom2_all: an optional SECOND channel pair over the same (query, entry) grid whose z-scores are added with the
+// same weights (BASELINE.json config 5, "fused SC + M2DP scoring": build-defined, no reference counterpart)
 __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i,
+                                                           const float* __restrict__ e_p, const float* __restrict__ e_i,
+                                                           const double* __restrict__ mom2_all,
                                                            int m, int n, const double* __restrict__ mom_all, int G,
                                                            int q_row0, int db_row0, int mask_width, double p_weight,
                                                            int k, int32_t* __restrict__ idx, float* __restrict__ score) {
-  __shared__ double st[4];
+  __shared__ double st[8];
   __shared__ double rv[256];
   __shared__ int rj[256];
   const int tid = threadIdx.x, q = blockIdx.x;
   const bool plain = (d_i == nullptr);   // single distance matrix, no z-score fusion (run_test.m types other than m2dp/sc)
-  if (!plain && tid < 2) {  // Chan's parallel combination of the shard moments, fixed (rank) order
+  const bool two = (e_p != nullptr);
+  if (!plain && tid < (two ? 4 : 2)) {  // Chan's parallel combination of the shard moments, fixed (rank) order
     double cn = 0.0, mean = 0.0, m2 = 0.0;
     for (int g = 0; g < G; g++) {
-      const double* o = mom_all + (((size_t)g * m + q) * 2 + tid) * 3;
+      const double* o = (tid < 2 ? mom_all : mom2_all) + (((size_t)g * m + q) * 2 + (tid & 1)) * 3;
       const double nb = o[0], mb = o[1], m2b = o[2];
       if (nb <= 0.0) continue;
       const double tot = cn + nb, delta = mb - mean;
@@ -125,6 +130,7 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
       if (plain) f = (double)vp;
       else if (fastdiv) f = p_weight * div_rn((double)vp - mp, sp, rsp) + div_rn((double)vi - mi, si, rsi);        // run_test.m:40
       else f = p_weight * (((double)vp - mp) / sp) + ((double)vi - mi) / si;
+      if (two) f += p_weight * (((double)e_p[(size_t)q * n + j] - st[4]) / st[5]) + ((double)e_i[(size_t)q * n + j] - st[6]) / st[7];
       int dij = ig - jg;
       if (dij < 0) dij = -dij;
       if (dij < mask_width) f = __builtin_inf();                                      // run_test.m:47-53
@@ -176,9 +182,9 @@ void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int 
 
 void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int m, int n, const double* mom_all,
                         int G, int q_row0, int db_row0, int mask_width, double p_weight, int k, int32_t* idx,
-                        float* score) {
+                        float* score, const float* e_p, const float* e_i, const double* mom2_all) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(fuse_select_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, m, n, mom_all, G, q_row0, db_row0,
+  hipLaunchKernelGGL(fuse_select_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
                      mask_width, p_weight, k, idx, score);
 }
 

@@ -51,7 +51,7 @@ void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk
 void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom);
 void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int m, int n, const double* mom_all,
                         int G, int q_row0, int db_row0, int mask_width, double p_weight, int k, int32_t* idx,
-                        float* score);
+                        float* score, const float* e_p = nullptr, const float* e_i = nullptr, const double* mom2_all = nullptr);
 
 // sc_gen.hip / m2dp_gen.hip — pts_align.h:7-46 + SC.cpp:12-76 / M2DP.cpp:38-109 (+ test_m2dp.cpp:44-68)
 void launch_ave_chain(hipStream_t st, const float* inten, const int64_t* offs, int N, float* ave);

@@ -600,6 +600,53 @@ int pr_match_topk(pr_ctx* ctx, int type, const double* h1, int32_t m, const doub
   return distance_host(ctx, type, h1, m, h2, n, nullptr, nullptr, mask_width, p_weight, k, idx, score, true);
 }
 
+int pr_fuse_select2_dev(pr_ctx* ctx, const float* d_p, const float* d_i, const float* e_p, const float* e_i, int32_t m, int32_t n,
+                        const double* mom_all, const double* mom2_all, int32_t G, int32_t q_row0, int32_t db_row0,
+                        int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score) {
+  if (!ctx || !d_p || !d_i || !e_p || !e_i || !mom_all || !mom2_all || !idx || !score || m < 0 || n < 1 || G < 1 || k < 1) return PR_EINVAL;
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_fuse_select(ctx->stream, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, e_p, e_i, mom2_all);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+// BASELINE.json config 5: SC and M2DP signatures of the same places scored together (build-defined)
+int pr_match_topk_fused(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32_t m, const double* sc2, const double* m2dp2,
+                        int32_t n, int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score) {
+  if (!ctx) return PR_EINVAL;
+  if (m < 0 || n < 2 || k < 1 || !idx || !score || (m > 0 && (!sc1 || !m2dp1)) || !sc2 || !m2dp2)
+    PR_FAIL(ctx, PR_EINVAL, "pr_match_topk_fused: bad arguments (m=%d, n=%d, k=%d)", m, n, k);
+  if (m == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  pr_sigset* ss[4] = {nullptr, nullptr, nullptr, nullptr};   // SC query, SC db, M2DP query, M2DP db
+  DevBuf d[4], mom[2], didx, dsc;
+  int rc = PR_OK;
+  do {
+    if ((rc = pr_sigset_create(ctx, PR_TYPE_SC, PR_ROLE_QUERY, m, &ss[0])) || (rc = pr_sigset_create(ctx, PR_TYPE_SC, PR_ROLE_DB, n, &ss[1])) ||
+        (rc = pr_sigset_create(ctx, PR_TYPE_M2DP, PR_ROLE_QUERY, m, &ss[2])) || (rc = pr_sigset_create(ctx, PR_TYPE_M2DP, PR_ROLE_DB, n, &ss[3]))) break;
+    if ((rc = pr_sigset_pack(ctx, ss[0], sc1, PR_F64, PR_HOST, m)) || (rc = pr_sigset_pack(ctx, ss[1], sc2, PR_F64, PR_HOST, n)) ||
+        (rc = pr_sigset_pack(ctx, ss[2], m2dp1, PR_F64, PR_HOST, m)) || (rc = pr_sigset_pack(ctx, ss[3], m2dp2, PR_F64, PR_HOST, n))) break;
+    const size_t mn = (size_t)m * n;
+    bool ok = true;
+    for (auto& b : d) ok = ok && b.alloc(mn * 4) == hipSuccess;
+    ok = ok && mom[0].alloc((size_t)m * 6 * 8) == hipSuccess && mom[1].alloc((size_t)m * 6 * 8) == hipSuccess &&
+         didx.alloc((size_t)m * k * 4) == hipSuccess && dsc.alloc((size_t)m * k * 4) == hipSuccess;
+    if (!ok) { ctx->err = "out of device memory for the four m x n distance matrices"; rc = PR_ENOMEM; break; }
+    if ((rc = pr_distances_dev(ctx, ss[0], ss[1], d[0].as<float>(), d[1].as<float>())) ||
+        (rc = pr_distances_dev(ctx, ss[2], ss[3], d[2].as<float>(), d[3].as<float>())) ||
+        (rc = pr_row_moments_dev(ctx, d[0].as<float>(), d[1].as<float>(), m, n, mom[0].as<double>())) ||
+        (rc = pr_row_moments_dev(ctx, d[2].as<float>(), d[3].as<float>(), m, n, mom[1].as<double>())) ||
+        (rc = pr_fuse_select2_dev(ctx, d[0].as<float>(), d[1].as<float>(), d[2].as<float>(), d[3].as<float>(), m, n, mom[0].as<double>(),
+                                  mom[1].as<double>(), 1, 0, 0, mask_width, p_weight, k, didx.as<int32_t>(), dsc.as<float>()))) break;
+    if (hipMemcpyAsync(idx, didx.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(score, dsc.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
+    rc = pr_sync(ctx);
+  } while (0);
+  if (rc != PR_OK) (void)hipStreamSynchronize(ctx->stream);
+  for (auto* q : ss) pr_sigset_destroy(ctx, q);
+  return rc;
+}
+
 // GIST / BoW (run_test.m:32-35): one distance matrix from raw f64 rows of `cols` columns, no packing, no fusion
 static int plain_cols_host(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n, int32_t cols,
                            float* out, int32_t mask_width, int32_t k, int32_t* idx, float* score, bool want_topk) {

@@ -45,6 +45,7 @@ def lib():
     L.pr_ref_m2dp_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, _dp, _dp]
     L.pr_ref_delight_generate.argtypes = [_dp, _fp, _lp, C.c_int32, _dp]
     L.pr_ref_delight_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, _dp]
+    L.pr_ref_match_topk_fused.argtypes = [_dp, _dp, C.c_int32, _dp, _dp, C.c_int32, C.c_int32, C.c_double, C.c_int32, _ip, _dp]
     L.pr_ref_gist_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, C.c_int32, _dp]
     L.pr_ref_bow_distance.argtypes = [_dp, C.c_int32, _dp, C.c_int32, C.c_int32, _dp]
     L.pr_ref_unordered_order.argtypes = [_ip, C.c_int32, _ip]
@@ -161,6 +162,16 @@ def match_topk(type_, h1, h2, mask_width, p_weight=2.0, k=1):
     idx = np.empty((m, k), np.int32)
     sc = np.empty((m, k))
     rc = lib().pr_ref_match_topk(type_, h1, m, h2, n, mask_width, p_weight, k, idx, sc)
+    return rc, idx, sc
+
+
+def match_topk_fused(sc1, m2dp1, sc2, m2dp2, mask_width, p_weight=2.0, k=1):
+    """BASELINE config 5 (build-defined): SC and M2DP z-scores of the same (query, entry) pairs added up."""
+    sc1 = np.ascontiguousarray(sc1, np.float64); sc2 = np.ascontiguousarray(sc2, np.float64)
+    a1 = np.ascontiguousarray(m2dp1, np.float64); a2 = np.ascontiguousarray(m2dp2, np.float64)
+    m, n = sc1.shape[0], sc2.shape[0]
+    idx = np.empty((m, k), np.int32); sc = np.empty((m, k))
+    rc = lib().pr_ref_match_topk_fused(sc1, a1, m, sc2, a2, n, mask_width, p_weight, k, idx, sc)
     return rc, idx, sc
 
 

@@ -316,6 +316,23 @@ def test_plain_types_match_topk_vs_oracle(api, type_):
     assert np.array_equal(i, oidx[:, 0])
 
 
+def test_fused_sc_m2dp_scoring_vs_oracle(api):
+    """BASELINE config 5 at a small size: the build-defined 4-channel score (no reference counterpart) against the fp64
+    oracle - indices exact, scores to float accuracy; a planted copy must win."""
+    n, m = 230, 41
+    sdb = synth.sc_database(71, n); sq, planted = synth.sc_queries(72, sdb, m)
+    mdb = synth.m2dp_database(73, n); mq, planted2 = synth.m2dp_queries(74, mdb, m)
+    rc, oidx, osc = oracle_lib.match_topk_fused(sq, mq, sdb, mdb, 3, 2.0, 3)
+    assert rc == 0
+    idx, sc = api.match_topk_fused(sq, mq, sdb, mdb, mask_width=3, p_weight=2.0, k=3)
+    assert np.array_equal(idx, oidx) and np.abs(sc - osc).max() < 2e-4
+    # one channel pair switched off (identical rows give z = NaN there) is not the point; agreement of SC-only with the fused
+    # top-1 on queries planted in BOTH databases at the same index is
+    same = planted == planted2
+    if same.any():
+        assert (idx[same, 0] == planted[same]).all()
+
+
 def test_sigset_capacity_limit_is_an_error_not_an_overflow(api):
     import ctypes as C
     from so_dso_place_recognition_amd import _lib
