@@ -24,6 +24,7 @@ constexpr int M2_TILE = 96 * 64;                // floats per (channel, 32-row t
 inline int sc_qgroups8(int m) { return ((m + 31) / 32) * 4; }
 inline int sc_dgroups(int n) { return (n + 15) / 16; }
 inline int m2_tiles(int sigs) { return (sigs + 7) / 8; }      // 8 signatures x 4 variants = 32 rows
+inline int m2_qtiles(int sigs) { return ((m2_tiles(sigs) + 11) / 12) * 12; }   // query tiles: workgroups take 3 or 4 of them
 
 // sc_pack.hip — processSC.m:15-20 (row L2 normalisation) + per-ring rfft over the 60 sectors, written in the
 // MFMA operand layout of `role`.  sig: device [rows][2400] of T.  flags[0] |= 1 if a row has zero norm.

@@ -124,7 +124,7 @@ void launch_m2dp_pack(hipStream_t st, const void* sig, int dtype, int sigs, floa
 
 void launch_m2dp_match(hipStream_t st, const float* qpk, int m, const float* dpk, int n, float* d_p, float* d_i) {
   if (m <= 0 || n <= 0) return;
-  const int QT = ((m2_tiles(m) + 3) / 4) * 4, DT = m2_tiles(n);
+  const int QT = m2_qtiles(m), DT = m2_tiles(n);
   const int base = (QT / 4) * 2, DT4 = (DT + 3) / 4;
   int nsplit = (1024 + base - 1) / base;
   if (nsplit > DT4 / 4) nsplit = DT4 / 4;

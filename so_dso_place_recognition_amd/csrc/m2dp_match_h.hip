@@ -11,6 +11,8 @@
 // A workgroup (4 waves) owns 4 query tiles (32 queries) resident in LDS (96 KB) and sweeps the DB 8 tiles at a time; each
 // wave computes all 4 query tiles x its own 2 DB tiles per step (24 MFMAs per K-step and 4 DB operand loads: half the
 // L1 traffic per MFMA of a 2x2 wave tile), DB operands straight from L2/L1 into VGPRs.
+#include <cstdlib>
+
 #include "kernels.hpp"
 
 namespace pr {
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(256) void m2dp_pack_h_kernel(const T* __restrict__ 
 
 struct HL { u32x4 h, l; };
 
+template <int QTB>   // query tiles per workgroup: 4 (96 KB of LDS: one workgroup per CU) or 3 (72 KB: two, their epilogues and request stalls overlap)
 __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __restrict__ qpk, const u32x4* __restrict__ dpk,
                                                               float* __restrict__ dist_p, float* __restrict__ dist_i,
                                                               int m, int n, int QT, int DT, int nsplit) {
@@ -51,20 +54,21 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
   int b = blockIdx.x;
   const int split = b % nsplit;
   b /= nsplit;
-  const int ch = b & 1, qt4 = b >> 1;               // 4 query tiles per workgroup
+  const int ch = b & 1, qt4 = b >> 1;               // QTB query tiles per workgroup
+  if (qt4 * QTB * 8 >= m) return;                   // padding tiles only (the query tile count is rounded up to a multiple of 12)
   const int DT8 = (DT + 7) / 8;                     // DB swept in steps of 8 tiles (2 per wave)
   const int s0 = (int)((long long)DT8 * split / nsplit), s1 = (int)((long long)DT8 * (split + 1) / nsplit);
   {
-    const u32x4* src = qpk + ((size_t)ch * QT + (size_t)qt4 * 4) * TV;
-    for (int i = tid; i < 4 * TV; i += 256) ldsv[i] = src[i];
+    const u32x4* src = qpk + ((size_t)ch * QT + (size_t)qt4 * QTB) * TV;
+    for (int i = tid; i < QTB * TV; i += 256) ldsv[i] = src[i];
   }
   __syncthreads();
   const u32x4* la = ldsv + lane;
   float* dist = ch ? dist_i : dist_p;
   // distances of this workgroup's 32 query rows: invalid rows fall outside the descriptor's range
-  const int qrow0 = qt4 * 32;
+  const int qrow0 = qt4 * QTB * 8;
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
-      dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 32 ? m - qrow0 : 32) : 0) * n * 4, 0x00020000);
+      dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < QTB * 8 ? m - qrow0 : QTB * 8) : 0) * n * 4, 0x00020000);
   const unsigned st_lane = (unsigned)((2 * (lane & 3) + (lane >> 5)) * n + ((lane & 31) >> 2)) * 4u;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (s0 >= s1) return;
@@ -75,18 +79,18 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
   const u32x4* pb = dpk + ((size_t)ch * DT + (size_t)s0 * 8 + w * 2) * TV + lane;
   struct BSet { HL b0, b1; };
   BSet bs[3];               // K-steps st, st + 1, st + 2 (period 3 divides the 12 K-steps of a sweep step)
-  HL a[4];                  // the 4 query tiles of the current K-step; tile t is reloaded for the next K-step behind its own MFMAs
+  HL a[QTB];                // the 4 query tiles of the current K-step; tile t is reloaded for the next K-step behind its own MFMAs
 #define LDB(dst, p, st) { dst.b0.h = (p)[(st) * 128]; dst.b0.l = (p)[(st) * 128 + 64]; dst.b1.h = (p)[TV + (st) * 128]; dst.b1.l = (p)[TV + (st) * 128 + 64]; }
 #define LDA1(t, st) { a[t].h = la[(t) * TV + (st) * 128]; a[t].l = la[(t) * TV + (st) * 128 + 64]; }
 #define MF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
   LDB(bs[0], pb, 0)
   LDB(bs[1], pb, 1)
 #pragma unroll
-  for (int t = 0; t < 4; t++) LDA1(t, 0)
+  for (int t = 0; t < QTB; t++) LDA1(t, 0)
   for (int s = s0; s < s1; s++) {
     const int dt0 = s * 8 + w * 2;
     const u32x4* pn = pb + 8 * TV;           // same wave column, next sweep step
-    f32x16 acc[4][2];
+    f32x16 acc[QTB][2];
 #define SBAR() __builtin_amdgcn_sched_barrier(0)
 #pragma unroll
     for (int st = 0; st < 12; st++) {
@@ -99,11 +103,12 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
       const u32x4* pq = (st + 2 < 12) ? pb + (st + 2) * 128 : pn + (st + 2 - 12) * 128;
       const bool first = st == 0;
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
+      for (int t = 0; t < QTB; t++) {
         SBAR();
         acc[t][0] = MF(a[t].h, c.b0.h, first ? zero : acc[t][0]);
         SBAR();
         if (t == 0) nx.b0.h = pq[0]; else if (t == 1) nx.b0.l = pq[64]; else if (t == 2) nx.b1.h = pq[TV]; else nx.b1.l = pq[TV + 64];
+        if (QTB == 3 && t == 2) { SBAR(); nx.b1.l = pq[TV + 64]; }
         SBAR();
         acc[t][1] = MF(a[t].h, c.b1.h, first ? zero : acc[t][1]);
         acc[t][0] = MF(a[t].h, c.b0.l, acc[t][0]);
@@ -128,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
     // After the quad reduction all four lanes of a quad hold the block maximum, so lane (lane & 3) = gq keeps the value
     // of query pair gq: ONE store per (query tile, DB tile) with all 64 lanes active instead of four with 16.
 #pragma unroll
-    for (int i = 0; i < 4; i++)
+    for (int i = 0; i < QTB; i++)
 #pragma unroll
       for (int j = 0; j < 2; j++) {
         float sel = 0.f;
@@ -163,14 +168,27 @@ void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, vo
 
 void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i) {
   if (m <= 0 || n <= 0) return;
-  const int QT = ((m2_tiles(m) + 3) / 4) * 4, DT = m2_tiles(n);
-  const int base = (QT / 4) * 2, DT8 = (DT + 7) / 8;
-  int nsplit = (1024 + base - 1) / base;
+  const int QT = m2_qtiles(m), DT = m2_tiles(n);
+  // 4 query tiles per workgroup; PR_M2_QTB=3 selects the two-workgroups-per-CU variant for A/B runs (measured 6.4 ms against
+  // 5.55 ms at 4096 x 50k: the overlap of two workgroups does not pay for a third more DB operand traffic per MFMA)
+  static const int qtb = (getenv("PR_M2_QTB") && atoi(getenv("PR_M2_QTB")) == 3) ? 3 : 4;
+  const int base = (QT / qtb) * 2, DT8 = (DT + 7) / 8;
+  // DB ranges per query block: enough workgroups for ~4 rounds, and among the next few counts the one that wastes the
+  // least of its last round (the workgroups that hold padding tiles only return at once and do not count)
+  const int real = ((m + qtb * 8 - 1) / (qtb * 8)) * 2, slots = 256 * (qtb == 3 ? 2 : 1);
+  int ns0 = (1024 + real - 1) / real, nsplit = ns0;
+  double best = 0.0;
+  for (int ns = ns0; ns < ns0 + 12; ns++) {
+    const long long blocks = (long long)real * ns, rounds = (blocks + slots - 1) / slots;
+    const double util = (double)blocks / (double)(rounds * slots);
+    if (util > best + 1e-9) { best = util; nsplit = ns; }
+  }
   if (nsplit > DT8 / 4) nsplit = DT8 / 4;
   if (nsplit < 1) nsplit = 1;
-  const size_t lds = (size_t)4 * TB;
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(m2dp_match_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(m2dp_match_h_kernel, dim3(base * nsplit), dim3(256), lds, st, static_cast<const u32x4*>(qpk),
+  const size_t lds = (size_t)qtb * TB;
+  auto* k = qtb == 4 ? m2dp_match_h_kernel<4> : m2dp_match_h_kernel<3>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k, dim3(base * nsplit), dim3(256), lds, st, static_cast<const u32x4*>(qpk),
                      static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
 }
 

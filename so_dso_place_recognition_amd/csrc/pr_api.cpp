@@ -85,7 +85,7 @@ size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups, int sc_m
     *groups = pr::sc_dgroups(max_sigs);
     return (size_t)2 * *groups * pr::SC_DIMG + 16 * pr::SC_DSTEP;  // + zero tail of 8 slots read past the last group (sc_match.hip)
   }
-  if (role == PR_ROLE_QUERY) { *groups = ((pr::m2_tiles(max_sigs) + 3) / 4) * 4; return (size_t)2 * *groups * pr::M2_TILE; }
+  if (role == PR_ROLE_QUERY) { *groups = pr::m2_qtiles(max_sigs); return (size_t)2 * *groups * pr::M2_TILE; }
   *groups = pr::m2_tiles(max_sigs);
   return (size_t)(2 * *groups + 16) * pr::M2_TILE;                 // + tail tiles read by the last sweep step (8 tiles per step + prefetch)
 }
