@@ -333,6 +333,25 @@ def test_fused_sc_m2dp_scoring_vs_oracle(api):
         assert (idx[same, 0] == planted[same]).all()
 
 
+def test_plain_matchers_size_independent_properties(api):
+    """DELIGHT / GIST / BoW at a size the oracle would not finish quickly: self-distance matrices are symmetric (the octant
+    permutations are involutions; L2 and L1 scores are symmetric) with a zero diagonal, and every row's top-1 under a
+    1-wide mask is never the row itself."""
+    rng = np.random.default_rng(9)
+    n = 1500
+    h = rng.poisson(3.0, size=(16 * n, 256)).astype(np.float64)
+    d = api.processDELIGHT(h, h)
+    assert d.shape == (n, n) and np.abs(d - d.T).max() < 1e-5 * d.max() and np.abs(np.diag(d)).max() < 1e-6
+    g = synth.gist_signatures(10, n, 200)
+    d = api.processGIST(g, g)
+    assert np.abs(d - d.T).max() <= 1e-6 * d.max() and np.abs(np.diag(d)).max() == 0.0
+    b = synth.bow_signatures(11, 600, cols=200, vocab=2000, fill=(40, 150))
+    d = api.processBoW(b, b)
+    assert np.abs(d - d.T).max() < 1e-6 and np.abs(np.diag(d)).max() < 1e-6
+    idx, sc = api.match_topk("bow", b, b, mask_width=1, k=1)
+    assert (idx[:, 0] != np.arange(600)).all()
+
+
 def test_sigset_capacity_limit_is_an_error_not_an_overflow(api):
     import ctypes as C
     from so_dso_place_recognition_amd import _lib
