@@ -120,6 +120,58 @@ class Matcher:
         return self._bufs["d_p"], self._bufs.get("d_i")
 
 
+class FusedMatcher:
+    """BASELINE.json config 5 ("fused SC + M2DP scoring", build-defined: DESIGN.md §7): an SC and an M2DP matcher over the
+    same places; the four row z-scores are added (weights p, 1, p, 1) in ONE top-k pass (pr_fuse_select2_dev).  Shards like
+    Matcher: the moments of both descriptor types travel in the same all_gather ([m, 4, 3] f64 per rank)."""
+
+    def __init__(self, max_queries: int, max_db: int, ctx: Context | None = None, device: int | None = None):
+        self.sc = Matcher("sc", max_queries, max_db, ctx, device)
+        self.m2 = Matcher("m2dp", max_queries, max_db, self.sc.ctx)
+        self.ctx, self.dev, self.lib = self.sc.ctx, self.sc.dev, self.sc.lib
+
+    def close(self):
+        self.sc.close(); self.m2.close()
+
+    def pack_database(self, sc_sig: torch.Tensor, m2dp_sig: torch.Tensor):
+        self.sc.pack_database(sc_sig); self.m2.pack_database(m2dp_sig)
+        assert self.sc.n == self.m2.n, "the two databases must describe the same places"
+
+    def match(self, sc_queries: torch.Tensor, m2dp_queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
+              db_row0: int = 0, q_row0: int = 0, group=None):
+        import torch.distributed as dist
+        torch.cuda.current_stream(self.dev).synchronize()
+        m = self.sc._pack(self.sc.q, sc_queries)
+        assert self.m2._pack(self.m2.q, m2dp_queries) == m
+        n = self.sc.n
+        G = dist.get_world_size(group) if (group is not None or (dist.is_available() and dist.is_initialized())) else 1
+        lib, h = self.lib, self.ctx.h
+        d = [self.sc._buf("d_p", (m, n), torch.float32), self.sc._buf("d_i", (m, n), torch.float32),
+             self.m2._buf("d_p", (m, n), torch.float32), self.m2._buf("d_i", (m, n), torch.float32)]
+        mom = [self.sc._buf("mom", (m, 2, 3), torch.float64), self.m2._buf("mom", (m, 2, 3), torch.float64)]
+        idx = self.sc._buf("idx", (m, k), torch.int32)
+        score = self.sc._buf("score", (m, k), torch.float32)
+        self.ctx.check(lib.pr_distances_dev(h, self.sc.q, self.sc.db, _dptr(d[0]), _dptr(d[1])))
+        self.ctx.check(lib.pr_distances_dev(h, self.m2.q, self.m2.db, _dptr(d[2]), _dptr(d[3])))
+
+        def local_moments():
+            self.ctx.check(lib.pr_row_moments_dev(h, _dptr(d[0]), _dptr(d[1]), m, n, _dptr(mom[0])))
+            self.ctx.check(lib.pr_row_moments_dev(h, _dptr(d[2]), _dptr(d[3]), m, n, _dptr(mom[1])))
+            self.ctx.sync()
+            return torch.cat(mom, dim=1)                                   # [m, 4, 3]
+
+        def local_select(mom_all, G_):
+            mom_all = mom_all.reshape(G_, m, 4, 3)
+            m1, m2 = mom_all[:, :, :2].contiguous(), mom_all[:, :, 2:].contiguous()
+            torch.cuda.current_stream(self.dev).synchronize()
+            self.ctx.check(lib.pr_fuse_select2_dev(h, _dptr(d[0]), _dptr(d[1]), _dptr(d[2]), _dptr(d[3]), m, n, _dptr(m1), _dptr(m2), G_,
+                                                   q_row0, db_row0, int(mask_width), float(p_weight), int(k), _dptr(idx), _dptr(score)))
+            self.ctx.sync()
+            return idx, score
+
+        return sharded_topk(local_moments, local_select, k, group if G > 1 else None, G)
+
+
 def sharded_topk(local_moments, local_select, k: int, group, G: int):
     """The exchange protocol of SURVEY.md §8-e around two local callables (HIP in production; a numpy stand-in in
     the gloo CPU tests): moments -> all_gather -> select with the moments of all shards -> all_gather -> merge."""

@@ -352,6 +352,45 @@ def test_plain_matchers_size_independent_properties(api):
     assert (idx[:, 0] != np.arange(600)).all()
 
 
+def test_fused_matcher_device_path_and_two_shards(api):
+    """FusedMatcher (config 5 on device-resident signatures): one rank == the host API; and the sharded arithmetic - the DB
+    split in two, per-shard moments stacked in rank order, per-shard top-k with GLOBAL indices, k-way merge - gives the same
+    top-k as the unsharded run (what two ranks would compute, without the processes)."""
+    import torch
+    from so_dso_place_recognition_amd.matcher import FusedMatcher, merge_topk, _dptr
+    n, m, k, mask = 301, 37, 3, 2
+    sdb = synth.sc_database(81, n); sq, _ = synth.sc_queries(82, sdb, m)
+    mdb = synth.m2dp_database(83, n); mq, _ = synth.m2dp_queries(84, mdb, m)
+    want_idx, want_sc = api.match_topk_fused(sq, mq, sdb, mdb, mask_width=mask, k=k)
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    fm = FusedMatcher(m, n)
+    fm.pack_database(t(sdb), t(mdb))
+    idx, sc = fm.match(t(sq), t(mq), mask, 2.0, k)
+    assert np.array_equal(idx.cpu().numpy(), want_idx) and np.abs(sc.cpu().numpy() - want_sc).max() < 1e-5
+    fm.close()
+    cut = 160                                                            # shard 0: rows [0, 160), shard 1: [160, 301)
+    parts, moms = [], []
+    for lo, hi in ((0, cut), (cut, n)):
+        f = FusedMatcher(m, hi - lo)
+        f.pack_database(t(sdb[lo:hi]), t(mdb[4 * lo:4 * hi]))
+        grabbed = {}
+        import so_dso_place_recognition_amd.matcher as M
+        orig = M.sharded_topk
+        M.sharded_topk = lambda lm, ls, k_, group, G: grabbed.update(lm=lm, ls=ls) or (None, None)
+        try:
+            f.match(t(sq), t(mq), mask, 2.0, k, db_row0=lo)
+        finally:
+            M.sharded_topk = orig
+        parts.append((f, grabbed)); moms.append(grabbed["lm"]().clone())
+    mom_all = torch.stack(moms)                                          # [2, m, 4, 3] in rank order
+    outs = [g["ls"](mom_all, 2) for f, g in parts]
+    idx2, sc2 = merge_topk(torch.stack([o[0].clone() for o in outs]), torch.stack([o[1].clone() for o in outs]), k)
+    assert np.array_equal(idx2.cpu().numpy(), want_idx) and np.abs(sc2.cpu().numpy() - want_sc).max() < 1e-5
+    for f, g in parts:
+        f.close()
+
+
 def test_sigset_capacity_limit_is_an_error_not_an_overflow(api):
     import ctypes as C
     from so_dso_place_recognition_amd import _lib
