@@ -111,7 +111,9 @@ def main():
     gen_s = time.time() - t0
 
     from so_dso_place_recognition_amd.api import Context
-    mt = Matcher("sc", m, hi - lo, ctx=Context(local, sc_arith=args.sc_arith))
+    # the library context lives on torch's current stream: its kernels, torch's buffers and RCCL's collectives are ordered by
+    # the stream, a step has no host synchronisation (pr_create_on_stream)
+    mt = Matcher("sc", m, hi - lo, ctx=Context(local, sc_arith=args.sc_arith, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
     arith = mt.ctx.sc_arith
     ev = HipEvents()
     e0, e1 = ev.create(), ev.create()

@@ -29,6 +29,11 @@ enum { PR_HOST = 0, PR_DEVICE = 1 };
 /* arithmetic of the SC and M2DP matchers (processSC.m:22-33, processM2DP.m:12-22 on the GPU): split-f16 (fp32 operands carried
  * as f16 hi + lo, three f16 MFMAs per product, fp32 accumulate; default, 2-3x faster, same 1e-7 error as fp32) or plain fp32 MFMA */
 enum { PR_SC_ARITH_F16X2 = 0, PR_SC_ARITH_F32 = 1 };
+/* What a zero-norm SC row does.  MATLAB divides 0/0 (processSC.m:16,19): every distance to or from that signature is NaN, and
+ * normalize(.,2) / min (run_test.m:40,57) leave NaNs out [normalize's 'omitnan' from memory], so the signature simply never matches.
+ * PR_NAN_EXCLUDE (default) does exactly that and reports PR_WARN_NAN_ROWS; PR_NAN_FAIL turns it into the error PR_ENAN at pr_sync. */
+enum { PR_NAN_EXCLUDE = 0, PR_NAN_FAIL = 1 };
+enum { PR_WARN_NAN_ROWS = 1, PR_WARN_M2DP_SVD = 2 };   /* bits of pr_take_warnings */
 
 #define PR_SC_SIG_LEN 2400    /* 2 x numS*numR = 2 x 60*20, SC/SC.h:7-8, test_sc.cpp:37-38 */
 #define PR_M2DP_SIG_LEN 384   /* 2 x (numP*numQ + numS*numR) = 2 x 192, M2DP/M2DP.h:7-10, test_m2dp.cpp:37-39 */
@@ -36,6 +41,10 @@ enum { PR_SC_ARITH_F16X2 = 0, PR_SC_ARITH_F32 = 1 };
 
 /* ---- context ------------------------------------------------------------------------------------ */
 int pr_create(int device_id, pr_ctx** out);
+/* The same on a stream the CALLER owns (a hipStream_t, e.g. the stream a torch / RCCL process group enqueues on): every kernel of
+ * the context is ordered with the caller's work on that stream, no host synchronisation is needed between the library's phases and
+ * the caller's collectives (SURVEY.md §8-e "issue A and B on the compute stream").  The stream must outlive the context. */
+int pr_create_on_stream(int device_id, void* hip_stream, pr_ctx** out);
 void pr_destroy(pr_ctx* ctx);
 const char* pr_last_error(const pr_ctx* ctx);        /* valid until the next call on ctx; ctx may be NULL */
 const char* pr_version(void);
@@ -45,6 +54,9 @@ const char* pr_version(void);
 int pr_set_sc_arith(pr_ctx* ctx, int arith);
 int pr_get_sc_arith(const pr_ctx* ctx);
 int pr_sync(pr_ctx* ctx);                            /* waits for the context's stream; reports deferred errors */
+int pr_set_nan_policy(pr_ctx* ctx, int policy);      /* PR_NAN_EXCLUDE | PR_NAN_FAIL */
+int pr_get_nan_policy(const pr_ctx* ctx);
+int pr_take_warnings(pr_ctx* ctx);                   /* PR_WARN_* bits raised since the last call (synchronises the stream), then cleared */
 void* pr_stream(pr_ctx* ctx);                        /* the context's hipStream_t (for event timing by the caller) */
 
 /* ---- host-buffer entry points = the reference's own call boundary --------------------------------- */
@@ -83,6 +95,11 @@ int pr_m2dp_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2,
  * score = the chi-square distance, h1[16m][256], h2[16n][256], p_weight ignored. */
 int pr_match_topk(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n,
                   int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score);
+/* The same with the scores as the reference holds them (MATLAB double, run_test.m:57 `diff_v`).  For SC and M2DP both variants
+ * re-evaluate the k + 8 best pairs of the fp32 all-pairs pass in fp64 from the raw signatures (pr_rerank_dev): indices and scores
+ * are those of the reference's double arithmetic given the row statistics (see DESIGN.md for the error of those). */
+int pr_match_topk_f64(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n,
+                      int32_t mask_width, double p_weight, int32_t k, int32_t* idx, double* score);
 
 /* The two remaining `type`s of run_test.m:32-35, whose signatures have no fixed length (`cols` columns per row):
  *   gist: h [m][cols];            dist(i,j) = sum_c (h1[i,c] - h2[j,c])^2                    (processGIST.m:1-10)
@@ -100,6 +117,8 @@ int pr_match_topk_cols(pr_ctx* ctx, int type, const double* h1, int32_t m, const
  * pr_fuse_select2_dev is the device-level step (two channel pairs over the same grid, moments as pr_row_moments_dev). */
 int pr_match_topk_fused(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32_t m, const double* sc2, const double* m2dp2,
                         int32_t n, int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score);
+int pr_match_topk_fused_f64(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32_t m, const double* sc2, const double* m2dp2,
+                            int32_t n, int32_t mask_width, double p_weight, int32_t k, int32_t* idx, double* score);
 int pr_fuse_select2_dev(pr_ctx* ctx, const float* d_p, const float* d_i, const float* e_p, const float* e_i, int32_t m, int32_t n,
                         const double* mom_all, const double* mom2_all, int32_t G, int32_t q_row0, int32_t db_row0,
                         int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score);
@@ -130,6 +149,21 @@ int pr_row_moments_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
 int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n,
                        const double* mom_all, int32_t G, int32_t q_row0, int32_t db_row0, int32_t mask_width,
                        double p_weight, int32_t k, int32_t* idx, float* score);
+
+/* fp64 re-evaluation of the survivors of pr_fuse_select_dev (run with k_in = k + 8): for every (query, idx_in entry of THIS shard)
+ * the distances of the pair again from the RAW signatures in fp64, in the reference's own formulation (processSC.m:15-33: rows / L2
+ * norm, 120 shifted / mirrored variants, (1 - dot)/2, min; processM2DP.m:12-22), the fused score of run_test.m:40 with the combined
+ * moments, then the k best by (score, index) (run_test.m:57).  q_sc/db_sc: DEVICE [m][2400] / [n_local][2400] or NULL; q_m2/db_m2:
+ * DEVICE [4m][384] / [4 n_local][384] or NULL (both pairs given = BASELINE config 5's sum of four z-scores); dtype PR_F64 | PR_F32;
+ * mom_sc / mom_m2: DEVICE [G][m][2][3] as pr_row_moments_dev writes them.  idx_in: DEVICE [m][k_in] global indices inside
+ * [db_row0, db_row0 + n_local) or -1.  idx: DEVICE [m][k], score: DEVICE f64 [m][k].  k_in <= 128. */
+int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
+                  const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
+                  int32_t mask_width, double p_weight, int32_t k_in, const int32_t* idx_in, int32_t k, int32_t* idx, double* score);
+/* k-way merge of the per-shard results of G shards (SURVEY.md §8-e collective B's second half): idx_all DEVICE [G][m][k],
+ * score_all DEVICE f64 [G][m][k] -> idx [m][k], score [m][k] by (score, global index); -1 / NaN entries last.  G * k <= 128. */
+int pr_merge_topk_dev(pr_ctx* ctx, const int32_t* idx_all, const double* score_all, int32_t G, int32_t m, int32_t k,
+                      int32_t* idx, double* score);
 
 /* Device-buffer variants of the generators (same layouts as the host versions, pointers in HBM). */
 int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
@@ -174,6 +208,13 @@ int pr_read_signatures_bin(const char* path, double** out, int64_t* rows, int64_
 /* PosesPts.h:12-24 / :36-39 record writers (the producer side, OutputWrapperSODSO.cpp:24-31). */
 int pr_write_poses(const char* path, const int32_t* ids, const double* w2c, int64_t n);
 int pr_write_points(const char* path, const int32_t* ids, const double* xyz, const float* inten, int64_t n);
+/* Replaces the evaluation half of run_test(type, hist1, hist2, gt1, gt2, loop_diff, mask_width) (match_signatures/run_test.m:3-22 ground-truth
+ * loop pairs, :58-85 precision / recall sweep): diff_v / diff_idx [m] = the per-query best score and 0-based index (run_test.m:57),
+ * gt1 [m][cols], gt2 [n][cols] positions.  auc = trapz(recall, precision), top_recall = recall at the last 100 %-precision point,
+ * lp_detected (optional) [m][2] receives the *n_detected pairs (query, match) of that prefix. */
+int pr_precision_recall(const double* diff_v, const int32_t* diff_idx, int32_t m, const double* gt1, const double* gt2, int32_t n,
+                        int32_t cols, double loop_diff, int32_t mask_width, double* auc, double* top_recall, int32_t* lp_detected,
+                        int32_t* n_detected);
 const char* pr_host_last_error(void);
 
 #ifdef __cplusplus

@@ -384,12 +384,17 @@ void fuse_topk(const double* dp, const double* di, int m, int n, int mask_width,
 #pragma omp parallel for schedule(static)
   for (int i = 0; i < m; i++) {
     const double* a = dp + (size_t)i * n; const double* b = di + (size_t)i * n;
-    double ma = 0, mb = 0;
-    for (int j = 0; j < n; j++) { ma += a[j]; mb += b[j]; }
-    ma /= n; mb /= n;
+    // MATLAB normalize(.,2) = (x - mean)/std with N-1, both computed with 'omitnan' [from memory: normalize.m]: NaN
+    // distances (a zero-norm signature, processSC.m:16,19) stay NaN themselves but do not poison the row
+    double ma = 0, mb = 0; int na = 0, nb = 0;
+    for (int j = 0; j < n; j++) { if (!std::isnan(a[j])) { ma += a[j]; na++; } if (!std::isnan(b[j])) { mb += b[j]; nb++; } }
+    ma /= na; mb /= nb;
     double va = 0, vb = 0;
-    for (int j = 0; j < n; j++) { va += (a[j] - ma) * (a[j] - ma); vb += (b[j] - mb) * (b[j] - mb); }
-    double sa = std::sqrt(va / (n - 1)), sb = std::sqrt(vb / (n - 1));
+    for (int j = 0; j < n; j++) {
+      if (!std::isnan(a[j])) va += (a[j] - ma) * (a[j] - ma);
+      if (!std::isnan(b[j])) vb += (b[j] - mb) * (b[j] - mb);
+    }
+    double sa = std::sqrt(va / (na - 1)), sb = std::sqrt(vb / (nb - 1));
     std::vector<double> f(n);
     for (int j = 0; j < n; j++) {
       f[j] = p_weight * ((a[j] - ma) / sa) + (b[j] - mb) / sb;                    // :40
@@ -685,8 +690,9 @@ int pr_ref_match_topk(int type, const double* h1, int32_t m, const double* h2, i
   std::vector<double> dp((size_t)m * n), di((size_t)m * n);
   int rc = type == 0 ? pr_ref_sc_distance(h1, m, h2, n, dp.data(), di.data())
                      : pr_ref_m2dp_distance(h1, m, h2, n, dp.data(), di.data());
-  if (rc) return rc;
-  return pr_ref_fuse_topk(dp.data(), di.data(), m, n, mask_width, p_weight, k, idx, score);
+  if (rc && rc != PR_REF_ENAN) return rc;              // ENAN: the NaN rows / columns are in dp / di, as in MATLAB
+  const int rc2 = pr_ref_fuse_topk(dp.data(), di.data(), m, n, mask_width, p_weight, k, idx, score);
+  return rc2 ? rc2 : rc;
 }
 
 // BASELINE.json config 5 ("fused SC + M2DP scoring"), which has NO reference counterpart (run_test.m handles one type per
@@ -699,18 +705,18 @@ int pr_ref_match_topk_fused(const double* sc1, const double* m2dp1, int32_t m, c
   std::vector<double> d[4];
   for (auto& v : d) v.resize(mn);
   int rc = pr_ref_sc_distance(sc1, m, sc2, n, d[0].data(), d[1].data());
-  if (!rc) rc = pr_ref_m2dp_distance(m2dp1, m, m2dp2, n, d[2].data(), d[3].data());
-  if (rc) return rc;
+  if (!rc || rc == PR_REF_ENAN) { const int r2 = pr_ref_m2dp_distance(m2dp1, m, m2dp2, n, d[2].data(), d[3].data()); if (r2) rc = r2; }
+  if (rc && rc != PR_REF_ENAN) return rc;
   std::vector<double> f(mn, 0.0);
   for (int c = 0; c < 4; c++)
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < m; i++) {
       const double* a = d[c].data() + (size_t)i * n;
-      double mu = 0, va = 0;
-      for (int j = 0; j < n; j++) mu += a[j];
-      mu /= n;
-      for (int j = 0; j < n; j++) va += (a[j] - mu) * (a[j] - mu);
-      const double sd = std::sqrt(va / (n - 1)), wt = (c % 2 == 0) ? p_weight : 1.0;
+      double mu = 0, va = 0; int cnt = 0;
+      for (int j = 0; j < n; j++) if (!std::isnan(a[j])) { mu += a[j]; cnt++; }
+      mu /= cnt;
+      for (int j = 0; j < n; j++) if (!std::isnan(a[j])) va += (a[j] - mu) * (a[j] - mu);
+      const double sd = std::sqrt(va / (cnt - 1)), wt = (c % 2 == 0) ? p_weight : 1.0;
       for (int j = 0; j < n; j++) f[(size_t)i * n + j] += wt * ((a[j] - mu) / sd);
     }
   return pr_ref_select_topk(f.data(), m, n, mask_width, k, idx, score);

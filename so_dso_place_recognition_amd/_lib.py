@@ -11,6 +11,8 @@ import os
 PR_OK, PR_EINVAL, PR_ENOMEM, PR_EHIP, PR_EIO, PR_ENAN = 0, -1, -2, -3, -4, -5
 TYPE_SC, TYPE_M2DP, TYPE_DELIGHT, TYPE_GIST, TYPE_BOW = 0, 1, 2, 3, 4
 SC_ARITH_F16X2, SC_ARITH_F32 = 0, 1
+NAN_EXCLUDE, NAN_FAIL = 0, 1
+WARN_NAN_ROWS, WARN_M2DP_SVD = 1, 2
 ROLE_QUERY, ROLE_DB = 0, 1
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
@@ -22,6 +24,15 @@ LIB_PATH = os.environ.get("PR_AMD_LIB") or os.path.join(_HERE, "libpr_amd.so")  
 _vp, _i32, _dbl = C.c_void_p, C.c_int32, C.c_double
 SYMBOLS = {
     "pr_create": (C.c_int, [C.c_int, C.POINTER(_vp)]),
+    "pr_create_on_stream": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
+    "pr_set_nan_policy": (C.c_int, [_vp, C.c_int]),
+    "pr_get_nan_policy": (C.c_int, [_vp]),
+    "pr_take_warnings": (C.c_int, [_vp]),
+    "pr_match_topk_f64": (C.c_int, [_vp, C.c_int, _vp, _i32, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
+    "pr_match_topk_fused_f64": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
+    "pr_rerank_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _i32, _vp,
+                                _i32, _vp, _vp]),
+    "pr_merge_topk_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "pr_destroy": (None, [_vp]),
     "pr_last_error": (C.c_char_p, [_vp]),
     "pr_version": (C.c_char_p, []),
@@ -69,6 +80,8 @@ SYMBOLS = {
     "pr_read_signatures_bin": (C.c_int, [C.c_char_p, C.POINTER(_vp), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "pr_write_poses": (C.c_int, [C.c_char_p, _vp, _vp, C.c_int64]),
     "pr_write_points": (C.c_int, [C.c_char_p, _vp, _vp, _vp, C.c_int64]),
+    "pr_precision_recall": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _i32, _dbl, _i32, C.POINTER(_dbl), C.POINTER(_dbl), _vp,
+                                      C.POINTER(_i32)]),
     "pr_host_last_error": (C.c_char_p, []),
 }
 

@@ -23,17 +23,29 @@ def _ptr(a):
 class Context:
     """One HIP device + stream (pr_ctx)."""
 
-    def __init__(self, device: int = 0, sc_arith: str | None = None):
-        """sc_arith: None (library default: "f16x2", or PR_SC_MATCH=f32 from the environment), "f16x2" or "f32"."""
+    def __init__(self, device: int = 0, sc_arith: str | None = None, stream: int | None = None, nan_policy: str | None = None):
+        """sc_arith: None (library default: "f16x2", or PR_SC_MATCH=f32 from the environment), "f16x2" or "f32".
+        stream: a hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream; 0 = the null stream): the
+        context's kernels are enqueued there (pr_create_on_stream).  nan_policy: "exclude" (default, MATLAB's behaviour for
+        zero-norm SC rows) or "fail" (PR_ENAN)."""
         self.lib = _lib.load()
         h = C.c_void_p()
-        rc = self.lib.pr_create(device, C.byref(h))
+        if stream is None:
+            rc = self.lib.pr_create(device, C.byref(h))
+        else:
+            rc = self.lib.pr_create_on_stream(device, C.c_void_p(stream), C.byref(h))
         if rc != 0:
             raise PRError(rc, self.lib.pr_last_error(None).decode())
         self.h = h
         self.device = device
         if sc_arith is not None:
             self.check(self.lib.pr_set_sc_arith(h, {"f16x2": _lib.SC_ARITH_F16X2, "f32": _lib.SC_ARITH_F32}[sc_arith]))
+        if nan_policy is not None:
+            self.check(self.lib.pr_set_nan_policy(h, {"exclude": _lib.NAN_EXCLUDE, "fail": _lib.NAN_FAIL}[nan_policy]))
+
+    def take_warnings(self) -> int:
+        """PR_WARN_* bits raised since the last call (1: zero-norm SC rows excluded, 2: an M2DP singular pair did not converge)."""
+        return int(self.lib.pr_take_warnings(self.h))
 
     @property
     def sc_arith(self) -> str:
@@ -226,7 +238,8 @@ def processBoW(hist1, hist2, ctx: Context | None = None):
 
 
 def match_topk(type_, hist1, hist2, mask_width=0, p_weight=2.0, k=1, ctx: Context | None = None):
-    """run_test.m:26-57 generalised to top-k: returns (idx int32 [m,k] 0-based, score float32 [m,k])."""
+    """run_test.m:26-57 generalised to top-k: returns (idx int32 [m,k] 0-based, score float64 [m,k] as MATLAB holds it;
+    float32 for gist / bow, whose distances are a single fp32 matrix)."""
     ctx = ctx or default_context()
     t = {"sc": TYPE_SC, "m2dp": TYPE_M2DP, "delight": TYPE_DELIGHT, "gist": TYPE_GIST, "bow": TYPE_BOW}.get(type_, type_)
     if t in (TYPE_GIST, TYPE_BOW):
@@ -243,27 +256,29 @@ def match_topk(type_, hist1, hist2, mask_width=0, p_weight=2.0, k=1, ctx: Contex
     div, width = {TYPE_SC: (1, 2400), TYPE_M2DP: (4, 384), TYPE_DELIGHT: (16, 256)}[t]
     h1 = np.ascontiguousarray(hist1, np.float64)
     h2 = np.ascontiguousarray(hist2, np.float64)
-    if h1.shape[1] != width or h2.shape[1] != width:
+    if h1.ndim != 2 or h2.ndim != 2 or h1.shape[1] != width or h2.shape[1] != width:
         raise ValueError(f"signature width must be {width}")
+    if h1.shape[0] % div or h2.shape[0] % div:
+        raise ValueError(f"signature matrices of this type hold {div} rows per signature")
     m, n = h1.shape[0] // div, h2.shape[0] // div
     idx = np.empty((m, k), np.int32)
-    sc = np.empty((m, k), np.float32)
-    ctx.check(ctx.lib.pr_match_topk(ctx.h, t, _ptr(h1), m, _ptr(h2), n, int(mask_width), float(p_weight), int(k),
-                                    _ptr(idx), _ptr(sc)))
+    sc = np.empty((m, k), np.float64)
+    ctx.check(ctx.lib.pr_match_topk_f64(ctx.h, t, _ptr(h1), m, _ptr(h2), n, int(mask_width), float(p_weight), int(k),
+                                        _ptr(idx), _ptr(sc)))
     return idx, sc
 
 
 def match_topk_fused(sc1, m2dp1, sc2, m2dp2, mask_width=0, p_weight=2.0, k=1, ctx: Context | None = None):
     """BASELINE config 5 (build-defined, no reference counterpart): SC [m, 2400] and M2DP [4 m, 384] signatures of the same
-    places scored together - the four row z-scores added with weights p, 1, p, 1.  Returns (idx int32 [m,k], score float32)."""
+    places scored together - the four row z-scores added with weights p, 1, p, 1.  Returns (idx int32 [m,k], score float64)."""
     ctx = ctx or default_context()
     a1 = np.ascontiguousarray(sc1, np.float64); a2 = np.ascontiguousarray(sc2, np.float64)
     b1 = np.ascontiguousarray(m2dp1, np.float64); b2 = np.ascontiguousarray(m2dp2, np.float64)
     m, n = a1.shape[0], a2.shape[0]
     if b1.shape != (4 * m, 384) or b2.shape != (4 * n, 384) or a1.shape[1] != 2400 or a2.shape[1] != 2400:
         raise ValueError("need SC [m, 2400] and M2DP [4 m, 384] signatures of the same m (n) places")
-    idx = np.empty((m, k), np.int32); sc = np.empty((m, k), np.float32)
-    ctx.check(ctx.lib.pr_match_topk_fused(ctx.h, _ptr(a1), _ptr(b1), m, _ptr(a2), _ptr(b2), n, int(mask_width), float(p_weight),
+    idx = np.empty((m, k), np.int32); sc = np.empty((m, k), np.float64)
+    ctx.check(ctx.lib.pr_match_topk_fused_f64(ctx.h, _ptr(a1), _ptr(b1), m, _ptr(a2), _ptr(b2), n, int(mask_width), float(p_weight),
                                           int(k), _ptr(idx), _ptr(sc)))
     return idx, sc
 

@@ -1,8 +1,10 @@
 // match_signatures — executable counterpart of match_signatures/run_test.m:25-57 (the reference runs it from MATLAB:
 // test_kitti.m:18-28).  Options mirror run_test's arguments:
 //   --type sc|m2dp|delight|gist|bow --hist1 F --hist2 F [--mask_width W=0] [--p_weight 2] [--topk K=1] [--one_based 0|1] --out F
+//   [--gt1 F --gt2 F --loop_diff L]   positions of the signatures (text matrices, one row per signature): the evaluation half of
+//                                     run_test (run_test.m:3-22, :58-85) - prints `AUC = ...` and `top_recall = ...`
 // Output: one line per query: K pairs "index score" (0-based indices unless --one_based 1), and the reference's
-// console lines `type` / `tm` (ms per query, run_test.m:42-44).
+// console lines `type` / `tm` (ms per query, run_test.m:42-44).  Scores are doubles, as MATLAB holds them.
 #include <chrono>
 #include <vector>
 
@@ -35,20 +37,44 @@ int main(int argc, char** argv) {
   if (c1 != width || c2 != width || r1 % div || r2 % div) { fprintf(stderr, "signature files must be [%d*m x %ld]\n", div, (long)width); return 2; }
   const int32_t m = (int32_t)(r1 / div), n = (int32_t)(r2 / div), k = (int32_t)prm.num("topk", 1);
   std::vector<int32_t> idx((size_t)m * k);
-  std::vector<float> score((size_t)m * k);
+  std::vector<double> score((size_t)m * k);
+  std::vector<float> score32;
   pr_ctx* ctx = nullptr;
   if (pr_create((int)prm.num("device", 0), &ctx) != PR_OK) { fprintf(stderr, "%s\n", pr_last_error(nullptr)); return 3; }
   const auto t0 = std::chrono::steady_clock::now();
-  const int rc = cols_type ? pr_match_topk_cols(ctx, t, h1, m, h2, n, (int32_t)width, (int32_t)prm.num("mask_width", 0), k, idx.data(), score.data())
-                           : pr_match_topk(ctx, t, h1, m, h2, n, (int32_t)prm.num("mask_width", 0), prm.num("p_weight", 2.0), k, idx.data(), score.data());
+  int rc;
+  if (cols_type) {
+    score32.resize(score.size());
+    rc = pr_match_topk_cols(ctx, t, h1, m, h2, n, (int32_t)width, (int32_t)prm.num("mask_width", 0), k, idx.data(), score32.data());
+    for (size_t i = 0; i < score.size(); i++) score[i] = (double)score32[i];
+  } else {
+    rc = pr_match_topk_f64(ctx, t, h1, m, h2, n, (int32_t)prm.num("mask_width", 0), prm.num("p_weight", 2.0), k, idx.data(), score.data());
+  }
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (rc != PR_OK) { fprintf(stderr, "match failed (%d): %s\n", rc, pr_last_error(ctx)); pr_destroy(ctx); return 4; }
   printf("type = %s\ntm = %g\n", type.c_str(), m ? 1000.0 * secs / m : 0.0);
+  if (pr_take_warnings(ctx) & PR_WARN_NAN_ROWS) printf("warning: zero-norm signature rows never match (NaN in MATLAB, processSC.m:16,19)\n");
+  std::string g1f, g2f;
+  if (prm.get("gt1", g1f) && prm.get("gt2", g2f)) {   // run_test.m:3-22, 58-85
+    double *g1 = nullptr, *g2 = nullptr;
+    int64_t gr1, gc1, gr2, gc2;
+    if (rd(g1f, &g1, &gr1, &gc1) != PR_OK || rd(g2f, &g2, &gr2, &gc2) != PR_OK) { fprintf(stderr, "%s\n", pr_host_last_error()); pr_destroy(ctx); return 2; }
+    if (gr1 != m || gr2 != n || gc1 != gc2) { fprintf(stderr, "gt files must hold one row per signature (%d / %d rows, same columns)\n", m, n); pr_destroy(ctx); return 2; }
+    std::vector<double> v((size_t)m);
+    std::vector<int32_t> bi((size_t)m);
+    for (int32_t i = 0; i < m; i++) { v[i] = score[(size_t)i * k]; bi[i] = idx[(size_t)i * k]; }
+    double auc = 0, tr = 0;
+    int32_t nd = 0;
+    if (pr_precision_recall(v.data(), bi.data(), m, g1, g2, n, (int32_t)gc1, prm.num("loop_diff", 10.0), (int32_t)prm.num("mask_width", 0), &auc, &tr,
+                            nullptr, &nd) != PR_OK) { fprintf(stderr, "%s\n", pr_host_last_error()); pr_destroy(ctx); return 4; }
+    printf("AUC = %.9g\ntop_recall = %.9g\nlp_detected = %d\n", auc, tr, nd);
+    pr_free(g1); pr_free(g2);
+  }
   FILE* f = fopen(outf.c_str(), "w");
   if (!f) { fprintf(stderr, "cannot write %s\n", outf.c_str()); pr_destroy(ctx); return 5; }
   const int base = prm.num("one_based", 0) != 0 ? 1 : 0;
   for (int32_t i = 0; i < m; i++) {
-    for (int32_t j = 0; j < k; j++) fprintf(f, "%s%d %.9g", j ? " " : "", idx[(size_t)i * k + j] < 0 ? -1 : idx[(size_t)i * k + j] + base, (double)score[(size_t)i * k + j]);
+    for (int32_t j = 0; j < k; j++) fprintf(f, "%s%d %.17g", j ? " " : "", idx[(size_t)i * k + j] < 0 ? -1 : idx[(size_t)i * k + j] + base, score[(size_t)i * k + j]);
     fputc('\n', f);
   }
   fclose(f);

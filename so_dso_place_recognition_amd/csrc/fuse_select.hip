@@ -37,9 +37,12 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restric
     // are fp32 in [0, 1], so with c inside the data range the M2 = S2 - S1^2/n cancellation costs < 1e-13 relative), fixed
     // reduction tree -> deterministic.
     const float* row = (ch ? d_i : d_p) + (size_t)q * n;
-    const double c = (double)row[0];
-    double s1 = 0.0, s2 = 0.0;
-    auto acc = [&](float v) { const double d = (double)v - c; s1 += d; s2 += d * d; };
+    const float r0 = row[0];
+    const double c = (r0 == r0) ? (double)r0 : 0.5;      // NaN first element: any pivot inside the data range will do
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    // NaN entries (distances to / from a zero-norm signature, processSC.m:16,19) are left out of the row statistics,
+    // as MATLAB's normalize(.,2) does (mean / std with 'omitnan') [from memory; the reference cannot be run here]
+    auto acc = [&](float v) { if (v == v) { const double d = (double)v - c; s1 += d; s2 += d * d; cnt += 1.0; } };
     // 16-byte loads over the aligned body of the row (4 of them in flight per thread), scalars on the ragged ends
     int head = (int)((4 - ((reinterpret_cast<size_t>(row) >> 2) & 3)) & 3);
     if (head > n) head = n;
@@ -58,25 +61,47 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restric
     for (int t = head + 4 * nv + tid; t < n; t += 256) acc(row[t]);
     const double S1 = block_sum(s1, red, tid);
     const double S2 = block_sum(s2, red, tid);
+    const double N = block_sum(cnt, red, tid);
     if (tid == 0) {
       double* o = mom + ((size_t)q * 2 + ch) * 3;
-      o[0] = (double)n;
-      o[1] = c + S1 / (double)n;
-      o[2] = S2 - S1 * S1 / (double)n;
+      o[0] = N;
+      o[1] = N > 0.0 ? c + S1 / N : 0.0;
+      o[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
     }
   }
 }
 
-struct Cand {
-  double v;
-  int j;
-};
 __device__ __forceinline__ bool cand_less(double av, int aj, double bv, int bj) {   // (a) < (b) lexicographic
   return av < bv || (av == bv && aj < bj);
 }
 
+// argmin over the workgroup of (v, j) pairs with j >= 0 (j < 0 = no candidate); result in rv[0], rj[0]
+__device__ __forceinline__ void block_argmin(double* rv, int* rj, int tid) {
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      const int oj = rj[tid + s];
+      if (oj >= 0 && (rj[tid] < 0 || cand_less(rv[tid + s], oj, rv[tid], rj[tid]))) {
+        rv[tid] = rv[tid + s];
+        rj[tid] = oj;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+constexpr int FS_CAP = 2048;   // survivors of the threshold pass kept in LDS
+
 // e_p / e_i / mom2_all: an optional SECOND channel pair over the same (query, entry) grid whose z-scores are added with the
-// same weights (BASELINE.json config 5, "fused SC + M2DP scoring": build-defined, no reference counterpart)
+// same weights (BASELINE.json config 5, "fused SC + M2DP scoring": build-defined, no reference counterpart).
+//
+// Selection of the k smallest (score, index) pairs of a row in at most TWO passes over it, whatever k:
+//   pass 1  every thread keeps the minimum of its elements; k = 1 ends here (block argmin).  Otherwise the k smallest of
+//           the 256 thread minima are k distinct elements of the row, so the k-th of them, tau, bounds the k-th smallest
+//           element of the row from above.
+//   pass 2  every element with score <= tau (ties included) goes to an LDS list - about k entries for unstructured
+//           data - and the k best of the list are taken by (score, index).
+// Rows that overflow the list (masses of equal scores, e.g. +Inf of the mask) fall back to one pass per selected element.
 __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i,
                                                            const float* __restrict__ e_p, const float* __restrict__ e_i,
                                                            const double* __restrict__ mom2_all,
@@ -86,6 +111,9 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   __shared__ double st[8];
   __shared__ double rv[256];
   __shared__ int rj[256];
+  __shared__ double lv[FS_CAP];
+  __shared__ int lj[FS_CAP];
+  __shared__ int lcnt;
   const int tid = threadIdx.x, q = blockIdx.x;
   const bool plain = (d_i == nullptr);   // single distance matrix, no z-score fusion (run_test.m types other than m2dp/sc)
   const bool two = (e_p != nullptr);
@@ -103,6 +131,7 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
     st[tid * 2] = mean;
     st[tid * 2 + 1] = sqrt(m2 / (cn - 1.0));
   }
+  if (tid == 0) lcnt = 0;
   __syncthreads();
   const double mp = plain ? 0.0 : st[0], sp = plain ? 1.0 : st[1], mi = plain ? 0.0 : st[2], si = plain ? 1.0 : st[3];
   const float* rp = d_p + (size_t)q * n;
@@ -115,59 +144,122 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   const bool fastdiv = !plain && sp > 1e-290 && sp < 1e290 && si > 1e-290 && si < 1e290;
   const double rsp = 1.0 / sp, rsi = 1.0 / si;
   int head = (int)((4 - ((reinterpret_cast<size_t>(rp) >> 2) & 3)) & 3);
-  if (head > n || ((reinterpret_cast<size_t>(rp) ^ reinterpret_cast<size_t>(ri)) & 15)) head = n;   // rows not co-aligned: scalar loads
-  const int nv = (n - head) >> 2;
+  if (head > n) head = n;
+  // rows not co-aligned mod 16 B (d_p and d_i carved out of one allocation with m*n % 4 != 0): no vector body, the scalar
+  // tail loop below walks the whole row
+  const bool coaligned = !((reinterpret_cast<size_t>(rp) ^ reinterpret_cast<size_t>(ri)) & 15);
+  if (!coaligned) head = 0;
+  const int nv = coaligned ? (n - head) >> 2 : 0;
   const f32x4* rp4 = reinterpret_cast<const f32x4*>(rp + head);
   const f32x4* ri4 = reinterpret_cast<const f32x4*>(ri + head);
-  double pv = -__builtin_inf();
-  int pj = -1;
-  for (int t = 0; t < k; t++) {
-    double bv = 0.0;
-    int bj = -1;
-    auto consider = [&](float vp, float vi, int j) {
-      const int jg = db_row0 + j;
-      double f;
-      if (plain) f = (double)vp;
-      else if (fastdiv) f = p_weight * div_rn((double)vp - mp, sp, rsp) + div_rn((double)vi - mi, si, rsi);        // run_test.m:40
-      else f = p_weight * (((double)vp - mp) / sp) + ((double)vi - mi) / si;
-      if (two) f += p_weight * (((double)e_p[(size_t)q * n + j] - st[4]) / st[5]) + ((double)e_i[(size_t)q * n + j] - st[6]) / st[7];
-      int dij = ig - jg;
-      if (dij < 0) dij = -dij;
-      if (dij < mask_width) f = __builtin_inf();                                      // run_test.m:47-53
-      if (f != f) return;                                                              // NaN never wins (MATLAB min)
-      if (!cand_less(pv, pj, f, jg)) return;                                           // already selected
-      if (bj < 0 || cand_less(f, jg, bv, bj)) { bv = f; bj = jg; }
-    };
-    if (tid < head) consider(rp[tid], ri[tid], tid);
+
+  auto fused = [&](float vp, float vi, int j) -> double {
+    const int jg = db_row0 + j;
+    double f;
+    if (plain) f = (double)vp;
+    else if (fastdiv) f = p_weight * div_rn((double)vp - mp, sp, rsp) + div_rn((double)vi - mi, si, rsi);        // run_test.m:40
+    else f = p_weight * (((double)vp - mp) / sp) + ((double)vi - mi) / si;
+    if (two) f += p_weight * (((double)e_p[(size_t)q * n + j] - st[4]) / st[5]) + ((double)e_i[(size_t)q * n + j] - st[6]) / st[7];
+    int dij = ig - jg;
+    if (dij < 0) dij = -dij;
+    if (dij < mask_width) f = __builtin_inf();                                      // run_test.m:47-53
+    return f;                                                                        // NaN never wins (MATLAB min)
+  };
+  // visit(j, f) over this thread's elements of the row
+  auto sweep = [&](auto&& visit) {
+    if (tid < head) visit(tid, fused(rp[tid], ri[tid], tid));
     for (int j = tid; j < nv; j += 256) {
       const f32x4 a = rp4[j], b = ri4[j];
       const int j0 = head + 4 * j;
-      consider(a[0], b[0], j0); consider(a[1], b[1], j0 + 1); consider(a[2], b[2], j0 + 2); consider(a[3], b[3], j0 + 3);
+      visit(j0, fused(a[0], b[0], j0)); visit(j0 + 1, fused(a[1], b[1], j0 + 1));
+      visit(j0 + 2, fused(a[2], b[2], j0 + 2)); visit(j0 + 3, fused(a[3], b[3], j0 + 3));
     }
-    for (int j = head + 4 * nv + tid; j < n; j += 256) consider(rp[j], ri[j], j);
-    rv[tid] = bv;
-    rj[tid] = bj;
-    __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if (tid < s) {
-        const int oj = rj[tid + s];
-        if (oj >= 0 && (rj[tid] < 0 || cand_less(rv[tid + s], oj, rv[tid], rj[tid]))) {
-          rv[tid] = rv[tid + s];
-          rj[tid] = oj;
-        }
+    for (int j = head + 4 * nv + tid; j < n; j += 256) visit(j, fused(rp[j], ri[j], j));
+  };
+  auto emit = [&](int t, double v, int jg) {
+    idx[(size_t)q * k + t] = jg;
+    score[(size_t)q * k + t] = (jg >= 0) ? (float)v : __builtin_nanf("");
+  };
+
+  // ---- pass 1: thread minima
+  double bv = 0.0;
+  int bj = -1;
+  sweep([&](int j, double f) {
+    const int jg = db_row0 + j;
+    if (f == f && (bj < 0 || cand_less(f, jg, bv, bj))) { bv = f; bj = jg; }
+  });
+  rv[tid] = bv;
+  rj[tid] = bj;
+  if (k == 1) {
+    block_argmin(rv, rj, tid);
+    if (tid == 0) emit(0, rv[0], rj[0]);
+    return;
+  }
+  // tau = the min(k, 256)-th smallest thread minimum (+Inf when fewer exist); k > 256: no bound from the minima
+  double tau = __builtin_inf();
+  if (k <= 256) {
+    double mv = bv;
+    int mj = bj;
+    for (int t = 0; t < k; t++) {
+      rv[tid] = mv; rj[tid] = mj;
+      block_argmin(rv, rj, tid);
+      const double wv = rv[0];
+      const int wj = rj[0];
+      __syncthreads();
+      if (wj < 0) { tau = __builtin_inf(); break; }
+      tau = wv;
+      if (mj == wj) mj = -1;                                                         // that thread's minimum is taken
+    }
+  }
+  // ---- pass 2: everything at or below tau
+  sweep([&](int j, double f) {
+    if (f <= tau) {
+      const int slot = atomicAdd(&lcnt, 1);
+      if (slot < FS_CAP) { lv[slot] = f; lj[slot] = db_row0 + j; }
+    }
+  });
+  __syncthreads();
+  const int L = lcnt;
+  if (L <= FS_CAP) {
+    for (int t = 0; t < k; t++) {
+      double cv = 0.0;
+      int cj = -1, cs = -1;
+      for (int s = tid; s < L; s += 256)
+        if (lj[s] >= 0 && (cj < 0 || cand_less(lv[s], lj[s], cv, cj))) { cv = lv[s]; cj = lj[s]; cs = s; }
+      rv[tid] = cv; rj[tid] = cj;
+      block_argmin(rv, rj, tid);
+      const double wv = rv[0];
+      const int wj = rj[0];
+      __syncthreads();
+      if (cs >= 0 && cj == wj) lj[cs] = -1;                                          // global indices are unique within a row
+      if (tid == 0) emit(t, wv, wj);
+      if (wj < 0) {
+        if (tid == 0) for (int u = t + 1; u < k; u++) emit(u, 0.0, -1);
+        break;
       }
       __syncthreads();
     }
+    return;
+  }
+  // ---- fallback: one pass per selected element
+  double pv = -__builtin_inf();
+  int pj = -1;
+  for (int t = 0; t < k; t++) {
+    bv = 0.0; bj = -1;
+    sweep([&](int j, double f) {
+      const int jg = db_row0 + j;
+      if (f != f) return;
+      if (!cand_less(pv, pj, f, jg)) return;                                         // already selected
+      if (bj < 0 || cand_less(f, jg, bv, bj)) { bv = f; bj = jg; }
+    });
+    rv[tid] = bv; rj[tid] = bj;
+    block_argmin(rv, rj, tid);
     pv = rv[0];
     pj = rj[0];
     __syncthreads();
-    if (tid == 0) {
-      idx[(size_t)q * k + t] = pj;
-      score[(size_t)q * k + t] = (pj >= 0) ? (float)pv : __builtin_nanf("");
-    }
+    if (tid == 0) emit(t, pv, pj);
     if (pj < 0) {  // fewer than k candidates: fill the rest
-      if (tid == 0)
-        for (int u = t + 1; u < k; u++) { idx[(size_t)q * k + u] = -1; score[(size_t)q * k + u] = __builtin_nanf(""); }
+      if (tid == 0) for (int u = t + 1; u < k; u++) emit(u, 0.0, -1);
       break;
     }
   }

@@ -358,4 +358,60 @@ int pr_write_points(const char* path, const int32_t* ids, const double* xyz, con
   return PR_OK;
 }
 
+// run_test.m:3-22 + :58-85: ground-truth loop pairs, precision / recall sweep over the queries sorted by their best score,
+// top recall at 100 % precision, AUC = trapz(recall, precision).  gt1 [m][cols], gt2 [n][cols] positions of the signatures
+// (test_kitti.m:23-25: columns 4, 8, 12 of gt.txt; test_robotcar.m:31-36: gps.txt), diff_idx 0-based.
+int pr_precision_recall(const double* diff_v, const int32_t* diff_idx, int32_t m, const double* gt1, const double* gt2, int32_t n,
+                        int32_t cols, double loop_diff, int32_t mask_width, double* auc, double* top_recall, int32_t* lp_detected,
+                        int32_t* n_detected) {
+  if (m < 0 || n < 0 || cols < 1 || (m > 0 && (!diff_v || !diff_idx || !gt1)) || (n > 0 && !gt2) || !auc || !top_recall) {
+    g_io_err = "pr_precision_recall: bad arguments";
+    return PR_EINVAL;
+  }
+  const double thr = loop_diff * loop_diff;
+  auto d2 = [&](int a, int b) {
+    double s = 0.0;
+    for (int c = 0; c < cols; c++) { const double t = gt1[(size_t)a * cols + c] - gt2[(size_t)b * cols + c]; s += t * t; }
+    return s;
+  };
+  // ground-truth pairs (:3-22): for every i the closest j with |i - j| >= mask_width (first minimum), kept when closer than loop_diff
+  int64_t L = 0;
+  for (int i = 0; i < m; i++) {
+    double best = INFINITY;
+    bool any = false;
+    for (int j = 0; j < n; j++) {
+      if (std::abs(i - j) < mask_width) continue;
+      const double d = d2(i, j);
+      if (d < best) { best = d; any = true; }
+    }
+    if (any && best < thr) L++;
+  }
+  const int64_t total_lp = L == 0 ? 0 : (L < 2 ? 2 : L);     // MATLAB length() of an L x 2 matrix (:22)
+  std::vector<int> rank((size_t)m);
+  for (int i = 0; i < m; i++) rank[i] = i;
+  std::stable_sort(rank.begin(), rank.end(), [&](int a, int b) {    // [~, diff_rank] = sort(diff_v): ascending, NaN last, stable
+    const double x = diff_v[a], y = diff_v[b];
+    if (std::isnan(x) || std::isnan(y)) return !std::isnan(x) && std::isnan(y);
+    return x < y;
+  });
+  int64_t tp = 0, fp = 0;
+  int top_count = 0;
+  double tr = 0.0, area = 0.0, pprev = 0.0, rprev = 0.0;
+  for (int i = 0; i < m; i++) {
+    const int a = rank[i], b = diff_idx[a];
+    if (b >= 0 && b < n && d2(a, b) < thr) tp++; else fp++;
+    const double p = (double)tp / (double)(tp + fp);
+    const double r = total_lp ? (double)tp / (double)total_lp : NAN;
+    if (p == 1.0) { top_count = i + 1; tr = r; }
+    if (i > 0) area += (r - rprev) * (p + pprev) / 2.0;      // trapz(recall, precision) (:85)
+    pprev = p; rprev = r;
+  }
+  *auc = area;
+  *top_recall = tr;
+  if (n_detected) *n_detected = top_count;
+  if (lp_detected)
+    for (int i = 0; i < top_count; i++) { lp_detected[2 * i] = rank[i]; lp_detected[2 * i + 1] = diff_idx[rank[i]]; }
+  return PR_OK;
+}
+
 }  // extern "C"

@@ -28,15 +28,16 @@ inline int m2_qtiles(int sigs) { return ((m2_tiles(sigs) + 11) / 12) * 12; }   /
 
 // sc_pack.hip — processSC.m:15-20 (row L2 normalisation) + per-ring rfft over the 60 sectors, written in the
 // MFMA operand layout of `role`.  sig: device [rows][2400] of T.  flags[0] |= 1 if a row has zero norm.
+// bad[row] |= 1 << channel for such rows (they are packed as zeros; launch_nan_fixup writes their NaN distances).
 void launch_sc_pack(hipStream_t st, const void* sig, int dtype, int rows, int role, float* packed, int groups,
-                    const double* twiddle, int* flags);
+                    const double* twiddle, int* flags, int* bad);
 // sc_match.hip — processSC.m:22-33 for both channels.  Writes d_p, d_i device [m][n].
 void launch_sc_match(hipStream_t st, const float* qpk, int m, const float* dpk, int n, const float* cst,
                      float* d_p, float* d_i, int nsplit_override);
 size_t sc_match_lds_bytes();
 // sc_match_h.hip — the same on the f16 matrix cores with split (hi + lo) operands; packed images from launch_sc_pack_h
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
-                      const double* twiddle, int* flags);
+                      const double* twiddle, int* flags, int* bad);
 void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p,
                        float* d_i, int nsplit_override);
 size_t sc_match_h_lds_bytes();
@@ -54,6 +55,15 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
                         int G, int q_row0, int db_row0, int mask_width, double p_weight, int k, int32_t* idx,
                         float* score, const float* e_p = nullptr, const float* e_i = nullptr, const double* mom2_all = nullptr);
 
+// rerank.hip — NaN rows / columns of zero-norm signatures (processSC.m:16,19), the fp64 re-evaluation of the fp32
+// selection's survivors (processSC.m:15-33 / processM2DP.m:12-22 + run_test.m:40 per pair) and the k-way shard merge
+void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, const int* qbad, const int* dbad);
+void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
+                   const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
+                   double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
+                   float* score32);
+void launch_merge_topk(hipStream_t st, const int32_t* idx_all, const double* score_all, int G, int m, int k, int32_t* idx, double* score);
+
 // sc_gen.hip / m2dp_gen.hip — pts_align.h:7-46 + SC.cpp:12-76 / M2DP.cpp:38-109 (+ test_m2dp.cpp:44-68)
 void launch_ave_chain(hipStream_t st, const float* inten, const int64_t* offs, int N, float* ave);
 void launch_cloud_frames(hipStream_t st, const double* xyz, const int64_t* offs, int N, double* frames);
@@ -61,7 +71,7 @@ void launch_sc_bin(hipStream_t st, const double* xyz, const float* inten, const 
                    const double* frames, const float* ave, double* out);
 void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
                          double max_rho, const double* frames, const float* ave, const double* planes, double* mats,
-                         double* out);
+                         double* out, int* flags /* [1] |= 1: a leading singular pair did not converge */);
 size_t m2dp_generate_scratch_bytes(int N);
 
 // plain_match.hip — processGIST.m:1-10, processBoW.m:1-38 (h1, h2: device, row-major doubles; BoW rows alternate ids | weights)

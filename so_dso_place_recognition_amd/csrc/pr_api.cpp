@@ -21,10 +21,13 @@
 struct pr_ctx {
   int device = -1;
   hipStream_t stream = nullptr;
+  bool own_stream = true;        // false: pr_create_on_stream (the caller's stream)
+  int nan_policy = PR_NAN_EXCLUDE;
+  int warnings = 0;              // PR_WARN_* bits not yet taken
   hipStream_t side = nullptr;    // overlaps the sequential float-average chain with the moments pass
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
-  int* d_flags = nullptr;        // [4] deferred error bits (bit0: zero-norm row at pack time)
+  int* d_flags = nullptr;        // [4] deferred bits: [0] zero-norm row at pack time, [1] M2DP singular pair not converged
   double* d_twiddle = nullptr;   // cos[60], sin[60] of 2*pi*t/60
   float* d_cst = nullptr;        // SC stage-2 constants [31][2][64]
   void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16] (sc_match_h.hip)
@@ -40,6 +43,7 @@ struct pr_sigset {
   int sc_mode = 0;               // SC: arithmetic the image was packed for (pr_ctx::sc_mode at creation)
   float* packed = nullptr;
   size_t floats = 0;
+  int* bad = nullptr;            // SC: [max_sigs] bit c = channel c of that row has zero norm (NaN row in MATLAB, processSC.m:16,19)
 };
 
 static thread_local std::string g_err;   // errors without a context
@@ -94,9 +98,12 @@ int check_flags(pr_ctx* ctx) {
   int h[4];
   PR_HIP(ctx, hipMemcpyAsync(h, ctx->d_flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (h[0] || h[1]) PR_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof h, ctx->stream));
+  if (h[1]) ctx->warnings |= PR_WARN_M2DP_SVD;
   if (h[0]) {
-    PR_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof h, ctx->stream));
-    PR_FAIL(ctx, PR_ENAN, "a signature row has zero L2 norm (MATLAB would produce NaN distances, processSC.m:16,19)");
+    if (ctx->nan_policy == PR_NAN_FAIL)
+      PR_FAIL(ctx, PR_ENAN, "a signature row has zero L2 norm (MATLAB would produce NaN distances, processSC.m:16,19)");
+    ctx->warnings |= PR_WARN_NAN_ROWS;
   }
   return PR_OK;
 }
@@ -109,7 +116,7 @@ const char* pr_version(void) { return "so_dso_place_recognition_amd 0.1 (gfx950)
 
 const char* pr_last_error(const pr_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
 
-int pr_create(int device_id, pr_ctx** out) {
+static int create_common(int device_id, hipStream_t external, bool use_external, pr_ctx** out) {
   if (!out) PR_FAIL((pr_ctx*)nullptr, PR_EINVAL, "pr_create: out is NULL");
   *out = nullptr;
   int ndev = 0;
@@ -129,7 +136,8 @@ int pr_create(int device_id, pr_ctx** out) {
   do {
 #define TRY(call) if ((call) != hipSuccess) { g_err = std::string(#call) + " failed"; rc = PR_EHIP; break; }
     TRY(hipSetDevice(device_id));
-    TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    if (use_external) { ctx->stream = external; ctx->own_stream = false; }
+    else TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
     TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
@@ -217,10 +225,16 @@ int pr_create(int device_id, pr_ctx** out) {
   return PR_OK;
 }
 
+int pr_create(int device_id, pr_ctx** out) { return create_common(device_id, nullptr, false, out); }
+
+int pr_create_on_stream(int device_id, void* hip_stream, pr_ctx** out) {
+  return create_common(device_id, static_cast<hipStream_t>(hip_stream), true, out);
+}
+
 void pr_destroy(pr_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  if (ctx->stream) { (void)hipStreamSynchronize(ctx->stream); (void)hipStreamDestroy(ctx->stream); }
+  if (ctx->stream || !ctx->own_stream) { (void)hipStreamSynchronize(ctx->stream); if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream); }
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -240,6 +254,23 @@ int pr_set_sc_arith(pr_ctx* ctx, int arith) {
 }
 
 int pr_get_sc_arith(const pr_ctx* ctx) { return ctx ? ctx->sc_mode : PR_EINVAL; }
+
+int pr_set_nan_policy(pr_ctx* ctx, int policy) {
+  if (!ctx) return PR_EINVAL;
+  if (policy != PR_NAN_EXCLUDE && policy != PR_NAN_FAIL) PR_FAIL(ctx, PR_EINVAL, "pr_set_nan_policy: unknown policy %d", policy);
+  ctx->nan_policy = policy;
+  return PR_OK;
+}
+
+int pr_get_nan_policy(const pr_ctx* ctx) { return ctx ? ctx->nan_policy : PR_EINVAL; }
+
+int pr_take_warnings(pr_ctx* ctx) {
+  if (!ctx) return 0;
+  if (set_device(ctx) == PR_OK) (void)check_flags(ctx);
+  const int w = ctx->warnings;
+  ctx->warnings = 0;
+  return w;
+}
 
 void* pr_stream(pr_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
@@ -450,6 +481,10 @@ int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigse
   s->floats = sigset_floats(type, role, max_sigs, &s->groups, s->sc_mode);
   hipError_t e = hipMalloc((void**)&s->packed, s->floats * sizeof(float) + 16);
   if (e != hipSuccess) { delete s; PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: hipMalloc(%zu B) failed: %s", s->floats * 4, hipGetErrorString(e)); }
+  if (type == PR_TYPE_SC) {
+    e = hipMalloc((void**)&s->bad, ((size_t)max_sigs + 1) * sizeof(int));
+    if (e != hipSuccess) { (void)hipFree(s->packed); delete s; PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: hipMalloc failed: %s", hipGetErrorString(e)); }
+  }
   *out = s;
   return PR_OK;
 }
@@ -458,6 +493,7 @@ void pr_sigset_destroy(pr_ctx* ctx, pr_sigset* s) {
   if (!s) return;
   if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
   if (s->packed) (void)hipFree(s->packed);
+  if (s->bad) (void)hipFree(s->bad);
   delete s;
 }
 
@@ -481,14 +517,15 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
   }
   // padding rows/tiles must be zero: they yield dot = 0 and are masked on store
   PR_HIP(ctx, hipMemsetAsync(s->packed, 0, s->floats * sizeof(float), ctx->stream));
+  if (s->bad) PR_HIP(ctx, hipMemsetAsync(s->bad, 0, ((size_t)s->max_sigs + 1) * sizeof(int), ctx->stream));
   // the channel stride must match the matcher's view of THIS count (not the capacity)
   int groups;
   (void)sigset_floats(s->type, s->role, n_sigs, &groups, s->sc_mode);
   s->groups = groups;
   if (s->type == PR_TYPE_SC && s->sc_mode == 0)
-    pr::launch_sc_pack_h(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags);
+    pr::launch_sc_pack_h(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags, s->bad);
   else if (s->type == PR_TYPE_SC)
-    pr::launch_sc_pack(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags);
+    pr::launch_sc_pack(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags, s->bad);
   else if (s->type == PR_TYPE_M2DP)
     if (s->sc_mode == PR_SC_ARITH_F16X2) pr::launch_m2dp_pack_h(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
     else pr::launch_m2dp_pack(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
@@ -517,6 +554,7 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
     else pr::launch_m2dp_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
   else
     pr::launch_delight_match(ctx->stream, q->packed, q->count, db->packed, delight_masks(db), db->count, d_p);
+  if (q->type == PR_TYPE_SC) pr::launch_nan_fixup(ctx->stream, d_p, d_i, q->count, db->count, q->bad, db->bad);   // processSC.m:16,19
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -540,36 +578,104 @@ int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
   return PR_OK;
 }
 
+int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
+                  const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
+                  int32_t mask_width, double p_weight, int32_t k_in, const int32_t* idx_in, int32_t k, int32_t* idx, double* score) {
+  if (!ctx) return PR_EINVAL;
+  const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
+  if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !idx_in || !idx || !score ||
+      m < 0 || n_local < 1 || G < 1 || k < 1 || k_in < k || k_in > 128 ||
+      (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
+    PR_FAIL(ctx, PR_EINVAL, "pr_rerank_dev: bad arguments (m=%d, n_local=%d, G=%d, k=%d, k_in=%d)", m, n_local, G, k, k_in);
+  if (m == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  double* cand = nullptr;
+  PR_HIP(ctx, hipMallocAsync((void**)&cand, (size_t)m * k_in * sizeof(double), ctx->stream));
+  pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
+                    p_weight, k_in, idx_in, cand, k, idx, score, nullptr);
+  PR_HIP(ctx, hipGetLastError());
+  PR_HIP(ctx, hipFreeAsync(cand, ctx->stream));
+  return PR_OK;
+}
+
+int pr_merge_topk_dev(pr_ctx* ctx, const int32_t* idx_all, const double* score_all, int32_t G, int32_t m, int32_t k, int32_t* idx,
+                      double* score) {
+  if (!ctx) return PR_EINVAL;
+  if (!idx_all || !score_all || !idx || !score || G < 1 || m < 0 || k < 1 || (int64_t)G * k > 128)
+    PR_FAIL(ctx, PR_EINVAL, "pr_merge_topk_dev: bad arguments (G=%d, m=%d, k=%d; G*k <= 128)", G, m, k);
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_merge_topk(ctx->stream, idx_all, score_all, G, m, k, idx, score);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
 // ------------------------------------------------------------------------------------------- host-buffer path
+// survivors of the fp32 selection that the fp64 re-evaluation looks at (k + 8, the interface's cap is 128)
+static int rerank_width(int k) { return k + 8 > 128 ? 128 : k + 8; }
+
+// score32 / score64: exactly one is non-null
 static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n,
                          float* out_p, float* out_i, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,
-                         float* score, bool want_topk) {
+                         float* score32, double* score64, bool want_topk) {
   if (!ctx) return PR_EINVAL;
   if (m < 0 || n < 0 || (m > 0 && !h1) || (n > 0 && !h2)) PR_FAIL(ctx, PR_EINVAL, "bad signature buffers (m=%d, n=%d)", m, n);
   const bool plain = (type == PR_TYPE_DELIGHT);
-  if (want_topk && ((n < 2 && !plain) || k < 1 || !idx || !score))
-    PR_FAIL(ctx, PR_EINVAL, "pr_match_topk needs n >= 2 (N-1 standard deviation), k >= 1 and output buffers");
+  if (want_topk && (k < 1 || k > 120 || !idx || (!score32 && !score64)))
+    PR_FAIL(ctx, PR_EINVAL, "pr_match_topk needs 1 <= k <= 120 and output buffers");
+  if (want_topk && n == 0) {   // nothing to match against: every query row is "no candidate"
+    for (size_t i = 0; i < (size_t)m * k; i++) { idx[i] = -1; if (score32) score32[i] = NAN; else score64[i] = NAN; }
+    return PR_OK;
+  }
+  if (want_topk && n < 2 && !plain)
+    PR_FAIL(ctx, PR_EINVAL, "pr_match_topk needs n >= 2 (N-1 standard deviation)");
   if (m == 0 || n == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
+  const size_t rows_per = (type == PR_TYPE_SC) ? 1 : (type == PR_TYPE_M2DP ? 4 : 16);
+  const size_t cols = (type == PR_TYPE_SC) ? PR_SC_SIG_LEN : (type == PR_TYPE_M2DP ? PR_M2DP_SIG_LEN : PR_DELIGHT_SIG_LEN);
   pr_sigset *q = nullptr, *d = nullptr;
   int rc = pr_sigset_create(ctx, type, PR_ROLE_QUERY, m, &q);
   if (rc == PR_OK) rc = pr_sigset_create(ctx, type, PR_ROLE_DB, n, &d);
-  DevBuf dp, di, mom, didx, dsc;
+  DevBuf raw1, raw2, dp, di, mom, didx, dsc, dsc64, dcand;
   do {
     if (rc) break;
-    if ((rc = pr_sigset_pack(ctx, q, h1, PR_F64, PR_HOST, m))) break;
-    if ((rc = pr_sigset_pack(ctx, d, h2, PR_F64, PR_HOST, n))) break;
+    // the raw signatures stay on the device for the fp64 re-evaluation of the selection's survivors
+    const size_t b1 = (size_t)m * rows_per * cols * 8, b2 = (size_t)n * rows_per * cols * 8;
+    if (raw1.alloc(b1) != hipSuccess || raw2.alloc(b2) != hipSuccess) { ctx->err = "out of device memory for the signatures"; rc = PR_ENOMEM; break; }
+    if (hipMemcpyAsync(raw1.p, h1, b1, hipMemcpyHostToDevice, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(raw2.p, h2, b2, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { ctx->err = "H2D copy failed"; rc = PR_EHIP; break; }
+    if ((rc = pr_sigset_pack(ctx, q, raw1.p, PR_F64, PR_DEVICE, m))) break;
+    if ((rc = pr_sigset_pack(ctx, d, raw2.p, PR_F64, PR_DEVICE, n))) break;
     const size_t mn = (size_t)m * n;
     if (dp.alloc(mn * 4) != hipSuccess || (!plain && di.alloc(mn * 4) != hipSuccess)) { ctx->err = "out of device memory for the m x n distance matrices"; rc = PR_ENOMEM; break; }
     if ((rc = pr_distances_dev(ctx, q, d, dp.as<float>(), plain ? nullptr : di.as<float>()))) break;
     if (want_topk) {
-      if (mom.alloc((size_t)m * 6 * 8) != hipSuccess || didx.alloc((size_t)m * k * 4) != hipSuccess ||
-          dsc.alloc((size_t)m * k * 4) != hipSuccess) { ctx->err = "out of device memory"; rc = PR_ENOMEM; break; }
+      const int kin = plain ? k : rerank_width(k);
+      if (mom.alloc((size_t)m * 6 * 8) != hipSuccess || didx.alloc((size_t)m * kin * 4) != hipSuccess ||
+          dsc.alloc((size_t)m * kin * 4) != hipSuccess || dsc64.alloc((size_t)m * k * 8) != hipSuccess ||
+          dcand.alloc((size_t)m * k * 4) != hipSuccess) { ctx->err = "out of device memory"; rc = PR_ENOMEM; break; }
       if (!plain && (rc = pr_row_moments_dev(ctx, dp.as<float>(), di.as<float>(), m, n, mom.as<double>()))) break;
       if ((rc = pr_fuse_select_dev(ctx, dp.as<float>(), plain ? nullptr : di.as<float>(), m, n, mom.as<double>(), 1, 0, 0, mask_width,
-                                   p_weight, k, didx.as<int32_t>(), dsc.as<float>()))) break;
-      if (hipMemcpyAsync(idx, didx.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-          hipMemcpyAsync(score, dsc.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
+                                   p_weight, kin, didx.as<int32_t>(), dsc.as<float>()))) break;
+      std::vector<float> tmp;
+      if (plain) {   // DELIGHT: a single fp32 chi-square matrix, no fusion (run_test.m:26-36) - nothing to re-evaluate
+        if (score64) tmp.resize((size_t)m * k);
+        if (hipMemcpyAsync(idx, didx.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(score32 ? score32 : tmp.data(), dsc.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
+        if ((rc = pr_sync(ctx))) break;
+        if (score64) for (size_t i = 0; i < tmp.size(); i++) score64[i] = (double)tmp[i];
+        break;
+      }
+      const bool sc = type == PR_TYPE_SC;
+      if ((rc = pr_rerank_dev(ctx, sc ? raw1.p : nullptr, sc ? raw2.p : nullptr, PR_F64, sc ? nullptr : raw1.p, sc ? nullptr : raw2.p, PR_F64,
+                              sc ? mom.as<double>() : nullptr, sc ? nullptr : mom.as<double>(), m, n, 1, 0, 0, mask_width, p_weight, kin,
+                              didx.as<int32_t>(), k, dcand.as<int32_t>(), dsc64.as<double>()))) break;
+      std::vector<double> t64;
+      if (score32) t64.resize((size_t)m * k);
+      if (hipMemcpyAsync(idx, dcand.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipMemcpyAsync(score64 ? score64 : t64.data(), dsc64.p, (size_t)m * k * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
+      if ((rc = pr_sync(ctx))) break;
+      if (score32) for (size_t i = 0; i < t64.size(); i++) score32[i] = (float)t64[i];
+      break;
     }
     if (out_p && hipMemcpyAsync(out_p, dp.p, mn * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
     if (out_i && !plain && hipMemcpyAsync(out_i, di.p, mn * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
@@ -582,22 +688,31 @@ static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, con
 }
 
 int pr_sc_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, float* d_struct, float* d_int) {
-  return distance_host(ctx, PR_TYPE_SC, h1, m, h2, n, d_struct, d_int, 0, 0, 0, nullptr, nullptr, false);
+  return distance_host(ctx, PR_TYPE_SC, h1, m, h2, n, d_struct, d_int, 0, 0, 0, nullptr, nullptr, nullptr, false);
 }
 
 int pr_m2dp_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, float* d_cnt, float* d_int) {
-  return distance_host(ctx, PR_TYPE_M2DP, h1, m, h2, n, d_cnt, d_int, 0, 0, 0, nullptr, nullptr, false);
+  return distance_host(ctx, PR_TYPE_M2DP, h1, m, h2, n, d_cnt, d_int, 0, 0, 0, nullptr, nullptr, nullptr, false);
 }
 
 int pr_delight_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, float* dist) {
-  return distance_host(ctx, PR_TYPE_DELIGHT, h1, m, h2, n, dist, nullptr, 0, 0, 0, nullptr, nullptr, false);
+  return distance_host(ctx, PR_TYPE_DELIGHT, h1, m, h2, n, dist, nullptr, 0, 0, 0, nullptr, nullptr, nullptr, false);
 }
 
 int pr_match_topk(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n, int32_t mask_width,
                   double p_weight, int32_t k, int32_t* idx, float* score) {
   if (!ctx) return PR_EINVAL;
   if (type != PR_TYPE_SC && type != PR_TYPE_M2DP && type != PR_TYPE_DELIGHT) PR_FAIL(ctx, PR_EINVAL, "pr_match_topk: unknown type %d", type);
-  return distance_host(ctx, type, h1, m, h2, n, nullptr, nullptr, mask_width, p_weight, k, idx, score, true);
+  if (!score) PR_FAIL(ctx, PR_EINVAL, "pr_match_topk: score is NULL");
+  return distance_host(ctx, type, h1, m, h2, n, nullptr, nullptr, mask_width, p_weight, k, idx, score, nullptr, true);
+}
+
+int pr_match_topk_f64(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n, int32_t mask_width,
+                      double p_weight, int32_t k, int32_t* idx, double* score) {
+  if (!ctx) return PR_EINVAL;
+  if (type != PR_TYPE_SC && type != PR_TYPE_M2DP && type != PR_TYPE_DELIGHT) PR_FAIL(ctx, PR_EINVAL, "pr_match_topk_f64: unknown type %d", type);
+  if (!score) PR_FAIL(ctx, PR_EINVAL, "pr_match_topk_f64: score is NULL");
+  return distance_host(ctx, type, h1, m, h2, n, nullptr, nullptr, mask_width, p_weight, k, idx, nullptr, score, true);
 }
 
 int pr_fuse_select2_dev(pr_ctx* ctx, const float* d_p, const float* d_i, const float* e_p, const float* e_i, int32_t m, int32_t n,
@@ -611,40 +726,63 @@ int pr_fuse_select2_dev(pr_ctx* ctx, const float* d_p, const float* d_i, const f
 }
 
 // BASELINE.json config 5: SC and M2DP signatures of the same places scored together (build-defined)
-int pr_match_topk_fused(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32_t m, const double* sc2, const double* m2dp2,
-                        int32_t n, int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score) {
+static int fused_host(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32_t m, const double* sc2, const double* m2dp2,
+                      int32_t n, int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score32, double* score64) {
   if (!ctx) return PR_EINVAL;
-  if (m < 0 || n < 2 || k < 1 || !idx || !score || (m > 0 && (!sc1 || !m2dp1)) || !sc2 || !m2dp2)
+  if (m < 0 || n < 2 || k < 1 || k > 120 || !idx || (!score32 && !score64) || (m > 0 && (!sc1 || !m2dp1)) || !sc2 || !m2dp2)
     PR_FAIL(ctx, PR_EINVAL, "pr_match_topk_fused: bad arguments (m=%d, n=%d, k=%d)", m, n, k);
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   pr_sigset* ss[4] = {nullptr, nullptr, nullptr, nullptr};   // SC query, SC db, M2DP query, M2DP db
-  DevBuf d[4], mom[2], didx, dsc;
+  DevBuf raw[4], d[4], mom[2], didx, dsc, dcand, dsc64;
+  const void* host[4] = {sc1, sc2, m2dp1, m2dp2};
+  const size_t bytes[4] = {(size_t)m * 2400 * 8, (size_t)n * 2400 * 8, (size_t)m * 4 * 384 * 8, (size_t)n * 4 * 384 * 8};
+  const int kin = rerank_width(k);
   int rc = PR_OK;
   do {
     if ((rc = pr_sigset_create(ctx, PR_TYPE_SC, PR_ROLE_QUERY, m, &ss[0])) || (rc = pr_sigset_create(ctx, PR_TYPE_SC, PR_ROLE_DB, n, &ss[1])) ||
         (rc = pr_sigset_create(ctx, PR_TYPE_M2DP, PR_ROLE_QUERY, m, &ss[2])) || (rc = pr_sigset_create(ctx, PR_TYPE_M2DP, PR_ROLE_DB, n, &ss[3]))) break;
-    if ((rc = pr_sigset_pack(ctx, ss[0], sc1, PR_F64, PR_HOST, m)) || (rc = pr_sigset_pack(ctx, ss[1], sc2, PR_F64, PR_HOST, n)) ||
-        (rc = pr_sigset_pack(ctx, ss[2], m2dp1, PR_F64, PR_HOST, m)) || (rc = pr_sigset_pack(ctx, ss[3], m2dp2, PR_F64, PR_HOST, n))) break;
-    const size_t mn = (size_t)m * n;
     bool ok = true;
+    for (int i = 0; i < 4; i++)
+      ok = ok && raw[i].alloc(bytes[i]) == hipSuccess &&
+           hipMemcpyAsync(raw[i].p, host[i], bytes[i], hipMemcpyHostToDevice, ctx->stream) == hipSuccess;
+    if (!ok) { ctx->err = "out of device memory for the signatures"; rc = PR_ENOMEM; break; }
+    if ((rc = pr_sigset_pack(ctx, ss[0], raw[0].p, PR_F64, PR_DEVICE, m)) || (rc = pr_sigset_pack(ctx, ss[1], raw[1].p, PR_F64, PR_DEVICE, n)) ||
+        (rc = pr_sigset_pack(ctx, ss[2], raw[2].p, PR_F64, PR_DEVICE, m)) || (rc = pr_sigset_pack(ctx, ss[3], raw[3].p, PR_F64, PR_DEVICE, n))) break;
+    const size_t mn = (size_t)m * n;
     for (auto& b : d) ok = ok && b.alloc(mn * 4) == hipSuccess;
     ok = ok && mom[0].alloc((size_t)m * 6 * 8) == hipSuccess && mom[1].alloc((size_t)m * 6 * 8) == hipSuccess &&
-         didx.alloc((size_t)m * k * 4) == hipSuccess && dsc.alloc((size_t)m * k * 4) == hipSuccess;
+         didx.alloc((size_t)m * kin * 4) == hipSuccess && dsc.alloc((size_t)m * kin * 4) == hipSuccess &&
+         dcand.alloc((size_t)m * k * 4) == hipSuccess && dsc64.alloc((size_t)m * k * 8) == hipSuccess;
     if (!ok) { ctx->err = "out of device memory for the four m x n distance matrices"; rc = PR_ENOMEM; break; }
     if ((rc = pr_distances_dev(ctx, ss[0], ss[1], d[0].as<float>(), d[1].as<float>())) ||
         (rc = pr_distances_dev(ctx, ss[2], ss[3], d[2].as<float>(), d[3].as<float>())) ||
         (rc = pr_row_moments_dev(ctx, d[0].as<float>(), d[1].as<float>(), m, n, mom[0].as<double>())) ||
         (rc = pr_row_moments_dev(ctx, d[2].as<float>(), d[3].as<float>(), m, n, mom[1].as<double>())) ||
         (rc = pr_fuse_select2_dev(ctx, d[0].as<float>(), d[1].as<float>(), d[2].as<float>(), d[3].as<float>(), m, n, mom[0].as<double>(),
-                                  mom[1].as<double>(), 1, 0, 0, mask_width, p_weight, k, didx.as<int32_t>(), dsc.as<float>()))) break;
-    if (hipMemcpyAsync(idx, didx.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        hipMemcpyAsync(score, dsc.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
-    rc = pr_sync(ctx);
+                                  mom[1].as<double>(), 1, 0, 0, mask_width, p_weight, kin, didx.as<int32_t>(), dsc.as<float>())) ||
+        (rc = pr_rerank_dev(ctx, raw[0].p, raw[1].p, PR_F64, raw[2].p, raw[3].p, PR_F64, mom[0].as<double>(), mom[1].as<double>(), m, n, 1,
+                            0, 0, mask_width, p_weight, kin, didx.as<int32_t>(), k, dcand.as<int32_t>(), dsc64.as<double>()))) break;
+    std::vector<double> t64;
+    if (score32) t64.resize((size_t)m * k);
+    if (hipMemcpyAsync(idx, dcand.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipMemcpyAsync(score64 ? score64 : t64.data(), dsc64.p, (size_t)m * k * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
+    if ((rc = pr_sync(ctx))) break;
+    if (score32) for (size_t i = 0; i < t64.size(); i++) score32[i] = (float)t64[i];
   } while (0);
   if (rc != PR_OK) (void)hipStreamSynchronize(ctx->stream);
   for (auto* q : ss) pr_sigset_destroy(ctx, q);
   return rc;
+}
+
+int pr_match_topk_fused(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32_t m, const double* sc2, const double* m2dp2,
+                        int32_t n, int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score) {
+  return fused_host(ctx, sc1, m2dp1, m, sc2, m2dp2, n, mask_width, p_weight, k, idx, score, nullptr);
+}
+
+int pr_match_topk_fused_f64(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32_t m, const double* sc2, const double* m2dp2,
+                            int32_t n, int32_t mask_width, double p_weight, int32_t k, int32_t* idx, double* score) {
+  return fused_host(ctx, sc1, m2dp1, m, sc2, m2dp2, n, mask_width, p_weight, k, idx, nullptr, score);
 }
 
 // GIST / BoW (run_test.m:32-35): one distance matrix from raw f64 rows of `cols` columns, no packing, no fusion
@@ -656,6 +794,7 @@ static int plain_cols_host(pr_ctx* ctx, int type, const double* h1, int32_t m, c
     PR_FAIL(ctx, PR_EINVAL, "bad signature buffers (m=%d, n=%d, cols=%d)", m, n, cols);
   if (type == PR_TYPE_BOW && (size_t)cols * 16 > 160 * 1024) PR_FAIL(ctx, PR_EINVAL, "BoW rows of %d columns do not fit the LDS", cols);
   if (want_topk && (k < 1 || !idx || !score)) PR_FAIL(ctx, PR_EINVAL, "top-k needs k >= 1 and output buffers");
+  if (want_topk && n == 0) { for (size_t i = 0; i < (size_t)m * k; i++) { idx[i] = -1; score[i] = NAN; } return PR_OK; }
   if (m == 0 || n == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   const size_t rows1 = (type == PR_TYPE_BOW ? 2 : 1) * (size_t)m, rows2 = (type == PR_TYPE_BOW ? 2 : 1) * (size_t)n;
@@ -740,7 +879,7 @@ int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, con
   PR_HIP(ctx, mats.alloc(pr::m2dp_generate_scratch_bytes(N)));
   if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc;
   pr::launch_m2dp_bin_svd(ctx->stream, xyz, inten, offs, N, max_rho, frames.as<double>(), ave.as<float>(), ctx->d_planes,
-                          mats.as<double>(), out);
+                          mats.as<double>(), out, ctx->d_flags);
   PR_HIP(ctx, hipGetLastError());
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PR_OK;

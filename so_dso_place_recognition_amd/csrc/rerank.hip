@@ -1,0 +1,266 @@
+// rerank.hip — the fp64 end of run_test.m:38-57 on gfx950: what makes the returned top-k and its scores those of the
+// reference's double arithmetic although the all-pairs matchers work in fp32.
+//
+//   nan_fixup     distances to / from a zero-norm signature are NaN in MATLAB (processSC.m:16,19: 0/0); the matchers see
+//                 such rows as all-zero operands, this kernel writes the NaNs.
+//   rerank        for every (query, survivor of the fp32 top-(k+8) selection): the distance of that pair again, now
+//                 straight from the raw signatures in fp64 and in the reference's own formulation - SC: rows / L2 norm,
+//                 the 120 shifted / mirrored variants, (1 - dot)/2, minimum (processSC.m:15-33); M2DP: (1 - dot)/2 over
+//                 the 4 x 4 sign variants (processM2DP.m:12-22) - and the fused z-score of run_test.m:40 with the row
+//                 moments of all shards.  One workgroup per pair; ~0.6 M fp64 multiply-adds per SC pair.
+//   rerank_sort   orders the survivors of a query by (fp64 score, index) and keeps k (run_test.m:57, ties -> lower index).
+//   merge_topk    k-way merge of the per-shard top-k lists of G database shards by (score, global index).
+#include "kernels.hpp"
+
+namespace pr {
+namespace {
+
+__global__ __launch_bounds__(256) void nan_rows_kernel(float* __restrict__ d_p, float* __restrict__ d_i, int n,
+                                                        const int* __restrict__ qbad) {
+  const int q = blockIdx.x, b = qbad[q];
+  if (!b) return;
+  const float nanv = __builtin_nanf("");
+  for (int j = threadIdx.x; j < n; j += 256) {
+    if (b & 1) d_p[(size_t)q * n + j] = nanv;
+    if ((b & 2) && d_i) d_i[(size_t)q * n + j] = nanv;
+  }
+}
+
+__global__ __launch_bounds__(256) void nan_cols_kernel(float* __restrict__ d_p, float* __restrict__ d_i, int m, int n,
+                                                        const int* __restrict__ dbad) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const int b = dbad[j];
+  if (!b) return;
+  const float nanv = __builtin_nanf("");
+  for (int q = blockIdx.y; q < m; q += gridDim.y) {
+    if (b & 1) d_p[(size_t)q * n + j] = nanv;
+    if ((b & 2) && d_i) d_i[(size_t)q * n + j] = nanv;
+  }
+}
+
+__device__ __forceinline__ double ld(const void* p, int dtype, size_t i) {
+  return dtype == 0 ? static_cast<const double*>(p)[i] : (double)static_cast<const float*>(p)[i];
+}
+
+__device__ __forceinline__ double block_sum256(double v, double* red, int tid) {
+  red[tid] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// MATLAB min: NaN only if every element is NaN
+__device__ __forceinline__ double block_min256(double v, double* red, int tid) {
+  red[tid] = v;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (tid < s) {
+      const double a = red[tid], b = red[tid + s];
+      red[tid] = (a != a) ? b : ((b != b) ? a : (b < a ? b : a));
+    }
+    __syncthreads();
+  }
+  const double r = red[0];
+  __syncthreads();
+  return r;
+}
+
+// processSC.m:15-33 for one channel of one pair, fp64.  a / b: the 1200-vectors (bin = sector * 20 + ring).
+__device__ double sc_pair_exact(const void* qsig, int qdt, size_t qoff, const void* dsig, int ddt, size_t doff,
+                                double* qs /*60 x 21*/, double* ds /*1200*/, double* red, int tid) {
+  double pq = 0.0, pd = 0.0;
+  for (int i = tid; i < 1200; i += 256) {
+    const double x = ld(qsig, qdt, qoff + i), y = ld(dsig, ddt, doff + i);
+    qs[(i / 20) * 21 + (i % 20)] = x;
+    ds[i] = y;
+    pq += x * x;
+    pd += y * y;
+  }
+  const double nq = sqrt(block_sum256(pq, red, tid));
+  const double nd = sqrt(block_sum256(pd, red, tid));
+  for (int i = tid; i < 1200; i += 256) {                       // processSC.m:16,19 (0/0 = NaN stays NaN)
+    const int a = (i / 20) * 21 + (i % 20);
+    qs[a] = qs[a] / nq;
+    ds[i] = ds[i] / nd;
+  }
+  __syncthreads();
+  // thread = (variant v = 2 k0 + mirrored, half of the 60 sectors): 240 threads x 600 multiply-adds
+  double part = 0.0;
+  const int v = tid >> 1, h = tid & 1;
+  if (tid < 240) {
+    const int k0 = v >> 1, mir = v & 1;
+    for (int c = 30 * h; c < 30 * h + 30; c++) {
+      int s = mir ? k0 - c : k0 + c;                            // permute_sc, processSC.m:37-45 (0-based)
+      s = ((s % 60) + 60) % 60;
+      const double* qa = qs + s * 21;
+      const double* db = ds + c * 20;
+#pragma unroll
+      for (int r = 0; r < 20; r++) part += qa[r] * db[r];
+    }
+  }
+  red[tid] = part;
+  __syncthreads();
+  double diff = __builtin_nan("");
+  if (tid < 240 && h == 0) diff = (1.0 - (red[tid] + red[tid + 1])) / 2.0;   // processSC.m:30
+  __syncthreads();
+  return block_min256(diff, red, tid);                                        // processSC.m:31
+}
+
+// processM2DP.m:12-22 for one channel of one pair: rows [4][384], channel columns [192 ch, 192 ch + 192)
+__device__ double m2dp_pair_exact(const void* qsig, int qdt, size_t qoff, const void* dsig, int ddt, size_t doff, int ch,
+                                  double* red, int tid) {
+  // thread = (a, b, part of 16 x 12 columns)
+  const int ab = tid >> 4, part = tid & 15, a = ab >> 2, b = ab & 3;
+  double s = 0.0;
+  for (int c = part * 12; c < part * 12 + 12; c++)
+    s += ld(qsig, qdt, qoff + (size_t)a * 384 + ch * 192 + c) * ld(dsig, ddt, doff + (size_t)b * 384 + ch * 192 + c);
+  red[tid] = s;
+  __syncthreads();
+  double diff = __builtin_nan("");
+  if (part == 0) {
+    double dot = 0.0;
+    for (int p = 0; p < 16; p++) dot += red[tid + p];
+    diff = (1.0 - dot) / 2.0;                                   // processM2DP.m:15
+  }
+  __syncthreads();
+  return block_min256(diff, red, tid);                          // processM2DP.m:19
+}
+
+struct RerankArgs {
+  const void* q_sc; const void* db_sc; int sc_dt;               // raw SC signatures [m][2400] / [n_local][2400] or null
+  const void* q_m2; const void* db_m2; int m2_dt;               // raw M2DP signatures [4 m][384] / [4 n_local][384] or null
+  const double* mom_sc; const double* mom_m2;                   // [G][m][2][3] moments of all shards per descriptor type
+  int m, n_local, G, q_row0, db_row0, mask_width, kin;
+  double p_weight;
+};
+
+__device__ void chan_combine(const double* mom_all, int G, int m, int q, int ch, double& mean, double& sd) {
+  double cn = 0.0, mu = 0.0, m2 = 0.0;
+  for (int g = 0; g < G; g++) {                                 // rank order, as fuse_select_kernel
+    const double* o = mom_all + (((size_t)g * m + q) * 2 + ch) * 3;
+    const double nb = o[0], mb = o[1], m2b = o[2];
+    if (nb <= 0.0) continue;
+    const double tot = cn + nb, delta = mb - mu;
+    mu += delta * (nb / tot);
+    m2 += m2b + delta * delta * (cn * nb / tot);
+    cn = tot;
+  }
+  mean = mu;
+  sd = sqrt(m2 / (cn - 1.0));
+}
+
+__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t* __restrict__ idx_in,
+                                                      double* __restrict__ cand_score) {
+  __shared__ double qs[60 * 21];
+  __shared__ double ds[1200];
+  __shared__ double red[256];
+  const int tid = threadIdx.x, q = blockIdx.x / A.kin, t = blockIdx.x % A.kin;
+  const int jg = idx_in[(size_t)q * A.kin + t];
+  double* out = cand_score + (size_t)q * A.kin + t;
+  if (jg < 0) { if (tid == 0) *out = __builtin_nan(""); return; }
+  int dij = (A.q_row0 + q) - jg;
+  if (dij < 0) dij = -dij;
+  if (dij < A.mask_width) { if (tid == 0) *out = __builtin_inf(); return; }   // run_test.m:47-53
+  const int jl = jg - A.db_row0;
+  double f = 0.0;
+  if (A.q_sc) {
+    for (int ch = 0; ch < 2; ch++) {
+      const double d = sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + ch * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + ch * 1200,
+                                     qs, ds, red, tid);
+      double mean, sd;
+      chan_combine(A.mom_sc, A.G, A.m, q, ch, mean, sd);
+      f += (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);    // run_test.m:40
+    }
+  }
+  if (A.q_m2) {
+    for (int ch = 0; ch < 2; ch++) {
+      const double d = m2dp_pair_exact(A.q_m2, A.m2_dt, (size_t)q * 4 * 384, A.db_m2, A.m2_dt, (size_t)jl * 4 * 384, ch, red, tid);
+      double mean, sd;
+      chan_combine(A.mom_m2, A.G, A.m, q, ch, mean, sd);
+      f += (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);
+    }
+  }
+  if (tid == 0) *out = f;
+}
+
+__device__ __forceinline__ bool cand_before(double av, int aj, double bv, int bj) {   // NaN / -1 entries sort last
+  const bool abad = (aj < 0) || (av != av), bbad = (bj < 0) || (bv != bv);
+  if (abad != bbad) return bbad;
+  if (abad) return false;
+  return av < bv || (av == bv && aj < bj);
+}
+
+// one thread per query: selection of the k best of `cnt` candidates laid out with the given strides
+__device__ void select_k(const int32_t* idx, const double* sc, int cnt, int k, int32_t* oidx, double* osc, float* osc32) {
+  unsigned long long taken_lo = 0, taken_hi = 0;                // cnt <= 128
+  for (int t = 0; t < k; t++) {
+    int best = -1;
+    for (int c = 0; c < cnt; c++) {
+      const bool tk = c < 64 ? (taken_lo >> c) & 1 : (taken_hi >> (c - 64)) & 1;
+      if (tk) continue;
+      if (best < 0 || cand_before(sc[c], idx[c], sc[best], idx[best])) best = c;
+    }
+    const bool ok = best >= 0 && idx[best] >= 0 && sc[best] == sc[best];
+    if (best >= 0) { if (best < 64) taken_lo |= 1ull << best; else taken_hi |= 1ull << (best - 64); }
+    oidx[t] = ok ? idx[best] : -1;
+    const double v = ok ? sc[best] : __builtin_nan("");
+    if (osc) osc[t] = v;
+    if (osc32) osc32[t] = (float)v;
+  }
+}
+
+__global__ __launch_bounds__(64) void rerank_sort_kernel(const int32_t* __restrict__ idx_in, const double* __restrict__ cand_score,
+                                                          int m, int kin, int k, int32_t* __restrict__ idx, double* __restrict__ score,
+                                                          float* __restrict__ score32) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= m) return;
+  select_k(idx_in + (size_t)q * kin, cand_score + (size_t)q * kin, kin, k, idx + (size_t)q * k, score ? score + (size_t)q * k : nullptr,
+           score32 ? score32 + (size_t)q * k : nullptr);
+}
+
+// idx_all [G][m][k], score_all [G][m][k] -> idx [m][k], score [m][k]
+__global__ __launch_bounds__(64) void merge_topk_kernel(const int32_t* __restrict__ idx_all, const double* __restrict__ score_all,
+                                                         int G, int m, int k, int32_t* __restrict__ idx, double* __restrict__ score) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= m) return;
+  int32_t ci[128];
+  double cs[128];
+  int cnt = 0;
+  for (int g = 0; g < G; g++)
+    for (int t = 0; t < k && cnt < 128; t++, cnt++) {
+      ci[cnt] = idx_all[((size_t)g * m + q) * k + t];
+      cs[cnt] = score_all[((size_t)g * m + q) * k + t];
+    }
+  select_k(ci, cs, cnt, k, idx + (size_t)q * k, score + (size_t)q * k, nullptr);
+}
+
+}  // namespace
+
+void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, const int* qbad, const int* dbad) {
+  if (m <= 0 || n <= 0) return;
+  if (qbad) hipLaunchKernelGGL(nan_rows_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, n, qbad);
+  if (dbad) hipLaunchKernelGGL(nan_cols_kernel, dim3((n + 255) / 256, m < 64 ? m : 64), dim3(256), 0, st, d_p, d_i, m, n, dbad);
+}
+
+void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
+                   const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
+                   double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
+                   float* score32) {
+  if (m <= 0) return;
+  RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight};
+  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
+  hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
+}
+
+void launch_merge_topk(hipStream_t st, const int32_t* idx_all, const double* score_all, int G, int m, int k, int32_t* idx, double* score) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(merge_topk_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_all, score_all, G, m, k, idx, score);
+}
+
+}  // namespace pr

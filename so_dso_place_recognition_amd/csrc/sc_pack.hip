@@ -21,7 +21,8 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void sc_pack_kernel(const T* __restrict__ sig, int rows, int role,
                                                        float* __restrict__ packed, int groups,
-                                                       const double* __restrict__ tw, int* __restrict__ flags) {
+                                                       const double* __restrict__ tw, int* __restrict__ flags,
+                                                       int* __restrict__ bad) {
   __shared__ double x[1200];
   __shared__ double red[256];
   __shared__ double tws[120];
@@ -42,8 +43,11 @@ __global__ __launch_bounds__(256) void sc_pack_kernel(const T* __restrict__ sig,
     __syncthreads();
   }
   const double nr = sqrt(red[0]);
-  if (!(nr > 0.0) && tid == 0) atomicOr(flags, 1);   // MATLAB would produce a NaN row
-  for (int i = tid; i < 1200; i += 256) x[i] = x[i] / nr;   // processSC.m:16,19
+  // zero (or NaN) norm: MATLAB produces a NaN row (processSC.m:16,19).  The row is packed as zeros and
+  // marked in bad[row] (bit = channel); launch_nan_fixup writes the NaN distances behind the matcher.
+  const bool isbad = !(nr > 0.0) || !(nr < __builtin_inf());
+  if (isbad && tid == 0) { atomicOr(flags, 1); atomicOr(bad + row, 1 << ch); }
+  for (int i = tid; i < 1200; i += 256) x[i] = isbad ? 0.0 : x[i] / nr;   // processSC.m:16,19
   __syncthreads();
   const double scale = 0.12909944487358055;  // 1/sqrt(60)
   for (int o = tid; o < SC_NF * 40; o += 256) {
@@ -83,7 +87,8 @@ __global__ __launch_bounds__(256) void sc_pack_kernel(const T* __restrict__ sig,
 template <typename T>
 __global__ __launch_bounds__(320) void sc_pack_h_kernel(const T* __restrict__ sig, int rows, int role,
                                                          unsigned short* __restrict__ packed, int groups,
-                                                         const double* __restrict__ tw, int* __restrict__ flags) {
+                                                         const double* __restrict__ tw, int* __restrict__ flags,
+                                                         int* __restrict__ bad) {
   __shared__ double x[1200];
   __shared__ double red[320];
   __shared__ double tws[120];
@@ -106,8 +111,9 @@ __global__ __launch_bounds__(320) void sc_pack_h_kernel(const T* __restrict__ si
     __syncthreads();
   }
   const double nr = sqrt(red[0]);
-  if (!(nr > 0.0) && tid == 0) atomicOr(flags, 1);   // MATLAB would produce a NaN row
-  for (int i = tid; i < 1200; i += 320) x[i] = x[i] / nr;   // processSC.m:16,19
+  const bool isbad = !(nr > 0.0) || !(nr < __builtin_inf());   // see sc_pack_kernel
+  if (isbad && tid == 0) { atomicOr(flags, 1); atomicOr(bad + row, 1 << ch); }
+  for (int i = tid; i < 1200; i += 320) x[i] = isbad ? 0.0 : x[i] / nr;   // processSC.m:16,19
   __syncthreads();
   const double scale = 0.12909944487358055 * (role == 0 ? 256.0 : 128.0);  // 1/sqrt(60) x 2^8 | 2^7
   // One thread per (ring, frequency f <= 15): the bins f and 30 - f share every product, because
@@ -172,7 +178,8 @@ __global__ __launch_bounds__(320) void sc_pack_h_kernel(const T* __restrict__ si
 template <typename T, int ROLE>
 __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict__ sig, int rows,
                                                              unsigned short* __restrict__ packed, int groups,
-                                                             const double* __restrict__ tw, int* __restrict__ flags) {
+                                                             const double* __restrict__ tw, int* __restrict__ flags,
+                                                             int* __restrict__ bad) {
   constexpr int SL = ROLE == 0 ? SCH_QBLK : SCH_DFREQ;          // bytes of one (group, frequency) slice
   constexpr int NG = ROLE == 0 ? 2 : 1;                         // groups per 16 signatures
   constexpr int IMGB = ROLE == 0 ? SCH_QIMG : SCH_DIMG;
@@ -222,9 +229,11 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
 #pragma unroll
   for (int r = 0; r < 20; r++) n2 += part[lrow * 20 + r];
   const double nr = sqrt(n2);
-  if (valid && ring == 0 && fb == 0 && !(nr > 0.0)) atomicOr(flags, 1);   // MATLAB would produce a NaN row
-  const double sc = 0.12909944487358055 * (ROLE == 0 ? 256.0 : 128.0) / nr;   // 1/sqrt(60) x 2^8 | 2^7, over the norm (processSC.m:16,19)
+  const bool isbad = !(nr > 0.0) || !(nr < __builtin_inf());   // MATLAB: NaN row -> zeros here + bad[row], see sc_pack_kernel
+  if (valid && ring == 0 && fb == 0 && isbad) { atomicOr(flags, 1); atomicOr(bad + row, 1 << ch); }
+  const double sc = isbad ? 0.0 : 0.12909944487358055 * (ROLE == 0 ? 256.0 : 128.0) / nr;   // 1/sqrt(60) x 2^8 | 2^7, over the norm (processSC.m:16,19)
   auto put = [&](double val, int slice, int im) {
+    if (isbad) val = 0.0;
     // through fp32: two hardware converts instead of ~80 instructions of software f64 -> f16; the double rounding can
     // move hi by one f16 ulp in rare halfway cases, and lo = f16(val - hi) takes up the difference either way
     // (the empty asm keeps the compiler from folding the two casts back into its software f64 -> f16 sequence)
@@ -272,38 +281,38 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
 }
 
 template <typename T, int ROLE>
-void launch_pack_col(hipStream_t st, const T* sig, int rows, unsigned short* packed, int groups, const double* tw, int* flags) {
+void launch_pack_col(hipStream_t st, const T* sig, int rows, unsigned short* packed, int groups, const double* tw, int* flags, int* bad) {
   hipLaunchKernelGGL((sc_pack_h_col_kernel<T, ROLE>), dim3((unsigned)(((rows + 15) / 16 + 7) / 8) * 64), dim3(320), 0, st, sig, rows, packed,
-                     groups, tw, flags);
+                     groups, tw, flags, bad);
 }
 
 }  // namespace
 
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
-                      const double* twiddle, int* flags) {
+                      const double* twiddle, int* flags, int* bad) {
   if (rows <= 0) return;
   static const bool valu = getenv("PR_SC_PACK") && !strcmp(getenv("PR_SC_PACK"), "valu");   // the per-thread DFT, kept for A/B runs
   if (valu && dtype == 0)
     hipLaunchKernelGGL(sc_pack_h_kernel<double>, dim3(rows * 2), dim3(320), 0, st, (const double*)sig, rows, role,
-                       (unsigned short*)packed, groups, twiddle, flags);
+                       (unsigned short*)packed, groups, twiddle, flags, bad);
   else if (valu)
     hipLaunchKernelGGL(sc_pack_h_kernel<float>, dim3(rows * 2), dim3(320), 0, st, (const float*)sig, rows, role,
-                       (unsigned short*)packed, groups, twiddle, flags);
-  else if (dtype == 0 && role == 0) launch_pack_col<double, 0>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags);
-  else if (dtype == 0) launch_pack_col<double, 1>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags);
-  else if (role == 0) launch_pack_col<float, 0>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags);
-  else launch_pack_col<float, 1>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags);
+                       (unsigned short*)packed, groups, twiddle, flags, bad);
+  else if (dtype == 0 && role == 0) launch_pack_col<double, 0>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
+  else if (dtype == 0) launch_pack_col<double, 1>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
+  else if (role == 0) launch_pack_col<float, 0>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
+  else launch_pack_col<float, 1>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
 }
 
 void launch_sc_pack(hipStream_t st, const void* sig, int dtype, int rows, int role, float* packed, int groups,
-                    const double* twiddle, int* flags) {
+                    const double* twiddle, int* flags, int* bad) {
   if (rows <= 0) return;
   if (dtype == 0)
     hipLaunchKernelGGL(sc_pack_kernel<double>, dim3(rows * 2), dim3(256), 0, st, (const double*)sig, rows, role,
-                       packed, groups, twiddle, flags);
+                       packed, groups, twiddle, flags, bad);
   else
     hipLaunchKernelGGL(sc_pack_kernel<float>, dim3(rows * 2), dim3(256), 0, st, (const float*)sig, rows, role,
-                       packed, groups, twiddle, flags);
+                       packed, groups, twiddle, flags, bad);
 }
 
 }  // namespace pr

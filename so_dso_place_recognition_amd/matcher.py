@@ -2,14 +2,20 @@
 database row-sharded over the ranks of a torch.distributed group (one process per GPU, RCCL over xGMI).
 
 PyTorch is plumbing here (device buffers, streams, the two small collectives); all arithmetic is in
-libpr_amd.so through the C ABI (plain device pointers).
+libpr_amd.so through the C ABI (plain device pointers).  The library context is created ON torch's current
+stream (pr_create_on_stream), so the library's kernels, torch's allocations and RCCL's collectives are ordered
+by the stream itself: a step has no host synchronisation at all.
 
 Sharding: every rank holds the DB rows [db_row0, db_row0 + n_local) and ALL queries.
-  1. local: pack, distances (m x n_local), per-row fp64 moments (count, mean, M2) per channel   [HIP]
-  2. all_gather of the moments  (m x 2 x 3 f64 per rank = 48 B per query)                             [RCCL]
-  3. local: Chan-combine in rank order -> global mean/std, fused score, mask on GLOBAL indices,
-     per-shard top-k (ties -> lower global index)                                                    [HIP]
-  4. all_gather of (idx, score) (8k B per query per rank), k-way merge by (score, idx)               [RCCL + tiny sort]
+  1. local: pack, distances (m x n_local), per-row fp64 moments (count, mean, M2) per channel          [HIP]
+  2. all_gather_into_tensor of the moments  (m x 2 x 3 f64 per rank = 48 B per query)                        [RCCL]
+     (all-gather + Chan combination in rank order instead of §8-e's all-reduce: same bytes at this size, and the
+     result does not depend on the reduction order RCCL happens to pick - every rank computes the same bits)
+  3. local: Chan-combine -> global mean/std, fused fp32 score, mask on GLOBAL indices, per-shard top-(k+8)
+     (ties -> lower global index), then the fp64 re-evaluation of those survivors from the raw signatures
+     (pr_rerank_dev) -> per-shard top-k with the reference's double scores                              [HIP]
+  4. all_gather_into_tensor of (idx i32, score f64) (12k B per query per rank), k-way merge on the device
+     by (score, idx) (pr_merge_topk_dev)                                                                 [RCCL + HIP]
 With one rank steps 2 and 4 are skipped.
 """
 from __future__ import annotations
@@ -23,27 +29,54 @@ from . import _lib
 from .api import Context
 
 
-def _dptr(t: torch.Tensor):
+def _dptr(t: torch.Tensor | None):
+    if t is None:
+        return None
     assert t.is_cuda and t.is_contiguous()
     return C.c_void_p(t.data_ptr())
 
 
-class Matcher:
+def _torch_dt(t: torch.Tensor) -> int:
+    return {torch.float64: _lib.F64, torch.float32: _lib.F32}[t.dtype]
+
+
+def _stream_context(device: int, **kw) -> Context:
+    """A library context whose kernels run on torch's current stream of that device."""
+    return Context(device, stream=int(torch.cuda.current_stream(device).cuda_stream), **kw)
+
+
+class _Base:
+    def _init_ctx(self, ctx, device):
+        if device is None:
+            device = ctx.device if ctx is not None else torch.cuda.current_device()
+        self.ctx = ctx or _stream_context(device)
+        self.dev = torch.device("cuda", self.ctx.device)
+        self.lib = self.ctx.lib
+        # a context on its own stream (the caller built it that way) needs the two streams joined by hand
+        self.shared_stream = self.ctx.stream == int(torch.cuda.current_stream(self.dev).cuda_stream)
+
+    def _enter(self):      # torch work issued so far must be visible to the library's stream
+        if not self.shared_stream:
+            torch.cuda.current_stream(self.dev).synchronize()
+
+    def _leave(self):      # ... and the library's work to torch's
+        if not self.shared_stream:
+            self.ctx.sync()
+
+
+class Matcher(_Base):
     def __init__(self, type_: str, max_queries: int, max_db: int, ctx: Context | None = None, device: int | None = None):
         self.type = {"sc": _lib.TYPE_SC, "m2dp": _lib.TYPE_M2DP, "delight": _lib.TYPE_DELIGHT}[type_]
         self.rows_per_sig, self.sig_len = {_lib.TYPE_SC: (1, 2400), _lib.TYPE_M2DP: (4, 384), _lib.TYPE_DELIGHT: (16, 256)}[self.type]
         self.plain = self.type == _lib.TYPE_DELIGHT      # one distance matrix, no z-score fusion (run_test.m:26-36)
-        if device is None:
-            device = torch.cuda.current_device()
-        self.ctx = ctx or Context(device)
-        self.dev = torch.device("cuda", self.ctx.device)
-        self.lib = self.ctx.lib
+        self._init_ctx(ctx, device)
         self.q = C.c_void_p()
         self.db = C.c_void_p()
         self.ctx.check(self.lib.pr_sigset_create(self.ctx.h, self.type, _lib.ROLE_QUERY, max_queries, C.byref(self.q)))
         self.ctx.check(self.lib.pr_sigset_create(self.ctx.h, self.type, _lib.ROLE_DB, max_db, C.byref(self.db)))
         self.max_queries, self.max_db = max_queries, max_db
         self.n = 0
+        self.db_sig = None             # the raw DB shard (the fp64 re-evaluation reads it)
         self._bufs = {}
         self.pre_distances = None      # optional callables (e.g. HIP event records) around the distance launch
         self.post_distances = None
@@ -64,71 +97,95 @@ class Matcher:
     def _pack(self, handle, sig: torch.Tensor):
         assert sig.is_cuda and sig.is_contiguous() and sig.dim() == 2 and sig.shape[1] == self.sig_len
         assert sig.shape[0] % self.rows_per_sig == 0
-        dt = {torch.float64: _lib.F64, torch.float32: _lib.F32}[sig.dtype]
         n = sig.shape[0] // self.rows_per_sig
-        self.ctx.check(self.lib.pr_sigset_pack(self.ctx.h, handle, _dptr(sig), dt, _lib.DEVICE, n))
+        self.ctx.check(self.lib.pr_sigset_pack(self.ctx.h, handle, _dptr(sig), _torch_dt(sig), _lib.DEVICE, n))
         return n
 
     def pack_database(self, sig: torch.Tensor):
-        """processSC.m:18-20 (normalise hist2) + operand layout; sig: device [n(*4), sig_len] f64/f32."""
-        torch.cuda.current_stream(self.dev).synchronize()
+        """processSC.m:18-20 (normalise hist2) + operand layout; sig: device [n(*4), sig_len] f64/f32 (kept: the
+        re-evaluation of the selected pairs reads the raw rows)."""
+        self._enter()
         self.n = self._pack(self.db, sig)
+        self.db_sig = sig
 
-    def match(self, queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
-              db_row0: int = 0, q_row0: int = 0, group=None):
-        """Returns (idx int32 [m,k] GLOBAL DB row indices, score float32 [m,k]) as device tensors."""
-        import torch.distributed as dist
-        torch.cuda.current_stream(self.dev).synchronize()
+    def local_phase1(self, queries: torch.Tensor):
+        """pack(q) + distances + row moments of this shard -> moments [m, 2, 3] f64 (zeros for DELIGHT)."""
+        self._enter()
         m = self._pack(self.q, queries)
         n = self.n
-        G = dist.get_world_size(group) if (group is not None or (dist.is_available() and dist.is_initialized())) else 1
+        self._q_sig, self._m = queries, m
         d_p = self._buf("d_p", (m, n), torch.float32)
         d_i = None if self.plain else self._buf("d_i", (m, n), torch.float32)
         mom = self._buf("mom", (m, 2, 3), torch.float64)
-        idx = self._buf("idx", (m, k), torch.int32)
-        score = self._buf("score", (m, k), torch.float32)
         lib, h = self.lib, self.ctx.h
         if self.pre_distances:
             self.pre_distances()
-        p_i = None if self.plain else _dptr(d_i)
-        self.ctx.check(lib.pr_distances_dev(h, self.q, self.db, _dptr(d_p), p_i))
+        self.ctx.check(lib.pr_distances_dev(h, self.q, self.db, _dptr(d_p), _dptr(d_i)))
         if self.post_distances:
             self.post_distances()
-
-        def local_moments():
-            if self.plain:
-                mom.zero_()
-                torch.cuda.current_stream(self.dev).synchronize()
-                return mom
+        if self.plain:
+            self._leave()
+            mom.zero_()
+        else:
             self.ctx.check(lib.pr_row_moments_dev(h, _dptr(d_p), _dptr(d_i), m, n, _dptr(mom)))
-            if G > 1:
-                self.ctx.sync()
-            return mom
+            self._leave()
+        return mom
 
-        def local_select(mom_all, G_):
-            if G_ > 1:
-                torch.cuda.current_stream(self.dev).synchronize()
-            self.ctx.check(lib.pr_fuse_select_dev(h, _dptr(d_p), p_i, m, n, _dptr(mom_all), G_, q_row0, db_row0,
-                                                  int(mask_width), float(p_weight), int(k), _dptr(idx), _dptr(score)))
-            self.ctx.sync()
-            return idx, score
+    def local_phase2(self, mom_all: torch.Tensor, G: int, mask_width, p_weight, k, db_row0, q_row0):
+        """fp32 selection of the k + 8 best of this shard with the moments of all shards, fp64 re-evaluation -> (idx, score)."""
+        m, n = self._m, self.n
+        lib, h = self.lib, self.ctx.h
+        d_p, d_i = self._bufs["d_p"], self._bufs.get("d_i")
+        kin = k if self.plain else min(k + 8, 128)
+        idx_in = self._buf("idx_in", (m, kin), torch.int32)
+        sc32 = self._buf("sc32", (m, kin), torch.float32)
+        idx = self._buf("idx", (m, k), torch.int32)
+        score = self._buf("score", (m, k), torch.float64)
+        mom_all = mom_all.contiguous()
+        self._enter()
+        self.ctx.check(lib.pr_fuse_select_dev(h, _dptr(d_p), None if self.plain else _dptr(d_i), m, n, _dptr(mom_all), G, q_row0, db_row0,
+                                              int(mask_width), float(p_weight), int(kin), _dptr(idx_in), _dptr(sc32)))
+        if self.plain:
+            self._leave()
+            return idx_in, sc32.to(torch.float64)
+        sc = self.type == _lib.TYPE_SC
+        raw = (_dptr(self._q_sig), _dptr(self.db_sig), _torch_dt(self.db_sig))
+        none = (None, None, 0)
+        assert self._q_sig.dtype == self.db_sig.dtype
+        self.ctx.check(lib.pr_rerank_dev(h, *(raw if sc else none), *(none if sc else raw), _dptr(mom_all) if sc else None,
+                                         None if sc else _dptr(mom_all), m, n, G, q_row0, db_row0, int(mask_width), float(p_weight),
+                                         kin, _dptr(idx_in), int(k), _dptr(idx), _dptr(score)))
+        self._leave()
+        return idx, score
 
-        return sharded_topk(local_moments, local_select, k, group if G > 1 else None, G)
+    def merge(self, idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
+        return _merge_dev(self, idx_all, sc_all, k)
+
+    def match(self, queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
+              db_row0: int = 0, q_row0: int = 0, group=None):
+        """Returns (idx int32 [m,k] GLOBAL DB row indices, score float64 [m,k]) as device tensors."""
+        G = _world(group)
+        return sharded_topk(lambda: self.local_phase1(queries),
+                            lambda mom_all, G_: self.local_phase2(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
+                            k, group if G > 1 else None, G, merge=self.merge)
 
     def distances(self):
         """The last distance matrices (device, float32 [m, n_local])."""
         return self._bufs["d_p"], self._bufs.get("d_i")
 
 
-class FusedMatcher:
+class FusedMatcher(_Base):
     """BASELINE.json config 5 ("fused SC + M2DP scoring", build-defined: DESIGN.md §7): an SC and an M2DP matcher over the
     same places; the four row z-scores are added (weights p, 1, p, 1) in ONE top-k pass (pr_fuse_select2_dev).  Shards like
     Matcher: the moments of both descriptor types travel in the same all_gather ([m, 4, 3] f64 per rank)."""
 
     def __init__(self, max_queries: int, max_db: int, ctx: Context | None = None, device: int | None = None):
-        self.sc = Matcher("sc", max_queries, max_db, ctx, device)
-        self.m2 = Matcher("m2dp", max_queries, max_db, self.sc.ctx)
-        self.ctx, self.dev, self.lib = self.sc.ctx, self.sc.dev, self.sc.lib
+        self._init_ctx(ctx, device)
+        self.sc = Matcher("sc", max_queries, max_db, self.ctx)
+        self.m2 = Matcher("m2dp", max_queries, max_db, self.ctx)
+        self._bufs = {}
+
+    _buf = Matcher._buf
 
     def close(self):
         self.sc.close(); self.m2.close()
@@ -137,66 +194,90 @@ class FusedMatcher:
         self.sc.pack_database(sc_sig); self.m2.pack_database(m2dp_sig)
         assert self.sc.n == self.m2.n, "the two databases must describe the same places"
 
+    def local_phase1(self, sc_queries, m2dp_queries):
+        a = self.sc.local_phase1(sc_queries)
+        b = self.m2.local_phase1(m2dp_queries)
+        assert self.sc._m == self.m2._m
+        return torch.cat([a, b], dim=1)                                    # [m, 4, 3]
+
+    def local_phase2(self, mom_all, G, mask_width, p_weight, k, db_row0, q_row0):
+        m, n = self.sc._m, self.sc.n
+        lib, h = self.lib, self.ctx.h
+        mom_all = mom_all.reshape(G, m, 4, 3)
+        m1, m2 = mom_all[:, :, :2].contiguous(), mom_all[:, :, 2:].contiguous()
+        d = [self.sc._bufs["d_p"], self.sc._bufs["d_i"], self.m2._bufs["d_p"], self.m2._bufs["d_i"]]
+        kin = min(k + 8, 128)
+        idx_in = self._buf("idx_in", (m, kin), torch.int32)
+        sc32 = self._buf("sc32", (m, kin), torch.float32)
+        idx = self._buf("idx", (m, k), torch.int32)
+        score = self._buf("score", (m, k), torch.float64)
+        self._enter()
+        self.ctx.check(lib.pr_fuse_select2_dev(h, _dptr(d[0]), _dptr(d[1]), _dptr(d[2]), _dptr(d[3]), m, n, _dptr(m1), _dptr(m2), G,
+                                               q_row0, db_row0, int(mask_width), float(p_weight), int(kin), _dptr(idx_in), _dptr(sc32)))
+        self.ctx.check(lib.pr_rerank_dev(h, _dptr(self.sc._q_sig), _dptr(self.sc.db_sig), _torch_dt(self.sc.db_sig),
+                                         _dptr(self.m2._q_sig), _dptr(self.m2.db_sig), _torch_dt(self.m2.db_sig), _dptr(m1), _dptr(m2),
+                                         m, n, G, q_row0, db_row0, int(mask_width), float(p_weight), kin, _dptr(idx_in), int(k),
+                                         _dptr(idx), _dptr(score)))
+        self._leave()
+        return idx, score
+
+    def merge(self, idx_all, sc_all, k):
+        return _merge_dev(self, idx_all, sc_all, k)
+
     def match(self, sc_queries: torch.Tensor, m2dp_queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
               db_row0: int = 0, q_row0: int = 0, group=None):
-        import torch.distributed as dist
-        torch.cuda.current_stream(self.dev).synchronize()
-        m = self.sc._pack(self.sc.q, sc_queries)
-        assert self.m2._pack(self.m2.q, m2dp_queries) == m
-        n = self.sc.n
-        G = dist.get_world_size(group) if (group is not None or (dist.is_available() and dist.is_initialized())) else 1
-        lib, h = self.lib, self.ctx.h
-        d = [self.sc._buf("d_p", (m, n), torch.float32), self.sc._buf("d_i", (m, n), torch.float32),
-             self.m2._buf("d_p", (m, n), torch.float32), self.m2._buf("d_i", (m, n), torch.float32)]
-        mom = [self.sc._buf("mom", (m, 2, 3), torch.float64), self.m2._buf("mom", (m, 2, 3), torch.float64)]
-        idx = self.sc._buf("idx", (m, k), torch.int32)
-        score = self.sc._buf("score", (m, k), torch.float32)
-        self.ctx.check(lib.pr_distances_dev(h, self.sc.q, self.sc.db, _dptr(d[0]), _dptr(d[1])))
-        self.ctx.check(lib.pr_distances_dev(h, self.m2.q, self.m2.db, _dptr(d[2]), _dptr(d[3])))
-
-        def local_moments():
-            self.ctx.check(lib.pr_row_moments_dev(h, _dptr(d[0]), _dptr(d[1]), m, n, _dptr(mom[0])))
-            self.ctx.check(lib.pr_row_moments_dev(h, _dptr(d[2]), _dptr(d[3]), m, n, _dptr(mom[1])))
-            self.ctx.sync()
-            return torch.cat(mom, dim=1)                                   # [m, 4, 3]
-
-        def local_select(mom_all, G_):
-            mom_all = mom_all.reshape(G_, m, 4, 3)
-            m1, m2 = mom_all[:, :, :2].contiguous(), mom_all[:, :, 2:].contiguous()
-            torch.cuda.current_stream(self.dev).synchronize()
-            self.ctx.check(lib.pr_fuse_select2_dev(h, _dptr(d[0]), _dptr(d[1]), _dptr(d[2]), _dptr(d[3]), m, n, _dptr(m1), _dptr(m2), G_,
-                                                   q_row0, db_row0, int(mask_width), float(p_weight), int(k), _dptr(idx), _dptr(score)))
-            self.ctx.sync()
-            return idx, score
-
-        return sharded_topk(local_moments, local_select, k, group if G > 1 else None, G)
+        G = _world(group)
+        return sharded_topk(lambda: self.local_phase1(sc_queries, m2dp_queries),
+                            lambda mom_all, G_: self.local_phase2(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
+                            k, group if G > 1 else None, G, merge=self.merge)
 
 
-def sharded_topk(local_moments, local_select, k: int, group, G: int):
+def _world(group) -> int:
+    import torch.distributed as dist
+    return dist.get_world_size(group) if (group is not None or (dist.is_available() and dist.is_initialized())) else 1
+
+
+def _merge_dev(owner, idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
+    """pr_merge_topk_dev on [G, m, k] device tensors."""
+    G, m, kk = idx_all.shape
+    assert kk == k
+    idx = torch.empty((m, k), dtype=torch.int32, device=idx_all.device)
+    score = torch.empty((m, k), dtype=torch.float64, device=idx_all.device)
+    owner._enter()
+    owner.ctx.check(owner.lib.pr_merge_topk_dev(owner.ctx.h, _dptr(idx_all.contiguous()), _dptr(sc_all.contiguous()), G, m, k,
+                                                _dptr(idx), _dptr(score)))
+    owner._leave()
+    return idx, score
+
+
+def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None):
     """The exchange protocol of SURVEY.md §8-e around two local callables (HIP in production; a numpy stand-in in
     the gloo CPU tests): moments -> all_gather -> select with the moments of all shards -> all_gather -> merge."""
     import torch.distributed as dist
     mom = local_moments()
     if G == 1:
-        return local_select(mom, 1)
+        return local_select(mom.unsqueeze(0) if mom.dim() == 3 else mom, 1)
     stage_on_host = dist.get_backend(group) == "gloo"   # gloo has no device all_gather: used by the single-GPU tests
 
-    def gather(t):   # list form: identical semantics on nccl (RCCL) and gloo
+    def gather(t):   # output = the ranks' tensors concatenated along dim 0, viewed as [G, ...]
         src = t.contiguous()
         if stage_on_host and src.is_cuda:
             src = src.cpu()
-        outs = [torch.empty_like(src) for _ in range(G)]
-        dist.all_gather(outs, src, group=group)
-        return torch.stack(outs).to(t.device)
+        out = torch.empty((G * src.shape[0],) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)
+        dist.all_gather_into_tensor(out, src, group=group)   # nccl: RCCL, on the stream the library's kernels run on
+        return out.view((G,) + tuple(src.shape)).to(t.device)
 
     mom_all = gather(mom)
     idx, score = local_select(mom_all, G)
     idx_all, sc_all = gather(idx), gather(score)
+    if merge is not None and idx_all.is_cuda:
+        return merge(idx_all, sc_all, k)
     return merge_topk(idx_all, sc_all, k)
 
 
 def merge_topk(idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
-    """k-way merge of per-shard top-k lists [G, m, k] by (score, index) ascending; -1 / NaN entries sort last."""
+    """k-way merge of per-shard top-k lists [G, m, k] by (score, index) ascending; -1 / NaN entries sort last.
+    (torch restatement of pr_merge_topk_dev for host tensors: the gloo tests)"""
     G, m, kk = idx_all.shape
     idx = idx_all.permute(1, 0, 2).reshape(m, G * kk).to(torch.int64)
     sc = sc_all.permute(1, 0, 2).reshape(m, G * kk).to(torch.float64)
@@ -205,8 +286,12 @@ def merge_topk(idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
     idx_key = torch.where(bad, torch.full_like(idx, 2 ** 62), idx)
     o1 = torch.argsort(idx_key, dim=1, stable=True)
     sc1 = torch.gather(sc, 1, o1)
-    o2 = torch.argsort(sc1, dim=1, stable=True)
-    order = torch.gather(o1, 1, o2)[:, :k]
+    bad1 = torch.gather(bad, 1, o1)
+    # bad entries after every good one, also after good +Inf scores
+    key2 = torch.where(bad1, torch.full_like(sc1, float("inf")), sc1)
+    o2 = torch.argsort(key2 + 0.0, dim=1, stable=True)
+    o2b = torch.argsort(torch.gather(bad1, 1, o2).to(torch.int8), dim=1, stable=True)
+    order = torch.gather(o1, 1, torch.gather(o2, 1, o2b))[:, :k]
     out_idx = torch.gather(idx, 1, order)
     out_sc = torch.gather(sc_all.permute(1, 0, 2).reshape(m, G * kk), 1, order)
     out_bad = torch.gather(bad, 1, order)

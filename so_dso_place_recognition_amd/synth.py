@@ -182,3 +182,100 @@ def bow_signatures(seed: int, n: int, cols: int = 120, vocab: int = 400, fill=(2
 def gist_signatures(seed: int, n: int, cols: int = 96):
     rng = np.random.default_rng(seed)
     return np.abs(rng.normal(0.1, 0.05, size=(n, cols)))
+
+
+# ----------------------------------------------------------------------------- the same samplers on a torch device
+# Bit-identical to the numpy versions above (uint64 arithmetic carried in int64 two's complement: add / multiply wrap,
+# logical shifts by masking), so that full-size inputs (10^5 - 10^6 signatures, 5000 x 50 000 points) are drawn in HBM in
+# a fraction of a second instead of minutes of host time.  tests/test_synth_torch.py pins them against the numpy versions.
+def _s64(x: int) -> int:
+    x &= 0xFFFFFFFFFFFFFFFF
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def _t_lsr(z, s: int):
+    return (z >> s) & ((1 << (64 - s)) - 1)
+
+
+def _t_splitmix64(x):
+    z = x + _s64(0x9E3779B97F4A7C15)
+    z = (z ^ _t_lsr(z, 30)) * _s64(0xBF58476D1CE4E5B9)
+    z = (z ^ _t_lsr(z, 27)) * _s64(0x94D049BB133111EB)
+    return z ^ _t_lsr(z, 31)
+
+
+def uniform_torch(seed: int, streams, count: int, offset: int = 0):
+    """streams: int64 tensor [S] (on the target device) -> U[0,1) float64 [S, count], == uniform(seed, streams, count, offset)."""
+    import torch
+    b = _t_splitmix64(_t_splitmix64(streams) ^ _s64(seed))
+    ctr = torch.arange(offset, offset + count, dtype=torch.int64, device=streams.device)
+    h = _t_splitmix64(b[:, None] + ctr[None, :])
+    return _t_lsr(h, 11).to(torch.float64) * (2.0 ** -53)
+
+
+def sc_database_torch(seed: int, n: int, first: int = 0, device="cuda", chunk: int = 8192):
+    """== sc_database(seed, n, first) as a float64 tensor on `device`."""
+    import torch
+    out = torch.empty((n, 2400), dtype=torch.float64, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        u = uniform_torch(seed, torch.arange(first + s, first + e, dtype=torch.int64, device=device), 3600).reshape(e - s, 3, 1200)
+        occ = u[:, 0] < 0.6
+        out[s:e, :1200] = torch.where(occ, 8.0 * u[:, 1], torch.zeros_like(u[:, 1]))
+        out[s:e, 1200:] = (occ & (u[:, 2] < 0.45)).to(torch.float64)
+    return out
+
+
+def m2dp_database_torch(seed: int, n: int, first: int = 0, device="cuda", chunk: int = 8192):
+    """== m2dp_database(seed, n, first) up to the last ulp of the row norms (torch reduces the 64 / 128 squares in another
+    order than numpy); float64 [4n, 384] on `device`."""
+    import torch
+    out = torch.empty((4 * n, 384), dtype=torch.float64, device=device)
+    for s in range(0, n, chunk):
+        e = min(n, s + chunk)
+        u = uniform_torch(seed, torch.arange(first + s, first + e, dtype=torch.int64, device=device), 384 * 5).reshape(e - s, 5, 2, 192)
+        w = 0.3 + u[:, :1] + 0.15 * (u[:, 1:] - 0.5)
+        uu = w[..., :64] / torch.sqrt((w[..., :64] ** 2).sum(-1, keepdim=True))
+        vv = w[..., 64:] / torch.sqrt((w[..., 64:] ** 2).sum(-1, keepdim=True))
+        out[4 * s:4 * e] = torch.cat([uu, vv], -1).reshape(4 * (e - s), 384)
+    return out
+
+
+def scene_clouds_torch(seed: int, N: int, P: int, max_rho: float = 45.0, first: int = 0, device="cuda", chunk: int = 64):
+    """== scene_clouds(seed, N, P, max_rho, first) as device tensors (xyz f64 [N*P,3], inten f32 [N*P], offs i64 [N+1]):
+    the first P accepted points of the first int(1.3 P) + 64 draws of every cloud (clouds whose first round accepts fewer
+    than P points - none with the §8-d scene parameters - are drawn by the numpy sampler)."""
+    import torch
+    n = int(P * 1.3) + 64
+    xyz = torch.empty((N * P, 3), dtype=torch.float64, device=device)
+    it = torch.empty((N * P,), dtype=torch.float32, device=device)
+    for c0 in range(0, N, chunk):
+        c1 = min(N, c0 + chunk)
+        C_ = c1 - c0
+        cl = torch.arange(first + c0, first + c1, dtype=torch.int64, device=device)
+        bx = uniform_torch(seed, cl * 4 + 0, 32 * 7).reshape(C_, 32, 7)
+        centre = torch.stack([-38 + 76 * bx[..., 0], -4 + 5 * bx[..., 1], -24 + 48 * bx[..., 2]], -1)
+        half = torch.stack([0.5 + 3.5 * bx[..., 3], 0.5 + 2.5 * bx[..., 4], 0.5 + 3.5 * bx[..., 5]], -1)
+        base_i = 20 + 215 * bx[..., 6]
+        u = uniform_torch(seed, cl * 4 + 1, n * 6).reshape(C_, n, 6)
+        ground = u[..., 0] < 0.3
+        box = torch.clamp((u[..., 1] * 32).to(torch.int64), max=31)
+        pg = torch.stack([-42 + 84 * u[..., 2], 1.6 + (-0.05 + 0.1 * u[..., 3]), -28 + 56 * u[..., 4]], -1)
+        gi = box[..., None].expand(-1, -1, 3)
+        pb = torch.gather(centre, 1, gi) + torch.gather(half, 1, gi) * (2 * u[..., 2:5] - 1)
+        p = torch.where(ground[..., None], pg, pb)
+        inten = torch.where(ground, torch.full_like(u[..., 5], 60.0), torch.gather(base_i, 1, box)) + (-20 + 40 * u[..., 5])
+        ok = ((p[..., 0] * p[..., 0] + p[..., 1] * p[..., 1]) + p[..., 2] * p[..., 2]) < max_rho * max_rho
+        rank = torch.cumsum(ok.to(torch.int64), 1) - 1
+        have = rank[:, -1] + 1
+        take = ok & (rank < P)
+        ci, pi = torch.nonzero(take, as_tuple=True)
+        dst = (c0 + ci) * P + rank[ci, pi]
+        full = have[ci] >= P
+        xyz[dst[full]] = p[ci[full], pi[full]]
+        it[dst[full]] = inten[ci[full], pi[full]].to(torch.float32)
+        for c in torch.nonzero(have < P).flatten().tolist():          # not seen with the §8-d parameters
+            a, b = scene_cloud(seed, first + c0 + c, P, max_rho)
+            xyz[(c0 + c) * P:(c0 + c + 1) * P] = torch.from_numpy(a).to(device)
+            it[(c0 + c) * P:(c0 + c + 1) * P] = torch.from_numpy(b).to(device)
+    return xyz, it, torch.arange(N + 1, dtype=torch.int64, device=device) * P

@@ -61,7 +61,7 @@ def test_config1_end_to_end(golden_dir, tmp_path):
         m = np.loadtxt(res)
         rc, oidx, osc = oracle_lib.match_topk(t, got, got, 10, 2.0, 2)         # same (text-rounded) inputs on both sides
         assert np.array_equal(m[:, [0, 2]].astype(np.int32), oidx)
-        assert np.abs(m[:, [1, 3]] - osc).max() < 5e-4
+        assert np.abs(m[:, [1, 3]] - osc).max() < 1e-5
 
 
 @pytest.mark.gpu
@@ -106,3 +106,50 @@ def test_match_signatures_gist_and_bow(tmp_path):
         m = np.loadtxt(res)
         assert np.array_equal(m[:, [0, 2]].astype(np.int32), oidx)
         assert np.abs(m[:, [1, 3]] - osc).max() < 1e-5 * max(1.0, np.abs(osc).max())
+
+
+@pytest.mark.gpu
+def test_config1_full_kitti_seq00(ref_sequence, tmp_path):
+    """BASELINE.json config 1 at its stated size: all 3505 poses of the reference's KITTI seq00 file x 400 synthetic points per
+    pose (the reference's point file is a missing blob) through test_sc / test_m2dp / match_signatures --mask_width 100
+    (test_kitti.m:19).  The incoming ids must be byte-equal to the file the reference itself holds
+    (results/KITTI/seq00/incoming_id_file.txt); every signature is compared with the oracle's, the matches on a row sample."""
+    poses, ref_ids = ref_sequence("kitti_seq00")
+    pts = str(tmp_path / "pts_history_file.txt")
+    helpers.write_synthetic_points(poses, pts, per_pose=400)
+    sigs = {}
+    for exe, key, polar in (("test_sc", "sc_file", False), ("test_m2dp", "m2dp_file", True)):
+        sig = str(tmp_path / f"history_{exe}.txt"); ids = str(tmp_path / f"ids_{exe}.txt")
+        r = subprocess.run([os.path.join(BIN, exe), f"_poses_history_file:={poses}", f"_pts_history_file:={pts}",
+                            f"_{key}:={sig}", f"_incoming_id_file:={ids}", "_lidarRange:=45.0"], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        assert open(ids, "rb").read() == open(ref_ids, "rb").read()                  # the reference's own known answer
+        x, it, offs, oid = oracle_lib.pts_preprocess(poses, pts, None, 45.0, polar)
+        assert len(oid) == 3475
+        got = np.loadtxt(sig)
+        want = oracle_lib.m2dp_generate(x, it, offs) if polar else oracle_lib.sc_generate(x, it, offs)
+        assert got.shape == want.shape
+        bad = ~np.isclose(got, want, rtol=2e-5, atol=1e-12)                          # 6 significant digits in the text
+        if polar:   # a cloud whose two leading singular values nearly coincide has no unique leading pair (N6): tolerate a handful of rows
+            assert bad.any(1).sum() <= 8, bad.any(1).sum()
+        else:
+            assert not bad.any()
+        sigs[exe] = (sig, got)
+    rows = np.arange(0, 3475, 217)
+    for type_, exe, t in (("sc", "test_sc", 0), ("m2dp", "test_m2dp", 1)):
+        sig, got = sigs[exe]
+        res = str(tmp_path / f"match_{type_}.txt")
+        r = subprocess.run([os.path.join(BIN, "match_signatures"), "--type", type_, "--hist1", sig, "--hist2", sig,
+                            "--mask_width", "100", "--out", res], capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        mres = np.loadtxt(res)
+        div = 4 if t else 1
+        qr = got.reshape(-1, div, got.shape[1])[rows].reshape(-1, got.shape[1])
+        fn = oracle_lib.m2dp_distance if t else oracle_lib.sc_distance
+        rc, a, b = fn(got, qr)                                                       # roles swapped (symmetric distance), see test_gpu_configs.py
+        dp, di = a.T, b.T
+        z = lambda d: (d - d.mean(1, keepdims=True)) / np.sqrt(((d - d.mean(1, keepdims=True)) ** 2).sum(1, keepdims=True) / (d.shape[1] - 1))
+        f = 2.0 * z(dp) + z(di)
+        f[np.abs(rows[:, None] - np.arange(f.shape[1])[None, :]) < 100] = np.inf
+        assert np.array_equal(mres[rows, 0].astype(np.int64), f.argmin(1))
+        assert np.abs(mres[rows, 1] - f.min(1)).max() < 1e-5

@@ -101,3 +101,23 @@ def test_drivers_run_kitti_and_run_robotcar():
     f = _rff(both, scale=40.0)
     auc, top_recall, det = ev.run_robotcar(d1, d2, "gist", hist1=f[: len(g1)], hist2=f[len(g1):])
     assert auc > 0.9 and top_recall > 0.3 and all(((g1[a] - g2[b]) ** 2).sum() < 625.0 for a, b in det)
+
+
+def test_c_abi_precision_recall_equals_the_python_restatement():
+    """pr_precision_recall (what `match_signatures --gt1 --gt2 --loop_diff` prints) against eval.precision_recall."""
+    import ctypes as C
+    from so_dso_place_recognition_amd import _lib, eval as E
+    lib = _lib.load()
+    rng = np.random.default_rng(1)
+    for m, n, mask, ld in ((200, 220, 5, 10.0), (50, 50, 0, 3.0), (7, 3, 2, 1e9), (5, 5, 100, 10.0)):
+        gt1 = np.cumsum(rng.normal(0, 3, (m, 3)), 0)
+        gt2 = np.concatenate([gt1[:n // 2] + rng.normal(0, 1, (n // 2, 3)), rng.normal(0, 100, (n - n // 2, 3))])[:n]
+        v = rng.random(m); idx = rng.integers(0, n, m).astype(np.int32)
+        idx[:min(m, n) // 2] = np.arange(min(m, n) // 2); v[:min(m, n) // 2] *= 0.3
+        a = E.precision_recall(v, idx, gt1, gt2, ld, mask)
+        auc, tr, nd = C.c_double(), C.c_double(), C.c_int32()
+        lp = np.zeros((m, 2), np.int32)
+        p = lambda x: x.ctypes.data_as(C.c_void_p)
+        assert lib.pr_precision_recall(p(v), p(idx), m, p(gt1), p(gt2), n, 3, ld, mask, C.byref(auc), C.byref(tr), p(lp), C.byref(nd)) == 0
+        assert (np.isnan(a[0]) and np.isnan(auc.value)) or abs(a[0] - auc.value) < 1e-12
+        assert a[1] == tr.value and nd.value == len(a[2]) and np.array_equal(lp[:nd.value], a[2])
