@@ -120,4 +120,4 @@ def test_c_abi_precision_recall_equals_the_python_restatement():
         p = lambda x: x.ctypes.data_as(C.c_void_p)
         assert lib.pr_precision_recall(p(v), p(idx), m, p(gt1), p(gt2), n, 3, ld, mask, C.byref(auc), C.byref(tr), p(lp), C.byref(nd)) == 0
         assert (np.isnan(a[0]) and np.isnan(auc.value)) or abs(a[0] - auc.value) < 1e-12
-        assert a[1] == tr.value and nd.value == len(a[2]) and np.array_equal(lp[:nd.value], a[2])
+        assert (a[1] == tr.value or (np.isnan(a[1]) and np.isnan(tr.value))) and nd.value == len(a[2]) and np.array_equal(lp[:nd.value], a[2])
