@@ -165,6 +165,25 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
 int pr_merge_topk_dev(pr_ctx* ctx, const int32_t* idx_all, const double* score_all, int32_t G, int32_t m, int32_t k,
                       int32_t* idx, double* score);
 
+/* ---- the database row-sharded over several GPUs of one node (the reference is single-device MATLAB,
+ * match_signatures/run_test.m:25-57 - this is that computation with hist2 split by rows) ---------------------------------------
+ * pr_group_create: one context per entry of device_ids; with G > 1 distinct devices the two exchanges (row moments, per-shard top-k)
+ * are ncclAllGather calls of ONE in-process RCCL communicator set (ncclCommInitAll; librccl.so.1 is dlopen'ed here, not linked),
+ * enqueued on the compute streams between the kernels.  Device ids may repeat (several shards on one GPU - tests on a one-GPU box):
+ * such a group exchanges with event-ordered device copies, since RCCL refuses duplicate devices.  PR_GROUP_EXCHANGE=rccl|copy overrides.
+ * pr_group_set_database: hist2 (host f64, [n][2400] SC or [4n][384] M2DP); shard g holds rows [g n/G, (g+1) n/G) raw + packed.
+ * pr_group_match_topk: run_test.m:26-57 for hist1 (host f64) against the sharded hist2: idx [m][k] GLOBAL 0-based rows (-1: none),
+ * score [m][k] doubles; identical to pr_match_topk_f64 on the unsharded database (same arithmetic, Chan combination in rank order). */
+typedef struct pr_group pr_group;
+int pr_group_create(const int32_t* device_ids, int32_t G, pr_group** out);
+void pr_group_destroy(pr_group* g);
+const char* pr_group_last_error(const pr_group* g);     /* g may be NULL (creation errors) */
+int32_t pr_group_size(const pr_group* g);
+int pr_group_uses_rccl(const pr_group* g);
+int pr_group_set_database(pr_group* g, int type, const double* h2, int32_t n);
+int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,
+                        double* score);
+
 /* Device-buffer variants of the generators (same layouts as the host versions, pointers in HBM). */
 int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
                        double max_rho, double* out);

@@ -33,6 +33,13 @@ SYMBOLS = {
     "pr_rerank_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _i32, _vp,
                                 _i32, _vp, _vp]),
     "pr_merge_topk_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "pr_group_create": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
+    "pr_group_destroy": (None, [_vp]),
+    "pr_group_last_error": (C.c_char_p, [_vp]),
+    "pr_group_size": (_i32, [_vp]),
+    "pr_group_uses_rccl": (C.c_int, [_vp]),
+    "pr_group_set_database": (C.c_int, [_vp, C.c_int, _vp, _i32]),
+    "pr_group_match_topk": (C.c_int, [_vp, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_destroy": (None, [_vp]),
     "pr_last_error": (C.c_char_p, [_vp]),
     "pr_version": (C.c_char_p, []),

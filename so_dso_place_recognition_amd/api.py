@@ -73,6 +73,58 @@ class Context:
         return int(self.lib.pr_stream(self.h) or 0)
 
 
+class Group:
+    """pr_group: hist2 row-sharded over the GPUs `devices` of this node inside the C ABI (RCCL all-gathers between the kernels;
+    repeated device ids = several shards on one GPU, exchanged by device copies)."""
+
+    def __init__(self, devices):
+        self.lib = _lib.load()
+        d = np.ascontiguousarray(devices, np.int32)
+        h = C.c_void_p()
+        rc = self.lib.pr_group_create(_ptr(d), len(d), C.byref(h))
+        if rc != 0:
+            raise PRError(rc, self.lib.pr_group_last_error(None).decode())
+        self.h = h
+        self.div, self.width = None, None
+
+    @property
+    def uses_rccl(self) -> bool:
+        return bool(self.lib.pr_group_uses_rccl(self.h))
+
+    def _check(self, rc):
+        if rc != 0:
+            raise PRError(rc, self.lib.pr_group_last_error(self.h).decode())
+
+    def set_database(self, type_: str, hist2):
+        t = {"sc": TYPE_SC, "m2dp": TYPE_M2DP}[type_]
+        self.div, self.width = {TYPE_SC: (1, 2400), TYPE_M2DP: (4, 384)}[t]
+        h2 = np.ascontiguousarray(hist2, np.float64)
+        if h2.ndim != 2 or h2.shape[1] != self.width or h2.shape[0] % self.div:
+            raise ValueError(f"expected a [{self.div}*n, {self.width}] signature matrix")
+        self._check(self.lib.pr_group_set_database(self.h, t, _ptr(h2), h2.shape[0] // self.div))
+
+    def match_topk(self, hist1, mask_width=0, p_weight=2.0, k=1):
+        """run_test.m:26-57 against the sharded database -> (idx int32 [m,k] global rows, score float64 [m,k])."""
+        h1 = np.ascontiguousarray(hist1, np.float64)
+        if h1.ndim != 2 or h1.shape[1] != self.width or h1.shape[0] % self.div:
+            raise ValueError(f"expected a [{self.div}*m, {self.width}] signature matrix")
+        m = h1.shape[0] // self.div
+        idx = np.empty((m, k), np.int32); sc = np.empty((m, k), np.float64)
+        self._check(self.lib.pr_group_match_topk(self.h, _ptr(h1), m, int(mask_width), float(p_weight), int(k), _ptr(idx), _ptr(sc)))
+        return idx, sc
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.pr_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 _default_ctx = None
 
 

@@ -1,6 +1,7 @@
 // match_signatures — executable counterpart of match_signatures/run_test.m:25-57 (the reference runs it from MATLAB:
 // test_kitti.m:18-28).  Options mirror run_test's arguments:
 //   --type sc|m2dp|delight|gist|bow --hist1 F --hist2 F [--mask_width W=0] [--p_weight 2] [--topk K=1] [--one_based 0|1] --out F
+//   [--devices 0,1,...]               hist2 row-sharded over these GPUs (pr_group: RCCL all-gathers between the kernels; sc | m2dp)
 //   [--gt1 F --gt2 F --loop_diff L]   positions of the signatures (text matrices, one row per signature): the evaluation half of
 //                                     run_test (run_test.m:3-22, :58-85) - prints `AUC = ...` and `top_recall = ...`
 // Output: one line per query: K pairs "index score" (0-based indices unless --one_based 1), and the reference's
@@ -40,10 +41,25 @@ int main(int argc, char** argv) {
   std::vector<double> score((size_t)m * k);
   std::vector<float> score32;
   pr_ctx* ctx = nullptr;
-  if (pr_create((int)prm.num("device", 0), &ctx) != PR_OK) { fprintf(stderr, "%s\n", pr_last_error(nullptr)); return 3; }
+  std::string devs;
+  std::vector<int32_t> dev_ids;
+  if (prm.get("devices", devs)) {
+    for (size_t p = 0; p < devs.size();) { dev_ids.push_back(atoi(devs.c_str() + p)); p = devs.find(',', p); if (p == std::string::npos) break; p++; }
+    if (dev_ids.empty() || (t != PR_TYPE_SC && t != PR_TYPE_M2DP)) { fprintf(stderr, "--devices needs a device list and --type sc|m2dp\n"); return 1; }
+  }
+  if (pr_create(dev_ids.empty() ? (int)prm.num("device", 0) : dev_ids[0], &ctx) != PR_OK) { fprintf(stderr, "%s\n", pr_last_error(nullptr)); return 3; }
+  pr_group* grp = nullptr;
+  if (!dev_ids.empty()) {
+    if (pr_group_create(dev_ids.data(), (int32_t)dev_ids.size(), &grp) != PR_OK) { fprintf(stderr, "%s\n", pr_group_last_error(nullptr)); return 3; }
+    if (pr_group_set_database(grp, t, h2, n) != PR_OK) { fprintf(stderr, "%s\n", pr_group_last_error(grp)); return 4; }
+    printf("devices = %d (%s)\n", (int)dev_ids.size(), pr_group_uses_rccl(grp) ? "RCCL" : "copies");
+  }
   const auto t0 = std::chrono::steady_clock::now();
   int rc;
-  if (cols_type) {
+  if (grp) {
+    rc = pr_group_match_topk(grp, h1, m, (int32_t)prm.num("mask_width", 0), prm.num("p_weight", 2.0), k, idx.data(), score.data());
+    if (rc != PR_OK) { fprintf(stderr, "match failed (%d): %s\n", rc, pr_group_last_error(grp)); return 4; }
+  } else if (cols_type) {
     score32.resize(score.size());
     rc = pr_match_topk_cols(ctx, t, h1, m, h2, n, (int32_t)width, (int32_t)prm.num("mask_width", 0), k, idx.data(), score32.data());
     for (size_t i = 0; i < score.size(); i++) score[i] = (double)score32[i];
@@ -79,6 +95,7 @@ int main(int argc, char** argv) {
   }
   fclose(f);
   pr_free(h1); pr_free(h2);
+  pr_group_destroy(grp);
   pr_destroy(ctx);
   return 0;
 }

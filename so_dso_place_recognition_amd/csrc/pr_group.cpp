@@ -1,0 +1,313 @@
+// pr_group.cpp — the database row-sharded over several GPUs of one node inside the C ABI (SURVEY.md §8-b "same calls on a
+// pr_group created over device ids {0..G-1}", §8-e).  The reference is single-threaded, single-device MATLAB
+// (match_signatures/run_test.m:25-57); this is that computation with hist2 split by rows:
+//
+//   every device g holds rows [g n/G, (g+1) n/G) of the database (raw f64 + packed operand image) and ALL queries
+//   1. per device: pack queries, all-pairs distances, per-row moments of the shard                    pr_distances_dev, pr_row_moments_dev
+//   A. all-gather of the moments (48 B per query per rank)                                           ncclAllGather on the compute streams
+//   2. per device: fused fp32 score with the statistics of the WHOLE row (Chan combination in rank order), mask on
+//      global indices, per-shard top-(k+8), fp64 re-evaluation -> per-shard top-k                     pr_fuse_select_dev, pr_rerank_dev
+//   B. all-gather of (index, score)  (12 k B per query per rank)                                      ncclAllGather on the compute streams
+//   3. k-way merge by (score, global index) on device 0                                               pr_merge_topk_dev
+//
+// One host thread drives all devices; everything is asynchronous on each context's stream, the two collectives are
+// enqueued on those same streams between the kernels (one ncclGroupStart/End per collective, communicators from
+// ncclCommInitAll), and the host waits once, at the end.  RCCL is loaded with dlopen at group creation (librccl.so.1 - the
+// copy PyTorch has already loaded when the caller is a torch process), so libpr_amd.so itself does not depend on it.
+// Device ids may repeat ("virtual shards" on one GPU: how the sharded arithmetic is tested on a one-GPU box); RCCL refuses
+// duplicate devices in a communicator, so such a group exchanges by device-to-device copies ordered with events instead.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/place_recognition.h"
+
+namespace {
+
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool load(std::string& err) {
+    if (h) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+      h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (h) break;
+    }
+    if (!h) { err = std::string("cannot load RCCL: ") + dlerror(); return false; }
+#define SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(h, name)); if (!field) { err = "RCCL lacks " name; return false; }
+    SYM(CommInitAll, "ncclCommInitAll") SYM(CommDestroy, "ncclCommDestroy") SYM(AllGather, "ncclAllGather")
+    SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    return true;
+  }
+};
+
+struct Shard {
+  int device = 0;
+  pr_ctx* ctx = nullptr;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev = nullptr;
+  pr_sigset *q = nullptr, *db = nullptr;
+  int32_t row0 = 0, rows = 0;                 // this shard's global DB rows
+  void *raw_db = nullptr, *raw_q = nullptr;   // f64 signatures (the re-evaluation reads them)
+  float *d_p = nullptr, *d_i = nullptr;
+  double *mom = nullptr, *mom_all = nullptr, *score = nullptr, *score_all = nullptr;
+  int32_t *idx_in = nullptr, *idx = nullptr, *idx_all = nullptr;
+  float* sc32 = nullptr;
+};
+
+}  // namespace
+
+struct pr_group {
+  int G = 0;
+  std::vector<Shard> s;
+  bool rccl = false;
+  Rccl nc;
+  std::vector<ncclComm_t> comms;
+  std::string err;
+  int type = -1;
+  int32_t n = 0, q_cap = 0, k_cap = 0;
+};
+
+static thread_local std::string g_gerr;
+
+#define G_FAIL(g, code, ...)                                      \
+  do {                                                            \
+    char _b[512];                                                 \
+    snprintf(_b, sizeof _b, __VA_ARGS__);                         \
+    if (g) (g)->err = _b; else g_gerr = _b;                       \
+    return (code);                                                \
+  } while (0)
+#define G_HIP(g, call)                                                                                  \
+  do {                                                                                                  \
+    hipError_t _e = (call);                                                                             \
+    if (_e != hipSuccess) G_FAIL(g, (_e == hipErrorOutOfMemory ? PR_ENOMEM : PR_EHIP), "%s failed: %s", #call, hipGetErrorString(_e)); \
+  } while (0)
+#define G_PR(g, sh, call)                                                                               \
+  do {                                                                                                  \
+    int _rc = (call);                                                                                   \
+    if (_rc != PR_OK) G_FAIL(g, _rc, "device %d: %s", (sh).device, pr_last_error((sh).ctx));            \
+  } while (0)
+#define G_NCCL(g, call)                                                                                 \
+  do {                                                                                                  \
+    ncclResult_t _r = (call);                                                                           \
+    if (_r != ncclSuccess) G_FAIL(g, PR_EHIP, "%s failed: %s", #call, (g)->nc.GetErrorString(_r));      \
+  } while (0)
+
+static void free_match_buffers(Shard& sh) {
+  (void)hipSetDevice(sh.device);
+  for (void* p : {(void*)sh.raw_q, (void*)sh.d_p, (void*)sh.d_i, (void*)sh.mom, (void*)sh.mom_all, (void*)sh.score, (void*)sh.score_all,
+                  (void*)sh.idx_in, (void*)sh.idx, (void*)sh.idx_all, (void*)sh.sc32})
+    if (p) (void)hipFree(p);
+  sh.raw_q = nullptr; sh.d_p = sh.d_i = sh.sc32 = nullptr; sh.mom = sh.mom_all = sh.score = sh.score_all = nullptr;
+  sh.idx_in = sh.idx = sh.idx_all = nullptr;
+  if (sh.q) { pr_sigset_destroy(sh.ctx, sh.q); sh.q = nullptr; }
+}
+
+// all-gather of `bytes` per rank: src_g on device g -> dst_h[g * bytes ..] on every device h, on the compute streams
+static int exchange(pr_group* g, std::vector<const void*>& src, std::vector<void*>& dst, size_t bytes) {
+  const int G = g->G;
+  if (g->rccl) {
+    G_NCCL(g, g->nc.GroupStart());
+    for (int r = 0; r < G; r++) {
+      G_HIP(g, hipSetDevice(g->s[r].device));
+      G_NCCL(g, g->nc.AllGather(src[r], dst[r], bytes, ncclChar, g->comms[r], g->s[r].stream));
+    }
+    G_NCCL(g, g->nc.GroupEnd());
+    return PR_OK;
+  }
+  for (int r = 0; r < G; r++) {          // producer side: "my slice is ready"
+    G_HIP(g, hipSetDevice(g->s[r].device));
+    G_HIP(g, hipEventRecord(g->s[r].ev, g->s[r].stream));
+  }
+  for (int h = 0; h < G; h++) {
+    G_HIP(g, hipSetDevice(g->s[h].device));
+    for (int r = 0; r < G; r++) {
+      if (r != h) G_HIP(g, hipStreamWaitEvent(g->s[h].stream, g->s[r].ev, 0));
+      char* d = static_cast<char*>(dst[h]) + (size_t)r * bytes;
+      if (g->s[r].device == g->s[h].device) G_HIP(g, hipMemcpyAsync(d, src[r], bytes, hipMemcpyDeviceToDevice, g->s[h].stream));
+      else G_HIP(g, hipMemcpyPeerAsync(d, g->s[h].device, src[r], g->s[r].device, bytes, g->s[h].stream));
+    }
+  }
+  return PR_OK;
+}
+
+extern "C" {
+
+const char* pr_group_last_error(const pr_group* g) { return g ? g->err.c_str() : g_gerr.c_str(); }
+int32_t pr_group_size(const pr_group* g) { return g ? g->G : 0; }
+int pr_group_uses_rccl(const pr_group* g) { return g && g->rccl; }
+
+void pr_group_destroy(pr_group* g) {
+  if (!g) return;
+  for (auto& sh : g->s) {
+    if (!sh.ctx) continue;
+    (void)hipSetDevice(sh.device);
+    (void)pr_sync(sh.ctx);
+  }
+  if (g->rccl) for (auto c : g->comms) if (c) (void)g->nc.CommDestroy(c);
+  for (auto& sh : g->s) {
+    if (!sh.ctx) continue;
+    free_match_buffers(sh);
+    if (sh.db) pr_sigset_destroy(sh.ctx, sh.db);
+    if (sh.raw_db) (void)hipFree(sh.raw_db);
+    if (sh.ev) (void)hipEventDestroy(sh.ev);
+    pr_destroy(sh.ctx);
+  }
+  delete g;
+}
+
+int pr_group_create(const int32_t* device_ids, int32_t G, pr_group** out) {
+  if (!out) G_FAIL((pr_group*)nullptr, PR_EINVAL, "pr_group_create: out is NULL");
+  *out = nullptr;
+  if (!device_ids || G < 1 || G > 64) G_FAIL((pr_group*)nullptr, PR_EINVAL, "pr_group_create: need 1..64 device ids");
+  pr_group* g = new (std::nothrow) pr_group;
+  if (!g) G_FAIL((pr_group*)nullptr, PR_ENOMEM, "out of host memory");
+  g->G = G;
+  g->s.resize(G);
+  bool distinct = true;
+  for (int r = 0; r < G; r++)
+    for (int t = 0; t < r; t++) distinct = distinct && device_ids[r] != device_ids[t];
+  for (int r = 0; r < G; r++) {
+    Shard& sh = g->s[r];
+    sh.device = device_ids[r];
+    if (pr_create(sh.device, &sh.ctx) != PR_OK) { g_gerr = std::string("pr_group_create: ") + pr_last_error(nullptr); pr_group_destroy(g); return PR_EHIP; }
+    sh.stream = static_cast<hipStream_t>(pr_stream(sh.ctx));
+    if (hipSetDevice(sh.device) != hipSuccess || hipEventCreateWithFlags(&sh.ev, hipEventDisableTiming) != hipSuccess) {
+      g_gerr = "pr_group_create: hipEventCreate failed"; pr_group_destroy(g); return PR_EHIP;
+    }
+  }
+  // RCCL over xGMI when every shard has its own GPU (PR_GROUP_EXCHANGE=rccl|copy overrides: rccl needs distinct devices)
+  const char* ex = getenv("PR_GROUP_EXCHANGE");
+  bool want_rccl = distinct && G > 1;
+  if (ex && !strcmp(ex, "copy")) want_rccl = false;
+  if (ex && !strcmp(ex, "rccl")) {
+    if (!distinct) { g_gerr = "pr_group_create: PR_GROUP_EXCHANGE=rccl needs distinct devices"; pr_group_destroy(g); return PR_EINVAL; }
+    want_rccl = true;
+  }
+  if (want_rccl) {
+    if (!g->nc.load(g_gerr)) { pr_group_destroy(g); return PR_EHIP; }
+    g->comms.assign(G, nullptr);
+    std::vector<int> devs(device_ids, device_ids + G);
+    const ncclResult_t r = g->nc.CommInitAll(g->comms.data(), G, devs.data());
+    if (r != ncclSuccess) { g_gerr = std::string("ncclCommInitAll failed: ") + g->nc.GetErrorString(r); g->comms.clear(); pr_group_destroy(g); return PR_EHIP; }
+    g->rccl = true;
+  } else if (distinct && G > 1) {   // copies between devices: let the copy engines reach the peers directly
+    for (int r = 0; r < G; r++) {
+      (void)hipSetDevice(device_ids[r]);
+      for (int t = 0; t < G; t++) if (t != r) (void)hipDeviceEnablePeerAccess(device_ids[t], 0);
+    }
+    (void)hipGetLastError();
+  }
+  *out = g;
+  return PR_OK;
+}
+
+// hist2 of run_test.m:1, host f64: [n][2400] (SC) or [4n][384] (M2DP); rows [g n/G, (g+1) n/G) go to shard g
+int pr_group_set_database(pr_group* g, int type, const double* h2, int32_t n) {
+  if (!g) return PR_EINVAL;
+  if ((type != PR_TYPE_SC && type != PR_TYPE_M2DP) || n < 2 || !h2) G_FAIL(g, PR_EINVAL, "pr_group_set_database: type must be SC or M2DP, n >= 2");
+  const size_t row_doubles = type == PR_TYPE_SC ? PR_SC_SIG_LEN : (size_t)4 * PR_M2DP_SIG_LEN;
+  for (int r = 0; r < g->G; r++) {
+    Shard& sh = g->s[r];
+    G_HIP(g, hipSetDevice(sh.device));
+    if (sh.db) { pr_sigset_destroy(sh.ctx, sh.db); sh.db = nullptr; }
+    if (sh.raw_db) { (void)hipFree(sh.raw_db); sh.raw_db = nullptr; }
+    free_match_buffers(sh);
+    sh.row0 = (int32_t)((int64_t)n * r / g->G);
+    sh.rows = (int32_t)((int64_t)n * (r + 1) / g->G) - sh.row0;
+    if (sh.rows < 1) G_FAIL(g, PR_EINVAL, "pr_group_set_database: fewer signatures (%d) than shards (%d)", n, g->G);
+    const size_t bytes = (size_t)sh.rows * row_doubles * 8;
+    G_HIP(g, hipMalloc(&sh.raw_db, bytes));
+    G_HIP(g, hipMemcpyAsync(sh.raw_db, h2 + (size_t)sh.row0 * row_doubles, bytes, hipMemcpyHostToDevice, sh.stream));
+    G_PR(g, sh, pr_sigset_create(sh.ctx, type, PR_ROLE_DB, sh.rows, &sh.db));
+    G_PR(g, sh, pr_sigset_pack(sh.ctx, sh.db, sh.raw_db, PR_F64, PR_DEVICE, sh.rows));
+  }
+  for (auto& sh : g->s) { G_HIP(g, hipSetDevice(sh.device)); G_PR(g, sh, pr_sync(sh.ctx)); }   // h2 may be released by the caller
+  g->type = type; g->n = n; g->q_cap = 0; g->k_cap = 0;
+  return PR_OK;
+}
+
+// run_test.m:26-57 over the sharded database: idx [m][k] global 0-based rows of hist2 (-1: none), score [m][k] f64
+int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,
+                        double* score) {
+  if (!g) return PR_EINVAL;
+  if (g->type < 0) G_FAIL(g, PR_EINVAL, "pr_group_match_topk: no database (pr_group_set_database)");
+  const int G = g->G;
+  if (m < 0 || (m > 0 && !h1) || k < 1 || k > 120 || (int64_t)G * k > 128 || !idx || !score)
+    G_FAIL(g, PR_EINVAL, "pr_group_match_topk: bad arguments (m=%d, k=%d; G*k <= 128)", m, k);
+  if (m == 0) return PR_OK;
+  const int type = g->type;
+  const bool sc = type == PR_TYPE_SC;
+  const size_t row_doubles = sc ? PR_SC_SIG_LEN : (size_t)4 * PR_M2DP_SIG_LEN;
+  const int kin = k + 8 > 128 ? 128 : k + 8;
+  if (m > g->q_cap || k > g->k_cap) {                         // (re)allocate the per-device work buffers
+    const int32_t qc = m > g->q_cap ? m : g->q_cap, kc = k > g->k_cap ? k : g->k_cap;
+    const int kinc = kc + 8 > 128 ? 128 : kc + 8;
+    for (auto& sh : g->s) {
+      free_match_buffers(sh);
+      G_HIP(g, hipSetDevice(sh.device));
+      G_PR(g, sh, pr_sigset_create(sh.ctx, type, PR_ROLE_QUERY, qc, &sh.q));
+      G_HIP(g, hipMalloc(&sh.raw_q, (size_t)qc * row_doubles * 8));
+      G_HIP(g, hipMalloc((void**)&sh.d_p, (size_t)qc * sh.rows * 4));
+      G_HIP(g, hipMalloc((void**)&sh.d_i, (size_t)qc * sh.rows * 4));
+      G_HIP(g, hipMalloc((void**)&sh.mom, (size_t)qc * 6 * 8));
+      G_HIP(g, hipMalloc((void**)&sh.mom_all, (size_t)G * qc * 6 * 8));
+      G_HIP(g, hipMalloc((void**)&sh.idx_in, (size_t)qc * kinc * 4));
+      G_HIP(g, hipMalloc((void**)&sh.sc32, (size_t)qc * kinc * 4));
+      G_HIP(g, hipMalloc((void**)&sh.idx, (size_t)qc * kc * 4));
+      G_HIP(g, hipMalloc((void**)&sh.score, (size_t)qc * kc * 8));
+      G_HIP(g, hipMalloc((void**)&sh.idx_all, (size_t)G * qc * kc * 4));
+      G_HIP(g, hipMalloc((void**)&sh.score_all, (size_t)G * qc * kc * 8));
+    }
+    g->q_cap = qc; g->k_cap = kc;
+  }
+  // 1. local distances and moments
+  for (auto& sh : g->s) {
+    G_HIP(g, hipSetDevice(sh.device));
+    G_HIP(g, hipMemcpyAsync(sh.raw_q, h1, (size_t)m * row_doubles * 8, hipMemcpyHostToDevice, sh.stream));
+    G_PR(g, sh, pr_sigset_pack(sh.ctx, sh.q, sh.raw_q, PR_F64, PR_DEVICE, m));
+    G_PR(g, sh, pr_distances_dev(sh.ctx, sh.q, sh.db, sh.d_p, sh.d_i));
+    G_PR(g, sh, pr_row_moments_dev(sh.ctx, sh.d_p, sh.d_i, m, sh.rows, sh.mom));
+  }
+  std::vector<const void*> src(G);
+  std::vector<void*> dst(G);
+  // A. moments of every shard on every device
+  for (int r = 0; r < G; r++) { src[r] = g->s[r].mom; dst[r] = g->s[r].mom_all; }
+  if (int rc = exchange(g, src, dst, (size_t)m * 6 * 8)) return rc;
+  // 2. per-shard selection with the whole row's statistics + fp64 re-evaluation
+  for (auto& sh : g->s) {
+    G_HIP(g, hipSetDevice(sh.device));
+    G_PR(g, sh, pr_fuse_select_dev(sh.ctx, sh.d_p, sh.d_i, m, sh.rows, sh.mom_all, G, 0, sh.row0, mask_width, p_weight, kin, sh.idx_in, sh.sc32));
+    G_PR(g, sh, pr_rerank_dev(sh.ctx, sc ? sh.raw_q : nullptr, sc ? sh.raw_db : nullptr, PR_F64, sc ? nullptr : sh.raw_q, sc ? nullptr : sh.raw_db,
+                              PR_F64, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, m, sh.rows, G, 0, sh.row0, mask_width, p_weight, kin,
+                              sh.idx_in, k, sh.idx, sh.score));
+  }
+  // B. per-shard top-k of every shard on every device
+  for (int r = 0; r < G; r++) { src[r] = g->s[r].idx; dst[r] = g->s[r].idx_all; }
+  if (int rc = exchange(g, src, dst, (size_t)m * k * 4)) return rc;
+  for (int r = 0; r < G; r++) { src[r] = g->s[r].score; dst[r] = g->s[r].score_all; }
+  if (int rc = exchange(g, src, dst, (size_t)m * k * 8)) return rc;
+  // 3. merge on device 0, copy out, one host wait per device
+  Shard& s0 = g->s[0];
+  G_HIP(g, hipSetDevice(s0.device));
+  G_PR(g, s0, pr_merge_topk_dev(s0.ctx, s0.idx_all, s0.score_all, G, m, k, s0.idx_in /*reused as output*/, reinterpret_cast<double*>(s0.mom_all)));
+  G_HIP(g, hipMemcpyAsync(idx, s0.idx_in, (size_t)m * k * 4, hipMemcpyDeviceToHost, s0.stream));
+  G_HIP(g, hipMemcpyAsync(score, s0.mom_all, (size_t)m * k * 8, hipMemcpyDeviceToHost, s0.stream));
+  for (auto& sh : g->s) { G_HIP(g, hipSetDevice(sh.device)); G_PR(g, sh, pr_sync(sh.ctx)); }
+  return PR_OK;
+}
+
+}  // extern "C"

@@ -71,9 +71,15 @@ __device__ __forceinline__ double block_min256(double v, double* red, int tid) {
   return r;
 }
 
-// processSC.m:15-33 for one channel of one pair, fp64.  a / b: the 1200-vectors (bin = sector * 20 + ring).
+// processSC.m:15-33 for one channel of one pair, fp64.  buf: 60 x 21 (query, padded sector stride) + 1200 (entry) doubles.
+// Thread = (ring r, block of 5 consecutive shifts): it walks the 60 sectors of the entry once and keeps the 5 forward and
+// 5 mirrored variants of its shifts in registers - a sliding window over the query's ring column, so every step costs three
+// LDS reads (entry value, one new query value per direction) for ten multiply-adds; the first version read two operands
+// per multiply-add and was LDS-bound at 3.2 ms per 4096 x 9 pairs.
 __device__ double sc_pair_exact(const void* qsig, int qdt, size_t qoff, const void* dsig, int ddt, size_t doff,
-                                double* qs /*60 x 21*/, double* ds /*1200*/, double* red, int tid) {
+                                double* buf /*60*21 + 1200*/, double* red, int tid) {
+  double* qs = buf;
+  double* ds = buf + 60 * 21;
   double pq = 0.0, pd = 0.0;
   for (int i = tid; i < 1200; i += 256) {
     const double x = ld(qsig, qdt, qoff + i), y = ld(dsig, ddt, doff + i);
@@ -90,26 +96,49 @@ __device__ double sc_pair_exact(const void* qsig, int qdt, size_t qoff, const vo
     ds[i] = ds[i] / nd;
   }
   __syncthreads();
-  // thread = (variant v = 2 k0 + mirrored, half of the 60 sectors): 240 threads x 600 multiply-adds
-  double part = 0.0;
-  const int v = tid >> 1, h = tid & 1;
+  const int r = tid % 20, blk = tid / 20;                        // blk 0..11 (tid < 240): shifts 5 blk .. 5 blk + 4
+  double af[5] = {0, 0, 0, 0, 0}, am[5] = {0, 0, 0, 0, 0};
   if (tid < 240) {
-    const int k0 = v >> 1, mir = v & 1;
-    for (int c = 30 * h; c < 30 * h + 30; c++) {
-      int s = mir ? k0 - c : k0 + c;                            // permute_sc, processSC.m:37-45 (0-based)
-      s = ((s % 60) + 60) % 60;
-      const double* qa = qs + s * 21;
-      const double* db = ds + c * 20;
+    double wf[5], wm[5];
+    const double* qc = qs + r;
 #pragma unroll
-      for (int r = 0; r < 20; r++) part += qa[r] * db[r];
+    for (int j = 0; j < 5; j++) { wf[j] = qc[(5 * blk + j) * 21]; wm[j] = wf[j]; }
+    int nf = (5 * blk + 5) % 60;                                 // sector entering the forward window next
+    int nm = (5 * blk + 59) % 60;                                // ... and the mirrored one
+    for (int c0 = 0; c0 < 60; c0 += 5) {
+#pragma unroll
+      for (int u = 0; u < 5; u++) {                              // sector c = c0 + u of the entry (permute_sc, processSC.m:37-45)
+        const double dv = ds[(c0 + u) * 20 + r];
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          af[j] += wf[(j + u) % 5] * dv;                         // q[(k0 + c) % 60], k0 = 5 blk + j
+          am[j] += wm[(j + 5 - u) % 5] * dv;                     // q[(k0 - c) % 60]
+        }
+        wf[u] = qc[nf * 21];
+        wm[(4 - u + 5) % 5] = qc[nm * 21];
+        nf = nf == 59 ? 0 : nf + 1;
+        nm = nm == 0 ? 59 : nm - 1;
+      }
     }
   }
-  red[tid] = part;
+  __syncthreads();                                               // all reads of qs / ds done: the buffer becomes [variant][ring]
+  if (tid < 240) {
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      buf[(2 * (5 * blk + j)) * 20 + r] = af[j];
+      buf[(2 * (5 * blk + j) + 1) * 20 + r] = am[j];
+    }
+  }
   __syncthreads();
   double diff = __builtin_nan("");
-  if (tid < 240 && h == 0) diff = (1.0 - (red[tid] + red[tid + 1])) / 2.0;   // processSC.m:30
-  __syncthreads();
-  return block_min256(diff, red, tid);                                        // processSC.m:31
+  if (tid < 120) {
+    double dot = 0.0;
+#pragma unroll
+    for (int q = 0; q < 20; q++) dot += buf[tid * 20 + q];
+    diff = (1.0 - dot) / 2.0;                                    // processSC.m:30
+  }
+  const double best = block_min256(diff, red, tid);              // processSC.m:31 (its barriers also free buf for the next channel)
+  return best;
 }
 
 // processM2DP.m:12-22 for one channel of one pair: rows [4][384], channel columns [192 ch, 192 ch + 192)
@@ -157,8 +186,7 @@ __device__ void chan_combine(const double* mom_all, int G, int m, int q, int ch,
 
 __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t* __restrict__ idx_in,
                                                       double* __restrict__ cand_score) {
-  __shared__ double qs[60 * 21];
-  __shared__ double ds[1200];
+  __shared__ double buf[60 * 21 + 1200];
   __shared__ double red[256];
   const int tid = threadIdx.x, q = blockIdx.x / A.kin, t = blockIdx.x % A.kin;
   const int jg = idx_in[(size_t)q * A.kin + t];
@@ -172,7 +200,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
   if (A.q_sc) {
     for (int ch = 0; ch < 2; ch++) {
       const double d = sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + ch * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + ch * 1200,
-                                     qs, ds, red, tid);
+                                     buf, red, tid);
       double mean, sd;
       chan_combine(A.mom_sc, A.G, A.m, q, ch, mean, sd);
       f += (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);    // run_test.m:40

@@ -61,7 +61,11 @@ def test_config1_end_to_end(golden_dir, tmp_path):
         m = np.loadtxt(res)
         rc, oidx, osc = oracle_lib.match_topk(t, got, got, 10, 2.0, 2)         # same (text-rounded) inputs on both sides
         assert np.array_equal(m[:, [0, 2]].astype(np.int32), oidx)
-        assert np.abs(m[:, [1, 3]] - osc).max() < 1e-5
+        if t == 2:
+            assert np.abs(m[:, [1, 3]] - osc).max() < 1e-5 * max(1.0, np.abs(osc).max())        # DELIGHT: one fp32 chi-square matrix
+        else:       # toy clouds: every row's distances lie within ~1e-3 of each other, so the z-score amplifies the fp32 pass's 2e-8 (helpers.score_tol)
+            rc, odp, odi = oracle_lib.sc_distance(got, got) if t == 0 else oracle_lib.m2dp_distance(got, got)
+            assert (np.abs(m[:, [1, 3]] - osc) <= helpers.score_tol(osc, helpers.row_sigmas(odp, odi))).all()
 
 
 @pytest.mark.gpu
@@ -152,4 +156,5 @@ def test_config1_full_kitti_seq00(ref_sequence, tmp_path):
         f = 2.0 * z(dp) + z(di)
         f[np.abs(rows[:, None] - np.arange(f.shape[1])[None, :]) < 100] = np.inf
         assert np.array_equal(mres[rows, 0].astype(np.int64), f.argmin(1))
-        assert np.abs(mres[rows, 1] - f.min(1)).max() < 1e-5
+        sg = (np.std(dp, axis=1, ddof=1), np.std(di, axis=1, ddof=1))
+        assert (np.abs(mres[rows, 1] - f.min(1)) <= helpers.score_tol(f.min(1), sg)).all()

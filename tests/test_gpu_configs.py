@@ -20,6 +20,7 @@ import numpy as np
 import pytest
 import torch
 
+import helpers
 import oracle_lib
 from so_dso_place_recognition_amd import _lib, synth
 
@@ -89,7 +90,7 @@ def test_config2_generate_5000x50000_then_match(api):
         assert np.abs(gp[rows].cpu().numpy() - dp).max() < 1e-5 and np.abs(gi[rows].cpu().numpy() - di).max() < 1e-5
         oi, osc = topk_rows(2.0 * zscore_rows(dp) + zscore_rows(di), rows, mask, 3)
         assert np.array_equal(idx[rows], oi)
-        assert np.abs(sc[rows] - osc).max() < 1e-5
+        assert (np.abs(sc[rows] - osc) <= helpers.score_tol(osc)).all()
         if mask == 0:
             assert np.array_equal(idx[:, 0], np.arange(N))                                       # every cloud finds itself
     mt.close(); ctx.close()
@@ -114,7 +115,7 @@ def test_config3_m2dp_50k_db_4096_queries(api):
     gp, gi = mt.distances()
     assert np.abs(gp[rows].cpu().numpy() - dp).max() < 1e-5 and np.abs(gi[rows].cpu().numpy() - di).max() < 1e-5
     oi, osc = topk_rows(2.0 * zscore_rows(dp) + zscore_rows(di), rows, 0, 2)
-    assert np.array_equal(idx[rows], oi) and np.abs(sc[rows] - osc).max() < 1e-5
+    assert np.array_equal(idx[rows], oi) and (np.abs(sc[rows] - osc) <= helpers.score_tol(osc, helpers.row_sigmas(dp, di))).all()
     mt.close()
 
 
@@ -155,11 +156,11 @@ def test_config4_200k_db_in_8_shards(api):
     dp, di = oracle_rows("sc", q_h[rows], [chunks[lo].cpu().numpy() for lo, hi in shards])
     f = 2.0 * zscore_rows(dp) + zscore_rows(di)                      # GLOBAL row statistics (run_test.m:40)
     oi, osc = topk_rows(f, rows, mask, k)
-    assert np.array_equal(idx[rows], oi) and np.abs(sc[rows] - osc).max() < 1e-5
+    assert np.array_equal(idx[rows], oi) and (np.abs(sc[rows] - osc) <= helpers.score_tol(osc)).all()
     for g in (0, 5, 7):                                              # rank g's own answer: the best of ITS rows under the global statistics
         lo, hi = shards[g]
         si, ss = topk_rows(f[:, lo:hi], rows, mask, k, lo)
-        assert np.array_equal(per[g][0].cpu().numpy()[rows], si) and np.abs(per[g][1].cpu().numpy()[rows] - ss).max() < 1e-5
+        assert np.array_equal(per[g][0].cpu().numpy()[rows], si) and (np.abs(per[g][1].cpu().numpy()[rows] - ss) <= helpers.score_tol(ss)).all()
         gp, gi = ms[g].distances()
         assert np.abs(gp[rows].cpu().numpy() - dp[:, lo:hi]).max() < 1e-5 and np.abs(gi[rows].cpu().numpy() - di[:, lo:hi]).max() < 1e-5
     for mt in ms:
@@ -199,11 +200,11 @@ def test_config5_fused_1m_db_in_8_shards(api):
     full = [np.concatenate(d[c], 1) for c in range(4)]
     f = 2.0 * zscore_rows(full[0]) + zscore_rows(full[1]) + 2.0 * zscore_rows(full[2]) + zscore_rows(full[3])
     oi, osc = topk_rows(f, rows, mask, k)
-    assert np.array_equal(idx[rows], oi) and np.abs(sc[rows] - osc).max() < 1e-5
+    assert np.array_equal(idx[rows], oi) and (np.abs(sc[rows] - osc) <= 2 * helpers.score_tol(osc)).all()    # two descriptor types, each with its own row statistics
     g = 3
     lo, hi = shards[g]
     si, ss = topk_rows(f[:, lo:hi], rows, mask, k, lo)
-    assert np.array_equal(per[g][0].cpu().numpy()[rows], si) and np.abs(per[g][1].cpu().numpy()[rows] - ss).max() < 1e-5
+    assert np.array_equal(per[g][0].cpu().numpy()[rows], si) and (np.abs(per[g][1].cpu().numpy()[rows] - ss) <= 2 * helpers.score_tol(ss)).all()
     for mt in ms:
         mt.close()
 
@@ -216,8 +217,7 @@ def test_near_ties_are_ordered_by_the_fp64_reevaluation(api):
     db = synth.sc_database(45, n)
     q, planted = synth.sc_queries(46, db, m)
     rng = np.random.default_rng(12)
-    twins = n - 1 - np.arange(m)                                      # entry n-1-t becomes a near-copy of query t's planted entry
-    assert not np.isin(twins, planted).any()
+    twins = np.setdiff1d(np.arange(n), planted)[-m:]                 # entry twins[t] becomes a near-copy of query t's planted entry
     for t in range(m):
         delta = 10.0 ** rng.uniform(-8.5, -4.5)
         e = db[planted[t]].copy()
@@ -230,14 +230,14 @@ def test_near_ties_are_ordered_by_the_fp64_reevaluation(api):
     assert (gap < 1e-3).sum() > m // 2 and (gap > 0).all()          # the test has teeth: most pairs are closer than fp32 noise / sigma
     idx, sc = api.match_topk("sc", q, db, 0, 2.0, 3)
     assert np.array_equal(idx, oidx)
-    assert np.abs(sc - osc).max() < 1e-5
+    assert (np.abs(sc - osc) <= helpers.score_tol(osc)).all()
     # the same through the device-resident path on two shards
     from so_dso_place_recognition_amd.matcher import Matcher
     tq = torch.from_numpy(q).cuda()
     cut = 700
     ms, per, i2, s2 = _sharded_run(lambda cap: Matcher("sc", m, cap), [(0, cut), (cut, n)],
                                    lambda mt, lo, hi: mt.pack_database(torch.from_numpy(db[lo:hi]).cuda()), (tq,), 0, 3)
-    assert np.array_equal(i2, oidx) and np.abs(s2 - osc).max() < 1e-5
+    assert np.array_equal(i2, oidx) and (np.abs(s2 - osc) <= helpers.score_tol(osc)).all()
     for mt in ms:
         mt.close()
 
@@ -302,6 +302,6 @@ def test_drive_2000_frames_mask_100(api):
     dp, di = oracle_rows("sc", o[rows], [o])
     oi, osc = topk_rows(2.0 * zscore_rows(dp) + zscore_rows(di), rows, 100, 2)
     assert np.array_equal(idx[rows], oi)
-    assert np.abs(sc[rows] - osc).max() < 1e-5
+    assert (np.abs(sc[rows] - osc) <= helpers.score_tol(osc, helpers.row_sigmas(dp, di))).all()
     second = np.arange(lap + 50, N - 50)
     assert (np.abs(idx[second, 0] - (second - lap)) <= 3).mean() > 0.7           # loop closures onto the first lap
