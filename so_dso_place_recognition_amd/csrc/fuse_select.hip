@@ -273,8 +273,8 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
     return;
   }
   // ---- fallback: one pass per selected element
-  double pv = -__builtin_inf();
-  int pj = -1;
+  double pv = -__builtin_inf(), bv = 0.0;
+  int pj = -1, bj = -1;
   for (int t = 0; t < k; t++) {
     bv = 0.0; bj = -1;
     sweep([&](int j, double f) {
