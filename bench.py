@@ -10,6 +10,9 @@ One step = the whole match path on inputs already resident in HBM as f64 signatu
 i.e. run_test.m:25-57.  With N > 1 GPUs the SAME 100k DB is row-sharded over the ranks (strong scaling,
 SURVEY.md §8-e); queries are replicated.  value = queries of all steps / max-over-ranks wall time.
 
+`extra` (outside the timed region, N = 1 only): the secondary workloads of BASELINE.json measured in the same run - M2DP matching
+over a 50k-signature DB (config 3), SC generation from 50 000-point clouds (config 2), and the fp32-MFMA arithmetic of the SC matcher.
+
 Extra objects on the JSON line: `roofline` (the dominant kernel - sc_match_h_kernel, split-f16 MFMA, by default;
 sc_match_kernel, fp32 MFMA, with --sc-arith f32 - timed live with HIP events on the stream it runs on; algorithmic
 FLOPs = 23 856 fp32 FLOP per (query, entry) pair = 71 568 f16 FLOP in the split form), `cpu_baseline` (the CPU oracle =
@@ -64,6 +67,96 @@ class HipEvents:
         return ms.value
 
 
+def extra_workloads(dev, ev, args):
+    """Secondary workloads of BASELINE.json, measured after (outside) the timed region on the same GPU."""
+    import numpy as np
+    import torch
+    from so_dso_place_recognition_amd import synth
+    from so_dso_place_recognition_amd.api import Context
+    from so_dso_place_recognition_amd.matcher import Matcher
+    P = lambda t: C.c_void_p(t.data_ptr())
+    out = {}
+    cur = int(torch.cuda.current_stream(dev).cuda_stream)
+
+    def timed(ctx, fn, reps=3):
+        ts = []
+        for _ in range(reps + 1):
+            a, b = ev.create(), ev.create()
+            ev.record(a, ctx.stream); fn(); ev.record(b, ctx.stream)
+            ts.append(ev.elapsed_ms(a, b))
+        return float(np.mean(ts[1:]))
+
+    # config 3: M2DP 192-d x 2 channels, 4 x 4 sign variants, 50k-signature DB, 4096 queries
+    n, m = 50_000, 4096
+    db = synth.m2dp_database_torch(43, n, device=dev)
+    q_h, planted = synth.m2dp_queries(44, db.cpu().numpy(), m)
+    q = torch.from_numpy(q_h).to(dev)
+    mt = Matcher("m2dp", m, n, ctx=Context(dev.index, stream=cur))
+    pair = [ev.create(), ev.create()]
+    kms = []
+
+    def m2_step():
+        mt.pack_database(db)
+        mt.pre_distances = lambda: ev.record(pair[0], mt.ctx.stream)
+        mt.post_distances = lambda: ev.record(pair[1], mt.ctx.stream)
+        return mt.match(q, 0, 2.0, 1)
+    m2_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        idx, _ = m2_step()
+        kms.append(ev.elapsed_ms(pair[0], pair[1]))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    f16 = mt.ctx.sc_arith == "f16x2"
+    fpp = 12288 * (3 if f16 else 1)
+    k = float(np.mean(kms))
+    out["m2dp_match_50k"] = {"queries_per_s": m / dt, "ms_per_step": 1e3 * dt, "kernel": "m2dp_match_h_kernel" if f16 else "m2dp_match_kernel",
+                             "ms_per_launch": k, "flop_per_pair": fpp, "achieved_TFLOPs": m * n * fpp / (k * 1e-3) / 1e12,
+                             "frac_of_mfma_peak": m * n * fpp / (k * 1e-3) / 1e12 / (MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS),
+                             "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == planted).sum()), "queries": m}
+    mt.close(); del db, q, mt
+    torch.cuda.empty_cache()
+    # config 2: SC / M2DP generation from 50 000-point clouds resident in HBM
+    N, PTS = 1024, 50_000
+    xyz, it, offs = synth.scene_clouds_torch(42, N, PTS, device=dev)
+    ctx = Context(dev.index, stream=cur)
+    sig = torch.empty((N, 2400), dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    ms = timed(ctx, lambda: ctx.check(ctx.lib.pr_sc_generate_dev(ctx.h, P(xyz), P(it), P(offs), N, 45.0, P(sig))))
+    by = N * (28 * PTS + 19200)
+    out["sc_generate_50k_pts"] = {"clouds": N, "points_per_cloud": PTS, "ms": ms, "clouds_per_s": N / (ms * 1e-3), "bound": "hbm",
+                                  "algorithmic_bytes_per_cloud": 28 * PTS + 19200, "achieved_GBps": by / (ms * 1e-3) / 1e9,
+                                  "frac_of_8TBps": by / (ms * 1e-3) / 8e12}
+    Nm = 128
+    sigm = torch.empty((4 * Nm, 384), dtype=torch.float64, device=dev)
+    ms = timed(ctx, lambda: ctx.check(ctx.lib.pr_m2dp_generate_dev(ctx.h, P(xyz), P(it), P(offs), Nm, 45.0, P(sigm))), reps=2)
+    out["m2dp_generate_50k_pts"] = {"clouds": Nm, "points_per_cloud": PTS, "ms": ms, "clouds_per_s": Nm / (ms * 1e-3),
+                                    "plane_projections_per_s": Nm * 256 * PTS / (ms * 1e-3), "bound": "valu (fp64 dots + polar classification), not HBM"}
+    ctx.close(); del xyz, it, offs, sig, sigm
+    torch.cuda.empty_cache()
+    # the fp32-MFMA arithmetic of the SC matcher on the metric workload (one launch)
+    n, m = args.db, args.queries
+    db = synth.sc_database_torch(45, n, device=dev)
+    q_h, planted = synth.sc_queries(46, np.empty((0, 2400)), m, db_first=0, n_global=n, db_seed=45)
+    q = torch.from_numpy(q_h).to(dev)
+    mt = Matcher("sc", m, n, ctx=Context(dev.index, sc_arith="f32", stream=cur))
+    mt.pack_database(db)
+    kms = []
+    mt.pre_distances = lambda: ev.record(pair[0], mt.ctx.stream)
+    mt.post_distances = lambda: ev.record(pair[1], mt.ctx.stream)
+    for _ in range(2):
+        idx, _ = mt.match(q, 0, 2.0, 1)
+        kms.append(ev.elapsed_ms(pair[0], pair[1]))
+    k = kms[-1]
+    out["sc_match_100k_f32_arith"] = {"kernel": "sc_match_kernel", "ms_per_launch": k, "flop_per_pair": FLOP_PER_PAIR,
+                                      "achieved_TFLOPs": m * n * FLOP_PER_PAIR / (k * 1e-3) / 1e12,
+                                      "frac_of_fp32_mfma_peak": m * n * FLOP_PER_PAIR / (k * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                                      "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == planted).sum()), "queries": m}
+    mt.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,6 +168,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sc-arith", default=None, choices=["f16x2", "f32"],
                     help="SC matcher arithmetic (default: the library's, split-f16 MFMA; f32 = the fp32-MFMA kernel)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under `extra`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: several ranks on ONE GPU, tests only)")
     args = ap.parse_args()
 
@@ -104,9 +198,9 @@ def main():
     n, m = args.db, args.queries
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world          # this rank's DB rows
     t0 = time.time()
-    db_host = synth.sc_database(45, hi - lo, first=lo)
-    q_host, planted = synth.sc_queries(46, db_host, m, db_first=lo, n_global=n, db_seed=45)
-    db = torch.from_numpy(db_host).to(dev)                            # f64 [n_local, 2400] resident in HBM
+    db = synth.sc_database_torch(45, hi - lo, first=lo, device=dev)   # f64 [n_local, 2400] drawn in HBM (== synth.sc_database bit for bit)
+    db_host = db.cpu().numpy() if (rank == 0 and world == 1 and not args.no_cpu_baseline) else None
+    q_host, planted = synth.sc_queries(46, np.empty((0, 2400)), m, db_first=0, n_global=n, db_seed=45)
     q = torch.from_numpy(q_host).to(dev)                              # f64 [m, 2400]
     gen_s = time.time() - t0
 
@@ -116,23 +210,20 @@ def main():
     mt = Matcher("sc", m, hi - lo, ctx=Context(local, sc_arith=args.sc_arith, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
     arith = mt.ctx.sc_arith
     ev = HipEvents()
-    e0, e1 = ev.create(), ev.create()
+    evs = [(ev.create(), ev.create()) for _ in range(args.steps)]     # one pair per timed step, read after the timed region
     stream = mt.ctx.stream
-    kern_ms = []
 
-    def step(timed_kernel: bool):
+    def step(pair):
         mt.pack_database(db)
-        if timed_kernel:   # the only launch between the two records is sc_match_kernel, on the stream it runs on
-            mt.pre_distances = lambda: ev.record(e0, stream)
-            mt.post_distances = lambda: ev.record(e1, stream)
+        if pair is not None:   # the only launches between the two records are the matcher and the NaN fix-up, on the stream they run on
+            mt.pre_distances = lambda: ev.record(pair[0], stream)
+            mt.post_distances = lambda: ev.record(pair[1], stream)
         out = mt.match(q, 0, 2.0, 1, db_row0=lo)
-        if timed_kernel:
-            mt.pre_distances = mt.post_distances = None
-            kern_ms.append(ev.elapsed_ms(e0, e1))
+        mt.pre_distances = mt.post_distances = None
         return out
 
     for _ in range(args.warmup):
-        step(False)
+        step(None)
 
     def barrier():
         if world > 1:
@@ -141,10 +232,11 @@ def main():
 
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        idx, score = step(True)
+    for i in range(args.steps):
+        idx, score = step(evs[i])
     barrier()
     dt = time.perf_counter() - t0
+    kern_ms = [ev.elapsed_ms(a, b) for a, b in evs]
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -164,7 +256,7 @@ def main():
         ach = pairs * fpp / (kms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
             if tr["workload"] == {"db": n, "queries": m, "n_gpus": world}:
                 traffic = tr[kname]["hbm_bytes_per_launch"]
         except Exception:
@@ -181,6 +273,8 @@ def main():
                        "step": "pack(q)+pack(db)+distances+moments+fuse/top-1" + ("+2 all_gathers" if world > 1 else "")},
             "roofline": {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak,
                          "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+                         "traffic_source": ("profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE passes of this command, per launch"
+                                            if traffic is not None else None),
                          "flop_per_pair": fpp, "pairs_per_launch": pairs, "ms_per_launch": kms,
                          # the same launch priced as the fp32 formulation it replaces (what an fp32-MFMA kernel would need)
                          "fp32_formulation_tflops": pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12,
@@ -194,14 +288,30 @@ def main():
             import oracle_lib                                           # the checker: CPU port of the reference
             cores = os.cpu_count() or 1
             S = args.cpu_sample if args.cpu_sample > 0 else min(cores, 32)
-            os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+            omp = C.CDLL("libgomp.so.1")
+            omp.omp_set_num_threads(1)                                  # the reference itself is single-threaded (SC/test_sc.cpp:40-56, run_test.m)
+            t0 = time.perf_counter()
+            rc1, oidx1, osc1 = oracle_lib.match_topk(0, q_host[:1], db_host, 0, 2.0, 1)
+            cdt1 = time.perf_counter() - t0
+            omp.omp_set_num_threads(cores)
             t0 = time.perf_counter()
             rc, oidx, osc = oracle_lib.match_topk(0, q_host[:S], db_host, 0, 2.0, 1)
             cdt = time.perf_counter() - t0
-            out["cpu_baseline"] = {"value": S / cdt, "unit": "queries/s", "cores": min(cores, S), "kind": "port",
-                                   "sample": f"{S} queries x full {n}-signature DB, dense 120-variant fp64 (oracle/pr_ref.cpp), {cdt:.1f} s"}
+            out["cpu_baseline"] = {"value": S / cdt, "unit": "queries/s", "cores": min(cores, S), "kind": "port", "nproc": cores,
+                                   "value_1_thread": 1.0 / cdt1,
+                                   "sample": f"{S} queries x full {n}-signature DB on {min(cores, S)} threads ({cdt:.1f} s) and 1 query on 1 thread "
+                                             f"({cdt1:.1f} s), dense 120-variant fp64 (oracle/pr_ref.cpp)"}
+            err = np.abs(osc[:, 0] - score_h[:S])
             out["parity"].update({"oracle_queries": S, "oracle_top1_equal": bool((oidx[:, 0] == idx_h[:S]).all()),
-                                  "oracle_max_abs_score_err": float(np.abs(osc[:, 0] - score_h[:S]).max())})
+                                  "oracle_max_abs_score_err": float(err.max()),
+                                  "oracle_max_rel_score_err": float((err / np.abs(osc[:, 0])).max()),
+                                  "score_note": "planted matches sit at z ~ -160; the returned score is exact in the pair's distances (fp64 re-evaluation), "
+                                                "its row statistics carry the fp32 pass's ~2e-7 relative error (DESIGN.md)"})
+        if world == 1 and not args.no_extra:
+            mt.close()
+            del db, mt
+            torch.cuda.empty_cache()
+            out["extra"] = extra_workloads(dev, ev, args)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -156,5 +156,5 @@ def test_config1_full_kitti_seq00(ref_sequence, tmp_path):
         f = 2.0 * z(dp) + z(di)
         f[np.abs(rows[:, None] - np.arange(f.shape[1])[None, :]) < 100] = np.inf
         assert np.array_equal(mres[rows, 0].astype(np.int64), f.argmin(1))
-        sg = (np.std(dp, axis=1, ddof=1), np.std(di, axis=1, ddof=1))
+        sg = (np.std(dp, axis=1, ddof=1), np.std(di, axis=1, ddof=1), dp.shape[1])
         assert (np.abs(mres[rows, 1] - f.min(1)) <= helpers.score_tol(f.min(1), sg)).all()

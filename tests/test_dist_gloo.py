@@ -101,14 +101,14 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
-           "--warmup", "0", "--db", "6001", "--queries", "130", "--backend", "gloo", "--no-cpu-baseline"]
+           "--warmup", "0", "--db", "6001", "--queries", "130", "--backend", "gloo", "--no-cpu-baseline", "--no-extra"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["parity"]["planted_top1_correct"] == 130 and d["scaling"] == "strong"
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--db", "6001",
-                          "--queries", "130", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600)
+                          "--queries", "130", "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert d1["parity"]["planted_top1_correct"] == 130
