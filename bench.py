@@ -164,7 +164,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--db", type=int, default=100_000, help="total DB signatures (sharded over the ranks)")
     ap.add_argument("--queries", type=int, default=4096)
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="queries for the CPU baseline (-1: one per host core, <= 32)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="queries for the CPU baseline (-1: one per host core, <= 128)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sc-arith", default=None, choices=["f16x2", "f32"],
                     help="SC matcher arithmetic (default: the library's, split-f16 MFMA; f32 = the fp32-MFMA kernel)")
@@ -287,7 +287,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib                                           # the checker: CPU port of the reference
             cores = os.cpu_count() or 1
-            S = args.cpu_sample if args.cpu_sample > 0 else min(cores, 32)
+            S = args.cpu_sample if args.cpu_sample > 0 else min(cores, 128)
             omp = C.CDLL("libgomp.so.1")
             omp.omp_set_num_threads(1)                                  # the reference itself is single-threaded (SC/test_sc.cpp:40-56, run_test.m)
             t0 = time.perf_counter()

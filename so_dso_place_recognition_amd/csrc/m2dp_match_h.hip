@@ -156,6 +156,96 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
 #undef MF
 }
 
+
+// The shipped geometry: EIGHT waves per workgroup (two per SIMD), each 4 query tiles x ONE DB tile (64 accumulators, 12 MFMAs
+// and 2 DB operand loads per K-step: the same loads per MFMA as the 4-wave kernel above).  The 4-wave kernel runs one wave per
+// SIMD (96 KB of query tiles leave room for one workgroup per CU), so nothing covers its epilogue (8 tiles x ~40 instructions
+// per sweep step = 14 % of the step) nor the operand-request stalls: the matrix pipe was 76 % busy.  Here the second wave
+// of every SIMD fills those holes.  Same LDS image, same packed layouts, same result bit for bit (the products of a
+// (query tile, DB tile) pair are accumulated in the same order).
+__global__ __launch_bounds__(512, 2) void m2dp_match_h8_kernel(const u32x4* __restrict__ qpk, const u32x4* __restrict__ dpk,
+                                                               float* __restrict__ dist_p, float* __restrict__ dist_i,
+                                                               int m, int n, int QT, int DT, int nsplit) {
+  constexpr int QTB = 4;
+  extern __shared__ __attribute__((aligned(16))) u32x4 ldsv[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);      // 0..7
+  int b = blockIdx.x;
+  const int split = b % nsplit;
+  b /= nsplit;
+  const int ch = b & 1, qt4 = b >> 1;
+  if (qt4 * QTB * 8 >= m) return;
+  const int DT8 = (DT + 7) / 8;                     // DB swept in steps of 8 tiles (one per wave)
+  const int s0 = (int)((long long)DT8 * split / nsplit), s1 = (int)((long long)DT8 * (split + 1) / nsplit);
+  {
+    const u32x4* src = qpk + ((size_t)ch * QT + (size_t)qt4 * QTB) * TV;
+    for (int i = tid; i < QTB * TV; i += 512) ldsv[i] = src[i];
+  }
+  __syncthreads();
+  const u32x4* la = ldsv + lane;
+  float* dist = ch ? dist_i : dist_p;
+  const int qrow0 = qt4 * QTB * 8;
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+      dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < QTB * 8 ? m - qrow0 : QTB * 8) : 0) * n * 4, 0x00020000);
+  const unsigned st_lane = (unsigned)((2 * (lane & 3) + (lane >> 5)) * n + ((lane & 31) >> 2)) * 4u;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (s0 >= s1) return;
+  const u32x4* pb = dpk + ((size_t)ch * DT + (size_t)s0 * 8 + w) * TV + lane;
+  HL bs[3];                 // DB operands of K-steps st, st + 1, st + 2
+  HL a[QTB];
+#define MF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
+#define SBAR() __builtin_amdgcn_sched_barrier(0)
+  bs[0].h = pb[0]; bs[0].l = pb[64];
+  bs[1].h = pb[128]; bs[1].l = pb[128 + 64];
+#pragma unroll
+  for (int t = 0; t < QTB; t++) { a[t].h = la[t * TV]; a[t].l = la[t * TV + 64]; }
+  for (int s = s0; s < s1; s++) {
+    const int dt0 = s * 8 + w;
+    const u32x4* pn = pb + 8 * TV;
+    f32x16 acc[QTB];
+#pragma unroll
+    for (int st = 0; st < 12; st++) {
+      const HL& c = bs[st % 3];
+      HL& nx = bs[(st + 2) % 3];
+      const u32x4* pq = (st + 2 < 12) ? pb + (st + 2) * 128 : pn + (st + 2 - 12) * 128;
+      const bool first = st == 0;
+#pragma unroll
+      for (int t = 0; t < QTB; t++) {
+        SBAR();
+        acc[t] = MF(a[t].h, c.h, first ? zero : acc[t]);
+        SBAR();
+        if (t == 0) nx.h = pq[0]; else if (t == 1) nx.l = pq[64];
+        SBAR();
+        acc[t] = MF(a[t].h, c.l, acc[t]);
+        SBAR();
+        a[t].h = la[t * TV + ((st + 1) % 12) * 128];
+        SBAR();
+        acc[t] = MF(a[t].l, c.h, acc[t]);
+        SBAR();
+        a[t].l = la[t * TV + ((st + 1) % 12) * 128 + 64];
+        SBAR();
+      }
+    }
+    pb = pn;
+#pragma unroll
+    for (int i = 0; i < QTB; i++) {
+      float sel = 0.f;
+#pragma unroll
+      for (int gq = 0; gq < 4; gq++) {
+        float mx = fmaxf(fmaxf(acc[i][gq * 4], acc[i][gq * 4 + 1]), fmaxf(acc[i][gq * 4 + 2], acc[i][gq * 4 + 3]));
+        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xf, 0xf, true)));   // quad_perm [1,0,3,2]
+        mx = fmaxf(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4E, 0xf, 0xf, true)));   // quad_perm [2,3,0,1]
+        sel = ((lane & 3) == gq) ? mx : sel;
+      }
+      const int drow = dt0 * 8 + ((lane & 31) >> 2);
+      const unsigned off = (drow < n) ? st_lane + (unsigned)((8 * i) * n + dt0 * 8) * 4u : 0x80000000u;
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(sel, -0x1p-17f, 0.5f)), rd, (int)off, 0, 0);   // processM2DP.m:15,19
+    }
+  }
+#undef SBAR
+#undef MF
+}
+
 }  // namespace
 
 void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, void* packed, int tiles) {
@@ -172,6 +262,7 @@ void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk
   // 4 query tiles per workgroup; PR_M2_QTB=3 selects the two-workgroups-per-CU variant for A/B runs (measured 6.4 ms against
   // 5.55 ms at 4096 x 50k: the overlap of two workgroups does not pay for a third more DB operand traffic per MFMA)
   static const int qtb = (getenv("PR_M2_QTB") && atoi(getenv("PR_M2_QTB")) == 3) ? 3 : 4;
+  static const bool eight = !(getenv("PR_M2_WAVES") && atoi(getenv("PR_M2_WAVES")) == 4);   // PR_M2_WAVES=4: the one-wave-per-SIMD kernel, for A/B runs
   const int base = (QT / qtb) * 2, DT8 = (DT + 7) / 8;
   // DB ranges per query block: enough workgroups for ~4 rounds, and among the next few counts the one that wastes the
   // least of its last round (the workgroups that hold padding tiles only return at once and do not count)
@@ -186,6 +277,12 @@ void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk
   if (nsplit > DT8 / 4) nsplit = DT8 / 4;
   if (nsplit < 1) nsplit = 1;
   const size_t lds = (size_t)qtb * TB;
+  if (eight && qtb == 4) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(m2dp_match_h8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(m2dp_match_h8_kernel, dim3(base * nsplit), dim3(512), lds, st, static_cast<const u32x4*>(qpk),
+                       static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
+    return;
+  }
   auto* k = qtb == 4 ? m2dp_match_h_kernel<4> : m2dp_match_h_kernel<3>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(base * nsplit), dim3(256), lds, st, static_cast<const u32x4*>(qpk),

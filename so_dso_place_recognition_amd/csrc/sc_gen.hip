@@ -57,6 +57,37 @@ __device__ void jacobi_eig3(double a[3][3], double v[3][3]) {
   }
 }
 
+// raw moments (sum p, sum p p^T) of a cloud of n points -> frame {mean[3], v0[3], v1[3], v2[3], 0, n, 0, 0}: scatter matrix
+// cov = sum pp^T - n mean mean^T (un-normalised as pts_align.h:30), 3x3 Jacobi, eigenvalues ascending (Eigen::SelfAdjointEigenSolver
+// order, :32-34), canonical signs (N3)
+__device__ void finish_frame(const double s[9], double n, double* f) {
+  const double mx = s[0] / n, my = s[1] / n, mz = s[2] / n;
+  double a[3][3], v[3][3];
+  a[0][0] = s[3] - n * mx * mx; a[0][1] = s[4] - n * mx * my; a[0][2] = s[5] - n * mx * mz;
+  a[1][1] = s[6] - n * my * my; a[1][2] = s[7] - n * my * mz; a[2][2] = s[8] - n * mz * mz;
+  a[1][0] = a[0][1]; a[2][0] = a[0][2]; a[2][1] = a[1][2];
+  jacobi_eig3(a, v);
+  int ord[3] = {0, 1, 2};
+  for (int i = 0; i < 2; i++)
+    for (int j = 0; j < 2 - i; j++)
+      if (a[ord[j + 1]][ord[j + 1]] < a[ord[j]][ord[j]]) { const int t = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = t; }
+  double e[3][3];
+  for (int j = 0; j < 3; j++)
+    for (int k = 0; k < 3; k++) e[j][k] = v[k][ord[j]];
+  for (int j = 0; j < 2; j++) {   // canonical sign: largest-|component| positive (N3)
+    int im = 0;
+    for (int k = 1; k < 3; k++) if (fabs(e[j][k]) > fabs(e[j][im])) im = k;
+    if (e[j][im] < 0) for (int k = 0; k < 3; k++) e[j][k] = -e[j][k];
+  }
+  const double cx = e[0][1] * e[1][2] - e[0][2] * e[1][1], cy = e[0][2] * e[1][0] - e[0][0] * e[1][2],
+               cz = e[0][0] * e[1][1] - e[0][1] * e[1][0];
+  if (cx * e[2][0] + cy * e[2][1] + cz * e[2][2] < 0) for (int k = 0; k < 3; k++) e[2][k] = -e[2][k];   // det = +1
+  f[0] = mx; f[1] = my; f[2] = mz;
+  for (int j = 0; j < 3; j++)
+    for (int k = 0; k < 3; k++) f[3 + 3 * j + k] = e[j][k];
+  f[12] = 0; f[13] = n; f[14] = 0; f[15] = 0;
+}
+
 // The float average of the reference is a sequential sum in input order (SC.cpp:60-64, M2DP.cpp:77-81): one dependent
 // v_add_f32 per point, ~5 cycles each - 0.1 ms for 50k points whatever the number of clouds.  One wave per CPW = 8
 // clouds: all 64 lanes stream the next CH = 512 floats of each of the 8 clouds (coalesced 16-byte loads, requested one
@@ -156,33 +187,7 @@ __global__ __launch_bounds__(FT) void cloud_frames_kernel(const double* __restri
       for (int i = 0; i < RW; i++) v += red[i][k];
       s[k] = v;
     }
-    const double n = (double)P;
-    const double mx = s[0] / n, my = s[1] / n, mz = s[2] / n;
-    double a[3][3], v[3][3];
-    a[0][0] = s[3] - n * mx * mx; a[0][1] = s[4] - n * mx * my; a[0][2] = s[5] - n * mx * mz;
-    a[1][1] = s[6] - n * my * my; a[1][2] = s[7] - n * my * mz; a[2][2] = s[8] - n * mz * mz;
-    a[1][0] = a[0][1]; a[2][0] = a[0][2]; a[2][1] = a[1][2];
-    jacobi_eig3(a, v);
-    int ord[3] = {0, 1, 2};   // ascending eigenvalues (Eigen::SelfAdjointEigenSolver order, pts_align.h:32-34)
-    for (int i = 0; i < 2; i++)
-      for (int j = 0; j < 2 - i; j++)
-        if (a[ord[j + 1]][ord[j + 1]] < a[ord[j]][ord[j]]) { const int t = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = t; }
-    double e[3][3];
-    for (int j = 0; j < 3; j++)
-      for (int k = 0; k < 3; k++) e[j][k] = v[k][ord[j]];
-    for (int j = 0; j < 2; j++) {   // canonical sign: largest-|component| positive (N3)
-      int im = 0;
-      for (int k = 1; k < 3; k++) if (fabs(e[j][k]) > fabs(e[j][im])) im = k;
-      if (e[j][im] < 0) for (int k = 0; k < 3; k++) e[j][k] = -e[j][k];
-    }
-    const double cx = e[0][1] * e[1][2] - e[0][2] * e[1][1], cy = e[0][2] * e[1][0] - e[0][0] * e[1][2],
-                 cz = e[0][0] * e[1][1] - e[0][1] * e[1][0];
-    if (cx * e[2][0] + cy * e[2][1] + cz * e[2][2] < 0) for (int k = 0; k < 3; k++) e[2][k] = -e[2][k];   // det = +1
-    double* f = frames + (size_t)c * 16;
-    f[0] = mx; f[1] = my; f[2] = mz;
-    for (int j = 0; j < 3; j++)
-      for (int k = 0; k < 3; k++) f[3 + 3 * j + k] = e[j][k];
-    f[12] = 0; f[13] = n; f[14] = 0; f[15] = 0;
+    finish_frame(s, (double)P, frames + (size_t)c * 16);
   }
 }
 
