@@ -67,6 +67,15 @@ void launch_merge_topk(hipStream_t st, const int32_t* idx_all, const double* sco
 // sc_gen.hip / m2dp_gen.hip — pts_align.h:7-46 + SC.cpp:12-76 / M2DP.cpp:38-109 (+ test_m2dp.cpp:44-68)
 void launch_ave_chain(hipStream_t st, const float* inten, const int64_t* offs, int N, float* ave);
 void launch_cloud_frames(hipStream_t st, const double* xyz, const int64_t* offs, int N, double* frames);
+// the one-HBM-pass path of SC generation (see sc_gen.hip): a batch of clouds small enough for the Infinity Cache, W workgroups per cloud
+constexpr int SC_MAX_W = 16;                     // slices per cloud
+constexpr int SC_MAX_SPLIT_CLOUDS = 1024;        // clouds per batch when W > 1
+constexpr size_t SC_SCRATCH_PER_STREAM = (size_t)2 * SC_MAX_SPLIT_CLOUDS * 4 + (size_t)SC_MAX_SPLIT_CLOUDS * SC_MAX_W * 9 * 8 +
+                                         (size_t)768 * (1200 * 4 + 3 * 1200 * 8);   // tickets + partial moments + partial grids (nb * W <= 768)
+size_t sc_generate_scratch_bytes();
+void launch_sc_batch(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int c0, int c1, int W, double max_rho,
+                     double* frames, char* scratch, double* out);
+void launch_sc_finish(hipStream_t st, const float* ave, int N, double* out);
 void launch_sc_bin(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double max_rho,
                    const double* frames, const float* ave, double* out);
 void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,

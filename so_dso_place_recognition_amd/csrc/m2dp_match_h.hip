@@ -157,12 +157,13 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
 }
 
 
-// The shipped geometry: EIGHT waves per workgroup (two per SIMD), each 4 query tiles x ONE DB tile (64 accumulators, 12 MFMAs
-// and 2 DB operand loads per K-step: the same loads per MFMA as the 4-wave kernel above).  The 4-wave kernel runs one wave per
-// SIMD (96 KB of query tiles leave room for one workgroup per CU), so nothing covers its epilogue (8 tiles x ~40 instructions
-// per sweep step = 14 % of the step) nor the operand-request stalls: the matrix pipe was 76 % busy.  Here the second wave
-// of every SIMD fills those holes.  Same LDS image, same packed layouts, same result bit for bit (the products of a
-// (query tile, DB tile) pair are accumulated in the same order).
+// A/B variant (PR_M2_WAVES=8, not the default): EIGHT waves per workgroup (two per SIMD), each 4 query tiles x ONE DB tile (64
+// accumulators, 12 MFMAs and 2 DB operand loads per K-step: the same loads per MFMA as the 4-wave kernel above).  The 4-wave
+// kernel runs one wave per SIMD (96 KB of query tiles leave room for one workgroup per CU), so nothing covers its epilogue (8
+// tiles x ~40 instructions per sweep step = 14 % of the step) nor its operand-request stalls: the matrix pipe is 76 % busy.
+// Here the second wave of every SIMD fills those holes - and the launch is 2 % SLOWER (5.64 against 5.50 ms at 4096 x 50k,
+// same box, same run): the chip runs this kernel at ~1.7 GHz against its power limit, so a busier matrix pipe is paid back
+// in clock (MI355X_MICROARCH.md "DVFS give-back").  Same LDS image, same packed layouts, same result bit for bit.
 __global__ __launch_bounds__(512, 2) void m2dp_match_h8_kernel(const u32x4* __restrict__ qpk, const u32x4* __restrict__ dpk,
                                                                float* __restrict__ dist_p, float* __restrict__ dist_i,
                                                                int m, int n, int QT, int DT, int nsplit) {
@@ -262,7 +263,7 @@ void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk
   // 4 query tiles per workgroup; PR_M2_QTB=3 selects the two-workgroups-per-CU variant for A/B runs (measured 6.4 ms against
   // 5.55 ms at 4096 x 50k: the overlap of two workgroups does not pay for a third more DB operand traffic per MFMA)
   static const int qtb = (getenv("PR_M2_QTB") && atoi(getenv("PR_M2_QTB")) == 3) ? 3 : 4;
-  static const bool eight = !(getenv("PR_M2_WAVES") && atoi(getenv("PR_M2_WAVES")) == 4);   // PR_M2_WAVES=4: the one-wave-per-SIMD kernel, for A/B runs
+  static const bool eight = getenv("PR_M2_WAVES") && atoi(getenv("PR_M2_WAVES")) == 8;   // PR_M2_WAVES=8: the two-waves-per-SIMD kernel, for A/B runs
   const int base = (QT / qtb) * 2, DT8 = (DT + 7) / 8;
   // DB ranges per query block: enough workgroups for ~4 rounds, and among the next few counts the one that wastes the
   // least of its last round (the workgroups that hold padding tiles only return at once and do not count)

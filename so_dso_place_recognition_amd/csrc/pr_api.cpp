@@ -25,6 +25,9 @@ struct pr_ctx {
   int nan_policy = PR_NAN_EXCLUDE;
   int warnings = 0;              // PR_WARN_* bits not yet taken
   hipStream_t side = nullptr;    // overlaps the sequential float-average chain with the moments pass
+  hipStream_t side2 = nullptr;   // SC generation: odd batches (kernel boundaries of one stream hide behind the other's kernels)
+  hipEvent_t ev_b = nullptr;
+  char* sc_scratch = nullptr;    // tickets + partial moments / bin grids of the split SC generation, one half per stream
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   int* d_flags = nullptr;        // [4] deferred bits: [0] zero-norm row at pack time, [1] M2DP singular pair not converged
@@ -139,6 +142,8 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
     if (use_external) { ctx->stream = external; ctx->own_stream = false; }
     else TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    TRY(hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
+    TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
     TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     TRY(hipMalloc((void**)&ctx->d_flags, 4 * sizeof(int)));
@@ -236,6 +241,9 @@ void pr_destroy(pr_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->stream || !ctx->own_stream) { (void)hipStreamSynchronize(ctx->stream); if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream); }
   if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+  if (ctx->side2) { (void)hipStreamSynchronize(ctx->side2); (void)hipStreamDestroy(ctx->side2); }
+  if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
+  if (ctx->sc_scratch) (void)hipFree(ctx->sc_scratch);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
@@ -862,8 +870,55 @@ int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const
   DevBuf frames, ave;
   PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
   PR_HIP(ctx, ave.alloc((size_t)N * 4));
-  if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc;
-  pr::launch_sc_bin(ctx->stream, xyz, inten, offs, N, max_rho, frames.as<double>(), ave.as<float>(), out);
+  // Default: two streaming passes over all clouds at once (moments, then binning).  PR_SC_GEN=batched selects the
+  // cache-resident variant below - batches of ~96 MB, W workgroups per cloud, last-arriver merges - which moves half the
+  // HBM bytes but measured 6.25 ms against 2.6 ms at 5000 x 50 000 points (74 batches x 2 launches of ~550 workgroups each
+  // cannot keep enough loads in flight; tools/experiments/README.md).
+  static const bool two_pass = !(getenv("PR_SC_GEN") && !strcmp(getenv("PR_SC_GEN"), "batched"));
+  if (two_pass) {
+    if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc;
+    pr::launch_sc_bin(ctx->stream, xyz, inten, offs, N, max_rho, frames.as<double>(), ave.as<float>(), out);
+    PR_HIP(ctx, hipGetLastError());
+    PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PR_OK;
+  }
+  if (!ctx->sc_scratch) {
+    PR_HIP(ctx, hipMalloc((void**)&ctx->sc_scratch, pr::sc_generate_scratch_bytes()));
+    PR_HIP(ctx, hipMemsetAsync(ctx->sc_scratch, 0, pr::sc_generate_scratch_bytes(), ctx->stream));   // the tickets reset themselves afterwards
+  }
+  // cloud sizes decide the batches: offs comes back to the host (N + 1 values; the call synchronises at its end anyway)
+  std::vector<int64_t> ho((size_t)N + 1);
+  PR_HIP(ctx, hipMemcpyAsync(ho.data(), offs, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // the float-average chain over all clouds on the side stream; odd batches on side2
+  PR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  PR_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  PR_HIP(ctx, hipStreamWaitEvent(ctx->side2, ctx->ev_fork, 0));
+  pr::launch_ave_chain(ctx->side, inten, offs, N, ave.as<float>());
+  PR_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+  // Batches of ~96 MB of points (two of them fit the 256 MB Infinity Cache): the binning pass of a batch re-reads what its
+  // moments pass has just pulled through the cache, so HBM sees every point once.
+  static const int64_t batch_bytes = getenv("PR_SC_BATCH_MB") ? (int64_t)atol(getenv("PR_SC_BATCH_MB")) << 20 : (int64_t)96 << 20;
+  hipStream_t st[2] = {ctx->stream, ctx->side2};
+  int nbatch = 0;
+  for (int c0 = 0; c0 < N;) {
+    int c1 = c0;
+    int64_t pts = 0;
+    while (c1 < N && (c1 == c0 || (pts + ho[c1 + 1] - ho[c1]) * 28 <= batch_bytes)) { pts += ho[c1 + 1] - ho[c1]; c1++; }
+    int nb = c1 - c0;
+    int W = (512 + nb - 1) / nb;                       // >= ~512 workgroups per launch
+    if (W > pr::SC_MAX_W) W = pr::SC_MAX_W;
+    if (nb > 384) W = 1;                                // many small clouds: one workgroup per cloud fills the chip already
+    while (W > 1 && (int64_t)nb * W > 768) W--;         // capacity of the partial-grid scratch
+    pr::launch_sc_batch(st[nbatch & 1], xyz, inten, offs, c0, c1, W, max_rho, frames.as<double>(),
+                        ctx->sc_scratch + (size_t)(nbatch & 1) * pr::SC_SCRATCH_PER_STREAM, out);
+    nbatch++;
+    c0 = c1;
+  }
+  PR_HIP(ctx, hipEventRecord(ctx->ev_b, ctx->side2));
+  PR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_b, 0));
+  PR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  pr::launch_sc_finish(ctx->stream, ave.as<float>(), N, out);
   PR_HIP(ctx, hipGetLastError());
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PR_OK;

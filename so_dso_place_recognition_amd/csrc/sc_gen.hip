@@ -16,6 +16,16 @@
 //                  atomics: count (u32 add), min/max of x (order-preserving u64 keys), fp64 intensity sum; epilogue
 //                  max-min and mean > ave ? 1 : 0 (:67-75) -> out[c][2400].
 // Bound: HBM (28 B per point per pass); the points are never written back.
+//
+// One HBM pass instead of two (launch_sc_generate): the clouds are taken in batches of ~96 MB, small enough for two batches
+// to stay in the 256 MB Infinity Cache, and every batch runs moments -> binning back to back, so the binning pass re-reads
+// the points from the cache, not from HBM.  A batch of 50 000-point clouds holds only ~70 of them - one workgroup per cloud
+// would leave most of the chip idle - so both kernels split a cloud over W workgroups (cloud_frames_split / sc_bin_split):
+// each takes a slice of the points, writes its partial moments (9 doubles) or partial bin grids (33.6 KB) and takes a ticket;
+// the last to arrive merges the partials in slice order - moments are summed in that fixed order, counts add, min / max
+// commute and the fp64 intensity sums are exact (floats of <= 24 bits, a few thousand per bin) - so the result does not depend
+// on which workgroup came last.  Consecutive batches alternate between two streams, which hides the kernel boundaries.  The float
+// average chain runs over all clouds on a third stream and meets the bins in sc_finish.
 #include "fast_bins.hpp"
 #include "kernels.hpp"
 
@@ -249,11 +259,181 @@ __global__ __launch_bounds__(512) void sc_bin_kernel(const double* __restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------- split (batched) path
+constexpr int PART_BYTES = 1200 * 4 + 3 * 1200 * 8;   // partial bin grids of one (cloud, slice): cnt u32 | lo u64 | hi u64 | sum f64
+
+// last-arriver protocol (MI355X_MICROARCH.md "Valid forms"): plain stores -> __syncthreads -> lane-0 agent-scope release ->
+// ticket; the winner: agent-scope acquire -> __syncthreads -> plain loads.  The ticket counter resets itself for the next batch.
+__device__ __forceinline__ bool last_arriver(unsigned* ticket, int W, int tid, int* flag) {
+  __syncthreads();
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == (unsigned)(W - 1));
+    if (last) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+
+__global__ __launch_bounds__(FT) void cloud_frames_split_kernel(const double* __restrict__ xyz, const int64_t* __restrict__ offs,
+                                                                 int c0, int W, double* __restrict__ partial,
+                                                                 unsigned* __restrict__ ticket, double* __restrict__ frames) {
+  __shared__ double red[RW][9];
+  __shared__ int flag;
+  const int cl = blockIdx.x / W, sl = blockIdx.x - cl * W, c = c0 + cl;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int64_t o0 = offs[c];
+  const int64_t P = offs[c + 1] - o0;
+  const int64_t i0 = P * sl / W, i1 = P * (sl + 1) / W;
+  {
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    const double* p = xyz + 3 * o0;
+    for (int64_t i = i0 + tid; i < i1; i += FT) {
+      const double x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+      s[0] += x; s[1] += y; s[2] += z;
+      s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      double v = s[k];
+      for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+      if (lane == 0) red[w][k] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < 9) {
+    double v = 0;
+    for (int i = 0; i < RW; i++) v += red[i][tid];
+    partial[((size_t)cl * W + sl) * 9 + tid] = v;
+  }
+  if (!last_arriver(ticket + cl, W, tid, &flag)) return;
+  if (tid == 0) {
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int u = 0; u < W; u++)                                   // slice order: the sum does not depend on the arrival order
+      for (int k = 0; k < 9; k++) s[k] += partial[((size_t)cl * W + u) * 9 + k];
+    finish_frame(s, (double)P, frames + (size_t)c * 16);
+  }
+}
+
+// binning of slice sl of cloud c; the last slice to finish merges all W partial grids and writes, per bin,
+// out[b] = max - min of the aligned x (SC.cpp:74) and out[1200 + b] = MEAN intensity (-inf for an empty bin); sc_finish turns
+// the mean into the 0/1 of SC.cpp:69-70 once the float average is known.
+__global__ __launch_bounds__(512) void sc_bin_split_kernel(const double* __restrict__ xyz, const float* __restrict__ inten,
+                                                            const int64_t* __restrict__ offs, int c0, int W,
+                                                            const double* __restrict__ frames, double max_rho,
+                                                            char* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                            double* __restrict__ out) {
+  __shared__ unsigned int cnt[1200];
+  __shared__ unsigned long long lo[1200], hi[1200];
+  __shared__ double sum[1200];
+  __shared__ int flag;
+  const int cl = blockIdx.x / W, sl = blockIdx.x - cl * W, c = c0 + cl, tid = threadIdx.x;
+  const int64_t o0 = offs[c];
+  const int64_t P = offs[c + 1] - o0;
+  const int64_t i0 = P * sl / W, i1 = P * (sl + 1) / W;
+  for (int b = tid; b < 1200; b += 512) { cnt[b] = 0u; lo[b] = ~0ull; hi[b] = 0ull; sum[b] = 0.0; }
+  __syncthreads();
+  const double* f = frames + (size_t)c * 16;
+  const double mx = f[0], my = f[1], mz = f[2];
+  const double e00 = f[3], e01 = f[4], e02 = f[5], e10 = f[6], e11 = f[7], e12 = f[8], e20 = f[9], e21 = f[10], e22 = f[11];
+  const double S_res_inv = 60 / (2.0 * M_PI), R_res_inv = 20 / max_rho;   // SC.cpp:5-8
+  const float S_f = (float)S_res_inv, R_f = (float)R_res_inv;
+  const double* p = xyz + 3 * o0;
+  const float* it = inten + o0;
+  for (int64_t i = i0 + tid; i < i1; i += 512) {
+    const double x = p[3 * i] - mx, y = p[3 * i + 1] - my, z = p[3 * i + 2] - mz;   // pts_align.h:24-26
+    const double nx = (x * e00 + y * e01) + z * e02;                                // :37-39
+    const double yp = (x * e10 + y * e11) + z * e12;
+    const double zp = (x * e20 + y * e21) + z * e22;
+    const int si = polar_sector(zp, yp, S_res_inv, S_f);    // SC.cpp:37
+    const int ri = polar_ring(yp, zp, R_res_inv, R_f);      // SC.cpp:38
+    const int idx = si * 20 + ri;                                                   // :39
+    if (idx >= 1200 || idx < 0) continue;                                           // :42-44
+    atomicAdd(&cnt[idx], 1u);
+    const unsigned long long k = dkey(nx);
+    atomicMin(&lo[idx], k);
+    atomicMax(&hi[idx], k);
+    atomicAdd(&sum[idx], (double)it[i]);
+  }
+  __syncthreads();
+  if (W > 1) {
+    char* mine = partial + ((size_t)cl * W + sl) * PART_BYTES;
+    unsigned* pc = reinterpret_cast<unsigned*>(mine);
+    unsigned long long* pl = reinterpret_cast<unsigned long long*>(mine + 4800);
+    unsigned long long* ph = pl + 1200;
+    double* ps = reinterpret_cast<double*>(ph + 1200);
+    for (int b = tid; b < 1200; b += 512) { pc[b] = cnt[b]; pl[b] = lo[b]; ph[b] = hi[b]; ps[b] = sum[b]; }
+    if (!last_arriver(ticket + cl, W, tid, &flag)) return;
+    for (int u = 0; u < W; u++) {
+      if (u == sl) continue;
+      const char* o = partial + ((size_t)cl * W + u) * PART_BYTES;
+      const unsigned* qc = reinterpret_cast<const unsigned*>(o);
+      const unsigned long long* ql = reinterpret_cast<const unsigned long long*>(o + 4800);
+      const unsigned long long* qh = ql + 1200;
+      const double* qs = reinterpret_cast<const double*>(qh + 1200);
+      for (int b = tid; b < 1200; b += 512) {
+        cnt[b] += qc[b];
+        lo[b] = ql[b] < lo[b] ? ql[b] : lo[b];
+        hi[b] = qh[b] > hi[b] ? qh[b] : hi[b];
+        sum[b] += qs[b];                                         // exact: floats of <= 24 bits, a few thousand per bin
+      }
+    }
+  }
+  double* o = out + (size_t)c * 2400;
+  for (int b = tid; b < 1200; b += 512) {
+    const unsigned int n = cnt[b];
+    o[b] = n ? dunkey(hi[b]) - dunkey(lo[b]) : 0.0;                                 // :74
+    o[1200 + b] = n ? sum[b] / (double)n : -__builtin_inf();                        // the mean; sc_finish compares it with the average
+  }
+}
+
+// out[c][1200 + b]: mean intensity of the bin -> (mean > float average) ? 1 : 0   (SC.cpp:69-70)
+__global__ __launch_bounds__(256) void sc_finish_kernel(const float* __restrict__ ave_in, int N, double* __restrict__ out) {
+  const int c = blockIdx.x;
+  const double ave = (double)ave_in[c];   // the float average, widened (double > float promotes the float, SC.cpp:70)
+  double* o = out + (size_t)c * 2400 + 1200;
+  for (int b = threadIdx.x; b < 1200; b += 256) o[b] = o[b] > ave ? 1.0 : 0.0;
+}
+
 }  // namespace
 
 void launch_ave_chain(hipStream_t st, const float* inten, const int64_t* offs, int N, float* ave) {
   if (N <= 0) return;
   hipLaunchKernelGGL(ave_chain_kernel, dim3((N + CPW - 1) / CPW), dim3(64), 0, st, inten, offs, N, ave);
+}
+
+
+size_t sc_generate_scratch_bytes() { return (size_t)2 * SC_SCRATCH_PER_STREAM; }
+
+// Clouds c0..c1-1 as ONE batch on stream st: moments then bins, W workgroups per cloud.  scratch: this stream's
+// SC_SCRATCH_PER_STREAM bytes = [tickets frames | tickets bins | partial moments | partial grids], tickets zero once.
+void launch_sc_batch(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int c0, int c1, int W, double max_rho,
+                     double* frames, char* scratch, double* out) {
+  const int nb = c1 - c0;
+  if (nb <= 0) return;
+  unsigned* tk_f = reinterpret_cast<unsigned*>(scratch);
+  unsigned* tk_b = tk_f + SC_MAX_SPLIT_CLOUDS;
+  double* pm = reinterpret_cast<double*>(scratch + 2 * SC_MAX_SPLIT_CLOUDS * 4);
+  char* pg = reinterpret_cast<char*>(pm + (size_t)SC_MAX_SPLIT_CLOUDS * SC_MAX_W * 9);
+  if (W <= 1) {
+    hipLaunchKernelGGL(cloud_frames_kernel, dim3(nb), dim3(FT), 0, st, xyz, offs + c0, frames + (size_t)c0 * 16);
+    hipLaunchKernelGGL(sc_bin_split_kernel, dim3(nb), dim3(512), 0, st, xyz, inten, offs, c0, 1, frames, max_rho, pg, tk_b, out);
+    return;
+  }
+  hipLaunchKernelGGL(cloud_frames_split_kernel, dim3(nb * W), dim3(FT), 0, st, xyz, offs, c0, W, pm, tk_f, frames);
+  hipLaunchKernelGGL(sc_bin_split_kernel, dim3(nb * W), dim3(512), 0, st, xyz, inten, offs, c0, W, frames, max_rho, pg, tk_b, out);
+}
+
+void launch_sc_finish(hipStream_t st, const float* ave, int N, double* out) {
+  if (N <= 0) return;
+  hipLaunchKernelGGL(sc_finish_kernel, dim3(N), dim3(256), 0, st, ave, N, out);
 }
 
 void launch_cloud_frames(hipStream_t st, const double* xyz, const int64_t* offs, int N, double* frames) {
