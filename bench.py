@@ -168,6 +168,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sc-arith", default=None, choices=["f16x2", "f32"],
                     help="SC matcher arithmetic (default: the library's, split-f16 MFMA; f32 = the fp32-MFMA kernel)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="N = 1 only: run the two all-gathers (RCCL, one-rank group) and the device merge of the sharded protocol anyway")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under `extra`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: several ranks on ONE GPU, tests only)")
     args = ap.parse_args()
@@ -194,6 +196,9 @@ def main():
         else:
             dist.init_process_group(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if args.force_exchange and world == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     n, m = args.db, args.queries
     lo, hi = (n * rank) // world, (n * (rank + 1)) // world          # this rank's DB rows
@@ -218,7 +223,7 @@ def main():
         if pair is not None:   # the only launches between the two records are the matcher and the NaN fix-up, on the stream they run on
             mt.pre_distances = lambda: ev.record(pair[0], stream)
             mt.post_distances = lambda: ev.record(pair[1], stream)
-        out = mt.match(q, 0, 2.0, 1, db_row0=lo)
+        out = mt.match(q, 0, 2.0, 1, db_row0=lo, force_exchange=args.force_exchange)
         mt.pre_distances = mt.post_distances = None
         return out
 
@@ -270,7 +275,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "sc_match_100k", "db_signatures": n, "queries_per_step": m, "descriptor": "SC 20x60 x 2 channels",
                        "mask_width": 0, "p_weight": 2.0, "k": 1, "db_rows_per_gpu": hi - lo,
-                       "step": "pack(q)+pack(db)+distances+moments+fuse/top-1" + ("+2 all_gathers" if world > 1 else "")},
+                       "step": "pack(q)+pack(db)+distances+moments+select(k+8)+fp64 re-evaluation"
+                               + ("+3 all_gathers+merge" if (world > 1 or args.force_exchange) else "")},
             "roofline": {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak,
                          "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
                          "traffic_source": ("profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE passes of this command, per launch"
@@ -313,7 +319,7 @@ def main():
             torch.cuda.empty_cache()
             out["extra"] = extra_workloads(dev, ev, args)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or args.force_exchange:
         dist.destroy_process_group()
 
 

@@ -253,17 +253,9 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
     TICK(7)
 // request tile T of frequency Q of this group (Q >= 31: nothing - the first requests of the next group are issued by
 // hand late in the stage-2 phase, when half of the packed registers are free again)
-#if defined(EXP_NOLOADB)
-#define LDB(Q, T) {}
-#else
 #define LDB(Q, T) { if ((Q) < SC_NF) load_b<((Q) < SC_NF ? (Q) : 0), T>(Bt[(Q) & 3], rs, voff); }
-#endif
-#if defined(EXP_NOLOADA)
-#define LDA(P, Q, T) {}
-#else
 #define LDA(P, Q, T) { if ((Q) < SC_NF) { if (((Q) >> 1) == ((P) >> 1)) load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], ncur, rcur); \
                                         else load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], nnxt, rnxt); } }
-#endif
 #define FREQ(P, t1, t2, W0, W1, W2, W3, W4, W5)                                                   \
   {                                                                                               \
     SB(); MF0(t1, At[(P) & 3].h, Bt[(P) & 3].reh);  SB(); LDB((P) + 1, B_IML); LDA(P, (P) + 1, A_L); W0;   \
@@ -274,13 +266,8 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
     SB(); MFA(t2, At[(P) & 3].rh, Bt[(P) & 3].iml); SB(); LDA(P, (P) + 2, A_RH); W5;              \
     SB();                                                                                         \
   }
-#ifdef EXP_NOPACK
-#define PKF(J, R) { if ((J) == 7 || (J) == 3) pack_F<J, R>(hb, Fa, Fb); }
-#define PKM(J, R) { if ((J) == 7 || (J) == 3) pack_M<J, R>(hb, Ma, Mb); }
-#else
 #define PKF(J, R) pack_F<J, R>(hb, Fa, Fb)
 #define PKM(J, R) pack_M<J, R>(hb, Ma, Mb)
-#endif
 #define PK(J, R) { PKF(J, R); PKM(J, R); }
 #define NONE ((void)0)
 // LDS bases of this lane's tiles: current pair and next pair (one opaque add per pair and operand kind)

@@ -162,12 +162,13 @@ class Matcher(_Base):
         return _merge_dev(self, idx_all, sc_all, k)
 
     def match(self, queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
-              db_row0: int = 0, q_row0: int = 0, group=None):
-        """Returns (idx int32 [m,k] GLOBAL DB row indices, score float64 [m,k]) as device tensors."""
+              db_row0: int = 0, q_row0: int = 0, group=None, force_exchange: bool = False):
+        """Returns (idx int32 [m,k] GLOBAL DB row indices, score float64 [m,k]) as device tensors.
+        force_exchange: run the two all-gathers and the merge even with one rank (measures the protocol's overhead)."""
         G = _world(group)
         return sharded_topk(lambda: self.local_phase1(queries),
                             lambda mom_all, G_: self.local_phase2(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
-                            k, group if G > 1 else None, G, merge=self.merge)
+                            k, group if (G > 1 or force_exchange) else None, G, merge=self.merge, force_exchange=force_exchange)
 
     def distances(self):
         """The last distance matrices (device, float32 [m, n_local])."""
@@ -250,12 +251,12 @@ def _merge_dev(owner, idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
     return idx, score
 
 
-def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None):
+def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None, force_exchange: bool = False):
     """The exchange protocol of SURVEY.md §8-e around two local callables (HIP in production; a numpy stand-in in
     the gloo CPU tests): moments -> all_gather -> select with the moments of all shards -> all_gather -> merge."""
     import torch.distributed as dist
     mom = local_moments()
-    if G == 1:
+    if G == 1 and not force_exchange:
         return local_select(mom.unsqueeze(0) if mom.dim() == 3 else mom, 1)
     stage_on_host = dist.get_backend(group) == "gloo"   # gloo has no device all_gather: used by the single-GPU tests
 
