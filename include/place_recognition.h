@@ -160,6 +160,17 @@ int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
 int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                   const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
                   int32_t mask_width, double p_weight, int32_t k_in, const int32_t* idx_in, int32_t k, int32_t* idx, double* score);
+/* The sharded form of the re-evaluation (what makes its cost independent of the number of shards): the shards' fp32 top-(k+8) lists
+ * are merged FIRST (pr_merge_topk_dev on the gathered lists) into the global candidates cand_idx DEVICE [m][k_in]; every shard then
+ * evaluates only the candidates inside its rows [db_row0, db_row0 + n_local) - part DEVICE f64 [m][k_in], NaN for the others -
+ * and pr_rerank_finish_dev takes each candidate's score from its owner (part_all DEVICE [G][m][k_in]) and selects the k best. */
+int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
+                          const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
+                          int32_t mask_width, double p_weight, int32_t k_in, const int32_t* cand_idx, double* part);
+int pr_rerank_finish_dev(pr_ctx* ctx, const int32_t* cand_idx, const double* part_all, int32_t G, int32_t m, int32_t k_in, int32_t k,
+                         int32_t* idx, double* score);
+/* fp32 scores of pr_fuse_select_dev as doubles (the merge works on doubles): DEVICE score32 [count] -> score64 [count] */
+int pr_widen_scores_dev(pr_ctx* ctx, const float* score32, int64_t count, double* score64);
 /* k-way merge of the per-shard results of G shards (SURVEY.md §8-e collective B's second half): idx_all DEVICE [G][m][k],
  * score_all DEVICE f64 [G][m][k] -> idx [m][k], score [m][k] by (score, global index); -1 / NaN entries last.  G * k <= 128. */
 int pr_merge_topk_dev(pr_ctx* ctx, const int32_t* idx_all, const double* score_all, int32_t G, int32_t m, int32_t k,

@@ -62,6 +62,13 @@ void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_d
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
                    double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
                    float* score32);
+// the sharded form: scores of the candidates THIS shard owns (NaN elsewhere), then owner-wise combination + selection
+void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
+                           const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
+                           double p_weight, int kin, const int32_t* idx_in, double* cand_score);
+void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,
+                          double* score);
+void launch_widen(hipStream_t st, const float* a, long long n, double* b);
 void launch_merge_topk(hipStream_t st, const int32_t* idx_all, const double* score_all, int G, int m, int k, int32_t* idx, double* score);
 
 // sc_gen.hip / m2dp_gen.hip — pts_align.h:7-46 + SC.cpp:12-76 / M2DP.cpp:38-109 (+ test_m2dp.cpp:44-68)

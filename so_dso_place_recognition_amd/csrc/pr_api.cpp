@@ -606,6 +606,43 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
   return PR_OK;
 }
 
+int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
+                          const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
+                          int32_t mask_width, double p_weight, int32_t k_in, const int32_t* cand_idx, double* part) {
+  if (!ctx) return PR_EINVAL;
+  const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
+  if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !cand_idx || !part ||
+      m < 0 || n_local < 1 || G < 1 || k_in < 1 || k_in > 128 ||
+      (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
+    PR_FAIL(ctx, PR_EINVAL, "pr_rerank_partial_dev: bad arguments (m=%d, n_local=%d, G=%d, k_in=%d)", m, n_local, G, k_in);
+  if (m == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_rerank_partial(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0,
+                            mask_width, p_weight, k_in, cand_idx, part);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+int pr_rerank_finish_dev(pr_ctx* ctx, const int32_t* cand_idx, const double* part_all, int32_t G, int32_t m, int32_t k_in, int32_t k,
+                         int32_t* idx, double* score) {
+  if (!ctx) return PR_EINVAL;
+  if (!cand_idx || !part_all || !idx || !score || G < 1 || m < 0 || k < 1 || k_in < k || k_in > 128)
+    PR_FAIL(ctx, PR_EINVAL, "pr_rerank_finish_dev: bad arguments (G=%d, m=%d, k=%d, k_in=%d)", G, m, k, k_in);
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_rerank_finish(ctx->stream, cand_idx, part_all, G, m, k_in, k, idx, score);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+int pr_widen_scores_dev(pr_ctx* ctx, const float* score32, int64_t count, double* score64) {
+  if (!ctx) return PR_EINVAL;
+  if (count < 0 || (count > 0 && (!score32 || !score64))) PR_FAIL(ctx, PR_EINVAL, "pr_widen_scores_dev: bad arguments");
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_widen(ctx->stream, score32, count, score64);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
 int pr_merge_topk_dev(pr_ctx* ctx, const int32_t* idx_all, const double* score_all, int32_t G, int32_t m, int32_t k, int32_t* idx,
                       double* score) {
   if (!ctx) return PR_EINVAL;

@@ -6,9 +6,13 @@
 //   1. per device: pack queries, all-pairs distances, per-row moments of the shard                    pr_distances_dev, pr_row_moments_dev
 //   A. all-gather of the moments (48 B per query per rank)                                           ncclAllGather on the compute streams
 //   2. per device: fused fp32 score with the statistics of the WHOLE row (Chan combination in rank order), mask on
-//      global indices, per-shard top-(k+8), fp64 re-evaluation -> per-shard top-k                     pr_fuse_select_dev, pr_rerank_dev
-//   B. all-gather of (index, score)  (12 k B per query per rank)                                      ncclAllGather on the compute streams
-//   3. k-way merge by (score, global index) on device 0                                               pr_merge_topk_dev
+//      global indices, per-shard top-(k+8)                                                            pr_fuse_select_dev
+//   B. all-gather of the per-shard (index, fp32 score) lists; merged on every device into the GLOBAL top-(k+8) candidates -
+//      the list an unsharded run selects                                                              ncclAllGather, pr_merge_topk_dev
+//   3. per device: fp64 re-evaluation of the candidates inside its own rows (on average (k+8)/G per query: the cost does not
+//      grow with G)                                                                                   pr_rerank_partial_dev
+//   C. all-gather of the partial scores; device 0 takes every candidate's score from its owner and keeps the k best
+//                                                                                                     ncclAllGather, pr_rerank_finish_dev
 //
 // One host thread drives all devices; everything is asynchronous on each context's stream, the two collectives are
 // enqueued on those same streams between the kernels (one ncclGroupStart/End per collective, communicators from
@@ -63,8 +67,8 @@ struct Shard {
   int32_t row0 = 0, rows = 0;                 // this shard's global DB rows
   void *raw_db = nullptr, *raw_q = nullptr;   // f64 signatures (the re-evaluation reads them)
   float *d_p = nullptr, *d_i = nullptr;
-  double *mom = nullptr, *mom_all = nullptr, *score = nullptr, *score_all = nullptr;
-  int32_t *idx_in = nullptr, *idx = nullptr, *idx_all = nullptr;
+  double *mom = nullptr, *mom_all = nullptr, *score = nullptr, *score_all = nullptr, *sc64 = nullptr, *part = nullptr, *dump = nullptr;
+  int32_t *idx_in = nullptr, *idx = nullptr, *idx_all = nullptr, *cand = nullptr;
   float* sc32 = nullptr;
 };
 
@@ -109,10 +113,10 @@ static thread_local std::string g_gerr;
 static void free_match_buffers(Shard& sh) {
   (void)hipSetDevice(sh.device);
   for (void* p : {(void*)sh.raw_q, (void*)sh.d_p, (void*)sh.d_i, (void*)sh.mom, (void*)sh.mom_all, (void*)sh.score, (void*)sh.score_all,
-                  (void*)sh.idx_in, (void*)sh.idx, (void*)sh.idx_all, (void*)sh.sc32})
+                  (void*)sh.idx_in, (void*)sh.idx, (void*)sh.idx_all, (void*)sh.sc32, (void*)sh.sc64, (void*)sh.part, (void*)sh.cand, (void*)sh.dump})
     if (p) (void)hipFree(p);
-  sh.raw_q = nullptr; sh.d_p = sh.d_i = sh.sc32 = nullptr; sh.mom = sh.mom_all = sh.score = sh.score_all = nullptr;
-  sh.idx_in = sh.idx = sh.idx_all = nullptr;
+  sh.raw_q = nullptr; sh.d_p = sh.d_i = sh.sc32 = nullptr; sh.mom = sh.mom_all = sh.score = sh.score_all = sh.sc64 = sh.part = sh.dump = nullptr;
+  sh.idx_in = sh.idx = sh.idx_all = sh.cand = nullptr;
   if (sh.q) { pr_sigset_destroy(sh.ctx, sh.q); sh.q = nullptr; }
 }
 
@@ -246,8 +250,8 @@ int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_w
   if (!g) return PR_EINVAL;
   if (g->type < 0) G_FAIL(g, PR_EINVAL, "pr_group_match_topk: no database (pr_group_set_database)");
   const int G = g->G;
-  if (m < 0 || (m > 0 && !h1) || k < 1 || k > 120 || (int64_t)G * k > 128 || !idx || !score)
-    G_FAIL(g, PR_EINVAL, "pr_group_match_topk: bad arguments (m=%d, k=%d; G*k <= 128)", m, k);
+  if (m < 0 || (m > 0 && !h1) || k < 1 || k > 120 || (int64_t)G * (k + 8) > 128 || !idx || !score)
+    G_FAIL(g, PR_EINVAL, "pr_group_match_topk: bad arguments (m=%d, k=%d; G*(k+8) <= 128)", m, k);
   if (m == 0) return PR_OK;
   const int type = g->type;
   const bool sc = type == PR_TYPE_SC;
@@ -269,8 +273,12 @@ int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_w
       G_HIP(g, hipMalloc((void**)&sh.sc32, (size_t)qc * kinc * 4));
       G_HIP(g, hipMalloc((void**)&sh.idx, (size_t)qc * kc * 4));
       G_HIP(g, hipMalloc((void**)&sh.score, (size_t)qc * kc * 8));
-      G_HIP(g, hipMalloc((void**)&sh.idx_all, (size_t)G * qc * kc * 4));
-      G_HIP(g, hipMalloc((void**)&sh.score_all, (size_t)G * qc * kc * 8));
+      G_HIP(g, hipMalloc((void**)&sh.idx_all, (size_t)G * qc * kinc * 4));
+      G_HIP(g, hipMalloc((void**)&sh.score_all, (size_t)G * qc * kinc * 8));
+      G_HIP(g, hipMalloc((void**)&sh.sc64, (size_t)qc * kinc * 8));
+      G_HIP(g, hipMalloc((void**)&sh.part, (size_t)qc * kinc * 8));
+      G_HIP(g, hipMalloc((void**)&sh.dump, (size_t)qc * kinc * 8));
+      G_HIP(g, hipMalloc((void**)&sh.cand, (size_t)qc * kinc * 4));
     }
     g->q_cap = qc; g->k_cap = kc;
   }
@@ -287,25 +295,33 @@ int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_w
   // A. moments of every shard on every device
   for (int r = 0; r < G; r++) { src[r] = g->s[r].mom; dst[r] = g->s[r].mom_all; }
   if (int rc = exchange(g, src, dst, (size_t)m * 6 * 8)) return rc;
-  // 2. per-shard selection with the whole row's statistics + fp64 re-evaluation
+  // 2. per-shard fp32 selection with the whole row's statistics
   for (auto& sh : g->s) {
     G_HIP(g, hipSetDevice(sh.device));
     G_PR(g, sh, pr_fuse_select_dev(sh.ctx, sh.d_p, sh.d_i, m, sh.rows, sh.mom_all, G, 0, sh.row0, mask_width, p_weight, kin, sh.idx_in, sh.sc32));
-    G_PR(g, sh, pr_rerank_dev(sh.ctx, sc ? sh.raw_q : nullptr, sc ? sh.raw_db : nullptr, PR_F64, sc ? nullptr : sh.raw_q, sc ? nullptr : sh.raw_db,
-                              PR_F64, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, m, sh.rows, G, 0, sh.row0, mask_width, p_weight, kin,
-                              sh.idx_in, k, sh.idx, sh.score));
+    G_PR(g, sh, pr_widen_scores_dev(sh.ctx, sh.sc32, (int64_t)m * kin, sh.sc64));
   }
-  // B. per-shard top-k of every shard on every device
-  for (int r = 0; r < G; r++) { src[r] = g->s[r].idx; dst[r] = g->s[r].idx_all; }
-  if (int rc = exchange(g, src, dst, (size_t)m * k * 4)) return rc;
-  for (int r = 0; r < G; r++) { src[r] = g->s[r].score; dst[r] = g->s[r].score_all; }
-  if (int rc = exchange(g, src, dst, (size_t)m * k * 8)) return rc;
-  // 3. merge on device 0, copy out, one host wait per device
+  // B. every shard's candidates on every device, merged into the global top-(k+8) of the fp32 pass
+  for (int r = 0; r < G; r++) { src[r] = g->s[r].idx_in; dst[r] = g->s[r].idx_all; }
+  if (int rc = exchange(g, src, dst, (size_t)m * kin * 4)) return rc;
+  for (int r = 0; r < G; r++) { src[r] = g->s[r].sc64; dst[r] = g->s[r].score_all; }
+  if (int rc = exchange(g, src, dst, (size_t)m * kin * 8)) return rc;
+  // 3. fp64 re-evaluation of the candidates each shard owns
+  for (auto& sh : g->s) {
+    G_HIP(g, hipSetDevice(sh.device));
+    G_PR(g, sh, pr_merge_topk_dev(sh.ctx, sh.idx_all, sh.score_all, G, m, kin, sh.cand, sh.dump /*the merged fp32 scores are not used; sc64 may still be read by the other shards' copies*/));
+    G_PR(g, sh, pr_rerank_partial_dev(sh.ctx, sc ? sh.raw_q : nullptr, sc ? sh.raw_db : nullptr, PR_F64, sc ? nullptr : sh.raw_q,
+                                      sc ? nullptr : sh.raw_db, PR_F64, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, m, sh.rows, G, 0,
+                                      sh.row0, mask_width, p_weight, kin, sh.cand, sh.part));
+  }
+  // C. partial scores of every shard on every device; device 0 finishes
+  for (int r = 0; r < G; r++) { src[r] = g->s[r].part; dst[r] = g->s[r].score_all; }
+  if (int rc = exchange(g, src, dst, (size_t)m * kin * 8)) return rc;
   Shard& s0 = g->s[0];
   G_HIP(g, hipSetDevice(s0.device));
-  G_PR(g, s0, pr_merge_topk_dev(s0.ctx, s0.idx_all, s0.score_all, G, m, k, s0.idx_in /*reused as output*/, reinterpret_cast<double*>(s0.mom_all)));
-  G_HIP(g, hipMemcpyAsync(idx, s0.idx_in, (size_t)m * k * 4, hipMemcpyDeviceToHost, s0.stream));
-  G_HIP(g, hipMemcpyAsync(score, s0.mom_all, (size_t)m * k * 8, hipMemcpyDeviceToHost, s0.stream));
+  G_PR(g, s0, pr_rerank_finish_dev(s0.ctx, s0.cand, s0.score_all, G, m, kin, k, s0.idx, s0.score));
+  G_HIP(g, hipMemcpyAsync(idx, s0.idx, (size_t)m * k * 4, hipMemcpyDeviceToHost, s0.stream));
+  G_HIP(g, hipMemcpyAsync(score, s0.score, (size_t)m * k * 8, hipMemcpyDeviceToHost, s0.stream));
   for (auto& sh : g->s) { G_HIP(g, hipSetDevice(sh.device)); G_PR(g, sh, pr_sync(sh.ctx)); }
   return PR_OK;
 }

@@ -196,6 +196,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
   if (dij < 0) dij = -dij;
   if (dij < A.mask_width) { if (tid == 0) *out = __builtin_inf(); return; }   // run_test.m:47-53
   const int jl = jg - A.db_row0;
+  if (jl < 0 || jl >= A.n_local) { if (tid == 0) *out = __builtin_nan(""); return; }   // another shard's row: its owner evaluates it
   double f = 0.0;
   if (A.q_sc) {
     for (int ch = 0; ch < 2; ch++) {
@@ -252,6 +253,32 @@ __global__ __launch_bounds__(64) void rerank_sort_kernel(const int32_t* __restri
            score32 ? score32 + (size_t)q * k : nullptr);
 }
 
+// cand_idx [m][kin] + the partial evaluations of G shards [G][m][kin] (NaN where the candidate is not the shard's) -> the k best.
+// Every candidate has exactly one owner; a masked pair is +Inf at its owner.
+__global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __restrict__ cand_idx, const double* __restrict__ part_all,
+                                                            int G, int m, int kin, int k, int32_t* __restrict__ idx,
+                                                            double* __restrict__ score) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= m) return;
+  int32_t ci[128];
+  double cs[128];
+  for (int t = 0; t < kin; t++) {
+    ci[t] = cand_idx[(size_t)q * kin + t];
+    double v = __builtin_nan("");
+    for (int g = 0; g < G; g++) {
+      const double x = part_all[((size_t)g * m + q) * kin + t];
+      if (x == x) { v = x; break; }
+    }
+    cs[t] = v;
+  }
+  select_k(ci, cs, kin, k, idx + (size_t)q * k, score + (size_t)q * k, nullptr);
+}
+
+__global__ __launch_bounds__(256) void widen_kernel(const float* __restrict__ a, long long n, double* __restrict__ b) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) b[i] = (double)a[i];
+}
+
 // idx_all [G][m][k], score_all [G][m][k] -> idx [m][k], score [m][k]
 __global__ __launch_bounds__(64) void merge_topk_kernel(const int32_t* __restrict__ idx_all, const double* __restrict__ score_all,
                                                          int G, int m, int k, int32_t* __restrict__ idx, double* __restrict__ score) {
@@ -284,6 +311,25 @@ void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_d
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight};
   hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
   hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
+}
+
+void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
+                           const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
+                           double p_weight, int kin, const int32_t* idx_in, double* cand_score) {
+  if (m <= 0) return;
+  RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight};
+  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
+}
+
+void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,
+                          double* score) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(rerank_finish_kernel, dim3((m + 63) / 64), dim3(64), 0, st, cand_idx, part_all, G, m, kin, k, idx, score);
+}
+
+void launch_widen(hipStream_t st, const float* a, long long n, double* b) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, a, n, b);
 }
 
 void launch_merge_topk(hipStream_t st, const int32_t* idx_all, const double* score_all, int G, int m, int k, int32_t* idx, double* score) {

@@ -12,11 +12,15 @@ Sharding: every rank holds the DB rows [db_row0, db_row0 + n_l
      (all-gather + Chan combination in rank order instead of §8-e's all-reduce: same bytes at this size, and the
      result does not depend on the reduction order RCCL happens to pick - every rank computes the same bits)
   3. local: Chan-combine -> global mean/std, fused fp32 score, mask on GLOBAL indices, per-shard top-(k+8)
-     (ties -> lower global index), then the fp64 re-evaluation of those survivors from the raw signatures
-     (pr_rerank_dev) -> per-shard top-k with the reference's double scores                              [HIP]
-  4. all_gather_into_tensor of (idx i32, score f64) (12k B per query per rank), k-way merge on the device
-     by (score, idx) (pr_merge_topk_dev)                                                                 [RCCL + HIP]
-With one rank steps 2 and 4 are skipped.
+     (ties -> lower global index)                                                                      [HIP]
+  4. all_gather_into_tensor of the per-shard (idx i32, fp32 score) lists, k-way merge on the device by
+     (score, idx) (pr_merge_topk_dev) -> the GLOBAL top-(k+8) candidates, the same list an unsharded run
+     selects                                                                                           [RCCL + HIP]
+  5. local: fp64 re-evaluation, from the raw signatures, of the candidates that lie in this shard
+     (pr_rerank_partial_dev; on average (k+8)/G pairs per query: the cost does not grow with G)          [HIP]
+  6. all_gather_into_tensor of the partial scores (8 (k+8) B per query per rank), every candidate's score taken
+     from its owner, the k best by (score, idx) (pr_rerank_finish_dev)                                  [RCCL + HIP]
+With one rank steps 2, 4 and 6 are skipped (pr_rerank_dev does 5 + the selection).
 """
 from __future__ import annotations
 
@@ -131,32 +135,61 @@ class Matcher(_Base):
             self._leave()
         return mom
 
-    def local_phase2(self, mom_all: torch.Tensor, G: int, mask_width, p_weight, k, db_row0, q_row0):
-        """fp32 selection of the k + 8 best of this shard with the moments of all shards, fp64 re-evaluation -> (idx, score)."""
+    def _kin(self, k):
+        return k if self.plain else min(k + 8, 128)
+
+    def local_select(self, mom_all: torch.Tensor, G: int, mask_width, p_weight, k, db_row0, q_row0):
+        """fp32 selection of this shard's k + 8 best with the moments of all shards -> (idx_in i32 [m,kin], score f64 [m,kin])."""
         m, n = self._m, self.n
-        lib, h = self.lib, self.ctx.h
         d_p, d_i = self._bufs["d_p"], self._bufs.get("d_i")
-        kin = k if self.plain else min(k + 8, 128)
+        kin = self._kin(k)
         idx_in = self._buf("idx_in", (m, kin), torch.int32)
         sc32 = self._buf("sc32", (m, kin), torch.float32)
-        idx = self._buf("idx", (m, k), torch.int32)
-        score = self._buf("score", (m, k), torch.float64)
-        mom_all = mom_all.contiguous()
+        self._mom_all = mom_all.contiguous()
+        self._args = (G, q_row0, db_row0, int(mask_width), float(p_weight))
         self._enter()
-        self.ctx.check(lib.pr_fuse_select_dev(h, _dptr(d_p), None if self.plain else _dptr(d_i), m, n, _dptr(mom_all), G, q_row0, db_row0,
-                                              int(mask_width), float(p_weight), int(kin), _dptr(idx_in), _dptr(sc32)))
-        if self.plain:
-            self._leave()
-            return idx_in, sc32.to(torch.float64)
+        self.ctx.check(self.lib.pr_fuse_select_dev(self.ctx.h, _dptr(d_p), None if self.plain else _dptr(d_i), m, n, _dptr(self._mom_all), G,
+                                                   q_row0, db_row0, int(mask_width), float(p_weight), int(kin), _dptr(idx_in), _dptr(sc32)))
+        self._leave()
+        return idx_in, sc32.to(torch.float64)
+
+    def _raw_args(self):
         sc = self.type == _lib.TYPE_SC
+        assert self._q_sig.dtype == self.db_sig.dtype
         raw = (_dptr(self._q_sig), _dptr(self.db_sig), _torch_dt(self.db_sig))
         none = (None, None, 0)
-        assert self._q_sig.dtype == self.db_sig.dtype
-        self.ctx.check(lib.pr_rerank_dev(h, *(raw if sc else none), *(none if sc else raw), _dptr(mom_all) if sc else None,
-                                         None if sc else _dptr(mom_all), m, n, G, q_row0, db_row0, int(mask_width), float(p_weight),
-                                         kin, _dptr(idx_in), int(k), _dptr(idx), _dptr(score)))
+        return (*(raw if sc else none), *(none if sc else raw), _dptr(self._mom_all) if sc else None, None if sc else _dptr(self._mom_all))
+
+    def local_rerank(self, cand_idx: torch.Tensor, k: int, partial: bool):
+        """fp64 re-evaluation of the candidates [m,kin]: partial=False -> (idx [m,k], score [m,k]) (all candidates are this
+        shard's: the one-rank path); partial=True -> scores [m,kin], NaN for candidates outside this shard."""
+        m, n = self._m, self.n
+        G, q_row0, db_row0, mask_width, p_weight = self._args
+        kin = cand_idx.shape[1]
+        cand_idx = cand_idx.contiguous()
+        self._enter()
+        if partial:
+            part = self._buf("part", (m, kin), torch.float64)
+            self.ctx.check(self.lib.pr_rerank_partial_dev(self.ctx.h, *self._raw_args(), m, n, G, q_row0, db_row0, mask_width, p_weight, kin,
+                                                          _dptr(cand_idx), _dptr(part)))
+            self._leave()
+            return part
+        idx = self._buf("idx", (m, k), torch.int32)
+        score = self._buf("score", (m, k), torch.float64)
+        self.ctx.check(self.lib.pr_rerank_dev(self.ctx.h, *self._raw_args(), m, n, G, q_row0, db_row0, mask_width, p_weight, kin,
+                                              _dptr(cand_idx), int(k), _dptr(idx), _dptr(score)))
         self._leave()
         return idx, score
+
+    def finish(self, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int):
+        return _finish_dev(self, cand_idx, part_all, k)
+
+    def local_phase2(self, mom_all: torch.Tensor, G: int, mask_width, p_weight, k, db_row0, q_row0):
+        """Selection + re-evaluation of this shard alone -> its own top-k (what rank g would answer by itself)."""
+        idx_in, sc = self.local_select(mom_all, G, mask_width, p_weight, k, db_row0, q_row0)
+        if self.plain:
+            return idx_in, sc
+        return self.local_rerank(idx_in, k, partial=False)
 
     def merge(self, idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
         return _merge_dev(self, idx_all, sc_all, k)
@@ -167,8 +200,9 @@ class Matcher(_Base):
         force_exchange: run the two all-gathers and the merge even with one rank (measures the protocol's overhead)."""
         G = _world(group)
         return sharded_topk(lambda: self.local_phase1(queries),
-                            lambda mom_all, G_: self.local_phase2(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
-                            k, group if (G > 1 or force_exchange) else None, G, merge=self.merge, force_exchange=force_exchange)
+                            lambda mom_all, G_: self.local_select(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
+                            k, group if (G > 1 or force_exchange) else None, G, merge=self.merge, force_exchange=force_exchange,
+                            rerank=None if self.plain else self.local_rerank, finish=self.finish)
 
     def distances(self):
         """The last distance matrices (device, float32 [m, n_local])."""
@@ -201,26 +235,49 @@ class FusedMatcher(_Base):
         assert self.sc._m == self.m2._m
         return torch.cat([a, b], dim=1)                                    # [m, 4, 3]
 
-    def local_phase2(self, mom_all, G, mask_width, p_weight, k, db_row0, q_row0):
+    def local_select(self, mom_all, G, mask_width, p_weight, k, db_row0, q_row0):
         m, n = self.sc._m, self.sc.n
         lib, h = self.lib, self.ctx.h
         mom_all = mom_all.reshape(G, m, 4, 3)
-        m1, m2 = mom_all[:, :, :2].contiguous(), mom_all[:, :, 2:].contiguous()
+        self._m1, self._m2 = mom_all[:, :, :2].contiguous(), mom_all[:, :, 2:].contiguous()
+        self._args = (G, q_row0, db_row0, int(mask_width), float(p_weight))
         d = [self.sc._bufs["d_p"], self.sc._bufs["d_i"], self.m2._bufs["d_p"], self.m2._bufs["d_i"]]
         kin = min(k + 8, 128)
         idx_in = self._buf("idx_in", (m, kin), torch.int32)
         sc32 = self._buf("sc32", (m, kin), torch.float32)
+        self._enter()
+        self.ctx.check(lib.pr_fuse_select2_dev(h, _dptr(d[0]), _dptr(d[1]), _dptr(d[2]), _dptr(d[3]), m, n, _dptr(self._m1), _dptr(self._m2), G,
+                                               q_row0, db_row0, int(mask_width), float(p_weight), int(kin), _dptr(idx_in), _dptr(sc32)))
+        self._leave()
+        return idx_in, sc32.to(torch.float64)
+
+    def local_rerank(self, cand_idx, k, partial):
+        m, n = self.sc._m, self.sc.n
+        G, q_row0, db_row0, mask_width, p_weight = self._args
+        kin = cand_idx.shape[1]
+        cand_idx = cand_idx.contiguous()
+        raw = (_dptr(self.sc._q_sig), _dptr(self.sc.db_sig), _torch_dt(self.sc.db_sig), _dptr(self.m2._q_sig), _dptr(self.m2.db_sig),
+               _torch_dt(self.m2.db_sig), _dptr(self._m1), _dptr(self._m2))
+        self._enter()
+        if partial:
+            part = self._buf("part", (m, kin), torch.float64)
+            self.ctx.check(self.lib.pr_rerank_partial_dev(self.ctx.h, *raw, m, n, G, q_row0, db_row0, mask_width, p_weight, kin, _dptr(cand_idx),
+                                                          _dptr(part)))
+            self._leave()
+            return part
         idx = self._buf("idx", (m, k), torch.int32)
         score = self._buf("score", (m, k), torch.float64)
-        self._enter()
-        self.ctx.check(lib.pr_fuse_select2_dev(h, _dptr(d[0]), _dptr(d[1]), _dptr(d[2]), _dptr(d[3]), m, n, _dptr(m1), _dptr(m2), G,
-                                               q_row0, db_row0, int(mask_width), float(p_weight), int(kin), _dptr(idx_in), _dptr(sc32)))
-        self.ctx.check(lib.pr_rerank_dev(h, _dptr(self.sc._q_sig), _dptr(self.sc.db_sig), _torch_dt(self.sc.db_sig),
-                                         _dptr(self.m2._q_sig), _dptr(self.m2.db_sig), _torch_dt(self.m2.db_sig), _dptr(m1), _dptr(m2),
-                                         m, n, G, q_row0, db_row0, int(mask_width), float(p_weight), kin, _dptr(idx_in), int(k),
-                                         _dptr(idx), _dptr(score)))
+        self.ctx.check(self.lib.pr_rerank_dev(self.ctx.h, *raw, m, n, G, q_row0, db_row0, mask_width, p_weight, kin, _dptr(cand_idx), int(k),
+                                              _dptr(idx), _dptr(score)))
         self._leave()
         return idx, score
+
+    def finish(self, cand_idx, part_all, k):
+        return _finish_dev(self, cand_idx, part_all, k)
+
+    def local_phase2(self, mom_all, G, mask_width, p_weight, k, db_row0, q_row0):
+        idx_in, _ = self.local_select(mom_all, G, mask_width, p_weight, k, db_row0, q_row0)
+        return self.local_rerank(idx_in, k, partial=False)
 
     def merge(self, idx_all, sc_all, k):
         return _merge_dev(self, idx_all, sc_all, k)
@@ -229,8 +286,8 @@ class FusedMatcher(_Base):
               db_row0: int = 0, q_row0: int = 0, group=None):
         G = _world(group)
         return sharded_topk(lambda: self.local_phase1(sc_queries, m2dp_queries),
-                            lambda mom_all, G_: self.local_phase2(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
-                            k, group if G > 1 else None, G, merge=self.merge)
+                            lambda mom_all, G_: self.local_select(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
+                            k, group if G > 1 else None, G, merge=self.merge, rerank=self.local_rerank, finish=self.finish)
 
 
 def _world(group) -> int:
@@ -251,13 +308,26 @@ def _merge_dev(owner, idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
     return idx, score
 
 
-def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None, force_exchange: bool = False):
+def _finish_dev(owner, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int):
+    """pr_rerank_finish_dev: candidates [m, kin] + the shards' partial scores [G, m, kin] -> (idx [m,k], score [m,k])."""
+    G, m, kin = part_all.shape
+    idx = torch.empty((m, k), dtype=torch.int32, device=cand_idx.device)
+    score = torch.empty((m, k), dtype=torch.float64, device=cand_idx.device)
+    owner._enter()
+    owner.ctx.check(owner.lib.pr_rerank_finish_dev(owner.ctx.h, _dptr(cand_idx.contiguous()), _dptr(part_all.contiguous()), G, m, kin, k,
+                                                   _dptr(idx), _dptr(score)))
+    owner._leave()
+    return idx, score
+
+
+def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None, force_exchange: bool = False, rerank=None, finish=None):
     """The exchange protocol of SURVEY.md §8-e around two local callables (HIP in production; a numpy stand-in in
     the gloo CPU tests): moments -> all_gather -> select with the moments of all shards -> all_gather -> merge."""
     import torch.distributed as dist
     mom = local_moments()
     if G == 1 and not force_exchange:
-        return local_select(mom.unsqueeze(0) if mom.dim() == 3 else mom, 1)
+        idx_in, sc = local_select(mom.unsqueeze(0) if mom.dim() == 3 else mom, 1)
+        return rerank(idx_in, k, False) if rerank is not None else (idx_in, sc)
     stage_on_host = dist.get_backend(group) == "gloo"   # gloo has no device all_gather: used by the single-GPU tests
 
     def gather(t):   # output = the ranks' tensors concatenated along dim 0, viewed as [G, ...]
@@ -269,11 +339,15 @@ def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None,
         return out.view((G,) + tuple(src.shape)).to(t.device)
 
     mom_all = gather(mom)
-    idx, score = local_select(mom_all, G)
-    idx_all, sc_all = gather(idx), gather(score)
-    if merge is not None and idx_all.is_cuda:
-        return merge(idx_all, sc_all, k)
-    return merge_topk(idx_all, sc_all, k)
+    idx_in, sc = local_select(mom_all, G)
+    kin = idx_in.shape[1]
+    idx_all, sc_all = gather(idx_in), gather(sc)
+    do_merge = merge if (merge is not None and idx_all.is_cuda) else merge_topk
+    if rerank is None:                                   # nothing to re-evaluate (numpy stand-ins of the gloo tests, DELIGHT)
+        return do_merge(idx_all, sc_all, k)
+    cand_idx, _ = do_merge(idx_all, sc_all, kin)         # the global top-(k+8) of the fp32 pass, identical on every rank
+    part_all = gather(rerank(cand_idx, k, True))
+    return finish(cand_idx, part_all, k)
 
 
 def merge_topk(idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):

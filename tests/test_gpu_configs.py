@@ -121,8 +121,10 @@ def test_config3_m2dp_50k_db_4096_queries(api):
 
 # ------------------------------------------------------------------------------------------------ configs 4 and 5
 def _sharded_run(make_matcher, shards, pack, phase1_args, mask, k):
-    """What G ranks compute, one shard after the other on this GPU: phase 1 everywhere, moments stacked in rank order,
-    phase 2 everywhere with GLOBAL row offsets, device merge.  Returns per-shard results and the merged one."""
+    """What G ranks compute, one shard after the other on this GPU, with the production protocol (matcher.sharded_topk):
+    phase 1 everywhere, moments stacked in rank order; fp32 selection everywhere with GLOBAL row offsets; the lists merged
+    into the global top-(k+8); every shard re-evaluates the candidates it owns; owner-wise finish.  Also returns what
+    every rank would answer alone (its own top-k under the global statistics)."""
     ms, moms = [], []
     for (lo, hi) in shards:
         mt = make_matcher(hi - lo)
@@ -131,9 +133,14 @@ def _sharded_run(make_matcher, shards, pack, phase1_args, mask, k):
         ms.append(mt)
     mom_all = torch.stack(moms)
     G = len(shards)
-    per = [mt.local_phase2(mom_all, G, mask, 2.0, k, lo, 0) for mt, (lo, hi) in zip(ms, shards)]
-    per = [(a.clone(), b.clone()) for a, b in per]
-    idx, sc = ms[0].merge(torch.stack([p[0] for p in per]), torch.stack([p[1] for p in per]), k)
+    sel = [mt.local_select(mom_all, G, mask, 2.0, k, lo, 0) for mt, (lo, hi) in zip(ms, shards)]
+    sel = [(a.clone(), b.clone()) for a, b in sel]
+    kin = sel[0][0].shape[1]
+    cand, _ = ms[0].merge(torch.stack([p[0] for p in sel]), torch.stack([p[1] for p in sel]), kin)
+    part_all = torch.stack([mt.local_rerank(cand, k, True).clone() for mt in ms])
+    assert (torch.isnan(part_all).sum(0) == G - 1).all() or mask > 0          # exactly one owner per candidate (masked pairs: +Inf everywhere)
+    idx, sc = ms[0].finish(cand, part_all, k)
+    per = [tuple(t.clone() for t in mt.local_rerank(a, k, False)) for mt, (a, b) in zip(ms, sel)]
     return ms, per, idx.cpu().numpy(), sc.cpu().numpy()
 
 

@@ -431,11 +431,17 @@ def test_fused_matcher_device_path_and_two_shards(api):
         moms.append(f.local_phase1(t(sq), t(mq)).clone())
         parts.append((f, lo))
     mom_all = torch.stack(moms)                                          # [2, m, 4, 3] in rank order
-    outs = [f.local_phase2(mom_all, 2, mask, 2.0, k, lo, 0) for f, lo in parts]
-    idx2, sc2 = parts[0][0].merge(torch.stack([o[0].clone() for o in outs]), torch.stack([o[1].clone() for o in outs]), k)
+    outs = [tuple(x.clone() for x in f.local_phase2(mom_all, 2, mask, 2.0, k, lo, 0)) for f, lo in parts]   # every shard's own top-k
+    idx2, sc2 = parts[0][0].merge(torch.stack([o[0] for o in outs]), torch.stack([o[1] for o in outs]), k)
     assert np.array_equal(idx2.cpu().numpy(), want_idx) and np.abs(sc2.cpu().numpy() - want_sc).max() < 1e-9
     i3, s3 = merge_topk(torch.stack([o[0].cpu() for o in outs]), torch.stack([o[1].cpu() for o in outs]), k)   # torch restatement
     assert np.array_equal(i3.numpy(), want_idx)
+    # the production protocol: fp32 lists merged first, owners re-evaluate, finish
+    sel = [tuple(x.clone() for x in f.local_select(mom_all, 2, mask, 2.0, k, lo, 0)) for f, lo in parts]
+    cand, _ = parts[0][0].merge(torch.stack([a for a, b in sel]), torch.stack([b for a, b in sel]), sel[0][0].shape[1])
+    part_all = torch.stack([f.local_rerank(cand, k, True).clone() for f, lo in parts])
+    idx4, sc4 = parts[0][0].finish(cand, part_all, k)
+    assert np.array_equal(idx4.cpu().numpy(), want_idx) and np.abs(sc4.cpu().numpy() - want_sc).max() < 1e-9
     for f, lo in parts:
         f.close()
 

@@ -21,11 +21,13 @@ echo
 } > $txt
 rm -rf $out/${tag}_trace
 rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o sc -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $out/${tag}_trace.log 2>&1
-python $root/profiles/summarize.py $(find $out/${tag}_trace -name "*_results.db") >> $txt
+python $root/profiles/summarize.py $(find $out/${tag}_trace -name "*_results.db") | sed "s#$out/##" >> $txt
+rm -rf $out/${tag}_trace
 i=0
 for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
   i=$((i+1)); d=$out/${tag}_pmc$i; rm -rf $d
   rocprofv3 --pmc $grp -d $d -o sc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $d.log 2>&1
   python $root/profiles/summarize.py $(find $d -name "*_results.db") | sed "s#$out/##" >> $txt
+  rm -rf $d
 done
 cat $txt | cut -c1-220
