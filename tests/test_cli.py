@@ -158,3 +158,32 @@ def test_config1_full_kitti_seq00(ref_sequence, tmp_path):
         assert np.array_equal(mres[rows, 0].astype(np.int64), f.argmin(1))
         sg = (np.std(dp, axis=1, ddof=1), np.std(di, axis=1, ddof=1), dp.shape[1])
         assert (np.abs(mres[rows, 1] - f.min(1)) <= helpers.score_tol(f.min(1), sg)).all()
+
+
+@pytest.mark.gpu
+def test_match_signatures_devices_and_ground_truth(tmp_path):
+    """`match_signatures --devices 0,0` (hist2 row-sharded through pr_group; two shards on the one GPU of the test box) gives
+    the file of the single-context run, and `--gt1 --gt2 --loop_diff` prints the AUC / top recall of run_test.m:58-85 as
+    eval.precision_recall computes them from the same matches."""
+    from so_dso_place_recognition_amd import synth, eval as ev
+    n = 260
+    sig = synth.sc_database(45, n)
+    sig[130:] = synth.sc_queries(46, sig[:130], 130)[0]                      # second half: revisits of (random) places of the first half
+    f = str(tmp_path / "history_sc.txt"); api.write_signatures(f, sig)
+    rng = np.random.default_rng(4)
+    gt = np.cumsum(rng.normal(0, 4, (n, 3)), 0)
+    g = str(tmp_path / "gt.txt"); np.savetxt(g, gt)
+    outs = []
+    for extra in ([], ["--devices", "0,0"]):
+        res = str(tmp_path / f"m{len(extra)}.txt")
+        r = subprocess.run([os.path.join(BIN, "match_signatures"), "--type", "sc", "--hist1", f, "--hist2", f, "--mask_width", "20",
+                            "--out", res, "--gt1", g, "--gt2", g, "--loop_diff", "15"] + extra, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
+        outs.append((np.loadtxt(res), r.stdout))
+    assert np.array_equal(outs[0][0][:, 0], outs[1][0][:, 0]) and np.abs(outs[0][0][:, 1] - outs[1][0][:, 1]).max() < 1e-9
+    assert "devices = 2 (copies)" in outs[1][1]
+    m = outs[0][0]
+    auc, tr, det = ev.precision_recall(m[:, 1], m[:, 0].astype(np.int64), np.loadtxt(g), np.loadtxt(g), 15.0, 20)[:3]
+    line = {l.split(" = ")[0]: l.split(" = ")[1] for l in outs[0][1].splitlines() if " = " in l}
+    assert abs(float(line["AUC"]) - auc) < 1e-9 or (np.isnan(auc) and line["AUC"].strip() == "nan")
+    assert abs(float(line["top_recall"]) - tr) < 1e-9 and int(line["lp_detected"]) == len(det)

@@ -501,3 +501,19 @@ def test_group_sharded_match_equals_unsharded(api, type_, devices, exchange, mon
 
 def div_rows(type_):
     return 4 if type_ == "m2dp" else 1
+
+
+def test_matcher_float32_signatures_and_larger_k(api):
+    """Signatures stored as float32 in HBM (half the memory of the reference's doubles): the pack kernels and the fp64
+    re-evaluation read them as they are; the oracle gets the same float32-rounded values.  k = 7."""
+    import torch
+    from so_dso_place_recognition_amd.matcher import Matcher
+    n, m, k = 700, 50, 7
+    db = synth.sc_database(45, n).astype(np.float32); q, _ = synth.sc_queries(46, db.astype(np.float64), m)
+    q = q.astype(np.float32)
+    mt = Matcher("sc", m, n)
+    mt.pack_database(torch.from_numpy(db).cuda())
+    idx, sc = mt.match(torch.from_numpy(q).cuda(), mask_width=2, k=k)
+    rc, oidx, osc = oracle_lib.match_topk(0, q.astype(np.float64), db.astype(np.float64), 2, 2.0, k)
+    assert np.array_equal(idx.cpu().numpy(), oidx) and (np.abs(sc.cpu().numpy() - osc) <= helpers.score_tol(osc)).all()
+    mt.close()
