@@ -154,6 +154,38 @@ def extra_workloads(dev, ev, args):
                                       "frac_of_fp32_mfma_peak": m * n * FLOP_PER_PAIR / (k * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                       "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == planted).sum()), "queries": m}
     mt.close()
+    # online use (one keyframe at a time against a resident, already packed DB): wall time per call, host launch overhead included
+    mt = Matcher("sc", 32, n, ctx=Context(dev.index, stream=cur))
+    mt.pack_database(db)
+    lat = {}
+    for mq in (1, 8, 32):
+        qq = q[:mq].contiguous()
+        for _ in range(3):
+            mt.match(qq, 0, 2.0, 1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            idx, _ = mt.match(qq, 0, 2.0, 1)
+            torch.cuda.synchronize()
+        lat[f"m={mq}"] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / 20, "top1_correct": int((idx.cpu().numpy()[:, 0] == planted[:mq]).sum())}
+    out["sc_match_100k_latency"] = {"note": "pack(q) + distances + moments + select + fp64 re-evaluation, DB resident and packed, synchronised per call", **lat}
+    mt.close()
+    try:   # the same call replayed as one hipGraph
+        mg = Matcher.on_new_stream("sc", 8, n, device=dev.index)
+        with torch.cuda.stream(mg.stream):
+            mg.pack_database(db)
+        q1 = q[:1].clone()
+        cap = mg.capture(q1, 0, 2.0, 1)
+        for _ in range(3):
+            cap.run()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            cap.run()
+        out["sc_match_100k_latency"]["m=1 hipGraph replay"] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / 20,
+                                                                "top1_correct": int((cap.idx.cpu().numpy()[:, 0] == planted[:1]).sum())}
+        mg.close()
+    except Exception as e:   # graph capture is an extra, never a reason to lose the bench line
+        out["sc_match_100k_latency"]["m=1 hipGraph replay"] = {"error": repr(e)[:200]}
     return out
 
 
@@ -164,7 +196,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--db", type=int, default=100_000, help="total DB signatures (sharded over the ranks)")
     ap.add_argument("--queries", type=int, default=4096)
-    ap.add_argument("--cpu-sample", type=int, default=-1, help="queries for the CPU baseline (-1: one per host core, <= 128)")
+    ap.add_argument("--cpu-sample", type=int, default=-1, help="queries for the CPU baseline (-1: one per host core, <= 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sc-arith", default=None, choices=["f16x2", "f32"],
                     help="SC matcher arithmetic (default: the library's, split-f16 MFMA; f32 = the fp32-MFMA kernel)")
@@ -293,7 +325,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tests"))
             import oracle_lib                                           # the checker: CPU port of the reference
             cores = os.cpu_count() or 1
-            S = args.cpu_sample if args.cpu_sample > 0 else min(cores, 128)
+            S = args.cpu_sample if args.cpu_sample > 0 else min(cores, 64)
             omp = C.CDLL("libgomp.so.1")
             omp.omp_set_num_threads(1)                                  # the reference itself is single-threaded (SC/test_sc.cpp:40-56, run_test.m)
             t0 = time.perf_counter()

@@ -28,6 +28,8 @@ struct pr_ctx {
   hipStream_t side2 = nullptr;   // SC generation: odd batches (kernel boundaries of one stream hide behind the other's kernels)
   hipEvent_t ev_b = nullptr;
   char* sc_scratch = nullptr;    // tickets + partial moments / bin grids of the split SC generation, one half per stream
+  double* rr_scratch = nullptr;  // candidate scores of pr_rerank_dev (grow-only: a steady-state call allocates nothing and can be graph-captured)
+  size_t rr_cap = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
   int* d_flags = nullptr;        // [4] deferred bits: [0] zero-norm row at pack time, [1] M2DP singular pair not converged
@@ -85,7 +87,7 @@ size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups, int sc_m
   if (type == PR_TYPE_SC && sc_mode == 0) {   // split-f16 images, sizes in bytes / 4
     if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SCH_QIMG / 4; }
     *groups = pr::sc_dgroups(max_sigs);
-    return (size_t)(2 * *groups + 2) * pr::SCH_DIMG / 4;   // + two all-zero groups: the pipeline runs one group past the end
+    return (size_t)(2 * *groups + 9) * pr::SCH_DIMG / 4;   // + all-zero groups: a wave's pipeline runs one unit past the end (4 groups ahead for m <= 8, + its prefetch)
   }
   if (type == PR_TYPE_SC) {
     if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SC_QIMG; }
@@ -244,6 +246,7 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->side2) { (void)hipStreamSynchronize(ctx->side2); (void)hipStreamDestroy(ctx->side2); }
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->sc_scratch) (void)hipFree(ctx->sc_scratch);
+  if (ctx->rr_scratch) (void)hipFree(ctx->rr_scratch);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
@@ -597,12 +600,15 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
     PR_FAIL(ctx, PR_EINVAL, "pr_rerank_dev: bad arguments (m=%d, n_local=%d, G=%d, k=%d, k_in=%d)", m, n_local, G, k, k_in);
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
-  double* cand = nullptr;
-  PR_HIP(ctx, hipMallocAsync((void**)&cand, (size_t)m * k_in * sizeof(double), ctx->stream));
+  const size_t need = (size_t)m * k_in;
+  if (need > ctx->rr_cap) {
+    if (ctx->rr_scratch) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->rr_scratch)); ctx->rr_scratch = nullptr; ctx->rr_cap = 0; }
+    PR_HIP(ctx, hipMalloc((void**)&ctx->rr_scratch, need * sizeof(double)));
+    ctx->rr_cap = need;
+  }
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
-                    p_weight, k_in, idx_in, cand, k, idx, score, nullptr);
+                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr);
   PR_HIP(ctx, hipGetLastError());
-  PR_HIP(ctx, hipFreeAsync(cand, ctx->stream));
   return PR_OK;
 }
 

@@ -176,6 +176,10 @@ __device__ __forceinline__ void ep_store(float mx, __amdgpu_buffer_rsrc_t rd, in
     F[r0] = _f[0]; F[r0 + 1] = _f[1]; M[r0] = _m[0]; M[r0 + 1] = _m[1];             \
   }
 
+// ONEQ (m <= 8, the online case of one keyframe per call): all four waves of a workgroup work for the SAME 8-query group
+// - wave w takes DB groups g0 + w, g0 + w + 4, ... - instead of four query groups sharing every DB group, so a call
+// takes a quarter of the time (three of four waves would otherwise multiply padding).
+template <bool ONEQ>
 __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restrict__ qpk,   // [2][QG32][4][31][1288 B]
                                                             const char* __restrict__ dpk,   // [2][DG][31][4][768 B] + one zero group
                                                             const u32x4* __restrict__ cst,  // [2][2][2][64] x 16 B
@@ -204,15 +208,17 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
 
   const int row = lane & 15, kg = lane >> 4;
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds;
-  const unsigned nat0 = lds0 + w * SCH_QIMG + row * 80 + (row >= 8 ? 8 : 0) + kg * 16;
-  const unsigned rot0 = lds0 + w * SCH_QIMG + (row ^ 8) * 80 + (row >= 8 ? 0 : 8) + kg * 16;
+  constexpr int GS = ONEQ ? 4 : 1;                                  // DB groups between two units of a wave
+  const int wq = ONEQ ? 0 : w;                                      // this wave's query group inside the workgroup's image
+  const unsigned nat0 = lds0 + wq * SCH_QIMG + row * 80 + (row >= 8 ? 8 : 0) + kg * 16;
+  const unsigned rot0 = lds0 + wq * SCH_QIMG + (row ^ 8) * 80 + (row >= 8 ? 0 : 8) + kg * 16;
   const int voff = (lane < 48) ? lane * 16 : (int)0x80000000;     // lanes 48-63: out of range -> zeros (K = 24..31)
   const float sg = (lane < 32) ? 1.0f : -1.0f;
   const f32x2 sg2 = {sg, sg};
   float* dist = ch ? dist_i : dist_p;
   const char* dbase = dpk + ((size_t)ch * DG) * SCH_DIMG;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  const int qrow0 = qg32 * 32 + w * 8;
+  const int qrow0 = qg32 * 32 + wq * 8;
   // distances of this wave's 8 query rows: byte offset = ((local row) * n + entry) * 4; local row = R (lanes 0-15) or 4 + R (16-31)
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
       dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 8 ? m - qrow0 : 8) : 0) * n * 4, 0x00020000);
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   AOps At[4];
   BOps Bt[4];
   __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)g0 * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g0 + (ONEQ ? w : 0)) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
   load_b<0, B_REH>(Bt[0], rs, voff); load_b<0, B_IMH>(Bt[0], rs, voff); load_b<0, B_REL>(Bt[0], rs, voff); load_b<0, B_IML>(Bt[0], rs, voff);
   load_a<0, A_H>(At[0], nat0, rot0); load_a<0, A_RH>(At[0], nat0, rot0); load_a<0, A_L>(At[0], nat0, rot0); load_a<0, A_RL>(At[0], nat0, rot0);
   load_b<1, B_REH>(Bt[1], rs, voff); load_b<1, B_IMH>(Bt[1], rs, voff); load_b<1, B_REL>(Bt[1], rs, voff);
@@ -242,9 +248,9 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev));
 #endif
-  for (int g = g0; g < g1; g++) {
+  for (int g = g0 + (ONEQ ? w : 0); g < g1; g += GS) {
     const __amdgpu_buffer_rsrc_t rsn =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g + 1) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g + GS) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
     f32x16 accE[4][2], accO[4][2];
     Half hb;
     Consts c;
@@ -336,7 +342,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
        // paying HBM latency in the middle of the in-order load queue.
       asm volatile("" : : "v"(pf_sink));
       const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<char*>(dbase + (size_t)(g + 2) * SCH_DIMG), 0, (g + 2 < DG) ? SCH_DIMG : 0, 0x00020000);
+          const_cast<char*>(dbase + (size_t)(g + 2 * GS) * SCH_DIMG), 0, (g + 2 * GS < DG) ? SCH_DIMG : 0, 0x00020000);
       pf_sink = __builtin_amdgcn_raw_buffer_load_b32(rp, pf_off, 0, 0);
     }
     swap_r<0>(hb, 0, 4);
@@ -363,7 +369,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   }
 #ifdef PR_SCH_TIMING
   if (blockIdx.x == 8 * 40 && tid == 0)   // one wave somewhere in the middle of the grid; written over the first distances
-    for (int i = 0; i < 8; i++) reinterpret_cast<unsigned long long*>(dist_p)[i] = tacc[i] / (unsigned long long)(g1 - g0);
+    for (int i = 0; i < 8; i++) reinterpret_cast<unsigned long long*>(dist_p)[i] = tacc[i] / (unsigned long long)((g1 - g0) / GS);
 #endif
 }
 
@@ -381,9 +387,18 @@ void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, 
   if (nsplit > DG / 32) nsplit = DG / 32;          // keep >= 8 DB groups (128 entries) per workgroup
   if (nsplit < 1) nsplit = 1;
   if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_match_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (m <= 8) {   // one query group: the four waves of a workgroup split the DB groups of its range
+    nsplit = DG / 32 < 32 ? (DG / 32 > 0 ? DG / 32 : 1) : 32;        // 8 x nsplit workgroups = one per CU, >= 8 units per wave
+    if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_match_h_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)sc_match_h_lds_bytes());
+    hipLaunchKernelGGL(sc_match_h_kernel<true>, dim3(8 * nsplit), dim3(256), sc_match_h_lds_bytes(), st, static_cast<const char*>(qpk),
+                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit);
+    return;
+  }
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_match_h_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sc_match_h_lds_bytes());
-  hipLaunchKernelGGL(sc_match_h_kernel, dim3(8 * QG32 * nsplit), dim3(256), sc_match_h_lds_bytes(), st,
+  hipLaunchKernelGGL(sc_match_h_kernel<false>, dim3(8 * QG32 * nsplit), dim3(256), sc_match_h_lds_bytes(), st,
                      static_cast<const char*>(qpk), static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i,
                      m, n, QG8, DG, nsplit);
 }

@@ -208,6 +208,52 @@ class Matcher(_Base):
         """The last distance matrices (device, float32 [m, n_local])."""
         return self._bufs["d_p"], self._bufs.get("d_i")
 
+    @classmethod
+    def on_new_stream(cls, type_: str, max_queries: int, max_db: int, device: int | None = None):
+        """A matcher whose library context lives on a stream of its own (`.stream`): what hipGraph capture needs (the null
+        stream cannot be captured).  Use it under `with torch.cuda.stream(mt.stream):`."""
+        device = torch.cuda.current_device() if device is None else device
+        st = torch.cuda.Stream(device)
+        with torch.cuda.stream(st):
+            mt = cls(type_, max_queries, max_db, ctx=_stream_context(device))
+        mt.stream = st
+        return mt
+
+    def capture(self, queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1):
+        """Captures one single-rank match() of the STATIC tensor `queries` against the resident, packed DB into a hipGraph
+        (online use: one keyframe per call - the ~10 kernel launches of a call replay as one graph launch).  Returns a
+        CapturedMatch: `.run(new_queries)` copies them into the static input and replays ON THE MATCHER'S STREAM (a replay
+        on another stream would not be ordered with the copy), `.idx` / `.score` are the static outputs.  The matcher must
+        come from on_new_stream()."""
+        st = self.stream
+        with torch.cuda.stream(st):
+            assert self.ctx.stream == int(st.cuda_stream)
+            self.match(queries, mask_width, p_weight, k)            # warm-up: allocates every buffer the call uses
+            st.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=st):
+                idx, score = self.match(queries, mask_width, p_weight, k)
+        return CapturedMatch(g, st, queries, idx, score)
+
+
+class CapturedMatch:
+    """A match() call as a hipGraph (Matcher.capture)."""
+
+    def __init__(self, graph, stream, queries, idx, score):
+        self.graph, self.stream, self.queries, self.idx, self.score = graph, stream, queries, idx, score
+
+    def run(self, new_queries: torch.Tensor | None = None, sync: bool = True):
+        if new_queries is not None:
+            self.stream.wait_stream(torch.cuda.current_stream(new_queries.device))   # whoever produced new_queries did it there
+            new_queries.record_stream(self.stream)
+        with torch.cuda.stream(self.stream):
+            if new_queries is not None:
+                self.queries.copy_(new_queries, non_blocking=True)
+            self.graph.replay()
+        if sync:
+            self.stream.synchronize()
+        return self.idx, self.score
+
 
 class FusedMatcher(_Base):
     """BASELINE.json config 5 ("fused SC + M2DP scoring", build-defined: DESIGN.md §7): an SC and an M2DP matcher over the

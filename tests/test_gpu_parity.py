@@ -517,3 +517,38 @@ def test_matcher_float32_signatures_and_larger_k(api):
     rc, oidx, osc = oracle_lib.match_topk(0, q.astype(np.float64), db.astype(np.float64), 2, 2.0, k)
     assert np.array_equal(idx.cpu().numpy(), oidx) and (np.abs(sc.cpu().numpy() - osc) <= helpers.score_tol(osc)).all()
     mt.close()
+
+
+def test_match_as_hipgraph_replay(api):
+    """One match() call captured into a hipGraph (online use: a keyframe per call): replays with new signatures in the static
+    input give what the eager call gives."""
+    import torch
+    from so_dso_place_recognition_amd.matcher import Matcher
+    n, m, k = 3000, 4, 2
+    db = synth.sc_database(45, n); q, planted = synth.sc_queries(46, db, 3 * m)
+    mt = Matcher.on_new_stream("sc", m, n)
+    with torch.cuda.stream(mt.stream):
+        mt.pack_database(torch.from_numpy(db).cuda())
+        qs = torch.from_numpy(q[:m]).cuda()
+    cap = mt.capture(qs, 0, 2.0, k)
+    for r in range(3):
+        idx, sc = cap.run(torch.from_numpy(q[r * m:(r + 1) * m]).cuda())
+        want_idx, want_sc = api.match_topk("sc", q[r * m:(r + 1) * m], db, 0, 2.0, k)
+        assert np.array_equal(idx.cpu().numpy(), want_idx) and np.abs(sc.cpu().numpy() - want_sc).max() < 1e-9
+        assert np.array_equal(idx.cpu().numpy()[:, 0], planted[r * m:(r + 1) * m])
+    mt.close()
+
+
+@pytest.mark.parametrize("m,n", [(1, 1000), (3, 333), (8, 4099), (5, 17)])
+def test_sc_small_query_batches_use_the_one_group_kernel(api, m, n):
+    """m <= 8 (a keyframe per call): the four waves of a workgroup share one query group and split the DB groups
+    (sc_match_h_kernel<true>).  Same distances, same top-k."""
+    db = synth.sc_database(45, n)
+    q, _ = synth.sc_queries(46, db, m)
+    rc, op, oi = oracle_lib.sc_distance(q, db)
+    gp, gi = api.processSC(q, db)
+    assert np.abs(gp - op).max() < 1e-5 and np.abs(gi - oi).max() < 1e-5
+    k = min(3, n)
+    idx, sc = api.match_topk("sc", q, db, 0, 2.0, k)
+    rc, oidx, osc = oracle_lib.match_topk(0, q, db, 0, 2.0, k)
+    assert np.array_equal(idx, oidx)
