@@ -528,7 +528,9 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
   }
   // padding rows/tiles must be zero: they yield dot = 0 and are masked on store
   PR_HIP(ctx, hipMemsetAsync(s->packed, 0, s->floats * sizeof(float), ctx->stream));
-  if (s->bad) PR_HIP(ctx, hipMemsetAsync(s->bad, 0, ((size_t)s->max_sigs + 1) * sizeof(int), ctx->stream));
+  // (a kernel, not hipMemsetAsync: captured into a hipGraph, the memset node of this small array - 20 bytes for a 4-query set - did
+  // not take effect on every replay on ROCm 7.0 / 7.2, and stale flags turn into NaN rows; tests/test_gpu_parity.py, hipgraph test)
+  if (s->bad) pr::launch_zero_ints(ctx->stream, s->bad, s->max_sigs + 1);
   // the channel stride must match the matcher's view of THIS count (not the capacity)
   int groups;
   (void)sigset_floats(s->type, s->role, n_sigs, &groups, s->sc_mode);

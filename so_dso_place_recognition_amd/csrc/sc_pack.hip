@@ -286,7 +286,16 @@ void launch_pack_col(hipStream_t st, const T* sig, int rows, unsigned short* pac
                      groups, tw, flags, bad);
 }
 
+__global__ __launch_bounds__(256) void zero_ints_kernel(int* __restrict__ p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
 }  // namespace
+
+void launch_zero_ints(hipStream_t st, int* p, int n) {
+  if (n > 0) hipLaunchKernelGGL(zero_ints_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, n);
+}
 
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
                       const double* twiddle, int* flags, int* bad) {

@@ -519,12 +519,13 @@ def test_matcher_float32_signatures_and_larger_k(api):
     mt.close()
 
 
-def test_match_as_hipgraph_replay(api):
+@pytest.mark.parametrize("m", [4, 32])
+def test_match_as_hipgraph_replay(api, m):
     """One match() call captured into a hipGraph (online use: a keyframe per call): replays with new signatures in the static
     input give what the eager call gives."""
     import torch
     from so_dso_place_recognition_amd.matcher import Matcher
-    n, m, k = 3000, 4, 2
+    n, k = 3000, 2
     db = synth.sc_database(45, n); q, planted = synth.sc_queries(46, db, 3 * m)
     mt = Matcher.on_new_stream("sc", m, n)
     with torch.cuda.stream(mt.stream):
