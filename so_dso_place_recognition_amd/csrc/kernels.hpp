@@ -42,6 +42,11 @@ void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int 
 void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p,
                        float* d_i, int nsplit_override);
 size_t sc_match_h_lds_bytes();
+// sc_match_p.hip — the same with two waves per SIMD sharing every unit (frequency-split stage 1, register-split stage 2); same packed
+// images, its own stage-2 constant table [4 quarters][E hh+hl | E lh | O hh+hl | O lh][64 lanes] x 16 B
+void launch_sc_match_p(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
+                       int nsplit_override);
+size_t sc_match_p_lds_bytes();
 
 // m2dp_match.hip — processM2DP.m:12-22 for both channels.
 void launch_m2dp_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed, int tiles);

@@ -323,6 +323,23 @@ def test_sc_both_arithmetics_vs_oracle(api):
     print("max |d - oracle|:", errs)
 
 
+def test_sc_two_wave_kernel_vs_oracle(api, monkeypatch):
+    """sc_match_p.hip (PR_SC_KERNEL=p, an experiment kept in the library: two waves per SIMD share every unit) must give the
+    oracle's distances and top-k like the default kernel; odd DB group counts and a ragged last query group included."""
+    monkeypatch.setenv("PR_SC_KERNEL", "p")
+    for seed, n, m in ((51, 333, 64), (52, 1000, 21), (53, 2049, 9)):
+        db = synth.sc_database(seed, n)
+        q, _ = synth.sc_queries(seed + 100, db, m)
+        rc, op, oi = oracle_lib.sc_distance(q, db)
+        rc, oidx, osc = oracle_lib.match_topk(0, q, db, 3, 2.0, 4)
+        ctx = api.Context(0)
+        gp, gi = api.processSC(q, db, ctx)
+        assert max(np.abs(gp - op).max(), np.abs(gi - oi).max()) < 2e-6
+        idx, sc = api.match_topk("sc", q, db, 3, 2.0, 4, ctx=ctx)
+        assert np.array_equal(idx, oidx)
+        ctx.close()
+
+
 def test_sc_mixed_arithmetic_sets_are_rejected(api):
     import ctypes as C
     from so_dso_place_recognition_amd import _lib
