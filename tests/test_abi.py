@@ -55,14 +55,14 @@ def test_product_does_not_link_the_oracle():
 def test_inline_asm_mfma_operands_are_not_written_right_before_use():
     """hipcc pads nothing for inline asm: a compiler-generated VALU write (spill reload, copy) of an operand within two
     instructions of a hand-written MFMA is silent corruption (seen once during development).  tools/audit_asm_hazards.py
-    scans the gfx950 assembly of both SC matchers for it."""
+    scans the gfx950 assembly of the SC matchers that contain asm MFMAs for it."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    src = [os.path.join(root, "so_dso_place_recognition_amd", "csrc", f) for f in ("sc_match_h.hip", "sc_match.hip")]
+    src = [os.path.join(root, "so_dso_place_recognition_amd", "csrc", f) for f in ("sc_match_h.hip", "sc_match.hip", "sc_match_r.hip")]
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "audit_asm_hazards.py")] + src, capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "372 inline-asm MFMAs checked, 0 finding" in r.stdout
+    assert "372 inline-asm MFMAs checked, 0 finding" in r.stdout and "186 inline-asm MFMAs checked, 0 finding" in r.stdout
     # the audit itself: a reload in front of an asm MFMA and a copy of its result right behind it are both reported
     sys.path.insert(0, os.path.join(root, "tools"))
     import audit_asm_hazards as aud

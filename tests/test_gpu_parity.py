@@ -323,10 +323,12 @@ def test_sc_both_arithmetics_vs_oracle(api):
     print("max |d - oracle|:", errs)
 
 
-def test_sc_two_wave_kernel_vs_oracle(api, monkeypatch):
-    """sc_match_p.hip (PR_SC_KERNEL=p, an experiment kept in the library: two waves per SIMD share every unit) must give the
-    oracle's distances and top-k like the default kernel; odd DB group counts and a ragged last query group included."""
-    monkeypatch.setenv("PR_SC_KERNEL", "p")
+@pytest.mark.parametrize("kernel", ["p", "r"])
+def test_sc_experiment_kernels_vs_oracle(api, monkeypatch, kernel):
+    """sc_match_p.hip (PR_SC_KERNEL=p: two waves per SIMD share every unit) and sc_match_r.hip (PR_SC_KERNEL=r: stage 2 rolled into
+    stage 1), experiments kept in the library, must give the oracle's distances and top-k like the default kernel; odd DB
+    group counts and a ragged last query group included."""
+    monkeypatch.setenv("PR_SC_KERNEL", kernel)
     for seed, n, m in ((51, 333, 64), (52, 1000, 21), (53, 2049, 9)):
         db = synth.sc_database(seed, n)
         q, _ = synth.sc_queries(seed + 100, db, m)
