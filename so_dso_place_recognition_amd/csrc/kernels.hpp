@@ -91,6 +91,10 @@ constexpr size_t SC_SCRATCH_PER_STREAM = (size_t)2 * SC_MAX_SPLIT_CLOUDS * 4 + (
 size_t sc_generate_scratch_bytes();
 void launch_sc_batch(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int c0, int c1, int W, double max_rho,
                      double* frames, char* scratch, double* out);
+size_t sc_cluster_scratch_bytes(int ncl, int CW);
+int sc_cluster_points_per_workgroup();
+int* launch_sc_cluster(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double max_rho, int CW, int ncu,
+                       char* scratch, double* frames, double* out);
 void launch_sc_finish(hipStream_t st, const float* ave, int N, double* out);
 void launch_sc_bin(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double max_rho,
                    const double* frames, const float* ave, double* out);

@@ -951,6 +951,33 @@ int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const
   // HBM bytes but measured 6.25 ms against 2.6 ms at 5000 x 50 000 points (74 batches x 2 launches of ~550 workgroups each
   // cannot keep enough loads in flight; tools/experiments/README.md).
   static const bool two_pass = !(getenv("PR_SC_GEN") && !strcmp(getenv("PR_SC_GEN"), "batched"));
+  static const bool cluster = getenv("PR_SC_GEN") && !strcmp(getenv("PR_SC_GEN"), "cluster");
+  if (cluster) {   // one HBM pass: clusters of workgroups hold a cloud in registers between the moments and the binning (sc_gen.hip)
+    std::vector<int64_t> ho((size_t)N + 1);
+    PR_HIP(ctx, hipMemcpyAsync(ho.data(), offs, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int64_t pmax = 0;
+    for (int c = 0; c < N; c++) pmax = std::max(pmax, ho[c + 1] - ho[c]);
+    int ncu = 0;
+    PR_HIP(ctx, hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, ctx->device));
+    int CW = 1;
+    while ((int64_t)CW * pr::sc_cluster_points_per_workgroup() < pmax) CW *= 2;
+    if (CW <= ncu / 8) {
+      const int ncl = 8 * ((ncu / 8) / CW);
+      const size_t need = pr::sc_cluster_scratch_bytes(ncl, CW);
+      DevBuf scr;
+      PR_HIP(ctx, scr.alloc(need));
+      pr::launch_ave_chain(ctx->stream, inten, offs, N, ave.as<float>());
+      int* err = pr::launch_sc_cluster(ctx->stream, xyz, inten, offs, N, max_rho, CW, ncu, scr.as<char>(), frames.as<double>(), out);
+      pr::launch_sc_finish(ctx->stream, ave.as<float>(), N, out);
+      int herr = 0;
+      PR_HIP(ctx, hipMemcpyAsync(&herr, err, 4, hipMemcpyDeviceToHost, ctx->stream));
+      PR_HIP(ctx, hipGetLastError());
+      PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      if (herr) PR_FAIL(ctx, PR_EHIP, "pr_sc_generate_dev: a cluster hand-off timed out");
+      return PR_OK;
+    }
+  }
   if (two_pass) {
     if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc;
     pr::launch_sc_bin(ctx->stream, xyz, inten, offs, N, max_rho, frames.as<double>(), ave.as<float>(), out);

@@ -394,6 +394,185 @@ __global__ __launch_bounds__(512) void sc_bin_split_kernel(const double* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------------- cluster path: ONE HBM pass
+// A cloud is read from HBM ONCE: CW workgroups (a cluster, all on one XCD, resident for the whole launch) each pull one slice
+// of it - up to 16 points per thread - into REGISTERS, add up the slice's moments, hand them to the cluster (last arriver
+// computes the PCA frame and publishes it with a sequence number the others spin on), and then bin their register-resident
+// points; the last workgroup to finish merges the CW partial bin grids and writes the signature.  Algorithmic bytes = HBM bytes
+// (28 per point + the output); the hand-offs stay in the XCD's L2.  A cluster walks clouds cl, cl + ncl, ...; scratch is
+// double-buffered by the parity of the walk (nobody can get two clouds ahead: the next frame needs everybody's moments).
+// Spins are bounded: a lost hand-off sets *err instead of hanging the GPU.
+constexpr int CK = 13;                        // points per thread held in registers
+constexpr int CL_PART = PART_BYTES;           // partial grid of one slice
+struct ClusterScratch {                       // per cluster, x 2 parities: see sc_cluster_scratch_bytes
+  unsigned ticket_m, ticket_b, seq[2], xcc[4];
+};
+// Hand-offs INSIDE one XCD: its L2 is the coherence point (the vector L1 is write-through), so a producer only waits for its stores
+// to be acknowledged (vmcnt 0) before the ticket / sequence atomic (executed in L2), and a consumer only invalidates its CU's L1
+// (buffer_inv sc0) before reading - no L2 write-back / invalidate as an agent-scope fence would do across XCDs.  The kernel
+// checks with HW_REG_XCC_ID that a cluster's workgroups really share an XCD and reports err = 2 otherwise (host: two-pass path).
+__device__ __forceinline__ void l1_invalidate() { asm volatile("buffer_inv sc0" ::: "memory"); }
+__device__ __forceinline__ bool last_arriver_xcd(unsigned* ticket, int W, int tid, int* flag) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t == (unsigned)(W - 1));
+    if (last) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      l1_invalidate();
+    }
+    *flag = last;
+  }
+  __syncthreads();
+  return *flag != 0;
+}
+__device__ __forceinline__ bool spin_until(unsigned* seq, unsigned want, int* err) {
+  for (int i = 0; i < (1 << 22); i++) {
+    if (__hip_atomic_load(seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == want) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  *err = 1;
+  return false;
+}
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void sc_gen_cluster_kernel(const double* __restrict__ xyz, const float* __restrict__ inten, const int64_t* __restrict__ offs, int N,
+                           double max_rho, int CW, int ncl, ClusterScratch* __restrict__ cs, double* __restrict__ pmom,
+                           double* __restrict__ pframe, char* __restrict__ pgrid, double* __restrict__ frames,
+                           double* __restrict__ out, int* __restrict__ err) {
+  __shared__ unsigned int cnt[1200];
+  __shared__ unsigned long long lo[1200], hi[1200];
+  __shared__ double sum[1200];
+  __shared__ double red[8][9];
+  __shared__ double frs[16];
+  __shared__ int flag;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+  const int cl = xcd + 8 * (j / CW), sl = j % CW;       // the cluster's workgroups share an XCD (workgroups go round-robin to XCDs)
+  if (cl >= ncl) return;
+  const double S_res_inv = 60 / (2.0 * M_PI), R_res_inv = 20 / max_rho;   // SC.cpp:5-8
+  const float S_f = (float)S_res_inv, R_f = (float)R_res_inv;
+  ClusterScratch* my = cs + cl;
+  if (tid == 0) {   // all workgroups of a cluster must sit on one XCD (that is what the cheap hand-offs assume)
+    unsigned x;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x));
+    x = (x & 0xf) + 1;
+    const unsigned prev = __hip_atomic_exchange(&my->xcc[0], x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev != 0 && prev != x) *err = 2;
+  }
+  unsigned it = 0;
+  for (int c = cl; c < N; c += ncl, it++) {
+    const int par = it & 1;
+    const int64_t o0 = offs[c];
+    const int64_t P = offs[c + 1] - o0;
+    const int64_t i0 = P * sl / CW, i1 = P * (sl + 1) / CW;
+    const double* p = xyz + 3 * o0;
+    const float* itn = inten + o0;
+    double px[CK], py[CK], pz[CK];
+    float pv[CK];
+#pragma unroll
+    for (int u = 0; u < CK; u++) {              // the whole slice is requested at once: 16 x 28 bytes per thread in flight
+      const int64_t i = i0 + tid + 512 * u;
+      const bool ok = i < i1;
+      px[u] = ok ? p[3 * i] : 0.0; py[u] = ok ? p[3 * i + 1] : 0.0; pz[u] = ok ? p[3 * i + 2] : 0.0;
+      pv[u] = ok ? itn[i] : 0.f;
+    }
+    for (int b = tid; b < 1200; b += 512) { cnt[b] = 0u; lo[b] = ~0ull; hi[b] = 0ull; sum[b] = 0.0; }
+    {   // moments of the slice (pts_align.h:9-21); points past the slice are zeros
+      double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int u = 0; u < CK; u++) {
+        const double x = px[u], y = py[u], z = pz[u];
+        s[0] += x; s[1] += y; s[2] += z;
+        s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;
+      }
+#pragma unroll
+      for (int k = 0; k < 9; k++) {
+        double v = s[k];
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
+        if (lane == 0) red[w][k] = v;
+      }
+    }
+    __syncthreads();
+    double* mom = pmom + ((size_t)(cl * 2 + par) * CW) * 9;
+    double* fr = pframe + (size_t)(cl * 2 + par) * 16;
+    if (tid < 9) {
+      double v = 0;
+      for (int q = 0; q < 8; q++) v += red[q][tid];
+      mom[sl * 9 + tid] = v;
+    }
+    if (last_arriver_xcd(&my->ticket_m, CW, tid, &flag)) {
+      if (tid == 0) {
+        double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        for (int u = 0; u < CW; u++)                                  // slice order: the sum does not depend on the arrival order
+          for (int k = 0; k < 9; k++) s[k] += mom[u * 9 + k];
+        double f[16];
+        finish_frame(s, (double)P, f);
+        for (int k = 0; k < 16; k++) { frs[k] = f[k]; fr[k] = f[k]; frames[(size_t)c * 16 + k] = f[k]; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_store(&my->seq[par], it + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    } else if (tid == 0) {
+      spin_until(&my->seq[par], it + 1, err);
+      l1_invalidate();
+      for (int k = 0; k < 16; k++) frs[k] = __hip_atomic_load(fr + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    const double mx = frs[0], my_ = frs[1], mz = frs[2];
+    const double e00 = frs[3], e01 = frs[4], e02 = frs[5], e10 = frs[6], e11 = frs[7], e12 = frs[8], e20 = frs[9], e21 = frs[10], e22 = frs[11];
+#pragma unroll
+    for (int u = 0; u < CK; u++) {
+      if (i0 + tid + 512 * u >= i1) continue;
+      const double x = px[u] - mx, y = py[u] - my_, z = pz[u] - mz;                   // pts_align.h:24-26
+      const double nx = (x * e00 + y * e01) + z * e02;                                // :37-39
+      const double yp = (x * e10 + y * e11) + z * e12;
+      const double zp = (x * e20 + y * e21) + z * e22;
+      const int si = polar_sector(zp, yp, S_res_inv, S_f);    // SC.cpp:37
+      const int ri = polar_ring(yp, zp, R_res_inv, R_f);      // SC.cpp:38
+      const int idx = si * 20 + ri;                                                   // :39
+      if (idx >= 1200 || idx < 0) continue;                                           // :42-44
+      atomicAdd(&cnt[idx], 1u);
+      const unsigned long long k = dkey(nx);
+      atomicMin(&lo[idx], k);
+      atomicMax(&hi[idx], k);
+      atomicAdd(&sum[idx], (double)pv[u]);
+      __builtin_amdgcn_sched_barrier(0);        // one point at a time: interleaving the 16 bodies costs more registers than it hides
+    }
+    __syncthreads();
+    if (CW > 1) {
+      char* base = pgrid + ((size_t)(cl * 2 + par) * CW) * CL_PART;
+      char* mine = base + (size_t)sl * CL_PART;
+      unsigned* pc = reinterpret_cast<unsigned*>(mine);
+      unsigned long long* pl = reinterpret_cast<unsigned long long*>(mine + 4800);
+      unsigned long long* ph = pl + 1200;
+      double* ps = reinterpret_cast<double*>(ph + 1200);
+      for (int b = tid; b < 1200; b += 512) { pc[b] = cnt[b]; pl[b] = lo[b]; ph[b] = hi[b]; ps[b] = sum[b]; }
+      if (!last_arriver_xcd(&my->ticket_b, CW, tid, &flag)) continue;
+      for (int u = 0; u < CW; u++) {
+        if (u == sl) continue;
+        const char* o = base + (size_t)u * CL_PART;
+        const unsigned* qc = reinterpret_cast<const unsigned*>(o);
+        const unsigned long long* ql = reinterpret_cast<const unsigned long long*>(o + 4800);
+        const unsigned long long* qh = ql + 1200;
+        const double* qs = reinterpret_cast<const double*>(qh + 1200);
+        for (int b = tid; b < 1200; b += 512) {
+          cnt[b] += qc[b];
+          lo[b] = ql[b] < lo[b] ? ql[b] : lo[b];
+          hi[b] = qh[b] > hi[b] ? qh[b] : hi[b];
+          sum[b] += qs[b];                                         // exact: floats of <= 24 bits, a few thousand per bin
+        }
+      }
+    }
+    double* o = out + (size_t)c * 2400;
+    for (int b = tid; b < 1200; b += 512) {
+      const unsigned int n = cnt[b];
+      o[b] = n ? dunkey(hi[b]) - dunkey(lo[b]) : 0.0;                                 // :74
+      o[1200 + b] = n ? sum[b] / (double)n : -__builtin_inf();                        // the mean; sc_finish compares it with the average
+    }
+    __syncthreads();
+  }
+}
+
 // out[c][1200 + b]: mean intensity of the bin -> (mean > float average) ? 1 : 0   (SC.cpp:69-70)
 __global__ __launch_bounds__(256) void sc_finish_kernel(const float* __restrict__ ave_in, int N, double* __restrict__ out) {
   const int c = blockIdx.x;
@@ -429,6 +608,31 @@ void launch_sc_batch(hipStream_t st, const double* xyz, const float* inten, cons
   }
   hipLaunchKernelGGL(cloud_frames_split_kernel, dim3(nb * W), dim3(FT), 0, st, xyz, offs, c0, W, pm, tk_f, frames);
   hipLaunchKernelGGL(sc_bin_split_kernel, dim3(nb * W), dim3(512), 0, st, xyz, inten, offs, c0, W, frames, max_rho, pg, tk_b, out);
+}
+
+// scratch of the cluster path for ncl clusters of CW workgroups: [ClusterScratch x ncl | moments | frames | partial grids | err]
+size_t sc_cluster_scratch_bytes(int ncl, int CW) {
+  return (size_t)ncl * sizeof(ClusterScratch) + (size_t)ncl * 2 * CW * 9 * 8 + (size_t)ncl * 2 * 16 * 8 + (size_t)ncl * 2 * CW * CL_PART + 64;
+}
+int sc_cluster_points_per_workgroup() { return 512 * CK; }
+
+// clusters of CW workgroups, one workgroup per CU: grid = 8 XCDs x (ncu / 8 / CW) clusters x CW.  The first
+// ncl * sizeof(ClusterScratch) bytes of scratch (tickets, sequence numbers) and the err word must be zero at entry
+// (launch_zero_ints); returns the device address of the err word.
+int* launch_sc_cluster(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double max_rho, int CW, int ncu,
+                       char* scratch, double* frames, double* out) {
+  const int per_xcd = (ncu / 8) / CW;                  // clusters per XCD
+  const int ncl = 8 * per_xcd;
+  ClusterScratch* cs = reinterpret_cast<ClusterScratch*>(scratch);
+  double* pmom = reinterpret_cast<double*>(scratch + (size_t)ncl * sizeof(ClusterScratch));
+  double* pframe = pmom + (size_t)ncl * 2 * CW * 9;
+  char* pgrid = reinterpret_cast<char*>(pframe + (size_t)ncl * 2 * 16);
+  int* err = reinterpret_cast<int*>(pgrid + (size_t)ncl * 2 * CW * CL_PART);
+  launch_zero_ints(st, reinterpret_cast<int*>(cs), (int)(ncl * sizeof(ClusterScratch) / 4));
+  launch_zero_ints(st, err, 1);
+  hipLaunchKernelGGL(sc_gen_cluster_kernel, dim3(8 * per_xcd * CW), dim3(512), 0, st, xyz, inten, offs, N, max_rho, CW, ncl, cs, pmom,
+                     pframe, pgrid, frames, out, err);
+  return err;
 }
 
 void launch_sc_finish(hipStream_t st, const float* ave, int N, double* out) {
