@@ -950,8 +950,8 @@ int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const
   // cache-resident variant below - batches of ~96 MB, W workgroups per cloud, last-arriver merges - which moves half the
   // HBM bytes but measured 6.25 ms against 2.6 ms at 5000 x 50 000 points (74 batches x 2 launches of ~550 workgroups each
   // cannot keep enough loads in flight; tools/experiments/README.md).
-  static const bool two_pass = !(getenv("PR_SC_GEN") && !strcmp(getenv("PR_SC_GEN"), "batched"));
-  static const bool cluster = getenv("PR_SC_GEN") && !strcmp(getenv("PR_SC_GEN"), "cluster");
+  const bool two_pass = !(getenv("PR_SC_GEN") && !strcmp(getenv("PR_SC_GEN"), "batched"));
+  const bool cluster = getenv("PR_SC_GEN") && !strcmp(getenv("PR_SC_GEN"), "cluster");
   if (cluster) {   // one HBM pass: clusters of workgroups hold a cloud in registers between the moments and the binning (sc_gen.hip)
     std::vector<int64_t> ho((size_t)N + 1);
     PR_HIP(ctx, hipMemcpyAsync(ho.data(), offs, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));

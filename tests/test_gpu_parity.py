@@ -187,6 +187,29 @@ def test_sc_generate_vs_oracle(api, P):
     assert np.abs(g[:, :1200] - o[:, :1200]).max() < 1e-10
 
 
+@pytest.mark.parametrize("variant", ["batched", "cluster"])
+def test_sc_generate_experiment_paths_vs_oracle(api, monkeypatch, variant):
+    """The one-pass generation variants kept in the library (PR_SC_GEN=batched / cluster: several workgroups per cloud with grid-level
+    hand-offs) give the oracle's signatures like the default two-pass path - large, ragged, tiny and empty clouds in one call."""
+    monkeypatch.setenv("PR_SC_GEN", variant)
+    parts = [synth.scene_cloud(42, 1, 30011), synth.scene_cloud(42, 2, 3), synth.scene_cloud(42, 3, 9000),
+             synth.scene_cloud(42, 4, 20011)]
+    xyz = np.concatenate([p[0] for p in parts]); it = np.concatenate([p[1] for p in parts])
+    offs = np.array([0, 30011, 30011, 30014, 39014, 59025], np.int64)              # cloud 1 is empty
+    o = oracle_lib.sc_generate(xyz, it, offs)
+    g = api.sc_generate(xyz, it, offs)
+    assert np.array_equal(g[1], np.zeros(2400))
+    for r in (0, 2, 3, 4):
+        assert np.array_equal(g[r, 1200:], o[r, 1200:]) and np.abs(g[r] - o[r]).max() < 1e-10
+    for nclouds in (40, 300):                                                      # more clouds than clusters: the walk and its double buffers
+        xyz, it, offs = synth.scene_clouds(43, nclouds, 9001)
+        monkeypatch.setenv("PR_SC_GEN", variant)
+        g = api.sc_generate(xyz, it, offs)
+        monkeypatch.delenv("PR_SC_GEN")
+        d = api.sc_generate(xyz, it, offs)
+        assert np.array_equal(g[:, 1200:], d[:, 1200:]) and np.abs(g - d).max() < 1e-10
+
+
 def test_sc_generate_ragged_and_empty(api, golden_dir):
     a, ia = synth.scene_cloud(42, 5, 700)
     b, ib = synth.scene_cloud(42, 6, 3)
