@@ -56,7 +56,7 @@ __device__ __forceinline__ void load_a(AOps& a, unsigned nat, unsigned rot) {
 }
 template <int P, int T>
 __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int voff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + T * SCH_DTILE, P * SCH_DFREQ, 0);   // tile offset folds into the instruction
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, P * SCH_DFREQ + T * SCH_DTILE, 0);   // frequency and tile in the scalar offset: ONE lane-offset register (voff + T * 768 cost three more, spilled)
   if (T == B_REH) b.reh = v; else if (T == B_REL) b.rel = v; else if (T == B_IMH) b.imh = v; else b.iml = v;
 }
 
@@ -222,9 +222,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   // distances of this wave's 8 query rows: byte offset = ((local row) * n + entry) * 4; local row = R (lanes 0-15) or 4 + R (16-31)
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
       dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 8 ? m - qrow0 : 8) : 0) * n * 4, 0x00020000);
-  const int st_lane = ((lane & 16) ? 4 * n : 0) * 4 + (lane & 15) * 4;
   const int pf_slot = (qg32 & 31) * 4 + w;                                  // 0..127
-  const int pf_off = (lane < 6) ? (pf_slot * 6 + lane) * 128 : (int)0x80000000;   // lines past the group are out of range
   unsigned pf_sink = 0;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(cst), 0, 8192, 0x00020000);
 
@@ -248,6 +246,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev));
 #endif
+  unsigned nbase = nat0, rbase = rot0;       // carried through the running tile addresses: nothing address-like stays live (= spilled) across a unit
   for (int g = g0 + (ONEQ ? w : 0); g < g1; g += GS) {
     const __amdgpu_buffer_rsrc_t rsn =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g + GS) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
@@ -255,7 +254,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
     Half hb;
     Consts c;
     f32x4 Fa, Ma, Fb, Mb, t1a, t2a, t1b, t2b;
-    unsigned ncur, rcur, nnxt = nat0, rnxt = rot0;
+    unsigned ncur, rcur, nnxt = nbase, rnxt = rbase;
     TICK(7)
 // request tile T of frequency Q of this group (Q >= 31: nothing - the first requests of the next group are issued by
 // hand late in the stage-2 phase, when half of the packed registers are free again)
@@ -343,6 +342,9 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
       asm volatile("" : : "v"(pf_sink));
       const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(dbase + (size_t)(g + 2 * GS) * SCH_DIMG), 0, (g + 2 * GS < DG) ? SCH_DIMG : 0, 0x00020000);
+      int lp = lane;
+      asm volatile("" : "+v"(lp));                 // recomputed here, not kept (or spilled) across the unit
+      const int pf_off = (lp < 6) ? (pf_slot * 6 + lp) * 128 : (int)0x80000000;   // lines past the group are out of range
       pf_sink = __builtin_amdgcn_raw_buffer_load_b32(rp, pf_off, 0, 0);
     }
     swap_r<0>(hb, 0, 4);
@@ -350,20 +352,30 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
     TICK(4)
     // (v_accvgpr_read next to in-flight MFMAs costs ~25 cycles each, so the epilogue is NOT interleaved with stage 2)
 #define NB(P, T) load_b<P, T>(Bt[P], rsn, voff)
-#define NA(P, T) load_a<P, T>(At[P], nat0, rot0)
+#define NA(P, T) load_a<P, T>(At[P], nbase, rbase)
     S2(false, 0, swap_r<1>(hb, 0, 1), NONE, swap_r<1>(hb, 1, 2), NONE, swap_r<1>(hb, 2, 3), NONE, swap_r<1>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
     S2(false, 1, swap_r<2>(hb, 0, 1), NONE, swap_r<2>(hb, 1, 2), NONE, swap_r<2>(hb, 2, 3), NONE, swap_r<2>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
     S2(false, 2, swap_r<3>(hb, 0, 1), NONE, swap_r<3>(hb, 1, 2), NONE, swap_r<3>(hb, 2, 3), NONE, swap_r<3>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
     // first requests of the next group (what its frequencies "-2" and "-1" would have issued)
-    S2(false, 3, NB(0, B_REH), NB(0, B_IMH), NB(0, B_REL), NB(0, B_IML), NB(1, B_REH), NB(1, B_IMH), NB(1, B_REL),
-       NA(0, A_H), NA(0, A_RH), NA(0, A_L), (NA(0, A_RL), NA(1, A_H)), NA(1, A_RH))
+    S2(false, 3, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE)
     TICK(5)
 #define EPILOGUE(R)                                                                               \
-  { const int st_base = (lane < 32 && g * 16 + (lane & 15) < n) ? st_lane : (int)0x80000000;      \
+  { const int st_base = (le < 32 && g * 16 + (le & 15) < n) ? st_lane : (int)0x80000000;          \
     float mx = -__builtin_inff();                                                                 \
     _Pragma("unroll") for (int e = 0; e < 16; e++) ep_elem<R>(mx, accE, accO, e);                 \
     ep_store<R>(mx, rd, st_base + (R) * 4 * n + g * 64); }
-    EPILOGUE(0) EPILOGUE(1) EPILOGUE(2) EPILOGUE(3)
+    int le = lane;
+    asm volatile("" : "+v"(le));                   // the store addresses are recomputed per unit, not kept (or spilled) across it
+    const int st_lane = ((le & 16) ? 4 * n : 0) * 4 + (le & 15) * 4;
+    EPILOGUE(0)
+    nbase = nnxt - 16 * 2 * SCH_QBLK; rbase = rnxt - 16 * 2 * SCH_QBLK;   // 16 pair advances back: the image's first block
+    // first requests of the next group (what its frequencies "-2" and "-1" would have issued): behind the spill reloads of the
+    // epilogue's addresses - a reload behind them would wait for these L2 / HBM loads, vmcnt being in order
+    SB();
+    NB(0, B_REH); NB(0, B_IMH); NB(0, B_REL); NB(0, B_IML); NB(1, B_REH); NB(1, B_IMH); NB(1, B_REL);
+    NA(0, A_H); NA(0, A_RH); NA(0, A_L); NA(0, A_RL); NA(1, A_H); NA(1, A_RH);
+    SB();
+    EPILOGUE(1) EPILOGUE(2) EPILOGUE(3)
     TICK(6)
     rs = rsn;
   }

@@ -48,7 +48,7 @@ __device__ __forceinline__ void load_a(AOps& a, unsigned nat, unsigned rot) {
 }
 template <int P, int T>
 __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int voff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + T * SCH_DTILE, P * SCH_DFREQ, 0);   // tile offset folds into the instruction
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, P * SCH_DFREQ + T * SCH_DTILE, 0);   // frequency and tile in the scalar offset: ONE lane-offset register
   if (T == B_REH) b.reh = v; else if (T == B_REL) b.rel = v; else if (T == B_IMH) b.imh = v; else b.iml = v;
 }
 
@@ -202,9 +202,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_r_kernel(const char* __restri
   const int qrow0 = qg32 * 32 + wq * 8;
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
       dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 8 ? m - qrow0 : 8) : 0) * n * 4, 0x00020000);
-  const int st_lane = ((lane & 16) ? 4 * n : 0) * 4 + (lane & 15) * 4;
   const int pf_slot = (qg32 & 31) * 4 + w;                                  // 0..127
-  const int pf_off = (lane < 6) ? (pf_slot * 6 + lane) * 128 : (int)0x80000000;   // lines past the group are out of range
   unsigned pf_sink = 0;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(cst), 0, 16384, 0x00020000);
 
@@ -230,6 +228,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_r_kernel(const char* __restri
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev));
 #endif
+  unsigned nbase = nat0, rbase = rot0;       // carried through the running tile addresses: nothing address-like stays live (= spilled) across a unit
   for (int g = g0; g < g1; g += GS) {
     const __amdgpu_buffer_rsrc_t rsn =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g + GS) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
@@ -237,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_r_kernel(const char* __restri
     Qtr Sx[2];
     Cst Cx[2];
     f32x4 Fa, Ma, Fb, Mb, t1a, t2a, t1b, t2b;
-    unsigned ncur, rcur, nnxt = nat0, rnxt = rot0;
+    unsigned ncur, rcur, nnxt = nbase, rnxt = rbase;
     TICK(7)
 #define LDB(Q, T) { if ((Q) < SC_NF) load_b<((Q) < SC_NF ? (Q) : 0), T>(Bt[(Q) & 3], rs, voff); }
 #define LDA(P, Q, T) { if ((Q) < SC_NF) { if (((Q) >> 1) == ((P) >> 1)) load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], ncur, rcur); \
@@ -314,12 +313,16 @@ __global__ __launch_bounds__(256, 1) void sc_match_r_kernel(const char* __restri
       asm volatile("" : : "v"(pf_sink));
       const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
           const_cast<char*>(dbase + (size_t)(g + 2 * GS) * SCH_DIMG), 0, (g + 2 * GS < DG) ? SCH_DIMG : 0, 0x00020000);
+      int lp = lane;
+      asm volatile("" : "+v"(lp));                 // recomputed here, not kept (or spilled) across the unit
+      const int pf_off = (lp < 6) ? (pf_slot * 6 + lp) * 128 : (int)0x80000000;   // lines past the group are out of range
       pf_sink = __builtin_amdgcn_raw_buffer_load_b32(rp, pf_off, 0, 0);
     }
     SB();
+    nbase = nnxt - 16 * 2 * SCH_QBLK; rbase = rnxt - 16 * 2 * SCH_QBLK;   // 16 pair advances back: the image's first block
     // ---------------------------------------------------------------- tail: items 11..15, pack of pair 15, next unit's first requests
 #define NB(P, T) load_b<P, T>(Bt[P], rsn, voff)
-#define NA(P, T) load_a<P, T>(At[P], nat0, rot0)
+#define NA(P, T) load_a<P, T>(At[P], nbase, rbase)
     X(11, 0) PK(15, 0) X(11, 1) PK(15, 1) X(11, 2) PK(15, 2) X(11, 3) PK(15, 3)
     X(11, 4) SWP(12, 0, 2) X(11, 5) SWP(12, 2, 4) X(11, 6) X(11, 7)
     X(12, 0) SWP(13, 0, 1) X(12, 1) SWP(13, 1, 2) X(12, 2) SWP(13, 2, 3) X(12, 3) SWP(13, 3, 4) X(12, 4) X(12, 5) X(12, 6) X(12, 7)
@@ -331,10 +334,13 @@ __global__ __launch_bounds__(256, 1) void sc_match_r_kernel(const char* __restri
     SB();
     TICK(4)
 #define EPILOGUE(R)                                                                               \
-  { const int st_base = (lane < 32 && g * 16 + (lane & 15) < n) ? st_lane : (int)0x80000000;      \
+  { const int st_base = (le < 32 && g * 16 + (le & 15) < n) ? st_lane : (int)0x80000000;          \
     float mx = -__builtin_inff();                                                                 \
     _Pragma("unroll") for (int e = 0; e < 16; e++) ep_elem<R>(mx, accE, accO, e);                 \
     ep_store<R>(mx, rd, st_base + (R) * 4 * n + g * 64); }
+    int le = lane;
+    asm volatile("" : "+v"(le));                   // the store addresses are recomputed per unit, not kept (or spilled) across it
+    const int st_lane = ((le & 16) ? 4 * n : 0) * 4 + (le & 15) * 4;
     EPILOGUE(0) EPILOGUE(1) EPILOGUE(2) EPILOGUE(3)
     TICK(5)
     rs = rsn;
