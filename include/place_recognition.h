@@ -159,14 +159,19 @@ int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
  * [db_row0, db_row0 + n_local) or -1.  idx: DEVICE [m][k], score: DEVICE f64 [m][k].  k_in <= 128. */
 int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                   const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
-                  int32_t mask_width, double p_weight, int32_t k_in, const int32_t* idx_in, int32_t k, int32_t* idx, double* score);
-/* The sharded form of the re-evaluation (what makes its cost independent of the number of shards): the shards' fp32 top-(k+8) lists
+                  int32_t mask_width, double p_weight, int32_t k_in, const int32_t* idx_in, const double* score_in, int32_t k, int32_t* idx,
+                  double* score);
+/* score_in / cand_score (both forms; DEVICE f64 [m][k_in], may be NULL): the candidates' scores from the fp32 pass, ascending as
+ * pr_fuse_select_dev / pr_merge_topk_dev deliver them.  With them a candidate beyond the k-th whose fp32 score exceeds the k-th by more than
+ * 64 x the error bound of an fp32 score (from the row statistics) is not re-evaluated - it cannot enter the exact top-k; results are identical.
+ * The sharded form of the re-evaluation (what makes its cost independent of the number of shards): the shards' fp32 top-(k+8) lists
  * are merged FIRST (pr_merge_topk_dev on the gathered lists) into the global candidates cand_idx DEVICE [m][k_in]; every shard then
  * evaluates only the candidates inside its rows [db_row0, db_row0 + n_local) - part DEVICE f64 [m][k_in], NaN for the others -
  * and pr_rerank_finish_dev takes each candidate's score from its owner (part_all DEVICE [G][m][k_in]) and selects the k best. */
 int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                           const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
-                          int32_t mask_width, double p_weight, int32_t k_in, const int32_t* cand_idx, double* part);
+                          int32_t mask_width, double p_weight, int32_t k_in, const int32_t* cand_idx, const double* cand_score, int32_t k,
+                          double* part);
 int pr_rerank_finish_dev(pr_ctx* ctx, const int32_t* cand_idx, const double* part_all, int32_t G, int32_t m, int32_t k_in, int32_t k,
                          int32_t* idx, double* score);
 /* fp32 scores of pr_fuse_select_dev as doubles (the merge works on doubles): DEVICE score32 [count] -> score64 [count] */

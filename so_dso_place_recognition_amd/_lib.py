@@ -31,9 +31,9 @@ SYMBOLS = {
     "pr_match_topk_f64": (C.c_int, [_vp, C.c_int, _vp, _i32, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_match_topk_fused_f64": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_rerank_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _i32, _vp,
-                                _i32, _vp, _vp]),
+                                _vp, _i32, _vp, _vp]),
     "pr_rerank_partial_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _i32,
-                                        _vp, _vp]),
+                                        _vp, _vp, _i32, _vp]),
     "pr_rerank_finish_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pr_widen_scores_dev": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "pr_merge_topk_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),

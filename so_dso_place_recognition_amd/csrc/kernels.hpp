@@ -70,11 +70,11 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
                    double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
-                   float* score32);
+                   float* score32, const double* cand_sc32);   // cand_sc32: the candidates' fp32-pass scores (ascending) or null: prunes hopeless candidates
 // the sharded form: scores of the candidates THIS shard owns (NaN elsewhere), then owner-wise combination + selection
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                           double p_weight, int kin, const int32_t* idx_in, double* cand_score);
+                           double p_weight, int kin, const int32_t* idx_in, double* cand_score, const double* cand_sc32, int k);
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,
                           double* score);
 void launch_widen(hipStream_t st, const float* a, long long n, double* b);

@@ -624,7 +624,8 @@ int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
 
 int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                   const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
-                  int32_t mask_width, double p_weight, int32_t k_in, const int32_t* idx_in, int32_t k, int32_t* idx, double* score) {
+                  int32_t mask_width, double p_weight, int32_t k_in, const int32_t* idx_in, const double* score_in, int32_t k, int32_t* idx,
+                  double* score) {
   if (!ctx) return PR_EINVAL;
   const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
   if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !idx_in || !idx || !score ||
@@ -640,24 +641,25 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
     ctx->rr_cap = need;
   }
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
-                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr);
+                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
 
 int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                           const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
-                          int32_t mask_width, double p_weight, int32_t k_in, const int32_t* cand_idx, double* part) {
+                          int32_t mask_width, double p_weight, int32_t k_in, const int32_t* cand_idx, const double* cand_score, int32_t k,
+                          double* part) {
   if (!ctx) return PR_EINVAL;
   const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
   if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !cand_idx || !part ||
-      m < 0 || n_local < 1 || G < 1 || k_in < 1 || k_in > 128 ||
+      m < 0 || n_local < 1 || G < 1 || k_in < 1 || k_in > 128 || k < 1 || k > k_in ||
       (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
     PR_FAIL(ctx, PR_EINVAL, "pr_rerank_partial_dev: bad arguments (m=%d, n_local=%d, G=%d, k_in=%d)", m, n_local, G, k_in);
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   pr::launch_rerank_partial(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0,
-                            mask_width, p_weight, k_in, cand_idx, part);
+                            mask_width, p_weight, k_in, cand_idx, part, cand_score, k);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -750,9 +752,12 @@ static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, con
         break;
       }
       const bool sc = type == PR_TYPE_SC;
+      DevBuf dsw;   // the fp32-pass scores as doubles: the re-evaluation skips candidates that cannot reach the top-k
+      if (dsw.alloc((size_t)m * kin * 8) != hipSuccess) { ctx->err = "out of device memory"; rc = PR_ENOMEM; break; }
+      if ((rc = pr_widen_scores_dev(ctx, dsc.as<float>(), (int64_t)m * kin, dsw.as<double>()))) break;
       if ((rc = pr_rerank_dev(ctx, sc ? raw1.p : nullptr, sc ? raw2.p : nullptr, PR_F64, sc ? nullptr : raw1.p, sc ? nullptr : raw2.p, PR_F64,
                               sc ? mom.as<double>() : nullptr, sc ? nullptr : mom.as<double>(), m, n, 1, 0, 0, mask_width, p_weight, kin,
-                              didx.as<int32_t>(), k, dcand.as<int32_t>(), dsc64.as<double>()))) break;
+                              didx.as<int32_t>(), dsw.as<double>(), k, dcand.as<int32_t>(), dsc64.as<double>()))) break;
       std::vector<double> t64;
       if (score32) t64.resize((size_t)m * k);
       if (hipMemcpyAsync(idx, dcand.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
@@ -818,7 +823,7 @@ static int fused_host(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   pr_sigset* ss[4] = {nullptr, nullptr, nullptr, nullptr};   // SC query, SC db, M2DP query, M2DP db
-  DevBuf raw[4], d[4], mom[2], didx, dsc, dcand, dsc64;
+  DevBuf raw[4], d[4], mom[2], didx, dsc, dcand, dsc64, dsw;
   const void* host[4] = {sc1, sc2, m2dp1, m2dp2};
   const size_t bytes[4] = {(size_t)m * 2400 * 8, (size_t)n * 2400 * 8, (size_t)m * 4 * 384 * 8, (size_t)n * 4 * 384 * 8};
   const int kin = rerank_width(k);
@@ -837,7 +842,7 @@ static int fused_host(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32
     for (auto& b : d) ok = ok && b.alloc(mn * 4) == hipSuccess;
     ok = ok && mom[0].alloc((size_t)m * 6 * 8) == hipSuccess && mom[1].alloc((size_t)m * 6 * 8) == hipSuccess &&
          didx.alloc((size_t)m * kin * 4) == hipSuccess && dsc.alloc((size_t)m * kin * 4) == hipSuccess &&
-         dcand.alloc((size_t)m * k * 4) == hipSuccess && dsc64.alloc((size_t)m * k * 8) == hipSuccess;
+         dcand.alloc((size_t)m * k * 4) == hipSuccess && dsc64.alloc((size_t)m * k * 8) == hipSuccess && dsw.alloc((size_t)m * kin * 8) == hipSuccess;
     if (!ok) { ctx->err = "out of device memory for the four m x n distance matrices"; rc = PR_ENOMEM; break; }
     if ((rc = pr_distances_dev(ctx, ss[0], ss[1], d[0].as<float>(), d[1].as<float>())) ||
         (rc = pr_distances_dev(ctx, ss[2], ss[3], d[2].as<float>(), d[3].as<float>())) ||
@@ -845,8 +850,9 @@ static int fused_host(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32
         (rc = pr_row_moments_dev(ctx, d[2].as<float>(), d[3].as<float>(), m, n, mom[1].as<double>())) ||
         (rc = pr_fuse_select2_dev(ctx, d[0].as<float>(), d[1].as<float>(), d[2].as<float>(), d[3].as<float>(), m, n, mom[0].as<double>(),
                                   mom[1].as<double>(), 1, 0, 0, mask_width, p_weight, kin, didx.as<int32_t>(), dsc.as<float>())) ||
+        (rc = pr_widen_scores_dev(ctx, dsc.as<float>(), (int64_t)m * kin, dsw.as<double>())) ||
         (rc = pr_rerank_dev(ctx, raw[0].p, raw[1].p, PR_F64, raw[2].p, raw[3].p, PR_F64, mom[0].as<double>(), mom[1].as<double>(), m, n, 1,
-                            0, 0, mask_width, p_weight, kin, didx.as<int32_t>(), k, dcand.as<int32_t>(), dsc64.as<double>()))) break;
+                            0, 0, mask_width, p_weight, kin, didx.as<int32_t>(), dsw.as<double>(), k, dcand.as<int32_t>(), dsc64.as<double>()))) break;
     std::vector<double> t64;
     if (score32) t64.resize((size_t)m * k);
     if (hipMemcpyAsync(idx, dcand.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||

@@ -309,10 +309,10 @@ int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_w
   // 3. fp64 re-evaluation of the candidates each shard owns
   for (auto& sh : g->s) {
     G_HIP(g, hipSetDevice(sh.device));
-    G_PR(g, sh, pr_merge_topk_dev(sh.ctx, sh.idx_all, sh.score_all, G, m, kin, sh.cand, sh.dump /*the merged fp32 scores are not used; sc64 may still be read by the other shards' copies*/));
+    G_PR(g, sh, pr_merge_topk_dev(sh.ctx, sh.idx_all, sh.score_all, G, m, kin, sh.cand, sh.dump /*the merged fp32 scores, in a buffer of their own: sc64 may still be read by the other shards' copies*/));
     G_PR(g, sh, pr_rerank_partial_dev(sh.ctx, sc ? sh.raw_q : nullptr, sc ? sh.raw_db : nullptr, PR_F64, sc ? nullptr : sh.raw_q,
                                       sc ? nullptr : sh.raw_db, PR_F64, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, m, sh.rows, G, 0,
-                                      sh.row0, mask_width, p_weight, kin, sh.cand, sh.part));
+                                      sh.row0, mask_width, p_weight, kin, sh.cand, sh.dump, k, sh.part));
   }
   // C. partial scores of every shard on every device; device 0 finishes
   for (int r = 0; r < G; r++) { src[r] = g->s[r].part; dst[r] = g->s[r].score_all; }

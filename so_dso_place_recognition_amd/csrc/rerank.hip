@@ -167,9 +167,10 @@ struct RerankArgs {
   const double* mom_sc; const double* mom_m2;                   // [G][m][2][3] moments of all shards per descriptor type
   int m, n_local, G, q_row0, db_row0, mask_width, kin;
   double p_weight;
+  const double* cand_sc; int k;                                 // fp32-pass scores of the candidates [m][kin], ascending, or null; the k wanted
 };
 
-__device__ void chan_combine(const double* mom_all, int G, int m, int q, int ch, double& mean, double& sd) {
+__device__ void chan_combine(const double* mom_all, int G, int m, int q, int ch, double& mean, double& sd, double* count = nullptr) {
   double cn = 0.0, mu = 0.0, m2 = 0.0;
   for (int g = 0; g < G; g++) {                                 // rank order, as fuse_select_kernel
     const double* o = mom_all + (((size_t)g * m + q) * 2 + ch) * 3;
@@ -182,6 +183,7 @@ __device__ void chan_combine(const double* mom_all, int G, int m, int q, int ch,
   }
   mean = mu;
   sd = sqrt(m2 / (cn - 1.0));
+  if (count) *count = cn;
 }
 
 __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t* __restrict__ idx_in,
@@ -197,6 +199,21 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
   if (dij < A.mask_width) { if (tid == 0) *out = __builtin_inf(); return; }   // run_test.m:47-53
   const int jl = jg - A.db_row0;
   if (jl < 0 || jl >= A.n_local) { if (tid == 0) *out = __builtin_nan(""); return; }   // another shard's row: its owner evaluates it
+  if (A.cand_sc && t >= A.k) {
+    // Candidates beyond the k-th of the fp32 pass whose fp32 score is above the k-th by more than 64 x the error bound of an fp32
+    // score cannot enter the exact top-k: they keep their fp32 score (it only has to sort behind the evaluated ones).  Bound of
+    // |fp32 score - exact score| given the row statistics: distance error 1e-6 per channel over its sigma,
+    // amplified by 1 + s^2 / (n - 1) through the statistics, + the rounding of the score itself.
+    const double sk = A.cand_sc[(size_t)q * A.kin + A.k - 1], st = A.cand_sc[(size_t)q * A.kin + t];
+    double w = 0.0, cn = 2.0;
+    for (int ch = 0; ch < 2; ch++) {
+      double mean, sd;
+      if (A.q_sc) { chan_combine(A.mom_sc, A.G, A.m, q, ch, mean, sd, &cn); w += (ch == 0 ? A.p_weight : 1.0) / sd; }
+      if (A.q_m2) { chan_combine(A.mom_m2, A.G, A.m, q, ch, mean, sd, &cn); w += (ch == 0 ? A.p_weight : 1.0) / sd; }
+    }
+    const double delta = 64.0 * (1e-6 * w * (1.0 + sk * sk / fmax(cn - 1.0, 1.0)) + 1e-6 * fabs(sk) + 1e-5);
+    if (st > sk + delta) { if (tid == 0) *out = st; return; }   // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
+  }
   double f = 0.0;
   if (A.q_sc) {
     for (int ch = 0; ch < 2; ch++) {
@@ -306,18 +323,18 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
                    double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
-                   float* score32) {
+                   float* score32, const double* cand_sc32) {
   if (m <= 0) return;
-  RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight};
+  RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k};
   hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
   hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
 }
 
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                           double p_weight, int kin, const int32_t* idx_in, double* cand_score) {
+                           double p_weight, int kin, const int32_t* idx_in, double* cand_score, const double* cand_sc32, int k) {
   if (m <= 0) return;
-  RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight};
+  RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k};
   hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
 }
 

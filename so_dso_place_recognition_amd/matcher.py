@@ -160,24 +160,26 @@ class Matcher(_Base):
         none = (None, None, 0)
         return (*(raw if sc else none), *(none if sc else raw), _dptr(self._mom_all) if sc else None, None if sc else _dptr(self._mom_all))
 
-    def local_rerank(self, cand_idx: torch.Tensor, k: int, partial: bool):
+    def local_rerank(self, cand_idx: torch.Tensor, k: int, partial: bool, cand_sc: torch.Tensor = None):
         """fp64 re-evaluation of the candidates [m,kin]: partial=False -> (idx [m,k], score [m,k]) (all candidates are this
-        shard's: the one-rank path); partial=True -> scores [m,kin], NaN for candidates outside this shard."""
+        shard's: the one-rank path); partial=True -> scores [m,kin], NaN for candidates outside this shard.  cand_sc: the
+        candidates' fp32-pass scores as f64 [m,kin] (ascending) - candidates that cannot reach the top-k are then not evaluated."""
         m, n = self._m, self.n
         G, q_row0, db_row0, mask_width, p_weight = self._args
         kin = cand_idx.shape[1]
         cand_idx = cand_idx.contiguous()
+        csc = None if cand_sc is None else _dptr(cand_sc.contiguous())
         self._enter()
         if partial:
             part = self._buf("part", (m, kin), torch.float64)
             self.ctx.check(self.lib.pr_rerank_partial_dev(self.ctx.h, *self._raw_args(), m, n, G, q_row0, db_row0, mask_width, p_weight, kin,
-                                                          _dptr(cand_idx), _dptr(part)))
+                                                          _dptr(cand_idx), csc, int(k), _dptr(part)))
             self._leave()
             return part
         idx = self._buf("idx", (m, k), torch.int32)
         score = self._buf("score", (m, k), torch.float64)
         self.ctx.check(self.lib.pr_rerank_dev(self.ctx.h, *self._raw_args(), m, n, G, q_row0, db_row0, mask_width, p_weight, kin,
-                                              _dptr(cand_idx), int(k), _dptr(idx), _dptr(score)))
+                                              _dptr(cand_idx), csc, int(k), _dptr(idx), _dptr(score)))
         self._leave()
         return idx, score
 
@@ -189,7 +191,7 @@ class Matcher(_Base):
         idx_in, sc = self.local_select(mom_all, G, mask_width, p_weight, k, db_row0, q_row0)
         if self.plain:
             return idx_in, sc
-        return self.local_rerank(idx_in, k, partial=False)
+        return self.local_rerank(idx_in, k, partial=False, cand_sc=sc)
 
     def merge(self, idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
         return _merge_dev(self, idx_all, sc_all, k)
@@ -297,23 +299,24 @@ class FusedMatcher(_Base):
         self._leave()
         return idx_in, sc32.to(torch.float64)
 
-    def local_rerank(self, cand_idx, k, partial):
+    def local_rerank(self, cand_idx, k, partial, cand_sc=None):
         m, n = self.sc._m, self.sc.n
         G, q_row0, db_row0, mask_width, p_weight = self._args
         kin = cand_idx.shape[1]
         cand_idx = cand_idx.contiguous()
         raw = (_dptr(self.sc._q_sig), _dptr(self.sc.db_sig), _torch_dt(self.sc.db_sig), _dptr(self.m2._q_sig), _dptr(self.m2.db_sig),
                _torch_dt(self.m2.db_sig), _dptr(self._m1), _dptr(self._m2))
+        csc = None if cand_sc is None else _dptr(cand_sc.contiguous())
         self._enter()
         if partial:
             part = self._buf("part", (m, kin), torch.float64)
             self.ctx.check(self.lib.pr_rerank_partial_dev(self.ctx.h, *raw, m, n, G, q_row0, db_row0, mask_width, p_weight, kin, _dptr(cand_idx),
-                                                          _dptr(part)))
+                                                          csc, int(k), _dptr(part)))
             self._leave()
             return part
         idx = self._buf("idx", (m, k), torch.int32)
         score = self._buf("score", (m, k), torch.float64)
-        self.ctx.check(self.lib.pr_rerank_dev(self.ctx.h, *raw, m, n, G, q_row0, db_row0, mask_width, p_weight, kin, _dptr(cand_idx), int(k),
+        self.ctx.check(self.lib.pr_rerank_dev(self.ctx.h, *raw, m, n, G, q_row0, db_row0, mask_width, p_weight, kin, _dptr(cand_idx), csc, int(k),
                                               _dptr(idx), _dptr(score)))
         self._leave()
         return idx, score
@@ -322,8 +325,8 @@ class FusedMatcher(_Base):
         return _finish_dev(self, cand_idx, part_all, k)
 
     def local_phase2(self, mom_all, G, mask_width, p_weight, k, db_row0, q_row0):
-        idx_in, _ = self.local_select(mom_all, G, mask_width, p_weight, k, db_row0, q_row0)
-        return self.local_rerank(idx_in, k, partial=False)
+        idx_in, sc = self.local_select(mom_all, G, mask_width, p_weight, k, db_row0, q_row0)
+        return self.local_rerank(idx_in, k, partial=False, cand_sc=sc)
 
     def merge(self, idx_all, sc_all, k):
         return _merge_dev(self, idx_all, sc_all, k)
@@ -373,7 +376,7 @@ def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None,
     mom = local_moments()
     if G == 1 and not force_exchange:
         idx_in, sc = local_select(mom.unsqueeze(0) if mom.dim() == 3 else mom, 1)
-        return rerank(idx_in, k, False) if rerank is not None else (idx_in, sc)
+        return rerank(idx_in, k, False, sc) if rerank is not None else (idx_in, sc)
     stage_on_host = dist.get_backend(group) == "gloo"   # gloo has no device all_gather: used by the single-GPU tests
 
     def gather(t):   # output = the ranks' tensors concatenated along dim 0, viewed as [G, ...]
@@ -391,8 +394,8 @@ def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None,
     do_merge = merge if (merge is not None and idx_all.is_cuda) else merge_topk
     if rerank is None:                                   # nothing to re-evaluate (numpy stand-ins of the gloo tests, DELIGHT)
         return do_merge(idx_all, sc_all, k)
-    cand_idx, _ = do_merge(idx_all, sc_all, kin)         # the global top-(k+8) of the fp32 pass, identical on every rank
-    part_all = gather(rerank(cand_idx, k, True))
+    cand_idx, cand_sc = do_merge(idx_all, sc_all, kin)   # the global top-(k+8) of the fp32 pass, identical on every rank
+    part_all = gather(rerank(cand_idx, k, True, cand_sc))
     return finish(cand_idx, part_all, k)
 
 

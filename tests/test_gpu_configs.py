@@ -249,6 +249,43 @@ def test_near_ties_are_ordered_by_the_fp64_reevaluation(api):
         mt.close()
 
 
+def test_pruned_reevaluation_gives_the_unpruned_result(api):
+    """pr_rerank_dev with the candidates' fp32 scores skips candidates that cannot reach the top-k (include/place_recognition.h): the
+    result must be bit for bit the one without them - planted matches (eight of nine candidates hopeless), plain random rows
+    (candidates ~0.05 apart) and families of near-copies (all candidates inside the margin, nothing may be skipped)."""
+    from so_dso_place_recognition_amd.matcher import Matcher
+    n, m = 3000, 96
+    db = synth.sc_database(45, n)
+    q, planted = synth.sc_queries(46, db, m)
+    rng = np.random.default_rng(3)
+    q[m // 3: 2 * m // 3] = synth.sc_database(77, m // 3)              # a third of the queries have no planted match
+    for t in range(2 * m // 3, m):                                     # a third have twelve near-copies of their match in the DB
+        for c in range(12):
+            e = db[planted[t]].copy()
+            occ = np.nonzero(e[:1200] > 0)[0]
+            e[rng.choice(occ, size=30, replace=False)] *= 1.0 + 1e-6 * rng.standard_normal(30)
+            db[n - 1 - ((t - 2 * m // 3) * 12 + c)] = e               # disjoint slots at the end of the DB
+    mt = Matcher("sc", m, n)
+    mt.pack_database(torch.from_numpy(db).cuda())
+    for k in (1, 3):
+        mom = mt.local_phase1(torch.from_numpy(q).cuda())
+        idx_in, sc = mt.local_select(mom.unsqueeze(0), 1, 0, 2.0, k, 0, 0)
+        a = tuple(x.clone() for x in mt.local_rerank(idx_in, k, False))
+        b = tuple(x.clone() for x in mt.local_rerank(idx_in, k, False, sc))
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+        pa = mt.local_rerank(idx_in, k, True).clone()
+        pb = mt.local_rerank(idx_in, k, True, sc).clone()
+        skipped = (pa != pb).sum().item()
+        assert skipped > m * 4                                          # it does skip: most candidates of the planted rows
+        assert torch.equal(pa[:, :k], pb[:, :k])
+        near = torch.arange(2 * m // 3, m, device="cuda")
+        near = near[sc[near, k + 7] - sc[near, 0] < 1e-3]               # rows whose candidates are all copies of the match (a few lost theirs to the copy slots)
+        assert len(near) > m // 6 and torch.equal(pa[near], pb[near])   # everything inside the margin is evaluated
+    # (no oracle here: families of 13 near-copies are more near-ties than the k + 8 candidates of the fp32 pass can hold; what this test
+    #  pins is pruned == unpruned - the oracle comparisons of the near-tie and full-size tests run through the pruned path anyway)
+    mt.close()
+
+
 # ------------------------------------------------------------------------------------------------ a drive
 def _drive(frames=2000, per_cloud=6000, seed=5):
     """Two laps of a closed circuit through a static world: consecutive clouds overlap almost completely, frame i and
