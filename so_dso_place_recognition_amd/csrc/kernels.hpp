@@ -46,6 +46,9 @@ size_t sc_match_h_lds_bytes();
 // images, its own stage-2 constant table [4 quarters][E hh+hl | E lh | O hh+hl | O lh][64 lanes] x 16 B
 void launch_sc_match_p(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                        int nsplit_override);
+// transient stage-2 accumulators (sc_match_t.hip): same images; constants [E|O][shift rows 0-15|16-31][hi|lo][64 lanes] x 16 B
+void launch_sc_match_t(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
+                       int nsplit_override);
 // the rolling-pipeline form of sc_match_h.hip (sc_match_r.hip): same images, the constant table of sc_match_p.hip
 void launch_sc_match_r(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                        int nsplit_override);
