@@ -96,18 +96,25 @@ __device__ __forceinline__ void transpose4(unsigned& z0, unsigned& z1, unsigned&
   swap32(z0, z2); swap32(z1, z3);
   swap16(z0, z1); swap16(z2, z3);
 }
+// the packed values of one step (four pairs) before their transpose: [forward | mirror][register r][octet]
+struct Step { unsigned h[2][4][4], l[2][4][4]; };
 template <int X, int R>
-__device__ __forceinline__ void transpose_xr(Packed& p, int j) {
-  unsigned a = p.h[X][R][0][j], b = p.h[X][R][1][j], c = p.h[X][R][2][j], d = p.h[X][R][3][j];
-  transpose4(a, b, c, d);
-  p.h[X][R][0][j] = a; p.h[X][R][1][j] = b; p.h[X][R][2][j] = c; p.h[X][R][3][j] = d;
-  a = p.l[X][R][0][j]; b = p.l[X][R][1][j]; c = p.l[X][R][2][j]; d = p.l[X][R][3][j];
-  transpose4(a, b, c, d);
-  p.l[X][R][0][j] = a; p.l[X][R][1][j] = b; p.l[X][R][2][j] = c; p.l[X][R][3][j] = d;
+__device__ __forceinline__ void transpose_xr(Packed& p, Step& z, int j) {
+  transpose4(z.h[X][R][0], z.h[X][R][1], z.h[X][R][2], z.h[X][R][3]);
+  p.h[X][R][0][j] = z.h[X][R][0]; p.h[X][R][1][j] = z.h[X][R][1]; p.h[X][R][2][j] = z.h[X][R][2]; p.h[X][R][3][j] = z.h[X][R][3];
+  transpose4(z.l[X][R][0], z.l[X][R][1], z.l[X][R][2], z.l[X][R][3]);
+  p.l[X][R][0][j] = z.l[X][R][0]; p.l[X][R][1][j] = z.l[X][R][1]; p.l[X][R][2][j] = z.l[X][R][2]; p.l[X][R][3][j] = z.l[X][R][3];
 }
 
-__device__ __forceinline__ f32x4 mfma16i(const u32x4& a, const u32x4& b, const f32x4& c) {
-  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+// stage-2 MFMA: constants in ArchVGPRs, the packed B operand in AccVGPRs (the constraint pins the finished operands there: hipcc would
+// otherwise shuttle them between the register files), result tile in ArchVGPRs
+__device__ __forceinline__ f32x4 mfma16z(const u32x4& a, const u32x4& b) {
+  f32x4 d;
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+  return d;
+}
+__device__ __forceinline__ void mfma16a(f32x4& d, const u32x4& a, const u32x4& b) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
 }
 
 // A operands of stage 2: [E | O][shift rows 0..15 | 16..31][hi | lo] tiles, lane = 16 (K group) + row
@@ -116,16 +123,16 @@ struct CstT { u32x4 t[2][2][2]; };
 // stage 2 + epilogue of (forward | mirror) X, stage-1 register R, query half H (rows q = 4 H + R): max over the 32 shift rows of E + |O|
 template <int X, int R, int H>
 __device__ __forceinline__ float stage2_tile(const Packed& p, const CstT& c) {
-  const f32x4 z = {0.f, 0.f, 0.f, 0.f};
   float mx = -__builtin_inff();
 #pragma unroll
   for (int part = 0; part < 2; part++) {
-    f32x4 e = mfma16i(c.t[0][part][0], p.h[X][R][H], z);
-    f32x4 o = mfma16i(c.t[1][part][0], p.h[X][R][H + 2], z);
-    e = mfma16i(c.t[0][part][0], p.l[X][R][H], e);
-    o = mfma16i(c.t[1][part][0], p.l[X][R][H + 2], o);
-    e = mfma16i(c.t[0][part][1], p.h[X][R][H], e);
-    o = mfma16i(c.t[1][part][1], p.h[X][R][H + 2], o);
+    f32x4 e = mfma16z(c.t[0][part][0], p.h[X][R][H]);
+    f32x4 o = mfma16z(c.t[1][part][0], p.h[X][R][H + 2]);
+    mfma16a(e, c.t[0][part][0], p.l[X][R][H]);
+    mfma16a(o, c.t[1][part][0], p.l[X][R][H + 2]);
+    mfma16a(e, c.t[0][part][1], p.h[X][R][H]);
+    mfma16a(o, c.t[1][part][1], p.h[X][R][H + 2]);
+    asm volatile("s_nop 9");                       // the tiles are read by VALU next: asm MFMAs are not padded
 #pragma unroll
     for (int i = 0; i < 4; i += 2) mx = fmaxf(fmaxf(mx, e[i] + __builtin_fabsf(o[i])), e[i + 1] + __builtin_fabsf(o[i + 1]));
   }
@@ -200,6 +207,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
     const __amdgpu_buffer_rsrc_t rsn =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g + 1) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
     Packed pk;
+    Step zs;
     f32x4 Fa, Ma, Fb, Mb, t1a, t2a, t1b, t2b;
     unsigned ncur, rcur, nnxt = nat0 + QOFF(0), rnxt = rot0 + QOFF(0);
 // request tile T of sequence index Q (Q >= 31: nothing)
@@ -217,8 +225,8 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
     SB();                                                                                         \
   }
 // pair P (sequence indices 2P, 2P+1): step j = P >> 2 (register j), octet o = P & 3 (block o until the transpose)
-#define PKF(P, R) { unsigned _h, _l; split2(Fa[R], Fb[R], _h, _l); pk.h[0][R][(P) & 3][(P) >> 2] = _h; pk.l[0][R][(P) & 3][(P) >> 2] = _l; }
-#define PKM(P, R) { unsigned _h, _l; split2(Ma[R], Mb[R], _h, _l); pk.h[1][R][(P) & 3][(P) >> 2] = _h; pk.l[1][R][(P) & 3][(P) >> 2] = _l; }
+#define PKF(P, R) { split2(Fa[R], Fb[R], zs.h[0][R][(P) & 3], zs.l[0][R][(P) & 3]); }
+#define PKM(P, R) { split2(Ma[R], Mb[R], zs.h[1][R][(P) & 3], zs.l[1][R][(P) & 3]); }
 #define NONE ((void)0)
 // LDS bases of this lane's tiles: current pair and next pair P + 1 (its block offset is a constant of the sequence)
 #define ADV(P) { ncur = nnxt; rcur = rnxt; nnxt = nat0 + QOFF(2 * (P) + 2 < 32 ? 2 * (P) + 2 : 0); rnxt = rot0 + QOFF(2 * (P) + 2 < 32 ? 2 * (P) + 2 : 0); \
@@ -233,8 +241,8 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
   FREQ(2 * (P), t1a, t2a, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PKF((P) - 1, 0), PKM((P) - 1, 0), PKF((P) - 1, 1)) \
   FREQ(2 * (P) + 1, t1b, t2b, PKM((P) - 1, 1), PKF((P) - 1, 2), PKM((P) - 1, 2), PKF((P) - 1, 3), PKM((P) - 1, 3), FMA_ALL(Fa, Ma, t1a, t2a))
 // the transposes of step J (pairs 4J..4J+3 packed): 64 swaps
-#define TRANSPOSE(J) { SB(); transpose_xr<0, 0>(pk, J); transpose_xr<0, 1>(pk, J); transpose_xr<0, 2>(pk, J); transpose_xr<0, 3>(pk, J); \
-                       transpose_xr<1, 0>(pk, J); transpose_xr<1, 1>(pk, J); transpose_xr<1, 2>(pk, J); transpose_xr<1, 3>(pk, J); SB(); }
+#define TRANSPOSE(J) { SB(); transpose_xr<0, 0>(pk, zs, J); transpose_xr<0, 1>(pk, zs, J); transpose_xr<0, 2>(pk, zs, J); transpose_xr<0, 3>(pk, zs, J); \
+                       transpose_xr<1, 0>(pk, zs, J); transpose_xr<1, 1>(pk, zs, J); transpose_xr<1, 2>(pk, zs, J); transpose_xr<1, 3>(pk, zs, J); SB(); }
 
     PAIR0() PAIR(1) PAIR(2) PAIR(3)
     PAIR(4) TRANSPOSE(0) PAIR(5) PAIR(6) PAIR(7)
