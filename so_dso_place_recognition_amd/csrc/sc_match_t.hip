@@ -11,6 +11,9 @@
 // transpose has its four partners after every four pairs.
 #include "kernels.hpp"
 
+#ifndef T_PARTS
+#define T_PARTS 2
+#endif
 namespace pr {
 namespace {
 
@@ -51,8 +54,8 @@ __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int v
 // MFMAs + their fillers behind the last write, except the one after DRAIN().
 // (s_nop 1 in front: in this kernel hipcc parks stage-1 operands in AccVGPRs and may restore one right before the asm statement, which it
 //  does not pad - tools/audit_asm_hazards.py)
-#define MF0(d, a, b) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b))
-#define MFA(d, a, b) asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b))
+#define MF0(d, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b))
+#define MFA(d, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b))
 #define DRAIN() asm volatile("s_nop 9")
 #define SB() __builtin_amdgcn_sched_barrier(0)
 #ifdef PR_SCH_TIMING
@@ -108,10 +111,8 @@ __device__ __forceinline__ void transpose_xr(Packed& p, Step& z, int j) {
 
 // stage-2 MFMA: constants in ArchVGPRs, the packed B operand in AccVGPRs (the constraint pins the finished operands there: hipcc would
 // otherwise shuttle them between the register files), result tile in ArchVGPRs
-__device__ __forceinline__ f32x4 mfma16z(const u32x4& a, const u32x4& b) {
-  f32x4 d;
+__device__ __forceinline__ void mfma16z(f32x4& d, const u32x4& a, const u32x4& b) {
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
-  return d;
 }
 __device__ __forceinline__ void mfma16a(f32x4& d, const u32x4& a, const u32x4& b) {
   asm volatile("s_nop 1\n\tv_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
@@ -120,22 +121,28 @@ __device__ __forceinline__ void mfma16a(f32x4& d, const u32x4& a, const u32x4& b
 // A operands of stage 2: [E | O][shift rows 0..15 | 16..31][hi | lo] tiles, lane = 16 (K group) + row
 struct CstT { u32x4 t[2][2][2]; };
 
-// stage 2 + epilogue of (forward | mirror) X, stage-1 register R, query half H (rows q = 4 H + R): max over the 32 shift rows of E + |O|
-template <int X, int R, int H>
-__device__ __forceinline__ float stage2_tile(const Packed& p, const CstT& c) {
-  float mx = -__builtin_inff();
+// stage-2 group k = (R * 2 + H) * 2 + X: the four (16 shift rows x 16 pairs) tiles E / O x shift rows 0-15 / 16-31 of (forward | mirror) X,
+// stage-1 register R, query half H (rows q = 4 H + R): twelve MFMAs (three split products per tile); every B operand serves both row blocks
+struct Tiles { f32x4 e0, o0, e1, o1; };
+template <int K>
+__device__ __forceinline__ void s2_issue(const Packed& p, const CstT& c, Tiles& t) {
+  constexpr int X = K & 1, H = (K >> 1) & 1, R = K >> 2;
+  mfma16z(t.e0, c.t[0][0][0], p.h[X][R][H]);
+  mfma16z(t.e1, c.t[0][1][0], p.h[X][R][H]);
+  mfma16z(t.o0, c.t[1][0][0], p.h[X][R][H + 2]);
+  mfma16z(t.o1, c.t[1][1][0], p.h[X][R][H + 2]);
+  mfma16a(t.e0, c.t[0][0][1], p.h[X][R][H]);
+  mfma16a(t.e1, c.t[0][1][1], p.h[X][R][H]);
+  mfma16a(t.o0, c.t[1][0][1], p.h[X][R][H + 2]);
+  mfma16a(t.o1, c.t[1][1][1], p.h[X][R][H + 2]);
+  mfma16a(t.e0, c.t[0][0][0], p.l[X][R][H]);
+  mfma16a(t.e1, c.t[0][1][0], p.l[X][R][H]);
+  mfma16a(t.o0, c.t[1][0][0], p.l[X][R][H + 2]);
+  mfma16a(t.o1, c.t[1][1][0], p.l[X][R][H + 2]);
+}
+__device__ __forceinline__ float s2_reduce(float mx, const Tiles& t) {
 #pragma unroll
-  for (int part = 0; part < 2; part++) {
-    f32x4 e = mfma16z(c.t[0][part][0], p.h[X][R][H]);
-    f32x4 o = mfma16z(c.t[1][part][0], p.h[X][R][H + 2]);
-    mfma16a(e, c.t[0][part][0], p.l[X][R][H]);
-    mfma16a(o, c.t[1][part][0], p.l[X][R][H + 2]);
-    mfma16a(e, c.t[0][part][1], p.h[X][R][H]);
-    mfma16a(o, c.t[1][part][1], p.h[X][R][H + 2]);
-    asm volatile("s_nop 9");                       // the tiles are read by VALU next: asm MFMAs are not padded
-#pragma unroll
-    for (int i = 0; i < 4; i += 2) mx = fmaxf(fmaxf(mx, e[i] + __builtin_fabsf(o[i])), e[i + 1] + __builtin_fabsf(o[i + 1]));
-  }
+  for (int i = 0; i < 4; i++) mx = fmaxf(fmaxf(mx, t.e0[i] + __builtin_fabsf(t.o0[i])), t.e1[i] + __builtin_fabsf(t.o1[i]));
   return mx;
 }
 
@@ -181,6 +188,8 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
   const int qrow0 = qg32 * 32 + w * 8;
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
       dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 8 ? m - qrow0 : 8) : 0) * n * 4, 0x00020000);
+  const int pf_slot = (qg32 & 31) * 4 + w;                                  // 0..127
+  unsigned pf_sink = 0;
   CstT c;                                               // the stage-2 constants stay in registers for the whole kernel
 #pragma unroll
   for (int eo = 0; eo < 2; eo++)
@@ -240,14 +249,23 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
   ADV(P)                                                                                          \
   FREQ(2 * (P), t1a, t2a, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PKF((P) - 1, 0), PKM((P) - 1, 0), PKF((P) - 1, 1)) \
   FREQ(2 * (P) + 1, t1b, t2b, PKM((P) - 1, 1), PKF((P) - 1, 2), PKM((P) - 1, 2), PKF((P) - 1, 3), PKM((P) - 1, 3), FMA_ALL(Fa, Ma, t1a, t2a))
+// the pair that packs the LAST pair of step J = ((P) - 1) >> 2 also transposes the step, register by register, right behind the packs
+#define TX(X, R, J) transpose_xr<X, R>(pk, zs, J)
+#define PAIRT(P)                                                                                  \
+  ADV(P)                                                                                          \
+  FREQ(2 * (P), t1a, t2a, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PKF((P) - 1, 0),                                   \
+       { PKM((P) - 1, 0); TX(0, 0, ((P) - 1) >> 2); }, { PKF((P) - 1, 1); TX(1, 0, ((P) - 1) >> 2); })                                   \
+  FREQ(2 * (P) + 1, t1b, t2b, { PKM((P) - 1, 1); TX(0, 1, ((P) - 1) >> 2); }, { PKF((P) - 1, 2); TX(1, 1, ((P) - 1) >> 2); },           \
+       { PKM((P) - 1, 2); TX(0, 2, ((P) - 1) >> 2); }, { PKF((P) - 1, 3); TX(1, 2, ((P) - 1) >> 2); },                                   \
+       { PKM((P) - 1, 3); TX(0, 3, ((P) - 1) >> 2); }, { FMA_ALL(Fa, Ma, t1a, t2a); TX(1, 3, ((P) - 1) >> 2); })
 // the transposes of step J (pairs 4J..4J+3 packed): 64 swaps
 #define TRANSPOSE(J) { SB(); transpose_xr<0, 0>(pk, zs, J); transpose_xr<0, 1>(pk, zs, J); transpose_xr<0, 2>(pk, zs, J); transpose_xr<0, 3>(pk, zs, J); \
                        transpose_xr<1, 0>(pk, zs, J); transpose_xr<1, 1>(pk, zs, J); transpose_xr<1, 2>(pk, zs, J); transpose_xr<1, 3>(pk, zs, J); SB(); }
 
     PAIR0() PAIR(1) PAIR(2) PAIR(3)
-    PAIR(4) TRANSPOSE(0) PAIR(5) PAIR(6) PAIR(7)
-    PAIR(8) TRANSPOSE(1) PAIR(9) PAIR(10) PAIR(11)
-    PAIR(12) TRANSPOSE(2) PAIR(13) PAIR(14)
+    PAIRT(4) PAIR(5) PAIR(6) PAIR(7)
+    PAIRT(8) PAIR(9) PAIR(10) PAIR(11)
+    PAIRT(12) PAIR(13) PAIR(14)
     ADV(15)
     FREQ(30, t1a, t2a, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), { PKF(14, 0); PKM(14, 0); }, { PKF(14, 1); PKM(14, 1); },
          { PKF(14, 2); PKM(14, 2); })
@@ -258,6 +276,15 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
     Fb = f32x4{0.f, 0.f, 0.f, 0.f}; Mb = Fb;            // sequence index 31 = frequency 31: the zero pad of the K = 32 slots
     PKF(15, 0) PKM(15, 0) PKF(15, 1) PKM(15, 1) PKF(15, 2) PKM(15, 2) PKF(15, 3) PKM(15, 3)
     TRANSPOSE(3)
+    {  // L2 prefetch of group g + 2 for the whole XCD (as sc_match_h.hip): this wave's 6 of its 744 cache lines
+      asm volatile("" : : "v"(pf_sink));
+      const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(dbase + (size_t)(g + 2) * SCH_DIMG), 0, (g + 2 < DG) ? SCH_DIMG : 0, 0x00020000);
+      int lp = lane;
+      asm volatile("" : "+v"(lp));
+      const int pf_off = (lp < 6) ? (pf_slot * 6 + lp) * 128 : (int)0x80000000;
+      pf_sink = __builtin_amdgcn_raw_buffer_load_b32(rp, pf_off, 0, 0);
+    }
     // first requests of the next group
     {
       const unsigned n0 = nat0 + QOFF(0), r0 = rot0 + QOFF(0);
@@ -272,15 +299,28 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
     int le = lane;
     asm volatile("" : "+v"(le));
     const bool live = le < 16 && g * 16 + le < n;
-#define RESULT(R, H)                                                                              \
-  { float mx = fmaxf(stage2_tile<0, R, H>(pk, c), stage2_tile<1, R, H>(pk, c));                   \
-    unsigned a = __float_as_uint(mx), b = a;                                                      \
-    swap32(a, b); mx = fmaxf(__uint_as_float(a), __uint_as_float(b));                             \
-    a = __float_as_uint(mx); b = a;                                                               \
-    swap16(a, b); mx = fmaxf(__uint_as_float(a), __uint_as_float(b));                             \
-    const int st = live ? ((4 * (H) + (R)) * n + g * 16 + le) * 4 : (int)0x80000000;              \
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(mx, -0x1p-26f, 0.5f)), rd, st, 0, 0); }
-    RESULT(0, 0) RESULT(0, 1) RESULT(1, 0) RESULT(1, 1) RESULT(2, 0) RESULT(2, 1) RESULT(3, 0) RESULT(3, 1)
+    // software pipeline over the 16 groups: the twelve MFMAs of group k + 1 are issued before group k's tiles are reduced (their 48+ wait
+    // states are what an asm MFMA result needs before a VALU read: nothing is padded around asm), 2 groups = one (R, H) result
+    Tiles tl[2];
+    float mxr = -__builtin_inff();
+#define FINISH(RH)                                                                                \
+  { unsigned a = __float_as_uint(mxr), b = a;                                                     \
+    swap32(a, b); mxr = fmaxf(__uint_as_float(a), __uint_as_float(b));                            \
+    a = __float_as_uint(mxr); b = a;                                                              \
+    swap16(a, b); mxr = fmaxf(__uint_as_float(a), __uint_as_float(b));                            \
+    const int st = live ? ((4 * ((RH) & 1) + ((RH) >> 1)) * n + g * 16 + le) * 4 : (int)0x80000000; \
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(mxr, -0x1p-26f, 0.5f)), rd, st, 0, 0); \
+    mxr = -__builtin_inff(); }
+#define STEP2(K)                                                                                  \
+  { SB(); s2_issue<K>(pk, c, tl[(K) & 1]); SB();                                                  \
+    mxr = s2_reduce(mxr, tl[((K) - 1) & 1]);                                                      \
+    if ((((K) - 1) & 1) == 1) FINISH(((K) - 1) >> 1)                                              \
+    SB(); }
+    SB(); s2_issue<0>(pk, c, tl[0]); SB();
+    STEP2(1) STEP2(2) STEP2(3) STEP2(4) STEP2(5) STEP2(6) STEP2(7) STEP2(8) STEP2(9) STEP2(10) STEP2(11) STEP2(12) STEP2(13) STEP2(14) STEP2(15)
+    DRAIN(); SB();
+    mxr = s2_reduce(mxr, tl[1]);
+    FINISH(7)
     rs = rsn;
   }
 }
