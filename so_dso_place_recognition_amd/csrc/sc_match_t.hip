@@ -212,6 +212,10 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
     load_b<seqf(1), B_REH>(Bt[1], rs, voff); load_b<seqf(1), B_IMH>(Bt[1], rs, voff); load_b<seqf(1), B_REL>(Bt[1], rs, voff);
     load_a<1, A_H>(At[1], n0, r0); load_a<1, A_RH>(At[1], n0, r0);
   }
+#ifdef PR_SCH_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev));
+#endif
   for (int g = g0; g < g1; g++) {
     const __amdgpu_buffer_rsrc_t rsn =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g + 1) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
@@ -263,8 +267,11 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
                        transpose_xr<1, 0>(pk, zs, J); transpose_xr<1, 1>(pk, zs, J); transpose_xr<1, 2>(pk, zs, J); transpose_xr<1, 3>(pk, zs, J); SB(); }
 
     PAIR0() PAIR(1) PAIR(2) PAIR(3)
+    TICK(0)
     PAIRT(4) PAIR(5) PAIR(6) PAIR(7)
+    TICK(1)
     PAIRT(8) PAIR(9) PAIR(10) PAIR(11)
+    TICK(2)
     PAIRT(12) PAIR(13) PAIR(14)
     ADV(15)
     FREQ(30, t1a, t2a, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), { PKF(14, 0); PKM(14, 0); }, { PKF(14, 1); PKM(14, 1); },
@@ -275,7 +282,9 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
     FM2(Fa, Ma, t1a, t2a, 0); FM2(Fa, Ma, t1a, t2a, 2);
     Fb = f32x4{0.f, 0.f, 0.f, 0.f}; Mb = Fb;            // sequence index 31 = frequency 31: the zero pad of the K = 32 slots
     PKF(15, 0) PKM(15, 0) PKF(15, 1) PKM(15, 1) PKF(15, 2) PKM(15, 2) PKF(15, 3) PKM(15, 3)
+    TICK(3)
     TRANSPOSE(3)
+    TICK(4)
     {  // L2 prefetch of group g + 2 for the whole XCD (as sc_match_h.hip): this wave's 6 of its 744 cache lines
       asm volatile("" : : "v"(pf_sink));
       const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
@@ -301,6 +310,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
     const bool live = le < 16 && g * 16 + le < n;
     // software pipeline over the 16 groups: the twelve MFMAs of group k + 1 are issued before group k's tiles are reduced (their 48+ wait
     // states are what an asm MFMA result needs before a VALU read: nothing is padded around asm), 2 groups = one (R, H) result
+    TICK(5)
     Tiles tl[2];
     float mxr = -__builtin_inff();
 #define FINISH(RH)                                                                                \
@@ -321,8 +331,13 @@ __global__ __launch_bounds__(256, 1) void sc_match_t_kernel(const char* __restri
     DRAIN(); SB();
     mxr = s2_reduce(mxr, tl[1]);
     FINISH(7)
+    TICK(6)
     rs = rsn;
   }
+#ifdef PR_SCH_TIMING
+  if (blockIdx.x == 8 * 40 && tid == 0)
+    for (int i = 0; i < 8; i++) reinterpret_cast<unsigned long long*>(dist_p)[i] = tacc[i] / (unsigned long long)(g1 - g0);
+#endif
 }
 
 }  // namespace
