@@ -46,6 +46,9 @@ size_t sc_match_h_lds_bytes();
 // images, its own stage-2 constant table [4 quarters][E hh+hl | E lh | O hh+hl | O lh][64 lanes] x 16 B
 void launch_sc_match_p(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                        int nsplit_override);
+// sc_match_h.hip with stage 2 deferred to the end of the unit and transient tiles (sc_match_d.hip): same images and constants
+void launch_sc_match_d(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
+                       int nsplit_override);
 // transient stage-2 accumulators (sc_match_t.hip): same images; constants [E|O][shift rows 0-15|16-31][hi|lo][64 lanes] x 16 B
 void launch_sc_match_t(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                        int nsplit_override);

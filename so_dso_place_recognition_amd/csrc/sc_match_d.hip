@@ -1,0 +1,401 @@
+// sc_match_d.hip — EXPERIMENT (PR_SC_KERNEL=d selects it for m > 8): sc_match_h.hip with stage 2 DEFERRED to the end of the unit and
+// TRANSIENT stage-2 tiles.
+//
+// sc_match_h.hip runs stage 2 per half of the frequencies into 256 persistent AccVGPR accumulators and then pulls every one of them out in
+// a VALU-only epilogue.  Here both halves' packed operands are kept (the first half's 32 operand tuples, already swapped, are parked in
+// AccVGPRs while stage 1 of the second half runs) and stage 2 runs once per unit: per (stage-1 register, forward | mirror) the E and the O
+// tile (32 shift rows x 32 pairs, in ArchVGPRs) get their twelve MFMAs over both halves and are reduced (E + |O|, max) while the next
+// pair of tiles is being computed - no persistent accumulators, no v_accvgpr_read, no MFMA-free epilogue.  Same images, constants, stage 1.
+#include "kernels.hpp"
+
+namespace pr {
+namespace {
+
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
+
+struct AOps { u32x4 h, l, rh, rl; };          // query row operands: Q hi, Q lo, and the same with Re/Im rows exchanged
+struct BOps { u32x4 reh, rel, imh, iml; };    // DB column operands: Re hi, Re lo, Im hi, Im lo
+
+// one operand tile (4 registers) per call, so that every request can be placed in its own MFMA gap
+enum { A_H = 0, A_L = 1, A_RH = 2, A_RL = 3 };
+enum { B_REH = 0, B_REL = 1, B_IMH = 2, B_IML = 3 };
+// nat / rot: 32-bit LDS byte addresses of this lane's 16 B in the block of frequency (P & ~1); the odd frequency of the
+// pair and the lo tile are immediate offsets of the ds_read2_b64 (8-bit, in units of 8 B: 1288 + 40 + 8 < 2048)
+typedef const u32x4_a8 __attribute__((address_space(3))) * lds_tile_p;
+template <int P, int T>
+__device__ __forceinline__ void load_a(AOps& a, unsigned nat, unsigned rot) {
+  const unsigned addr = ((T & 2) ? rot : nat) + (P & 1) * SCH_QBLK + (T & 1) * 40;
+  const u32x4 v = *reinterpret_cast<lds_tile_p>(addr);
+  if (T == A_H) a.h = v; else if (T == A_L) a.l = v; else if (T == A_RH) a.rh = v; else a.rl = v;
+}
+template <int P, int T>
+__device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int voff) {
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, P * SCH_DFREQ + T * SCH_DTILE, 0);   // frequency and tile in the scalar offset: ONE lane-offset register (voff + T * 768 cost three more, spilled)
+  if (T == B_REH) b.reh = v; else if (T == B_REL) b.rel = v; else if (T == B_IMH) b.imh = v; else b.iml = v;
+}
+
+// Stage-1 MFMAs in VGPR form, ONE instruction per asm statement so that VALU work can be placed between them by hand
+// (the wave issues in order: back-to-back MFMAs would block it).  The 256 stage-2 accumulators own the AccVGPR half and
+// hipcc picks one MFMA register form per function, hence asm.  hipcc pads nothing around asm (cdna_hip_programming.md
+// §5.7): an accumulate chain on the same vDst needs no wait states; every VALU reader of t1/t2 below sits at least two
+// MFMAs + their fillers behind the last write, except the one after DRAIN().
+#define MF0(d, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b))
+#define MFA(d, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b))
+#define DRAIN() asm volatile("s_nop 9")
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#ifdef PR_SCH_TIMING
+#define TICK(i) { SB(); unsigned long long _t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t)); tacc[i] += _t - tprev; tprev = _t; SB(); }
+#else
+#define TICK(i)
+#endif
+
+// (hi, lo) split of two fp32 values into packed f16 pairs: hi = f16(x) (v_cvt_pk_f16_f32), lo = f16(x - hi) with the
+// residual formed exactly in fp32 by v_fma_mix_f32 (f16 operand x -1 + f32 operand) - the mixlo/mixhi forms that write a
+// 16-bit half directly cost ~2x the issue time of a full-register VALU op on gfx950 (tools/ubench/valu_rate.hip).
+__device__ __forceinline__ void split2(float x, float y, unsigned& hi, unsigned& lo) {
+  const f32x2 v = {x, y};
+  hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+  f32x2 r;
+  asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
+      "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+      : "=&v"(r[0]), "=&v"(r[1])
+      : "v"(hi), "v"(x), "v"(y));
+  lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+}
+
+// Packed results of 16 frequencies (one half) for the 4 stage-1 registers r: [kind][r] is a 4-register MFMA operand
+// whose element j holds pair j (lanes 0-31) / pair j+4 (lanes 32-63) after the swap.
+struct Half {
+  u32x4 reFh[4], reFl[4], imFh[4], imFl[4];   // forward (S): Re / Im operands, hi / lo
+  u32x4 reMh[4], reMl[4], imMh[4], imMl[4];   // mirror (P)
+};
+
+__device__ __forceinline__ void swap32(u32x4& a, u32x4& b, int e) {   // lanes 32-63 of a[e] <-> lanes 0-31 of b[e]
+  const u32x2 v = __builtin_amdgcn_permlane32_swap(a[e], b[e], false, false);
+  a[e] = v[0];
+  b[e] = v[1];
+}
+
+// frequencies (2J, 2J+1) of the half -> element J&3 of the "re" (J < 4) or "im" (J >= 4) registers, still as (Re | Im)
+template <int J, int R>
+__device__ __forceinline__ void pack_F(Half& hb, const f32x4& Fa, const f32x4& Fb) {
+  unsigned h, l;
+  split2(Fa[R], Fb[R], h, l);
+  if (J < 4) { hb.reFh[R][J & 3] = h; hb.reFl[R][J & 3] = l; } else { hb.imFh[R][J & 3] = h; hb.imFl[R][J & 3] = l; }
+}
+template <int J, int R>
+__device__ __forceinline__ void pack_M(Half& hb, const f32x4& Ma, const f32x4& Mb) {
+  unsigned h, l;
+  split2(Ma[R], Mb[R], h, l);
+  if (J < 4) { hb.reMh[R][J & 3] = h; hb.reMl[R][J & 3] = l; } else { hb.imMh[R][J & 3] = h; hb.imMl[R][J & 3] = l; }
+}
+template <int R>
+__device__ __forceinline__ void swap_r(Half& hb, int e0, int e1) {   // elements e0..e1-1 of the 8 operands of register R
+  for (int e = e0; e < e1; e++) {
+    swap32(hb.reFh[R], hb.imFh[R], e);
+    swap32(hb.reFl[R], hb.imFl[R], e);
+    swap32(hb.reMh[R], hb.imMh[R], e);
+    swap32(hb.reMl[R], hb.imMl[R], e);
+  }
+}
+
+
+struct Consts { u32x4 ch, cl, sh, sl; };   // A operands of one half: cos hi/lo, -sin hi/lo
+template <int HALF>
+__device__ __forceinline__ void load_consts(Consts& c, __amdgpu_buffer_rsrc_t rc, int lane16) {   // [E|O][half][hi|lo][64] x 16 B
+  c.ch = __builtin_amdgcn_raw_buffer_load_b128(rc, lane16, ((0 * 2 + HALF) * 2 + 0) * 1024, 0);
+  c.cl = __builtin_amdgcn_raw_buffer_load_b128(rc, lane16, ((0 * 2 + HALF) * 2 + 1) * 1024, 0);
+  c.sh = __builtin_amdgcn_raw_buffer_load_b128(rc, lane16, ((1 * 2 + HALF) * 2 + 0) * 1024, 0);
+  c.sl = __builtin_amdgcn_raw_buffer_load_b128(rc, lane16, ((1 * 2 + HALF) * 2 + 1) * 1024, 0);
+}
+
+// epilogue piece: shift rows e of register R -> running max over E + |O| of forward and mirror
+template <int R>
+__device__ __forceinline__ void ep_elem(float& mx, const f32x16 (&accE)[4][2], const f32x16 (&accO)[4][2], int e) {
+  const float vf = accE[R][0][e] + __builtin_fabsf(accO[R][0][e]);
+  const float vm = accE[R][1][e] + __builtin_fabsf(accO[R][1][e]);
+  mx = fmaxf(fmaxf(mx, vf), vm);
+}
+// 2 queries x 16 entries (lanes 0..31): d = (1 - max)/2 with the 2^-25 operand scaling folded in   (processSC.m:30).
+// Branch-free (a buffer store whose invalid lanes are out of range), so that the whole group body stays ONE basic block
+// and the hand-placed order survives the compiler's sinking passes.
+template <int R>
+__device__ __forceinline__ void ep_store(float mx, __amdgpu_buffer_rsrc_t rd, int st_off) {
+  const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+  mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));     // max over the two lane halves (shift rows +0..3 | +4..7)
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(mx, -0x1p-26f, 0.5f)), rd, st_off, 0, 0);   // plain store: the nt hint cost 0.7 % and 28 % more HBM write traffic (partial lines bypass the L2 merge)
+}
+
+// F = T1 + s T2, M = T1 - s T2 for registers r0, r0+1: two v_pk_fma_f32
+#define FM2(F, M, t1, t2, r0)                                                        \
+  {                                                                                  \
+    const f32x2 _a = {t1[r0], t1[r0 + 1]}, _b = {t2[r0], t2[r0 + 1]};                \
+    const f32x2 _f = __builtin_elementwise_fma(_b, sg2, _a), _m = __builtin_elementwise_fma(_b, -sg2, _a); \
+    F[r0] = _f[0]; F[r0 + 1] = _f[1]; M[r0] = _m[0]; M[r0 + 1] = _m[1];             \
+  }
+
+
+// stage-2 MFMAs as asm statements: the tile lives in ArchVGPRs, the B operand in AccVGPRs (first half, parked) or ArchVGPRs (second half)
+#define M32Z(d, a, b, BC) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), BC(b))
+#define M32A(d, a, b, BC) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), BC(b))
+
+// the twelve MFMAs of (register R, forward | mirror V): E tile from the Re operands, O tile from the Im operands, three split products per half
+template <int R, int V>
+__device__ __forceinline__ void s2_issue(const Half& h0, const Half& h1, const Consts& c0, const Consts& c1, f32x16& e, f32x16& o) {
+  const u32x4& r0h = V ? h0.reMh[R] : h0.reFh[R]; const u32x4& r0l = V ? h0.reMl[R] : h0.reFl[R];
+  const u32x4& i0h = V ? h0.imMh[R] : h0.imFh[R]; const u32x4& i0l = V ? h0.imMl[R] : h0.imFl[R];
+  const u32x4& r1h = V ? h1.reMh[R] : h1.reFh[R]; const u32x4& r1l = V ? h1.reMl[R] : h1.reFl[R];
+  const u32x4& i1h = V ? h1.imMh[R] : h1.imFh[R]; const u32x4& i1l = V ? h1.imMl[R] : h1.imFl[R];
+  M32Z(e, c0.ch, r0h, "a"); M32Z(o, c0.sh, i0h, "a");
+  M32A(e, c0.cl, r0h, "a"); M32A(o, c0.sl, i0h, "a");
+  M32A(e, c0.ch, r0l, "a"); M32A(o, c0.sh, i0l, "a");
+  M32A(e, c1.ch, r1h, "v"); M32A(o, c1.sh, i1h, "v");
+  M32A(e, c1.cl, r1h, "v"); M32A(o, c1.sl, i1h, "v");
+  M32A(e, c1.ch, r1l, "v"); M32A(o, c1.sh, i1l, "v");
+}
+__device__ __forceinline__ float s2_reduce(float mx, const f32x16& e, const f32x16& o) {
+#pragma unroll
+  for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, e[i] + __builtin_fabsf(o[i])), e[i + 1] + __builtin_fabsf(o[i + 1]));
+  return mx;
+}
+// parks the 8 operand tuples of register R in AccVGPRs (an empty asm whose operand must be an AccVGPR tuple)
+template <int R>
+__device__ __forceinline__ void park_r(Half& h) {
+  asm volatile("" : "+a"(h.reFh[R]), "+a"(h.reFl[R]), "+a"(h.imFh[R]), "+a"(h.imFl[R]));
+  asm volatile("" : "+a"(h.reMh[R]), "+a"(h.reMl[R]), "+a"(h.imMh[R]), "+a"(h.imMl[R]));
+}
+
+__global__ __launch_bounds__(256, 1) void sc_match_d_kernel(const char* __restrict__ qpk,   // [2][QG32][4][31][1288 B]
+                                                            const char* __restrict__ dpk,   // [2][DG][31][4][768 B] + one zero group
+                                                            const u32x4* __restrict__ cst,  // [2][2][2][64] x 16 B
+                                                            float* __restrict__ dist_p, float* __restrict__ dist_i,
+                                                            int m, int n, int QG8, int DG, int nsplit) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // XCD-aware mapping (workgroups go round-robin to the 8 XCDs, each with its own L2): all workgroups of one XCD work
+  // on ONE channel and on the same quarter of the DB ranges, consecutive workgroups of an XCD on consecutive 32-query
+  // blocks - so the ~32 resident workgroups of an XCD sweep the same DB range together and share it through that L2.
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int ch = xcd & 1;
+  const int range = (xcd >> 1) + 4 * (idx % nsplit), qg32 = idx / nsplit;      // nsplit = ranges per XCD slice
+  const int nrange = 4 * nsplit;
+  const int g0 = (int)((long long)DG * range / nrange), g1 = (int)((long long)DG * (range + 1) / nrange);
+
+  {  // the 4 query groups of this workgroup -> LDS (linear copy; the packed image IS the LDS image) + zeroed tail
+    const u32x4* src = reinterpret_cast<const u32x4*>(qpk + ((size_t)ch * QG8 + (size_t)qg32 * 4) * SCH_QIMG);
+    u32x4* dst = reinterpret_cast<u32x4*>(lds);
+    constexpr int NV = 4 * SCH_QIMG / 16;
+    for (int i = tid; i < NV + 4; i += 256) dst[i] = (i < NV) ? src[i] : u32x4{0u, 0u, 0u, 0u};
+  }
+  __syncthreads();
+  if (g0 >= g1) return;
+
+  const int row = lane & 15, kg = lane >> 4;
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds;
+  constexpr int GS = 1;
+  const int wq = w;                                      // this wave's query group inside the workgroup's image
+  const unsigned nat0 = lds0 + wq * SCH_QIMG + row * 80 + (row >= 8 ? 8 : 0) + kg * 16;
+  const unsigned rot0 = lds0 + wq * SCH_QIMG + (row ^ 8) * 80 + (row >= 8 ? 0 : 8) + kg * 16;
+  const int voff = (lane < 48) ? lane * 16 : (int)0x80000000;     // lanes 48-63: out of range -> zeros (K = 24..31)
+  const float sg = (lane < 32) ? 1.0f : -1.0f;
+  const f32x2 sg2 = {sg, sg};
+  float* dist = ch ? dist_i : dist_p;
+  const char* dbase = dpk + ((size_t)ch * DG) * SCH_DIMG;
+  const int qrow0 = qg32 * 32 + wq * 8;
+  // distances of this wave's 8 query rows: byte offset = ((local row) * n + entry) * 4; local row = R (lanes 0-15) or 4 + R (16-31)
+  const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+      dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 8 ? m - qrow0 : 8) : 0) * n * 4, 0x00020000);
+  const int pf_slot = (qg32 & 31) * 4 + w;                                  // 0..127
+  unsigned pf_sink = 0;
+  const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(cst), 0, 8192, 0x00020000);
+
+  // Software pipeline over the slot sequence (6 stage-1 MFMAs per frequency), per operand TILE: the DB tiles of frequency
+  // q are requested 8-12 MFMA slots ahead (Re hi, Im hi, Re lo during frequency q-2, Im lo during q-1), the query tiles 4
+  // slots ahead (during q-1); buffers rotate with period 4 (DB) and 2 (queries) over 32 positions per group, position 31
+  // being a ghost whose requests are issued by hand at the start of the stage-2 phase.  hipcc counts all these loads, so
+  // every MFMA waits with the exact vmcnt / lgkmcnt for its own operands only.  The wave issues in order, so the VALU
+  // work is placed by hand into the gaps between MFMAs and pinned with sched_barrier: the F/M combination of a
+  // frequency runs two MFMAs after its last stage-1 MFMA, the split/pack of pair J-1 under the stage-1 MFMAs of pair J,
+  // the permlane swaps of register r+1 and the epilogue of register r-1 under the 12 stage-2 MFMAs of register r.
+  AOps At[4];
+  BOps Bt[4];
+  __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)g0 * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
+  load_b<0, B_REH>(Bt[0], rs, voff); load_b<0, B_IMH>(Bt[0], rs, voff); load_b<0, B_REL>(Bt[0], rs, voff); load_b<0, B_IML>(Bt[0], rs, voff);
+  load_a<0, A_H>(At[0], nat0, rot0); load_a<0, A_RH>(At[0], nat0, rot0); load_a<0, A_L>(At[0], nat0, rot0); load_a<0, A_RL>(At[0], nat0, rot0);
+  load_b<1, B_REH>(Bt[1], rs, voff); load_b<1, B_IMH>(Bt[1], rs, voff); load_b<1, B_REL>(Bt[1], rs, voff);
+  load_a<1, A_H>(At[1], nat0, rot0); load_a<1, A_RH>(At[1], nat0, rot0);
+#ifdef PR_SCH_TIMING
+  unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev));
+#endif
+  Consts c0, c1;                                     // the stage-2 constants of both halves stay in registers for the whole kernel
+  load_consts<0>(c0, rc, lane * 16);
+  load_consts<1>(c1, rc, lane * 16);
+  unsigned nbase = nat0, rbase = rot0;       // carried through the running tile addresses: nothing address-like stays live (= spilled) across a unit
+  for (int g = g0; g < g1; g += GS) {
+    const __amdgpu_buffer_rsrc_t rsn =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g + GS) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
+    Half hbs[2];                                     // packed operands of the two halves; hbs[0] is parked in AccVGPRs during the second half
+    f32x4 Fa, Ma, Fb, Mb, t1a, t2a, t1b, t2b;
+    unsigned ncur, rcur, nnxt = nbase, rnxt = rbase;
+    TICK(7)
+// request tile T of frequency Q of this group (Q >= 31: nothing - the first requests of the next group are issued by
+// hand late in the stage-2 phase, when half of the packed registers are free again)
+#define LDB(Q, T) { if ((Q) < SC_NF) load_b<((Q) < SC_NF ? (Q) : 0), T>(Bt[(Q) & 3], rs, voff); }
+#define LDA(P, Q, T) { if ((Q) < SC_NF) { if (((Q) >> 1) == ((P) >> 1)) load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], ncur, rcur); \
+                                        else load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], nnxt, rnxt); } }
+#define FREQ(P, t1, t2, W0, W1, W2, W3, W4, W5)                                                   \
+  {                                                                                               \
+    SB(); MF0(t1, At[(P) & 3].h, Bt[(P) & 3].reh);  SB(); LDB((P) + 1, B_IML); LDA(P, (P) + 1, A_L); W0;   \
+    SB(); MF0(t2, At[(P) & 3].rh, Bt[(P) & 3].imh); SB(); LDB((P) + 2, B_REH); W1;                \
+    SB(); MFA(t1, At[(P) & 3].l, Bt[(P) & 3].reh);  SB(); LDB((P) + 2, B_IMH); LDA(P, (P) + 1, A_RL); W2;  \
+    SB(); MFA(t2, At[(P) & 3].rl, Bt[(P) & 3].imh); SB(); LDA(P, (P) + 2, A_H); W3;               \
+    SB(); MFA(t1, At[(P) & 3].h, Bt[(P) & 3].rel);  SB(); LDB((P) + 2, B_REL); W4;                \
+    SB(); MFA(t2, At[(P) & 3].rh, Bt[(P) & 3].iml); SB(); LDA(P, (P) + 2, A_RH); W5;              \
+    SB();                                                                                         \
+  }
+#define PKF(J, R) pack_F<J, R>(hb, Fa, Fb)
+#define PKM(J, R) pack_M<J, R>(hb, Ma, Mb)
+#define PK(J, R) { PKF(J, R); PKM(J, R); }
+#define NONE ((void)0)
+// LDS bases of this lane's tiles: current pair and next pair (one opaque add per pair and operand kind)
+#define ADV() { ncur = nnxt; rcur = rnxt; nnxt = ncur + 2 * SCH_QBLK; rnxt = rcur + 2 * SCH_QBLK; asm("" : "+v"(nnxt)); asm("" : "+v"(rnxt)); }
+// Pair J of half H.  The VALU work is spread as evenly as the dependences allow, ~3 instructions per MFMA gap (a
+// 16x16x32 MFMA hides two or three; a gap with six costs ~34 cycles instead of ~18): the F/M combination of the previous
+// pair's second frequency (its last MFMA is two slots back), the eight split/pack pieces of the previous pair, and in
+// the last gap the F/M combination of this pair's first frequency (after the last reader of the old Fa/Ma).
+#define FMA_ALL(F, M, t1, t2) { FM2(F, M, t1, t2, 0); FM2(F, M, t1, t2, 2); }
+#define PAIR0(H)                                                                                  \
+  ADV()                                                                                           \
+  FREQ(16 * (H), t1a, t2a, NONE, NONE, NONE, NONE, NONE, NONE)                                    \
+  FREQ(16 * (H) + 1, t1b, t2b, NONE, NONE, NONE, NONE, NONE, FMA_ALL(Fa, Ma, t1a, t2a))
+#define PAIR(H, J)                                                                                \
+  ADV()                                                                                           \
+  FREQ(16 * (H) + 2 * (J), t1a, t2a, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PKF((J) - 1, 0), PKM((J) - 1, 0), PKF((J) - 1, 1)) \
+  FREQ(16 * (H) + 2 * (J) + 1, t1b, t2b, PKM((J) - 1, 1), PKF((J) - 1, 2), PKM((J) - 1, 2), PKF((J) - 1, 3), PKM((J) - 1, 3), FMA_ALL(Fa, Ma, t1a, t2a))
+// the 12 stage-2 MFMAs of register R with the VALU pieces W0..W11 in their gaps
+#define S2(FIRST, R, W0, W1, W2, W3, W4, W5, W6, W7, W8, W9, W10, W11)                             \
+  { stage2_one<FIRST, R, 0>(hb, c, accE, accO, zero); SB(); W0; SB();                             \
+    stage2_one<FIRST, R, 1>(hb, c, accE, accO, zero); SB(); W1; SB();                             \
+    stage2_one<FIRST, R, 2>(hb, c, accE, accO, zero); SB(); W2; SB();                             \
+    stage2_one<FIRST, R, 3>(hb, c, accE, accO, zero); SB(); W3; SB();                             \
+    stage2_one<FIRST, R, 4>(hb, c, accE, accO, zero); SB(); W4; SB();                             \
+    stage2_one<FIRST, R, 5>(hb, c, accE, accO, zero); SB(); W5; SB();                             \
+    stage2_one<FIRST, R, 6>(hb, c, accE, accO, zero); SB(); W6; SB();                             \
+    stage2_one<FIRST, R, 7>(hb, c, accE, accO, zero); SB(); W7; SB();                             \
+    stage2_one<FIRST, R, 8>(hb, c, accE, accO, zero); SB(); W8; SB();                             \
+    stage2_one<FIRST, R, 9>(hb, c, accE, accO, zero); SB(); W9; SB();                             \
+    stage2_one<FIRST, R, 10>(hb, c, accE, accO, zero); SB(); W10; SB();                           \
+    stage2_one<FIRST, R, 11>(hb, c, accE, accO, zero); SB(); W11; SB(); }
+
+    // ---------------------------------------------------------------- first half: frequencies 0..15
+#define hb hbs[0]
+    PAIR0(0) PAIR(0, 1) PAIR(0, 2) PAIR(0, 3) PAIR(0, 4) PAIR(0, 5) PAIR(0, 6) PAIR(0, 7)
+    TICK(0)
+    DRAIN();
+    SB();
+    FM2(Fb, Mb, t1b, t2b, 0); FM2(Fb, Mb, t1b, t2b, 2);
+    PK(7, 0) PK(7, 1) PK(7, 2) PK(7, 3)
+    SB();
+    swap_r<0>(hb, 0, 4); swap_r<1>(hb, 0, 4); swap_r<2>(hb, 0, 4); swap_r<3>(hb, 0, 4);   // the swaps need ArchVGPRs: before the operands are parked
+    SB();
+    park_r<0>(hb); park_r<1>(hb); park_r<2>(hb); park_r<3>(hb);
+    SB();
+#undef hb
+    TICK(1)
+    TICK(2)
+    // ---------------------------------------------------------------- second half: frequencies 16..30
+#define hb hbs[1]
+    PAIR0(1) PAIR(1, 1) PAIR(1, 2) PAIR(1, 3) PAIR(1, 4) PAIR(1, 5) PAIR(1, 6)
+    ADV()
+    FREQ(30, t1a, t2a, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PK(6, 0), PK(6, 1), PK(6, 2))
+    PK(6, 3)
+    TICK(3)
+    DRAIN();
+    SB();
+    FM2(Fa, Ma, t1a, t2a, 0); FM2(Fa, Ma, t1a, t2a, 2);
+    Fb = f32x4{0.f, 0.f, 0.f, 0.f}; Mb = Fb;
+    PK(7, 0) PK(7, 1) PK(7, 2) PK(7, 3)
+    SB();
+    {  // L2 prefetch of group g + 2 for the whole XCD: this wave's 6 of its 744 cache lines (1/128 of the group), one
+       // dword per line into a register nobody reads before the same point of the next group.  The ~128 waves that sweep
+       // this range on this XCD cover the group between them, so the demand loads two groups later hit the L2 instead of
+       // paying HBM latency in the middle of the in-order load queue.
+      asm volatile("" : : "v"(pf_sink));
+      const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<char*>(dbase + (size_t)(g + 2 * GS) * SCH_DIMG), 0, (g + 2 * GS < DG) ? SCH_DIMG : 0, 0x00020000);
+      int lp = lane;
+      asm volatile("" : "+v"(lp));                 // recomputed here, not kept (or spilled) across the unit
+      const int pf_off = (lp < 6) ? (pf_slot * 6 + lp) * 128 : (int)0x80000000;   // lines past the group are out of range
+      pf_sink = __builtin_amdgcn_raw_buffer_load_b32(rp, pf_off, 0, 0);
+    }
+    swap_r<0>(hb, 0, 4);
+    SB();
+    TICK(4)
+#define NB(P, T) load_b<P, T>(Bt[P], rsn, voff)
+#define NA(P, T) load_a<P, T>(At[P], nbase, rbase)
+    nbase = nnxt - 16 * 2 * SCH_QBLK; rbase = rnxt - 16 * 2 * SCH_QBLK;   // 16 pair advances back: the image's first block
+    // ---------------------------------------------------------------- stage 2, once per unit: group s = 2 R + V (V = forward | mirror), twelve
+    // MFMAs into a fresh (E, O) tile pair; group s + 1 is issued before group s is reduced; the swaps of register R + 1 of the second
+    // half and the first requests of the next unit sit between the groups, under the MFMAs in flight
+    f32x16 tE[2], tO[2];
+    float mx = -__builtin_inff();
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int st_lane = ((le & 16) ? 4 * n : 0) * 4 + (le & 15) * 4;
+    const int st_base = (le < 32 && g * 16 + (le & 15) < n) ? st_lane : (int)0x80000000;
+#define GRP(S) s2_issue<((S) >> 1), ((S) & 1)>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1])
+#define RED(S) { mx = s2_reduce(mx, tE[(S) & 1], tO[(S) & 1]);                                    \
+                 if ((S) & 1) { ep_store<((S) >> 1)>(mx, rd, st_base + ((S) >> 1) * 4 * n + g * 64); mx = -__builtin_inff(); } }
+    SB(); GRP(0); SB(); swap_r<1>(hb, 0, 4); SB();
+    GRP(1); SB(); RED(0) SB();
+    GRP(2); SB(); RED(1) swap_r<2>(hb, 0, 4); SB();
+    GRP(3); SB(); RED(2) NB(0, B_REH); NB(0, B_IMH); NB(0, B_REL); NB(0, B_IML); SB();
+    GRP(4); SB(); RED(3) swap_r<3>(hb, 0, 4); SB();
+    GRP(5); SB(); RED(4) NB(1, B_REH); NB(1, B_IMH); NB(1, B_REL); NA(0, A_H); NA(0, A_RH); SB();
+    GRP(6); SB(); RED(5) NA(0, A_L); NA(0, A_RL); NA(1, A_H); NA(1, A_RH); SB();
+    GRP(7); SB(); RED(6) SB();
+    asm volatile("s_nop 15\n\ts_nop 15");          // the last tiles are read next: nothing pads an asm MFMA
+    SB();
+    RED(7)
+#undef hb
+    TICK(5)
+    TICK(6)
+    rs = rsn;
+  }
+#ifdef PR_SCH_TIMING
+  if (blockIdx.x == 8 * 40 && tid == 0)   // one wave somewhere in the middle of the grid; written over the first distances
+    for (int i = 0; i < 8; i++) reinterpret_cast<unsigned long long*>(dist_p)[i] = tacc[i] / (unsigned long long)((g1 - g0) / GS);
+#endif
+}
+
+}  // namespace
+
+size_t sc_match_d_lds_bytes() { return (size_t)4 * SCH_QIMG + 64; }
+
+void launch_sc_match_d(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
+                       int nsplit_override) {
+  if (m <= 0 || n <= 0) return;
+  const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n);
+  const int QG32 = QG8 / 4;
+  int nsplit = (128 + QG32 - 1) / QG32;
+  if (nsplit > DG / 32) nsplit = DG / 32;
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_match_d_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)sc_match_d_lds_bytes());
+  hipLaunchKernelGGL(sc_match_d_kernel, dim3(8 * QG32 * nsplit), dim3(256), sc_match_d_lds_bytes(), st,
+                     static_cast<const char*>(qpk), static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i,
+                     m, n, QG8, DG, nsplit);
+}
+
+}  // namespace pr

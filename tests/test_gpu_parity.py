@@ -346,7 +346,7 @@ def test_sc_both_arithmetics_vs_oracle(api):
     print("max |d - oracle|:", errs)
 
 
-@pytest.mark.parametrize("kernel", ["p", "r", "t"])
+@pytest.mark.parametrize("kernel", ["p", "r", "t", "d"])
 def test_sc_experiment_kernels_vs_oracle(api, monkeypatch, kernel):
     """sc_match_p.hip (PR_SC_KERNEL=p: two waves per SIMD share every unit), sc_match_r.hip (PR_SC_KERNEL=r: stage 2 rolled into
     stage 1) and sc_match_t.hip (PR_SC_KERNEL=t: transient stage-2 accumulators), experiments kept in the library, must give the oracle's distances and top-k like the default kernel; odd DB
