@@ -143,8 +143,8 @@ __device__ __forceinline__ void ep_store(float mx, __amdgpu_buffer_rsrc_t rd, in
 
 
 // stage-2 MFMAs as asm statements: the tile lives in ArchVGPRs, the B operand in AccVGPRs (first half, parked) or ArchVGPRs (second half)
-#define M32Z(d, a, b, BC) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), BC(b))
-#define M32A(d, a, b, BC) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), BC(b))
+#define M32Z(d, a, b, BC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), BC(b))
+#define M32A(d, a, b, BC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), BC(b))
 
 // the twelve MFMAs of (register R, forward | mirror V): E tile from the Re operands, O tile from the Im operands, three split products per half
 template <int R, int V>
