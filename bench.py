@@ -13,7 +13,7 @@ SURVEY.md §8-e); queries are replicated.  value = queries of all steps / max-ov
 `extra` (outside the timed region, N = 1 only): the secondary workloads of BASELINE.json measured in the same run - M2DP matching
 over a 50k-signature DB (config 3), SC generation from 50 000-point clouds (config 2), and the fp32-MFMA arithmetic of the SC matcher.
 
-Extra objects on the JSON line: `roofline` (the dominant kernel - sc_match_h_kernel, split-f16 MFMA, by default;
+Extra objects on the JSON line: `roofline` (the dominant kernel - sc_match_d_kernel, split-f16 MFMA, by default;
 sc_match_kernel, fp32 MFMA, with --sc-arith f32 - timed live with HIP events on the stream it runs on; algorithmic
 FLOPs = 23 856 fp32 FLOP per (query, entry) pair = 71 568 f16 FLOP in the split form), `cpu_baseline` (the CPU oracle =
 a port of the reference, timed on this host's cores on a bounded query sample at N = 1), `parity` (GPU top-1 vs
@@ -288,7 +288,7 @@ def main():
         kms = float(np.mean(kern_ms))
         pairs = m * (hi - lo)
         f16 = arith == "f16x2"
-        kname = "sc_match_h_kernel" if f16 else "sc_match_kernel"
+        kname = {"h": "sc_match_h_kernel", "p": "sc_match_p_kernel", "r": "sc_match_r_kernel", "t": "sc_match_t_kernel"}.get(os.environ.get("PR_SC_KERNEL", "d"), "sc_match_d_kernel") if f16 else "sc_match_kernel"
         fpp, peak = (FLOP_PER_PAIR_F16X2, MFMA_F16_PEAK_TFLOPS) if f16 else (FLOP_PER_PAIR, MFMA_F32_PEAK_TFLOPS)
         ach = pairs * fpp / (kms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)

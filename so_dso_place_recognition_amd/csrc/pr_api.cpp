@@ -38,7 +38,7 @@ struct pr_ctx {
   void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16] (sc_match_h.hip)
   void* d_cst_t = nullptr;       // stage-2 constants of sc_match_t.hip: [E|O][shift rows 0-15|16-31][hi|lo][64 lanes][8 f16]
   void* d_cst_p = nullptr;       // stage-2 constants of sc_match_p.hip: [quarter][E hh+hl | E lh | O hh+hl | O lh][64 lanes][8 f16]
-  int sc_kernel_p = 0;           // PR_SC_KERNEL=p: the two-waves-per-SIMD matcher (sc_match_p.hip) for m > 8
+  int sc_kernel_p = 4;           // split-f16 SC matcher for m > 8: 4 = sc_match_d.hip (default), PR_SC_KERNEL=h|p|r|t selects sc_match_h / _p / _r / _t (0 / 1 / 2 / 3)
   int sc_mode = PR_SC_ARITH_F16X2;   // PR_SC_ARITH_*: split-f16 MFMA (sc_match_h.hip) | fp32 MFMA (sc_match.hip); PR_SC_MATCH=f32 selects the latter
   double* d_planes = nullptr;    // M2DP xProj[64][3], yProj[64][3]
   int sc_nsplit = 0;             // PR_SC_NSPLIT override (experiments)
@@ -276,7 +276,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
   if (rc != PR_OK) { pr_destroy(ctx); return rc; }
   if (const char* s = getenv("PR_SC_NSPLIT")) ctx->sc_nsplit = atoi(s);
   if (const char* s = getenv("PR_SC_MATCH")) ctx->sc_mode = (strcmp(s, "f32") == 0) ? 1 : 0;
-  if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel_p = (strcmp(s, "p") == 0) ? 1 : (strcmp(s, "r") == 0) ? 2 : (strcmp(s, "t") == 0) ? 3 : (strcmp(s, "d") == 0) ? 4 : 0;
+  if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel_p = (strcmp(s, "p") == 0) ? 1 : (strcmp(s, "r") == 0) ? 2 : (strcmp(s, "t") == 0) ? 3 : (strcmp(s, "h") == 0) ? 0 : 4;
   *out = ctx;
   return PR_OK;
 }
