@@ -146,24 +146,23 @@ __device__ __forceinline__ void ep_store(float mx, __amdgpu_buffer_rsrc_t rd, in
 #define M32Z(d, a, b, BC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), BC(b))
 #define M32A(d, a, b, BC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), BC(b))
 
-// the twelve MFMAs of (register R, forward | mirror V): E tile from the Re operands, O tile from the Im operands, three split products per half
-template <int R, int V>
-__device__ __forceinline__ void s2_issue(const Half& h0, const Half& h1, const Consts& c0, const Consts& c1, f32x16& e, f32x16& o) {
-  const u32x4& r0h = V ? h0.reMh[R] : h0.reFh[R]; const u32x4& r0l = V ? h0.reMl[R] : h0.reFl[R];
-  const u32x4& i0h = V ? h0.imMh[R] : h0.imFh[R]; const u32x4& i0l = V ? h0.imMl[R] : h0.imFl[R];
-  const u32x4& r1h = V ? h1.reMh[R] : h1.reFh[R]; const u32x4& r1l = V ? h1.reMl[R] : h1.reFl[R];
-  const u32x4& i1h = V ? h1.imMh[R] : h1.imFh[R]; const u32x4& i1l = V ? h1.imMl[R] : h1.imFl[R];
-  M32Z(e, c0.ch, r0h, "a"); M32Z(o, c0.sh, i0h, "a");
-  M32A(e, c0.cl, r0h, "a"); M32A(o, c0.sl, i0h, "a");
-  M32A(e, c0.ch, r0l, "a"); M32A(o, c0.sh, i0l, "a");
-  M32A(e, c1.ch, r1h, "v"); M32A(o, c1.sh, i1h, "v");
-  M32A(e, c1.cl, r1h, "v"); M32A(o, c1.sl, i1h, "v");
-  M32A(e, c1.ch, r1l, "v"); M32A(o, c1.sh, i1l, "v");
+// MFMA I (0..11) of (register R, forward | mirror V): E tile from the Re operands (even I), O tile from the Im operands (odd I); I >> 1 =
+// 0..2 the three split products of the first half (operands parked in AccVGPRs), 3..5 those of the second half (ArchVGPRs)
+template <int R, int V, int I>
+__device__ __forceinline__ void s2_one(const Half& h0, const Half& h1, const Consts& c0, const Consts& c1, f32x16& e, f32x16& o) {
+  constexpr int PART = I & 1, T = (I >> 1) % 3, HF = (I >> 1) / 3;
+  const Half& h = HF ? h1 : h0;
+  const Consts& c = HF ? c1 : c0;
+  const u32x4& ca = PART ? (T == 1 ? c.sl : c.sh) : (T == 1 ? c.cl : c.ch);
+  const u32x4& op = PART ? (V ? (T == 2 ? h.imMl[R] : h.imMh[R]) : (T == 2 ? h.imFl[R] : h.imFh[R]))
+                         : (V ? (T == 2 ? h.reMl[R] : h.reMh[R]) : (T == 2 ? h.reFl[R] : h.reFh[R]));
+  f32x16& d = PART ? o : e;
+  if (I < 2) { if (HF) M32Z(d, ca, op, "v"); else M32Z(d, ca, op, "a"); }
+  else { if (HF) M32A(d, ca, op, "v"); else M32A(d, ca, op, "a"); }
 }
-__device__ __forceinline__ float s2_reduce(float mx, const f32x16& e, const f32x16& o) {
-#pragma unroll
-  for (int i = 0; i < 16; i += 2) mx = fmaxf(fmaxf(mx, e[i] + __builtin_fabsf(o[i])), e[i + 1] + __builtin_fabsf(o[i + 1]));
-  return mx;
+// one step of the reduction of a finished (E, O) tile pair: shift rows 2 i, 2 i + 1
+__device__ __forceinline__ float red_piece(float mx, const f32x16& e, const f32x16& o, int i) {
+  return fmaxf(fmaxf(mx, e[2 * i] + __builtin_fabsf(o[2 * i])), e[2 * i + 1] + __builtin_fabsf(o[2 * i + 1]));
 }
 // parks the 8 operand tuples of register R in AccVGPRs (an empty asm whose operand must be an AccVGPR tuple)
 template <int R>
@@ -353,20 +352,36 @@ __global__ __launch_bounds__(256, 1) void sc_match_d_kernel(const char* __restri
     asm volatile("" : "+v"(le));
     const int st_lane = ((le & 16) ? 4 * n : 0) * 4 + (le & 15) * 4;
     const int st_base = (le < 32 && g * 16 + (le & 15) < n) ? st_lane : (int)0x80000000;
-#define GRP(S) s2_issue<((S) >> 1), ((S) & 1)>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1])
-#define RED(S) { mx = s2_reduce(mx, tE[(S) & 1], tO[(S) & 1]);                                    \
-                 if ((S) & 1) { ep_store<((S) >> 1)>(mx, rd, st_base + ((S) >> 1) * 4 * n + g * 64); mx = -__builtin_inff(); } }
-    SB(); GRP(0); SB(); swap_r<1>(hb, 0, 4); SB();
-    GRP(1); SB(); RED(0) SB();
-    GRP(2); SB(); RED(1) swap_r<2>(hb, 0, 4); SB();
-    GRP(3); SB(); RED(2) NB(0, B_REH); NB(0, B_IMH); NB(0, B_REL); NB(0, B_IML); SB();
-    GRP(4); SB(); RED(3) swap_r<3>(hb, 0, 4); SB();
-    GRP(5); SB(); RED(4) NB(1, B_REH); NB(1, B_IMH); NB(1, B_REL); NA(0, A_H); NA(0, A_RH); SB();
-    GRP(6); SB(); RED(5) NA(0, A_L); NA(0, A_RL); NA(1, A_H); NA(1, A_RH); SB();
-    GRP(7); SB(); RED(6) SB();
+// group S: its twelve MFMAs with VALU pieces W0..W11 in the gaps behind them (an in-order wave: what is not placed between the MFMAs waits behind all twelve)
+#define S2G(S, W0, W1, W2, W3, W4, W5, W6, W7, W8, W9, W10, W11)                                   \
+  { SB(); s2_one<((S) >> 1), ((S) & 1), 0>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W0;   \
+    SB(); s2_one<((S) >> 1), ((S) & 1), 1>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W1;   \
+    SB(); s2_one<((S) >> 1), ((S) & 1), 2>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W2;   \
+    SB(); s2_one<((S) >> 1), ((S) & 1), 3>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W3;   \
+    SB(); s2_one<((S) >> 1), ((S) & 1), 4>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W4;   \
+    SB(); s2_one<((S) >> 1), ((S) & 1), 5>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W5;   \
+    SB(); s2_one<((S) >> 1), ((S) & 1), 6>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W6;   \
+    SB(); s2_one<((S) >> 1), ((S) & 1), 7>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W7;   \
+    SB(); s2_one<((S) >> 1), ((S) & 1), 8>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W8;   \
+    SB(); s2_one<((S) >> 1), ((S) & 1), 9>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W9;   \
+    SB(); s2_one<((S) >> 1), ((S) & 1), 10>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W10; \
+    SB(); s2_one<((S) >> 1), ((S) & 1), 11>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1]); SB(); W11; SB(); }
+// piece i of the reduction of group S (issued 3+ MFMAs after the last MFMA that wrote its tiles: nothing pads an asm MFMA)
+#define RP(S, i) mx = red_piece(mx, tE[(S) & 1], tO[(S) & 1], i)
+#define ST(S) { ep_store<((S) >> 1)>(mx, rd, st_base + ((S) >> 1) * 4 * n + g * 64); mx = -__builtin_inff(); }
+#define NONE2 ((void)0)
+    S2G(0, swap_r<1>(hb, 0, 1), swap_r<1>(hb, 1, 2), swap_r<1>(hb, 2, 3), swap_r<1>(hb, 3, 4), NONE2, NONE2, NONE2, NONE2, NONE2, NONE2, NONE2, NONE2)
+    S2G(1, NONE2, NONE2, NONE2, RP(0, 0), RP(0, 1), RP(0, 2), RP(0, 3), RP(0, 4), RP(0, 5), RP(0, 6), RP(0, 7), NONE2)
+    S2G(2, swap_r<2>(hb, 0, 2), swap_r<2>(hb, 2, 4), NONE2, RP(1, 0), RP(1, 1), RP(1, 2), RP(1, 3), RP(1, 4), RP(1, 5), RP(1, 6), RP(1, 7), ST(1))
+    S2G(3, NB(0, B_REH), NB(0, B_IMH), NB(0, B_REL), RP(2, 0), RP(2, 1), RP(2, 2), RP(2, 3), RP(2, 4), RP(2, 5), RP(2, 6), RP(2, 7), NB(0, B_IML))
+    S2G(4, swap_r<3>(hb, 0, 2), swap_r<3>(hb, 2, 4), NONE2, RP(3, 0), RP(3, 1), RP(3, 2), RP(3, 3), RP(3, 4), RP(3, 5), RP(3, 6), RP(3, 7), ST(3))
+    S2G(5, NB(1, B_REH), NB(1, B_IMH), NB(1, B_REL), RP(4, 0), RP(4, 1), RP(4, 2), RP(4, 3), RP(4, 4), RP(4, 5), RP(4, 6), RP(4, 7), NA(0, A_H))
+    S2G(6, NA(0, A_RH), NA(0, A_L), NA(0, A_RL), RP(5, 0), RP(5, 1), RP(5, 2), RP(5, 3), RP(5, 4), RP(5, 5), RP(5, 6), RP(5, 7), ST(5))
+    S2G(7, NA(1, A_H), NA(1, A_RH), NONE2, RP(6, 0), RP(6, 1), RP(6, 2), RP(6, 3), RP(6, 4), RP(6, 5), RP(6, 6), RP(6, 7), NONE2)
     asm volatile("s_nop 15\n\ts_nop 15");          // the last tiles are read next: nothing pads an asm MFMA
     SB();
-    RED(7)
+    RP(7, 0); RP(7, 1); RP(7, 2); RP(7, 3); RP(7, 4); RP(7, 5); RP(7, 6); RP(7, 7);
+    ST(7)
 #undef hb
     TICK(5)
     TICK(6)
