@@ -298,14 +298,19 @@ __global__ __launch_bounds__(256, 1) void sc_match_d_kernel(const char* __restri
 
     // ---------------------------------------------------------------- first half: frequencies 0..15
 #define hb hbs[0]
-    PAIR0(0) PAIR(0, 1) PAIR(0, 2) PAIR(0, 3) PAIR(0, 4) PAIR(0, 5) PAIR(0, 6) PAIR(0, 7)
+    PAIR0(0) PAIR(0, 1) PAIR(0, 2) PAIR(0, 3) PAIR(0, 4) PAIR(0, 5) PAIR(0, 6)
+    // pair 7 also hosts the swaps of elements 0, 1 (pairs 0, 1 / 4, 5: packed by now) of all four registers; elements 2, 3 follow in the tail
+    ADV()
+    FREQ(14, t1a, t2a, swap_r<0>(hb, 0, 1), { FM2(Fb, Mb, t1b, t2b, 0); swap_r<0>(hb, 1, 2); }, { FM2(Fb, Mb, t1b, t2b, 2); swap_r<1>(hb, 0, 1); },
+         { PKF(6, 0); swap_r<1>(hb, 1, 2); }, { PKM(6, 0); swap_r<2>(hb, 0, 1); }, { PKF(6, 1); swap_r<2>(hb, 1, 2); })
+    FREQ(15, t1b, t2b, { PKM(6, 1); swap_r<3>(hb, 0, 1); }, { PKF(6, 2); swap_r<3>(hb, 1, 2); }, PKM(6, 2), PKF(6, 3), PKM(6, 3), FMA_ALL(Fa, Ma, t1a, t2a))
     TICK(0)
     DRAIN();
     SB();
     FM2(Fb, Mb, t1b, t2b, 0); FM2(Fb, Mb, t1b, t2b, 2);
     PK(7, 0) PK(7, 1) PK(7, 2) PK(7, 3)
     SB();
-    swap_r<0>(hb, 0, 4); swap_r<1>(hb, 0, 4); swap_r<2>(hb, 0, 4); swap_r<3>(hb, 0, 4);   // the swaps need ArchVGPRs: before the operands are parked
+    swap_r<0>(hb, 2, 4); swap_r<1>(hb, 2, 4); swap_r<2>(hb, 2, 4); swap_r<3>(hb, 2, 4);   // the swaps need ArchVGPRs: before the operands are parked
     SB();
     park_r<0>(hb); park_r<1>(hb); park_r<2>(hb); park_r<3>(hb);
     SB();
