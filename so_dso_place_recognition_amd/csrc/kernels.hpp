@@ -56,6 +56,10 @@ void launch_sc_match_t(hipStream_t st, const void* qpk, int m, const void* dpk, 
 void launch_sc_match_r(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                        int nsplit_override);
 size_t sc_match_p_lds_bytes();
+// sc_match_e.hip — the pair-walk form (no row-exchanged query operand; see the file): single = 0: split-f16 (three products, 4 waves),
+// single = 1: one f16 product per term (PR_SC_ARITH_F16), 8 waves = two per SIMD; same packed images and constants as sc_match_h.hip
+void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
+                       int nsplit_override, int single);
 
 // m2dp_match.hip — processM2DP.m:12-22 for both channels.
 void launch_m2dp_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed, int tiles);

@@ -276,7 +276,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
   if (rc != PR_OK) { pr_destroy(ctx); return rc; }
   if (const char* s = getenv("PR_SC_NSPLIT")) ctx->sc_nsplit = atoi(s);
   if (const char* s = getenv("PR_SC_MATCH")) ctx->sc_mode = (strcmp(s, "f32") == 0) ? 1 : 0;
-  if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel_p = (strcmp(s, "p") == 0) ? 1 : (strcmp(s, "r") == 0) ? 2 : (strcmp(s, "t") == 0) ? 3 : (strcmp(s, "h") == 0) ? 0 : 4;
+  if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel_p = (strcmp(s, "p") == 0) ? 1 : (strcmp(s, "r") == 0) ? 2 : (strcmp(s, "t") == 0) ? 3 : (strcmp(s, "h") == 0) ? 0 : (strcmp(s, "e") == 0) ? 5 : (strcmp(s, "e1") == 0) ? 6 : 4;
   *out = ctx;
   return PR_OK;
 }
@@ -611,6 +611,8 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
     PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: the two sets were packed for different arithmetic modes");
   if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel_p == 4 && q->count > 8)
     pr::launch_sc_match_d(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit);
+  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel_p >= 5 && q->count > 8)
+    pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, ctx->sc_kernel_p == 6);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel_p == 3 && q->count > 8)
     pr::launch_sc_match_t(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_t, d_p, d_i, ctx->sc_nsplit);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel_p == 2 && q->count > 8)
