@@ -288,7 +288,7 @@ def main():
         kms = float(np.mean(kern_ms))
         pairs = m * (hi - lo)
         f16 = arith == "f16x2"
-        kname = {"h": "sc_match_h_kernel", "p": "sc_match_p_kernel", "r": "sc_match_r_kernel", "t": "sc_match_t_kernel"}.get(os.environ.get("PR_SC_KERNEL", "d"), "sc_match_d_kernel") if f16 else "sc_match_kernel"
+        kname = {"h": "sc_match_h_kernel", "d": "sc_match_d_kernel"}.get(os.environ.get("PR_SC_KERNEL", "e"), "sc_match_e_kernel") if f16 else "sc_match_kernel"
         fpp, peak = (FLOP_PER_PAIR_F16X2, MFMA_F16_PEAK_TFLOPS) if f16 else (FLOP_PER_PAIR, MFMA_F32_PEAK_TFLOPS)
         ach = pairs * fpp / (kms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)

@@ -42,20 +42,9 @@ void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int 
 void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p,
                        float* d_i, int nsplit_override);
 size_t sc_match_h_lds_bytes();
-// sc_match_p.hip — the same with two waves per SIMD sharing every unit (frequency-split stage 1, register-split stage 2); same packed
-// images, its own stage-2 constant table [4 quarters][E hh+hl | E lh | O hh+hl | O lh][64 lanes] x 16 B
-void launch_sc_match_p(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
-                       int nsplit_override);
 // sc_match_h.hip with stage 2 deferred to the end of the unit and transient tiles (sc_match_d.hip): same images and constants
 void launch_sc_match_d(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                        int nsplit_override);
-// transient stage-2 accumulators (sc_match_t.hip): same images; constants [E|O][shift rows 0-15|16-31][hi|lo][64 lanes] x 16 B
-void launch_sc_match_t(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
-                       int nsplit_override);
-// the rolling-pipeline form of sc_match_h.hip (sc_match_r.hip): same images, the constant table of sc_match_p.hip
-void launch_sc_match_r(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
-                       int nsplit_override);
-size_t sc_match_p_lds_bytes();
 // sc_match_e.hip — the pair-walk form (no row-exchanged query operand; see the file): single = 0: split-f16 (three products, 4 waves),
 // single = 1: one f16 product per term (PR_SC_ARITH_F16), 8 waves = two per SIMD; same packed images and constants as sc_match_h.hip
 void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,

@@ -36,9 +36,7 @@ struct pr_ctx {
   double* d_twiddle = nullptr;   // cos[60], sin[60] of 2*pi*t/60
   float* d_cst = nullptr;        // SC stage-2 constants [31][2][64]
   void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16] (sc_match_h.hip)
-  void* d_cst_t = nullptr;       // stage-2 constants of sc_match_t.hip: [E|O][shift rows 0-15|16-31][hi|lo][64 lanes][8 f16]
-  void* d_cst_p = nullptr;       // stage-2 constants of sc_match_p.hip: [quarter][E hh+hl | E lh | O hh+hl | O lh][64 lanes][8 f16]
-  int sc_kernel_p = 4;           // split-f16 SC matcher for m > 8: 4 = sc_match_d.hip (default), PR_SC_KERNEL=h|p|r|t selects sc_match_h / _p / _r / _t (0 / 1 / 2 / 3)
+  int sc_kernel = 2;             // split-f16 SC matcher for m > 8: 2 = sc_match_e.hip (default); PR_SC_KERNEL=d | h selects sc_match_d.hip (1, the round-2 default) / sc_match_h.hip (0, round 1; always the kernel for m <= 8)
   int sc_mode = PR_SC_ARITH_F16X2;   // PR_SC_ARITH_*: split-f16 MFMA (sc_match_h.hip) | fp32 MFMA (sc_match.hip); PR_SC_MATCH=f32 selects the latter
   double* d_planes = nullptr;    // M2DP xProj[64][3], yProj[64][3]
   int sc_nsplit = 0;             // PR_SC_NSPLIT override (experiments)
@@ -212,51 +210,6 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
       TRY(hipMalloc(&ctx->d_cst_h, ch.size() * sizeof(_Float16)));
       TRY(hipMemcpy(ctx->d_cst_h, ch.data(), ch.size() * sizeof(_Float16), hipMemcpyHostToDevice));
     }
-    {   // sc_match_p.hip: per quarter (8 frequencies) the A operands of v_mfma_f32_32x32x16_f16 against B = (S_hi | S_lo) by lane half:
-        // tile "hh+hl" = C_hi in BOTH lane halves, tile "lh" = C_lo in lanes 0-31 and 0 in lanes 32-63; same scaling (2^10) and shift rows
-      std::vector<_Float16> cp((size_t)4 * 4 * 64 * 8);
-      for (int qd = 0; qd < 4; qd++)
-        for (int eo = 0; eo < 2; eo++)
-          for (int l = 0; l < 64; l++)
-            for (int e = 0; e < 8; e++) {
-              int k = l & 31; if (k > 30) k = 30;
-              const int f = 8 * qd + e;
-              double v = 0.0;
-              if (f < pr::SC_NF) {
-                const int t = (f * k) % 60;
-                const double w = (f == 0 || f == 30) ? 1.0 : 2.0;
-                v = (eo == 0 ? w * tw[t] : -w * tw[60 + t]) * 1024.0;
-              }
-              const _Float16 hi = (_Float16)v;
-              const _Float16 lo = (_Float16)(v - (double)hi);
-              cp[((((size_t)qd * 4 + eo * 2 + 0) * 64) + l) * 8 + e] = hi;
-              cp[((((size_t)qd * 4 + eo * 2 + 1) * 64) + l) * 8 + e] = (l < 32) ? lo : (_Float16)0.0;
-            }
-      TRY(hipMalloc(&ctx->d_cst_p, cp.size() * sizeof(_Float16)));
-      TRY(hipMemcpy(ctx->d_cst_p, cp.data(), cp.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-    }
-    {   // sc_match_t.hip: A operands of v_mfma_f32_16x16x32_f16, lane = 16 (K group G) + shift row u: K slot 8 G + t = frequency 8 G + t
-      std::vector<_Float16> ct((size_t)2 * 2 * 2 * 64 * 8);
-      for (int eo = 0; eo < 2; eo++)
-        for (int part = 0; part < 2; part++)
-          for (int l = 0; l < 64; l++)
-            for (int t = 0; t < 8; t++) {
-              int k = 16 * part + (l & 15); if (k > 30) k = 30;
-              const int f = 8 * (l >> 4) + t;
-              double v = 0.0;
-              if (f < pr::SC_NF) {
-                const int tt = (f * k) % 60;
-                const double w = (f == 0 || f == 30) ? 1.0 : 2.0;
-                v = (eo == 0 ? w * tw[tt] : -w * tw[60 + tt]) * 1024.0;
-              }
-              const _Float16 hi = (_Float16)v;
-              const _Float16 lo = (_Float16)(v - (double)hi);
-              ct[((((size_t)eo * 2 + part) * 2 + 0) * 64 + l) * 8 + t] = hi;
-              ct[((((size_t)eo * 2 + part) * 2 + 1) * 64 + l) * 8 + t] = lo;
-            }
-      TRY(hipMalloc(&ctx->d_cst_t, ct.size() * sizeof(_Float16)));
-      TRY(hipMemcpy(ctx->d_cst_t, ct.data(), ct.size() * sizeof(_Float16), hipMemcpyHostToDevice));
-    }
     // M2DP plane table from the frozen float normals (M2DP/M2DP.cpp:9-30)
     double pl[2][64][3];
     for (int k = 0; k < 64; k++) {
@@ -276,7 +229,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
   if (rc != PR_OK) { pr_destroy(ctx); return rc; }
   if (const char* s = getenv("PR_SC_NSPLIT")) ctx->sc_nsplit = atoi(s);
   if (const char* s = getenv("PR_SC_MATCH")) ctx->sc_mode = (strcmp(s, "f32") == 0) ? 1 : 0;
-  if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel_p = (strcmp(s, "p") == 0) ? 1 : (strcmp(s, "r") == 0) ? 2 : (strcmp(s, "t") == 0) ? 3 : (strcmp(s, "h") == 0) ? 0 : (strcmp(s, "e") == 0) ? 5 : (strcmp(s, "e1") == 0) ? 6 : 4;
+  if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel = (strcmp(s, "h") == 0) ? 0 : (strcmp(s, "d") == 0) ? 1 : 2;
   *out = ctx;
   return PR_OK;
 }
@@ -302,8 +255,6 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->d_cst) (void)hipFree(ctx->d_cst);
   if (ctx->d_cst_h) (void)hipFree(ctx->d_cst_h);
-  if (ctx->d_cst_p) (void)hipFree(ctx->d_cst_p);
-  if (ctx->d_cst_t) (void)hipFree(ctx->d_cst_t);
   if (ctx->d_planes) (void)hipFree(ctx->d_planes);
   delete ctx;
 }
@@ -609,16 +560,10 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
   if (int rc = set_device(ctx)) return rc;
   if (q->type != PR_TYPE_DELIGHT && q->sc_mode != db->sc_mode)
     PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: the two sets were packed for different arithmetic modes");
-  if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel_p == 4 && q->count > 8)
+  if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && q->count > 8)
+    pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 0);
+  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 1 && q->count > 8)
     pr::launch_sc_match_d(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit);
-  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel_p >= 5 && q->count > 8)
-    pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, ctx->sc_kernel_p == 6);
-  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel_p == 3 && q->count > 8)
-    pr::launch_sc_match_t(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_t, d_p, d_i, ctx->sc_nsplit);
-  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel_p == 2 && q->count > 8)
-    pr::launch_sc_match_r(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_p, d_p, d_i, ctx->sc_nsplit);
-  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel_p == 1 && q->count > 8)
-    pr::launch_sc_match_p(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_p, d_p, d_i, ctx->sc_nsplit);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0)
     pr::launch_sc_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit);
   else if (q->type == PR_TYPE_SC)

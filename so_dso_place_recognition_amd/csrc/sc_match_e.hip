@@ -16,12 +16,20 @@
 //  * all packed operands stay in ArchVGPRs (nothing is parked in AccVGPRs, no v_accvgpr_write); the stage-2 constants are requested
 //    once per unit while the last stage-1 quad runs.
 //  * LO = false is the single-product arithmetic (PR_SC_ARITH_F16): operands hi only, one MFMA per product.
+#include <cstdlib>
+
 #include "kernels.hpp"
-#ifndef E_PP
-#define E_PP 2
-#endif
 #ifndef E_BD
-#define E_BD 3          // depth of the DB operand ring (tiles of E_BD - 1 frequencies in flight)
+#define E_BD 4          // depth of the DB operand ring, split-f16 form
+#endif
+#ifndef E_PK
+#define E_PK 0          // 1: F / M combination with v_pk_add_f32
+#endif
+#ifndef E_ABL
+#define E_ABL 0         // ablation hooks (timing experiments only; results are wrong by construction)
+#endif
+#ifndef E_BD1
+#define E_BD1 6         // the same, single-product form (a position is only two MFMAs long)
 #endif
 
 namespace pr {
@@ -54,11 +62,6 @@ __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int v
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, F * SCH_DFREQ + T * SCH_DTILE, 0);
   if (T == B_REH) b.reh = v; else if (T == B_REL) b.rel = v; else if (T == B_IMH) b.imh = v; else b.iml = v;
 }
-
-template <bool LO, int F, int T>
-__device__ __forceinline__ void req_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int voff) { if constexpr (LO || T == B_REH || T == B_IMH) load_b<F, T>(b, rs, voff); }
-template <bool LO, int T>
-__device__ __forceinline__ void req_a(AOps& a, unsigned addr) { if constexpr (LO || T == A_H) load_a<T>(a, addr); }
 
 // MFMAs as asm statements (VGPR form; hipcc pads nothing around asm, cdna_hip_programming.md §5.7): every VALU reader of a result sits
 // behind a DRAIN() or at least two further MFMAs + their fillers
@@ -145,12 +148,77 @@ __device__ __forceinline__ void ep_store(float mx, __amdgpu_buffer_rsrc_t rd, in
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(mx, -0x1p-26f, 0.5f)), rd, st_off, 0, 0);
 }
 
-template <bool LO, int NW>
+// ---------------------------------------------------------------------------------------------------------------- stage-1 schedule
+// The 32 walk positions of a unit form 8 quads (4 per half); quad QD computes T1 / T2' of frequencies (2E, 2E+8, 2E+1, 2E+9) of its half
+// into register set QD & 1:  T[set][0..7] = t1a, t2a, t1b, t2b (first pair), t1c, t2c, t1d, t2d (second pair).  A position has 6 gaps
+// (behind its 6 MFMAs; with one product per term the last four follow each other directly), a quad 24.  VALU work, 4 instructions per gap:
+//   gap 21..23 of quad QD and gap 0 of quad QD+1:  swap + combination of quad QD's FIRST pair  (in place: t1a = Re S, t1b = Im S, t2b = Re P, t2a = Im P)
+//   gap 1..4 of quad QD+1:                         swap + combination of quad QD's SECOND pair (t1c, t1d, t2d, t2c)
+//   gap 5..20 of quad QD+1:                        the 16 splits of quad QD -> element E of the half's 16 (32) operand tuples
+// so every reader of an MFMA result sits two or more MFMAs + eight VALU behind it, and set QD & 1 is free again when quad QD+2 starts.
+template <bool LO>
+__device__ __forceinline__ void swp2(f32x4& x, f32x4& y, f32x4& u, f32x4& v, int e) { swap32f(x, y, e); swap32f(u, v, e); }
+// X, Y, U, V -> Re S = X + V (in x), Re P = X - V (in v), Im S = Y - U (in y), Im P = Y + U (in u), registers r0, r0 + 1
+__device__ __forceinline__ void cmb2(f32x4& x, f32x4& y, f32x4& u, f32x4& v, int r0) {
+#if E_PK
+  const f32x2 _x = {x[r0], x[r0 + 1]}, _y = {y[r0], y[r0 + 1]}, _u = {u[r0], u[r0 + 1]}, _v = {v[r0], v[r0 + 1]};
+  const f32x2 _sr = _x + _v, _pr = _x - _v, _si = _y - _u, _pi = _y + _u;
+  x[r0] = _sr[0]; x[r0 + 1] = _sr[1]; v[r0] = _pr[0]; v[r0 + 1] = _pr[1];
+  y[r0] = _si[0]; y[r0 + 1] = _si[1]; u[r0] = _pi[0]; u[r0 + 1] = _pi[1];
+#else
+  // plain v_add / v_sub: beside MFMAs a v_pk_add_f32 costs ~10 cycles against ~4.4 for a plain VALU op (tools/ubench/mfma16_fillers.hip),
+  // and hipcc would SLP-pack adjacent adds on its own - hence asm
+#pragma unroll
+  for (int r = r0; r < r0 + 2; r++) {
+    float sr, pr, si, pi;
+    asm volatile("v_add_f32 %0, %4, %7\n\tv_sub_f32 %1, %4, %7\n\tv_sub_f32 %2, %5, %6\n\tv_add_f32 %3, %5, %6"
+                 : "=&v"(sr), "=&v"(pr), "=&v"(si), "=&v"(pi) : "v"(x[r]), "v"(y[r]), "v"(u[r]), "v"(v[r]));
+    x[r] = sr; v[r] = pr; y[r] = si; u[r] = pi;
+  }
+#endif
+}
+// (the empty volatile asm pins the packed value HERE: hipcc otherwise sinks the whole pure combine / convert chain down to its stage-2
+// consumer and keeps the fp32 values live instead - twice the registers)
+#define PIN(x) asm volatile("" : "+v"(x))
+template <bool LO, int E, int R, int KIND>
+__device__ __forceinline__ void split_piece(Half<LO>& hb, const f32x4 (&t)[8]) {
+  constexpr int ia = KIND == 0 ? 0 : KIND == 1 ? 2 : KIND == 2 ? 3 : 1;     // Re S: t1a|t1c, Im S: t1b|t1d, Re P: t2b|t2d, Im P: t2a|t2c
+  unsigned h, l = 0;
+  if constexpr (LO) { split2(t[ia][R], t[ia + 4][R], h, l); PIN(h); PIN(l); }
+  else { h = pack2(t[ia][R], t[ia + 4][R]); PIN(h); }
+  if constexpr (KIND == 0) { hb.reFh[R][E] = h; if constexpr (LO) hb.reFl[R][E] = l; }
+  if constexpr (KIND == 1) { hb.imFh[R][E] = h; if constexpr (LO) hb.imFl[R][E] = l; }
+  if constexpr (KIND == 2) { hb.reMh[R][E] = h; if constexpr (LO) hb.reMl[R][E] = l; }
+  if constexpr (KIND == 3) { hb.imMh[R][E] = h; if constexpr (LO) hb.imMl[R][E] = l; }
+}
+// the VALU work of gap G (0..23) of quad QD (0..8; 8 = the drain behind the last quad)
+template <bool LO, int QD, int G>
+__device__ __forceinline__ void valu_slot(f32x4 (&T)[2][8], Half<LO> (&hbs)[2]) {
+  constexpr int cur = QD & 1, prv = cur ^ 1;
+  if constexpr (QD >= 1) {            // quad QD - 1, in set prv
+    constexpr int PH = (QD - 1) >> 2, PE = (QD - 1) & 3;
+    f32x4 (&t)[8] = T[prv];
+    if constexpr (G == 0) cmb2(t[0], t[2], t[1], t[3], 2);
+    if constexpr (G == 1) { swp2<LO>(t[4], t[6], t[5], t[7], 0); swp2<LO>(t[4], t[6], t[5], t[7], 1); }
+    if constexpr (G == 2) cmb2(t[4], t[6], t[5], t[7], 0);
+    if constexpr (G == 3) { swp2<LO>(t[4], t[6], t[5], t[7], 2); swp2<LO>(t[4], t[6], t[5], t[7], 3); }
+    if constexpr (G == 4) cmb2(t[4], t[6], t[5], t[7], 2);
+    if constexpr (G >= 5 && G <= 20) split_piece<LO, PE, ((G - 5) >> 2), ((G - 5) & 3)>(hbs[PH], t);
+  }
+  if constexpr (QD <= 7) {            // this quad's first pair
+    f32x4 (&t)[8] = T[cur];
+    if constexpr (G == 21) { swp2<LO>(t[0], t[2], t[1], t[3], 0); swp2<LO>(t[0], t[2], t[1], t[3], 1); }
+    if constexpr (G == 22) cmb2(t[0], t[2], t[1], t[3], 0);
+    if constexpr (G == 23) { swp2<LO>(t[0], t[2], t[1], t[3], 2); swp2<LO>(t[0], t[2], t[1], t[3], 3); }
+  }
+}
+
+template <bool LO, int NW, int GSTEP>
 __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char* __restrict__ qpk,   // [2][QG32][4][31][1288 B]
                                                             const char* __restrict__ dpk,   // [2][DG][31][4][768 B] + zero groups
                                                             const u32x4* __restrict__ cst,  // [2][2][2][64] x 16 B
                                                             float* __restrict__ dist_p, float* __restrict__ dist_i,
-                                                            int m, int n, int QG8, int DG, int nsplit) {
+                                                            int m, int n, int QG8, int DG, int nsplit, int phase) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -171,8 +239,17 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
 
   const int row = lane & 15, kg = lane >> 4;
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds;
-  const int wq = w & 3, dpar = w >> 2;                    // (NW = 4: every wave takes every group)
-  constexpr int GSTEP = NW / 4;                    // query group inside the image; parity of this wave's DB groups
+  // query group inside the image; which of the GSTEP interleaved DB group sequences this wave takes.  NW = 4, GSTEP = 2: waves 0, 1 and
+  // waves 2, 3 walk different groups, so the two pairs are not held in step by shared L1 lines and their stage-1 (vector-memory bound)
+  // and stage-2 (matrix bound) phases can overlap
+  const int wq = w & 3, dpar = (NW == 8) ? (w >> 2) : 0;
+  // NW = 4, GSTEP = 2 ("split traversal"): waves 2, 3 walk the range from its middle (and wrap around), so the two wave pairs are never
+  // on the same group: nothing holds them in step, and one pair's stage 1 (vector-memory bound) can overlap the other's stage 2
+  constexpr bool SPLITW = (NW == 4 && GSTEP == 2);
+  constexpr int GINC = SPLITW ? 1 : GSTEP;
+  const int gcnt = g1 - g0, gshift = (SPLITW && (w >> 1)) ? gcnt / 2 : 0;
+  constexpr int BD = LO ? E_BD : E_BD1;            // depth of the DB operand ring: the tiles of BD - 1 walk positions are in flight
+  constexpr int AD = LO ? 2 : 3;                   // the same for the query tiles
   const unsigned nat0 = lds0 + wq * SCH_QIMG + row * 80 + (row >= 8 ? 8 : 0) + kg * 16;
   const int voff = (lane < 48) ? lane * 16 : (int)0x80000000;     // lanes 48-63: out of range -> zeros (K = 24..31)
   float* dist = ch ? dist_i : dist_p;
@@ -180,128 +257,106 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   const int qrow0 = qg32 * 32 + wq * 8;
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
       dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 8 ? m - qrow0 : 8) : 0) * n * 4, 0x00020000);
-  const int pf_slot = (qg32 & 31) * NW + w;                                 // 0..32 NW - 1
+  const int pf_slot = SPLITW ? (qg32 & 31) * 2 + (w & 1) : (qg32 & 31) * NW + w;   // this wave's share of the group(s) it helps to prefetch
+  constexpr int PFL = SPLITW ? 12 : 6;                                       // cache lines per wave
   unsigned pf_sink = 0;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(cst), 0, 8192, 0x00020000);
   if (g0 + dpar >= g1) return;
+  if (SPLITW && (w >> 1)) for (int i = 0; i < phase; i++) __builtin_amdgcn_s_sleep(100);   // start the second pair ~phase x 6.4 k cycles late
 
-  AOps At[2];
-  BOps Bt[E_BD];
+  AOps At[AD];
+  BOps Bt[BD];
   __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g0 + dpar) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
-#define NB(P, T) (req_b<LO, seqf(P), T>(Bt[P], RS, voff))
-#define NA(T) (req_a<LO, T>(At[0], nat0))
-#define NB1(T) (req_b<LO && E_BD == 3 || (!LO && E_BD == 3 && (T == B_REH || T == B_IMH)), seqf(1), T>(Bt[1 % E_BD], RS, voff))
-#define RS rs
-  NB(0, B_REH); NB(0, B_IMH); NB(0, B_REL); NB(0, B_IML);
-  NA(A_H); NA(A_L);
-  if constexpr (E_BD == 3) { NB(1, B_REH); NB(1, B_IMH); NB(1, B_REL); NB(1, B_IML); }
-#undef RS
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g0 + dpar + gshift) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
+// request K of the first ones of a unit (issued before the loop for the first unit, in the stage-2 gaps of the previous unit otherwise):
+// the DB tiles of walk positions 0 .. BD - 2 (TPB tiles each), then the query tiles of positions 0 .. AD - 2
+  constexpr int TPB = LO ? 4 : 2, TPA = LO ? 2 : 1, NREQ = (BD - 1) * TPB + (AD - 1) * TPA;
+#define FIRST_REQ(K, RSRC)                                                                                         \
+  { if constexpr ((K) < (BD - 1) * TPB) {                                                                          \
+      constexpr int _p = (K) / TPB, _t = LO ? (K) % TPB : 2 * ((K) % TPB);      /* order Re hi, (Re lo), Im hi, (Im lo) */ \
+      constexpr int _tt = LO ? (_t == 1 ? B_IMH : _t == 2 ? B_REL : _t == 3 ? B_IML : B_REH) : _t;                 \
+      load_b<seqf(_p), _tt>(Bt[_p % BD], RSRC, voff);                                                              \
+    } else if constexpr ((K) < NREQ) {                                                                             \
+      constexpr int _k = (K) - (BD - 1) * TPB, _p = _k / TPA, _t = _k % TPA;                                       \
+      load_a<_t>(At[_p % AD], nat0 + seqf(_p) * SCH_QBLK);                                                         \
+    } }
+  FIRST_REQ(0, rs) FIRST_REQ(1, rs) FIRST_REQ(2, rs) FIRST_REQ(3, rs) FIRST_REQ(4, rs) FIRST_REQ(5, rs) FIRST_REQ(6, rs) FIRST_REQ(7, rs)
+  FIRST_REQ(8, rs) FIRST_REQ(9, rs) FIRST_REQ(10, rs) FIRST_REQ(11, rs) FIRST_REQ(12, rs) FIRST_REQ(13, rs) FIRST_REQ(14, rs) FIRST_REQ(15, rs)
+  FIRST_REQ(16, rs) FIRST_REQ(17, rs) FIRST_REQ(18, rs) FIRST_REQ(19, rs) FIRST_REQ(20, rs) FIRST_REQ(21, rs) FIRST_REQ(22, rs) FIRST_REQ(23, rs)
+  static_assert(NREQ <= 24, "FIRST_REQ list too short");
 
-  for (int g = g0 + dpar; g < g1; g += GSTEP) {
+  for (int gi = dpar; gi < gcnt; gi += GINC) {
+    // group of this iteration and of the next (the image ends with zero groups: the request past the last group is harmless)
+    const int gs0 = gi + gshift, gs1 = gi + GINC + gshift;
+    const int g = g0 + (gs0 >= gcnt ? gs0 - gcnt : gs0);
+    const int gn = (SPLITW && gi + GINC < gcnt) ? g0 + (gs1 >= gcnt ? gs1 - gcnt : gs1) : g + GINC;
     const __amdgpu_buffer_rsrc_t rsn =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g + GSTEP) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)gn * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
     Half<LO> hbs[2];
+    if constexpr ((E_ABL & 8) != 0) { for (int h_ = 0; h_ < 2; h_++) for (int r_ = 0; r_ < 4; r_++) { hbs[h_].reFh[r_] = hbs[h_].imFh[r_] = hbs[h_].reMh[r_] = hbs[h_].imMh[r_] = u32x4{0u, 0u, 0u, 0u}; if constexpr (LO) hbs[h_].reFl[r_] = hbs[h_].imFl[r_] = hbs[h_].reMl[r_] = hbs[h_].imMl[r_] = u32x4{0u, 0u, 0u, 0u}; } }
     Consts c0, c1;
-    f32x4 t1a, t2a, t1b, t2b, t1c, t2c, t1d, t2d;
-    unsigned na, nb, nnxt = nat0;          // LDS addresses of the pair's two hi tiles (f, f + 8) and of the next pair's first
+    f32x4 T[2][8];
 
-// request tile T of walk position Q of this group (Q >= 31: nothing - the next group's first requests are issued in stage 2)
-#define LDB(Q, T) { if constexpr (seqf(Q) < SC_NF && (Q) < 32 && (LO || (T == B_REH || T == B_IMH))) load_b<(seqf(Q) < SC_NF ? seqf(Q) : 0), T>(Bt[(Q) % E_BD], rs, voff); }
-// query tiles of walk position Q = P + 1, requested during position P: the partner of the pair (odd Q) or the next pair's first (even Q)
-#define LDA(Q, T) { if constexpr (seqf(Q) < SC_NF && (Q) < 32 && (LO || T == A_H)) { if constexpr (((Q) & 1) != 0) load_a<T>(At[(Q) & 1], nb); else load_a<T>(At[(Q) & 1], nnxt); } }
-// start of the pair at walk position P (even): this pair's addresses, and the next pair's (the half boundary jumps 9 blocks)
-#define ADV(P) { na = nnxt; nb = na + 8 * SCH_QBLK; nnxt = na + ((((P) & 15) == 14) ? 9 : 1) * SCH_QBLK; asm("" : "+v"(nb)); asm("" : "+v"(nnxt)); }
-#define NONE ((void)0)
-// one frequency (walk position P): its 6 (LO) or 2 MFMAs, the requests for positions P + 1 (query tiles) and P + 2 (DB tiles), and
-// VALU pieces W0..W5 in the gaps
-#define FREQ(P, t1, t2, W0, W1, W2, W3, W4, W5)                                                                  \
+// request tile T of walk position Q of this unit (Q >= 31: nothing)
+#define LDB(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || (TT == B_REH || TT == B_IMH)) && !(E_ABL & 2) && (!(E_ABL & 1) || TT == B_REH || TT == B_IMH)) load_b<seqf((Q) < 32 ? (Q) : 0), TT>(Bt[(Q) % BD], rs, voff); }
+#define LDA(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || TT == A_H) && !(E_ABL & 4)) load_a<TT>(At[(Q) % AD], nat0 + seqf((Q) < 32 ? (Q) : 0) * SCH_QBLK); }
+#define VS(P, G) { if constexpr (!(E_ABL & 8)) valu_slot<LO, ((P) >> 2), (((P) & 3) * 6 + (G))>(T, hbs); }
+// one walk position: its 6 (LO) or 2 MFMAs, the requests for positions P + AD - 1 (query tiles) and P + BD - 1 (DB tiles), the quad's VALU
+// work of these six gaps
+#define FREQ(P)                                                                                                  \
   {                                                                                                              \
-    SB(); MF0(t1, At[(P) & 1].h, Bt[(P) % E_BD].reh); SB(); LDA((P) + 1, A_H); W0;                                  \
-    SB(); MF0(t2, At[(P) & 1].h, Bt[(P) % E_BD].imh); SB(); LDA((P) + 1, A_L); W1;                                  \
-    SB(); if constexpr (LO) MFA(t1, At[(P) & 1].l, Bt[(P) % E_BD].reh); SB(); LDB((P) + E_BD - 1, B_REH); W2;                        \
-    SB(); if constexpr (LO) MFA(t2, At[(P) & 1].l, Bt[(P) % E_BD].imh); SB(); LDB((P) + E_BD - 1, B_IMH); W3;                        \
-    SB(); if constexpr (LO) MFA(t1, At[(P) & 1].h, Bt[(P) % E_BD].rel); SB(); LDB((P) + E_BD - 1, B_REL); W4;                        \
-    SB(); if constexpr (LO) MFA(t2, At[(P) & 1].h, Bt[(P) % E_BD].iml); SB(); LDB((P) + E_BD - 1, B_IML); W5;                        \
-    SB();                                                                                                        \
+    f32x4& t1 = T[((P) >> 2) & 1][2 * ((P) & 3)];                                                                \
+    f32x4& t2 = T[((P) >> 2) & 1][2 * ((P) & 3) + 1];                                                            \
+    if constexpr (seqf(P) < SC_NF) {                                                                             \
+      SB(); MF0(t1, At[(P) % AD].h, Bt[(P) % BD].reh); SB(); LDA((P) + AD - 1, A_H); VS(P, 0);                   \
+      SB(); MF0(t2, At[(P) % AD].h, Bt[(P) % BD].imh); SB(); LDA((P) + AD - 1, A_L); VS(P, 1);                   \
+      SB(); if constexpr (LO) MFA(t1, At[(P) % AD].l, Bt[(P) % BD].reh); SB(); LDB((P) + BD - 1, B_REH); VS(P, 2); \
+      SB(); if constexpr (LO) MFA(t2, At[(P) % AD].l, Bt[(P) % BD].imh); SB(); LDB((P) + BD - 1, B_IMH); VS(P, 3); \
+      SB(); if constexpr (LO) MFA(t1, At[(P) % AD].h, Bt[(P) % BD].rel); SB(); LDB((P) + BD - 1, B_REL); VS(P, 4); \
+      SB(); if constexpr (LO) MFA(t2, At[(P) % AD].h, Bt[(P) % BD].iml); SB(); LDB((P) + BD - 1, B_IML); VS(P, 5); \
+      SB();                                                                                                      \
+    } else {                                                                                                     \
+      t1 = f32x4{0.f, 0.f, 0.f, 0.f}; t2 = t1;          /* the ghost frequency 31 */                              \
+      SB(); VS(P, 0); SB(); VS(P, 1); SB(); VS(P, 2); SB(); VS(P, 3); SB(); VS(P, 4); SB(); VS(P, 5); SB();       \
+    }                                                                                                            \
   }
-// (T1_f, T1_f+8, T2'_f, T2'_f+8) -> X, Y, U, V (in place), then Re S, Im S, Re P, Im P (in place: x <- X + V, v <- X - V, y <- Y - U, u <- Y + U)
-#define SWP(x, y, u, v, e) { swap32f(x, y, e); swap32f(u, v, e); }
-#define CMB(x, y, u, v, r0)                                                                       \
-  {                                                                                               \
-    const f32x2 _x = {x[r0], x[r0 + 1]}, _y = {y[r0], y[r0 + 1]}, _u = {u[r0], u[r0 + 1]}, _v = {v[r0], v[r0 + 1]}; \
-    const f32x2 _sr = _x + _v, _pr = _x - _v, _si = _y - _u, _pi = _y + _u;                       \
-    x[r0] = _sr[0]; x[r0 + 1] = _sr[1]; v[r0] = _pr[0]; v[r0 + 1] = _pr[1];                       \
-    y[r0] = _si[0]; y[r0 + 1] = _si[1]; u[r0] = _pi[0]; u[r0 + 1] = _pi[1];                       \
-  }
-// after CMB: t1a = Re S, t1b = Im S, t2b = Re P, t2a = Im P of the quad's first pair; t1c, t1d, t2d, t2c of its second pair.
-// element E of the half's operands for register R
-// (the empty volatile asm pins the packed value HERE: hipcc otherwise sinks the whole pure combine / convert chain down to its stage-2
-// consumer and keeps the fp32 values live instead - twice the registers)
-#define PIN(x) asm volatile("" : "+v"(x))
-#define PKQ(E, R)                                                                                 \
-  {                                                                                               \
-    if constexpr (LO) {                                                                           \
-      unsigned _h, _l;                                                                            \
-      split2(t1a[R], t1c[R], _h, _l); PIN(_h); PIN(_l); hb.reFh[R][E] = _h; hb.reFl[LO ? R : 0][E] = _l; \
-      split2(t1b[R], t1d[R], _h, _l); PIN(_h); PIN(_l); hb.imFh[R][E] = _h; hb.imFl[LO ? R : 0][E] = _l; \
-      split2(t2b[R], t2d[R], _h, _l); PIN(_h); PIN(_l); hb.reMh[R][E] = _h; hb.reMl[LO ? R : 0][E] = _l; \
-      split2(t2a[R], t2c[R], _h, _l); PIN(_h); PIN(_l); hb.imMh[R][E] = _h; hb.imMl[LO ? R : 0][E] = _l; \
-    } else {                                                                                      \
-      unsigned _a = pack2(t1a[R], t1c[R]), _b = pack2(t1b[R], t1d[R]), _c = pack2(t2b[R], t2d[R]), _d = pack2(t2a[R], t2c[R]); \
-      PIN(_a); PIN(_b); PIN(_c); PIN(_d);                                                         \
-      hb.reFh[R][E] = _a; hb.imFh[R][E] = _b; hb.reMh[R][E] = _c; hb.imMh[R][E] = _d;             \
-    }                                                                                             \
-  }
-// quad E of half H: walk positions 16 H + 4 E .. + 3 = frequencies (2E, 2E+8, 2E+1, 2E+9) of the half
-#define QUAD(H, E, X0, X1)                                                                        \
-  ADV(16 * (H) + 4 * (E))                                                                         \
-  FREQ(16 * (H) + 4 * (E), t1a, t2a, NONE, NONE, NONE, NONE, NONE, NONE)                          \
-  FREQ(16 * (H) + 4 * (E) + 1, t1b, t2b, NONE, NONE, NONE, NONE, NONE, NONE)                      \
-  ADV(16 * (H) + 4 * (E) + 2)                                                                     \
-  FREQ(16 * (H) + 4 * (E) + 2, t1c, t2c, NONE, NONE, SWP(t1a, t1b, t2a, t2b, 0), SWP(t1a, t1b, t2a, t2b, 1), SWP(t1a, t1b, t2a, t2b, 2), SWP(t1a, t1b, t2a, t2b, 3)) \
-  if constexpr (seqf(16 * (H) + 4 * (E) + 3) < SC_NF) {                                                 \
-    FREQ(16 * (H) + 4 * (E) + 3, t1d, t2d, NONE, CMB(t1a, t1b, t2a, t2b, 0), NONE, CMB(t1a, t1b, t2a, t2b, 2), X0, X1) \
-  } else {                                                                                        \
-    t1d = f32x4{0.f, 0.f, 0.f, 0.f}; t2d = t1d;                                                   \
-    CMB(t1a, t1b, t2a, t2b, 0) CMB(t1a, t1b, t2a, t2b, 2) X0; X1;                                 \
-  }                                                                                               \
-  SB(); DRAIN(); SB();                                                                            \
-  SWP(t1c, t1d, t2c, t2d, 0) SWP(t1c, t1d, t2c, t2d, 1) SWP(t1c, t1d, t2c, t2d, 2) SWP(t1c, t1d, t2c, t2d, 3) \
-  CMB(t1c, t1d, t2c, t2d, 0) CMB(t1c, t1d, t2c, t2d, 2)                                           \
-  PKQ(E, 0) PKQ(E, 1) PKQ(E, 2) PKQ(E, 3)                                                         \
-  SB();
-
-#define hb hbs[0]
-    QUAD(0, 0, NONE, NONE) QUAD(0, 1, NONE, NONE) QUAD(0, 2, NONE, NONE) QUAD(0, 3, NONE, NONE)
-#undef hb
+    FREQ(0) FREQ(1) FREQ(2) FREQ(3) FREQ(4) FREQ(5) FREQ(6) FREQ(7) FREQ(8) FREQ(9) FREQ(10) FREQ(11) FREQ(12) FREQ(13) FREQ(14) FREQ(15)
+    FREQ(16) FREQ(17) FREQ(18) FREQ(19)
+    // (quad 4 has just finished the splits of quad 3: the first half's operands are complete)
     if constexpr (NW == 4) { SB(); park_half<LO>(hbs[0]); SB(); }      // one wave per SIMD: 512 registers, half of them AccVGPRs
-#define hb hbs[1]
-    QUAD(1, 0, NONE, NONE) QUAD(1, 1, NONE, NONE) QUAD(1, 2, NONE, NONE)
+    FREQ(20) FREQ(21) FREQ(22) FREQ(23) FREQ(24) FREQ(25) FREQ(26) FREQ(27)
     // the last quad also requests the stage-2 constants (the operand rings are draining)
-    QUAD(1, 3, (load_consts<0, LO>(c0, rc, lane * 16)), (load_consts<1, LO>(c1, rc, lane * 16)))
-#undef hb
-    {  // L2 prefetch for the whole XCD: the 256 waves that sweep this range on this XCD cover the two groups of the iteration after next
-       // (1488 cache lines) with 6 lines each, one dword per line into a register nobody reads before the same point of the next unit
+    FREQ(28) FREQ(29)
+    load_consts<0, LO>(c0, rc, lane * 16);
+    FREQ(30)
+    load_consts<1, LO>(c1, rc, lane * 16);
+    FREQ(31)
+    SB(); DRAIN(); SB();
+#define VD(G) { if constexpr (!(E_ABL & 8)) valu_slot<LO, 8, G>(T, hbs); }
+    VD(0) VD(1) VD(2) VD(3) VD(4) VD(5) VD(6) VD(7) VD(8) VD(9) VD(10) VD(11) VD(12) VD(13) VD(14) VD(15) VD(16) VD(17) VD(18) VD(19) VD(20)
+    SB();
+    {  // L2 prefetch for the whole XCD: the 32 NW waves that sweep this range on this XCD cover the group(s) of the iteration after next
+       // with 6 cache lines each, one dword per line into a register nobody reads before the same point of the next unit
       asm volatile("" : : "v"(pf_sink));
-      const int gp = (g - dpar) + 2 * GSTEP;
-      const int pf_bytes = (gp + GSTEP <= DG) ? GSTEP * SCH_DIMG : (gp < DG ? (DG - gp) * SCH_DIMG : 0);
+      const int gs2 = gi + 2 * GINC + gshift;
+      const int gp = SPLITW ? g0 + (gs2 >= gcnt ? gs2 - gcnt : gs2) : (g - dpar) + 2 * GSTEP;
+      constexpr int PFG = SPLITW ? 1 : GSTEP;
+      const int pf_bytes = (SPLITW && gi + 2 * GINC >= gcnt) ? 0 : (gp + PFG <= DG) ? PFG * SCH_DIMG : (gp < DG ? (DG - gp) * SCH_DIMG : 0);
       const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)gp * SCH_DIMG), 0, pf_bytes, 0x00020000);
       int lp = lane;
       asm volatile("" : "+v"(lp));
-      const int pf_off = (lp < 6) ? (pf_slot * 6 + lp) * 128 : (int)0x80000000;   // 32 NW waves x 6 lines >= GSTEP x 744 lines
+      const int pf_off = (lp < PFL) ? (pf_slot * PFL + lp) * 128 : (int)0x80000000;   // waves x PFL lines >= 744 lines per group
       pf_sink = __builtin_amdgcn_raw_buffer_load_b32(rp, pf_off, 0, 0);
     }
     // ---------------------------------------------------------------- stage 2: group S = 2 R + V, its MFMAs into a fresh (E, O) tile pair;
     // group S + 1 is issued before group S is reduced; the first requests of the next unit sit between the groups
-    constexpr int PP = E_PP;
-    f32x16 tE[PP], tO[PP];
+    f32x16 tE[2], tO[2];
     float mx = -__builtin_inff();
     int le = lane;
     asm volatile("" : "+v"(le));
     const int st_lane = ((le & 16) ? 4 * n : 0) * 4 + (le & 15) * 4;
     const int st_base = (le < 32 && g * 16 + (le & 15) < n) ? st_lane : (int)0x80000000;
-#define S2I(S, I) s2_one<LO, (NW == 4), ((S) >> 1), ((S) & 1), I>(hbs[0], hbs[1], c0, c1, tE[(S) & (PP - 1)], tO[(S) & (PP - 1)])
+#define S2I(S, I) if constexpr (!(E_ABL & 16) || (I) < 2) s2_one<LO, (NW == 4), ((S) >> 1), ((S) & 1), I>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1])
 #define S2G(S, W0, W1, W2, W3, W4, W5, W6, W7, W8, W9, W10, W11)                                   \
   { if constexpr (LO) {                                                                            \
     SB(); S2I(S, 0); SB(); W0;  SB(); S2I(S, 1); SB(); W1;  SB(); S2I(S, 2); SB(); W2;             \
@@ -311,38 +366,22 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   } else {                                                                                         \
     SB(); S2I(S, 0); SB(); W0; W1; W2; SB(); S2I(S, 1); SB(); S2I(S, 2); SB(); W3; W4; W5;         \
     W6; W7; W8; SB(); S2I(S, 3); SB(); W9; W10; W11; SB(); } }
-#define RP(S, i) mx = red_piece(mx, tE[(S) & (PP - 1)], tO[(S) & (PP - 1)], i)
+#define RP(S, i) mx = red_piece(mx, tE[(S) & 1], tO[(S) & 1], i)
 #define ST(S) { ep_store(mx, rd, st_base + ((S) >> 1) * 4 * n + g * 64); mx = -__builtin_inff(); }
-#define RS rsn
-    if constexpr (PP == 2) {
+#define NX(K) FIRST_REQ(K, rsn)
+#define NONE ((void)0)
     S2G(0, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE)
-    S2G(1, NONE, NONE, NONE, RP(0, 0), RP(0, 1), RP(0, 2), RP(0, 3), RP(0, 4), RP(0, 5), RP(0, 6), RP(0, 7), NONE)
-    S2G(2, NONE, NONE, NONE, RP(1, 0), RP(1, 1), RP(1, 2), RP(1, 3), RP(1, 4), RP(1, 5), RP(1, 6), RP(1, 7), ST(1))
-    S2G(3, NB(0, B_REH), NB(0, B_IMH), NB(0, B_REL), RP(2, 0), RP(2, 1), RP(2, 2), RP(2, 3), RP(2, 4), RP(2, 5), RP(2, 6), RP(2, 7), NB(0, B_IML))
-    S2G(4, NA(A_H), NA(A_L), NONE, RP(3, 0), RP(3, 1), RP(3, 2), RP(3, 3), RP(3, 4), RP(3, 5), RP(3, 6), RP(3, 7), ST(3))
-    S2G(5, NB1(B_REH), NB1(B_IMH), NB1(B_REL), RP(4, 0), RP(4, 1), RP(4, 2), RP(4, 3), RP(4, 4), RP(4, 5), RP(4, 6), RP(4, 7), NB1(B_IML))
-    S2G(6, NONE, NONE, NONE, RP(5, 0), RP(5, 1), RP(5, 2), RP(5, 3), RP(5, 4), RP(5, 5), RP(5, 6), RP(5, 7), ST(5))
-    S2G(7, NONE, NONE, NONE, RP(6, 0), RP(6, 1), RP(6, 2), RP(6, 3), RP(6, 4), RP(6, 5), RP(6, 6), RP(6, 7), NONE)
+    S2G(1, NX(16), NX(17), NX(18), RP(0, 0), RP(0, 1), RP(0, 2), RP(0, 3), RP(0, 4), RP(0, 5), RP(0, 6), RP(0, 7), NX(19))
+    S2G(2, NX(0), NX(1), NX(20), RP(1, 0), RP(1, 1), RP(1, 2), RP(1, 3), RP(1, 4), RP(1, 5), RP(1, 6), RP(1, 7), ST(1))
+    S2G(3, NX(2), NX(3), NX(4), RP(2, 0), RP(2, 1), RP(2, 2), RP(2, 3), RP(2, 4), RP(2, 5), RP(2, 6), RP(2, 7), NX(22))
+    S2G(4, NX(5), NX(6), NX(21), RP(3, 0), RP(3, 1), RP(3, 2), RP(3, 3), RP(3, 4), RP(3, 5), RP(3, 6), RP(3, 7), ST(3))
+    S2G(5, NX(7), NX(8), NX(9), RP(4, 0), RP(4, 1), RP(4, 2), RP(4, 3), RP(4, 4), RP(4, 5), RP(4, 6), RP(4, 7), NX(23))
+    S2G(6, NX(10), NX(11), NX(12), RP(5, 0), RP(5, 1), RP(5, 2), RP(5, 3), RP(5, 4), RP(5, 5), RP(5, 6), RP(5, 7), ST(5))
+    S2G(7, NX(13), NX(14), NX(15), RP(6, 0), RP(6, 1), RP(6, 2), RP(6, 3), RP(6, 4), RP(6, 5), RP(6, 6), RP(6, 7), NONE)
     asm volatile("s_nop 15\n\ts_nop 15");          // the last tiles are read next: nothing pads an asm MFMA
     SB();
     RP(7, 0); RP(7, 1); RP(7, 2); RP(7, 3); RP(7, 4); RP(7, 5); RP(7, 6); RP(7, 7);
     ST(7)
-    } else {
-// one tile pair: the group's MFMAs, then (behind the wait states nothing else provides) its reduction; the partner wave has the pipe meanwhile
-#define S2R(S, W0, W1, W2, W3)                                                                   \
-    S2G(S, W0, W1, W2, W3, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE)                        \
-    asm volatile("s_nop 15\n\ts_nop 15"); SB();                                                   \
-    RP(S, 0); RP(S, 1); RP(S, 2); RP(S, 3); RP(S, 4); RP(S, 5); RP(S, 6); RP(S, 7); SB();
-    S2R(0, NONE, NONE, NONE, NONE)
-    S2R(1, NONE, NONE, NONE, NONE) ST(1)
-    S2R(2, NB(0, B_REH), NB(0, B_IMH), NB(0, B_REL), NB(0, B_IML))
-    S2R(3, NA(A_H), NA(A_L), NONE, NONE) ST(3)
-    S2R(4, NB1(B_REH), NB1(B_IMH), NB1(B_REL), NB1(B_IML))
-    S2R(5, NONE, NONE, NONE, NONE) ST(5)
-    S2R(6, NONE, NONE, NONE, NONE)
-    S2R(7, NONE, NONE, NONE, NONE) ST(7)
-    }
-#undef RS
     rs = rsn;
   }
 }
@@ -360,12 +399,16 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
   if (nsplit > DG / 32) nsplit = DG / 32;
   if (nsplit < 1) nsplit = 1;
   if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
+  static const int phase = getenv("PR_SC_E_PHASE") ? atoi(getenv("PR_SC_E_PHASE")) : 1;
+  static const int gs = getenv("PR_SC_E_GS") ? atoi(getenv("PR_SC_E_GS")) : 1;
   auto go = [&](auto kern, int nw) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes());
     hipLaunchKernelGGL(kern, dim3(8 * QG32 * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(), st, static_cast<const char*>(qpk),
-                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit);
+                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, phase);
   };
-  if (single) go(sc_match_e_kernel<false, 8>, 8); else go(sc_match_e_kernel<true, 4>, 4);
+  if (single) go(sc_match_e_kernel<false, 8, 2>, 8);
+  else if (gs == 2) go(sc_match_e_kernel<true, 4, 2>, 4);
+  else go(sc_match_e_kernel<true, 4, 1>, 4);
 }
 
 }  // namespace pr
