@@ -27,13 +27,19 @@ enum { PR_ROLE_QUERY = 0, PR_ROLE_DB = 1 };         /* hist1 / hist2 of run_test
 enum { PR_F64 = 0, PR_F32 = 1 };
 enum { PR_HOST = 0, PR_DEVICE = 1 };
 /* arithmetic of the SC and M2DP matchers (processSC.m:22-33, processM2DP.m:12-22 on the GPU): split-f16 (fp32 operands carried
- * as f16 hi + lo, three f16 MFMAs per product, fp32 accumulate; default, 2-3x faster, same 1e-7 error as fp32) or plain fp32 MFMA */
-enum { PR_SC_ARITH_F16X2 = 0, PR_SC_ARITH_F32 = 1 };
+ * as f16 hi + lo, three f16 MFMAs per product, fp32 accumulate; default, 2-3x faster, same 1e-7 error as fp32), plain fp32 MFMA, or
+ * PR_SC_ARITH_F16 = BASELINE.json config 5's "fp16 descriptors": spectra / rows stored as ONE f16 (2976 B per SC entry and channel),
+ * one f16 MFMA per product, fp32 accumulate.  No reference counterpart (run_test.m handles fp64 only).  Its all-pairs distances are
+ * within PR_F16_DISTANCE_BOUND of the exact ones (worst case; ~1.3e-4 observed; SURVEY.md asks for 1e-3 on typical data); the top-k
+ * calls keep EXACT indices: the k + 56 best of the f16 pass are re-evaluated in fp64, and a query whose candidate list does not provably
+ * contain the exact top-k (pr_f16_margin_dev) is recomputed in split-f16 (host calls: automatically, PR_WARN_F16_FALLBACK is raised) */
+#define PR_F16_DISTANCE_BOUND 2e-3   /* |d_f16 - d| per channel: 8 u (u = 2^-11) on the correlation of unit-norm rows, halved */
+enum { PR_SC_ARITH_F16X2 = 0, PR_SC_ARITH_F32 = 1, PR_SC_ARITH_F16 = 2 };
 /* What a zero-norm SC row does.  MATLAB divides 0/0 (processSC.m:16,19): every distance to or from that signature is NaN, and
  * normalize(.,2) / min (run_test.m:40,57) leave NaNs out [normalize's 'omitnan' from memory], so the signature simply never matches.
  * PR_NAN_EXCLUDE (default) does exactly that and reports PR_WARN_NAN_ROWS; PR_NAN_FAIL turns it into the error PR_ENAN at pr_sync. */
 enum { PR_NAN_EXCLUDE = 0, PR_NAN_FAIL = 1 };
-enum { PR_WARN_NAN_ROWS = 1, PR_WARN_M2DP_SVD = 2 };   /* bits of pr_take_warnings */
+enum { PR_WARN_NAN_ROWS = 1, PR_WARN_M2DP_SVD = 2, PR_WARN_F16_FALLBACK = 4 };   /* bits of pr_take_warnings */
 
 #define PR_SC_SIG_LEN 2400    /* 2 x numS*numR = 2 x 60*20, SC/SC.h:7-8, test_sc.cpp:37-38 */
 #define PR_M2DP_SIG_LEN 384   /* 2 x (numP*numQ + numS*numR) = 2 x 192, M2DP/M2DP.h:7-10, test_m2dp.cpp:37-39 */
@@ -157,6 +163,16 @@ int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
  * DEVICE [4m][384] / [4 n_local][384] or NULL (both pairs given = BASELINE config 5's sum of four z-scores); dtype PR_F64 | PR_F32;
  * mom_sc / mom_m2: DEVICE [G][m][2][3] as pr_row_moments_dev writes them.  idx_in: DEVICE [m][k_in] global indices inside
  * [db_row0, db_row0 + n_local) or -1.  idx: DEVICE [m][k], score: DEVICE f64 [m][k].  k_in <= 128. */
+/* Width of the candidate list the top-k protocol re-evaluates for k results in the context's arithmetic: k + 8, or k + 56 in
+ * PR_SC_ARITH_F16 (capped at 128). */
+int pr_rerank_width(const pr_ctx* ctx, int32_t k);
+/* PR_SC_ARITH_F16 only: after pr_rerank_dev / pr_rerank_finish_dev, flags[q] = 1 (DEVICE i32 [m]) for every query whose candidate list
+ * (cand_score: the f16 pass scores of the k_in candidates, DEVICE f64 [m][k_in], ascending as pr_fuse_select_dev / pr_merge_topk_dev
+ * return them) does not provably contain the exact top-k: exact k-th score (score: DEVICE f64 [m][k]) >= last candidate's pass score
+ * minus the score error bound that PR_F16_DISTANCE_BOUND implies with the row's statistics (mom_*: as for pr_rerank_dev).
+ * count: DEVICE i32 [1], set to the number of flags.  Flagged queries must be recomputed in PR_SC_ARITH_F16X2. */
+int pr_f16_margin_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t m, int32_t G, double p_weight, int32_t k_in,
+                      const double* cand_score, int32_t k, const double* score, int32_t* flags, int32_t* count);
 int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                   const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
                   int32_t mask_width, double p_weight, int32_t k_in, const int32_t* idx_in, const double* score_in, int32_t k, int32_t* idx,
@@ -177,7 +193,7 @@ int pr_rerank_finish_dev(pr_ctx* ctx, const int32_t* cand_idx, const double* par
 /* fp32 scores of pr_fuse_select_dev as doubles (the merge works on doubles): DEVICE score32 [count] -> score64 [count] */
 int pr_widen_scores_dev(pr_ctx* ctx, const float* score32, int64_t count, double* score64);
 /* k-way merge of the per-shard results of G shards (SURVEY.md §8-e collective B's second half): idx_all DEVICE [G][m][k],
- * score_all DEVICE f64 [G][m][k] -> idx [m][k], score [m][k] by (score, global index); -1 / NaN entries last.  G * k <= 128. */
+ * score_all DEVICE f64 [G][m][k] -> idx [m][k], score [m][k] by (score, global index); -1 / NaN entries last (every list ascending, as the selection kernels write them).  G <= 64, k <= 128. */
 int pr_merge_topk_dev(pr_ctx* ctx, const int32_t* idx_all, const double* score_all, int32_t G, int32_t m, int32_t k,
                       int32_t* idx, double* score);
 

@@ -39,7 +39,7 @@ class Context:
         self.h = h
         self.device = device
         if sc_arith is not None:
-            self.check(self.lib.pr_set_sc_arith(h, {"f16x2": _lib.SC_ARITH_F16X2, "f32": _lib.SC_ARITH_F32}[sc_arith]))
+            self.check(self.lib.pr_set_sc_arith(h, {"f16x2": _lib.SC_ARITH_F16X2, "f32": _lib.SC_ARITH_F32, "f16": _lib.SC_ARITH_F16}[sc_arith]))
         if nan_policy is not None:
             self.check(self.lib.pr_set_nan_policy(h, {"exclude": _lib.NAN_EXCLUDE, "fail": _lib.NAN_FAIL}[nan_policy]))
 
@@ -49,7 +49,7 @@ class Context:
 
     @property
     def sc_arith(self) -> str:
-        return "f32" if self.lib.pr_get_sc_arith(self.h) == _lib.SC_ARITH_F32 else "f16x2"
+        return {_lib.SC_ARITH_F32: "f32", _lib.SC_ARITH_F16: "f16"}.get(self.lib.pr_get_sc_arith(self.h), "f16x2")
 
     def close(self):
         if getattr(self, "h", None):

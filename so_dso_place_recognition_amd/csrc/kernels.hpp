@@ -19,9 +19,15 @@ constexpr int SCH_QIMG = SC_NF * SCH_QBLK;      // 39 928 per (channel, 8-query 
 constexpr int SCH_DTILE = 768;                  // one 16x16x32 column operand: 48 lanes x 16 B
 constexpr int SCH_DFREQ = 4 * SCH_DTILE;        // Re hi, Re lo, Im hi, Im lo
 constexpr int SCH_DIMG = SC_NF * SCH_DFREQ;     // 95 232 per (channel, 16-entry DB group)
+// single-product f16 images (PR_SC_ARITH_F16, sc_match_e.hip): the hi halves only
+constexpr int SCF_QBLK = 648;                   // (8-query group, frequency): 16 rows x 40 B, rows 8..15 shifted by 8 B
+constexpr int SCF_QIMG = SC_NF * SCF_QBLK;      // 20 088 per (channel, 8-query group); a workgroup holds 8 groups = 64 queries
+constexpr int SCF_DFREQ = 2 * SCH_DTILE;        // Re, Im
+constexpr int SCF_DIMG = SC_NF * SCF_DFREQ;     // 47 616 per (channel, 16-entry DB group) = 2976 B per entry and channel
 constexpr int M2_TILE = 96 * 64;                // floats per (channel, 32-row tile): [kq(24)][lane(64)][4]
 
 inline int sc_qgroups8(int m) { return ((m + 31) / 32) * 4; }
+inline int sc_qgroups8_f16(int m) { return ((m + 63) / 64) * 8; }
 inline int sc_dgroups(int n) { return (n + 15) / 16; }
 inline int m2_tiles(int sigs) { return (sigs + 7) / 8; }      // 8 signatures x 4 variants = 32 rows
 inline int m2_qtiles(int sigs) { return ((m2_tiles(sigs) + 11) / 12) * 12; }   // query tiles: workgroups take 3 or 4 of them
@@ -38,7 +44,7 @@ size_t sc_match_lds_bytes();
 void launch_zero_ints(hipStream_t st, int* p, int n);
 // sc_match_h.hip — the same on the f16 matrix cores with split (hi + lo) operands; packed images from launch_sc_pack_h
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
-                      const double* twiddle, int* flags, int* bad);
+                      const double* twiddle, int* flags, int* bad, int single = 0);   // single: hi halves only (SCF_* layout)
 void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p,
                        float* d_i, int nsplit_override);
 size_t sc_match_h_lds_bytes();
@@ -55,7 +61,7 @@ void launch_m2dp_pack(hipStream_t st, const void* sig, int dtype, int sigs, floa
 void launch_m2dp_match(hipStream_t st, const float* qpk, int m, const float* dpk, int n, float* d_p, float* d_i);
 // m2dp_match_h.hip — the same with split-f16 operands on the f16 matrix cores (tiles of the same size, packed by launch_m2dp_pack_h)
 void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, void* packed, int tiles);
-void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i);
+void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i, int single = 0);   // single: hi halves only
 
 // fuse_select.hip — run_test.m:38-41,47-53,57
 void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom);
@@ -69,11 +75,14 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
                    double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
-                   float* score32, const double* cand_sc32);   // cand_sc32: the candidates' fp32-pass scores (ascending) or null: prunes hopeless candidates
+                   float* score32, const double* cand_sc32, double eps_d = 0.0);   // cand_sc32: the candidates' all-pairs-pass scores (ascending) or null: prunes hopeless candidates; eps_d: that pass's distance error bound (0: the fp32-grade 1e-6 with a 64x margin)
 // the sharded form: scores of the candidates THIS shard owns (NaN elsewhere), then owner-wise combination + selection
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                           double p_weight, int kin, const int32_t* idx_in, double* cand_score, const double* cand_sc32, int k);
+                           double p_weight, int kin, const int32_t* idx_in, double* cand_score, const double* cand_sc32, int k, double eps_d = 0.0);
+// PR_SC_ARITH_F16: flags[q] = 1 where the candidate list does not provably contain the exact top-k (rerank.hip), count += number of flags
+void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,
+                         const double* cand_sc, int k, const double* score, double eps_d, int32_t* flags, int32_t* count);
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,
                           double* score);
 void launch_widen(hipStream_t st, const float* a, long long n, double* b);

@@ -44,7 +44,9 @@ __global__ __launch_bounds__(256) void m2dp_pack_h_kernel(const T* __restrict__ 
 
 struct HL { u32x4 h, l; };
 
-template <int QTB>   // query tiles per workgroup: 4 (96 KB of LDS: one workgroup per CU) or 3 (72 KB: two, their epilogues and request stalls overlap)
+// QTB = query tiles per workgroup: 4 (96 KB of LDS: one workgroup per CU) or 3 (72 KB: two, their epilogues and request stalls overlap)
+// LO = false: the single-product arithmetic (PR_SC_ARITH_F16): the hi halves of the same tiles only, one MFMA per product
+template <int QTB, bool LO>
 __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __restrict__ qpk, const u32x4* __restrict__ dpk,
                                                               float* __restrict__ dist_p, float* __restrict__ dist_i,
                                                               int m, int n, int QT, int DT, int nsplit) {
@@ -80,8 +82,8 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
   struct BSet { HL b0, b1; };
   BSet bs[3];               // K-steps st, st + 1, st + 2 (period 3 divides the 12 K-steps of a sweep step)
   HL a[QTB];                // the 4 query tiles of the current K-step; tile t is reloaded for the next K-step behind its own MFMAs
-#define LDB(dst, p, st) { dst.b0.h = (p)[(st) * 128]; dst.b0.l = (p)[(st) * 128 + 64]; dst.b1.h = (p)[TV + (st) * 128]; dst.b1.l = (p)[TV + (st) * 128 + 64]; }
-#define LDA1(t, st) { a[t].h = la[(t) * TV + (st) * 128]; a[t].l = la[(t) * TV + (st) * 128 + 64]; }
+#define LDB(dst, p, st) { dst.b0.h = (p)[(st) * 128]; dst.b1.h = (p)[TV + (st) * 128]; if constexpr (LO) { dst.b0.l = (p)[(st) * 128 + 64]; dst.b1.l = (p)[TV + (st) * 128 + 64]; } }
+#define LDA1(t, st) { a[t].h = la[(t) * TV + (st) * 128]; if constexpr (LO) a[t].l = la[(t) * TV + (st) * 128 + 64]; }
 #define MF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
   LDB(bs[0], pb, 0)
   LDB(bs[1], pb, 1)
@@ -107,19 +109,29 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
         SBAR();
         acc[t][0] = MF(a[t].h, c.b0.h, first ? zero : acc[t][0]);
         SBAR();
-        if (t == 0) nx.b0.h = pq[0]; else if (t == 1) nx.b0.l = pq[64]; else if (t == 2) nx.b1.h = pq[TV]; else nx.b1.l = pq[TV + 64];
-        if (QTB == 3 && t == 2) { SBAR(); nx.b1.l = pq[TV + 64]; }
+        if constexpr (LO) {
+          if (t == 0) nx.b0.h = pq[0]; else if (t == 1) nx.b0.l = pq[64]; else if (t == 2) nx.b1.h = pq[TV]; else nx.b1.l = pq[TV + 64];
+          if (QTB == 3 && t == 2) { SBAR(); nx.b1.l = pq[TV + 64]; }
+        } else {
+          if (t == 0) nx.b0.h = pq[0]; else if (t == 1) nx.b1.h = pq[TV];
+        }
         SBAR();
         acc[t][1] = MF(a[t].h, c.b1.h, first ? zero : acc[t][1]);
-        acc[t][0] = MF(a[t].h, c.b0.l, acc[t][0]);
-        acc[t][1] = MF(a[t].h, c.b1.l, acc[t][1]);
+        if constexpr (LO) {
+          acc[t][0] = MF(a[t].h, c.b0.l, acc[t][0]);
+          acc[t][1] = MF(a[t].h, c.b1.l, acc[t][1]);
+        }
         SBAR();
-        a[t].h = la[t * TV + ((st + 1) % 12) * 128];              // the query tiles do not depend on the sweep step
-        SBAR();
-        acc[t][0] = MF(a[t].l, c.b0.h, acc[t][0]);
-        acc[t][1] = MF(a[t].l, c.b1.h, acc[t][1]);
-        SBAR();
-        a[t].l = la[t * TV + ((st + 1) % 12) * 128 + 64];
+        if constexpr (LO) {
+          a[t].h = la[t * TV + ((st + 1) % 12) * 128];              // the query tiles do not depend on the sweep step
+          SBAR();
+          acc[t][0] = MF(a[t].l, c.b0.h, acc[t][0]);
+          acc[t][1] = MF(a[t].l, c.b1.h, acc[t][1]);
+          SBAR();
+          a[t].l = la[t * TV + ((st + 1) % 12) * 128 + 64];
+        } else {
+          a[t].h = la[t * TV + ((st + 1) % 12) * 128];
+        }
         SBAR();
       }
     }
@@ -257,7 +269,7 @@ void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, vo
     hipLaunchKernelGGL(m2dp_pack_h_kernel<float>, dim3(sigs), dim3(256), 0, st, (const float*)sig, sigs, (unsigned short*)packed, tiles);
 }
 
-void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i) {
+void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i, int single) {
   if (m <= 0 || n <= 0) return;
   const int QT = m2_qtiles(m), DT = m2_tiles(n);
   // 4 query tiles per workgroup; PR_M2_QTB=3 selects the two-workgroups-per-CU variant for A/B runs (measured 6.4 ms against
@@ -278,13 +290,21 @@ void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk
   if (nsplit > DT8 / 4) nsplit = DT8 / 4;
   if (nsplit < 1) nsplit = 1;
   const size_t lds = (size_t)qtb * TB;
+  if (single) {
+    auto* k1 = m2dp_match_h_kernel<4, false>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * TB));
+    const int base4 = (QT / 4) * 2;
+    hipLaunchKernelGGL(k1, dim3(base4 * nsplit), dim3(256), (size_t)4 * TB, st, static_cast<const u32x4*>(qpk),
+                       static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
+    return;
+  }
   if (eight && qtb == 4) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(m2dp_match_h8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(m2dp_match_h8_kernel, dim3(base * nsplit), dim3(512), lds, st, static_cast<const u32x4*>(qpk),
                        static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
     return;
   }
-  auto* k = qtb == 4 ? m2dp_match_h_kernel<4> : m2dp_match_h_kernel<3>;
+  auto* k = qtb == 4 ? m2dp_match_h_kernel<4, true> : m2dp_match_h_kernel<3, true>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(base * nsplit), dim3(256), lds, st, static_cast<const u32x4*>(qpk),
                      static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);

@@ -35,6 +35,7 @@ struct pr_ctx {
   int* d_flags = nullptr;        // [4] deferred bits: [0] zero-norm row at pack time, [1] M2DP singular pair not converged
   double* d_twiddle = nullptr;   // cos[60], sin[60] of 2*pi*t/60
   float* d_cst = nullptr;        // SC stage-2 constants [31][2][64]
+  int32_t* d_margin = nullptr;    // [1] count of margin flags (PR_SC_ARITH_F16)
   void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16] (sc_match_h.hip)
   int sc_kernel = 2;             // split-f16 SC matcher for m > 8: 2 = sc_match_e.hip (default); PR_SC_KERNEL=d | h selects sc_match_d.hip (1, the round-2 default) / sc_match_h.hip (0, round 1; always the kernel for m <= 8)
   int sc_mode = PR_SC_ARITH_F16X2;   // PR_SC_ARITH_*: split-f16 MFMA (sc_match_h.hip) | fp32 MFMA (sc_match.hip); PR_SC_MATCH=f32 selects the latter
@@ -85,6 +86,11 @@ int set_device(pr_ctx* ctx) {
 
 size_t sigset_floats(int type, int role, int32_t max_sigs, int* groups, int sc_mode) {
   if (type == PR_TYPE_DELIGHT) { *groups = max_sigs; return (size_t)max_sigs * (4096 + 128) + 16; }   // histograms + empty-bin masks
+  if (type == PR_TYPE_SC && sc_mode == PR_SC_ARITH_F16) {   // single-product images (hi halves only), sizes in bytes / 4
+    if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8_f16(max_sigs); return (size_t)2 * *groups * pr::SCF_QIMG / 4; }
+    *groups = pr::sc_dgroups(max_sigs);
+    return (size_t)(2 * *groups + 9) * pr::SCF_DIMG / 4;
+  }
   if (type == PR_TYPE_SC && sc_mode == 0) {   // split-f16 images, sizes in bytes / 4
     if (role == PR_ROLE_QUERY) { *groups = pr::sc_qgroups8(max_sigs); return (size_t)2 * *groups * pr::SCH_QIMG / 4; }
     *groups = pr::sc_dgroups(max_sigs);
@@ -228,7 +234,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
   } while (0);
   if (rc != PR_OK) { pr_destroy(ctx); return rc; }
   if (const char* s = getenv("PR_SC_NSPLIT")) ctx->sc_nsplit = atoi(s);
-  if (const char* s = getenv("PR_SC_MATCH")) ctx->sc_mode = (strcmp(s, "f32") == 0) ? 1 : 0;
+  if (const char* s = getenv("PR_SC_MATCH")) ctx->sc_mode = (strcmp(s, "f32") == 0) ? PR_SC_ARITH_F32 : (strcmp(s, "f16") == 0) ? PR_SC_ARITH_F16 : PR_SC_ARITH_F16X2;
   if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel = (strcmp(s, "h") == 0) ? 0 : (strcmp(s, "d") == 0) ? 1 : 2;
   *out = ctx;
   return PR_OK;
@@ -261,7 +267,7 @@ void pr_destroy(pr_ctx* ctx) {
 
 int pr_set_sc_arith(pr_ctx* ctx, int arith) {
   if (!ctx) return PR_EINVAL;
-  if (arith != PR_SC_ARITH_F16X2 && arith != PR_SC_ARITH_F32) PR_FAIL(ctx, PR_EINVAL, "pr_set_sc_arith: unknown arithmetic %d", arith);
+  if (arith != PR_SC_ARITH_F16X2 && arith != PR_SC_ARITH_F32 && arith != PR_SC_ARITH_F16) PR_FAIL(ctx, PR_EINVAL, "pr_set_sc_arith: unknown arithmetic %d", arith);
   ctx->sc_mode = arith;
   return PR_OK;
 }
@@ -537,12 +543,13 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
   int groups;
   (void)sigset_floats(s->type, s->role, n_sigs, &groups, s->sc_mode);
   s->groups = groups;
-  if (s->type == PR_TYPE_SC && s->sc_mode == 0)
-    pr::launch_sc_pack_h(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags, s->bad);
+  if (s->type == PR_TYPE_SC && (s->sc_mode == PR_SC_ARITH_F16X2 || s->sc_mode == PR_SC_ARITH_F16))
+    pr::launch_sc_pack_h(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags, s->bad,
+                         s->sc_mode == PR_SC_ARITH_F16);
   else if (s->type == PR_TYPE_SC)
     pr::launch_sc_pack(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags, s->bad);
   else if (s->type == PR_TYPE_M2DP)
-    if (s->sc_mode == PR_SC_ARITH_F16X2) pr::launch_m2dp_pack_h(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
+    if (s->sc_mode != PR_SC_ARITH_F32) pr::launch_m2dp_pack_h(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
     else pr::launch_m2dp_pack(ctx->stream, dsig, dtype, n_sigs, s->packed, groups);
   else
     pr::launch_delight_pack(ctx->stream, dsig, dtype, n_sigs, s->packed, delight_masks(s));
@@ -560,7 +567,9 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
   if (int rc = set_device(ctx)) return rc;
   if (q->type != PR_TYPE_DELIGHT && q->sc_mode != db->sc_mode)
     PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: the two sets were packed for different arithmetic modes");
-  if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && q->count > 8)
+  if (q->type == PR_TYPE_SC && q->sc_mode == PR_SC_ARITH_F16)
+    pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 1);
+  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && q->count > 8)
     pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 0);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 1 && q->count > 8)
     pr::launch_sc_match_d(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit);
@@ -569,7 +578,7 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
   else if (q->type == PR_TYPE_SC)
     pr::launch_sc_match(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst, d_p, d_i, ctx->sc_nsplit);
   else if (q->type == PR_TYPE_M2DP)
-    if (q->sc_mode == PR_SC_ARITH_F16X2) pr::launch_m2dp_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
+    if (q->sc_mode != PR_SC_ARITH_F32) pr::launch_m2dp_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i, q->sc_mode == PR_SC_ARITH_F16);
     else pr::launch_m2dp_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
   else
     pr::launch_delight_match(ctx->stream, q->packed, q->count, db->packed, delight_masks(db), db->count, d_p);
@@ -597,6 +606,28 @@ int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
   return PR_OK;
 }
 
+// survivors of the all-pairs selection that the fp64 re-evaluation looks at: k + 8 (fp32-grade passes), k + 56 in the single-product
+// arithmetic, whose pass scores only bracket the exact ones to ~0.3 sigma (the interface's cap is 128)
+static int rerank_width(int k, int mode) { const int w = k + (mode == PR_SC_ARITH_F16 ? 56 : 8); return w > 128 ? 128 : w; }
+
+// distance error bound of the context's all-pairs arithmetic for the pruning / margin logic of the re-evaluation: 0 selects the
+// fp32-grade default (1e-6, generous 64x margin); the single-product f16 arithmetic carries 2e-3 (include/place_recognition.h)
+static double pass_eps(const pr_ctx* ctx) { return ctx->sc_mode == PR_SC_ARITH_F16 ? PR_F16_DISTANCE_BOUND : 0.0; }
+
+int pr_f16_margin_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t m, int32_t G, double p_weight, int32_t k_in,
+                      const double* cand_score, int32_t k, const double* score, int32_t* flags, int32_t* count) {
+  if (!ctx) return PR_EINVAL;
+  if ((!mom_sc && !mom_m2) || !cand_score || !score || !flags || !count || m < 0 || G < 1 || k < 1 || k_in < k || k_in > 128)
+    PR_FAIL(ctx, PR_EINVAL, "pr_f16_margin_dev: bad arguments (m=%d, G=%d, k=%d, k_in=%d)", m, G, k, k_in);
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_zero_ints(ctx->stream, count, 1);
+  pr::launch_margin_check(ctx->stream, mom_sc, mom_m2, G, m, p_weight, k_in, cand_score, k, score, PR_F16_DISTANCE_BOUND, flags, count);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+int pr_rerank_width(const pr_ctx* ctx, int32_t k) { return ctx ? rerank_width(k, ctx->sc_mode) : PR_EINVAL; }
+
 int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                   const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
                   int32_t mask_width, double p_weight, int32_t k_in, const int32_t* idx_in, const double* score_in, int32_t k, int32_t* idx,
@@ -616,7 +647,7 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
     ctx->rr_cap = need;
   }
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
-                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in);
+                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in, pass_eps(ctx));
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -634,7 +665,7 @@ int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int 
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   pr::launch_rerank_partial(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0,
-                            mask_width, p_weight, k_in, cand_idx, part, cand_score, k);
+                            mask_width, p_weight, k_in, cand_idx, part, cand_score, k, pass_eps(ctx));
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -662,8 +693,8 @@ int pr_widen_scores_dev(pr_ctx* ctx, const float* score32, int64_t count, double
 int pr_merge_topk_dev(pr_ctx* ctx, const int32_t* idx_all, const double* score_all, int32_t G, int32_t m, int32_t k, int32_t* idx,
                       double* score) {
   if (!ctx) return PR_EINVAL;
-  if (!idx_all || !score_all || !idx || !score || G < 1 || m < 0 || k < 1 || (int64_t)G * k > 128)
-    PR_FAIL(ctx, PR_EINVAL, "pr_merge_topk_dev: bad arguments (G=%d, m=%d, k=%d; G*k <= 128)", G, m, k);
+  if (!idx_all || !score_all || !idx || !score || G < 1 || G > 64 || m < 0 || k < 1 || k > 128)
+    PR_FAIL(ctx, PR_EINVAL, "pr_merge_topk_dev: bad arguments (G=%d, m=%d, k=%d; G <= 64, k <= 128)", G, m, k);
   if (int rc = set_device(ctx)) return rc;
   pr::launch_merge_topk(ctx->stream, idx_all, score_all, G, m, k, idx, score);
   PR_HIP(ctx, hipGetLastError());
@@ -671,8 +702,77 @@ int pr_merge_topk_dev(pr_ctx* ctx, const int32_t* idx_all, const double* score_a
 }
 
 // ------------------------------------------------------------------------------------------- host-buffer path
-// survivors of the fp32 selection that the fp64 re-evaluation looks at (k + 8, the interface's cap is 128)
-static int rerank_width(int k) { return k + 8 > 128 ? 128 : k + 8; }
+
+
+// PR_SC_ARITH_F16, host calls: margin check of the re-evaluated top-k; the flagged queries are matched again in split-f16 against the whole
+// DB (whose raw signatures are still on the device) and their rows of dcand / dsc64 overwritten.  hq_*: HOST query signatures, ddb_*: DEVICE
+// raw DB signatures (f64), either descriptor type may be absent; mom_*: the f16 pass moments [m][2][3]; cand_sc: its candidate scores.
+static int f16_fallback(pr_ctx* ctx, const double* hq_sc, const double* hq_m2, const void* ddb_sc, const void* ddb_m2, int32_t m, int32_t n,
+                        int32_t mask_width, double p_weight, int32_t k, const double* mom_sc, const double* mom_m2, int32_t kin,
+                        const double* cand_sc, int32_t* dcand, double* dsc64) {
+  DevBuf dflags, dcount;
+  if (dflags.alloc((size_t)m * 4) != hipSuccess || dcount.alloc(4) != hipSuccess) PR_FAIL(ctx, PR_ENOMEM, "out of device memory");
+  if (int rc = pr_f16_margin_dev(ctx, mom_sc, mom_m2, m, 1, p_weight, kin, cand_sc, k, dsc64, dflags.as<int32_t>(), dcount.as<int32_t>())) return rc;
+  int32_t cnt = 0;
+  PR_HIP(ctx, hipMemcpyAsync(&cnt, dcount.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (cnt == 0) return PR_OK;
+  std::vector<int32_t> fl(m), F;
+  PR_HIP(ctx, hipMemcpy(fl.data(), dflags.p, (size_t)m * 4, hipMemcpyDeviceToHost));
+  for (int32_t q = 0; q < m; q++) if (fl[q]) F.push_back(q);
+  const int32_t mf = (int32_t)F.size();
+  ctx->warnings |= PR_WARN_F16_FALLBACK;
+  const int kin2 = rerank_width(k, PR_SC_ARITH_F16X2);
+  pr_sigset* ss[4] = {nullptr, nullptr, nullptr, nullptr};   // SC query, SC db, M2DP query, M2DP db
+  DevBuf rq[2], d[4], mo[2], didx, dsc, dsw;
+  int rc = PR_OK;
+  ctx->sc_mode = PR_SC_ARITH_F16X2;
+  do {
+    const size_t mn = (size_t)mf * n;
+    for (int t = 0; t < 2 && rc == PR_OK; t++) {                // t = 0: SC, 1: M2DP
+      const double* hq = t ? hq_m2 : hq_sc;
+      const void* ddb = t ? ddb_m2 : ddb_sc;
+      if (!hq) continue;
+      const size_t rowlen = t ? 4 * 384 : 2400;
+      std::vector<double> g((size_t)mf * rowlen);
+      for (int32_t i = 0; i < mf; i++) memcpy(g.data() + (size_t)i * rowlen, hq + (size_t)F[i] * rowlen, rowlen * 8);
+      if (rq[t].alloc(g.size() * 8) != hipSuccess || d[2 * t].alloc(mn * 4) != hipSuccess || d[2 * t + 1].alloc(mn * 4) != hipSuccess ||
+          mo[t].alloc((size_t)mf * 6 * 8) != hipSuccess) { ctx->err = "out of device memory (f16 fallback)"; rc = PR_ENOMEM; break; }
+      if (hipMemcpy(rq[t].p, g.data(), g.size() * 8, hipMemcpyHostToDevice) != hipSuccess) { ctx->err = "H2D copy failed"; rc = PR_EHIP; break; }
+      if ((rc = pr_sigset_create(ctx, t ? PR_TYPE_M2DP : PR_TYPE_SC, PR_ROLE_QUERY, mf, &ss[2 * t])) ||
+          (rc = pr_sigset_create(ctx, t ? PR_TYPE_M2DP : PR_TYPE_SC, PR_ROLE_DB, n, &ss[2 * t + 1])) ||
+          (rc = pr_sigset_pack(ctx, ss[2 * t], rq[t].p, PR_F64, PR_DEVICE, mf)) || (rc = pr_sigset_pack(ctx, ss[2 * t + 1], ddb, PR_F64, PR_DEVICE, n)) ||
+          (rc = pr_distances_dev(ctx, ss[2 * t], ss[2 * t + 1], d[2 * t].as<float>(), d[2 * t + 1].as<float>())) ||
+          (rc = pr_row_moments_dev(ctx, d[2 * t].as<float>(), d[2 * t + 1].as<float>(), mf, n, mo[t].as<double>()))) break;
+    }
+    if (rc) break;
+    if (didx.alloc((size_t)kin2 * 4) != hipSuccess || dsc.alloc((size_t)kin2 * 4) != hipSuccess || dsw.alloc((size_t)kin2 * 8) != hipSuccess) { ctx->err = "out of device memory"; rc = PR_ENOMEM; break; }
+    const bool both = hq_sc && hq_m2;
+    for (int32_t i = 0; i < mf && rc == PR_OK; i++) {           // one row at a time: every flagged query has its own row number for the mask
+      const size_t o = (size_t)i * n;
+      const int32_t q0 = F[i];
+      if (both)
+        rc = pr_fuse_select2_dev(ctx, d[0].as<float>() + o, d[1].as<float>() + o, d[2].as<float>() + o, d[3].as<float>() + o, 1, n,
+                                 mo[0].as<double>() + (size_t)i * 6, mo[1].as<double>() + (size_t)i * 6, 1, q0, 0, mask_width, p_weight, kin2,
+                                 didx.as<int32_t>(), dsc.as<float>());
+      else {
+        const int t = hq_sc ? 0 : 1;
+        rc = pr_fuse_select_dev(ctx, d[2 * t].as<float>() + o, d[2 * t + 1].as<float>() + o, 1, n, mo[t].as<double>() + (size_t)i * 6, 1, q0, 0,
+                                mask_width, p_weight, kin2, didx.as<int32_t>(), dsc.as<float>());
+      }
+      if (rc || (rc = pr_widen_scores_dev(ctx, dsc.as<float>(), kin2, dsw.as<double>()))) break;
+      rc = pr_rerank_dev(ctx, hq_sc ? rq[0].as<double>() + (size_t)i * 2400 : nullptr, hq_sc ? ddb_sc : nullptr, PR_F64,
+                         hq_m2 ? rq[1].as<double>() + (size_t)i * 4 * 384 : nullptr, hq_m2 ? ddb_m2 : nullptr, PR_F64,
+                         hq_sc ? mo[0].as<double>() + (size_t)i * 6 : nullptr, hq_m2 ? mo[1].as<double>() + (size_t)i * 6 : nullptr, 1, n, 1, q0, 0,
+                         mask_width, p_weight, kin2, didx.as<int32_t>(), dsw.as<double>(), k, dcand + (size_t)q0 * k, dsc64 + (size_t)q0 * k);
+    }
+    if (rc == PR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "f16 fallback failed"; rc = PR_EHIP; }
+  } while (0);
+  if (rc != PR_OK) (void)hipStreamSynchronize(ctx->stream);
+  for (auto* q : ss) pr_sigset_destroy(ctx, q);
+  ctx->sc_mode = PR_SC_ARITH_F16;
+  return rc;
+}
 
 // score32 / score64: exactly one is non-null
 static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, const double* h2, int32_t n,
@@ -710,7 +810,7 @@ static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, con
     if (dp.alloc(mn * 4) != hipSuccess || (!plain && di.alloc(mn * 4) != hipSuccess)) { ctx->err = "out of device memory for the m x n distance matrices"; rc = PR_ENOMEM; break; }
     if ((rc = pr_distances_dev(ctx, q, d, dp.as<float>(), plain ? nullptr : di.as<float>()))) break;
     if (want_topk) {
-      const int kin = plain ? k : rerank_width(k);
+      const int kin = plain ? k : rerank_width(k, ctx->sc_mode);
       if (mom.alloc((size_t)m * 6 * 8) != hipSuccess || didx.alloc((size_t)m * kin * 4) != hipSuccess ||
           dsc.alloc((size_t)m * kin * 4) != hipSuccess || dsc64.alloc((size_t)m * k * 8) != hipSuccess ||
           dcand.alloc((size_t)m * k * 4) != hipSuccess) { ctx->err = "out of device memory"; rc = PR_ENOMEM; break; }
@@ -735,6 +835,10 @@ static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, con
                               didx.as<int32_t>(), dsw.as<double>(), k, dcand.as<int32_t>(), dsc64.as<double>()))) break;
       std::vector<double> t64;
       if (score32) t64.resize((size_t)m * k);
+      if (ctx->sc_mode == PR_SC_ARITH_F16 &&
+          (rc = f16_fallback(ctx, sc ? h1 : nullptr, sc ? nullptr : h1, sc ? raw2.p : nullptr, sc ? nullptr : raw2.p, m, n, mask_width, p_weight, k,
+                             sc ? mom.as<double>() : nullptr, sc ? nullptr : mom.as<double>(), kin, dsw.as<double>(), dcand.as<int32_t>(),
+                             dsc64.as<double>()))) break;
       if (hipMemcpyAsync(idx, dcand.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
           hipMemcpyAsync(score64 ? score64 : t64.data(), dsc64.p, (size_t)m * k * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
       if ((rc = pr_sync(ctx))) break;
@@ -801,7 +905,7 @@ static int fused_host(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32
   DevBuf raw[4], d[4], mom[2], didx, dsc, dcand, dsc64, dsw;
   const void* host[4] = {sc1, sc2, m2dp1, m2dp2};
   const size_t bytes[4] = {(size_t)m * 2400 * 8, (size_t)n * 2400 * 8, (size_t)m * 4 * 384 * 8, (size_t)n * 4 * 384 * 8};
-  const int kin = rerank_width(k);
+  const int kin = rerank_width(k, ctx->sc_mode);
   int rc = PR_OK;
   do {
     if ((rc = pr_sigset_create(ctx, PR_TYPE_SC, PR_ROLE_QUERY, m, &ss[0])) || (rc = pr_sigset_create(ctx, PR_TYPE_SC, PR_ROLE_DB, n, &ss[1])) ||
@@ -830,6 +934,9 @@ static int fused_host(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32
                             0, 0, mask_width, p_weight, kin, didx.as<int32_t>(), dsw.as<double>(), k, dcand.as<int32_t>(), dsc64.as<double>()))) break;
     std::vector<double> t64;
     if (score32) t64.resize((size_t)m * k);
+    if (ctx->sc_mode == PR_SC_ARITH_F16 &&
+        (rc = f16_fallback(ctx, sc1, m2dp1, raw[1].p, raw[3].p, m, n, mask_width, p_weight, k, mom[0].as<double>(), mom[1].as<double>(), kin,
+                           dsw.as<double>(), dcand.as<int32_t>(), dsc64.as<double>()))) break;
     if (hipMemcpyAsync(idx, dcand.p, (size_t)m * k * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
         hipMemcpyAsync(score64 ? score64 : t64.data(), dsc64.p, (size_t)m * k * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { ctx->err = "D2H copy failed"; rc = PR_EHIP; break; }
     if ((rc = pr_sync(ctx))) break;

@@ -250,8 +250,8 @@ int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_w
   if (!g) return PR_EINVAL;
   if (g->type < 0) G_FAIL(g, PR_EINVAL, "pr_group_match_topk: no database (pr_group_set_database)");
   const int G = g->G;
-  if (m < 0 || (m > 0 && !h1) || k < 1 || k > 120 || (int64_t)G * (k + 8) > 128 || !idx || !score)
-    G_FAIL(g, PR_EINVAL, "pr_group_match_topk: bad arguments (m=%d, k=%d; G*(k+8) <= 128)", m, k);
+  if (m < 0 || (m > 0 && !h1) || k < 1 || k > 120 || G > 64 || !idx || !score)
+    G_FAIL(g, PR_EINVAL, "pr_group_match_topk: bad arguments (m=%d, k=%d; k <= 120, at most 64 shards)", m, k);
   if (m == 0) return PR_OK;
   const int type = g->type;
   const bool sc = type == PR_TYPE_SC;

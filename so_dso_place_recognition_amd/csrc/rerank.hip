@@ -168,7 +168,16 @@ struct RerankArgs {
   int m, n_local, G, q_row0, db_row0, mask_width, kin;
   double p_weight;
   const double* cand_sc; int k;                                 // fp32-pass scores of the candidates [m][kin], ascending, or null; the k wanted
+  double eps_d, eps_mult;                                       // distance error bound of the all-pairs pass per channel, and the safety factor on it
 };
+
+// |all-pairs-pass score - exact score| <= this for a pair whose exact score is s, given the row statistics: distance error eps_d per
+// channel over its sigma (w = sum of weight / sigma over the channels), amplified by 1 + s^2 / (n - 1) through the statistics, + the
+// rounding of the score itself
+__device__ __forceinline__ double score_err_bound(double eps_d, double w, double s, double cn) {
+  return eps_d * w * (1.0 + s * s / fmax(cn - 1.0, 1.0)) + 1e-6 * fabs(s) + 1e-5;
+}
+__device__ double row_weight(const double* mom_sc, const double* mom_m2, int G, int m, int q, double p_weight, double* cn_out);
 
 __device__ void chan_combine(const double* mom_all, int G, int m, int q, int ch, double& mean, double& sd, double* count = nullptr) {
   double cn = 0.0, mu = 0.0, m2 = 0.0;
@@ -205,13 +214,9 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
     // |fp32 score - exact score| given the row statistics: distance error 1e-6 per channel over its sigma,
     // amplified by 1 + s^2 / (n - 1) through the statistics, + the rounding of the score itself.
     const double sk = A.cand_sc[(size_t)q * A.kin + A.k - 1], st = A.cand_sc[(size_t)q * A.kin + t];
-    double w = 0.0, cn = 2.0;
-    for (int ch = 0; ch < 2; ch++) {
-      double mean, sd;
-      if (A.q_sc) { chan_combine(A.mom_sc, A.G, A.m, q, ch, mean, sd, &cn); w += (ch == 0 ? A.p_weight : 1.0) / sd; }
-      if (A.q_m2) { chan_combine(A.mom_m2, A.G, A.m, q, ch, mean, sd, &cn); w += (ch == 0 ? A.p_weight : 1.0) / sd; }
-    }
-    const double delta = 64.0 * (1e-6 * w * (1.0 + sk * sk / fmax(cn - 1.0, 1.0)) + 1e-6 * fabs(sk) + 1e-5);
+    double cn = 2.0;
+    const double w = row_weight(A.q_sc ? A.mom_sc : nullptr, A.q_m2 ? A.mom_m2 : nullptr, A.G, A.m, q, A.p_weight, &cn);
+    const double delta = A.eps_mult * score_err_bound(A.eps_d, w, sk, cn);
     if (st > sk + delta) { if (tid == 0) *out = st; return; }   // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
   }
   double f = 0.0;
@@ -233,6 +238,41 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
     }
   }
   if (tid == 0) *out = f;
+}
+
+__device__ double row_weight(const double* mom_sc, const double* mom_m2, int G, int m, int q, double p_weight, double* cn_out) {
+  double w = 0.0, cn = 2.0;
+  for (int ch = 0; ch < 2; ch++) {
+    double mean, sd;
+    if (mom_sc) { chan_combine(mom_sc, G, m, q, ch, mean, sd, &cn); w += (ch == 0 ? p_weight : 1.0) / sd; }
+    if (mom_m2) { chan_combine(mom_m2, G, m, q, ch, mean, sd, &cn); w += (ch == 0 ? p_weight : 1.0) / sd; }
+  }
+  *cn_out = cn;
+  return w;
+}
+
+// PR_SC_ARITH_F16: is the exact top-k of the candidates provably the exact top-k of ALL entries?  cand_sc = the all-pairs-pass scores of
+// the k_in candidates (ascending: every entry that is NOT a candidate has a pass score >= the last one, T), score = the exact scores of
+// the k selected.  Every non-candidate's exact score is >= T - err(T); if the exact k-th best is below that, nothing outside the list can
+// enter the top-k (pruned candidates: rerank_kernel).  Otherwise - or when statistics / scores are not finite - the query is flagged.
+__global__ __launch_bounds__(64) void margin_check_kernel(const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int G, int m,
+                                                           double p_weight, int kin, const double* __restrict__ cand_sc, int k,
+                                                           const double* __restrict__ score, double eps_d, int32_t* __restrict__ flags,
+                                                           int32_t* __restrict__ count) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= m) return;
+  const double* cs = cand_sc + (size_t)q * kin;
+  int flag = 0;
+  const double T = cs[kin - 1];
+  if (T == T) {                                       // a full candidate list (NaN = fewer than k_in entries exist: nothing is outside it)
+    double cn = 2.0;
+    const double w = row_weight(mom_sc, mom_m2, G, m, q, p_weight, &cn);
+    const double sk = score[(size_t)q * k + k - 1];
+    const double lim = T - score_err_bound(eps_d, w, T, cn);
+    if (T < __builtin_inf() && !(sk < lim)) flag = 1;   // (T = +Inf: everything left is masked)
+  }
+  flags[q] = flag;
+  if (flag) atomicAdd(count, 1);
 }
 
 __device__ __forceinline__ bool cand_before(double av, int aj, double bv, int bj) {   // NaN / -1 entries sort last
@@ -296,20 +336,32 @@ __global__ __launch_bounds__(256) void widen_kernel(const float* __restrict__ a,
   if (i < n) b[i] = (double)a[i];
 }
 
-// idx_all [G][m][k], score_all [G][m][k] -> idx [m][k], score [m][k]
+// idx_all [G][m][k], score_all [G][m][k] -> idx [m][k], score [m][k].  Every shard's list is ascending by (score, index) with its missing
+// entries (-1 / NaN) last - as pr_fuse_select_dev and pr_rerank_dev write them - so this is a G-way merge with one cursor per list: no
+// limit on G * k (the selection over a gathered array capped it at 128, which 8 shards x the k + 56 candidates of PR_SC_ARITH_F16 exceed).
 __global__ __launch_bounds__(64) void merge_topk_kernel(const int32_t* __restrict__ idx_all, const double* __restrict__ score_all,
                                                          int G, int m, int k, int32_t* __restrict__ idx, double* __restrict__ score) {
-  const int q = blockIdx.x * 64 + threadIdx.x;
+  __shared__ unsigned char curs[64][65];                      // [cursor of list g][thread]: G <= 64, k <= 128 (a private array indexed at run
+  const int q = blockIdx.x * 64 + threadIdx.x;                // time would live in scratch memory)
   if (q >= m) return;
-  int32_t ci[128];
-  double cs[128];
-  int cnt = 0;
-  for (int g = 0; g < G; g++)
-    for (int t = 0; t < k && cnt < 128; t++, cnt++) {
-      ci[cnt] = idx_all[((size_t)g * m + q) * k + t];
-      cs[cnt] = score_all[((size_t)g * m + q) * k + t];
+  unsigned char (&cur)[64][65] = curs;
+  const int th = threadIdx.x;
+  for (int g = 0; g < G; g++) cur[g][th] = 0;
+  for (int t = 0; t < k; t++) {
+    int bg = -1, bj = -1;
+    double bv = 0.0;
+    for (int g = 0; g < G; g++) {
+      if (cur[g][th] >= k) continue;
+      const size_t o = ((size_t)g * m + q) * k + cur[g][th];
+      const int j = idx_all[o];
+      const double v = score_all[o];
+      if (bg < 0 || cand_before(v, j, bv, bj)) { bg = g; bj = j; bv = v; }
     }
-  select_k(ci, cs, cnt, k, idx + (size_t)q * k, score + (size_t)q * k, nullptr);
+    const bool ok = bg >= 0 && bj >= 0 && bv == bv;
+    if (bg >= 0) cur[bg][th]++;
+    idx[(size_t)q * k + t] = ok ? bj : -1;
+    score[(size_t)q * k + t] = ok ? bv : __builtin_nan("");
+  }
 }
 
 }  // namespace
@@ -323,19 +375,28 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
                    double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
-                   float* score32, const double* cand_sc32) {
+                   float* score32, const double* cand_sc32, double eps_d) {
   if (m <= 0) return;
-  RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k};
+  RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
+               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0};
   hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
   hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
 }
 
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                           double p_weight, int kin, const int32_t* idx_in, double* cand_score, const double* cand_sc32, int k) {
+                           double p_weight, int kin, const int32_t* idx_in, double* cand_score, const double* cand_sc32, int k, double eps_d) {
   if (m <= 0) return;
-  RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k};
+  RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
+               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0};
   hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
+}
+
+void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,
+                         const double* cand_sc, int k, const double* score, double eps_d, int32_t* flags, int32_t* count) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(margin_check_kernel, dim3((m + 63) / 64), dim3(64), 0, st, mom_sc, mom_m2, G, m, p_weight, kin, cand_sc, k, score, eps_d,
+                     flags, count);
 }
 
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,

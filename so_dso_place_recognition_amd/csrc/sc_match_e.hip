@@ -16,8 +16,6 @@
 //  * all packed operands stay in ArchVGPRs (nothing is parked in AccVGPRs, no v_accvgpr_write); the stage-2 constants are requested
 //    once per unit while the last stage-1 quad runs.
 //  * LO = false is the single-product arithmetic (PR_SC_ARITH_F16): operands hi only, one MFMA per product.
-#include <cstdlib>
-
 #include "kernels.hpp"
 #ifndef E_BD
 #define E_BD 4          // depth of the DB operand ring, split-f16 form
@@ -57,9 +55,11 @@ __device__ __forceinline__ void load_a(AOps& a, unsigned addr) {   // addr = thi
   const u32x4 v = *reinterpret_cast<lds_tile_p>(addr + T * 40);
   if (T == A_H) a.h = v; else a.l = v;
 }
-template <int F, int T>
+template <bool LO, int F, int T>
 __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int voff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, F * SCH_DFREQ + T * SCH_DTILE, 0);
+  // split-f16 image: [f][Re hi | Re lo | Im hi | Im lo]; single-product image: [f][Re | Im]
+  constexpr int off = LO ? F * SCH_DFREQ + T * SCH_DTILE : F * SCF_DFREQ + (T == B_IMH ? 1 : 0) * SCH_DTILE;
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, off, 0);
   if (T == B_REH) b.reh = v; else if (T == B_REL) b.rel = v; else if (T == B_IMH) b.imh = v; else b.iml = v;
 }
 
@@ -213,12 +213,12 @@ __device__ __forceinline__ void valu_slot(f32x4 (&T)[2][8], Half<LO> (&hbs)[2]) 
   }
 }
 
-template <bool LO, int NW, int GSTEP>
+template <bool LO, int NW>
 __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char* __restrict__ qpk,   // [2][QG32][4][31][1288 B]
                                                             const char* __restrict__ dpk,   // [2][DG][31][4][768 B] + zero groups
                                                             const u32x4* __restrict__ cst,  // [2][2][2][64] x 16 B
                                                             float* __restrict__ dist_p, float* __restrict__ dist_i,
-                                                            int m, int n, int QG8, int DG, int nsplit, int phase) {
+                                                            int m, int n, int QG8, int DG, int nsplit) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -229,45 +229,43 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   const int nrange = 4 * nsplit;
   const int g0 = (int)((long long)DG * range / nrange), g1 = (int)((long long)DG * (range + 1) / nrange);
 
-  {  // the 4 query groups of this workgroup -> LDS (linear copy; the packed image IS the LDS image) + zeroed tail
-    const u32x4* src = reinterpret_cast<const u32x4*>(qpk + ((size_t)ch * QG8 + (size_t)qg32 * 4) * SCH_QIMG);
+  // image geometry: split-f16 (4 query groups per workgroup) | single product (hi halves only: 8 query groups, kernels.hpp SCF_*)
+  constexpr int NQG = LO ? 4 : 8, QBLK = LO ? SCH_QBLK : SCF_QBLK, QIMG = LO ? SCH_QIMG : SCF_QIMG, DIMG = LO ? SCH_DIMG : SCF_DIMG;
+  constexpr int QROW = LO ? 80 : 40;
+  static_assert(NW == 4 || !LO, "two waves per SIMD: single-product form only (a split-f16 unit needs all 512 registers)");
+  {  // the query groups of this workgroup -> LDS (linear copy; the packed image IS the LDS image) + zeroed tail
+    const u32x4* src = reinterpret_cast<const u32x4*>(qpk + ((size_t)ch * QG8 + (size_t)qg32 * NQG) * QIMG);
     u32x4* dst = reinterpret_cast<u32x4*>(lds);
-    constexpr int NV = 4 * SCH_QIMG / 16;
+    constexpr int NV = NQG * QIMG / 16;
     for (int i = tid; i < NV + 4; i += 64 * NW) dst[i] = (i < NV) ? src[i] : u32x4{0u, 0u, 0u, 0u};
   }
   __syncthreads();
 
   const int row = lane & 15, kg = lane >> 4;
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds;
-  // query group inside the image; which of the GSTEP interleaved DB group sequences this wave takes.  NW = 4, GSTEP = 2: waves 0, 1 and
-  // waves 2, 3 walk different groups, so the two pairs are not held in step by shared L1 lines and their stage-1 (vector-memory bound)
-  // and stage-2 (matrix bound) phases can overlap
-  const int wq = w & 3, dpar = (NW == 8) ? (w >> 2) : 0;
-  // NW = 4, GSTEP = 2 ("split traversal"): waves 2, 3 walk the range from its middle (and wrap around), so the two wave pairs are never
-  // on the same group: nothing holds them in step, and one pair's stage 1 (vector-memory bound) can overlap the other's stage 2
-  constexpr bool SPLITW = (NW == 4 && GSTEP == 2);
-  constexpr int GINC = SPLITW ? 1 : GSTEP;
-  const int gcnt = g1 - g0, gshift = (SPLITW && (w >> 1)) ? gcnt / 2 : 0;
+  // query group inside the image; with more waves than query groups, wave w takes the DB groups g0 + w / NQG, + GSTEP, ...
+  const int wq = w & (NQG - 1), dpar = (NW > NQG) ? (w / NQG) : 0;
+  constexpr int GSTEP = NW / NQG;
+  const int gcnt = g1 - g0;
   constexpr int BD = LO ? E_BD : E_BD1;            // depth of the DB operand ring: the tiles of BD - 1 walk positions are in flight
   constexpr int AD = LO ? 2 : 3;                   // the same for the query tiles
-  const unsigned nat0 = lds0 + wq * SCH_QIMG + row * 80 + (row >= 8 ? 8 : 0) + kg * 16;
+  const unsigned nat0 = lds0 + wq * QIMG + row * QROW + (row >= 8 ? 8 : 0) + kg * 16;
   const int voff = (lane < 48) ? lane * 16 : (int)0x80000000;     // lanes 48-63: out of range -> zeros (K = 24..31)
   float* dist = ch ? dist_i : dist_p;
-  const char* dbase = dpk + ((size_t)ch * DG) * SCH_DIMG;
-  const int qrow0 = qg32 * 32 + wq * 8;
+  const char* dbase = dpk + ((size_t)ch * DG) * DIMG;
+  const int qrow0 = qg32 * (8 * NQG) + wq * 8;
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
       dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 8 ? m - qrow0 : 8) : 0) * n * 4, 0x00020000);
-  const int pf_slot = SPLITW ? (qg32 & 31) * 2 + (w & 1) : (qg32 & 31) * NW + w;   // this wave's share of the group(s) it helps to prefetch
-  constexpr int PFL = SPLITW ? 12 : 6;                                       // cache lines per wave
+  const int pf_slot = (qg32 & 31) * NW + w;                                  // this wave's share of the group(s) it helps to prefetch
+  constexpr int PFL = LO ? 6 : 2;                                            // cache lines per wave: 32 NW waves cover the GSTEP x DIMG / 128 lines
   unsigned pf_sink = 0;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(cst), 0, 8192, 0x00020000);
-  if (g0 + dpar >= g1) return;
-  if (SPLITW && (w >> 1)) for (int i = 0; i < phase; i++) __builtin_amdgcn_s_sleep(100);   // start the second pair ~phase x 6.4 k cycles late
+  if (dpar >= gcnt) return;
 
   AOps At[AD];
   BOps Bt[BD];
   __amdgpu_buffer_rsrc_t rs =
-      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g0 + dpar + gshift) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g0 + dpar) * DIMG), 0, DIMG, 0x00020000);
 // request K of the first ones of a unit (issued before the loop for the first unit, in the stage-2 gaps of the previous unit otherwise):
 // the DB tiles of walk positions 0 .. BD - 2 (TPB tiles each), then the query tiles of positions 0 .. AD - 2
   constexpr int TPB = LO ? 4 : 2, TPA = LO ? 2 : 1, NREQ = (BD - 1) * TPB + (AD - 1) * TPA;
@@ -275,31 +273,28 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   { if constexpr ((K) < (BD - 1) * TPB) {                                                                          \
       constexpr int _p = (K) / TPB, _t = LO ? (K) % TPB : 2 * ((K) % TPB);      /* order Re hi, (Re lo), Im hi, (Im lo) */ \
       constexpr int _tt = LO ? (_t == 1 ? B_IMH : _t == 2 ? B_REL : _t == 3 ? B_IML : B_REH) : _t;                 \
-      load_b<seqf(_p), _tt>(Bt[_p % BD], RSRC, voff);                                                              \
+      load_b<LO, seqf(_p), _tt>(Bt[_p % BD], RSRC, voff);                                                              \
     } else if constexpr ((K) < NREQ) {                                                                             \
       constexpr int _k = (K) - (BD - 1) * TPB, _p = _k / TPA, _t = _k % TPA;                                       \
-      load_a<_t>(At[_p % AD], nat0 + seqf(_p) * SCH_QBLK);                                                         \
+      load_a<_t>(At[_p % AD], nat0 + seqf(_p) * QBLK);                                                         \
     } }
   FIRST_REQ(0, rs) FIRST_REQ(1, rs) FIRST_REQ(2, rs) FIRST_REQ(3, rs) FIRST_REQ(4, rs) FIRST_REQ(5, rs) FIRST_REQ(6, rs) FIRST_REQ(7, rs)
   FIRST_REQ(8, rs) FIRST_REQ(9, rs) FIRST_REQ(10, rs) FIRST_REQ(11, rs) FIRST_REQ(12, rs) FIRST_REQ(13, rs) FIRST_REQ(14, rs) FIRST_REQ(15, rs)
   FIRST_REQ(16, rs) FIRST_REQ(17, rs) FIRST_REQ(18, rs) FIRST_REQ(19, rs) FIRST_REQ(20, rs) FIRST_REQ(21, rs) FIRST_REQ(22, rs) FIRST_REQ(23, rs)
   static_assert(NREQ <= 24, "FIRST_REQ list too short");
 
-  for (int gi = dpar; gi < gcnt; gi += GINC) {
-    // group of this iteration and of the next (the image ends with zero groups: the request past the last group is harmless)
-    const int gs0 = gi + gshift, gs1 = gi + GINC + gshift;
-    const int g = g0 + (gs0 >= gcnt ? gs0 - gcnt : gs0);
-    const int gn = (SPLITW && gi + GINC < gcnt) ? g0 + (gs1 >= gcnt ? gs1 - gcnt : gs1) : g + GINC;
+  for (int g = g0 + dpar; g < g1; g += GSTEP) {
+    const int gn = g + GSTEP;                       // (the image ends with zero groups: the requests past the last group are harmless)
     const __amdgpu_buffer_rsrc_t rsn =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)gn * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)gn * DIMG), 0, DIMG, 0x00020000);
     Half<LO> hbs[2];
     if constexpr ((E_ABL & 8) != 0) { for (int h_ = 0; h_ < 2; h_++) for (int r_ = 0; r_ < 4; r_++) { hbs[h_].reFh[r_] = hbs[h_].imFh[r_] = hbs[h_].reMh[r_] = hbs[h_].imMh[r_] = u32x4{0u, 0u, 0u, 0u}; if constexpr (LO) hbs[h_].reFl[r_] = hbs[h_].imFl[r_] = hbs[h_].reMl[r_] = hbs[h_].imMl[r_] = u32x4{0u, 0u, 0u, 0u}; } }
     Consts c0, c1;
     f32x4 T[2][8];
 
 // request tile T of walk position Q of this unit (Q >= 31: nothing)
-#define LDB(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || (TT == B_REH || TT == B_IMH)) && !(E_ABL & 2) && (!(E_ABL & 1) || TT == B_REH || TT == B_IMH)) load_b<seqf((Q) < 32 ? (Q) : 0), TT>(Bt[(Q) % BD], rs, voff); }
-#define LDA(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || TT == A_H) && !(E_ABL & 4)) load_a<TT>(At[(Q) % AD], nat0 + seqf((Q) < 32 ? (Q) : 0) * SCH_QBLK); }
+#define LDB(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || (TT == B_REH || TT == B_IMH)) && !(E_ABL & 2) && (!(E_ABL & 1) || TT == B_REH || TT == B_IMH)) load_b<LO, seqf((Q) < 32 ? (Q) : 0), TT>(Bt[(Q) % BD], rs, voff); }
+#define LDA(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || TT == A_H) && !(E_ABL & 4)) load_a<TT>(At[(Q) % AD], nat0 + seqf((Q) < 32 ? (Q) : 0) * QBLK); }
 #define VS(P, G) { if constexpr (!(E_ABL & 8)) valu_slot<LO, ((P) >> 2), (((P) & 3) * 6 + (G))>(T, hbs); }
 // one walk position: its 6 (LO) or 2 MFMAs, the requests for positions P + AD - 1 (query tiles) and P + BD - 1 (DB tiles), the quad's VALU
 // work of these six gaps
@@ -338,11 +333,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
     {  // L2 prefetch for the whole XCD: the 32 NW waves that sweep this range on this XCD cover the group(s) of the iteration after next
        // with 6 cache lines each, one dword per line into a register nobody reads before the same point of the next unit
       asm volatile("" : : "v"(pf_sink));
-      const int gs2 = gi + 2 * GINC + gshift;
-      const int gp = SPLITW ? g0 + (gs2 >= gcnt ? gs2 - gcnt : gs2) : (g - dpar) + 2 * GSTEP;
-      constexpr int PFG = SPLITW ? 1 : GSTEP;
-      const int pf_bytes = (SPLITW && gi + 2 * GINC >= gcnt) ? 0 : (gp + PFG <= DG) ? PFG * SCH_DIMG : (gp < DG ? (DG - gp) * SCH_DIMG : 0);
-      const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)gp * SCH_DIMG), 0, pf_bytes, 0x00020000);
+      const int gp = (g - dpar) + 2 * GSTEP;
+      const int pf_bytes = (gp + GSTEP <= DG) ? GSTEP * DIMG : (gp < DG ? (DG - gp) * DIMG : 0);
+      const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)gp * DIMG), 0, pf_bytes, 0x00020000);
       int lp = lane;
       asm volatile("" : "+v"(lp));
       const int pf_off = (lp < PFL) ? (pf_slot * PFL + lp) * 128 : (int)0x80000000;   // waves x PFL lines >= 744 lines per group
@@ -388,27 +381,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
 
 }  // namespace
 
-size_t sc_match_e_lds_bytes() { return (size_t)4 * SCH_QIMG + 64; }
+size_t sc_match_e_lds_bytes(int single) { return (single ? (size_t)8 * SCF_QIMG : (size_t)4 * SCH_QIMG) + 64; }
 
 void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                        int nsplit_override, int single) {
   if (m <= 0 || n <= 0) return;
-  const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n);
-  const int QG32 = QG8 / 4;
-  int nsplit = (128 + QG32 - 1) / QG32;
+  const int QG8 = single ? sc_qgroups8_f16(m) : sc_qgroups8(m), DG = sc_dgroups(n);
+  const int QGW = QG8 / (single ? 8 : 4);           // workgroups along the queries (64 | 32 queries each)
+  int nsplit = (128 + QGW - 1) / QGW;
   if (nsplit > DG / 32) nsplit = DG / 32;
   if (nsplit < 1) nsplit = 1;
   if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
-  static const int phase = getenv("PR_SC_E_PHASE") ? atoi(getenv("PR_SC_E_PHASE")) : 1;
-  static const int gs = getenv("PR_SC_E_GS") ? atoi(getenv("PR_SC_E_GS")) : 1;
   auto go = [&](auto kern, int nw) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes());
-    hipLaunchKernelGGL(kern, dim3(8 * QG32 * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(), st, static_cast<const char*>(qpk),
-                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, phase);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(single));
+    hipLaunchKernelGGL(kern, dim3(8 * QGW * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(single), st, static_cast<const char*>(qpk),
+                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit);
   };
-  if (single) go(sc_match_e_kernel<false, 8, 2>, 8);
-  else if (gs == 2) go(sc_match_e_kernel<true, 4, 2>, 4);
-  else go(sc_match_e_kernel<true, 4, 1>, 4);
+  if (single) go(sc_match_e_kernel<false, 8>, 8);
+  else go(sc_match_e_kernel<true, 4>, 4);
 }
 
 }  // namespace pr

@@ -175,14 +175,16 @@ __global__ __launch_bounds__(320) void sc_pack_h_kernel(const T* __restrict__ si
 //   norm      = every lane sums the squares of its column, the 20 partial sums of a signature are added in ring order
 //   output    = hi / lo halves scattered into an LDS copy of the workgroup's 8 frequency slices of the group image
 //               (a slice is contiguous: 3072 B per DB group, 1288 B per query group), then copied out linearly.
-template <typename T, int ROLE>
+template <typename T, int ROLE, bool LO>
 __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict__ sig, int rows,
                                                              unsigned short* __restrict__ packed, int groups,
                                                              const double* __restrict__ tw, int* __restrict__ flags,
                                                              int* __restrict__ bad) {
-  constexpr int SL = ROLE == 0 ? SCH_QBLK : SCH_DFREQ;          // bytes of one (group, frequency) slice
+  // LO = false: the single-product images (hi halves only, kernels.hpp SCF_*)
+  constexpr int SL = ROLE == 0 ? (LO ? SCH_QBLK : SCF_QBLK) : (LO ? SCH_DFREQ : SCF_DFREQ);   // bytes of one (group, frequency) slice
   constexpr int NG = ROLE == 0 ? 2 : 1;                         // groups per 16 signatures
-  constexpr int IMGB = ROLE == 0 ? SCH_QIMG : SCH_DIMG;
+  constexpr int IMGB = ROLE == 0 ? (LO ? SCH_QIMG : SCF_QIMG) : (LO ? SCH_DIMG : SCF_DIMG);
+  constexpr int QROW = LO ? 80 : 40;                            // bytes per query row: Q hi | Q lo
   __shared__ __attribute__((aligned(16))) char img[NG * 8 * SL];
   __shared__ double part[16 * 20];
   const int tid = threadIdx.x, lrow = tid / 20, ring = tid - 20 * lrow;
@@ -246,14 +248,14 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
     int bh, bl;   // byte offsets of hi and lo in the LDS copy
     if (ROLE == 0) {
       const int rr = (im << 3) | (lrow & 7);
-      bh = ((lrow >> 3) * 8 + slice) * SL + rr * 80 + (rr >= 8 ? 8 : 0) + ring * 2;
+      bh = ((lrow >> 3) * 8 + slice) * SL + rr * QROW + (rr >= 8 ? 8 : 0) + ring * 2;
       bl = bh + 40;
     } else {
-      bh = slice * SL + im * 2 * SCH_DTILE + (((ring >> 3) << 4) | lrow) * 16 + (ring & 7) * 2;
+      bh = slice * SL + im * (LO ? 2 : 1) * SCH_DTILE + (((ring >> 3) << 4) | lrow) * 16 + (ring & 7) * 2;
       bl = bh + SCH_DTILE;
     }
     *reinterpret_cast<_Float16*>(img + bh) = hi;
-    *reinterpret_cast<_Float16*>(img + bl) = lo;
+    if (LO) *reinterpret_cast<_Float16*>(img + bl) = lo;
   };
   if (valid) {
 #pragma unroll
@@ -280,9 +282,9 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
   }
 }
 
-template <typename T, int ROLE>
+template <typename T, int ROLE, bool LO = true>
 void launch_pack_col(hipStream_t st, const T* sig, int rows, unsigned short* packed, int groups, const double* tw, int* flags, int* bad) {
-  hipLaunchKernelGGL((sc_pack_h_col_kernel<T, ROLE>), dim3((unsigned)(((rows + 15) / 16 + 7) / 8) * 64), dim3(320), 0, st, sig, rows, packed,
+  hipLaunchKernelGGL((sc_pack_h_col_kernel<T, ROLE, LO>), dim3((unsigned)(((rows + 15) / 16 + 7) / 8) * 64), dim3(320), 0, st, sig, rows, packed,
                      groups, tw, flags, bad);
 }
 
@@ -298,8 +300,15 @@ void launch_zero_ints(hipStream_t st, int* p, int n) {
 }
 
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
-                      const double* twiddle, int* flags, int* bad) {
+                      const double* twiddle, int* flags, int* bad, int single) {
   if (rows <= 0) return;
+  if (single) {
+    if (dtype == 0 && role == 0) launch_pack_col<double, 0, false>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
+    else if (dtype == 0) launch_pack_col<double, 1, false>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
+    else if (role == 0) launch_pack_col<float, 0, false>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
+    else launch_pack_col<float, 1, false>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
+    return;
+  }
   static const bool valu = getenv("PR_SC_PACK") && !strcmp(getenv("PR_SC_PACK"), "valu");   // the per-thread DFT, kept for A/B runs
   if (valu && dtype == 0)
     hipLaunchKernelGGL(sc_pack_h_kernel<double>, dim3(rows * 2), dim3(320), 0, st, (const double*)sig, rows, role,

@@ -40,6 +40,11 @@ def _dptr(t: torch.Tensor | None):
     return C.c_void_p(t.data_ptr())
 
 
+def _dptr_mom(mt, sc: bool):
+    """The combined moments tensor of a Matcher as the (mom_sc | mom_m2) argument it belongs to (the other one is None)."""
+    return mt._mom_all if (mt.type == _lib.TYPE_SC) == sc else None
+
+
 def _torch_dt(t: torch.Tensor) -> int:
     return {torch.float64: _lib.F64, torch.float32: _lib.F32}[t.dtype]
 
@@ -67,6 +72,42 @@ class _Base:
         if not self.shared_stream:
             self.ctx.sync()
 
+    # ---- PR_SC_ARITH_F16 (single f16 product per term): exact indices need a margin check of the candidate list and, for the
+    # queries that fail it, a second pass in split-f16 (include/place_recognition.h)
+    @property
+    def f16(self) -> bool:
+        return self.ctx.sc_arith == "f16"
+
+    def _margin(self, mom_sc, mom_m2, G, p_weight, cand_sc: torch.Tensor, k: int, score: torch.Tensor):
+        """pr_f16_margin_dev -> (flags int32 [m], count int32 [1]) device tensors; no host synchronisation."""
+        m, kin = cand_sc.shape
+        flags = torch.empty((m,), dtype=torch.int32, device=self.dev)
+        count = torch.empty((1,), dtype=torch.int32, device=self.dev)
+        self._enter()
+        self.ctx.check(self.lib.pr_f16_margin_dev(self.ctx.h, _dptr(mom_sc), _dptr(mom_m2), m, G, float(p_weight), kin, _dptr(cand_sc.contiguous()),
+                                                  int(k), _dptr(score.contiguous()), _dptr(flags), _dptr(count)))
+        self._leave()
+        self.f16_flags, self.f16_count = flags, count
+        return flags, count
+
+    def _fallback_rows(self, run_rows, idx, score, mask_width, q_row0):
+        """Recomputes the flagged queries through `run_rows(rows tensor, q_row0 or None)` (a split-f16 matcher over the same DB) and
+        patches idx / score.  Reads the flag count back: one host synchronisation per call, only in the f16 arithmetic."""
+        cnt = int(self.f16_count.item())
+        self.f16_fallbacks = cnt
+        if cnt == 0:
+            return idx, score
+        rows = torch.nonzero(self.f16_flags, as_tuple=False).flatten()
+        idx, score = idx.clone(), score.clone()
+        if mask_width <= 0:                       # the mask does not look at the query's row number: one batch
+            i2, s2 = run_rows(rows, None)
+            idx[rows], score[rows] = i2, s2
+        else:
+            for r in rows.tolist():
+                i2, s2 = run_rows(rows.new_tensor([r]), q_row0 + r)
+                idx[r], score[r] = i2[0], s2[0]
+        return idx, score
+
 
 class Matcher(_Base):
     def __init__(self, type_: str, max_queries: int, max_db: int, ctx: Context | None = None, device: int | None = None):
@@ -74,6 +115,7 @@ class Matcher(_Base):
         self.rows_per_sig, self.sig_len = {_lib.TYPE_SC: (1, 2400), _lib.TYPE_M2DP: (4, 384), _lib.TYPE_DELIGHT: (16, 256)}[self.type]
         self.plain = self.type == _lib.TYPE_DELIGHT      # one distance matrix, no z-score fusion (run_test.m:26-36)
         self._init_ctx(ctx, device)
+        self._max_q, self._max_db = max_queries, max_db
         self.q = C.c_void_p()
         self.db = C.c_void_p()
         self.ctx.check(self.lib.pr_sigset_create(self.ctx.h, self.type, _lib.ROLE_QUERY, max_queries, C.byref(self.q)))
@@ -86,6 +128,9 @@ class Matcher(_Base):
         self.post_distances = None
 
     def close(self):
+        if getattr(self, "_twin", None) is not None:
+            self._twin.close()
+            self._twin = None
         if self.q:
             self.lib.pr_sigset_destroy(self.ctx.h, self.q)
             self.lib.pr_sigset_destroy(self.ctx.h, self.db)
@@ -136,7 +181,7 @@ class Matcher(_Base):
         return mom
 
     def _kin(self, k):
-        return k if self.plain else min(k + 8, 128)
+        return k if self.plain else int(self.lib.pr_rerank_width(self.ctx.h, int(k)))
 
     def local_select(self, mom_all: torch.Tensor, G: int, mask_width, p_weight, k, db_row0, q_row0):
         """fp32 selection of this shard's k + 8 best with the moments of all shards -> (idx_in i32 [m,kin], score f64 [m,kin])."""
@@ -197,14 +242,35 @@ class Matcher(_Base):
         return _merge_dev(self, idx_all, sc_all, k)
 
     def match(self, queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
-              db_row0: int = 0, q_row0: int = 0, group=None, force_exchange: bool = False):
+              db_row0: int = 0, q_row0: int = 0, group=None, force_exchange: bool = False, f16_fallback: bool = True):
         """Returns (idx int32 [m,k] GLOBAL DB row indices, score float64 [m,k]) as device tensors.
         force_exchange: run the two all-gathers and the merge even with one rank (measures the protocol's overhead)."""
         G = _world(group)
-        return sharded_topk(lambda: self.local_phase1(queries),
-                            lambda mom_all, G_: self.local_select(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
-                            k, group if (G > 1 or force_exchange) else None, G, merge=self.merge, force_exchange=force_exchange,
-                            rerank=None if self.plain else self.local_rerank, finish=self.finish)
+        f16 = self.f16 and not self.plain
+        post = (lambda cand_sc, idx, score: self._margin(_dptr_mom(self, True), _dptr_mom(self, False), self._args[0], p_weight, cand_sc, k,
+                                                          score)) if f16 else None
+        idx, score = sharded_topk(lambda: self.local_phase1(queries),
+                                  lambda mom_all, G_: self.local_select(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
+                                  k, group if (G > 1 or force_exchange) else None, G, merge=self.merge, force_exchange=force_exchange,
+                                  rerank=None if self.plain else self.local_rerank, finish=self.finish, post=post)
+        if f16 and f16_fallback:
+            def run_rows(rows, qr0):
+                fb = self._split_twin()
+                return fb.match(queries[rows].contiguous(), mask_width, p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group,
+                                force_exchange)
+            idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
+        return idx, score
+
+    def _split_twin(self):
+        """The same matcher in split-f16 over the same (already resident) raw DB, created and packed on first use."""
+        if getattr(self, "_twin", None) is None or self._twin_of is not self.db_sig:
+            if getattr(self, "_twin", None) is not None:
+                self._twin.close()
+            tw = Matcher({_lib.TYPE_SC: "sc", _lib.TYPE_M2DP: "m2dp"}[self.type], self._max_q, self._max_db,
+                         ctx=Context(self.ctx.device, sc_arith="f16x2", stream=self.ctx.stream))
+            tw.pack_database(self.db_sig)
+            self._twin, self._twin_of = tw, self.db_sig
+        return self._twin
 
     def distances(self):
         """The last distance matrices (device, float32 [m, n_local])."""
@@ -271,6 +337,9 @@ class FusedMatcher(_Base):
     _buf = Matcher._buf
 
     def close(self):
+        if getattr(self, "_twin", None) is not None:
+            self._twin.close()
+            self._twin = None
         self.sc.close(); self.m2.close()
 
     def pack_database(self, sc_sig: torch.Tensor, m2dp_sig: torch.Tensor):
@@ -290,7 +359,7 @@ class FusedMatcher(_Base):
         self._m1, self._m2 = mom_all[:, :, :2].contiguous(), mom_all[:, :, 2:].contiguous()
         self._args = (G, q_row0, db_row0, int(mask_width), float(p_weight))
         d = [self.sc._bufs["d_p"], self.sc._bufs["d_i"], self.m2._bufs["d_p"], self.m2._bufs["d_i"]]
-        kin = min(k + 8, 128)
+        kin = int(self.lib.pr_rerank_width(self.ctx.h, int(k)))
         idx_in = self._buf("idx_in", (m, kin), torch.int32)
         sc32 = self._buf("sc32", (m, kin), torch.float32)
         self._enter()
@@ -332,11 +401,28 @@ class FusedMatcher(_Base):
         return _merge_dev(self, idx_all, sc_all, k)
 
     def match(self, sc_queries: torch.Tensor, m2dp_queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
-              db_row0: int = 0, q_row0: int = 0, group=None):
+              db_row0: int = 0, q_row0: int = 0, group=None, f16_fallback: bool = True):
         G = _world(group)
-        return sharded_topk(lambda: self.local_phase1(sc_queries, m2dp_queries),
-                            lambda mom_all, G_: self.local_select(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
-                            k, group if G > 1 else None, G, merge=self.merge, rerank=self.local_rerank, finish=self.finish)
+        post = (lambda cand_sc, idx, score: self._margin(self._m1, self._m2, self._args[0], p_weight, cand_sc, k, score)) if self.f16 else None
+        idx, score = sharded_topk(lambda: self.local_phase1(sc_queries, m2dp_queries),
+                                  lambda mom_all, G_: self.local_select(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
+                                  k, group if G > 1 else None, G, merge=self.merge, rerank=self.local_rerank, finish=self.finish, post=post)
+        if self.f16 and f16_fallback:
+            def run_rows(rows, qr0):
+                fb = self._split_twin()
+                return fb.match(sc_queries[rows].contiguous(), m2dp_queries.view(-1, 4, 384)[rows].reshape(-1, 384).contiguous(), mask_width,
+                                p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group)
+            idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
+        return idx, score
+
+    def _split_twin(self):
+        if getattr(self, "_twin", None) is None or self._twin_of is not self.sc.db_sig:
+            if getattr(self, "_twin", None) is not None:
+                self._twin.close()
+            tw = FusedMatcher(self.sc._max_q, self.sc._max_db, ctx=Context(self.ctx.device, sc_arith="f16x2", stream=self.ctx.stream))
+            tw.pack_database(self.sc.db_sig, self.m2.db_sig)
+            self._twin, self._twin_of = tw, self.sc.db_sig
+        return self._twin
 
 
 def _world(group) -> int:
@@ -369,14 +455,20 @@ def _finish_dev(owner, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int):
     return idx, score
 
 
-def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None, force_exchange: bool = False, rerank=None, finish=None):
+def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None, force_exchange: bool = False, rerank=None, finish=None,
+                 post=None):
     """The exchange protocol of SURVEY.md §8-e around two local callables (HIP in production; a numpy stand-in in
     the gloo CPU tests): moments -> all_gather -> select with the moments of all shards -> all_gather -> merge."""
     import torch.distributed as dist
     mom = local_moments()
     if G == 1 and not force_exchange:
         idx_in, sc = local_select(mom.unsqueeze(0) if mom.dim() == 3 else mom, 1)
-        return rerank(idx_in, k, False, sc) if rerank is not None else (idx_in, sc)
+        if rerank is None:
+            return idx_in, sc
+        idx, score = rerank(idx_in, k, False, sc)
+        if post is not None:                             # PR_SC_ARITH_F16: margin flags of the candidate list (no synchronisation)
+            post(sc, idx, score)
+        return idx, score
     stage_on_host = dist.get_backend(group) == "gloo"   # gloo has no device all_gather: used by the single-GPU tests
 
     def gather(t):   # output = the ranks' tensors concatenated along dim 0, viewed as [G, ...]
@@ -396,7 +488,10 @@ def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None,
         return do_merge(idx_all, sc_all, k)
     cand_idx, cand_sc = do_merge(idx_all, sc_all, kin)   # the global top-(k+8) of the fp32 pass, identical on every rank
     part_all = gather(rerank(cand_idx, k, True, cand_sc))
-    return finish(cand_idx, part_all, k)
+    idx, score = finish(cand_idx, part_all, k)
+    if post is not None:
+        post(cand_sc, idx, score)
+    return idx, score
 
 
 def merge_topk(idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):

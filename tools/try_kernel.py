@@ -22,17 +22,19 @@ def one(name, n, m, reps, small):
     from so_dso_place_recognition_amd import api, synth
     from so_dso_place_recognition_amd.matcher import Matcher
     out = {"kernel": name}
-    # accuracy on a small case (m > 8 so that the selected kernel runs)
+    # accuracy on a small case (m > 8 so that the selected kernel runs); names "f16" / "f32" select the arithmetic instead of a kernel
+    arith = name if name in ("f16", "f32") else None
     db = synth.sc_database(45, small)
     q, _ = synth.sc_queries(46, db, 40)
-    dp, di = api.processSC(q, db)
+    dp, di = api.processSC(q, db, api.Context(0, sc_arith=arith))
     rc, op, oi = oracle_lib.sc_distance(q, db)
     out["max_abs_err"] = float(max(np.abs(dp - op).max(), np.abs(di - oi).max()))
     dev = torch.device("cuda", 0)
     dbt = synth.sc_database_torch(45, n, device=dev)
     q_h, planted = synth.sc_queries(46, dbt[: min(n, 200000)].cpu().numpy() if n > 200000 else dbt.cpu().numpy(), m)
     qt = torch.from_numpy(q_h).to(dev)
-    mt = Matcher("sc", m, n)
+    cur = int(torch.cuda.current_stream(dev).cuda_stream)
+    mt = Matcher("sc", m, n, ctx=api.Context(0, sc_arith=arith, stream=cur))
     ev = HipEvents()
     mt.pack_database(dbt)
     pair = [ev.create(), ev.create()]
