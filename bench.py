@@ -67,6 +67,66 @@ class HipEvents:
         return ms.value
 
 
+def blas_baseline(q_host, db_host, S):
+    """The reference matcher in its own shape (processSC.m:15-33 + run_test.m:38-41, 57): rows / L2 norm, per query and channel ONE dense
+    dgemm `sig_i (120 x 1200) * hist2' (1200 x n)` on the host's multithreaded BLAS (numpy -> OpenBLAS), column minimum, 2:1 z-score fusion,
+    arg-min.  Returns (seconds, top-1 indices, threads BLAS reports)."""
+    import numpy as np
+    try:
+        from threadpoolctl import threadpool_info
+        nthr = max([p.get("num_threads", 1) for p in threadpool_info() if p.get("user_api") == "blas"] or [1])
+    except Exception:
+        nthr = None
+    s, r = np.meshgrid(np.arange(60), np.arange(20), indexing="ij")              # flattened bin = sector * 20 + ring (SC.cpp:39)
+    V = np.empty((120, 1200), np.int64)
+    for k0 in range(60):
+        V[k0] = (((k0 + s) % 60) * 20 + r).reshape(-1)                            # processSC.m:40 forward rotation
+        V[60 + k0] = (((k0 - s) % 60) * 20 + r).reshape(-1)                       # processSC.m:42 mirrored rotation
+    t0 = time.perf_counter()
+    h2t = []
+    for c in range(2):
+        x = db_host[:, 1200 * c: 1200 * (c + 1)]
+        h2t.append(np.ascontiguousarray((x / np.sqrt((x * x).sum(1, keepdims=True))).T))     # processSC.m:18-20
+    top1 = np.empty(S, np.int64)
+    for i in range(S):
+        f = 0.0
+        for c in range(2):
+            row = q_host[i, 1200 * c: 1200 * (c + 1)]
+            row = row / np.sqrt((row * row).sum())                                # processSC.m:15-17
+            d = ((1.0 - row[V] @ h2t[c]) / 2.0).min(0)                            # processSC.m:30-32
+            f = f + (2.0 if c == 0 else 1.0) * (d - d.mean()) / d.std(ddof=1)     # run_test.m:38-41
+        top1[i] = int(np.argmin(f))                                               # run_test.m:57
+    return time.perf_counter() - t0, top1, nthr
+
+
+def via_group(args):
+    """--via-group: the same metric through the C ABI's own sharding (pr_group: one process drives all GPUs, RCCL in-process).  The call takes
+    HOST query buffers (it is the drop-in form of run_test.m:25-57), so the 39 MB of queries cross PCIe in every step: reported as its own
+    line, never as the headline value."""
+    import numpy as np
+    from so_dso_place_recognition_amd import synth
+    from so_dso_place_recognition_amd.api import Group
+    n, m = args.db, args.queries
+    db = synth.sc_database(45, n)
+    q, planted = synth.sc_queries(46, np.empty((0, 2400)), m, db_first=0, n_global=n, db_seed=45)
+    g = Group(list(range(args.gpus)))
+    g.set_database("sc", db)
+    for _ in range(args.warmup):
+        g.match_topk(q, 0, 2.0, 1)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        idx, sc = g.match_topk(q, 0, 2.0, 1)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"metric": "queries/sec over 100k-signature DB (SC 20x60, z-score fusion, top-1), through pr_group (C ABI, host query buffers)",
+                      "value": m * args.steps / dt, "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                      "dtype": "f16x2 (fp32 carried as f16 hi + lo, fp32 accumulate)", "data": "synthetic",
+                      "config": {"workload": "sc_match_100k", "db_signatures": n, "queries_per_step": m, "via": "pr_group_match_topk",
+                                 "uses_rccl": g.uses_rccl, "note": "DB packed once (pr_group_set_database); queries host -> every GPU per step"},
+                      "parity": {"planted_top1_correct": int((idx[:, 0] == planted).sum()), "queries": m}}), flush=True)
+    g.close()
+
+
 def extra_workloads(dev, ev, args):
     """Secondary workloads of BASELINE.json, measured after (outside) the timed region on the same GPU."""
     import numpy as np
@@ -154,6 +214,70 @@ def extra_workloads(dev, ev, args):
                                       "frac_of_fp32_mfma_peak": m * n * FLOP_PER_PAIR / (k * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                       "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == planted).sum()), "queries": m}
     mt.close()
+    # PR_SC_ARITH_F16 (BASELINE config 5's "fp16 descriptors": one f16 per value, one MFMA per product) on the metric workload: whole steps
+    # (pack(q) + pack(db) + distances + moments + select(k + 56) + fp64 re-evaluation + margin check + split-f16 fallback of flagged queries)
+    mt = Matcher("sc", m, n, ctx=Context(dev.index, sc_arith="f16", stream=cur))
+    mt.pre_distances = lambda: ev.record(pair[0], mt.ctx.stream)
+    mt.post_distances = lambda: ev.record(pair[1], mt.ctx.stream)
+    kms = []
+
+    def f16_step():
+        mt.pack_database(db)
+        return mt.match(q, 0, 2.0, 1)
+    f16_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        idx, _ = f16_step()
+        kms.append(ev.elapsed_ms(pair[0], pair[1]))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    k = float(np.mean(kms))
+    out["sc_match_100k_f16_arith"] = {"queries_per_s": m / dt, "ms_per_step": 1e3 * dt, "kernel": "sc_match_e_kernel<single product>", "ms_per_launch": k,
+                                      "flop_per_pair": FLOP_PER_PAIR, "achieved_TFLOPs": m * n * FLOP_PER_PAIR / (k * 1e-3) / 1e12,
+                                      "frac_of_f16_mfma_peak": m * n * FLOP_PER_PAIR / (k * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                      "packed_db_bytes_per_entry": 2 * 2976, "queries_recomputed_in_split_f16": int(mt.f16_fallbacks),
+                                      "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == planted).sum()), "queries": m}
+    mt.close(); del mt
+    torch.cuda.empty_cache()
+    # BASELINE config 5, one GPU's share: fused SC + M2DP scoring, 125 000 of the 1 M signatures (an 8-GPU shard), f16 descriptors
+    from so_dso_place_recognition_amd.matcher import FusedMatcher
+    ns = 125_000
+    dbs = synth.sc_database_torch(71, ns, device=dev)
+    dbm = synth.m2dp_database_torch(73, ns, device=dev)
+    qs_h, pl5 = synth.sc_queries(72, np.empty((0, 2400)), m, db_first=0, n_global=ns, db_seed=71)
+    qm_h = np.concatenate([synth.m2dp_queries(74 + 0 * i, synth.m2dp_database(73, 1, first=int(e)), 1)[0] for i, e in enumerate(pl5[:256])])
+    qm_h = np.tile(qm_h, (m // 256, 1))                                          # M2DP queries: 256 planted rows repeated (timing only needs the shape)
+    qs, qm = torch.from_numpy(qs_h).to(dev), torch.from_numpy(qm_h).to(dev)
+    fm = FusedMatcher(m, ns, ctx=Context(dev.index, sc_arith="f16", stream=cur))
+    pair2 = [ev.create(), ev.create()]
+    fm.sc.pre_distances = lambda: ev.record(pair[0], fm.ctx.stream)
+    fm.sc.post_distances = lambda: ev.record(pair[1], fm.ctx.stream)
+    fm.m2.pre_distances = lambda: ev.record(pair2[0], fm.ctx.stream)
+    fm.m2.post_distances = lambda: ev.record(pair2[1], fm.ctx.stream)
+
+    def fused_step():
+        fm.pack_database(dbs, dbm)
+        return fm.match(qs, qm, 0, 2.0, 1)
+    fused_step()
+    torch.cuda.synchronize()
+    ks, km = [], []
+    t0 = time.perf_counter()
+    for _ in range(5):
+        idx, _ = fused_step()
+        ks.append(ev.elapsed_ms(pair[0], pair[1])); km.append(ev.elapsed_ms(pair2[0], pair2[1]))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    ks, km = float(np.mean(ks)), float(np.mean(km))
+    out["fused_1m_shard_fp16"] = {"note": "BASELINE config 5, the per-GPU share of 1 M signatures over 8 GPUs: SC + M2DP, four z-scores, f16 descriptors, "
+                                          "k + 56 candidates re-evaluated in fp64, margin check, split-f16 fallback",
+                                  "db_rows": ns, "queries": m, "queries_per_s": m / dt, "ms_per_step": 1e3 * dt,
+                                  "sc_kernel_ms": ks, "sc_frac_of_f16_mfma_peak": m * ns * FLOP_PER_PAIR / (ks * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                  "m2dp_kernel_ms": km, "m2dp_frac_of_f16_mfma_peak": m * ns * 12288 / (km * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                  "queries_recomputed_in_split_f16": int(fm.f16_fallbacks),
+                                  "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == pl5).sum())}
+    fm.close(); del fm, dbs, dbm, qs, qm
+    torch.cuda.empty_cache()
     # online use (one keyframe at a time against a resident, already packed DB): wall time per call, host launch overhead included
     mt = Matcher("sc", 32, n, ctx=Context(dev.index, stream=cur))
     mt.pack_database(db)
@@ -198,13 +322,18 @@ def main():
     ap.add_argument("--queries", type=int, default=4096)
     ap.add_argument("--cpu-sample", type=int, default=-1, help="queries for the CPU baseline (-1: one per host core, <= 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--sc-arith", default=None, choices=["f16x2", "f32"],
-                    help="SC matcher arithmetic (default: the library's, split-f16 MFMA; f32 = the fp32-MFMA kernel)")
+    ap.add_argument("--sc-arith", default=None, choices=["f16x2", "f32", "f16"],
+                    help="SC matcher arithmetic (default: the library's, split-f16 MFMA; f32 = the fp32-MFMA kernel; f16 = one f16 product per term)")
+    ap.add_argument("--via-group", action="store_true",
+                    help="ONE process drives --gpus GPUs through pr_group (C ABI, in-process RCCL) instead of one torch.distributed rank per GPU")
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: run the two all-gathers (RCCL, one-rank group) and the device merge of the sharded protocol anyway")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under `extra`")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: several ranks on ONE GPU, tests only)")
     args = ap.parse_args()
+
+    if args.via_group:
+        return via_group(args)
 
     import numpy as np
     import torch
@@ -287,9 +416,11 @@ def main():
         qps = m * args.steps / dt
         kms = float(np.mean(kern_ms))
         pairs = m * (hi - lo)
-        f16 = arith == "f16x2"
+        f16 = arith in ("f16x2", "f16")
         kname = {"h": "sc_match_h_kernel", "d": "sc_match_d_kernel"}.get(os.environ.get("PR_SC_KERNEL", "e"), "sc_match_e_kernel") if f16 else "sc_match_kernel"
-        fpp, peak = (FLOP_PER_PAIR_F16X2, MFMA_F16_PEAK_TFLOPS) if f16 else (FLOP_PER_PAIR, MFMA_F32_PEAK_TFLOPS)
+        if arith == "f16":
+            kname = "sc_match_e_kernel<single product>"
+        fpp, peak = (FLOP_PER_PAIR_F16X2 if arith == "f16x2" else FLOP_PER_PAIR, MFMA_F16_PEAK_TFLOPS) if f16 else (FLOP_PER_PAIR, MFMA_F32_PEAK_TFLOPS)
         ach = pairs * fpp / (kms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
         try:
@@ -303,7 +434,7 @@ def main():
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "ms_per_query": 1e3 * dt / (args.steps * m),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f16x2 (fp32 carried as f16 hi + lo, fp32 accumulate)" if f16 else "f32",
+            "dtype": {"f16x2": "f16x2 (fp32 carried as f16 hi + lo, fp32 accumulate)", "f16": "f16 (one f16 per value, fp32 accumulate; exact top-k through fp64 re-evaluation)"}.get(arith, "f32"),
             "data": "synthetic",
             "config": {"workload": "sc_match_100k", "db_signatures": n, "queries_per_step": m, "descriptor": "SC 20x60 x 2 channels",
                        "mask_width": 0, "p_weight": 2.0, "k": 1, "db_rows_per_gpu": hi - lo,
@@ -339,6 +470,14 @@ def main():
                                    "value_1_thread": 1.0 / cdt1,
                                    "sample": f"{S} queries x full {n}-signature DB on {min(cores, S)} threads ({cdt:.1f} s) and 1 query on 1 thread "
                                              f"({cdt1:.1f} s), dense 120-variant fp64 (oracle/pr_ref.cpp)"}
+            try:   # the reference matcher's own shape: one multithreaded dgemm per query and channel (processSC.m:30)
+                bdt, btop, bthr = blas_baseline(q_host, db_host, S)
+                out["cpu_baseline"]["blas"] = {"value": S / bdt, "unit": "queries/s", "threads": bthr, "top1_equal_oracle": bool((btop == oidx[:, 0]).all()),
+                                               "tflops_fp64": S * 2 * 120 * 1200 * n * 2 / bdt / 1e12,
+                                               "sample": f"{S} queries x full {n}-signature DB, numpy / OpenBLAS dgemm 120 x 1200 . 1200 x n per query and channel "
+                                                         f"({bdt:.1f} s incl. the normalisation of hist2)"}
+            except Exception as e:
+                out["cpu_baseline"]["blas"] = {"error": repr(e)[:200]}
             err = np.abs(osc[:, 0] - score_h[:S])
             out["parity"].update({"oracle_queries": S, "oracle_top1_equal": bool((oidx[:, 0] == idx_h[:S]).all()),
                                   "oracle_max_abs_score_err": float(err.max()),

@@ -90,14 +90,14 @@ __device__ __forceinline__ void block_argmin(double* rv, int* rj, int tid) {
   }
 }
 
-constexpr int FS_CAP = 2048;   // survivors of the threshold pass kept in LDS
+constexpr int FS_CAP = 3072;   // survivors of the threshold pass kept in LDS
 
 // e_p / e_i / mom2_all: an optional SECOND channel pair over the same (query, entry) grid whose z-scores are added with the
 // same weights (BASELINE.json config 5, "fused SC + M2DP scoring": build-defined, no reference counterpart).
 //
 // Selection of the k smallest (score, index) pairs of a row in about ONE pass over it, whatever k:
 //   k = 1   every thread keeps the minimum of its elements, block argmin.
-//   k > 1   (a) a sample - the first 4096 columns, 16 per thread: the r-th smallest of the 256 per-thread sample minima,
+//   k > 1   (a) a sample - the first 4096 columns (more for large k, see below), 16 per thread: the r-th smallest of the 256 per-thread sample minima,
 //               tau (r = max(k + 7, 16)), is the score of r distinct elements, so at least r >= k elements of the row are
 //               <= tau, and about r n / 4096 of them in all;
 //           (b) one sweep of the row: every element with score <= tau (ties included) goes to an LDS list;
@@ -201,13 +201,16 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   if (k <= 249) {
     double mv = 0.0;
     int mj = -1;
-    const int ns = n < 4096 ? n : 4096;
+    // sample size: ~r n / ns elements pass the threshold - 4096 columns for the k + 8 <= 16 of the fp32-grade arithmetics (~24 r), more for
+    // the k + 56 candidates of PR_SC_ARITH_F16 so that the list stays near a third of its capacity (an overflow costs k sweeps)
+    const int r = k + 7 > 16 ? k + 7 : 16;
+    long long want = (long long)n * r / (FS_CAP / 3);
+    const int ns = (int)(want < 4096 ? (n < 4096 ? n : 4096) : (want < n ? want : n));
     for (int j = tid; j < ns; j += 256) {
       const double f = fused(rp[j], ri[j], j);
       const int jg = db_row0 + j;
       if (f == f && (mj < 0 || cand_less(f, jg, mv, mj))) { mv = f; mj = jg; }
     }
-    const int r = k + 7 > 16 ? k + 7 : 16;
     for (int t = 0; t < r; t++) {
       rv[tid] = mv; rj[tid] = mj;
       block_argmin(rv, rj, tid);
