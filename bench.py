@@ -278,22 +278,29 @@ def extra_workloads(dev, ev, args):
                                   "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == pl5).sum())}
     fm.close(); del fm, dbs, dbm, qs, qm
     torch.cuda.empty_cache()
-    # online use (one keyframe at a time against a resident, already packed DB): wall time per call, host launch overhead included
-    mt = Matcher("sc", 32, n, ctx=Context(dev.index, stream=cur))
-    mt.pack_database(db)
+    # online use (one keyframe at a time against a resident, already packed DB): wall time per call, host launch overhead included.
+    # The floor of such a call is one read of the packed DB image from HBM: 2 channels x ceil(n / 16) groups x 95 232 B (split-f16) or
+    # 47 616 B (one f16 per value); frac_of_8TBps prices the WHOLE call (pack(q) .. re-evaluation, ~10 launches) against that read at 8 TB/s.
     lat = {}
-    for mq in (1, 8, 32):
-        qq = q[:mq].contiguous()
-        for _ in range(3):
-            mt.match(qq, 0, 2.0, 1)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            idx, _ = mt.match(qq, 0, 2.0, 1)
+    for arith_l, gbytes in (("f16x2", 95232), ("f16", 47616)):
+        mt = Matcher("sc", 32, n, ctx=Context(dev.index, sc_arith=arith_l, stream=cur))
+        mt.pack_database(db)
+        img = 2 * ((n + 15) // 16) * gbytes
+        for mq in (1, 8, 32):
+            qq = q[:mq].contiguous()
+            for _ in range(3):
+                mt.match(qq, 0, 2.0, 1)
             torch.cuda.synchronize()
-        lat[f"m={mq}"] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / 20, "top1_correct": int((idx.cpu().numpy()[:, 0] == planted[:mq]).sum())}
-    out["sc_match_100k_latency"] = {"note": "pack(q) + distances + moments + select + fp64 re-evaluation, DB resident and packed, synchronised per call", **lat}
-    mt.close()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                idx, _ = mt.match(qq, 0, 2.0, 1)
+                torch.cuda.synchronize()
+            ms = 1e3 * (time.perf_counter() - t0) / 20
+            lat[f"m={mq}" + ("" if arith_l == "f16x2" else " f16")] = {"ms_per_call": ms, "hbm_bytes": img, "frac_of_8TBps": img / (ms * 1e-3) / 8e12,
+                                                                       "top1_correct": int((idx.cpu().numpy()[:, 0] == planted[:mq]).sum())}
+        mt.close()
+    out["sc_match_100k_latency"] = {"note": "pack(q) + distances + moments + select + fp64 re-evaluation (+ margin check in f16), DB resident and packed, "
+                                            "synchronised per call; hbm_bytes = one read of the packed DB image", **lat}
     try:   # the same call replayed as one hipGraph
         mg = Matcher.on_new_stream("sc", 8, n, device=dev.index)
         with torch.cuda.stream(mg.stream):
@@ -305,7 +312,9 @@ def extra_workloads(dev, ev, args):
         t0 = time.perf_counter()
         for _ in range(20):
             cap.run()
-        out["sc_match_100k_latency"]["m=1 hipGraph replay"] = {"ms_per_call": 1e3 * (time.perf_counter() - t0) / 20,
+        ms = 1e3 * (time.perf_counter() - t0) / 20
+        img = 2 * ((n + 15) // 16) * 95232
+        out["sc_match_100k_latency"]["m=1 hipGraph replay"] = {"ms_per_call": ms, "hbm_bytes": img, "frac_of_8TBps": img / (ms * 1e-3) / 8e12,
                                                                 "top1_correct": int((cap.idx.cpu().numpy()[:, 0] == planted[:1]).sum())}
         mg.close()
     except Exception as e:   # graph capture is an extra, never a reason to lose the bench line

@@ -13,10 +13,14 @@ def main():
         has_pmc = c.execute("select count(*) from counters_collection").fetchone()[0]
         if n and not has_pmc:
             print("-- kernel trace (rocprofv3 --kernel-trace --stats): name, calls, avg/min/max ms, total ms, vgpr, agpr, lds")
+            cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
+            grid = next((x for x in ("grid_size_x", "grid_x", "grid_size") if x in cols), None)
+            # one line per (kernel, grid size): the same kernel runs the timed step and the small latency / test launches
             q = ("select name, count(*), avg(end-start)/1e6, min(end-start)/1e6, max(end-start)/1e6, sum(end-start)/1e6,"
-                 " max(vgpr_count), max(accum_vgpr_count), max(lds_size) from kernels group by name order by 6 desc")
+                 " max(vgpr_count), max(accum_vgpr_count), max(lds_size)" + (", " + grid if grid else ", 0") +
+                 " from kernels group by name" + (", " + grid if grid else "") + " order by 6 desc")
             for r in c.execute(q):
-                print("%-72s n=%-3d avg=%9.3f min=%9.3f max=%9.3f total=%9.1f vgpr=%s agpr=%s lds=%s" % ((r[0][:72],) + r[1:]))
+                print("%-72s n=%-3d avg=%9.3f min=%9.3f max=%9.3f total=%9.1f vgpr=%s agpr=%s lds=%s grid=%s" % ((r[0][:72],) + r[1:]))
         if has_pmc:
             print("-- PMC (rocprofv3 --pmc ...): kernel, counter, sum over dispatches, dispatches")
             q = ("select kernel_name, counter_name, sum(value), count(*) from counters_collection"

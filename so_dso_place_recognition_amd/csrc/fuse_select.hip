@@ -71,26 +71,79 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restric
   }
 }
 
+// Few query rows (a keyframe per call): one workgroup per row leaves the chip idle and pays the row's whole latency in one place.  The row is
+// cut into P slices, one workgroup each (grid m x P): raw sums (count, S1, S2) about the row's first element per slice, added in slice order
+// by moments_finish_kernel - deterministic for a given (m, n).
+__global__ __launch_bounds__(256) void row_moments_slice_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i, int n, int m, int P,
+                                                                 double* __restrict__ part /* [P][m][2][3] */) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x, q = blockIdx.x, sl = blockIdx.y;
+  const int c0 = (int)((long long)n * sl / P), c1 = (int)((long long)n * (sl + 1) / P);
+  for (int ch = 0; ch < 2; ch++) {
+    const float* row = (ch ? d_i : d_p) + (size_t)q * n;
+    const float r0 = row[0];
+    const double c = (r0 == r0) ? (double)r0 : 0.5;
+    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
+    for (int j = c0 + tid; j < c1; j += 256) {
+      const float v = row[j];
+      if (v == v) { const double d = (double)v - c; s1 += d; s2 += d * d; cnt += 1.0; }
+    }
+    const double S1 = block_sum(s1, red, tid);
+    const double S2 = block_sum(s2, red, tid);
+    const double N = block_sum(cnt, red, tid);
+    if (tid == 0) {
+      double* o = part + (((size_t)sl * m + q) * 2 + ch) * 3;
+      o[0] = N; o[1] = S1; o[2] = S2;
+    }
+  }
+}
+__global__ __launch_bounds__(64) void moments_finish_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i, int n, int m, int P,
+                                                             const double* __restrict__ part, double* __restrict__ mom) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= 2 * m) return;
+  const int q = t >> 1, ch = t & 1;
+  const float r0 = ((ch ? d_i : d_p) + (size_t)q * n)[0];
+  const double c = (r0 == r0) ? (double)r0 : 0.5;
+  double N = 0.0, S1 = 0.0, S2 = 0.0;
+  for (int sl = 0; sl < P; sl++) {
+    const double* o = part + (((size_t)sl * m + q) * 2 + ch) * 3;
+    N += o[0]; S1 += o[1]; S2 += o[2];
+  }
+  double* o = mom + ((size_t)q * 2 + ch) * 3;
+  o[0] = N;
+  o[1] = N > 0.0 ? c + S1 / N : 0.0;
+  o[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
+}
+
 __device__ __forceinline__ bool cand_less(double av, int aj, double bv, int bj) {   // (a) < (b) lexicographic
   return av < bv || (av == bv && aj < bj);
 }
 
-// argmin over the workgroup of (v, j) pairs with j >= 0 (j < 0 = no candidate); result in rv[0], rj[0]
+// argmin over the workgroup of (v, j) pairs with j >= 0 (j < 0 = no candidate); result in rv[0], rj[0].  Inside a wave by lane exchanges
+// (no barrier), the four wave results through LDS: two barriers instead of nine - the selection loops below call this k + r times per row.
 __device__ __forceinline__ void block_argmin(double* rv, int* rj, int tid) {
-  __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) {
-      const int oj = rj[tid + s];
-      if (oj >= 0 && (rj[tid] < 0 || cand_less(rv[tid + s], oj, rv[tid], rj[tid]))) {
-        rv[tid] = rv[tid + s];
-        rj[tid] = oj;
-      }
-    }
-    __syncthreads();
+  double v = rv[tid];
+  int j = rj[tid];
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) {
+    const double ov = __shfl_xor(v, s, 64);
+    const int oj = __shfl_xor(j, s, 64);
+    if (oj >= 0 && (j < 0 || cand_less(ov, oj, v, j))) { v = ov; j = oj; }
   }
+  __syncthreads();                                   // everybody has read its own rv / rj entry
+  if ((tid & 63) == 0) { rv[tid >> 6] = v; rj[tid >> 6] = j; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; w++) {
+      const int oj = rj[w];
+      if (oj >= 0 && (j < 0 || cand_less(rv[w], oj, v, j))) { v = rv[w]; j = oj; }
+    }
+    rv[0] = v; rj[0] = j;
+  }
+  __syncthreads();
 }
 
-constexpr int FS_CAP = 3072;   // survivors of the threshold pass kept in LDS
+constexpr int FS_CAP = 4096;   // survivors of the threshold pass kept in LDS (a power of two: the list is bitonic-sorted for large k)
 
 // e_p / e_i / mom2_all: an optional SECOND channel pair over the same (query, entry) grid whose z-scores are added with the
 // same weights (BASELINE.json config 5, "fused SC + M2DP scoring": build-defined, no reference counterpart).
@@ -110,7 +163,7 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
                                                            const double* __restrict__ mom2_all,
                                                            int m, int n, const double* __restrict__ mom_all, int G,
                                                            int q_row0, int db_row0, int mask_width, double p_weight,
-                                                           int k, int32_t* __restrict__ idx, float* __restrict__ score) {
+                                                           int k, int32_t* __restrict__ idx, float* __restrict__ score, int P) {
   __shared__ double st[8];
   __shared__ double rv[256];
   __shared__ int rj[256];
@@ -137,6 +190,20 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   if (tid == 0) lcnt = 0;
   __syncthreads();
   const double mp = plain ? 0.0 : st[0], sp = plain ? 1.0 : st[1], mi = plain ? 0.0 : st[2], si = plain ? 1.0 : st[3];
+  // P > 1 (few query rows, grid m x P): this workgroup selects inside columns [c0, c0 + n) of its row only and writes list blockIdx.y of
+  // [P][m][k]; slice_merge_kernel merges the P ascending lists (the moments are those of the whole row either way)
+  const int n_row = n;
+  if (P > 1) {
+    const int c0 = (int)((long long)n_row * blockIdx.y / P), c1 = (int)((long long)n_row * (blockIdx.y + 1) / P);
+    const size_t ro = (size_t)q * n_row + c0;
+    d_p += ro - (size_t)q * (c1 - c0);          // so that the row addressing below (q * n + j with the slice length n) lands on the slice
+    if (d_i) d_i += ro - (size_t)q * (c1 - c0);
+    if (e_p) { e_p += ro - (size_t)q * (c1 - c0); e_i += ro - (size_t)q * (c1 - c0); }
+    db_row0 += c0;
+    n = c1 - c0;
+    idx += (size_t)blockIdx.y * m * k;
+    score += (size_t)blockIdx.y * m * k;
+  }
   const float* rp = d_p + (size_t)q * n;
   const float* ri = plain ? rp : d_i + (size_t)q * n;
   const int ig = q_row0 + q;
@@ -198,13 +265,13 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   }
   // ---- (a) threshold from a sample
   double tau = __builtin_inf();
-  if (k <= 249) {
+  if (k <= 249 && n > FS_CAP) {                    // (a row or slice that fits the list needs no threshold)
     double mv = 0.0;
     int mj = -1;
     // sample size: ~r n / ns elements pass the threshold - 4096 columns for the k + 8 <= 16 of the fp32-grade arithmetics (~24 r), more for
     // the k + 56 candidates of PR_SC_ARITH_F16 so that the list stays near a third of its capacity (an overflow costs k sweeps)
     const int r = k + 7 > 16 ? k + 7 : 16;
-    long long want = (long long)n * r / (FS_CAP / 3);
+    long long want = (long long)n * r / 1024;
     const int ns = (int)(want < 4096 ? (n < 4096 ? n : 4096) : (want < n ? want : n));
     for (int j = tid; j < ns; j += 256) {
       const double f = fused(rp[j], ri[j], j);
@@ -231,6 +298,26 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   });
   __syncthreads();
   const int L = lcnt;
+  if (L <= FS_CAP && k > 12) {
+    // many results: sort the list once (bitonic network over the next power of two, (+Inf, INT_MAX) padding) instead of k arg-min rounds
+    int N = 2;
+    while (N < L) N <<= 1;
+    for (int s = L + tid; s < N; s += 256) { lv[s] = __builtin_inf(); lj[s] = 0x7fffffff; }
+    __syncthreads();
+    for (int size = 2; size <= N; size <<= 1)
+      for (int stride = size >> 1; stride > 0; stride >>= 1) {
+        for (int i = tid; i < (N >> 1); i += 256) {
+          const int pos = 2 * i - (i & (stride - 1)), par = pos + stride;
+          const bool up = (pos & size) == 0;
+          const double a = lv[pos], b = lv[par];
+          const int aj = lj[pos], bj2 = lj[par];
+          if (cand_less(b, bj2, a, aj) == up) { lv[pos] = b; lj[pos] = bj2; lv[par] = a; lj[par] = aj; }
+        }
+        __syncthreads();
+      }
+    for (int t = tid; t < k; t += 256) emit(t, lv[t < L ? t : 0], t < L ? lj[t] : -1);
+    return;
+  }
   if (L <= FS_CAP) {
     for (int t = 0; t < k; t++) {
       double cv = 0.0;
@@ -276,19 +363,84 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   }
 }
 
+// P lists of k (score, index) pairs per query [P][m][k] -> the k best [m][k]; missing entries are -1.  One workgroup per query: the P k
+// entries (at most 8192) are sorted in LDS by a bitonic network.
+__global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restrict__ sidx, const float* __restrict__ sscore, int P, int m, int k,
+                                                           int32_t* __restrict__ idx, float* __restrict__ score) {
+  extern __shared__ __attribute__((aligned(8))) char smem[];
+  const int q = blockIdx.x, tid = threadIdx.x, T = P * k;
+  int N = 2;
+  while (N < T) N <<= 1;
+  float* lv = reinterpret_cast<float*>(smem);
+  int* lj = reinterpret_cast<int*>(smem) + N;
+  for (int s = tid; s < N; s += 256) {
+    int j = -1;
+    float v = 0.f;
+    if (s < T) { const size_t o = ((size_t)(s / k) * m + q) * k + (s % k); j = sidx[o]; v = sscore[o]; }
+    const bool ok = j >= 0 && v == v;
+    lv[s] = ok ? v : __builtin_inff();
+    lj[s] = ok ? j : 0x7fffffff;
+  }
+  __syncthreads();
+  for (int size = 2; size <= N; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < (N >> 1); i += 256) {
+        const int pos = 2 * i - (i & (stride - 1)), par = pos + stride;
+        const bool up = (pos & size) == 0;
+        const float a = lv[pos], b = lv[par];
+        const int aj = lj[pos], bj = lj[par];
+        if (cand_less((double)b, bj, (double)a, aj) == up) { lv[pos] = b; lj[pos] = bj; lv[par] = a; lj[par] = aj; }
+      }
+      __syncthreads();
+    }
+  for (int t = tid; t < k; t += 256) {
+    const bool ok = lj[t] != 0x7fffffff;
+    idx[(size_t)q * k + t] = ok ? lj[t] : -1;
+    score[(size_t)q * k + t] = ok ? lv[t] : __builtin_nanf("");
+  }
+}
+
 }  // namespace
 
-void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom) {
+// slices per row for m query rows of n columns: 1 = one workgroup per row (enough rows to fill the chip, or short rows)
+int select_slices(int m, int n) {
+  if (m > 16 || n < 16384) return 1;
+  int P = (n + FS_CAP - 1) / FS_CAP;                // slices that fit the selection's LDS list skip its sampling phase
+  if (P > 64) P = 64;
+  while (P > 1 && m * P > 768) P >>= 1;
+  return P;
+}
+size_t select_scratch_bytes() { return (size_t)64 * 16 * 128 * 8 + (size_t)64 * 16 * 6 * 8; }
+
+void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom, void* scratch) {
   if (m <= 0) return;
+  const int P = scratch ? select_slices(m, n) : 1;
+  if (P > 1) {
+    double* part = reinterpret_cast<double*>(static_cast<char*>(scratch) + (size_t)64 * 16 * 128 * 8);
+    hipLaunchKernelGGL(row_moments_slice_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, n, m, P, part);
+    hipLaunchKernelGGL(moments_finish_kernel, dim3((2 * m + 63) / 64), dim3(64), 0, st, d_p, d_i, n, m, P, part, mom);
+    return;
+  }
   hipLaunchKernelGGL(row_moments_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, n, mom);
 }
 
 void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int m, int n, const double* mom_all,
                         int G, int q_row0, int db_row0, int mask_width, double p_weight, int k, int32_t* idx,
-                        float* score, const float* e_p, const float* e_i, const double* mom2_all) {
+                        float* score, const float* e_p, const float* e_i, const double* mom2_all, void* scratch) {
   if (m <= 0) return;
+  const int P = (scratch && k <= 128) ? select_slices(m, n) : 1;
+  if (P > 1) {
+    int32_t* sidx = static_cast<int32_t*>(scratch);
+    float* ssc = reinterpret_cast<float*>(sidx + (size_t)64 * 16 * 128);
+    hipLaunchKernelGGL(fuse_select_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
+                       mask_width, p_weight, k, sidx, ssc, P);
+    int N = 2;
+    while (N < P * k) N <<= 1;
+    hipLaunchKernelGGL(slice_merge_kernel, dim3(m), dim3(256), (size_t)N * 8, st, sidx, ssc, P, m, k, idx, score);
+    return;
+  }
   hipLaunchKernelGGL(fuse_select_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
-                     mask_width, p_weight, k, idx, score);
+                     mask_width, p_weight, k, idx, score, 1);
 }
 
 }  // namespace pr

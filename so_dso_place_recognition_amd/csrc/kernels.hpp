@@ -64,10 +64,12 @@ void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, vo
 void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i, int single = 0);   // single: hi halves only
 
 // fuse_select.hip — run_test.m:38-41,47-53,57
-void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom);
+// scratch (select_scratch_bytes(), or null): lets a call with few query rows cut every row into slices (grid m x P) instead of one workgroup per row
+size_t select_scratch_bytes();
+void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom, void* scratch = nullptr);
 void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int m, int n, const double* mom_all,
                         int G, int q_row0, int db_row0, int mask_width, double p_weight, int k, int32_t* idx,
-                        float* score, const float* e_p = nullptr, const float* e_i = nullptr, const double* mom2_all = nullptr);
+                        float* score, const float* e_p = nullptr, const float* e_i = nullptr, const double* mom2_all = nullptr, void* scratch = nullptr);
 
 // rerank.hip — NaN rows / columns of zero-norm signatures (processSC.m:16,19), the fp64 re-evaluation of the fp32
 // selection's survivors (processSC.m:15-33 / processM2DP.m:12-22 + run_test.m:40 per pair) and the k-way shard merge

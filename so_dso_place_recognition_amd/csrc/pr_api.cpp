@@ -28,6 +28,7 @@ struct pr_ctx {
   hipStream_t side2 = nullptr;   // SC generation: odd batches (kernel boundaries of one stream hide behind the other's kernels)
   hipEvent_t ev_b = nullptr;
   char* sc_scratch = nullptr;    // tickets + partial moments / bin grids of the split SC generation, one half per stream
+  void* sel_scratch = nullptr;   // slice lists / partial moments of calls with few query rows (fuse_select.hip)
   double* rr_scratch = nullptr;  // candidate scores of pr_rerank_dev (grow-only: a steady-state call allocates nothing and can be graph-captured)
   size_t rr_cap = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -155,6 +156,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
     TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
     TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    TRY(hipMalloc(&ctx->sel_scratch, pr::select_scratch_bytes()));
     TRY(hipMalloc((void**)&ctx->d_flags, 4 * sizeof(int)));
     TRY(hipMemset(ctx->d_flags, 0, 4 * sizeof(int)));
     double tw[120 + 4 * 60 * 8];
@@ -255,6 +257,7 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->sc_scratch) (void)hipFree(ctx->sc_scratch);
   if (ctx->rr_scratch) (void)hipFree(ctx->rr_scratch);
+  if (ctx->sel_scratch) (void)hipFree(ctx->sel_scratch);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
@@ -590,7 +593,7 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
 int pr_row_moments_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n, double* mom) {
   if (!ctx || !d_p || !d_i || !mom || m < 0 || n < 1) return PR_EINVAL;
   if (int rc = set_device(ctx)) return rc;
-  pr::launch_row_moments(ctx->stream, d_p, d_i, m, n, mom);
+  pr::launch_row_moments(ctx->stream, d_p, d_i, m, n, mom, ctx->sel_scratch);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -601,7 +604,7 @@ int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
   if (!ctx || !d_p || (d_i && !mom_all) || !idx || !score || m < 0 || n < 1 || G < 1 || k < 1)
     return PR_EINVAL;
   if (int rc = set_device(ctx)) return rc;
-  pr::launch_fuse_select(ctx->stream, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score);
+  pr::launch_fuse_select(ctx->stream, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, nullptr, nullptr, nullptr, ctx->sel_scratch);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -888,7 +891,7 @@ int pr_fuse_select2_dev(pr_ctx* ctx, const float* d_p, const float* d_i, const f
                         int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score) {
   if (!ctx || !d_p || !d_i || !e_p || !e_i || !mom_all || !mom2_all || !idx || !score || m < 0 || n < 1 || G < 1 || k < 1) return PR_EINVAL;
   if (int rc = set_device(ctx)) return rc;
-  pr::launch_fuse_select(ctx->stream, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, e_p, e_i, mom2_all);
+  pr::launch_fuse_select(ctx->stream, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, e_p, e_i, mom2_all, ctx->sel_scratch);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }

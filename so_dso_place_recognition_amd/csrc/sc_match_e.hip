@@ -213,7 +213,9 @@ __device__ __forceinline__ void valu_slot(f32x4 (&T)[2][8], Half<LO> (&hbs)[2]) 
   }
 }
 
-template <bool LO, int NW>
+// NQG = query groups (of 8) a workgroup holds in LDS: 4 (split-f16), 8 (single product), or 1 (single product, m <= 8: an online call - all
+// eight waves share the one group and split the DB groups, 20 KB of LDS, several workgroups per CU)
+template <bool LO, int NW, int NQG>
 __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char* __restrict__ qpk,   // [2][QG32][4][31][1288 B]
                                                             const char* __restrict__ dpk,   // [2][DG][31][4][768 B] + zero groups
                                                             const u32x4* __restrict__ cst,  // [2][2][2][64] x 16 B
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   const int g0 = (int)((long long)DG * range / nrange), g1 = (int)((long long)DG * (range + 1) / nrange);
 
   // image geometry: split-f16 (4 query groups per workgroup) | single product (hi halves only: 8 query groups, kernels.hpp SCF_*)
-  constexpr int NQG = LO ? 4 : 8, QBLK = LO ? SCH_QBLK : SCF_QBLK, QIMG = LO ? SCH_QIMG : SCF_QIMG, DIMG = LO ? SCH_DIMG : SCF_DIMG;
+  constexpr int QBLK = LO ? SCH_QBLK : SCF_QBLK, QIMG = LO ? SCH_QIMG : SCF_QIMG, DIMG = LO ? SCH_DIMG : SCF_DIMG;
   constexpr int QROW = LO ? 80 : 40;
   static_assert(NW == 4 || !LO, "two waves per SIMD: single-product form only (a split-f16 unit needs all 512 registers)");
   {  // the query groups of this workgroup -> LDS (linear copy; the packed image IS the LDS image) + zeroed tail
@@ -381,24 +383,27 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
 
 }  // namespace
 
-size_t sc_match_e_lds_bytes(int single) { return (single ? (size_t)8 * SCF_QIMG : (size_t)4 * SCH_QIMG) + 64; }
+size_t sc_match_e_lds_bytes(int single, int nqg) { return (single ? (size_t)nqg * SCF_QIMG : (size_t)4 * SCH_QIMG) + 64; }
 
 void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                        int nsplit_override, int single) {
   if (m <= 0 || n <= 0) return;
   const int QG8 = single ? sc_qgroups8_f16(m) : sc_qgroups8(m), DG = sc_dgroups(n);
-  const int QGW = QG8 / (single ? 8 : 4);           // workgroups along the queries (64 | 32 queries each)
+  const int nqg = single ? (m <= 8 ? 1 : 8) : 4;
+  const int QGW = (single && m <= 8) ? 1 : QG8 / nqg;   // workgroups along the queries (8 nqg queries each)
   int nsplit = (128 + QGW - 1) / QGW;
   if (nsplit > DG / 32) nsplit = DG / 32;
   if (nsplit < 1) nsplit = 1;
+  if (nqg == 1) nsplit = DG / 128 > 0 ? DG / 128 : 1;   // an online call: ~32 DB groups per workgroup, 4 per wave; ~400 workgroups at n = 100k
   if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
   auto go = [&](auto kern, int nw) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(single));
-    hipLaunchKernelGGL(kern, dim3(8 * QGW * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(single), st, static_cast<const char*>(qpk),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(single, nqg));
+    hipLaunchKernelGGL(kern, dim3(8 * QGW * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(single, nqg), st, static_cast<const char*>(qpk),
                        static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit);
   };
-  if (single) go(sc_match_e_kernel<false, 8>, 8);
-  else go(sc_match_e_kernel<true, 4>, 4);
+  if (single && m <= 8) go(sc_match_e_kernel<false, 8, 1>, 8);
+  else if (single) go(sc_match_e_kernel<false, 8, 8>, 8);
+  else go(sc_match_e_kernel<true, 4, 4>, 4);
 }
 
 }  // namespace pr

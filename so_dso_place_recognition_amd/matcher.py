@@ -61,15 +61,28 @@ class _Base:
         self.ctx = ctx or _stream_context(device)
         self.dev = torch.device("cuda", self.ctx.device)
         self.lib = self.ctx.lib
-        # a context on its own stream (the caller built it that way) needs the two streams joined by hand
-        self.shared_stream = self.ctx.stream == int(torch.cuda.current_stream(self.dev).cuda_stream)
+        self._lib_stream = None if self.ctx.stream == 0 else torch.cuda.ExternalStream(self.ctx.stream, device=self.dev)
+
+    # The library's kernels run on self.ctx.stream; torch work (casts, zero_(), all_gather_into_tensor, output allocations) runs on torch's
+    # CURRENT stream, which may differ from the one the context was created on (`with torch.cuda.stream(s)`, DDP side streams).  The two
+    # are compared at every call: the same stream needs nothing, different streams are joined by events (no host wait).
+    def _same_stream(self) -> bool:
+        return self.ctx.stream == int(torch.cuda.current_stream(self.dev).cuda_stream)
 
     def _enter(self):      # torch work issued so far must be visible to the library's stream
-        if not self.shared_stream:
+        if self._same_stream():
+            return
+        if self._lib_stream is not None:
+            self._lib_stream.wait_stream(torch.cuda.current_stream(self.dev))
+        else:
             torch.cuda.current_stream(self.dev).synchronize()
 
     def _leave(self):      # ... and the library's work to torch's
-        if not self.shared_stream:
+        if self._same_stream():
+            return
+        if self._lib_stream is not None:
+            torch.cuda.current_stream(self.dev).wait_stream(self._lib_stream)
+        else:
             self.ctx.sync()
 
     # ---- PR_SC_ARITH_F16 (single f16 product per term): exact indices need a margin check of the candidate list and, for the

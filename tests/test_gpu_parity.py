@@ -595,3 +595,31 @@ def test_sc_small_query_batches_use_the_one_group_kernel(api, m, n):
     idx, sc = api.match_topk("sc", q, db, 0, 2.0, k)
     rc, oidx, osc = oracle_lib.match_topk(0, q, db, 0, 2.0, k)
     assert np.array_equal(idx, oidx)
+
+
+def test_matcher_called_under_another_torch_stream(api):
+    """The library context lives on the stream that was current at construction; calls made later under `with torch.cuda.stream(s)` put
+    torch's own work (casts, allocations, zero fills) on ANOTHER stream.  _enter / _leave compare the streams at every call and join
+    them with events: the results must be those of the plain call, also when the side stream is busy with unrelated work."""
+    import torch
+    from so_dso_place_recognition_amd.matcher import Matcher
+    n, m, k = 6000, 96, 3
+    db = torch.from_numpy(synth.sc_database(45, n)).cuda()
+    q_h, planted = synth.sc_queries(46, db.cpu().numpy(), m)
+    mt = Matcher("sc", m, n)
+    mt.pack_database(db)
+    q = torch.from_numpy(q_h).cuda()
+    ref_i, ref_s = (t.clone() for t in mt.match(q, 2, 2.0, k))
+    side = torch.cuda.Stream()
+    junk = torch.empty((4096, 4096), device="cuda")
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                junk = junk @ junk.T * 1e-4                           # keeps the side stream busy in front of the call
+            q2 = torch.from_numpy(q_h).cuda()                        # the queries are produced on the side stream
+            mt.pack_database(db)
+            i2, s2 = mt.match(q2, 2, 2.0, k)
+            i2, s2 = i2.clone(), s2.clone()
+        side.synchronize()
+        assert torch.equal(i2, ref_i) and torch.equal(s2, ref_s)
+    mt.close()

@@ -1,33 +1,56 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/profile_round.sh <tag>   -> gpurun_out/<tag>.txt
-# rocprofv3 kernel trace of bench.py (default arithmetic) + one PMC pass per counter group (never combined with traces),
-# summarised by profiles/summarize.py.
+# usage (on the GPU box, from the repo root): tools/profile_round.sh <tag>     e.g. r03_mid
+# -> gpurun_out/<tag>.txt: the un-profiled bench line, the rocprofv3 --kernel-trace --stats summary of the same command, and one --pmc pass per
+# counter group (never combined with another trace domain); gpurun_out/<tag>_traffic.json: HBM bytes per launch of every kernel
+# (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md).  Copy what should be judged into profiles/.
 set -u
-tag=${1:-round}
+tag=$1
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-txt=$out/$tag.txt
+f=$out/$tag.txt
 {
-echo "# $tag: python bench.py --steps 3 --warmup 1 --no-cpu-baseline   (PMC passes: --steps 1 --warmup 0)"
-echo "# MI355X, ROCm 7.2, rocprofv3 --kernel-trace --stats, then one --pmc group per run"
-echo
-echo "## bench.py JSON line (un-profiled run, steps 5, with the CPU baseline)"
-python $root/bench.py --steps 5 --warmup 2 2>/dev/null | tail -1
-echo
-echo "## bench.py JSON line, --sc-arith f32 (un-profiled)"
-python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --sc-arith f32 2>/dev/null | tail -1
-echo
-} > $txt
+  echo "# $tag: python bench.py --steps 3 --warmup 1 (kernel trace: + --no-cpu-baseline; PMC passes: --steps 1 --warmup 0 --no-cpu-baseline --no-extra)"
+  echo "# MI355X, rocprofv3 --kernel-trace --stats, then one --pmc group per run"
+  echo
+  echo "## bench.py JSON line (un-profiled run, with the CPU baseline)"
+  python $root/bench.py --steps 5 --warmup 2 2> $out/${tag}_bench.err | tail -n 1
+  echo
+} > $f
 rm -rf $out/${tag}_trace
-rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o sc -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > $out/${tag}_trace.log 2>&1
-python $root/profiles/summarize.py $(find $out/${tag}_trace -name "*_results.db") | sed "s#$out/##" >> $txt
-rm -rf $out/${tag}_trace
+rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o sc -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_trace.log 2>&1
+python $root/profiles/summarize.py $(find $out/${tag}_trace -name "*_results.db") | grep -v "at::native\|elementwise_kernel" >> $f
 i=0
-for grp in "FETCH_SIZE" "WRITE_SIZE" "GRBM_GUI_ACTIVE SQ_ACTIVE_INST_ANY SQ_INSTS_MFMA SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE"; do
-  i=$((i+1)); d=$out/${tag}_pmc$i; rm -rf $d
-  rocprofv3 --pmc $grp -d $d -o sc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > $d.log 2>&1
-  python $root/profiles/summarize.py $(find $d -name "*_results.db") | sed "s#$out/##" >> $txt
+for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_ANY" "SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU SQ_LDS_BANK_CONFLICT" \
+           "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  d=$out/${tag}_p$i
   rm -rf $d
+  rocprofv3 --pmc $grp -d $d -o sc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra ${PMC_BENCH_ARGS:-} > $d.log 2>&1
+  echo >> $f
+  python $root/profiles/summarize.py $(find $d -name "*_results.db") | grep -E "^==|^--|sc_match|sc_pack|fuse_select|row_moments|rerank_kernel" >> $f
 done
-cat $txt | cut -c1-220
+python - $out $tag <<'PY'
+import glob, json, sqlite3, sys
+out, tag = sys.argv[1], sys.argv[2]
+res = {"source": f"gpurun_out/{tag}.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra`; "
+                 "KiB per launch; FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md)",
+       "workload": {"db": 100000, "queries": 4096, "n_gpus": 1}}
+for db in glob.glob(f"{out}/{tag}_p*/**/*_results.db", recursive=True):
+    c = sqlite3.connect(db)
+    for name, ctr, val, n in c.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name"):
+        if ctr not in ("FETCH_SIZE", "WRITE_SIZE"):
+            continue
+        short = name.split("(")[0].split("::")[-1].split("<")[0].strip()
+        if "at::native" in name or "elementwise" in name:
+            continue
+        res.setdefault(short, {})[ctr + "_KiB"] = val / n
+for k, v in res.items():
+    if isinstance(v, dict) and "FETCH_SIZE_KiB" in v:
+        v["fetch_correction"] = 2.0
+        v["hbm_bytes_per_launch"] = (2.0 * v["FETCH_SIZE_KiB"] + v.get("WRITE_SIZE_KiB", 0.0)) * 1024
+json.dump(res, open(f"{out}/{tag}_traffic.json", "w"), indent=1)
+PY
+rm -rf $out/${tag}_trace $out/${tag}_p[0-9]*
+tail -n 60 $f
