@@ -87,7 +87,8 @@ int pr_delight_generate(pr_ctx* ctx, const double* xyz, const float* inten, cons
 int pr_delight_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n, float* dist);
 
 /* Replaces processSC(hist1, hist2) (match_signatures/processSC.m:1-45).  h1[m][2400], h2[n][2400] host f64;
- * d_struct / d_int: host f32 [m][n], either may be NULL.  PR_ENAN if a row has zero norm (MATLAB: NaN row). */
+ * d_struct / d_int: host f32 [m][n], either may be NULL.  A zero-norm row (MATLAB: 0/0 = NaN, processSC.m:16,19) gives NaN distances and
+ * PR_WARN_NAN_ROWS (default policy PR_NAN_EXCLUDE); with PR_NAN_FAIL the call returns PR_ENAN instead. */
 int pr_sc_distance(pr_ctx* ctx, const double* h1, int32_t m, const double* h2, int32_t n,
                    float* d_struct, float* d_int);
 
@@ -213,6 +214,7 @@ const char* pr_group_last_error(const pr_group* g);     /* g may be NULL (creati
 int32_t pr_group_size(const pr_group* g);
 int pr_group_uses_rccl(const pr_group* g);
 int pr_group_set_database(pr_group* g, int type, const double* h2, int32_t n);
+int pr_group_take_warnings(pr_group* g);                /* OR of the shards' pr_take_warnings (PR_WARN_* bits), then cleared */
 int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,
                         double* score);
 

@@ -45,6 +45,7 @@ SYMBOLS = {
     "pr_group_size": (_i32, [_vp]),
     "pr_group_uses_rccl": (C.c_int, [_vp]),
     "pr_group_set_database": (C.c_int, [_vp, C.c_int, _vp, _i32]),
+    "pr_group_take_warnings": (C.c_int, [_vp]),
     "pr_group_match_topk": (C.c_int, [_vp, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_destroy": (None, [_vp]),
     "pr_last_error": (C.c_char_p, [_vp]),

@@ -113,6 +113,10 @@ class Group:
         self._check(self.lib.pr_group_match_topk(self.h, _ptr(h1), m, int(mask_width), float(p_weight), int(k), _ptr(idx), _ptr(sc)))
         return idx, sc
 
+    def take_warnings(self) -> int:
+        """PR_WARN_* bits raised on any shard since the last call."""
+        return int(self.lib.pr_group_take_warnings(self.h))
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.pr_group_destroy(self.h)

@@ -47,7 +47,8 @@ int main(int argc, char** argv) {
     for (size_t p = 0; p < devs.size();) { dev_ids.push_back(atoi(devs.c_str() + p)); p = devs.find(',', p); if (p == std::string::npos) break; p++; }
     if (dev_ids.empty() || (t != PR_TYPE_SC && t != PR_TYPE_M2DP)) { fprintf(stderr, "--devices needs a device list and --type sc|m2dp\n"); return 1; }
   }
-  if (pr_create(dev_ids.empty() ? (int)prm.num("device", 0) : dev_ids[0], &ctx) != PR_OK) { fprintf(stderr, "%s\n", pr_last_error(nullptr)); return 3; }
+  // one context for the single-device call; with --devices the group owns one context per shard and this one is not needed
+  if (dev_ids.empty() && pr_create((int)prm.num("device", 0), &ctx) != PR_OK) { fprintf(stderr, "%s\n", pr_last_error(nullptr)); return 3; }
   pr_group* grp = nullptr;
   if (!dev_ids.empty()) {
     if (pr_group_create(dev_ids.data(), (int32_t)dev_ids.size(), &grp) != PR_OK) { fprintf(stderr, "%s\n", pr_group_last_error(nullptr)); return 3; }
@@ -69,7 +70,9 @@ int main(int argc, char** argv) {
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (rc != PR_OK) { fprintf(stderr, "match failed (%d): %s\n", rc, pr_last_error(ctx)); pr_destroy(ctx); return 4; }
   printf("type = %s\ntm = %g\n", type.c_str(), m ? 1000.0 * secs / m : 0.0);
-  if (pr_take_warnings(ctx) & PR_WARN_NAN_ROWS) printf("warning: zero-norm signature rows never match (NaN in MATLAB, processSC.m:16,19)\n");
+  const int warn = grp ? pr_group_take_warnings(grp) : pr_take_warnings(ctx);
+  if (warn > 0 && (warn & PR_WARN_F16_FALLBACK)) printf("note: some queries were recomputed in split-f16 (PR_SC_ARITH_F16 margin check)\n");
+  if (warn > 0 && (warn & PR_WARN_NAN_ROWS)) printf("warning: zero-norm signature rows never match (NaN in MATLAB, processSC.m:16,19)\n");
   std::string g1f, g2f;
   if (prm.get("gt1", g1f) && prm.get("gt2", g2f)) {   // run_test.m:3-22, 58-85
     double *g1 = nullptr, *g2 = nullptr;

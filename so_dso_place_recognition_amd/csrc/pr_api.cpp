@@ -784,8 +784,8 @@ static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, con
   if (!ctx) return PR_EINVAL;
   if (m < 0 || n < 0 || (m > 0 && !h1) || (n > 0 && !h2)) PR_FAIL(ctx, PR_EINVAL, "bad signature buffers (m=%d, n=%d)", m, n);
   const bool plain = (type == PR_TYPE_DELIGHT);
-  if (want_topk && (k < 1 || k > 120 || !idx || (!score32 && !score64)))
-    PR_FAIL(ctx, PR_EINVAL, "pr_match_topk needs 1 <= k <= 120 and output buffers");
+  if (want_topk && (k < 1 || (!plain && k > 120) || !idx || (!score32 && !score64)))   // (k + 8 candidates of the re-evaluation <= 128; DELIGHT has none)
+    PR_FAIL(ctx, PR_EINVAL, "pr_match_topk needs 1 <= k <= 120 (SC, M2DP) and output buffers");
   if (want_topk && n == 0) {   // nothing to match against: every query row is "no candidate"
     for (size_t i = 0; i < (size_t)m * k; i++) { idx[i] = -1; if (score32) score32[i] = NAN; else score64[i] = NAN; }
     return PR_OK;

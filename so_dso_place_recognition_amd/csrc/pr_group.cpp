@@ -62,7 +62,7 @@ struct Shard {
   int device = 0;
   pr_ctx* ctx = nullptr;
   hipStream_t stream = nullptr;
-  hipEvent_t ev = nullptr;
+  hipEvent_t ev = nullptr, ev_done = nullptr;   // "my slice is ready" / "I have copied every slice" (copy exchange)
   pr_sigset *q = nullptr, *db = nullptr;
   int32_t row0 = 0, rows = 0;                 // this shard's global DB rows
   void *raw_db = nullptr, *raw_q = nullptr;   // f64 signatures (the re-evaluation reads them)
@@ -144,6 +144,15 @@ static int exchange(pr_group* g, std::vector<const void*>& src, std::vector<void
       if (g->s[r].device == g->s[h].device) G_HIP(g, hipMemcpyAsync(d, src[r], bytes, hipMemcpyDeviceToDevice, g->s[h].stream));
       else G_HIP(g, hipMemcpyPeerAsync(d, g->s[h].device, src[r], g->s[r].device, bytes, g->s[h].stream));
     }
+    G_HIP(g, hipEventRecord(g->s[h].ev_done, g->s[h].stream));
+  }
+  // consumer side done -> producers: nothing a shard enqueues after this exchange (the next kernel that writes src, the next exchange's
+  // record of `ev`) runs before EVERY shard has copied its slice - the exchange is a full rendezvous of the G streams, like the collective
+  // it stands in for, so no later reuse of a source buffer can race with a peer's copy
+  for (int r = 0; r < G; r++) {
+    G_HIP(g, hipSetDevice(g->s[r].device));
+    for (int h = 0; h < G; h++)
+      if (h != r) G_HIP(g, hipStreamWaitEvent(g->s[r].stream, g->s[h].ev_done, 0));
   }
   return PR_OK;
 }
@@ -168,6 +177,7 @@ void pr_group_destroy(pr_group* g) {
     if (sh.db) pr_sigset_destroy(sh.ctx, sh.db);
     if (sh.raw_db) (void)hipFree(sh.raw_db);
     if (sh.ev) (void)hipEventDestroy(sh.ev);
+    if (sh.ev_done) (void)hipEventDestroy(sh.ev_done);
     pr_destroy(sh.ctx);
   }
   delete g;
@@ -189,7 +199,11 @@ int pr_group_create(const int32_t* device_ids, int32_t G, pr_group** out) {
     sh.device = device_ids[r];
     if (pr_create(sh.device, &sh.ctx) != PR_OK) { g_gerr = std::string("pr_group_create: ") + pr_last_error(nullptr); pr_group_destroy(g); return PR_EHIP; }
     sh.stream = static_cast<hipStream_t>(pr_stream(sh.ctx));
-    if (hipSetDevice(sh.device) != hipSuccess || hipEventCreateWithFlags(&sh.ev, hipEventDisableTiming) != hipSuccess) {
+    // the group protocol is the split-f16 / fp32 one (k + 8 candidates); the single-product arithmetic needs the margin check and its
+    // fallback, which live above pr_group (matcher.py) - a PR_SC_MATCH=f16 environment does not leak in here
+    if (pr_get_sc_arith(sh.ctx) == PR_SC_ARITH_F16) (void)pr_set_sc_arith(sh.ctx, PR_SC_ARITH_F16X2);
+    if (hipSetDevice(sh.device) != hipSuccess || hipEventCreateWithFlags(&sh.ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sh.ev_done, hipEventDisableTiming) != hipSuccess) {
       g_gerr = "pr_group_create: hipEventCreate failed"; pr_group_destroy(g); return PR_EHIP;
     }
   }
@@ -220,8 +234,8 @@ int pr_group_create(const int32_t* device_ids, int32_t G, pr_group** out) {
 }
 
 // hist2 of run_test.m:1, host f64: [n][2400] (SC) or [4n][384] (M2DP); rows [g n/G, (g+1) n/G) go to shard g
-int pr_group_set_database(pr_group* g, int type, const double* h2, int32_t n) {
-  if (!g) return PR_EINVAL;
+static int set_database_impl(pr_group* g, int type, const double* h2, int32_t n) {
+  g->type = -1; g->q_cap = 0; g->k_cap = 0;               // nothing usable until this call has succeeded
   if ((type != PR_TYPE_SC && type != PR_TYPE_M2DP) || n < 2 || !h2) G_FAIL(g, PR_EINVAL, "pr_group_set_database: type must be SC or M2DP, n >= 2");
   const size_t row_doubles = type == PR_TYPE_SC ? PR_SC_SIG_LEN : (size_t)4 * PR_M2DP_SIG_LEN;
   for (int r = 0; r < g->G; r++) {
@@ -245,9 +259,8 @@ int pr_group_set_database(pr_group* g, int type, const double* h2, int32_t n) {
 }
 
 // run_test.m:26-57 over the sharded database: idx [m][k] global 0-based rows of hist2 (-1: none), score [m][k] f64
-int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,
-                        double* score) {
-  if (!g) return PR_EINVAL;
+static int match_topk_impl(pr_group* g, const double* h1, int32_t m, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,
+                           double* score) {
   if (g->type < 0) G_FAIL(g, PR_EINVAL, "pr_group_match_topk: no database (pr_group_set_database)");
   const int G = g->G;
   if (m < 0 || (m > 0 && !h1) || k < 1 || k > 120 || G > 64 || !idx || !score)
@@ -260,6 +273,7 @@ int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_w
   if (m > g->q_cap || k > g->k_cap) {                         // (re)allocate the per-device work buffers
     const int32_t qc = m > g->q_cap ? m : g->q_cap, kc = k > g->k_cap ? k : g->k_cap;
     const int kinc = kc + 8 > 128 ? 128 : kc + 8;
+    g->q_cap = g->k_cap = 0;                                  // a failed allocation below leaves no buffer that looks usable
     for (auto& sh : g->s) {
       free_match_buffers(sh);
       G_HIP(g, hipSetDevice(sh.device));
@@ -324,6 +338,34 @@ int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_w
   G_HIP(g, hipMemcpyAsync(score, s0.score, (size_t)m * k * 8, hipMemcpyDeviceToHost, s0.stream));
   for (auto& sh : g->s) { G_HIP(g, hipSetDevice(sh.device)); G_PR(g, sh, pr_sync(sh.ctx)); }
   return PR_OK;
+}
+
+// a failed call may have work enqueued on some devices: wait for all of them before the error is reported, and keep the message
+static int settle(pr_group* g, int rc) {
+  if (rc == PR_OK) return rc;
+  const std::string keep = g->err;
+  for (auto& sh : g->s) if (sh.ctx) { (void)hipSetDevice(sh.device); (void)hipStreamSynchronize(sh.stream); }
+  g->err = keep;
+  return rc;
+}
+
+int pr_group_set_database(pr_group* g, int type, const double* h2, int32_t n) {
+  if (!g) return PR_EINVAL;
+  return settle(g, set_database_impl(g, type, h2, n));
+}
+
+int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,
+                        double* score) {
+  if (!g) return PR_EINVAL;
+  return settle(g, match_topk_impl(g, h1, m, mask_width, p_weight, k, idx, score));
+}
+
+// PR_WARN_* bits raised on any shard since the last call (zero-norm rows excluded, ...), then cleared
+int pr_group_take_warnings(pr_group* g) {
+  if (!g) return PR_EINVAL;
+  int w = 0;
+  for (auto& sh : g->s) if (sh.ctx) { (void)hipSetDevice(sh.device); const int x = pr_take_warnings(sh.ctx); if (x > 0) w |= x; }
+  return w;
 }
 
 }  // extern "C"

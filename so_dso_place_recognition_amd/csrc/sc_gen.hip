@@ -17,15 +17,11 @@
 //                  max-min and mean > ave ? 1 : 0 (:67-75) -> out[c][2400].
 // Bound: HBM (28 B per point per pass); the points are never written back.
 //
-// One HBM pass instead of two (launch_sc_generate): the clouds are taken in batches of ~96 MB, small enough for two batches
-// to stay in the 256 MB Infinity Cache, and every batch runs moments -> binning back to back, so the binning pass re-reads
-// the points from the cache, not from HBM.  A batch of 50 000-point clouds holds only ~70 of them - one workgroup per cloud
-// would leave most of the chip idle - so both kernels split a cloud over W workgroups (cloud_frames_split / sc_bin_split):
-// each takes a slice of the points, writes its partial moments (9 doubles) or partial bin grids (33.6 KB) and takes a ticket;
-// the last to arrive merges the partials in slice order - moments are summed in that fixed order, counts add, min / max
-// commute and the fp64 intensity sums are exact (floats of <= 24 bits, a few thousand per bin) - so the result does not depend
-// on which workgroup came last.  Consecutive batches alternate between two streams, which hides the kernel boundaries.  The float
-// average chain runs over all clouds on a third stream and meets the bins in sc_finish.
+// The DEFAULT is exactly these two streaming passes over all clouds at once (moments, then binning: 2 x 28 B per point at ~5.4 TB/s each).
+// Two one-pass designs are kept in this file for A/B runs only - both parity-green, both slower (tools/experiments/
+// README.md): PR_SC_GEN=batched (batches of ~96 MB so that the binning pass re-reads the Infinity Cache; a cloud split over W workgroups with
+// last-arriver merges: cloud_frames_split / sc_bin_split / sc_finish; 6.25 ms against 2.52 ms at 5000 x 50k points) and PR_SC_GEN=cluster
+// (eight workgroups of one XCD hold a cloud in registers between the moments and the binning: sc_gen_cluster_kernel; 6.6 ms).
 #include "fast_bins.hpp"
 #include "kernels.hpp"
 

@@ -1,5 +1,5 @@
-// sc_match_d.hip — EXPERIMENT (PR_SC_KERNEL=d selects it for m > 8): sc_match_h.hip with stage 2 DEFERRED to the end of the unit and
-// TRANSIENT stage-2 tiles.
+// sc_match_d.hip — round 2's default split-f16 SC matcher (PR_SC_KERNEL=d selects it for m > 8; the default is now sc_match_e.hip): sc_match_h.hip
+// with stage 2 DEFERRED to the end of the unit and TRANSIENT stage-2 tiles.
 //
 // sc_match_h.hip runs stage 2 per half of the frequencies into 256 persistent AccVGPR accumulators and then pulls every one of them out in
 // a VALU-only epilogue.  Here both halves' packed operands are kept (the first half's 32 operand tuples, already swapped, are parked in
@@ -281,20 +281,6 @@ __global__ __launch_bounds__(256, 1) void sc_match_d_kernel(const char* __restri
   ADV()                                                                                           \
   FREQ(16 * (H) + 2 * (J), t1a, t2a, NONE, FM2(Fb, Mb, t1b, t2b, 0), FM2(Fb, Mb, t1b, t2b, 2), PKF((J) - 1, 0), PKM((J) - 1, 0), PKF((J) - 1, 1)) \
   FREQ(16 * (H) + 2 * (J) + 1, t1b, t2b, PKM((J) - 1, 1), PKF((J) - 1, 2), PKM((J) - 1, 2), PKF((J) - 1, 3), PKM((J) - 1, 3), FMA_ALL(Fa, Ma, t1a, t2a))
-// the 12 stage-2 MFMAs of register R with the VALU pieces W0..W11 in their gaps
-#define S2(FIRST, R, W0, W1, W2, W3, W4, W5, W6, W7, W8, W9, W10, W11)                             \
-  { stage2_one<FIRST, R, 0>(hb, c, accE, accO, zero); SB(); W0; SB();                             \
-    stage2_one<FIRST, R, 1>(hb, c, accE, accO, zero); SB(); W1; SB();                             \
-    stage2_one<FIRST, R, 2>(hb, c, accE, accO, zero); SB(); W2; SB();                             \
-    stage2_one<FIRST, R, 3>(hb, c, accE, accO, zero); SB(); W3; SB();                             \
-    stage2_one<FIRST, R, 4>(hb, c, accE, accO, zero); SB(); W4; SB();                             \
-    stage2_one<FIRST, R, 5>(hb, c, accE, accO, zero); SB(); W5; SB();                             \
-    stage2_one<FIRST, R, 6>(hb, c, accE, accO, zero); SB(); W6; SB();                             \
-    stage2_one<FIRST, R, 7>(hb, c, accE, accO, zero); SB(); W7; SB();                             \
-    stage2_one<FIRST, R, 8>(hb, c, accE, accO, zero); SB(); W8; SB();                             \
-    stage2_one<FIRST, R, 9>(hb, c, accE, accO, zero); SB(); W9; SB();                             \
-    stage2_one<FIRST, R, 10>(hb, c, accE, accO, zero); SB(); W10; SB();                           \
-    stage2_one<FIRST, R, 11>(hb, c, accE, accO, zero); SB(); W11; SB(); }
 
     // ---------------------------------------------------------------- first half: frequencies 0..15
 #define hb hbs[0]

@@ -1,11 +1,8 @@
-// sc_match_e.hip — the split-f16 SC matcher with TWO waves per SIMD (processSC.m:22-33).
+// sc_match_e.hip — the default SC matcher (processSC.m:22-33) in both f16 arithmetics: split-f16 (PR_SC_ARITH_F16X2: every fp32 factor as
+// f16 hi + lo, three MFMAs per product) and single product (PR_SC_ARITH_F16: hi only).
 //
-// Same mathematics, packed images and stage-2 constants as sc_match_h.hip / sc_match_d.hip (read those headers first).  What changes:
+// Same mathematics, packed split images and stage-2 constants as sc_match_h.hip / sc_match_d.hip (read those headers first).  What changes:
 //
-//  * a wave's whole (8 queries x 16 entries x 31 frequencies) unit lives in 256 registers, so a 512-thread workgroup puts two waves on
-//    every SIMD: wave w works on query group (w & 3) of the 32-query LDS image and on the DB groups of parity (w >> 2).  One in-order
-//    wave issues an instruction every ~4.8 cycles and cannot overlap its VALU work (F / M combination, hi / lo split, reduction) with
-//    its own MFMAs unless every instruction is hand-placed; two waves interleave in hardware.
 //  * no row-exchanged query operand.  sc_match_h computes T2 = [Qi;Qr].Di^T from the LDS image read a second time with row ^ 8, so that
 //    F = T1 + s T2 is lane-aligned.  Here T2' = [Qr;Qi].Di^T comes from the SAME query tiles as T1 (two LDS reads per frequency
 //    instead of four, 32 operand registers fewer) and the exchange of the Re and Im row halves is folded into the permlane swap that
@@ -13,18 +10,19 @@
 //        swap32(T1_f, T1_f+8) = (QrDr_f | QrDr_f+8) =: X , (QiDr_f | QiDr_f+8) =: Y        swap32(T2'_f, T2'_f+8) = U (QrDi), V (QiDi)
 //        Re S = X + V   Im S = Y - U   Re P = X - V   Im P = Y + U           each already (f | f + 8) by lane half
 //    which is, after the split, exactly the operand layout sc_match_d reaches with 128 swaps of packed registers.
-//  * all packed operands stay in ArchVGPRs (nothing is parked in AccVGPRs, no v_accvgpr_write); the stage-2 constants are requested
-//    once per unit while the last stage-1 quad runs.
-//  * LO = false is the single-product arithmetic (PR_SC_ARITH_F16): operands hi only, one MFMA per product.
+//  * the schedule is a function of (quad, gap) - valu_slot<> below - instead of hand-written macro rows: 4 VALU instructions behind every
+//    stage-1 MFMA, the swaps / combination / split of a quad under the MFMAs of the next; DB tiles three walk positions ahead.
+//  * split-f16 (LO = true): one wave per SIMD, 4 query groups per workgroup; the packed operands of the whole unit are 256 registers, so
+//    the first half's are parked in AccVGPRs (park_half) and read from there by the stage-2 MFMAs.  ~3 % faster than sc_match_d; the
+//    cost model behind that (tools/ubench/mfma16_fillers.hip and the ablation table of DESIGN.md): one in-order wave adds up MFMA time (6 x 17.8 cycles per walk
+//    position), VALU beyond the two an MFMA hides (~4.4 cycles each; 8.5 for a permlane swap or an AccVGPR write), and ~22 cycles per
+//    operand request, vector or LDS alike - nothing overlaps much, whatever the placement.
+//  * single product (LO = false): the unit fits 256 registers, so the workgroup has EIGHT waves - two per SIMD, which do overlap - over
+//    8 query groups of the compact image (SCF_*: 64 queries in 160 KB of LDS); for m <= 8 (an online call) all eight waves share ONE query
+//    group and split the DB groups (NQG = 1: 20 KB of LDS, several workgroups per CU, 0.11 ms per 100k-entry DB = 5.3 TB/s).
 #include "kernels.hpp"
 #ifndef E_BD
 #define E_BD 4          // depth of the DB operand ring, split-f16 form
-#endif
-#ifndef E_PK
-#define E_PK 0          // 1: F / M combination with v_pk_add_f32
-#endif
-#ifndef E_ABL
-#define E_ABL 0         // ablation hooks (timing experiments only; results are wrong by construction)
 #endif
 #ifndef E_BD1
 #define E_BD1 6         // the same, single-product form (a position is only two MFMAs long)
@@ -160,22 +158,10 @@ template <bool LO>
 __device__ __forceinline__ void swp2(f32x4& x, f32x4& y, f32x4& u, f32x4& v, int e) { swap32f(x, y, e); swap32f(u, v, e); }
 // X, Y, U, V -> Re S = X + V (in x), Re P = X - V (in v), Im S = Y - U (in y), Im P = Y + U (in u), registers r0, r0 + 1
 __device__ __forceinline__ void cmb2(f32x4& x, f32x4& y, f32x4& u, f32x4& v, int r0) {
-#if E_PK
   const f32x2 _x = {x[r0], x[r0 + 1]}, _y = {y[r0], y[r0 + 1]}, _u = {u[r0], u[r0 + 1]}, _v = {v[r0], v[r0 + 1]};
   const f32x2 _sr = _x + _v, _pr = _x - _v, _si = _y - _u, _pi = _y + _u;
   x[r0] = _sr[0]; x[r0 + 1] = _sr[1]; v[r0] = _pr[0]; v[r0 + 1] = _pr[1];
   y[r0] = _si[0]; y[r0 + 1] = _si[1]; u[r0] = _pi[0]; u[r0 + 1] = _pi[1];
-#else
-  // plain v_add / v_sub: beside MFMAs a v_pk_add_f32 costs ~10 cycles against ~4.4 for a plain VALU op (tools/ubench/mfma16_fillers.hip),
-  // and hipcc would SLP-pack adjacent adds on its own - hence asm
-#pragma unroll
-  for (int r = r0; r < r0 + 2; r++) {
-    float sr, pr, si, pi;
-    asm volatile("v_add_f32 %0, %4, %7\n\tv_sub_f32 %1, %4, %7\n\tv_sub_f32 %2, %5, %6\n\tv_add_f32 %3, %5, %6"
-                 : "=&v"(sr), "=&v"(pr), "=&v"(si), "=&v"(pi) : "v"(x[r]), "v"(y[r]), "v"(u[r]), "v"(v[r]));
-    x[r] = sr; v[r] = pr; y[r] = si; u[r] = pi;
-  }
-#endif
 }
 // (the empty volatile asm pins the packed value HERE: hipcc otherwise sinks the whole pure combine / convert chain down to its stage-2
 // consumer and keeps the fp32 values live instead - twice the registers)
@@ -290,14 +276,13 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
     const __amdgpu_buffer_rsrc_t rsn =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)gn * DIMG), 0, DIMG, 0x00020000);
     Half<LO> hbs[2];
-    if constexpr ((E_ABL & 8) != 0) { for (int h_ = 0; h_ < 2; h_++) for (int r_ = 0; r_ < 4; r_++) { hbs[h_].reFh[r_] = hbs[h_].imFh[r_] = hbs[h_].reMh[r_] = hbs[h_].imMh[r_] = u32x4{0u, 0u, 0u, 0u}; if constexpr (LO) hbs[h_].reFl[r_] = hbs[h_].imFl[r_] = hbs[h_].reMl[r_] = hbs[h_].imMl[r_] = u32x4{0u, 0u, 0u, 0u}; } }
     Consts c0, c1;
     f32x4 T[2][8];
 
 // request tile T of walk position Q of this unit (Q >= 31: nothing)
-#define LDB(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || (TT == B_REH || TT == B_IMH)) && !(E_ABL & 2) && (!(E_ABL & 1) || TT == B_REH || TT == B_IMH)) load_b<LO, seqf((Q) < 32 ? (Q) : 0), TT>(Bt[(Q) % BD], rs, voff); }
-#define LDA(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || TT == A_H) && !(E_ABL & 4)) load_a<TT>(At[(Q) % AD], nat0 + seqf((Q) < 32 ? (Q) : 0) * QBLK); }
-#define VS(P, G) { if constexpr (!(E_ABL & 8)) valu_slot<LO, ((P) >> 2), (((P) & 3) * 6 + (G))>(T, hbs); }
+#define LDB(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || (TT == B_REH || TT == B_IMH))) load_b<LO, seqf((Q) < 32 ? (Q) : 0), TT>(Bt[(Q) % BD], rs, voff); }
+#define LDA(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || TT == A_H)) load_a<TT>(At[(Q) % AD], nat0 + seqf((Q) < 32 ? (Q) : 0) * QBLK); }
+#define VS(P, G) valu_slot<LO, ((P) >> 2), (((P) & 3) * 6 + (G))>(T, hbs)
 // one walk position: its 6 (LO) or 2 MFMAs, the requests for positions P + AD - 1 (query tiles) and P + BD - 1 (DB tiles), the quad's VALU
 // work of these six gaps
 #define FREQ(P)                                                                                                  \
@@ -329,7 +314,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
     load_consts<1, LO>(c1, rc, lane * 16);
     FREQ(31)
     SB(); DRAIN(); SB();
-#define VD(G) { if constexpr (!(E_ABL & 8)) valu_slot<LO, 8, G>(T, hbs); }
+#define VD(G) valu_slot<LO, 8, G>(T, hbs);
     VD(0) VD(1) VD(2) VD(3) VD(4) VD(5) VD(6) VD(7) VD(8) VD(9) VD(10) VD(11) VD(12) VD(13) VD(14) VD(15) VD(16) VD(17) VD(18) VD(19) VD(20)
     SB();
     {  // L2 prefetch for the whole XCD: the 32 NW waves that sweep this range on this XCD cover the group(s) of the iteration after next
@@ -351,7 +336,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
     asm volatile("" : "+v"(le));
     const int st_lane = ((le & 16) ? 4 * n : 0) * 4 + (le & 15) * 4;
     const int st_base = (le < 32 && g * 16 + (le & 15) < n) ? st_lane : (int)0x80000000;
-#define S2I(S, I) if constexpr (!(E_ABL & 16) || (I) < 2) s2_one<LO, (NW == 4), ((S) >> 1), ((S) & 1), I>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1])
+#define S2I(S, I) s2_one<LO, (NW == 4), ((S) >> 1), ((S) & 1), I>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1])
 #define S2G(S, W0, W1, W2, W3, W4, W5, W6, W7, W8, W9, W10, W11)                                   \
   { if constexpr (LO) {                                                                            \
     SB(); S2I(S, 0); SB(); W0;  SB(); S2I(S, 1); SB(); W1;  SB(); S2I(S, 2); SB(); W2;             \

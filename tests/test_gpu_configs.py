@@ -91,6 +91,9 @@ def test_config2_generate_5000x50000_then_match(api):
         oi, osc = topk_rows(2.0 * zscore_rows(dp) + zscore_rows(di), rows, mask, 3)
         assert np.array_equal(idx[rows], oi)
         assert (np.abs(sc[rows] - osc) <= helpers.score_tol(osc)).all()
+        flat = np.abs(osc) < 30                                                                  # real matches (|z| < 30) are inside
+        assert flat.sum() >= 8                                                                   # BASELINE.json's 1e-5 outright
+        assert (np.abs(sc[rows] - osc)[flat] < 1e-5).all(), np.abs(sc[rows] - osc)[flat].max()
         if mask == 0:
             assert np.array_equal(idx[:, 0], np.arange(N))                                       # every cloud finds itself
     mt.close(); ctx.close()
@@ -159,7 +162,7 @@ def test_config4_200k_db_in_8_shards(api):
     q = torch.from_numpy(q_h).cuda()
     ms, per, idx, sc = _sharded_run(lambda cap: Matcher("sc", m, cap), shards, pack, (q,), mask, k)
     assert np.array_equal(idx[:, 0], planted)
-    rows = np.arange(8)
+    rows = np.arange(16)
     dp, di = oracle_rows("sc", q_h[rows], [chunks[lo].cpu().numpy() for lo, hi in shards])
     f = 2.0 * zscore_rows(dp) + zscore_rows(di)                      # GLOBAL row statistics (run_test.m:40)
     oi, osc = topk_rows(f, rows, mask, k)
@@ -178,7 +181,7 @@ def test_config5_fused_1m_db_in_8_shards(api):
     from so_dso_place_recognition_amd.matcher import FusedMatcher
     n, G, m, k, mask = 1_000_000, 8, 64, 2, 0
     shards = [(n * g // G, n * (g + 1) // G) for g in range(G)]
-    R = 4
+    R = 16
     rows = np.arange(R)
     q_sc, planted = synth.sc_queries(72, np.empty((0, 2400)), m, db_first=0, n_global=n, db_seed=71)
     # M2DP queries planted on the SAME entries: rows of m2dp_database(73) + noise, as synth.m2dp_queries does
@@ -347,5 +350,8 @@ def test_drive_2000_frames_mask_100(api):
     oi, osc = topk_rows(2.0 * zscore_rows(dp) + zscore_rows(di), rows, 100, 2)
     assert np.array_equal(idx[rows], oi)
     assert (np.abs(sc[rows] - osc) <= helpers.score_tol(osc, helpers.row_sigmas(dp, di))).all()
+    flat = np.abs(osc) < 30                                                      # every compared score of a real sequence: flat 1e-5
+    assert flat.sum() >= 100
+    assert (np.abs(sc[rows] - osc)[flat] < 1e-5).all(), np.abs(sc[rows] - osc)[flat].max()
     second = np.arange(lap + 50, N - 50)
     assert (np.abs(idx[second, 0] - (second - lap)) <= 3).mean() > 0.7           # loop closures onto the first lap
