@@ -433,9 +433,9 @@ def main():
         ach = pairs * fpp / (kms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
         try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+            tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
             if tr["workload"] == {"db": n, "queries": m, "n_gpus": world}:
-                traffic = tr[kname]["hbm_bytes_per_launch"]
+                traffic = next(v["hbm_bytes_per_launch"] for kk, v in tr.items() if kk.startswith(kname.split("<")[0]) and (arith != "f16") == ("<false" not in kk))
         except Exception:
             pass
         out = {
@@ -451,7 +451,7 @@ def main():
                                + ("+3 all_gathers+merge" if (world > 1 or args.force_exchange) else "")},
             "roofline": {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak,
                          "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                         "traffic_source": ("profiles/r02_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE passes of this command, per launch"
+                         "traffic_source": ("profiles/r03_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE passes of this command, per launch"
                                             if traffic is not None else None),
                          "flop_per_pair": fpp, "pairs_per_launch": pairs, "ms_per_launch": kms,
                          # the same launch priced as the fp32 formulation it replaces (what an fp32-MFMA kernel would need)

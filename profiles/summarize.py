@@ -19,8 +19,17 @@ def main():
             q = ("select name, count(*), avg(end-start)/1e6, min(end-start)/1e6, max(end-start)/1e6, sum(end-start)/1e6,"
                  " max(vgpr_count), max(accum_vgpr_count), max(lds_size)" + (", " + grid if grid else ", 0") +
                  " from kernels group by name" + (", " + grid if grid else "") + " order by 6 desc")
-            for r in c.execute(q):
+            rows = list(c.execute(q))
+            for r in rows:
                 print("%-72s n=%-3d avg=%9.3f min=%9.3f max=%9.3f total=%9.1f vgpr=%s agpr=%s lds=%s grid=%s" % ((r[0][:72],) + r[1:]))
+            # the timed step's launches of a kernel that also serves small calls (same grid size): the launches above half its maximum
+            print("-- launches longer than half the kernel's longest one (the timed steps, where a kernel also serves small calls)")
+            for r in rows:
+                if r[4] > 4 * r[3] and r[4] > 1.0:
+                    cond = " and %s = %d" % (grid, r[9]) if grid else ""
+                    a = c.execute("select count(*), avg(end-start)/1e6, min(end-start)/1e6, max(end-start)/1e6 from kernels where name = ? and (end-start) > ?" + cond,
+                                  (r[0], r[4] * 0.5e6)).fetchone()
+                    print("%-72s n=%-3d avg=%9.3f min=%9.3f max=%9.3f" % ((r[0][:72],) + a))
         if has_pmc:
             print("-- PMC (rocprofv3 --pmc ...): kernel, counter, sum over dispatches, dispatches")
             q = ("select kernel_name, counter_name, sum(value), count(*) from counters_collection"

@@ -32,7 +32,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE
   python $root/profiles/summarize.py $(find $d -name "*_results.db") | grep -E "^==|^--|sc_match|sc_pack|fuse_select|row_moments|rerank_kernel" >> $f
 done
 python - $out $tag <<'PY'
-import glob, json, sqlite3, sys
+import glob, json, re, sqlite3, sys
 out, tag = sys.argv[1], sys.argv[2]
 res = {"source": f"gpurun_out/{tag}.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra`; "
                  "KiB per launch; FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md)",
@@ -42,9 +42,10 @@ for db in glob.glob(f"{out}/{tag}_p*/**/*_results.db", recursive=True):
     for name, ctr, val, n in c.execute("select kernel_name, counter_name, sum(value), count(*) from counters_collection group by kernel_name, counter_name"):
         if ctr not in ("FETCH_SIZE", "WRITE_SIZE"):
             continue
-        short = name.split("(")[0].split("::")[-1].split("<")[0].strip()
         if "at::native" in name or "elementwise" in name:
             continue
+        mm = re.search(r"([A-Za-z_]\w*(?:<[^()]*?>)?)\(", name.replace("(anonymous namespace)::", ""))
+        short = mm.group(1) if mm else name.strip()
         res.setdefault(short, {})[ctr + "_KiB"] = val / n
 for k, v in res.items():
     if isinstance(v, dict) and "FETCH_SIZE_KiB" in v:
