@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
 // Here the second wave of every SIMD fills those holes - and the launch is 2 % SLOWER (5.64 against 5.50 ms at 4096 x 50k,
 // same box, same run): the chip runs this kernel at ~1.7 GHz against its power limit, so a busier matrix pipe is paid back
 // in clock (MI355X_MICROARCH.md "DVFS give-back").  Same LDS image, same packed layouts, same result bit for bit.
+template <bool LO>
 __global__ __launch_bounds__(512, 2) void m2dp_match_h8_kernel(const u32x4* __restrict__ qpk, const u32x4* __restrict__ dpk,
                                                                float* __restrict__ dist_p, float* __restrict__ dist_i,
                                                                int m, int n, int QT, int DT, int nsplit) {
@@ -208,10 +209,10 @@ __global__ __launch_bounds__(512, 2) void m2dp_match_h8_kernel(const u32x4* __re
   HL a[QTB];
 #define MF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
 #define SBAR() __builtin_amdgcn_sched_barrier(0)
-  bs[0].h = pb[0]; bs[0].l = pb[64];
-  bs[1].h = pb[128]; bs[1].l = pb[128 + 64];
+  bs[0].h = pb[0]; bs[1].h = pb[128];
+  if constexpr (LO) { bs[0].l = pb[64]; bs[1].l = pb[128 + 64]; }
 #pragma unroll
-  for (int t = 0; t < QTB; t++) { a[t].h = la[t * TV]; a[t].l = la[t * TV + 64]; }
+  for (int t = 0; t < QTB; t++) { a[t].h = la[t * TV]; if constexpr (LO) a[t].l = la[t * TV + 64]; }
   for (int s = s0; s < s1; s++) {
     const int dt0 = s * 8 + w;
     const u32x4* pn = pb + 8 * TV;
@@ -227,15 +228,19 @@ __global__ __launch_bounds__(512, 2) void m2dp_match_h8_kernel(const u32x4* __re
         SBAR();
         acc[t] = MF(a[t].h, c.h, first ? zero : acc[t]);
         SBAR();
-        if (t == 0) nx.h = pq[0]; else if (t == 1) nx.l = pq[64];
+        if (t == 0) nx.h = pq[0]; else if (LO && t == 1) nx.l = pq[64];
         SBAR();
-        acc[t] = MF(a[t].h, c.l, acc[t]);
-        SBAR();
-        a[t].h = la[t * TV + ((st + 1) % 12) * 128];
-        SBAR();
-        acc[t] = MF(a[t].l, c.h, acc[t]);
-        SBAR();
-        a[t].l = la[t * TV + ((st + 1) % 12) * 128 + 64];
+        if constexpr (LO) {
+          acc[t] = MF(a[t].h, c.l, acc[t]);
+          SBAR();
+          a[t].h = la[t * TV + ((st + 1) % 12) * 128];
+          SBAR();
+          acc[t] = MF(a[t].l, c.h, acc[t]);
+          SBAR();
+          a[t].l = la[t * TV + ((st + 1) % 12) * 128 + 64];
+        } else {
+          a[t].h = la[t * TV + ((st + 1) % 12) * 128];
+        }
         SBAR();
       }
     }
@@ -291,16 +296,26 @@ void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk
   if (nsplit < 1) nsplit = 1;
   const size_t lds = (size_t)qtb * TB;
   if (single) {
-    auto* k1 = m2dp_match_h_kernel<4, false>;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * TB));
+    // one product per term: a wave of the 4-wave kernel is request-bound (8 MFMAs per 6 operand requests), so the single-product form runs
+    // EIGHT waves per workgroup (two per SIMD, 4 query tiles x one DB tile each); PR_M2_WAVES=4 selects the 4-wave form for A/B runs
+    static const bool four = getenv("PR_M2_WAVES") && atoi(getenv("PR_M2_WAVES")) == 4;
     const int base4 = (QT / 4) * 2;
-    hipLaunchKernelGGL(k1, dim3(base4 * nsplit), dim3(256), (size_t)4 * TB, st, static_cast<const u32x4*>(qpk),
-                       static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
+    if (four) {
+      auto* k1 = m2dp_match_h_kernel<4, false>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * TB));
+      hipLaunchKernelGGL(k1, dim3(base4 * nsplit), dim3(256), (size_t)4 * TB, st, static_cast<const u32x4*>(qpk),
+                         static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
+    } else {
+      auto* k8 = m2dp_match_h8_kernel<false>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * TB));
+      hipLaunchKernelGGL(k8, dim3(base4 * nsplit), dim3(512), (size_t)4 * TB, st, static_cast<const u32x4*>(qpk),
+                         static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
+    }
     return;
   }
   if (eight && qtb == 4) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(m2dp_match_h8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(m2dp_match_h8_kernel, dim3(base * nsplit), dim3(512), lds, st, static_cast<const u32x4*>(qpk),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(m2dp_match_h8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(m2dp_match_h8_kernel<true>, dim3(base * nsplit), dim3(512), lds, st, static_cast<const u32x4*>(qpk),
                        static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
     return;
   }
