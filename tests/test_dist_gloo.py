@@ -93,22 +93,24 @@ def test_merge_topk_ties_and_padding():
 
 
 @pytest.mark.gpu
-def test_bench_two_ranks_on_one_gpu(tmp_path):
+@pytest.mark.parametrize("arith", ["f16x2", "f16"])
+def test_bench_two_ranks_on_one_gpu(tmp_path, arith):
     """The real sharded GPU path (Matcher + libpr_amd.so) with 2 ranks sharing cuda:0 over gloo: the merged top-1 of the
-    row-sharded DB must equal the planted ground truth, exactly like the single-rank run."""
+    row-sharded DB must equal the planted ground truth, exactly like the single-rank run.  f16: the single-product arithmetic through the
+    same exchanges (k + 56 candidates per shard, margin check on the merged list)."""
     import json
     import subprocess
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
-           "--warmup", "0", "--db", "6001", "--queries", "130", "--backend", "gloo", "--no-cpu-baseline", "--no-extra"]
+           "--warmup", "0", "--db", "6001", "--queries", "130", "--backend", "gloo", "--no-cpu-baseline", "--no-extra", "--sc-arith", arith]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["parity"]["planted_top1_correct"] == 130 and d["scaling"] == "strong"
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--db", "6001",
-                          "--queries", "130", "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, timeout=600)
+                          "--queries", "130", "--no-cpu-baseline", "--no-extra", "--sc-arith", arith], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert d1["parity"]["planted_top1_correct"] == 130
