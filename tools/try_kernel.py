@@ -23,7 +23,7 @@ def one(name, n, m, reps, small):
     from so_dso_place_recognition_amd.matcher import Matcher
     out = {"kernel": name}
     # accuracy on a small case (m > 8 so that the selected kernel runs); names "f16" / "f32" select the arithmetic instead of a kernel
-    arith = name if name in ("f16", "f32") else None
+    arith = name.split(":")[0] if name.split(":")[0] in ("f16", "f32") else None      # "f16:e1" = arithmetic f16, PR_SC_KERNEL=e1
     db = synth.sc_database(45, small)
     q, _ = synth.sc_queries(46, db, 40)
     dp, di = api.processSC(q, db, api.Context(0, sc_arith=arith))
@@ -62,6 +62,6 @@ if __name__ == "__main__":
         one(a.names[0], a.n, a.m, a.reps, a.small)
     else:
         for nm in a.names:
-            env = dict(os.environ, PR_SC_KERNEL=nm)
+            env = dict(os.environ, PR_SC_KERNEL=nm.split(":")[-1])
             subprocess.call([sys.executable, os.path.abspath(__file__), nm, "--child", "--n", str(a.n), "--m", str(a.m), "--reps", str(a.reps),
                              "--small", str(a.small)], env=env)
