@@ -77,6 +77,11 @@ int pr_sc_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int
  * M2DP::getSignature (M2DP/M2DP.h:12-30, M2DP/M2DP.cpp:38-109) each.  out[4N][384]. */
 int pr_m2dp_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
                      double max_rho, double* out);
+/* The rows (cloud * 4 + variant, ascending) of the LAST pr_m2dp_generate / pr_m2dp_generate_dev call of this context whose leading
+ * singular pair is not unique (sigma_2 / sigma_1 > ~0.99: M2DP/M2DP.cpp:94-103's JacobiSVD returns whichever of the two near-equal
+ * directions its sweeps end on, and so does this library - those rows may differ from the reference's; PR_WARN_M2DP_SVD is the
+ * call-wide bit).  At most cap rows are written, *count is the number of such rows (the list holds up to 1024: PR_EINVAL beyond). */
+int pr_m2dp_svd_rows(pr_ctx* ctx, int32_t* rows, int32_t cap, int32_t* count);
 
 /* Replaces DELIGHT::getSignature looped as in DELIGHT/test_delight.cpp:41-56 (DELIGHT/DELIGHT.h:11-18, DELIGHT.cpp:8-24;
  * PCA alignment inside).  out[16N][256]: 16 intensity histograms per cloud. */

@@ -56,6 +56,7 @@ SYMBOLS = {
     "pr_stream": (_vp, [_vp]),
     "pr_sc_generate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
     "pr_m2dp_generate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
+    "pr_m2dp_svd_rows": (C.c_int, [_vp, _vp, _i32, _vp]),
     "pr_delight_generate": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "pr_delight_distance": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp]),
     "pr_gist_distance": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),

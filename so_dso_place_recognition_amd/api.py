@@ -175,6 +175,16 @@ def m2dp_generate(xyz, inten, offs, max_rho=45.0, ctx: Context | None = None) ->
     return out
 
 
+def m2dp_svd_rows(ctx: Context | None = None) -> np.ndarray:
+    """Rows (cloud * 4 + variant) of the context's last m2dp_generate call whose leading singular pair is not unique (pr_m2dp_svd_rows):
+    the rows PR_WARN_M2DP_SVD is about."""
+    ctx = ctx or default_context()
+    rows = np.empty(1024, np.int32)
+    cnt = np.zeros(1, np.int32)
+    ctx.check(ctx.lib.pr_m2dp_svd_rows(ctx.h, _ptr(rows), len(rows), _ptr(cnt)))
+    return rows[: int(cnt[0])].copy()
+
+
 def delight_generate(xyz, inten, offs, ctx: Context | None = None) -> np.ndarray:
     """test_delight.cpp:41-56 over clouds in CSR layout -> [16N, 256]."""
     ctx = ctx or default_context()

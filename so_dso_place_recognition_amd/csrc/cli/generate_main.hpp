@@ -54,6 +54,15 @@ inline int generate_main(int argc, char** argv, int kind) {
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (rc != PR_OK) { fprintf(stderr, "generate failed: %s\n", pr_last_error(ctx)); pr_destroy(ctx); pr_clouds_free(clouds); return 4; }
   lap("generate (incl. copies)");
+  if (m2dp && (pr_take_warnings(ctx) & PR_WARN_M2DP_SVD)) {    // rows whose leading singular pair is not unique (may differ from the reference's, N6)
+    std::vector<int32_t> rws(1024);
+    int32_t cnt = 0;
+    if (pr_m2dp_svd_rows(ctx, rws.data(), (int32_t)rws.size(), &cnt) == PR_OK) {
+      fprintf(stderr, "warning: leading singular pair not unique in %d row(s):", cnt);
+      for (int i = 0; i < cnt && i < (int)rws.size(); i++) fprintf(stderr, " %d", rws[i]);
+      fprintf(stderr, "\n");
+    }
+  }
   printProgress(N ? 1.0 : 0.0);
   printf("\n%s average time: %gms\n", delight ? "DELIGHT" : (m2dp ? "M2DP" : "SC"), N ? 1000.0 * secs / N : 0.0);   // test_sc.cpp:58-61
   const bool bin = outf.size() > 4 && outf.compare(outf.size() - 4, 4, ".bin") == 0;

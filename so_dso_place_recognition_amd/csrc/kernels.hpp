@@ -110,7 +110,9 @@ void launch_sc_bin(hipStream_t st, const double* xyz, const float* inten, const 
                    const double* frames, const float* ave, double* out);
 void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
                          double max_rho, const double* frames, const float* ave, const double* planes, double* mats,
-                         double* out, int* flags /* [1] |= 1: a leading singular pair did not converge */);
+                         double* out, int* flags /* [1] |= 1: a leading singular pair did not converge */,
+                         int* svd_rows /* [0] += 1 and [1 + slot] = signature row (cloud * 4 + variant) for each such pair */);
+constexpr int M2DP_SVD_ROWS_CAP = 1024;
 size_t m2dp_generate_scratch_bytes(int N);
 
 // plain_match.hip — processGIST.m:1-10, processBoW.m:1-38 (h1, h2: device, row-major doubles; BoW rows alternate ids | weights)

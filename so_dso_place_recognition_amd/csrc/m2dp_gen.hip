@@ -97,7 +97,7 @@ __device__ __forceinline__ double block_sum256(double v, double* red, int tid) {
 }
 
 __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict__ mats, int c0, double* __restrict__ out,
-                                                        int* __restrict__ flags) {
+                                                        int* __restrict__ flags, int* __restrict__ svd_rows) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   double* A = sm;               // 64 x 129 (padded rows)
   double* G = A + 64 * 129;     // 64 x 65
@@ -212,8 +212,12 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
   }
   // sigma_2 / sigma_1 > ~0.99: the leading pair is ill-defined in the reference too (JacobiSVD returns whichever of the two
   // near-equal directions its sweeps end on); the vector reached so far is written and the call reports it
-  // (pr_take_warnings bit PR_WARN_M2DP_SVD)
-  if (!converged && tid == 0) atomicOr(flags + 1, 1);
+  // (pr_take_warnings bit PR_WARN_M2DP_SVD; the row joins the list pr_m2dp_svd_rows returns: [0] = count, then up to M2DP_SVD_ROWS_CAP rows)
+  if (!converged && tid == 0) {
+    atomicOr(flags + 1, 1);
+    const int slot = atomicAdd(svd_rows, 1);
+    if (slot < M2DP_SVD_ROWS_CAP) svd_rows[1 + slot] = (c0 + cl) * 4 + var;
+  }
   // v = A^T u / sigma, sign so that sum(u) >= 0
   if (tid < 128) {
     double s = 0.0;
@@ -238,7 +242,7 @@ size_t m2dp_generate_scratch_bytes(int N) {
 
 void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
                          double max_rho, const double* frames, const float* ave, const double* planes, double* mats,
-                         double* out, int* flags) {
+                         double* out, int* flags, int* svd_rows) {
   if (N <= 0) return;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(m2dp_svd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)SVD_LDS);
@@ -250,7 +254,7 @@ void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, 
     else
       hipLaunchKernelGGL(m2dp_bin_kernel<4>, dim3(nc * 64), dim3(256), 0, st, xyz, inten, offs, frames, ave, planes, max_rho,
                          c0, mats);
-    hipLaunchKernelGGL(m2dp_svd_kernel, dim3(nc * 8), dim3(256), SVD_LDS, st, mats, c0, out, flags);
+    hipLaunchKernelGGL(m2dp_svd_kernel, dim3(nc * 8), dim3(256), SVD_LDS, st, mats, c0, out, flags, svd_rows);
   }
 }
 

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -33,6 +34,7 @@ struct pr_ctx {
   size_t rr_cap = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   std::string err;
+  int* d_svd_rows = nullptr;     // [1 + M2DP_SVD_ROWS_CAP] rows of the last pr_m2dp_generate* call whose leading singular pair did not converge
   int* d_flags = nullptr;        // [4] deferred bits: [0] zero-norm row at pack time, [1] M2DP singular pair not converged
   double* d_twiddle = nullptr;   // cos[60], sin[60] of 2*pi*t/60
   float* d_cst = nullptr;        // SC stage-2 constants [31][2][64]
@@ -159,6 +161,8 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
     TRY(hipMalloc(&ctx->sel_scratch, pr::select_scratch_bytes()));
     TRY(hipMalloc((void**)&ctx->d_flags, 4 * sizeof(int)));
     TRY(hipMemset(ctx->d_flags, 0, 4 * sizeof(int)));
+    TRY(hipMalloc((void**)&ctx->d_svd_rows, (1 + pr::M2DP_SVD_ROWS_CAP) * sizeof(int)));
+    TRY(hipMemset(ctx->d_svd_rows, 0, (1 + pr::M2DP_SVD_ROWS_CAP) * sizeof(int)));
     double tw[120 + 4 * 60 * 8];
     for (int t = 0; t < 60; t++) { tw[t] = std::cos(2.0 * M_PI * t / 60.0); tw[60 + t] = std::sin(2.0 * M_PI * t / 60.0); }
     // exact values at the multiples of 90 degrees
@@ -261,6 +265,7 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
+  if (ctx->d_svd_rows) (void)hipFree(ctx->d_svd_rows);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
   if (ctx->d_cst) (void)hipFree(ctx->d_cst);
   if (ctx->d_cst_h) (void)hipFree(ctx->d_cst_h);
@@ -1127,10 +1132,26 @@ int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, con
   PR_HIP(ctx, ave.alloc((size_t)N * 4));
   PR_HIP(ctx, mats.alloc(pr::m2dp_generate_scratch_bytes(N)));
   if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc;
+  PR_HIP(ctx, hipMemsetAsync(ctx->d_svd_rows, 0, sizeof(int), ctx->stream));
   pr::launch_m2dp_bin_svd(ctx->stream, xyz, inten, offs, N, max_rho, frames.as<double>(), ave.as<float>(), ctx->d_planes,
-                          mats.as<double>(), out, ctx->d_flags);
+                          mats.as<double>(), out, ctx->d_flags, ctx->d_svd_rows);
   PR_HIP(ctx, hipGetLastError());
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PR_OK;
+}
+
+int pr_m2dp_svd_rows(pr_ctx* ctx, int32_t* rows, int32_t cap, int32_t* count) {
+  if (!ctx || !count || cap < 0 || (cap > 0 && !rows)) return PR_EINVAL;
+  if (int rc = set_device(ctx)) return rc;
+  std::vector<int> h(1 + pr::M2DP_SVD_ROWS_CAP);
+  PR_HIP(ctx, hipMemcpyAsync(h.data(), ctx->d_svd_rows, h.size() * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  const int nl = h[0] < pr::M2DP_SVD_ROWS_CAP ? h[0] : pr::M2DP_SVD_ROWS_CAP;
+  std::sort(h.begin() + 1, h.begin() + 1 + nl);                      // both channels of a row may be listed
+  const int nu = (int)(std::unique(h.begin() + 1, h.begin() + 1 + nl) - (h.begin() + 1));
+  for (int i = 0; i < nu && i < cap; i++) rows[i] = h[1 + i];
+  *count = nu;
+  if (h[0] > pr::M2DP_SVD_ROWS_CAP) PR_FAIL(ctx, PR_EINVAL, "pr_m2dp_svd_rows: %d pairs did not converge, the list holds %d", h[0], pr::M2DP_SVD_ROWS_CAP);
   return PR_OK;
 }
 

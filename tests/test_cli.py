@@ -134,8 +134,12 @@ def test_config1_full_kitti_seq00(ref_sequence, tmp_path):
         want = oracle_lib.m2dp_generate(x, it, offs) if polar else oracle_lib.sc_generate(x, it, offs)
         assert got.shape == want.shape
         bad = ~np.isclose(got, want, rtol=2e-5, atol=1e-12)                          # 6 significant digits in the text
-        if polar:   # a cloud whose two leading singular values nearly coincide has no unique leading pair (N6): tolerate a handful of rows
-            assert bad.any(1).sum() <= 8, bad.any(1).sum()
+        if polar:   # a cloud whose two leading singular values nearly coincide has no unique leading pair (N6): exactly the rows the
+            # library names (pr_m2dp_svd_rows, printed by test_m2dp) may differ, and they are a handful
+            line = [l for l in r.stderr.splitlines() if l.startswith("warning: leading singular pair not unique")]
+            named = set(int(t) for t in line[0].split(":")[2].split()) if line else set()
+            assert set(np.nonzero(bad.any(1))[0].tolist()) <= named, (np.nonzero(bad.any(1))[0], named)
+            assert len(named) <= 8, named
         else:
             assert not bad.any()
         sigs[exe] = (sig, got)

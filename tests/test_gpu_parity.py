@@ -239,6 +239,8 @@ def test_m2dp_generate_vs_oracle(api, golden_dir):
     assert np.abs(g - o).max() < 1e-9
     gold = np.load(os.path.join(golden_dir, "synthetic_v1.npz"))
     assert np.abs(g - gold["m2dp_sig"]).max() < 1e-9
+    # well-separated leading singular values: no row is named (the naming itself: tests/test_cli.py::test_config1_full_kitti_seq00)
+    assert len(api.m2dp_svd_rows()) == 0 and not (api.default_context().take_warnings() & 2)
 
 
 def test_generators_large_ragged_batch_vs_oracle(api):
