@@ -229,6 +229,18 @@ int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const
 int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
                          double max_rho, double* out);
 int pr_delight_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double* out);
+/* The generators with the clouds' PCA frames (utils/pts_align.h:7-46) supplied by the caller: the moments pass over the points is skipped
+ * and only the binning pass runs (28 B per point once instead of twice).  frames: device [N][16] doubles = mean[3], the three
+ * eigenvectors by ascending eigenvalue [9], 0, point count, 0, 0 - as pr_cloud_frames_dev writes them (asynchronously, on the
+ * context's stream) and as pr_pts_preprocess_gpu leaves them beside the clouds it emits (pr_clouds_dev_frames).  Same results, bit
+ * for bit, as the calls above. */
+int pr_cloud_frames_dev(pr_ctx* ctx, const double* xyz, const int64_t* offs, int32_t N, double* frames);
+int pr_sc_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho,
+                              const double* frames, double* out);
+int pr_m2dp_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho,
+                                const double* frames, double* out);
+int pr_delight_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
+                                   const double* frames, double* out);
 
 /* ---- host-side rows a1/a2 (CPU in the reference too; no device, no context) ---------------------------- */
 
@@ -252,6 +264,17 @@ const float* pr_clouds_inten(const pr_clouds* c);       /* [offs[N]] */
 const int32_t* pr_clouds_ids(const pr_clouds* c);       /* [N] incoming ids */
 double pr_clouds_avg_ms(const pr_clouds* c);           /* the reference's "average time" of pts_preprocess.h:221-225 (files already parsed) */
 double pr_clouds_avg_pts(const pr_clouds* c);
+/* Clouds made by pr_pts_preprocess_gpu also stay in HBM (device of that context) with their PCA frames, laid out as the host arrays
+ * above, for pr_*_generate_frames_dev; NULL for clouds made on the host (and for an empty result).  Freed by pr_clouds_free. */
+const double* pr_clouds_dev_xyz(const pr_clouds* c);
+const float* pr_clouds_dev_inten(const pr_clouds* c);
+const int64_t* pr_clouds_dev_offs(const pr_clouds* c);
+const double* pr_clouds_dev_frames(const pr_clouds* c);  /* [N][16] */
+/* The loop of SC/test_sc.cpp:40-56 / M2DP/test_m2dp.cpp:41-68 / DELIGHT/test_delight.cpp:41-56 over a pr_clouds object: type = PR_TYPE_*,
+ * out = host [N][2400] | [4N][384] | [16N][256] (max_rho is ignored for DELIGHT).  Clouds that pr_pts_preprocess_gpu left in this
+ * context's HBM are taken from there with their frames (no upload, binning pass only); any other pr_clouds goes the way of
+ * pr_sc_generate / pr_m2dp_generate / pr_delight_generate from its host arrays.  Same signatures either way. */
+int pr_generate_clouds(pr_ctx* ctx, int type, const pr_clouds* c, double max_rho, double* out);
 void pr_clouds_free(pr_clouds* c);
 
 /* Signature matrix text I/O: writer = `ofstream << Eigen::MatrixXd` (test_sc.cpp:63-66, test_m2dp.cpp:83-86);

@@ -77,6 +77,15 @@ SYMBOLS = {
     "pr_fuse_select_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_sc_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
     "pr_m2dp_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
+    "pr_cloud_frames_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
+    "pr_sc_generate_frames_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp, _vp]),
+    "pr_m2dp_generate_frames_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp, _vp]),
+    "pr_delight_generate_frames_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp]),
+    "pr_generate_clouds": (C.c_int, [_vp, C.c_int, _vp, _dbl, _vp]),
+    "pr_clouds_dev_xyz": (_vp, [_vp]),
+    "pr_clouds_dev_inten": (_vp, [_vp]),
+    "pr_clouds_dev_offs": (_vp, [_vp]),
+    "pr_clouds_dev_frames": (_vp, [_vp]),
     "pr_pts_preprocess": (C.c_int, [C.c_char_p, C.c_char_p, C.c_char_p, _dbl, C.c_int, C.c_int, C.POINTER(_vp)]),
     "pr_pts_preprocess_gpu": (C.c_int, [_vp, C.c_char_p, C.c_char_p, C.c_char_p, _dbl, C.c_int, C.c_int, C.POINTER(_vp)]),
     "pr_hash_order": (C.c_int, [_vp, _i32, _vp]),

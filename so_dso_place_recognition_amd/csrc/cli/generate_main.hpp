@@ -48,9 +48,8 @@ inline int generate_main(int argc, char** argv, int kind) {
   const size_t cols = delight ? PR_DELIGHT_SIG_LEN : (m2dp ? PR_M2DP_SIG_LEN : PR_SC_SIG_LEN);
   std::vector<double> sig(rows * cols);
   const auto t0 = std::chrono::steady_clock::now();
-  rc = delight ? pr_delight_generate(ctx, pr_clouds_xyz(clouds), pr_clouds_inten(clouds), pr_clouds_offs(clouds), N, sig.data())
-     : m2dp ? pr_m2dp_generate(ctx, pr_clouds_xyz(clouds), pr_clouds_inten(clouds), pr_clouds_offs(clouds), N, lidarRange, sig.data())
-            : pr_sc_generate(ctx, pr_clouds_xyz(clouds), pr_clouds_inten(clouds), pr_clouds_offs(clouds), N, lidarRange, sig.data());
+  // (clouds the GPU pre-stage left in HBM are binned there with the frames it emitted; host-made clouds are uploaded and take both passes)
+  rc = pr_generate_clouds(ctx, delight ? PR_TYPE_DELIGHT : (m2dp ? PR_TYPE_M2DP : PR_TYPE_SC), clouds, lidarRange, sig.data());
   const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   if (rc != PR_OK) { fprintf(stderr, "generate failed: %s\n", pr_last_error(ctx)); pr_destroy(ctx); pr_clouds_free(clouds); return 4; }
   lap("generate (incl. copies)");

@@ -165,7 +165,14 @@ const float* pr_clouds_inten(const pr_clouds* c) { return c->inten.data(); }
 const int32_t* pr_clouds_ids(const pr_clouds* c) { return c->ids.data(); }
 double pr_clouds_avg_ms(const pr_clouds* c) { return c ? c->avg_ms : 0.0; }
 double pr_clouds_avg_pts(const pr_clouds* c) { return c ? c->avg_pts : 0.0; }
-void pr_clouds_free(pr_clouds* c) { delete c; }
+const double* pr_clouds_dev_xyz(const pr_clouds* c) { return c ? static_cast<const double*>(c->d_xyz) : nullptr; }
+const float* pr_clouds_dev_inten(const pr_clouds* c) { return c ? static_cast<const float*>(c->d_inten) : nullptr; }
+const int64_t* pr_clouds_dev_offs(const pr_clouds* c) { return c ? static_cast<const int64_t*>(c->d_offs) : nullptr; }
+const double* pr_clouds_dev_frames(const pr_clouds* c) { return c ? static_cast<const double*>(c->d_frames) : nullptr; }
+void pr_clouds_free(pr_clouds* c) {
+  if (c && c->release) c->release(c);
+  delete c;
+}
 
 // Text format of `ofstream << Eigen::MatrixXd` (test_sc.cpp:63-66): default IOFormat = stream precision (6 significant
 // digits), " " between coefficients, "\n" between rows, no trailing newline, every coefficient right-aligned to the

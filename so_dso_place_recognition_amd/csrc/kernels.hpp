@@ -138,6 +138,7 @@ void launch_keys(hipStream_t st, const int64_t* off, int e0, int e1, int64_t C, 
 void launch_order(hipStream_t st, int E, const int64_t* off, const int* nkeys, const int* keys, const int* sched_cnt, const int* sched_nb,
                   int nsched, int* next, const int64_t* boff, int* bkt, int* order);
 void launch_gather(hipStream_t st, int E, int64_t total, const int64_t* off, const int64_t* ooff, const int* pose_of, const int* order,
-                   const int* win, const double* xyz, const float* inten, const double* W, double range, double* oxyz, float* oint);
+                   const int* win, const double* xyz, const float* inten, const double* W, double range, double* oxyz, float* oint,
+                   double* frames /* non-NULL: one workgroup per cloud, which also leaves the cloud's PCA frame [E][16] (frames.hpp) */);
 
 }  // namespace pr

@@ -384,7 +384,7 @@ int pr_pts_preprocess_gpu(pr_ctx* ctx, const char* poses_file, const char* pts_f
   res->offs.assign(1, 0);
   int rc = PR_OK;
   DevBuf dxyz, dint, dbirth, dW, demit, dnr, ddeath, dpose, dfa, dcur, doff, dcnt, dlist, dcell, dval, dtv, dtf, dtb, dkeys, dwin,
-      dnk, dscnt, dsnb, dnext, dboff, dbkt, dord, dooff, doxyz, doint;
+      dnk, dscnt, dsnb, dnext, dboff, dbkt, dord, dooff, doxyz, doint, dfr;
 #define PRE_HIP(call) { hipError_t _e = (call); if (_e != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(_e); \
                         rc = (_e == hipErrorOutOfMemory) ? PR_ENOMEM : PR_EHIP; break; } }
 #define UP(buf, vec) { PRE_HIP((buf).alloc((vec).size() * sizeof((vec)[0]))); \
@@ -459,11 +459,11 @@ int pr_pts_preprocess_gpu(pr_ctx* ctx, const char* poses_file, const char* pts_f
     const int64_t TOT = ooff[E];
     UP(dscnt, scnt); UP(dsnb, snb); UP(dboff, boff); UP(dooff, ooff);
     PRE_HIP(dnext.alloc((size_t)S * 4)); PRE_HIP(dord.alloc((size_t)S * 4)); PRE_HIP(dbkt.alloc((size_t)boff[E] * 4));
-    PRE_HIP(doxyz.alloc((size_t)TOT * 24)); PRE_HIP(doint.alloc((size_t)TOT * 4));
+    PRE_HIP(doxyz.alloc((size_t)TOT * 24)); PRE_HIP(doint.alloc((size_t)TOT * 4)); PRE_HIP(dfr.alloc((size_t)E * 16 * 8));
     pr::launch_order(ctx->stream, E, doff.as<int64_t>(), dnk.as<int>(), dkeys.as<int>(), dscnt.as<int>(), dsnb.as<int>(), (int)scnt.size(),
                      dnext.as<int>(), dboff.as<int64_t>(), dbkt.as<int>(), dord.as<int>());
     pr::launch_gather(ctx->stream, E, TOT, doff.as<int64_t>(), dooff.as<int64_t>(), dpose.as<int>(), dord.as<int>(), dwin.as<int>(),
-                      dxyz.as<double>(), dint.as<float>(), dW.as<double>(), lidarRange, doxyz.as<double>(), doint.as<float>());
+                      dxyz.as<double>(), dint.as<float>(), dW.as<double>(), lidarRange, doxyz.as<double>(), doint.as<float>(), dfr.as<double>());
     res->xyz.resize((size_t)TOT * 3);
     res->inten.resize((size_t)TOT);
     PRE_HIP(hipMemcpyAsync(res->xyz.data(), doxyz.p, (size_t)TOT * 24, hipMemcpyDeviceToHost, ctx->stream));
@@ -471,10 +471,19 @@ int pr_pts_preprocess_gpu(pr_ctx* ctx, const char* poses_file, const char* pts_f
     PRE_HIP(hipStreamSynchronize(ctx->stream));
     PRE_HIP(hipGetLastError());
     for (int e = 0; e < E; e++) res->offs.push_back(ooff[e + 1]);
+    // the clouds and their frames stay in HBM with the host copies (pr_clouds_dev_*): the generators take them from there
+    res->d_xyz = doxyz.p; res->d_inten = doint.p; res->d_offs = dooff.p; res->d_frames = dfr.p;
+    doxyz.p = doint.p = dooff.p = dfr.p = nullptr;
+    res->device = ctx->device;
+    res->release = [](pr_clouds* c) {
+      (void)hipSetDevice(c->device);
+      for (void* p : {c->d_xyz, c->d_inten, c->d_offs, c->d_frames}) if (p) (void)hipFree(p);
+      c->d_xyz = c->d_inten = c->d_offs = c->d_frames = nullptr;
+    };
   } while (0);
 #undef UP
 #undef PRE_HIP
-  if (rc != PR_OK) { (void)hipStreamSynchronize(ctx->stream); delete res; if (idf) fclose(idf); return rc; }
+  if (rc != PR_OK) { (void)hipStreamSynchronize(ctx->stream); pr_clouds_free(res); if (idf) fclose(idf); return rc; }
   if (res->offs.size() == 1) res->offs.resize((size_t)E + 1, 0);
   for (int e = 0; e < E; e++) {
     res->ids.push_back(poses[pose_of[e]].id);
@@ -1035,6 +1044,41 @@ static int launch_frames_and_ave(pr_ctx* ctx, const double* xyz, const float* in
   return PR_OK;
 }
 
+int pr_cloud_frames_dev(pr_ctx* ctx, const double* xyz, const int64_t* offs, int32_t N, double* frames) {
+  if (!ctx) return PR_EINVAL;
+  if (N < 0 || !offs || (N > 0 && !frames)) PR_FAIL(ctx, PR_EINVAL, "pr_cloud_frames_dev: bad arguments (N=%d)", N);
+  if (N == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_cloud_frames(ctx->stream, xyz, offs, N, frames);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+// the float-average chain on the side stream, joined with the main stream (the frames are the caller's)
+static int launch_ave_only(pr_ctx* ctx, const float* inten, const int64_t* offs, int32_t N, float* ave) {
+  PR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+  PR_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+  pr::launch_ave_chain(ctx->side, inten, offs, N, ave);
+  PR_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+  PR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+  return PR_OK;
+}
+
+int pr_sc_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho,
+                              const double* frames, double* out) {
+  if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
+  if (N == 0) return PR_OK;
+  if (!frames) PR_FAIL(ctx, PR_EINVAL, "pr_sc_generate_frames_dev: frames is NULL");
+  if (int rc = set_device(ctx)) return rc;
+  DevBuf ave;
+  PR_HIP(ctx, ave.alloc((size_t)N * 4));
+  if (int rc = launch_ave_only(ctx, inten, offs, N, ave.as<float>())) return rc;
+  pr::launch_sc_bin(ctx->stream, xyz, inten, offs, N, max_rho, frames, ave.as<float>(), out);
+  PR_HIP(ctx, hipGetLastError());
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PR_OK;
+}
+
 int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
   if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
   if (N == 0) return PR_OK;
@@ -1123,21 +1167,31 @@ int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const
   return PR_OK;
 }
 
-int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
+static int m2dp_generate_impl(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho,
+                              const double* frames_in, double* out) {
   if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
   if (N == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   DevBuf frames, ave, mats;
-  PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
+  if (!frames_in) PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
   PR_HIP(ctx, ave.alloc((size_t)N * 4));
   PR_HIP(ctx, mats.alloc(pr::m2dp_generate_scratch_bytes(N)));
-  if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc;
+  if (frames_in) { if (int rc = launch_ave_only(ctx, inten, offs, N, ave.as<float>())) return rc; }
+  else if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc;
   PR_HIP(ctx, hipMemsetAsync(ctx->d_svd_rows, 0, sizeof(int), ctx->stream));
-  pr::launch_m2dp_bin_svd(ctx->stream, xyz, inten, offs, N, max_rho, frames.as<double>(), ave.as<float>(), ctx->d_planes,
+  pr::launch_m2dp_bin_svd(ctx->stream, xyz, inten, offs, N, max_rho, frames_in ? frames_in : frames.as<double>(), ave.as<float>(), ctx->d_planes,
                           mats.as<double>(), out, ctx->d_flags, ctx->d_svd_rows);
   PR_HIP(ctx, hipGetLastError());
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PR_OK;
+}
+int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
+  return m2dp_generate_impl(ctx, xyz, inten, offs, N, max_rho, nullptr, out);
+}
+int pr_m2dp_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho,
+                                const double* frames, double* out) {
+  if (ctx && N > 0 && !frames) PR_FAIL(ctx, PR_EINVAL, "pr_m2dp_generate_frames_dev: frames is NULL");
+  return m2dp_generate_impl(ctx, xyz, inten, offs, N, max_rho, frames, out);
 }
 
 int pr_m2dp_svd_rows(pr_ctx* ctx, int32_t* rows, int32_t cap, int32_t* count) {
@@ -1155,14 +1209,27 @@ int pr_m2dp_svd_rows(pr_ctx* ctx, int32_t* rows, int32_t cap, int32_t* count) {
   return PR_OK;
 }
 
+static int delight_generate_impl(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, const double* frames_in,
+                                 double* out);
 int pr_delight_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double* out) {
+  return delight_generate_impl(ctx, xyz, inten, offs, N, nullptr, out);
+}
+int pr_delight_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, const double* frames,
+                                   double* out) {
+  if (ctx && N > 0 && !frames) PR_FAIL(ctx, PR_EINVAL, "pr_delight_generate_frames_dev: frames is NULL");
+  return delight_generate_impl(ctx, xyz, inten, offs, N, frames, out);
+}
+static int delight_generate_impl(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, const double* frames_in,
+                                 double* out) {
   if (int rc = check_gen_args(ctx, xyz, inten, offs, N, 1.0, out)) return rc;
   if (N == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   DevBuf frames;
-  PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
-  pr::launch_cloud_frames(ctx->stream, xyz, offs, N, frames.as<double>());
-  pr::launch_delight_gen(ctx->stream, xyz, inten, offs, N, frames.as<double>(), out);
+  if (!frames_in) {
+    PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
+    pr::launch_cloud_frames(ctx->stream, xyz, offs, N, frames.as<double>());
+  }
+  pr::launch_delight_gen(ctx->stream, xyz, inten, offs, N, frames_in ? frames_in : frames.as<double>(), out);
   PR_HIP(ctx, hipGetLastError());
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PR_OK;
@@ -1210,6 +1277,31 @@ int pr_m2dp_generate(pr_ctx* ctx, const double* xyz, const float* inten, const i
 
 int pr_delight_generate(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double* out) {
   return generate_host(ctx, PR_TYPE_DELIGHT, xyz, inten, offs, N, 1.0, out);
+}
+
+int pr_generate_clouds(pr_ctx* ctx, int type, const pr_clouds* c, double max_rho, double* out) {
+  if (!ctx) return PR_EINVAL;
+  if (!c || (type != PR_TYPE_SC && type != PR_TYPE_M2DP && type != PR_TYPE_DELIGHT)) PR_FAIL(ctx, PR_EINVAL, "pr_generate_clouds: bad arguments");
+  const int32_t N = (int32_t)c->ids.size();
+  if (type == PR_TYPE_DELIGHT) max_rho = 1.0;
+  if (!c->d_frames || c->device != ctx->device)          // host-made clouds (or another device's): the two-pass path from the host arrays
+    return generate_host(ctx, type, c->xyz.data(), c->inten.data(), c->offs.data(), N, max_rho, out);
+  if (N > 0 && !out) PR_FAIL(ctx, PR_EINVAL, "pr_generate_clouds: out is NULL");
+  if (int rc = set_device(ctx)) return rc;
+  const size_t rowlen = (type == PR_TYPE_SC) ? PR_SC_SIG_LEN : (type == PR_TYPE_M2DP ? (size_t)4 * PR_M2DP_SIG_LEN : (size_t)16 * PR_DELIGHT_SIG_LEN);
+  DevBuf dout;
+  PR_HIP(ctx, dout.alloc((size_t)N * rowlen * 8));
+  const double* x = static_cast<const double*>(c->d_xyz);
+  const float* it = static_cast<const float*>(c->d_inten);
+  const int64_t* of = static_cast<const int64_t*>(c->d_offs);
+  const double* fr = static_cast<const double*>(c->d_frames);
+  int rc = (type == PR_TYPE_SC)     ? pr_sc_generate_frames_dev(ctx, x, it, of, N, max_rho, fr, dout.as<double>())
+           : (type == PR_TYPE_M2DP) ? pr_m2dp_generate_frames_dev(ctx, x, it, of, N, max_rho, fr, dout.as<double>())
+                                    : pr_delight_generate_frames_dev(ctx, x, it, of, N, fr, dout.as<double>());
+  if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
+  PR_HIP(ctx, hipMemcpyAsync(out, dout.p, (size_t)N * rowlen * 8, hipMemcpyDeviceToHost, ctx->stream));
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PR_OK;
 }
 
 }  // extern "C"

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "frames.hpp"
 #include "hash_order.hpp"
 #include "kernels.hpp"
 
@@ -209,6 +210,36 @@ __global__ __launch_bounds__(256) void gather_kernel(int E, const int64_t* __res
   oint[o] = inten[j];
 }
 
+// The same emission with one workgroup per cloud, which also adds up the cloud's raw moments on the way and leaves its PCA frame
+// (pts_align.h:7-46): thread t emits points t, t + 256, ... - the order in which cloud_frames_kernel (sc_gen.hip) reads them - and both
+// use reduce_moments_to_frame, so frames[e] has the bits a moments pass over the emitted cloud would produce; the generators then run
+// their binning pass only (pr_*_generate_frames_dev).
+__global__ __launch_bounds__(FRAME_THREADS) void gather_frames_kernel(const int64_t* __restrict__ off, const int64_t* __restrict__ ooff,
+                                                                      const int* __restrict__ pose_of, const int* __restrict__ order,
+                                                                      const int* __restrict__ win, const double* __restrict__ xyz,
+                                                                      const float* __restrict__ inten, const double* __restrict__ W,
+                                                                      double range, double* __restrict__ oxyz, float* __restrict__ oint,
+                                                                      double* __restrict__ frames) {
+  __shared__ double red[FRAME_THREADS / 64][9];
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const int64_t o0 = ooff[e], P = ooff[e + 1] - o0, m0 = off[e];
+  const double* w = W + 12 * (size_t)pose_of[e];
+  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int64_t i = tid; i < P; i += FRAME_THREADS) {
+    const int j = win[m0 + order[m0 + i]];
+    const double gp[3] = {xyz[3 * (size_t)j], xyz[3 * (size_t)j + 1], xyz[3 * (size_t)j + 2]};
+    double l[3];
+    (void)to_camera(w, gp, range, l);
+    const int64_t o = o0 + i;
+    oxyz[3 * o] = l[0]; oxyz[3 * o + 1] = l[1]; oxyz[3 * o + 2] = l[2];
+    oint[o] = inten[j];
+    const double x = l[0], y = l[1], z = l[2];
+    s[0] += x; s[1] += y; s[2] += z;
+    s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;
+  }
+  reduce_moments_to_frame(s, (double)P, red, frames + (size_t)e * 16);
+}
+
 Grid make_grid(double range, int polar) {
   Grid g;
   g.range = range;
@@ -263,7 +294,13 @@ void launch_order(hipStream_t st, int E, const int64_t* off, const int* nkeys, c
   hipLaunchKernelGGL(order_kernel, dim3((E + 63) / 64), dim3(64), 0, st, E, off, nkeys, keys, sched_cnt, sched_nb, nsched, next, boff, bkt, order);
 }
 void launch_gather(hipStream_t st, int E, int64_t total, const int64_t* off, const int64_t* ooff, const int* pose_of, const int* order,
-                   const int* win, const double* xyz, const float* inten, const double* W, double range, double* oxyz, float* oint) {
+                   const int* win, const double* xyz, const float* inten, const double* W, double range, double* oxyz, float* oint,
+                   double* frames) {
+  if (frames) {                 // one workgroup per cloud: the points and the cloud's PCA frame
+    if (E > 0) hipLaunchKernelGGL(gather_frames_kernel, dim3(E), dim3(FRAME_THREADS), 0, st, off, ooff, pose_of, order, win, xyz, inten, W, range,
+                                  oxyz, oint, frames);
+    return;
+  }
   if (total <= 0) return;
   hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, E, off, ooff, pose_of, order, win, xyz, inten,
                      W, range, oxyz, oint);

@@ -16,6 +16,13 @@ struct pr_clouds {
   std::vector<float> inten;
   std::vector<int32_t> ids;
   double avg_ms = 0, avg_pts = 0;
+  // pr_pts_preprocess_gpu leaves the emitted clouds and their PCA frames in HBM too (NULL otherwise), for pr_*_generate_frames_dev
+  void* d_xyz = nullptr;
+  void* d_inten = nullptr;
+  void* d_offs = nullptr;
+  void* d_frames = nullptr;
+  int device = -1;
+  void (*release)(pr_clouds*) = nullptr;    // frees the device copies (set by whoever made them)
 };
 
 namespace pr_rec {

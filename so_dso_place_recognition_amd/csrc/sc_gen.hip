@@ -23,76 +23,14 @@
 // last-arriver merges: cloud_frames_split / sc_bin_split / sc_finish; 6.25 ms against 2.52 ms at 5000 x 50k points) and PR_SC_GEN=cluster
 // (eight workgroups of one XCD hold a cloud in registers between the moments and the binning: sc_gen_cluster_kernel; 6.6 ms).
 #include "fast_bins.hpp"
+#include "frames.hpp"
 #include "kernels.hpp"
 
 namespace pr {
 namespace {
 
-constexpr int FT = 256;   // threads of cloud_frames
+constexpr int FT = FRAME_THREADS;   // threads of cloud_frames
 constexpr int RW = FT / 64;
-
-__device__ void jacobi_eig3(double a[3][3], double v[3][3]) {
-  for (int i = 0; i < 3; i++)
-    for (int j = 0; j < 3; j++) v[i][j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 64; sweep++) {
-    const double off = a[0][1] * a[0][1] + a[0][2] * a[0][2] + a[1][2] * a[1][2];
-    const double dia = a[0][0] * a[0][0] + a[1][1] * a[1][1] + a[2][2] * a[2][2];
-    if (off == 0.0 || off <= 1e-36 * dia) break;
-    for (int p = 0; p < 2; p++)
-      for (int q = p + 1; q < 3; q++) {
-        if (a[p][q] == 0.0) continue;
-        const double theta = (a[q][q] - a[p][p]) / (2.0 * a[p][q]);
-        const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double cs = 1.0 / sqrt(t * t + 1.0), sn = t * cs;
-        for (int k = 0; k < 3; k++) {
-          const double x = a[k][p], y = a[k][q];
-          a[k][p] = cs * x - sn * y;
-          a[k][q] = sn * x + cs * y;
-        }
-        for (int k = 0; k < 3; k++) {
-          const double x = a[p][k], y = a[q][k];
-          a[p][k] = cs * x - sn * y;
-          a[q][k] = sn * x + cs * y;
-        }
-        for (int k = 0; k < 3; k++) {
-          const double x = v[k][p], y = v[k][q];
-          v[k][p] = cs * x - sn * y;
-          v[k][q] = sn * x + cs * y;
-        }
-      }
-  }
-}
-
-// raw moments (sum p, sum p p^T) of a cloud of n points -> frame {mean[3], v0[3], v1[3], v2[3], 0, n, 0, 0}: scatter matrix
-// cov = sum pp^T - n mean mean^T (un-normalised as pts_align.h:30), 3x3 Jacobi, eigenvalues ascending (Eigen::SelfAdjointEigenSolver
-// order, :32-34), canonical signs (N3)
-__device__ void finish_frame(const double s[9], double n, double* f) {
-  const double mx = s[0] / n, my = s[1] / n, mz = s[2] / n;
-  double a[3][3], v[3][3];
-  a[0][0] = s[3] - n * mx * mx; a[0][1] = s[4] - n * mx * my; a[0][2] = s[5] - n * mx * mz;
-  a[1][1] = s[6] - n * my * my; a[1][2] = s[7] - n * my * mz; a[2][2] = s[8] - n * mz * mz;
-  a[1][0] = a[0][1]; a[2][0] = a[0][2]; a[2][1] = a[1][2];
-  jacobi_eig3(a, v);
-  int ord[3] = {0, 1, 2};
-  for (int i = 0; i < 2; i++)
-    for (int j = 0; j < 2 - i; j++)
-      if (a[ord[j + 1]][ord[j + 1]] < a[ord[j]][ord[j]]) { const int t = ord[j]; ord[j] = ord[j + 1]; ord[j + 1] = t; }
-  double e[3][3];
-  for (int j = 0; j < 3; j++)
-    for (int k = 0; k < 3; k++) e[j][k] = v[k][ord[j]];
-  for (int j = 0; j < 2; j++) {   // canonical sign: largest-|component| positive (N3)
-    int im = 0;
-    for (int k = 1; k < 3; k++) if (fabs(e[j][k]) > fabs(e[j][im])) im = k;
-    if (e[j][im] < 0) for (int k = 0; k < 3; k++) e[j][k] = -e[j][k];
-  }
-  const double cx = e[0][1] * e[1][2] - e[0][2] * e[1][1], cy = e[0][2] * e[1][0] - e[0][0] * e[1][2],
-               cz = e[0][0] * e[1][1] - e[0][1] * e[1][0];
-  if (cx * e[2][0] + cy * e[2][1] + cz * e[2][2] < 0) for (int k = 0; k < 3; k++) e[2][k] = -e[2][k];   // det = +1
-  f[0] = mx; f[1] = my; f[2] = mz;
-  for (int j = 0; j < 3; j++)
-    for (int k = 0; k < 3; k++) f[3 + 3 * j + k] = e[j][k];
-  f[12] = 0; f[13] = n; f[14] = 0; f[15] = 0;
-}
 
 // The float average of the reference is a sequential sum in input order (SC.cpp:60-64, M2DP.cpp:77-81): one dependent
 // v_add_f32 per point, ~5 cycles each - 0.1 ms for 50k points whatever the number of clouds.  One wave per CPW = 8
@@ -166,35 +104,17 @@ __global__ __launch_bounds__(64) void ave_chain_kernel(const float* __restrict__
 __global__ __launch_bounds__(FT) void cloud_frames_kernel(const double* __restrict__ xyz,
                                                            const int64_t* __restrict__ offs, double* __restrict__ frames) {
   __shared__ double red[RW][9];
-  const int c = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-  const int w = tid >> 6;
+  const int c = blockIdx.x, tid = threadIdx.x;
   const int64_t o0 = offs[c];
   const int64_t P = offs[c + 1] - o0;
-  {
-    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    const double* p = xyz + 3 * o0;
-    for (int64_t i = tid; i < P; i += FT) {
-      const double x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
-      s[0] += x; s[1] += y; s[2] += z;
-      s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;
-    }
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-      double v = s[k];
-      for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d);
-      if (lane == 0) red[w][k] = v;
-    }
+  double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  const double* p = xyz + 3 * o0;
+  for (int64_t i = tid; i < P; i += FT) {
+    const double x = p[3 * i], y = p[3 * i + 1], z = p[3 * i + 2];
+    s[0] += x; s[1] += y; s[2] += z;
+    s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;
   }
-  __syncthreads();
-  if (tid == 0) {
-    double s[9];
-    for (int k = 0; k < 9; k++) {
-      double v = 0;
-      for (int i = 0; i < RW; i++) v += red[i][k];
-      s[k] = v;
-    }
-    finish_frame(s, (double)P, frames + (size_t)c * 16);
-  }
+  reduce_moments_to_frame(s, (double)P, red, frames + (size_t)c * 16);
 }
 
 __device__ __forceinline__ unsigned long long dkey(double x) {   // order-preserving map double -> u64

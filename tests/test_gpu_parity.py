@@ -243,6 +243,41 @@ def test_m2dp_generate_vs_oracle(api, golden_dir):
     assert len(api.m2dp_svd_rows()) == 0 and not (api.default_context().take_warnings() & 2)
 
 
+def test_generators_with_caller_frames_equal_the_two_pass_calls(api):
+    """pr_cloud_frames_dev + pr_*_generate_frames_dev (binning pass only) give the bits of pr_*_generate_dev, ragged sizes and an empty cloud
+    included; the frames themselves hold mean, an orthonormal right-handed basis and the point count."""
+    import torch
+    rng = np.random.default_rng(11)
+    sizes = rng.integers(1, 3000, size=40); sizes[7] = 0; sizes[8] = 1; sizes[9] = 257
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    xyz = rng.normal(0, [12, 3, 9], (offs[-1], 3)); it = rng.random(offs[-1]).astype(np.float32)
+    dx, di, do = (torch.from_numpy(a).cuda() for a in (xyz, it, offs))
+    N = len(sizes)
+    ctx = api.Context(0)
+    fr = torch.empty((N, 16), dtype=torch.float64, device="cuda")
+    ctx.check(ctx.lib.pr_cloud_frames_dev(ctx.h, dx.data_ptr(), do.data_ptr(), N, fr.data_ptr()))
+    ctx.sync()
+    f = fr.cpu().numpy()
+    big = sizes >= 3
+    assert np.array_equal(f[:, 13], sizes.astype(np.float64))
+    assert np.abs(f[big, :3] - np.stack([xyz[offs[c]:offs[c + 1]].mean(0) for c in np.nonzero(big)[0]])).max() < 1e-12
+    R = f[big, 3:12].reshape(-1, 3, 3)
+    assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-12 and np.abs(np.linalg.det(R) - 1).max() < 1e-12
+    for name, rows, cols, rho in (("sc", N, 2400, 45.0), ("m2dp", 4 * N, 384, 45.0), ("delight", 16 * N, 256, None)):
+        a = torch.empty((rows, cols), dtype=torch.float64, device="cuda"); b = torch.empty_like(a)
+        two = getattr(ctx.lib, f"pr_{name}_generate_dev"); one = getattr(ctx.lib, f"pr_{name}_generate_frames_dev")
+        if rho is None:
+            ctx.check(two(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, a.data_ptr()))
+            ctx.check(one(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, fr.data_ptr(), b.data_ptr()))
+        else:
+            ctx.check(two(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, rho, a.data_ptr()))
+            ctx.check(one(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, rho, fr.data_ptr(), b.data_ptr()))
+        ctx.sync()
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64)), name
+    assert ctx.lib.pr_sc_generate_frames_dev(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, 45.0, None, a.data_ptr()) == -1   # PR_EINVAL
+    ctx.close()
+
+
 def test_generators_large_ragged_batch_vs_oracle(api):
     """300 clouds of 1..1100 points (a batch large enough for the 16-plane M2DP workgroups and several rounds of the
     float-average chain, sizes that are not multiples of its 512-float chunks, an empty cloud in the middle)."""

@@ -205,6 +205,55 @@ def test_gpu_prestage_equals_host_prestage(seq07, polar):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("polar", [False, True])
+def test_gpu_prestage_leaves_clouds_and_frames_in_hbm(seq07, polar):
+    """pr_pts_preprocess_gpu keeps the emitted clouds in HBM with the PCA frames its gather pass adds up (pr_clouds_dev_*): the device copies
+    are the host arrays, the frames are bit for bit those of a moments pass over them (pr_cloud_frames_dev), and pr_generate_clouds -
+    binning pass only, straight from HBM - returns the signatures of the two-pass host-array calls."""
+    import ctypes as C
+    import torch
+    from so_dso_place_recognition_amd import _lib
+    poses, pts, d = seq07
+    lib = _lib.load()
+    ctx = api.Context(0)
+    h = C.c_void_p()
+    ctx.check(lib.pr_pts_preprocess_gpu(ctx.h, poses.encode(), pts.encode(), None, 45.0, int(polar), 0, C.byref(h)))
+    try:
+        N = lib.pr_clouds_count(h)
+        offs = np.ctypeslib.as_array(lib.pr_clouds_offs(h), (N + 1,)).copy()
+        T = int(offs[-1])
+        xyz = np.ctypeslib.as_array(lib.pr_clouds_xyz(h), (T, 3)).copy()
+        it = np.ctypeslib.as_array(lib.pr_clouds_inten(h), (T,)).copy()
+        assert N > 50 and T > 10000 and lib.pr_clouds_dev_frames(h)
+        def dev(ptr, shape, dtype):               # a torch view of library-owned device memory
+            n = int(np.prod(shape))
+            out = torch.empty(n, dtype=dtype, device="cuda")
+            torch.cuda.synchronize()
+            import ctypes
+            hip = ctypes.CDLL("libamdhip64.so")
+            assert hip.hipMemcpy(C.c_void_p(out.data_ptr()), C.c_void_p(ptr), C.c_size_t(n * out.element_size()), 3) == 0
+            return out.reshape(shape)
+        dx = dev(lib.pr_clouds_dev_xyz(h), (T, 3), torch.float64)
+        di = dev(lib.pr_clouds_dev_inten(h), (T,), torch.float32)
+        do = dev(lib.pr_clouds_dev_offs(h), (N + 1,), torch.int64)
+        fr = dev(lib.pr_clouds_dev_frames(h), (N, 16), torch.float64)
+        assert np.array_equal(dx.cpu().numpy().view(np.uint64), xyz.view(np.uint64)) and np.array_equal(do.cpu().numpy(), offs)
+        assert np.array_equal(di.cpu().numpy().view(np.uint32), it.view(np.uint32))
+        fr2 = torch.empty_like(fr)
+        ctx.check(lib.pr_cloud_frames_dev(ctx.h, dx.data_ptr(), do.data_ptr(), N, fr2.data_ptr()))
+        ctx.sync()
+        assert np.array_equal(fr.cpu().numpy().view(np.uint64), fr2.cpu().numpy().view(np.uint64))
+        for type_, gen, rows, cols in ((0, api.sc_generate, N, 2400), (1, api.m2dp_generate, 4 * N, 384), (2, api.delight_generate, 16 * N, 256)):
+            got = np.empty((rows, cols))
+            ctx.check(lib.pr_generate_clouds(ctx.h, type_, h, 45.0, got.ctypes.data))
+            want = gen(xyz, it, offs, ctx=ctx) if type_ == 2 else gen(xyz, it, offs, 45.0, ctx)
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), type_
+    finally:
+        lib.pr_clouds_free(h)
+        ctx.close()
+
+
+@pytest.mark.gpu
 def test_gpu_prestage_resets_ranges_and_empty_inputs(golden_dir, tmp_path):
     """Two sequences back to back (a second reset in the middle), a shorter lidar range, unsorted point ids, and the
     degenerate inputs."""
