@@ -107,7 +107,7 @@ int* launch_sc_cluster(hipStream_t st, const double* xyz, const float* inten, co
                        char* scratch, double* frames, double* out);
 void launch_sc_finish(hipStream_t st, const float* ave, int N, double* out);
 void launch_sc_bin(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double max_rho,
-                   const double* frames, const float* ave, double* out);
+                   const double* frames, const float* ave /* NULL: out[c][1200..] = bin means, launch_sc_finish applies the averages */, double* out);
 void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
                          double max_rho, const double* frames, const float* ave, const double* planes, double* mats,
                          double* out, int* flags /* [1] |= 1: a leading singular pair did not converge */,

@@ -153,7 +153,11 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
     TRY(hipSetDevice(device_id));
     if (use_external) { ctx->stream = external; ctx->own_stream = false; }
     else TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
-    TRY(hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking));
+    {  // (highest priority: the few waves of the average chain are dispatched ahead of the streaming passes they run beside)
+      int plo = 0, phi = 0;
+      TRY(hipDeviceGetStreamPriorityRange(&plo, &phi));
+      TRY(hipStreamCreateWithPriority(&ctx->side, hipStreamNonBlocking, phi));
+    }
     TRY(hipStreamCreateWithFlags(&ctx->side2, hipStreamNonBlocking));
     TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
     TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
@@ -1054,14 +1058,22 @@ int pr_cloud_frames_dev(pr_ctx* ctx, const double* xyz, const int64_t* offs, int
   return PR_OK;
 }
 
-// the float-average chain on the side stream, joined with the main stream (the frames are the caller's)
-static int launch_ave_only(pr_ctx* ctx, const float* inten, const int64_t* offs, int32_t N, float* ave) {
+// the float-average chain (a dependent add per point: ~0.28 ms per 50 000 points, however many clouds) starts on the side stream ...
+static int fork_ave(pr_ctx* ctx, const float* inten, const int64_t* offs, int32_t N, float* ave) {
   PR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
   PR_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
   pr::launch_ave_chain(ctx->side, inten, offs, N, ave);
   PR_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+  return PR_OK;
+}
+// ... and is joined where its result is needed
+static int join_ave(pr_ctx* ctx) {
   PR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   return PR_OK;
+}
+static int launch_ave_only(pr_ctx* ctx, const float* inten, const int64_t* offs, int32_t N, float* ave) {
+  if (int rc = fork_ave(ctx, inten, offs, N, ave)) return rc;
+  return join_ave(ctx);
 }
 
 int pr_sc_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho,
@@ -1072,8 +1084,11 @@ int pr_sc_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten
   if (int rc = set_device(ctx)) return rc;
   DevBuf ave;
   PR_HIP(ctx, ave.alloc((size_t)N * 4));
-  if (int rc = launch_ave_only(ctx, inten, offs, N, ave.as<float>())) return rc;
-  pr::launch_sc_bin(ctx->stream, xyz, inten, offs, N, max_rho, frames, ave.as<float>(), out);
+  // the binning pass writes bin means and does not wait for the average chain beside it; sc_finish applies the averages
+  if (int rc = fork_ave(ctx, inten, offs, N, ave.as<float>())) return rc;
+  pr::launch_sc_bin(ctx->stream, xyz, inten, offs, N, max_rho, frames, nullptr, out);
+  if (int rc = join_ave(ctx)) return rc;
+  pr::launch_sc_finish(ctx->stream, ave.as<float>(), N, out);
   PR_HIP(ctx, hipGetLastError());
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PR_OK;
@@ -1119,8 +1134,11 @@ int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const
     }
   }
   if (two_pass) {
-    if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc;
-    pr::launch_sc_bin(ctx->stream, xyz, inten, offs, N, max_rho, frames.as<double>(), ave.as<float>(), out);
+    if (int rc = fork_ave(ctx, inten, offs, N, ave.as<float>())) return rc;
+    pr::launch_cloud_frames(ctx->stream, xyz, offs, N, frames.as<double>());
+    pr::launch_sc_bin(ctx->stream, xyz, inten, offs, N, max_rho, frames.as<double>(), nullptr, out);
+    if (int rc = join_ave(ctx)) return rc;
+    pr::launch_sc_finish(ctx->stream, ave.as<float>(), N, out);
     PR_HIP(ctx, hipGetLastError());
     PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PR_OK;

@@ -41,9 +41,13 @@ constexpr int CPW = 8;
 constexpr int ACH = 512;                     // floats per cloud and round
 __global__ __launch_bounds__(64) void ave_chain_kernel(const float* __restrict__ inten, const int64_t* __restrict__ offs,
                                                         int N, float* __restrict__ ave_out) {
-  __shared__ __attribute__((aligned(16))) float buf[CPW][ACH];
+  // rows of ACH + 4 floats: the eight adding lanes read eight different bank groups; + 32 floats: the read-ahead of the last block stays inside
+  __shared__ __attribute__((aligned(16))) float bufs[CPW * (ACH + 4) + 32];
+  float (*buf)[ACH + 4] = reinterpret_cast<float (*)[ACH + 4]>(bufs);
   typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
   typedef float f4a __attribute__((ext_vector_type(4)));
+  // the chain is the critical path of a generate call and shares its CU with the waves of the moments / binning pass: issue priority
+  __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x;
   const int cb = blockIdx.x * CPW;
   const float* base[CPW];
@@ -86,10 +90,27 @@ __global__ __launch_bounds__(64) void ave_chain_kernel(const float* __restrict__
     if (r0 + ACH < Pmax) request(r0 + ACH);
     __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the LDS writes of this wave are done (one wave per workgroup)
     if (lane < CPW) {
-#pragma unroll 8
-      for (int j = 0; j < ACH; j += 4) {
-        const f4a v = *reinterpret_cast<const f4a*>(&buf[lane][j]);
-        ave += v[0]; ave += v[1]; ave += v[2]; ave += v[3];
+      // 32 floats in registers while the next 32 are on their way from LDS: the chain waits for the adds only (~4.5 cycles each).  The
+      // scheduling barriers keep hipcc from hoisting a block's reads above the adds that still use its registers (it then copies 32 registers
+      // per block); the last block reads 32 floats ahead for nothing.
+      const f4a* src = reinterpret_cast<const f4a*>(&buf[lane][0]);
+      f4a a[8], b[8];
+#pragma unroll
+      for (int q = 0; q < 8; q++) a[q] = src[q];
+#pragma unroll 1
+      for (int j = 0; j < ACH / 4; j += 16) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) b[q] = src[j + 8 + q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { ave += a[q][0]; ave += a[q][1]; ave += a[q][2]; ave += a[q][3]; }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] = src[j + 16 + q];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < 8; q++) { ave += b[q][0]; ave += b[q][1]; ave += b[q][2]; ave += b[q][3]; }
       }
     }
   }
@@ -126,6 +147,9 @@ __device__ __forceinline__ double dunkey(unsigned long long k) {
   return __longlong_as_double((long long)b);
 }
 
+// MEAN: out[1200 + b] = the bin's mean intensity (-inf for an empty bin) instead of the 0/1 of SC.cpp:69-70 - sc_finish_kernel applies the
+// float average afterwards, so that the binning does not wait for the average chain (which runs beside it on a side stream)
+template <bool MEAN>
 __global__ __launch_bounds__(512) void sc_bin_kernel(const double* __restrict__ xyz, const float* __restrict__ inten,
                                                       const int64_t* __restrict__ offs, const double* __restrict__ frames,
                                                       const float* __restrict__ ave_in, double max_rho,
@@ -161,14 +185,14 @@ __global__ __launch_bounds__(512) void sc_bin_kernel(const double* __restrict__ 
     atomicAdd(&sum[idx], (double)it[i]);
   }
   __syncthreads();
-  const double ave = (double)ave_in[c];   // the float average, widened (double > float promotes the float, SC.cpp:70)
+  const double ave = MEAN ? 0.0 : (double)ave_in[c];   // the float average, widened (double > float promotes the float, SC.cpp:70)
   double* o = out + (size_t)c * 2400;
   for (int b = tid; b < 1200; b += 512) {
     const unsigned int n = cnt[b];
-    double st = 0.0, iv = 0.0;
+    double st = 0.0, iv = MEAN ? -__builtin_inf() : 0.0;
     if (n) {
       st = dunkey(hi[b]) - dunkey(lo[b]);                                           // :74
-      iv = (sum[b] / (double)n) > ave ? 1.0 : 0.0;                                  // :69-70
+      iv = MEAN ? sum[b] / (double)n : ((sum[b] / (double)n) > ave ? 1.0 : 0.0);    // :69-70
     }
     o[b] = st;
     o[1200 + b] = iv;
@@ -564,7 +588,8 @@ void launch_cloud_frames(hipStream_t st, const double* xyz, const int64_t* offs,
 void launch_sc_bin(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double max_rho,
                    const double* frames, const float* ave, double* out) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(sc_bin_kernel, dim3(N), dim3(512), 0, st, xyz, inten, offs, frames, ave, max_rho, out);
+  if (ave) hipLaunchKernelGGL(sc_bin_kernel<false>, dim3(N), dim3(512), 0, st, xyz, inten, offs, frames, ave, max_rho, out);
+  else hipLaunchKernelGGL(sc_bin_kernel<true>, dim3(N), dim3(512), 0, st, xyz, inten, offs, frames, ave, max_rho, out);   // + launch_sc_finish
 }
 
 }  // namespace pr
