@@ -82,4 +82,61 @@ __host__ __device__ __forceinline__ void polar_bins16(double y, double x, double
   ri = (int)floor(sqrt(x * x + y * y) * R_res_inv);
 }
 
+// ---------------------------------------------------------------------------------------------------------------- M2DP projections in fp32
+// m2dp_bin_kernel evaluates 16 plane projections per point (M2DP.cpp:56-62).  The reference's fp64 dots xp = xProj.pt, yp = yProj.pt
+// only decide two integers, so the fast path takes them in fp32 as well - from the point and the plane vectors rounded to float - and the
+// accept test carries the dot's error on top of the classifier's own:
+//   |xpf - xp| <= 5 * 2^-24 * sum |p_i q_i|  (two operand roundings, three roundings of the fma chain)  <= 3e-7 * (|q0| + |q1| + |q2|)
+// because the plane vectors have components <= 1 (pr_api.cpp: xa - (xa.n) n and n x that).  With delta = 4e-7 * (|q0f| + |q1f| + |q2f|):
+//   sector: accepted when min(|x|,|y|), | min - tan(pi/8) max | and max - min are all above  2e-5 max + 2 delta + 1e-30
+//           (2 delta bounds the error of each of the three quantities; 2e-5 max covers the fp32 arithmetic of the test itself, ~2e-7 max);
+//   ring:   accepted when frac(r R) is within 0.5 - (2e-5 + 1.5 delta R) of 0.5  (|r_f - r| <= sqrt(2) delta + 1 ulp of v_sqrt_f32 and the
+//           products: < 2e-6 bins for r R < 16; larger r R only has to stay >= 8, the bins that are dropped).
+// Anything else - boundaries, zeros of either sign, NaN, overflow, denormals - evaluates the reference's fp64 expressions on the fp64 dot.
+// About 0.03 % of the projections take that path (0.7 % with the 1e-3 margins of polar_bins16, i.e. a third of all WAVES).
+struct PointF {
+  float q0, q1, q2;
+  float dq2;   // 2 delta + 1e-30
+  float hw;    // accepted half-width of frac(r R) around 0.5
+};
+__host__ __device__ __forceinline__ PointF make_pointf(double q0, double q1, double q2, float R_f) {
+  PointF p;
+  p.q0 = (float)q0; p.q1 = (float)q1; p.q2 = (float)q2;
+  const float delta = 4e-7f * ((fabsf(p.q0) + fabsf(p.q1)) + fabsf(p.q2));
+  p.dq2 = 2.f * delta + 1e-30f;
+  p.hw = 0.5f - (2e-5f + 1.5f * delta * R_f);
+  return p;
+}
+// pf: the plane's xProj[3], yProj[3] rounded to float.  Branch-free (the caller runs several projections side by side so that their
+// dependent chains overlap); returns false when the fast path cannot vouch for the bins - si, ri are then meaningless.
+__host__ __device__ __forceinline__ bool proj_bins16_fast(const PointF& pt, const float* pf, float R_f, int& si, int& ri) {
+  const float xf = fmaf(pf[0], pt.q0, fmaf(pf[1], pt.q1, pf[2] * pt.q2));
+  const float yf = fmaf(pf[3], pt.q0, fmaf(pf[4], pt.q1, pf[5] * pt.q2));
+  const float a = fabsf(xf), b = fabsf(yf);
+  const float mn = fminf(a, b), mx = fmaxf(a, b);
+  const float e = fmaf(2e-5f, mx, pt.dq2), t = 0.414213568f * mx;            // tan(pi/8)
+  const float d3 = fminf(fminf(mn, fabsf(mn - t)), mx - mn);
+#if defined(__HIP_DEVICE_COMPILE__)
+  const float r = __builtin_amdgcn_sqrtf(fmaf(xf, xf, yf * yf));
+#else
+  const float r = sqrtf(fmaf(xf, xf, yf * yf));
+#endif
+  const float tt = r * R_f, fl = floorf(tt), fr = tt - fl;
+  const bool ok = (d3 > e) & (fabsf(fr - 0.5f) < pt.hw) & (tt < 1e6f);
+  // (an accepted point has neither coordinate at zero, so the comparisons see the signs)
+  const unsigned idx = (yf < 0.f ? 8u : 0u) | (xf < 0.f ? 4u : 0u) | (b > a ? 2u : 0u) | (mn > t ? 1u : 0u);
+  constexpr unsigned TAB_YPOS = 0xDCEFAB98u, TAB_YNEG = 0x23105467u;        // the nibble table of polar_bins16, by the sign of y
+  si = (int)(((idx & 8u ? TAB_YNEG : TAB_YPOS) >> (4 * (idx & 7u))) & 15u);
+  ri = ok ? (int)fl : 0;                                                     // (the conversion of a huge / NaN fl is never used)
+  return ok;
+}
+// the reference's evaluation of one projection (M2DP.cpp:56-62; no zero seed: SURVEY.md H4 / N5).  Compile without fp contraction.
+__host__ __device__ __forceinline__ void proj_bins16_exact(double q0, double q1, double q2, const double* pl, double S_res_inv,
+                                                          double R_res_inv, int& si, int& ri) {
+  const double xp = pl[0] * q0 + (pl[1] * q1 + pl[2] * q2);
+  const double yp = pl[3] * q0 + (pl[4] * q1 + pl[5] * q2);
+  si = (int)floor((atan2(yp, xp) + M_PI) * S_res_inv);
+  ri = (int)floor(sqrt(xp * xp + yp * yp) * R_res_inv);
+}
+
 }  // namespace pr

@@ -42,7 +42,7 @@ __device__ inline void jacobi_eig3(double a[3][3], double v[3][3]) {
 // raw moments (sum p, sum p p^T) of a cloud of n points -> frame {mean[3], v0[3], v1[3], v2[3], 0, n, 0, 0}: scatter matrix
 // cov = sum pp^T - n mean mean^T (un-normalised as pts_align.h:30), 3x3 Jacobi, eigenvalues ascending (Eigen::SelfAdjointEigenSolver
 // order, :32-34), canonical signs (N3)
-__device__ inline void finish_frame(const double s[9], double n, double* f) {
+__device__ __attribute__((noinline)) inline void finish_frame(const double s[9], double n, double* f) {
   const double mx = s[0] / n, my = s[1] / n, mz = s[2] / n;
   double a[3][3], v[3][3];
   a[0][0] = s[3] - n * mx * mx; a[0][1] = s[4] - n * mx * my; a[0][2] = s[5] - n * mx * mz;
@@ -72,7 +72,7 @@ __device__ inline void finish_frame(const double s[9], double n, double* f) {
 
 // the fixed reduction tree of a moments pass: 64-lane shuffle tree per wave, then the waves in order; thread 0 writes the frame.
 // Every moments pass that feeds thread t the same points in the same order (cloud_frames_kernel, gather_frames_kernel) gives the same bits.
-__device__ inline void reduce_moments_to_frame(const double (&s)[9], double n, double (*red)[9] /* LDS [FRAME_THREADS / 64][9] */, double* frame) {
+__device__ __forceinline__ void reduce_moments_to_frame(const double (&s)[9], double n, double (*red)[9] /* LDS [FRAME_THREADS / 64][9] */, double* frame) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
 #pragma unroll
   for (int k = 0; k < 9; k++) {

@@ -14,6 +14,8 @@
 //               u = dominant column, then polished with u <- A(A^T u)/||.|| on the original matrix until the
 //               update is below 4e-15; v = A^T u / sigma.  Sign: sum(u) >= 0 (N6).  Zero matrix -> (e0, e0).
 // Bound: fp64 VALU / transcendental (256 P atan2 per cloud), not HBM and not MFMA.
+#include <type_traits>
+
 #include "fast_bins.hpp"
 #include "kernels.hpp"
 
@@ -23,28 +25,48 @@ namespace {
 constexpr int MAT = 64 * 128;
 
 // PPB planes per workgroup: 16 for throughput (every point is read by 16 workgroups of its cloud), 4 when there are few
-// clouds - a workgroup is ~100 instructions per (point, plane) on one wave per SIMD, 1.4 ms for 50k points x 16 planes,
-// and a small batch has nothing else to hide that behind.
+// clouds - a small batch has nothing else to hide a workgroup's ~50 instructions per (point, plane) behind.
+//
+// What the kernel's time is made of (MI355X, 128 clouds x 50 000 points, PPB = 4; tools/gen_only.py under rocprofv3):
+//   * the projections are classified in fp32 (fast_bins.hpp: proj_bins16_fast - the dots included, with a rigorous error budget in the
+//     accept test), NPT = 4 points side by side without control flow, the plane constants read once per NPT projections; the ~0.03 % it does
+//     not vouch for evaluate the reference's fp64 expressions behind ONE rare branch: 55 VALU instructions per projection (92 before);
+//   * the LDS atomics: a 64-bit LDS atomic costs what ~25 VALU instructions cost (5.6 ms with u32 count + f64 sum, 3.6 ms with neither), so
+//     the FAST mode adds ONE u64 per projection: count << 47 | intensity in fixed point.  The scale comes from the cloud's float average
+//     (2^s with 2 ave P 2^s < 2^46), every point's intensity is rounded to that grid once, and the epilogue decides mean > ave
+//     (M2DP.cpp:84-91) from the fixed-point sum only where it is certain: | sum - n ave | above the accumulated rounding (n/2 grid steps)
+//     plus the fp64 slack of the reference's own sum and division.  Anything else - an uncertain bin (probability ~1e-9 per bin), a
+//     negative / non-finite / huge intensity, a sum that does not fit 47 bits, a cloud of 2^17 points or more - reruns the workgroup in the
+//     EXACT mode: u32 count + f64 sum per projection as before.  The counts are exact in both modes.
 template <int PPB>
 __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict__ xyz, const float* __restrict__ inten,
                                                         const int64_t* __restrict__ offs, const double* __restrict__ frames,
                                                         const float* __restrict__ ave_in,
                                                         const double* __restrict__ planes, double max_rho, int c0,
                                                         double* __restrict__ mats) {
-  __shared__ unsigned int cnt[PPB * 128];
-  __shared__ double isum[PPB * 128];
+  constexpr int NB = PPB * 128, SPARE = 32;     // + spare bins: dropped projections and padding lanes add there instead of branching
+  __shared__ unsigned long long acc[NB + SPARE];   // FAST: count << 47 | fixed-point sum;  EXACT: the f64 sums (same storage)
+  __shared__ unsigned int cnt[NB + SPARE];         // EXACT: counts
   __shared__ double pl[PPB][6];
+  __shared__ __attribute__((aligned(16))) float plf[PPB][8];   // the same rounded to float (fast classifier), padded to two 16-byte reads
+  __shared__ unsigned long long wtot[4];
+  __shared__ int need_exact;
+  double* isum = reinterpret_cast<double*>(acc);
   constexpr int NPG = 64 / PPB;              // plane groups per (cloud, variant)
+  constexpr int NPT = 4;                     // points per thread and round
   const int tid = threadIdx.x;
   const int pg = blockIdx.x % NPG, var = (blockIdx.x / NPG) & 3, cl = blockIdx.x / (4 * NPG);
   const int c = c0 + cl;
   const int64_t o0 = offs[c];
   const int64_t P = offs[c + 1] - o0;
-  for (int b = tid; b < PPB * 128; b += 256) { cnt[b] = 0u; isum[b] = 0.0; }
+  for (int b = tid; b < NB + SPARE; b += 256) acc[b] = 0ull;
   if (tid < PPB * 6) {
     const int k = tid / 6, a = tid % 6;
-    pl[k][a] = (a < 3) ? planes[(pg * PPB + k) * 3 + a] : planes[64 * 3 + (pg * PPB + k) * 3 + (a - 3)];
+    const double v = (a < 3) ? planes[(pg * PPB + k) * 3 + a] : planes[64 * 3 + (pg * PPB + k) * 3 + (a - 3)];
+    pl[k][a] = v;
+    plf[k][a] = (float)v;
   }
+  if (tid == 0) need_exact = 0;
   __syncthreads();
   const double* f = frames + (size_t)c * 16;
   const double mx = f[0], my = f[1], mz = f[2];
@@ -55,29 +77,119 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
   const float R_f = (float)R_res_inv;
   const double* p = xyz + 3 * o0;
   const float* it = inten + o0;
-  for (int64_t i = tid; i < P; i += 256) {
-    const double x = p[3 * i] - mx, y = p[3 * i + 1] - my, z = p[3 * i + 2] - mz;
-    const double q0 = dx * ((x * e00 + y * e01) + z * e02);
-    const double q1 = dy * ((x * e10 + y * e11) + z * e12);
-    const double q2 = dz * ((x * e20 + y * e21) + z * e22);
-    const double iv = (double)it[i];
-#pragma unroll 4
-    for (int k = 0; k < PPB; k++) {
-      const double xp = pl[k][0] * q0 + (pl[k][1] * q1 + pl[k][2] * q2);   // M2DP.cpp:56
-      const double yp = pl[k][3] * q0 + (pl[k][4] * q1 + pl[k][5] * q2);   // :57
-      int si, ri;   // floor((atan2(yp, xp) + pi) * S_res_inv), floor(sqrt(xp^2 + yp^2) * R_res_inv): M2DP.cpp:59-61
-      polar_bins16(yp, xp, S_res_inv, R_res_inv, R_f, si, ri);
-      const int idx = ri * 16 + si;
-      if (idx >= 128 || idx < 0) continue;
-      atomicAdd(&cnt[k * 128 + idx], 1u);
-      atomicAdd(&isum[k * 128 + idx], iv);
-    }
+  const double ave = (double)ave_in[c];      // the float average, widened (double > float promotes the float, M2DP.cpp:88)
+  // fixed-point grid of the FAST mode: 2^-s with (2 ave P) 2^s < 2^46
+  bool fast = P < (1 << 17) && ave >= 0.0 && ave < 1e300;
+  double scale = 1.0, inv_scale = 1.0;
+  if (fast) {
+    int e;
+    (void)frexp(2.0 * ave * (double)P + 1e-300, &e);
+    int sh = 46 - e;
+    sh = sh > 1000 ? 1000 : sh;
+    scale = ldexp(1.0, sh);
+    inv_scale = ldexp(1.0, -sh);
   }
-  __syncthreads();
-  const double ave = (double)ave_in[c];
+  // one pass over the cloud; FAST selects the accumulation
+  auto bin_points = [&](auto fast_tag) {
+    constexpr bool FAST = decltype(fast_tag)::value;
+    unsigned long long ltot = 0ull;
+    bool bad = false;
+    // (lane = consecutive point: coalesced loads.  The clouds of the reference's pipeline arrive in unordered_map iteration order, i.e.
+    // shuffled, so the 64 lanes of an LDS atomic spread over the bins; a spatially sorted cloud serialises them on a few addresses.)
+    for (int64_t i0 = tid; i0 < P; i0 += 256 * NPT) {
+      double q[NPT][3], iv[NPT];
+      unsigned long long fx[NPT];
+      PointF pt[NPT];
+      bool live[NPT];
+#pragma unroll
+      for (int u = 0; u < NPT; u++) {
+        const int64_t i = i0 + 256 * u;
+        live[u] = i < P;
+        const int64_t j = live[u] ? i : i0;
+        const double x = p[3 * j] - mx, y = p[3 * j + 1] - my, z = p[3 * j + 2] - mz;
+        q[u][0] = dx * ((x * e00 + y * e01) + z * e02);
+        q[u][1] = dy * ((x * e10 + y * e11) + z * e12);
+        q[u][2] = dz * ((x * e20 + y * e21) + z * e22);
+        iv[u] = (double)it[j];
+        pt[u] = make_pointf(q[u][0], q[u][1], q[u][2], R_f);
+        fx[u] = 0ull;
+        if constexpr (FAST) {
+          const double g = rint(iv[u] * scale);
+          const bool okv = g >= 0.0 && g < 0x1p46;                 // (NaN fails)
+          bad |= live[u] && !okv;
+          fx[u] = (live[u] && okv) ? (unsigned long long)g : 0ull;
+          ltot += fx[u];
+        }
+      }
+#pragma unroll 2
+      for (int k = 0; k < PPB; k++) {
+        float pf[8];
+        *reinterpret_cast<float4*>(pf) = *reinterpret_cast<const float4*>(&plf[k][0]);
+        *reinterpret_cast<float4*>(pf + 4) = *reinterpret_cast<const float4*>(&plf[k][4]);
+        // the NPT projections side by side: floor((atan2(yp, xp) + pi) * S_res_inv), floor(sqrt(xp^2 + yp^2) * R_res_inv) (M2DP.cpp:56-61)
+        // from the fp32 classifier; one rare branch for whatever it does not vouch for
+        int si[NPT], ri[NPT];
+        bool ok[NPT];
+#pragma unroll
+        for (int u = 0; u < NPT; u++) ok[u] = proj_bins16_fast(pt[u], pf, R_f, si[u], ri[u]);
+        bool all_ok = true;
+#pragma unroll
+        for (int u = 0; u < NPT; u++) all_ok &= ok[u];
+        if (!all_ok) {
+#pragma unroll
+          for (int u = 0; u < NPT; u++)
+            if (!ok[u]) proj_bins16_exact(q[u][0], q[u][1], q[u][2], pl[k], S_res_inv, R_res_inv, si[u], ri[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NPT; u++) {
+          const int idx = ri[u] * 16 + si[u];
+          const int slot = ((unsigned)idx < 128u && live[u]) ? k * 128 + idx : NB + (tid & (SPARE - 1));   // dropped: M2DP.cpp:66-68
+          if constexpr (FAST) atomicAdd(&acc[slot], (1ull << 47) + fx[u]);
+          else { atomicAdd(&cnt[slot], 1u); atomicAdd(&isum[slot], iv[u]); }
+        }
+      }
+    }
+    if constexpr (FAST) {
+      // the workgroup's total of the fixed-point values bounds every bin's sum: it has to fit the 47-bit field
+      for (int d = 32; d > 0; d >>= 1) ltot += __shfl_down(ltot, d);
+      if ((tid & 63) == 0) wtot[tid >> 6] = ltot;
+      if (bad) need_exact = 1;
+    }
+  };
   double* mc = mats + (((size_t)cl * 4 + var) * 2) * MAT + (size_t)pg * PPB * 128;
   double* mi = mc + MAT;
-  for (int b = tid; b < PPB * 128; b += 256) {
+  if (fast) {
+    bin_points(std::true_type{});
+    __syncthreads();
+    if (tid == 0 && ((wtot[0] + wtot[1]) + (wtot[2] + wtot[3])) >= (1ull << 47)) need_exact = 1;
+    // certain decisions only: | sum - n ave | against n/2 grid steps of rounding + the fp64 slack of the reference's sum and division
+    bool unsure = false;
+    for (int b = tid; b < NB; b += 256) {
+      const unsigned long long v = acc[b];
+      const double n = (double)(v >> 47), sd = (double)(v & ((1ull << 47) - 1ull)) * inv_scale;
+      const double diff = sd - n * ave, margin = n * inv_scale + (n + 4.0) * 0x1p-51 * (sd + n * ave);
+      unsure |= (n > 0.0) && !(fabs(diff) > margin);
+    }
+    if (unsure) need_exact = 1;
+    __syncthreads();
+    fast = need_exact == 0;
+    if (fast) {
+      for (int b = tid; b < NB; b += 256) {
+        const unsigned long long v = acc[b];
+        const double n = (double)(v >> 47), sd = (double)(v & ((1ull << 47) - 1ull)) * inv_scale;
+        mc[b] = n;
+        mi[b] = (n > 0.0 && sd > n * ave) ? 1.0 : 0.0;
+      }
+      return;
+    }
+    __syncthreads();
+    for (int b = tid; b < NB + SPARE; b += 256) acc[b] = 0ull;
+  }
+  for (int b = tid; b < NB + SPARE; b += 256) cnt[b] = 0u;
+  __syncthreads();
+  bin_points(std::false_type{});
+  __syncthreads();
+  for (int b = tid; b < NB; b += 256) {
     const unsigned int n = cnt[b];
     mc[b] = (double)n;
     mi[b] = n ? ((isum[b] / (double)n) > ave ? 1.0 : 0.0) : 0.0;

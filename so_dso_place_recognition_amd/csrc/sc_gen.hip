@@ -41,9 +41,8 @@ constexpr int CPW = 8;
 constexpr int ACH = 512;                     // floats per cloud and round
 __global__ __launch_bounds__(64) void ave_chain_kernel(const float* __restrict__ inten, const int64_t* __restrict__ offs,
                                                         int N, float* __restrict__ ave_out) {
-  // rows of ACH + 4 floats: the eight adding lanes read eight different bank groups; + 32 floats: the read-ahead of the last block stays inside
-  __shared__ __attribute__((aligned(16))) float bufs[CPW * (ACH + 4) + 32];
-  float (*buf)[ACH + 4] = reinterpret_cast<float (*)[ACH + 4]>(bufs);
+  // rows of ACH + 4 floats: the eight adding lanes read eight different bank groups; one more row: the read-ahead of the last block stays inside
+  __shared__ __attribute__((aligned(16))) float buf[CPW + 1][ACH + 4];
   typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
   typedef float f4a __attribute__((ext_vector_type(4)));
   // the chain is the critical path of a generate call and shares its CU with the waves of the moments / binning pass: issue priority

@@ -243,6 +243,28 @@ def test_m2dp_generate_vs_oracle(api, golden_dir):
     assert len(api.m2dp_svd_rows()) == 0 and not (api.default_context().take_warnings() & 2)
 
 
+def test_m2dp_generate_intensity_accumulation_modes_vs_oracle(api):
+    """m2dp_bin accumulates count and intensity of a projection in ONE 64-bit LDS atomic (fixed point on a per-cloud grid) and reruns a
+    workgroup with the exact u32 + f64 accumulation whenever that cannot be vouched for: negative intensities, values far below the
+    grid, all-zero clouds, clouds of 2^17 points or more.  Every case must give the oracle's signature."""
+    rng = np.random.default_rng(23)
+    clouds = []
+    def cloud(P, inten):
+        xyz = rng.normal(0, [14, 4, 9], (P, 3))
+        clouds.append((xyz, np.asarray(inten, np.float32)))
+    cloud(3000, rng.random(3000) * 255)                               # the fast mode
+    cloud(3000, rng.normal(0, 30, 3000))                              # negative values: exact mode
+    cloud(2500, np.zeros(2500))                                       # float average 0
+    cloud(2500, np.where(rng.random(2500) < 0.5, 1e-30, 80.0))        # values far below the fixed-point grid
+    cloud(2000, np.full(2000, 3e37))                                  # the float running sum overflows to inf: average inf
+    cloud((1 << 17) + 77, rng.random((1 << 17) + 77))                 # the count field (17 bits) cannot hold the cloud
+    cloud(1, [5.0])
+    xyz, it, offs = api._csr(clouds)
+    o = oracle_lib.m2dp_generate(xyz, it, offs)
+    g = api.m2dp_generate(xyz, it, offs)
+    assert g.shape == o.shape and np.abs(g - o).max() < 1e-9
+
+
 def test_generators_with_caller_frames_equal_the_two_pass_calls(api):
     """pr_cloud_frames_dev + pr_*_generate_frames_dev (binning pass only) give the bits of pr_*_generate_dev, ragged sizes and an empty cloud
     included; the frames themselves hold mean, an orthonormal right-handed basis and the point count."""
