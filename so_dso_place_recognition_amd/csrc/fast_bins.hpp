@@ -123,11 +123,19 @@ __host__ __device__ __forceinline__ bool proj_bins16_fast(const PointF& pt, cons
 #endif
   const float tt = r * R_f, fl = floorf(tt), fr = tt - fl;
   const bool ok = (d3 > e) & (fabsf(fr - 0.5f) < pt.hw) & (tt < 1e6f);
-  // (an accepted point has neither coordinate at zero, so the comparisons see the signs)
-  const unsigned idx = (yf < 0.f ? 8u : 0u) | (xf < 0.f ? 4u : 0u) | (b > a ? 2u : 0u) | (mn > t ? 1u : 0u);
-  constexpr unsigned TAB_YPOS = 0xDCEFAB98u, TAB_YNEG = 0x23105467u;        // the nibble table of polar_bins16, by the sign of y
-  si = (int)(((idx & 8u ? TAB_YNEG : TAB_YPOS) >> (4 * (idx & 7u))) & 15u);
-  ri = ok ? (int)fl : 0;                                                     // (the conversion of a huge / NaN fl is never used)
+  // Sector: sign bits instead of comparisons (an accepted point has neither coordinate, nor a - b, nor mn - t at zero):
+  //   shift = 16 [x < 0] + 8 [|y| > |x|] + 4 [min < max tan(pi/8)], table by the sign of y - the nibble table of polar_bins16 with the
+  //   entries of each pair exchanged (its last index bit is min > max tan(pi/8))
+  const unsigned sx = __builtin_bit_cast(unsigned, xf) >> 31, sab = __builtin_bit_cast(unsigned, a - b) >> 31,
+                 smt = __builtin_bit_cast(unsigned, mn - t) >> 31;
+  const unsigned sh = (((sx << 1 | sab) << 1) | smt) << 2;
+  constexpr unsigned TAB_YPOS = 0xCDFEBA89u, TAB_YNEG = 0x32014576u;
+  si = (int)((((int)__builtin_bit_cast(unsigned, yf) < 0 ? TAB_YNEG : TAB_YPOS) >> sh) & 15u);
+#if defined(__HIP_DEVICE_COMPILE__)
+  ri = (int)fl;                                  // (v_cvt_i32_f32 saturates; a rejected projection's ri is never used)
+#else
+  ri = ok ? (int)fl : 0;
+#endif
   return ok;
 }
 // the reference's evaluation of one projection (M2DP.cpp:56-62; no zero seed: SURVEY.md H4 / N5).  Compile without fp contraction.

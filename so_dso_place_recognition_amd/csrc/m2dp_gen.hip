@@ -96,8 +96,16 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
     bool bad = false;
     // (lane = consecutive point: coalesced loads.  The clouds of the reference's pipeline arrive in unordered_map iteration order, i.e.
     // shuffled, so the 64 lanes of an LDS atomic spread over the bins; a spatially sorted cloud serialises them on a few addresses.)
+    // the aligned point in fp64 (pts_align.h:24-39, test_m2dp.cpp:52-56); not kept in registers across the plane loop - the rare exact
+    // evaluation of a projection computes it again from memory (the same expressions, the same bits)
+    auto aligned = [&](int64_t j, double (&q)[3]) {
+      const double x = p[3 * j] - mx, y = p[3 * j + 1] - my, z = p[3 * j + 2] - mz;
+      q[0] = dx * ((x * e00 + y * e01) + z * e02);
+      q[1] = dy * ((x * e10 + y * e11) + z * e12);
+      q[2] = dz * ((x * e20 + y * e21) + z * e22);
+    };
     for (int64_t i0 = tid; i0 < P; i0 += 256 * NPT) {
-      double q[NPT][3], iv[NPT];
+      double iv[NPT];
       unsigned long long fx[NPT];
       PointF pt[NPT];
       bool live[NPT];
@@ -106,19 +114,18 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
         const int64_t i = i0 + 256 * u;
         live[u] = i < P;
         const int64_t j = live[u] ? i : i0;
-        const double x = p[3 * j] - mx, y = p[3 * j + 1] - my, z = p[3 * j + 2] - mz;
-        q[u][0] = dx * ((x * e00 + y * e01) + z * e02);
-        q[u][1] = dy * ((x * e10 + y * e11) + z * e12);
-        q[u][2] = dz * ((x * e20 + y * e21) + z * e22);
+        double q[3];
+        aligned(j, q);
         iv[u] = (double)it[j];
-        pt[u] = make_pointf(q[u][0], q[u][1], q[u][2], R_f);
+        pt[u] = make_pointf(q[0], q[1], q[2], R_f);
         fx[u] = 0ull;
         if constexpr (FAST) {
           const double g = rint(iv[u] * scale);
           const bool okv = g >= 0.0 && g < 0x1p46;                 // (NaN fails)
           bad |= live[u] && !okv;
-          fx[u] = (live[u] && okv) ? (unsigned long long)g : 0ull;
-          ltot += fx[u];
+          const unsigned long long gv = (live[u] && okv) ? (unsigned long long)g : 0ull;
+          ltot += gv;
+          fx[u] = live[u] ? (1ull << 47) + gv : 0ull;              // what a projection of this point adds (a padding lane: nothing)
         }
       }
 #pragma unroll 2
@@ -138,14 +145,23 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
         if (!all_ok) {
 #pragma unroll
           for (int u = 0; u < NPT; u++)
-            if (!ok[u]) proj_bins16_exact(q[u][0], q[u][1], q[u][2], pl[k], S_res_inv, R_res_inv, si[u], ri[u]);
+            if (!ok[u]) {
+              double q[3];
+              aligned((i0 + 256 * u < P) ? i0 + 256 * u : i0, q);
+              proj_bins16_exact(q[0], q[1], q[2], pl[k], S_res_inv, R_res_inv, si[u], ri[u]);
+            }
         }
 #pragma unroll
         for (int u = 0; u < NPT; u++) {
           const int idx = ri[u] * 16 + si[u];
-          const int slot = ((unsigned)idx < 128u && live[u]) ? k * 128 + idx : NB + (tid & (SPARE - 1));   // dropped: M2DP.cpp:66-68
-          if constexpr (FAST) atomicAdd(&acc[slot], (1ull << 47) + fx[u]);
-          else { atomicAdd(&cnt[slot], 1u); atomicAdd(&isum[slot], iv[u]); }
+          if constexpr (FAST) {
+            const int slot = ((unsigned)idx < 128u) ? k * 128 + idx : NB + (tid & (SPARE - 1));               // dropped: M2DP.cpp:66-68
+            atomicAdd(&acc[slot], fx[u]);
+          } else {
+            const int slot = ((unsigned)idx < 128u && live[u]) ? k * 128 + idx : NB + (tid & (SPARE - 1));
+            atomicAdd(&cnt[slot], 1u);
+            atomicAdd(&isum[slot], iv[u]);
+          }
         }
       }
     }
