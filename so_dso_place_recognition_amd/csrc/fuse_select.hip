@@ -143,7 +143,92 @@ __device__ __forceinline__ void block_argmin(double* rv, int* rj, int tid) {
   __syncthreads();
 }
 
-constexpr int FS_CAP = 4096;   // survivors of the threshold pass kept in LDS (a power of two: the list is bitonic-sorted for large k)
+constexpr int FS_CAP = 4096;   // survivors of the threshold pass kept in LDS (a power of two: the fallback of list_topk sorts it whole)
+constexpr int NONE_J = 0x7fffffff;   // index of a padding entry (value +Inf): sorts behind every real candidate
+
+__device__ __forceinline__ unsigned long long order_key(double x) {   // order-preserving map double -> u64 (no NaN in the lists)
+  const unsigned long long b = (unsigned long long)__double_as_longlong(x + 0.0);   // (-0 + 0 = +0: the two zeros are one value)
+  return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+
+// The k smallest (value, index) pairs of the LDS list lv / lj[0, L), k <= 249, into rv / rj[0, k) in ascending order (rj = NONE_J where the
+// list runs out), WITHOUT sorting the list: a most-significant-digit radix selection over the values' order keys (8 bits per pass, LDS
+// histogram, one wave picks the bucket that holds rank k) narrows the candidates until at most 256 elements are at or below the bucket -
+// three passes for scores that differ - and only those are sorted (bitonic network over 256, one compare-exchange per thread and step).
+// A full bitonic sort of 4096 fp64 pairs is 78 steps of 2048 compare-exchanges: 56 us per workgroup against ~4 for this.
+// Returns false when more than 256 elements tie around rank k down to the last digit (masses of equal scores): the caller sorts the whole list.
+template <typename V>
+__device__ bool list_topk(const V* lv, const int* lj, int L, int k, double* rv, int* rj, unsigned* hist, int* ctl, int tid) {
+  int C = L;
+  if (L > 256) {
+    unsigned long long prefix = 0ull;
+    int krem = k, below_total = 0, shd = -1;
+    for (int d = 0; d < 8 && shd < 0; d++) {
+      const int sh = 56 - 8 * d;
+      hist[tid] = 0u;
+      __syncthreads();
+      for (int s = tid; s < L; s += 256) {
+        const unsigned long long key = order_key((double)lv[s]);
+        if (d == 0 || (key >> (sh + 8)) == prefix) atomicAdd(&hist[(key >> sh) & 255ull], 1u);
+      }
+      __syncthreads();
+      if (tid < 64) {                                  // the bucket that holds rank krem: 4 buckets per lane, inclusive scan over the lanes
+        const unsigned c0 = hist[4 * tid], c1 = hist[4 * tid + 1], c2 = hist[4 * tid + 2], c3 = hist[4 * tid + 3];
+        const unsigned own = (c0 + c1) + (c2 + c3);
+        unsigned incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned up = __shfl_up(incl, o, 64);
+          if (tid >= o) incl += up;
+        }
+        const unsigned excl = incl - own;
+        if (excl < (unsigned)krem && (unsigned)krem <= incl) {
+          unsigned b = excl;
+          int bin = 4 * tid;
+          unsigned cb = c0;
+          if (b + c0 < (unsigned)krem) { b += c0; bin++; cb = c1;
+            if (b + c1 < (unsigned)krem) { b += c1; bin++; cb = c2;
+              if (b + c2 < (unsigned)krem) { b += c2; bin++; cb = c3; } } }
+          ctl[0] = bin; ctl[1] = (int)b; ctl[2] = (int)cb;
+        }
+      }
+      __syncthreads();
+      prefix = (prefix << 8) | (unsigned long long)ctl[0];
+      below_total += ctl[1];
+      krem -= ctl[1];
+      if (below_total + ctl[2] <= 256) shd = sh;
+      __syncthreads();
+    }
+    if (shd < 0) return false;
+    if (tid == 0) ctl[3] = 0;
+    __syncthreads();
+    for (int s = tid; s < L; s += 256) {
+      const double v = (double)lv[s];
+      if ((order_key(v) >> shd) <= prefix) {
+        const int slot = atomicAdd(&ctl[3], 1);
+        rv[slot] = v; rj[slot] = lj[s];
+      }
+    }
+    __syncthreads();
+    C = ctl[3];
+  } else {
+    if (tid < L) { rv[tid] = (double)lv[tid]; rj[tid] = lj[tid]; }
+  }
+  if (tid >= C) { rv[tid] = __builtin_inf(); rj[tid] = NONE_J; }
+  __syncthreads();
+  for (int size = 2; size <= 256; size <<= 1)
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      if (tid < 128) {
+        const int pos = 2 * tid - (tid & (stride - 1)), par = pos + stride;
+        const bool up = (pos & size) == 0;
+        const double a = rv[pos], b = rv[par];
+        const int aj = rj[pos], bj = rj[par];
+        if (cand_less(b, bj, a, aj) == up) { rv[pos] = b; rj[pos] = bj; rv[par] = a; rj[par] = aj; }
+      }
+      __syncthreads();
+    }
+  return true;
+}
 
 // e_p / e_i / mom2_all: an optional SECOND channel pair over the same (query, entry) grid whose z-scores are added with the
 // same weights (BASELINE.json config 5, "fused SC + M2DP scoring": build-defined, no reference counterpart).
@@ -170,6 +255,8 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   __shared__ double lv[FS_CAP];
   __shared__ int lj[FS_CAP];
   __shared__ int lcnt;
+  __shared__ unsigned hist[256];
+  __shared__ int ctl[4];
   const int tid = threadIdx.x, q = blockIdx.x;
   const bool plain = (d_i == nullptr);   // single distance matrix, no z-score fusion (run_test.m types other than m2dp/sc)
   const bool two = (e_p != nullptr);
@@ -290,19 +377,32 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
     }
   }
   // ---- (b) everything at or below tau
-  sweep([&](int j, double f) {
-    if (f <= tau) {
-      const int slot = atomicAdd(&lcnt, 1);
-      if (slot < FS_CAP) { lv[slot] = f; lj[slot] = db_row0 + j; }
-    }
-  });
+  const bool whole = k > 12 && n <= FS_CAP && !(tau < __builtin_inf());   // a slice that fits: element j IS list entry j (NaN: padding)
+  if (whole)
+    sweep([&](int j, double f) {
+      const bool ok = f == f;
+      lv[j] = ok ? f : __builtin_inf();
+      lj[j] = ok ? db_row0 + j : NONE_J;
+    });
+  else
+    sweep([&](int j, double f) {
+      if (f <= tau) {
+        const int slot = atomicAdd(&lcnt, 1);
+        if (slot < FS_CAP) { lv[slot] = f; lj[slot] = db_row0 + j; }
+      }
+    });
   __syncthreads();
-  const int L = lcnt;
+  const int L = whole ? n : lcnt;
   if (L <= FS_CAP && k > 12) {
-    // many results: sort the list once (bitonic network over the next power of two, (+Inf, INT_MAX) padding) instead of k arg-min rounds
+    // many results: the k best of the list by radix selection + a 256-entry sort ...
+    if (list_topk(lv, lj, L, k, rv, rj, hist, ctl, tid)) {
+      for (int t = tid; t < k; t += 256) emit(t, rv[t], rj[t] == NONE_J ? -1 : rj[t]);
+      return;
+    }
+    // ... or, when too many entries tie around rank k, by sorting it whole (bitonic network over the next power of two, (+Inf, NONE_J) padding)
     int N = 2;
     while (N < L) N <<= 1;
-    for (int s = L + tid; s < N; s += 256) { lv[s] = __builtin_inf(); lj[s] = 0x7fffffff; }
+    for (int s = L + tid; s < N; s += 256) { lv[s] = __builtin_inf(); lj[s] = NONE_J; }
     __syncthreads();
     for (int size = 2; size <= N; size <<= 1)
       for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -315,7 +415,7 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
         }
         __syncthreads();
       }
-    for (int t = tid; t < k; t += 256) emit(t, lv[t < L ? t : 0], t < L ? lj[t] : -1);
+    for (int t = tid; t < k; t += 256) emit(t, lv[t < L ? t : 0], (t < L && lj[t] != NONE_J) ? lj[t] : -1);
     return;
   }
   if (L <= FS_CAP) {
@@ -373,15 +473,27 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restr
   while (N < T) N <<= 1;
   float* lv = reinterpret_cast<float*>(smem);
   int* lj = reinterpret_cast<int*>(smem) + N;
+  __shared__ double rv[256];
+  __shared__ int rj[256];
+  __shared__ unsigned hist[256];
+  __shared__ int ctl[4];
   for (int s = tid; s < N; s += 256) {
     int j = -1;
     float v = 0.f;
     if (s < T) { const size_t o = ((size_t)(s / k) * m + q) * k + (s % k); j = sidx[o]; v = sscore[o]; }
     const bool ok = j >= 0 && v == v;
     lv[s] = ok ? v : __builtin_inff();
-    lj[s] = ok ? j : 0x7fffffff;
+    lj[s] = ok ? j : NONE_J;
   }
   __syncthreads();
+  if (k <= 249 && list_topk(lv, lj, T, k, rv, rj, hist, ctl, tid)) {      // radix selection + a 256-entry sort (see list_topk)
+    for (int t = tid; t < k; t += 256) {
+      const bool ok = rj[t] != NONE_J;
+      idx[(size_t)q * k + t] = ok ? rj[t] : -1;
+      score[(size_t)q * k + t] = ok ? (float)rv[t] : __builtin_nanf("");
+    }
+    return;
+  }
   for (int size = 2; size <= N; size <<= 1)
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
       for (int i = tid; i < (N >> 1); i += 256) {
@@ -394,7 +506,7 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restr
       __syncthreads();
     }
   for (int t = tid; t < k; t += 256) {
-    const bool ok = lj[t] != 0x7fffffff;
+    const bool ok = lj[t] != NONE_J;
     idx[(size_t)q * k + t] = ok ? lj[t] : -1;
     score[(size_t)q * k + t] = ok ? lv[t] : __builtin_nanf("");
   }

@@ -310,6 +310,43 @@ __global__ __launch_bounds__(64) void rerank_sort_kernel(const int32_t* __restri
            score32 ? score32 + (size_t)q * k : nullptr);
 }
 
+// The same with one WAVE per query (few query rows - an online call: one thread walking its 57 candidates alone is 16 us of load latency):
+// lane l holds candidates l and l + 64, k rounds of a wave arg-min by cand_before with the winner retired.
+__global__ __launch_bounds__(64) void rerank_sort_wave_kernel(const int32_t* __restrict__ idx_in, const double* __restrict__ cand_score,
+                                                               int m, int kin, int k, int32_t* __restrict__ idx, double* __restrict__ score,
+                                                               float* __restrict__ score32) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  double v[2];
+  int j[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int c = lane + 64 * h;
+    j[h] = c < kin ? idx_in[(size_t)q * kin + c] : -1;
+    v[h] = c < kin ? cand_score[(size_t)q * kin + c] : __builtin_nan("");
+  }
+  for (int t = 0; t < k; t++) {
+    const bool first = cand_before(v[0], j[0], v[1], j[1]) || !cand_before(v[1], j[1], v[0], j[0]);
+    double bv = first ? v[0] : v[1];
+    int bj = first ? j[0] : j[1];
+    int bc = lane + (first ? 0 : 64);                       // the candidate's position: retires exactly one entry even among equal bad ones
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const double ov = __shfl_xor(bv, s, 64);
+      const int oj = __shfl_xor(bj, s, 64), oc = __shfl_xor(bc, s, 64);
+      if (cand_before(ov, oj, bv, bj) || (!cand_before(bv, bj, ov, oj) && oc < bc)) { bv = ov; bj = oj; bc = oc; }
+    }
+    const bool ok = bj >= 0 && bv == bv;
+    if (lane == 0) {
+      idx[(size_t)q * k + t] = ok ? bj : -1;
+      const double o = ok ? bv : __builtin_nan("");
+      if (score) score[(size_t)q * k + t] = o;
+      if (score32) score32[(size_t)q * k + t] = (float)o;
+    }
+    if (bc == lane) { j[0] = -1; v[0] = __builtin_nan(""); }
+    if (bc == lane + 64) { j[1] = -1; v[1] = __builtin_nan(""); }
+  }
+}
+
 // cand_idx [m][kin] + the partial evaluations of G shards [G][m][kin] (NaN where the candidate is not the shard's) -> the k best.
 // Every candidate has exactly one owner; a masked pair is +Inf at its owner.
 __global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __restrict__ cand_idx, const double* __restrict__ part_all,
@@ -380,7 +417,10 @@ void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_d
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
                eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0};
   hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
-  hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
+  if (m <= 64 && kin <= 128)
+    hipLaunchKernelGGL(rerank_sort_wave_kernel, dim3(m), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
+  else
+    hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
 }
 
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,

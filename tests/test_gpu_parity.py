@@ -105,6 +105,41 @@ def test_fuse_select_rows_not_coaligned(api):
         ctx.close()
 
 
+@pytest.mark.parametrize("m,n,k", [(2, 100_000, 57), (1, 100_000, 128), (40, 30_000, 57), (3, 5000, 100), (5, 300, 20)])
+@pytest.mark.parametrize("flavour", ["distinct", "ties", "mass_ties"])
+def test_selection_of_many_candidates_by_radix_select(api, m, n, k, flavour):
+    """k > 12: the k best (value, index) pairs of a row come from a radix selection over the LDS list + a 256-entry sort (list_topk) - in the
+    row kernel, in the slice kernels of few-row calls (grid m x P) and in their merge.  Plain selection (no fusion) against numpy's stable
+    order: distinct values, ties that the index has to break, more than 256 equal values around rank k (the whole-list sort fallback), NaN
+    (never wins), +Inf, both zeros."""
+    import ctypes as C
+    import torch
+    rng = np.random.default_rng(m * 1000 + k)
+    d = rng.normal(0, 1, (m, n)).astype(np.float32)
+    if flavour == "ties":
+        d = np.round(d * 200) / 200                                  # ~1400 distinct values, dozens of equal entries each
+        d[:, ::7][d[:, ::7] == 0] = -0.0
+    if flavour == "mass_ties":
+        d = np.round(d * 2) / 2                                      # a dozen distinct values: thousands tie at the k-th
+    d[:, 5] = np.nan; d[:, n // 2] = np.inf; d[0, 11] = -np.inf
+    if m > 1:
+        d[1, : n - 3] = np.nan                                       # a row with fewer candidates than k
+    ctx = api.Context(0)
+    a = torch.from_numpy(d).cuda()
+    idx = torch.empty((m, k), dtype=torch.int32, device="cuda"); sc = torch.empty((m, k), dtype=torch.float32, device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    ctx.check(ctx.lib.pr_fuse_select_dev(ctx.h, P(a), None, m, n, None, 1, 0, 0, 0, 2.0, k, P(idx), P(sc)))
+    ctx.sync()
+    got_i, got_s = idx.cpu().numpy(), sc.cpu().numpy()
+    for r in range(m):
+        ok = np.nonzero(~np.isnan(d[r]))[0]
+        order = ok[np.argsort(d[r, ok], kind="stable")][:k]          # ties -> the lower index (MATLAB min, run_test.m:57)
+        want = np.full(k, -1); want[: len(order)] = order
+        assert np.array_equal(got_i[r], want), (r, got_i[r][:8], want[:8])
+        assert np.array_equal(got_s[r, : len(order)], d[r, order]) and np.isnan(got_s[r, len(order):]).all()
+    ctx.close()
+
+
 # ------------------------------------------------------------------------------------------------ a7
 @pytest.mark.parametrize("m,n", [(1, 2), (9, 40), (33, 130)])
 def test_m2dp_distance_vs_oracle(api, m, n):
