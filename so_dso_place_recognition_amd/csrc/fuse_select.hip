@@ -377,7 +377,7 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
     }
   }
   // ---- (b) everything at or below tau
-  const bool whole = k > 12 && n <= FS_CAP && !(tau < __builtin_inf());   // a slice that fits: element j IS list entry j (NaN: padding)
+  const bool whole = n <= FS_CAP && !(tau < __builtin_inf());   // a row or slice that fits: element j IS list entry j (NaN: padding)
   if (whole)
     sweep([&](int j, double f) {
       const bool ok = f == f;
@@ -393,9 +393,9 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
     });
   __syncthreads();
   const int L = whole ? n : lcnt;
-  if (L <= FS_CAP && k > 12) {
-    // many results: the k best of the list by radix selection + a 256-entry sort ...
-    if (list_topk(lv, lj, L, k, rv, rj, hist, ctl, tid)) {
+  if (L <= FS_CAP && (k > 12 || whole)) {
+    // many results (or a whole slice in the list): the k best by radix selection + a 256-entry sort ...
+    if (k <= 249 && list_topk(lv, lj, L, k, rv, rj, hist, ctl, tid)) {
       for (int t = tid; t < k; t += 256) emit(t, rv[t], rj[t] == NONE_J ? -1 : rj[t]);
       return;
     }

@@ -105,7 +105,8 @@ def test_fuse_select_rows_not_coaligned(api):
         ctx.close()
 
 
-@pytest.mark.parametrize("m,n,k", [(2, 100_000, 57), (1, 100_000, 128), (40, 30_000, 57), (3, 5000, 100), (5, 300, 20)])
+@pytest.mark.parametrize("m,n,k", [(2, 100_000, 57), (1, 100_000, 128), (2, 100_000, 9), (40, 30_000, 57), (3, 5000, 100), (5, 300, 20), (4, 3000, 3),
+                                   (2, 2000, 300)])
 @pytest.mark.parametrize("flavour", ["distinct", "ties", "mass_ties"])
 def test_selection_of_many_candidates_by_radix_select(api, m, n, k, flavour):
     """k > 12: the k best (value, index) pairs of a row come from a radix selection over the LDS list + a 256-entry sort (list_topk) - in the
