@@ -15,25 +15,17 @@
 namespace pr {
 namespace {
 
-__global__ __launch_bounds__(256) void nan_rows_kernel(float* __restrict__ d_p, float* __restrict__ d_i, int n,
-                                                        const int* __restrict__ qbad) {
-  const int q = blockIdx.x, b = qbad[q];
-  if (!b) return;
-  const float nanv = __builtin_nanf("");
-  for (int j = threadIdx.x; j < n; j += 256) {
-    if (b & 1) d_p[(size_t)q * n + j] = nanv;
-    if ((b & 2) && d_i) d_i[(size_t)q * n + j] = nanv;
-  }
-}
-
-__global__ __launch_bounds__(256) void nan_cols_kernel(float* __restrict__ d_p, float* __restrict__ d_i, int m, int n,
-                                                        const int* __restrict__ dbad) {
+// zero-norm signatures (processSC.m:16,19: MATLAB divides by zero, the row / column of distances is NaN): thread = DB column, walking the
+// query rows of its grid row; one launch for both kinds of flag
+__global__ __launch_bounds__(256) void nan_fixup_kernel(float* __restrict__ d_p, float* __restrict__ d_i, int m, int n,
+                                                         const int* __restrict__ qbad, const int* __restrict__ dbad) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
-  const int b = dbad[j];
-  if (!b) return;
+  const int bc = dbad ? dbad[j] : 0;
   const float nanv = __builtin_nanf("");
   for (int q = blockIdx.y; q < m; q += gridDim.y) {
+    const int b = bc | (qbad ? qbad[q] : 0);
+    if (!b) continue;
     if (b & 1) d_p[(size_t)q * n + j] = nanv;
     if ((b & 2) && d_i) d_i[(size_t)q * n + j] = nanv;
   }
@@ -405,8 +397,8 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const int32_t* __restric
 
 void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, const int* qbad, const int* dbad) {
   if (m <= 0 || n <= 0) return;
-  if (qbad) hipLaunchKernelGGL(nan_rows_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, n, qbad);
-  if (dbad) hipLaunchKernelGGL(nan_cols_kernel, dim3((n + 255) / 256, m < 64 ? m : 64), dim3(256), 0, st, d_p, d_i, m, n, dbad);
+  if (qbad || dbad)
+    hipLaunchKernelGGL(nan_fixup_kernel, dim3((n + 255) / 256, m < 64 ? m : 64), dim3(256), 0, st, d_p, d_i, m, n, qbad, dbad);
 }
 
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
