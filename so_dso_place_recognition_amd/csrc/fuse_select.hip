@@ -516,10 +516,10 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restr
 
 // slices per row for m query rows of n columns: 1 = one workgroup per row (enough rows to fill the chip, or short rows)
 int select_slices(int m, int n) {
-  if (m > 16 || n < 16384) return 1;
+  if (m > 64 || n < 16384) return 1;
   int P = (n + FS_CAP - 1) / FS_CAP;                // slices that fit the selection's LDS list skip its sampling phase
   if (P > 64) P = 64;
-  while (P > 1 && m * P > 768) P >>= 1;
+  while (P > 1 && m * P > 1024) P >>= 1;            // capacity of the scratch (partial moments: 1024 (row, slice) pairs), ~4 workgroups per CU
   return P;
 }
 size_t select_scratch_bytes() { return (size_t)64 * 16 * 128 * 8 + (size_t)64 * 16 * 6 * 8; }
@@ -540,7 +540,8 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
                         int G, int q_row0, int db_row0, int mask_width, double p_weight, int k, int32_t* idx,
                         float* score, const float* e_p, const float* e_i, const double* mom2_all, void* scratch) {
   if (m <= 0) return;
-  const int P = (scratch && k <= 128) ? select_slices(m, n) : 1;
+  int P = (scratch && k <= 128) ? select_slices(m, n) : 1;
+  if ((size_t)P * m * k > (size_t)64 * 16 * 128) P = 1;      // capacity of the slice lists
   if (P > 1) {
     int32_t* sidx = static_cast<int32_t*>(scratch);
     float* ssc = reinterpret_cast<float*>(sidx + (size_t)64 * 16 * 128);
