@@ -231,14 +231,17 @@ int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, con
 int pr_delight_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double* out);
 /* The generators with the clouds' PCA frames (utils/pts_align.h:7-46) supplied by the caller: the moments pass over the points is skipped
  * and only the binning pass runs (28 B per point once instead of twice).  frames: device [N][16] doubles = mean[3], the three
- * eigenvectors by ascending eigenvalue [9], 0, point count, 0, 0 - as pr_cloud_frames_dev writes them (asynchronously, on the
- * context's stream) and as pr_pts_preprocess_gpu leaves them beside the clouds it emits (pr_clouds_dev_frames).  Same results, bit
- * for bit, as the calls above. */
-int pr_cloud_frames_dev(pr_ctx* ctx, const double* xyz, const int64_t* offs, int32_t N, double* frames);
+ * eigenvectors by ascending eigenvalue [9], 0, point count, then optionally the cloud's float intensity average (the reference's
+ * sequential float sum in input order, SC.cpp:60-64 / M2DP.cpp:77-81, widened to double) and 1.0 where it is there.
+ * pr_cloud_frames_dev writes them (asynchronously, on the context's streams; with inten != NULL the averages too), and
+ * pr_pts_preprocess_gpu leaves them - averages included - beside the clouds it emits (pr_clouds_dev_frames).
+ * frames_have_ave != 0: slots 14 of the frames hold the averages and the call is the binning pass alone; 0: the call computes them
+ * (a chain of dependent float adds per cloud, beside the binning pass).  Same results, bit for bit, as the calls above. */
+int pr_cloud_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten /* may be NULL */, const int64_t* offs, int32_t N, double* frames);
 int pr_sc_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho,
-                              const double* frames, double* out);
+                              const double* frames, int frames_have_ave, double* out);
 int pr_m2dp_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho,
-                                const double* frames, double* out);
+                                const double* frames, int frames_have_ave, double* out);
 int pr_delight_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N,
                                    const double* frames, double* out);
 

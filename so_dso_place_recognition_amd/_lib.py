@@ -77,9 +77,9 @@ SYMBOLS = {
     "pr_fuse_select_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_sc_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
     "pr_m2dp_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp]),
-    "pr_cloud_frames_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
-    "pr_sc_generate_frames_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp, _vp]),
-    "pr_m2dp_generate_frames_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp, _vp]),
+    "pr_cloud_frames_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
+    "pr_sc_generate_frames_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp, C.c_int, _vp]),
+    "pr_m2dp_generate_frames_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _dbl, _vp, C.c_int, _vp]),
     "pr_delight_generate_frames_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp, _vp]),
     "pr_generate_clouds": (C.c_int, [_vp, C.c_int, _vp, _dbl, _vp]),
     "pr_clouds_dev_xyz": (_vp, [_vp]),

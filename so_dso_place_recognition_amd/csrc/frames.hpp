@@ -39,7 +39,8 @@ __device__ inline void jacobi_eig3(double a[3][3], double v[3][3]) {
   }
 }
 
-// raw moments (sum p, sum p p^T) of a cloud of n points -> frame {mean[3], v0[3], v1[3], v2[3], 0, n, 0, 0}: scatter matrix
+// raw moments (sum p, sum p p^T) of a cloud of n points -> frame {mean[3], v0[3], v1[3], v2[3], 0, n, ave, has_ave} (the last two are not
+// written here: the reference's sequential FLOAT average of the intensities, SC.cpp:60-64 / M2DP.cpp:77-81, widened, and 1.0 when it is there): scatter matrix
 // cov = sum pp^T - n mean mean^T (un-normalised as pts_align.h:30), 3x3 Jacobi, eigenvalues ascending (Eigen::SelfAdjointEigenSolver
 // order, :32-34), canonical signs (N3)
 __device__ __attribute__((noinline)) inline void finish_frame(const double s[9], double n, double* f) {
@@ -67,7 +68,7 @@ __device__ __attribute__((noinline)) inline void finish_frame(const double s[9],
   f[0] = mx; f[1] = my; f[2] = mz;
   for (int j = 0; j < 3; j++)
     for (int k = 0; k < 3; k++) f[3 + 3 * j + k] = e[j][k];
-  f[12] = 0; f[13] = n; f[14] = 0; f[15] = 0;
+  f[12] = 0; f[13] = n;      // slots 14, 15: the cloud's float intensity average and its presence flag - written by whoever computes it
 }
 
 // the fixed reduction tree of a moments pass: 64-lane shuffle tree per wave, then the waves in order; thread 0 writes the frame.
@@ -90,6 +91,38 @@ __device__ __forceinline__ void reduce_moments_to_frame(const double (&s)[9], do
     }
     finish_frame(t, n, frame);
   }
+}
+
+// The reference's float average of a cloud's intensities (a sequential float sum in input order, SC.cpp:60-64, M2DP.cpp:77-81) by ONE
+// workgroup of FRAME_THREADS threads: everybody stages 2048 floats into LDS (two buffers), thread 0 adds them in order, 32 values in
+// registers while the next 32 are on their way.  stage: LDS [2][2048 + 32] floats.  Returns the average in every thread... of thread 0
+// only (the others return 0); P = 0 gives 0 / 0 = NaN as the reference does.
+__device__ inline float block_sequential_average(const float* __restrict__ it, long long P, float (*stage)[2048 + 32]) {
+  typedef float f4a __attribute__((ext_vector_type(4)));
+  const int tid = threadIdx.x;
+  float sum = 0.f;
+  auto fill = [&](int b, long long c0) {
+    for (int s = tid; s < 2048; s += FRAME_THREADS) stage[b][s] = (c0 + s < P) ? it[c0 + s] : 0.f;      // x + 0 = x past the end
+  };
+  if (P > 0) fill(0, 0);
+  __syncthreads();
+  for (long long c0 = 0, b = 0; c0 < P; c0 += 2048, b ^= 1) {
+    if (c0 + 2048 < P) fill((int)(b ^ 1), c0 + 2048);
+    if (tid == 0) {
+      const f4a* src = reinterpret_cast<const f4a*>(&stage[b][0]);
+      const long long left = P - c0;
+      const int nq = (int)((left < 2048 ? left : 2048) + 3) >> 2;         // float4 groups that hold data (the tail of the last one is zeros)
+      for (int j = 0; j < nq; j += 8) {
+        f4a a[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) a[q] = src[j + q];                     // (up to 7 groups past nq: zeros or the spare 32 floats)
+#pragma unroll
+        for (int q = 0; q < 8; q++) { sum += a[q][0]; sum += a[q][1]; sum += a[q][2]; sum += a[q][3]; }
+      }
+    }
+    __syncthreads();
+  }
+  return tid == 0 ? sum / (float)P : 0.f;
 }
 
 }  // namespace pr

@@ -91,7 +91,8 @@ void launch_widen(hipStream_t st, const float* a, long long n, double* b);
 void launch_merge_topk(hipStream_t st, const int32_t* idx_all, const double* score_all, int G, int m, int k, int32_t* idx, double* score);
 
 // sc_gen.hip / m2dp_gen.hip — pts_align.h:7-46 + SC.cpp:12-76 / M2DP.cpp:38-109 (+ test_m2dp.cpp:44-68)
-void launch_ave_chain(hipStream_t st, const float* inten, const int64_t* offs, int N, float* ave);
+void launch_ave_chain(hipStream_t st, const float* inten, const int64_t* offs, int N, float* ave /* [N] or NULL */,
+                      double* frames = nullptr /* non-NULL: also frames[c][14] = the average, [15] = 1 (frames.hpp) */);
 void launch_cloud_frames(hipStream_t st, const double* xyz, const int64_t* offs, int N, double* frames);
 // the one-HBM-pass path of SC generation (see sc_gen.hip): a batch of clouds small enough for the Infinity Cache, W workgroups per cloud
 constexpr int SC_MAX_W = 16;                     // slices per cloud
@@ -107,7 +108,8 @@ int* launch_sc_cluster(hipStream_t st, const double* xyz, const float* inten, co
                        char* scratch, double* frames, double* out);
 void launch_sc_finish(hipStream_t st, const float* ave, int N, double* out);
 void launch_sc_bin(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double max_rho,
-                   const double* frames, const float* ave /* NULL: out[c][1200..] = bin means, launch_sc_finish applies the averages */, double* out);
+                   const double* frames, const float* ave /* NULL: out[c][1200..] = bin means, launch_sc_finish applies the averages */, double* out,
+                   int ave_in_frames = 0 /* with ave = NULL: the averages are frames[c][14] */);
 void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
                          double max_rho, const double* frames, const float* ave, const double* planes, double* mats,
                          double* out, int* flags /* [1] |= 1: a leading singular pair did not converge */,

@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
   const float R_f = (float)R_res_inv;
   const double* p = xyz + 3 * o0;
   const float* it = inten + o0;
-  const double ave = (double)ave_in[c];      // the float average, widened (double > float promotes the float, M2DP.cpp:88)
+  // the float average, widened (double > float promotes the float, M2DP.cpp:88); ave_in = NULL: the caller's frame carries it (frames.hpp)
+  const double ave = ave_in ? (double)ave_in[c] : f[14];
   // fixed-point grid of the FAST mode: 2^-s with (2 ave P) 2^s < 2^46
   bool fast = P < (1 << 17) && ave >= 0.0 && ave < 1e300;
   double scale = 1.0, inv_scale = 1.0;

@@ -1048,12 +1048,21 @@ static int launch_frames_and_ave(pr_ctx* ctx, const double* xyz, const float* in
   return PR_OK;
 }
 
-int pr_cloud_frames_dev(pr_ctx* ctx, const double* xyz, const int64_t* offs, int32_t N, double* frames) {
+int pr_cloud_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double* frames) {
   if (!ctx) return PR_EINVAL;
   if (N < 0 || !offs || (N > 0 && !frames)) PR_FAIL(ctx, PR_EINVAL, "pr_cloud_frames_dev: bad arguments (N=%d)", N);
   if (N == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
+  if (inten) {            // the float averages beside the moments pass (side stream), into slots 14 / 15 of the frames
+    PR_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream));
+    PR_HIP(ctx, hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    pr::launch_ave_chain(ctx->side, inten, offs, N, nullptr, frames);
+    PR_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side));
+  } else {
+    PR_HIP(ctx, hipMemset2DAsync(frames + 14, 16 * sizeof(double), 0, 2 * sizeof(double), (size_t)N, ctx->stream));
+  }
   pr::launch_cloud_frames(ctx->stream, xyz, offs, N, frames);
+  if (inten) PR_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -1077,11 +1086,17 @@ static int launch_ave_only(pr_ctx* ctx, const float* inten, const int64_t* offs,
 }
 
 int pr_sc_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho,
-                              const double* frames, double* out) {
+                              const double* frames, int frames_have_ave, double* out) {
   if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
   if (N == 0) return PR_OK;
   if (!frames) PR_FAIL(ctx, PR_EINVAL, "pr_sc_generate_frames_dev: frames is NULL");
   if (int rc = set_device(ctx)) return rc;
+  if (frames_have_ave) {        // everything but the binning pass came with the frames
+    pr::launch_sc_bin(ctx->stream, xyz, inten, offs, N, max_rho, frames, nullptr, out, 1);
+    PR_HIP(ctx, hipGetLastError());
+    PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PR_OK;
+  }
   DevBuf ave;
   PR_HIP(ctx, ave.alloc((size_t)N * 4));
   // the binning pass writes bin means and does not wait for the average chain beside it; sc_finish applies the averages
@@ -1186,30 +1201,31 @@ int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const
 }
 
 static int m2dp_generate_impl(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho,
-                              const double* frames_in, double* out) {
+                              const double* frames_in, int frames_have_ave, double* out) {
   if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
   if (N == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   DevBuf frames, ave, mats;
   if (!frames_in) PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
-  PR_HIP(ctx, ave.alloc((size_t)N * 4));
+  const bool own_ave = !(frames_in && frames_have_ave);
+  if (own_ave) PR_HIP(ctx, ave.alloc((size_t)N * 4));
   PR_HIP(ctx, mats.alloc(pr::m2dp_generate_scratch_bytes(N)));
-  if (frames_in) { if (int rc = launch_ave_only(ctx, inten, offs, N, ave.as<float>())) return rc; }
-  else if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc;
+  if (frames_in && own_ave) { if (int rc = launch_ave_only(ctx, inten, offs, N, ave.as<float>())) return rc; }
+  else if (!frames_in) { if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc; }
   PR_HIP(ctx, hipMemsetAsync(ctx->d_svd_rows, 0, sizeof(int), ctx->stream));
-  pr::launch_m2dp_bin_svd(ctx->stream, xyz, inten, offs, N, max_rho, frames_in ? frames_in : frames.as<double>(), ave.as<float>(), ctx->d_planes,
+  pr::launch_m2dp_bin_svd(ctx->stream, xyz, inten, offs, N, max_rho, frames_in ? frames_in : frames.as<double>(), own_ave ? ave.as<float>() : nullptr, ctx->d_planes,
                           mats.as<double>(), out, ctx->d_flags, ctx->d_svd_rows);
   PR_HIP(ctx, hipGetLastError());
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PR_OK;
 }
 int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
-  return m2dp_generate_impl(ctx, xyz, inten, offs, N, max_rho, nullptr, out);
+  return m2dp_generate_impl(ctx, xyz, inten, offs, N, max_rho, nullptr, 0, out);
 }
 int pr_m2dp_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho,
-                                const double* frames, double* out) {
+                                const double* frames, int frames_have_ave, double* out) {
   if (ctx && N > 0 && !frames) PR_FAIL(ctx, PR_EINVAL, "pr_m2dp_generate_frames_dev: frames is NULL");
-  return m2dp_generate_impl(ctx, xyz, inten, offs, N, max_rho, frames, out);
+  return m2dp_generate_impl(ctx, xyz, inten, offs, N, max_rho, frames, frames_have_ave, out);
 }
 
 int pr_m2dp_svd_rows(pr_ctx* ctx, int32_t* rows, int32_t cap, int32_t* count) {
@@ -1313,8 +1329,8 @@ int pr_generate_clouds(pr_ctx* ctx, int type, const pr_clouds* c, double max_rho
   const float* it = static_cast<const float*>(c->d_inten);
   const int64_t* of = static_cast<const int64_t*>(c->d_offs);
   const double* fr = static_cast<const double*>(c->d_frames);
-  int rc = (type == PR_TYPE_SC)     ? pr_sc_generate_frames_dev(ctx, x, it, of, N, max_rho, fr, dout.as<double>())
-           : (type == PR_TYPE_M2DP) ? pr_m2dp_generate_frames_dev(ctx, x, it, of, N, max_rho, fr, dout.as<double>())
+  int rc = (type == PR_TYPE_SC)     ? pr_sc_generate_frames_dev(ctx, x, it, of, N, max_rho, fr, 1, dout.as<double>())
+           : (type == PR_TYPE_M2DP) ? pr_m2dp_generate_frames_dev(ctx, x, it, of, N, max_rho, fr, 1, dout.as<double>())
                                     : pr_delight_generate_frames_dev(ctx, x, it, of, N, fr, dout.as<double>());
   if (rc) { (void)hipStreamSynchronize(ctx->stream); return rc; }
   PR_HIP(ctx, hipMemcpyAsync(out, dout.p, (size_t)N * rowlen * 8, hipMemcpyDeviceToHost, ctx->stream));

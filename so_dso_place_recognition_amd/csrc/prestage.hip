@@ -212,8 +212,8 @@ __global__ __launch_bounds__(256) void gather_kernel(int E, const int64_t* __res
 
 // The same emission with one workgroup per cloud, which also adds up the cloud's raw moments on the way and leaves its PCA frame
 // (pts_align.h:7-46): thread t emits points t, t + 256, ... - the order in which cloud_frames_kernel (sc_gen.hip) reads them - and both
-// use reduce_moments_to_frame, so frames[e] has the bits a moments pass over the emitted cloud would produce; the generators then run
-// their binning pass only (pr_*_generate_frames_dev).
+// use reduce_moments_to_frame, so frames[e] has the bits a moments pass over the emitted cloud would produce; the float intensity average
+// is added too, and the generators then run their binning pass only (pr_*_generate_frames_dev).
 __global__ __launch_bounds__(FRAME_THREADS) void gather_frames_kernel(const int64_t* __restrict__ off, const int64_t* __restrict__ ooff,
                                                                       const int* __restrict__ pose_of, const int* __restrict__ order,
                                                                       const int* __restrict__ win, const double* __restrict__ xyz,
@@ -221,6 +221,7 @@ __global__ __launch_bounds__(FRAME_THREADS) void gather_frames_kernel(const int6
                                                                       double range, double* __restrict__ oxyz, float* __restrict__ oint,
                                                                       double* __restrict__ frames) {
   __shared__ double red[FRAME_THREADS / 64][9];
+  __shared__ __attribute__((aligned(16))) float stage[2][2048 + 32];
   const int e = blockIdx.x, tid = threadIdx.x;
   const int64_t o0 = ooff[e], P = ooff[e + 1] - o0, m0 = off[e];
   const double* w = W + 12 * (size_t)pose_of[e];
@@ -238,6 +239,12 @@ __global__ __launch_bounds__(FRAME_THREADS) void gather_frames_kernel(const int6
     s[3] += x * x; s[4] += x * y; s[5] += x * z; s[6] += y * y; s[7] += y * z; s[8] += z * z;
   }
   reduce_moments_to_frame(s, (double)P, red, frames + (size_t)e * 16);
+  // ... and the reference's float average of the emitted intensities (in emission order), so that the generators have nothing left to do
+  // but their binning pass: frames[e][14], [15] = 1
+  __threadfence_block();
+  __syncthreads();                                 // this workgroup's oint stores are visible to it
+  const float a = block_sequential_average(oint + o0, P, stage);
+  if (tid == 0) { frames[(size_t)e * 16 + 14] = (double)a; frames[(size_t)e * 16 + 15] = 1.0; }
 }
 
 Grid make_grid(double range, int polar) {

@@ -40,7 +40,7 @@ constexpr int RW = FT / 64;
 constexpr int CPW = 8;
 constexpr int ACH = 512;                     // floats per cloud and round
 __global__ __launch_bounds__(64) void ave_chain_kernel(const float* __restrict__ inten, const int64_t* __restrict__ offs,
-                                                        int N, float* __restrict__ ave_out) {
+                                                        int N, float* __restrict__ ave_out, double* __restrict__ frames_out) {
   // rows of ACH + 4 floats: the eight adding lanes read eight different bank groups; one more row: the read-ahead of the last block stays inside
   __shared__ __attribute__((aligned(16))) float buf[CPW + 1][ACH + 4];
   typedef float f4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -117,7 +117,9 @@ __global__ __launch_bounds__(64) void ave_chain_kernel(const float* __restrict__
     int64_t P = 0;
 #pragma unroll
     for (int k = 0; k < CPW; k++) P = (lane == k) ? Pk[k] : P;
-    ave_out[cb + lane] = ave / (float)P;     // SC.cpp:64
+    const float a = ave / (float)P;          // SC.cpp:64
+    if (ave_out) ave_out[cb + lane] = a;
+    if (frames_out) { frames_out[(size_t)(cb + lane) * 16 + 14] = (double)a; frames_out[(size_t)(cb + lane) * 16 + 15] = 1.0; }   // frames.hpp
   }
 }
 
@@ -204,7 +206,8 @@ __global__ __launch_bounds__(512) void sc_bin_kernel(const double* __restrict__ 
   }
   for (; i < P; i += 512) bin(p[3 * i], p[3 * i + 1], p[3 * i + 2], it[i]);
   __syncthreads();
-  const double ave = MEAN ? 0.0 : (double)ave_in[c];   // the float average, widened (double > float promotes the float, SC.cpp:70)
+  // the float average, widened (double > float promotes the float, SC.cpp:70); ave_in = NULL: the caller's frame carries it (frames.hpp)
+  const double ave = MEAN ? 0.0 : (ave_in ? (double)ave_in[c] : f[14]);
   double* o = out + (size_t)c * 2400;
   for (int b = tid; b < 1200; b += 512) {
     const unsigned int n = cnt[b];
@@ -542,9 +545,9 @@ __global__ __launch_bounds__(256) void sc_finish_kernel(const float* __restrict_
 
 }  // namespace
 
-void launch_ave_chain(hipStream_t st, const float* inten, const int64_t* offs, int N, float* ave) {
+void launch_ave_chain(hipStream_t st, const float* inten, const int64_t* offs, int N, float* ave, double* frames) {
   if (N <= 0) return;
-  hipLaunchKernelGGL(ave_chain_kernel, dim3((N + CPW - 1) / CPW), dim3(64), 0, st, inten, offs, N, ave);
+  hipLaunchKernelGGL(ave_chain_kernel, dim3((N + CPW - 1) / CPW), dim3(64), 0, st, inten, offs, N, ave, frames);
 }
 
 
@@ -605,9 +608,9 @@ void launch_cloud_frames(hipStream_t st, const double* xyz, const int64_t* offs,
 }
 
 void launch_sc_bin(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N, double max_rho,
-                   const double* frames, const float* ave, double* out) {
+                   const double* frames, const float* ave, double* out, int ave_in_frames) {
   if (N <= 0) return;
-  if (ave) hipLaunchKernelGGL(sc_bin_kernel<false>, dim3(N), dim3(512), 0, st, xyz, inten, offs, frames, ave, max_rho, out);
+  if (ave || ave_in_frames) hipLaunchKernelGGL(sc_bin_kernel<false>, dim3(N), dim3(512), 0, st, xyz, inten, offs, frames, ave, max_rho, out);
   else hipLaunchKernelGGL(sc_bin_kernel<true>, dim3(N), dim3(512), 0, st, xyz, inten, offs, frames, ave, max_rho, out);   // + launch_sc_finish
 }
 

@@ -312,27 +312,37 @@ def test_generators_with_caller_frames_equal_the_two_pass_calls(api):
     dx, di, do = (torch.from_numpy(a).cuda() for a in (xyz, it, offs))
     N = len(sizes)
     ctx = api.Context(0)
-    fr = torch.empty((N, 16), dtype=torch.float64, device="cuda")
-    ctx.check(ctx.lib.pr_cloud_frames_dev(ctx.h, dx.data_ptr(), do.data_ptr(), N, fr.data_ptr()))
+    fr = torch.empty((N, 16), dtype=torch.float64, device="cuda")          # frames alone (slots 14, 15 zero)
+    fa = torch.empty((N, 16), dtype=torch.float64, device="cuda")          # frames + the float intensity averages
+    ctx.check(ctx.lib.pr_cloud_frames_dev(ctx.h, dx.data_ptr(), None, do.data_ptr(), N, fr.data_ptr()))
+    ctx.check(ctx.lib.pr_cloud_frames_dev(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, fa.data_ptr()))
     ctx.sync()
-    f = fr.cpu().numpy()
+    f = fr.cpu().numpy(); g = fa.cpu().numpy()
     big = sizes >= 3
     assert np.array_equal(f[:, 13], sizes.astype(np.float64))
     assert np.abs(f[big, :3] - np.stack([xyz[offs[c]:offs[c + 1]].mean(0) for c in np.nonzero(big)[0]])).max() < 1e-12
     R = f[big, 3:12].reshape(-1, 3, 3)
     assert np.abs(R @ R.transpose(0, 2, 1) - np.eye(3)).max() < 1e-12 and np.abs(np.linalg.det(R) - 1).max() < 1e-12
+    assert np.array_equal(f[:, :14].view(np.uint64), g[:, :14].view(np.uint64)) and not f[:, 14:].any() and (g[:, 15] == 1.0).all()
+    for c in np.nonzero(sizes > 0)[0]:                                     # the reference's sequential float sum in input order
+        acc = np.float32(0)
+        for v in it[offs[c]:offs[c + 1]]:
+            acc = np.float32(acc + v)
+        assert g[c, 14] == np.float64(np.float32(acc / np.float32(sizes[c]))), c
     for name, rows, cols, rho in (("sc", N, 2400, 45.0), ("m2dp", 4 * N, 384, 45.0), ("delight", 16 * N, 256, None)):
-        a = torch.empty((rows, cols), dtype=torch.float64, device="cuda"); b = torch.empty_like(a)
+        a = torch.empty((rows, cols), dtype=torch.float64, device="cuda"); b = torch.empty_like(a); b2 = torch.empty_like(a)
         two = getattr(ctx.lib, f"pr_{name}_generate_dev"); one = getattr(ctx.lib, f"pr_{name}_generate_frames_dev")
         if rho is None:
             ctx.check(two(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, a.data_ptr()))
             ctx.check(one(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, fr.data_ptr(), b.data_ptr()))
+            b2.copy_(b)
         else:
             ctx.check(two(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, rho, a.data_ptr()))
-            ctx.check(one(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, rho, fr.data_ptr(), b.data_ptr()))
+            ctx.check(one(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, rho, fr.data_ptr(), 0, b.data_ptr()))    # the call computes the averages
+            ctx.check(one(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, rho, fa.data_ptr(), 1, b2.data_ptr()))   # the binning pass alone
         ctx.sync()
-        assert torch.equal(a.view(torch.int64), b.view(torch.int64)), name
-    assert ctx.lib.pr_sc_generate_frames_dev(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, 45.0, None, a.data_ptr()) == -1   # PR_EINVAL
+        assert torch.equal(a.view(torch.int64), b.view(torch.int64)) and torch.equal(a.view(torch.int64), b2.view(torch.int64)), name
+    assert ctx.lib.pr_sc_generate_frames_dev(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, 45.0, None, 0, a.data_ptr()) == -1   # PR_EINVAL
     ctx.close()
 
 

@@ -240,9 +240,9 @@ def test_gpu_prestage_leaves_clouds_and_frames_in_hbm(seq07, polar):
         assert np.array_equal(dx.cpu().numpy().view(np.uint64), xyz.view(np.uint64)) and np.array_equal(do.cpu().numpy(), offs)
         assert np.array_equal(di.cpu().numpy().view(np.uint32), it.view(np.uint32))
         fr2 = torch.empty_like(fr)
-        ctx.check(lib.pr_cloud_frames_dev(ctx.h, dx.data_ptr(), do.data_ptr(), N, fr2.data_ptr()))
+        ctx.check(lib.pr_cloud_frames_dev(ctx.h, dx.data_ptr(), di.data_ptr(), do.data_ptr(), N, fr2.data_ptr()))    # moments pass + average chain
         ctx.sync()
-        assert np.array_equal(fr.cpu().numpy().view(np.uint64), fr2.cpu().numpy().view(np.uint64))
+        assert np.array_equal(fr.cpu().numpy().view(np.uint64), fr2.cpu().numpy().view(np.uint64))              # frames AND float averages
         for type_, gen, rows, cols in ((0, api.sc_generate, N, 2400), (1, api.m2dp_generate, 4 * N, 384), (2, api.delight_generate, 16 * N, 256)):
             got = np.empty((rows, cols))
             ctx.check(lib.pr_generate_clouds(ctx.h, type_, h, 45.0, got.ctypes.data))
