@@ -377,7 +377,7 @@ void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, 
                             (int)SVD_LDS);
   for (int c0 = 0; c0 < N; c0 += GEN_BATCH) {
     const int nc = (N - c0) < GEN_BATCH ? (N - c0) : GEN_BATCH;
-    if (nc * 16 >= 4096)
+    if (nc * 16 >= 768)        // one full round of 3 workgroups per CU: the 16-plane form reads and aligns a point once per 16 projections
       hipLaunchKernelGGL(m2dp_bin_kernel<16>, dim3(nc * 16), dim3(256), 0, st, xyz, inten, offs, frames, ave, planes, max_rho,
                          c0, mats);
     else
