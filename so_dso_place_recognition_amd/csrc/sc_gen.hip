@@ -1,23 +1,27 @@
 // sc_gen.hip — PCA alignment (utils/pts_align.h:7-46) and Scan-Context signature (SC/SC.cpp:12-76) on gfx950.
 //
-// Two kernels, one workgroup per cloud each (compiled with -ffp-contract=off so products/sums round as on the CPU):
+// Three kernels, one workgroup per cloud (ave_chain: one lane per cloud), compiled with -ffp-contract=off so products/sums round as on the CPU:
 //   ave_chain    : the reference's FLOAT sequential average of the intensities IN INPUT ORDER (SC.cpp:60-64,
 //                  M2DP.cpp:77-81; a tree sum differs at ~3e-4 and flips bins).  The chain of P
 //                  dependent v_add_f32 cannot be parallelised inside a cloud, so every LANE walks a different
 //                  cloud (8 independent chains per wave, per-lane 16-byte loads, two batches of 8 loads in flight per lane).
-//                  Runs on a side stream, overlapped with cloud_frames.  -> ave[c] (float).
+//                  Runs on a high-priority side stream beside the moments AND the binning pass (11 cycles per dependent add: 0.27 ms per
+//                  50 000 points - longer than either pass).  -> ave[c] (float) and / or frames[c][14..15] (frames.hpp).
 //   cloud_frames : one streaming pass over the cloud: fp64 raw moments (sum p, sum p p^T), fixed reduction tree;
 //                  mean, scatter matrix cov = sum pp^T - P mean mean^T (un-normalised as :30), 3x3 symmetric Jacobi
 //                  eigen-solver, eigenvalues ascending, canonical signs (N3)
-//                  -> frames[c] = {mean[3], v0[3], v1[3], v2[3], pad} (16 doubles).
+//                  -> frames[c] = {mean[3], v0[3], v1[3], v2[3], 0, P, [float average, flag]} (16 doubles, frames.hpp).  Callers that
+//                  bring the frames (the GPU pre-stage emits them, averages included) skip this pass and the chain.
 //   sc_bin       : second pass: centre, rotate (same association as the oracle), sector = floor((atan2(z,y)+pi)*60/2pi),
 //                  ring = floor(sqrt(y^2+z^2)*20/max_rho), idx = sector*20 + ring, dropped iff idx >= 1200 (the
 //                  ring-overflow aliasing of SC.cpp:39-44 is kept, H3); LDS-resident 1200-bin grids with LDS
 //                  atomics: count (u32 add), min/max of x (order-preserving u64 keys), fp64 intensity sum; epilogue
-//                  max-min and mean > ave ? 1 : 0 (:67-75) -> out[c][2400].
+//                  max-min and mean > ave ? 1 : 0 (:67-75) -> out[c][2400].  When the average is still on its way the pass writes the
+//                  bin MEANS (sc_bin_kernel<true>) and sc_finish_kernel applies the averages afterwards.
 // Bound: HBM (28 B per point per pass); the points are never written back.
 //
-// The DEFAULT is exactly these two streaming passes over all clouds at once (moments, then binning: 2 x 28 B per point at ~5.4 TB/s each).
+// The DEFAULT is exactly these two streaming passes over all clouds at once (moments, then binning: 24 + 28 B per point at ~5 TB/s each,
+// four points of a thread in flight); with the caller's frames it is the binning pass alone (0.28 ms per 1024 x 50k points = 0.64 of 8 TB/s).
 // Two one-pass designs are kept in this file for A/B runs only - both parity-green, both slower (tools/experiments/
 // README.md): PR_SC_GEN=batched (batches of ~96 MB so that the binning pass re-reads the Infinity Cache; a cloud split over W workgroups with
 // last-arriver merges: cloud_frames_split / sc_bin_split / sc_finish; 6.25 ms against 2.52 ms at 5000 x 50k points) and PR_SC_GEN=cluster
