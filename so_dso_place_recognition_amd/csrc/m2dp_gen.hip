@@ -1,19 +1,21 @@
 // m2dp_gen.hip — M2DP signature (M2DP/M2DP.cpp:38-109 + the 4-variant loop of test_m2dp.cpp:44-68) on gfx950.
 //
 // After cloud_frames (sc_gen.hip; PCA frame + float average, once per cloud as test_m2dp.cpp:45):
-//   m2dp_bin  : grid (cloud, variant, group of 16 planes).  Each thread centres + rotates its points, applies the
-//               variant signs pt' = (dx x, dy y, dx dy z) (test_m2dp.cpp:52-56), and for each of the group's planes
-//               xp = xProj.pt', yp = yProj.pt' evaluated as a0*b0 + (a1*b1 + a2*b2) with NO zero seed so that the
-//               degenerate plane 32 (xProj = yProj = +0) keeps its signed-zero behaviour;
+//   m2dp_bin  : grid (cloud, variant, group of 16 or 4 planes).  Each thread centres + rotates its points, applies the
+//               variant signs pt' = (dx x, dy y, dx dy z) (test_m2dp.cpp:52-56), and classifies the group's projections
+//               xp = xProj.pt', yp = yProj.pt' (the reference: a0*b0 + (a1*b1 + a2*b2) with NO zero seed so that the
+//               degenerate plane 32, xProj = yProj = +0, keeps its signed-zero behaviour):
 //               si = floor((atan2(yp,xp)+pi)*16/2pi), ri = floor(sqrt(xp^2+yp^2)*8/max_rho), idx = ri*16+si,
-//               dropped iff idx >= 128 (M2DP.cpp:66-68).  LDS-resident 16x128 count (u32) and intensity (f64) grids,
-//               LDS atomics; then mean > ave ? 1 : 0 (M2DP.cpp:84-91) and both 16x128 slabs go to the scratch
-//               matrices [cloud][variant][{count,intensity}][64][128] (f64).
+//               dropped iff idx >= 128 (M2DP.cpp:66-68) - in fp32 where that provably gives the reference's integers
+//               (fast_bins.hpp), in the reference's fp64 expressions otherwise.  LDS-resident per-plane 128-bin grids: ONE
+//               64-bit LDS atomic per projection (count << 47 | fixed-point intensity) or, where that cannot be vouched
+//               for, u32 count + f64 sum (see the kernel); then mean > ave ? 1 : 0 (M2DP.cpp:84-91) and both slabs go to
+//               the scratch matrices [cloud][variant][{count,intensity}][64][128] (f64).
 //   m2dp_svd  : grid (cloud, variant, channel): leading singular pair of the 64x128 matrix (JacobiSVD U.col(0),
 //               V.col(0), M2DP.cpp:94-103) in fp64: G = A A^T (64x64) in LDS, 8 normalised squarings (G^256),
 //               u = dominant column, then polished with u <- A(A^T u)/||.|| on the original matrix until the
 //               update is below 4e-15; v = A^T u / sigma.  Sign: sum(u) >= 0 (N6).  Zero matrix -> (e0, e0).
-// Bound: fp64 VALU / transcendental (256 P atan2 per cloud), not HBM and not MFMA.
+// Bound: VALU (~50 fp32 instructions per projection, 256 P projections per cloud) + LDS atomics, not HBM and not MFMA.
 #include <type_traits>
 
 #include "fast_bins.hpp"

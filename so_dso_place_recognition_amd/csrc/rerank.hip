@@ -8,7 +8,8 @@
 //                 the 120 shifted / mirrored variants, (1 - dot)/2, minimum (processSC.m:15-33); M2DP: (1 - dot)/2 over
 //                 the 4 x 4 sign variants (processM2DP.m:12-22) - and the fused z-score of run_test.m:40 with the row
 //                 moments of all shards.  One workgroup per pair; ~0.6 M fp64 multiply-adds per SC pair.
-//   rerank_sort   orders the survivors of a query by (fp64 score, index) and keeps k (run_test.m:57, ties -> lower index).
+//   rerank_sort   orders the survivors of a query by (fp64 score, index) and keeps k (run_test.m:57, ties -> lower index); one thread
+//                 per query, or one wave per query when there are at most 64 of them (an online call).
 //   merge_topk    k-way merge of the per-shard top-k lists of G database shards by (score, global index).
 #include "kernels.hpp"
 
