@@ -122,7 +122,9 @@ __host__ __device__ __forceinline__ bool proj_bins16_fast(const PointF& pt, cons
   const float r = sqrtf(fmaf(xf, xf, yf * yf));
 #endif
   const float tt = r * R_f, fl = floorf(tt), fr = tt - fl;
-  const bool ok = (d3 > e) & (fabsf(fr - 0.5f) < pt.hw) & (tt < 1e6f);
+  // (no range test on tt: from 2^23 on floor(tt) = tt and fr = 0, +Inf gives NaN - both fail the ring test; below that a huge ring index is
+  // merely one of the dropped ones)
+  const bool ok = (d3 > e) & (fabsf(fr - 0.5f) < pt.hw);
   // Sector: sign bits instead of comparisons (an accepted point has neither coordinate, nor a - b, nor mn - t at zero):
   //   shift = 16 [x < 0] + 8 [|y| > |x|] + 4 [min < max tan(pi/8)], table by the sign of y - the nibble table of polar_bins16 with the
   //   entries of each pair exchanged (its last index bit is min > max tan(pi/8))
