@@ -206,6 +206,10 @@ def extra_workloads(dev, ev, args):
     ms = timed(ctx, lambda: ctx.check(ctx.lib.pr_m2dp_generate_dev(ctx.h, P(xyz), P(it), P(offs), Nm, 45.0, P(sigm))), reps=2)
     out["m2dp_generate_50k_pts"] = {"clouds": Nm, "points_per_cloud": PTS, "ms": ms, "clouds_per_s": Nm / (ms * 1e-3),
                                     "plane_projections_per_s": Nm * 256 * PTS / (ms * 1e-3), "bound": "valu (fp64 dots + polar classification), not HBM"}
+    sigm = torch.empty((4 * N, 384), dtype=torch.float64, device=dev)
+    ms = timed(ctx, lambda: ctx.check(ctx.lib.pr_m2dp_generate_dev(ctx.h, P(xyz), P(it), P(offs), N, 45.0, P(sigm))), reps=2)
+    out["m2dp_generate_50k_pts_1024_clouds"] = {"clouds": N, "points_per_cloud": PTS, "ms": ms, "clouds_per_s": N / (ms * 1e-3),
+                                                "plane_projections_per_s": N * 256 * PTS / (ms * 1e-3)}
     ctx.close(); del xyz, it, offs, sig, sigm
     torch.cuda.empty_cache()
     # the fp32-MFMA arithmetic of the SC matcher on the metric workload (one launch)
