@@ -113,7 +113,9 @@ void launch_sc_bin(hipStream_t st, const double* xyz, const float* inten, const 
 void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
                          double max_rho, const double* frames, const float* ave, const double* planes, double* mats,
                          double* out, int* flags /* [1] |= 1: a leading singular pair did not converge */,
-                         int* svd_rows /* [0] += 1 and [1 + slot] = signature row (cloud * 4 + variant) for each such pair */);
+                         int* svd_rows /* [0] += 1 and [1 + slot] = signature row (cloud * 4 + variant) for each such pair */,
+                         hipStream_t st2 = nullptr, hipEvent_t* ev_bin = nullptr, hipEvent_t* ev_svd = nullptr /* [2] each: more than one
+                         batch of clouds -> the singular pairs of a batch run on st2 beside the binning of the next (see m2dp_gen.hip) */);
 constexpr int M2DP_SVD_ROWS_CAP = 1024;
 size_t m2dp_generate_scratch_bytes(int N);
 

@@ -366,26 +366,46 @@ constexpr int GEN_BATCH = 256;   // clouds per scratch batch (256 * 4 * 2 * 64 K
 
 }  // namespace
 
-size_t m2dp_generate_scratch_bytes(int N) {
+size_t m2dp_generate_scratch_bytes(int N) {     // one buffer of matrices per batch in flight: two when there is more than one batch
   const int nb = N < GEN_BATCH ? N : GEN_BATCH;
-  return (size_t)nb * 4 * 2 * MAT * sizeof(double);
+  return (size_t)(N > GEN_BATCH ? 2 : 1) * nb * 4 * 2 * MAT * sizeof(double);
 }
 
+// Batches of GEN_BATCH clouds: the binning of batch b + 1 (VALU-bound, stream st) runs beside the singular pairs of batch b (LDS-bound, one
+// 100 KB workgroup per CU, stream st2) - two matrix buffers, ev_bin[p] / ev_svd[p] order the two streams per buffer.  On return st has
+// joined st2.  (st2 / events null, or a single batch: everything on st.)
 void launch_m2dp_bin_svd(hipStream_t st, const double* xyz, const float* inten, const int64_t* offs, int N,
                          double max_rho, const double* frames, const float* ave, const double* planes, double* mats,
-                         double* out, int* flags, int* svd_rows) {
+                         double* out, int* flags, int* svd_rows, hipStream_t st2, hipEvent_t* ev_bin, hipEvent_t* ev_svd) {
   if (N <= 0) return;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(m2dp_svd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)SVD_LDS);
-  for (int c0 = 0; c0 < N; c0 += GEN_BATCH) {
+  const bool two = N > GEN_BATCH && st2 && ev_bin && ev_svd;
+  const size_t buf = (size_t)GEN_BATCH * 4 * 2 * MAT;
+  int b = 0;
+  for (int c0 = 0; c0 < N; c0 += GEN_BATCH, b++) {
     const int nc = (N - c0) < GEN_BATCH ? (N - c0) : GEN_BATCH;
+    const int p = two ? (b & 1) : 0;
+    double* m = mats + (size_t)p * buf;
+    if (two && b >= 2) (void)hipStreamWaitEvent(st, ev_svd[p], 0);          // the matrices of batch b - 2 have been consumed
     if (nc * 16 >= 768)        // one full round of 3 workgroups per CU: the 16-plane form reads and aligns a point once per 16 projections
       hipLaunchKernelGGL(m2dp_bin_kernel<16>, dim3(nc * 16), dim3(256), 0, st, xyz, inten, offs, frames, ave, planes, max_rho,
-                         c0, mats);
+                         c0, m);
     else
       hipLaunchKernelGGL(m2dp_bin_kernel<4>, dim3(nc * 64), dim3(256), 0, st, xyz, inten, offs, frames, ave, planes, max_rho,
-                         c0, mats);
-    hipLaunchKernelGGL(m2dp_svd_kernel, dim3(nc * 8), dim3(256), SVD_LDS, st, mats, c0, out, flags, svd_rows);
+                         c0, m);
+    hipStream_t ss = st;
+    if (two) {
+      (void)hipEventRecord(ev_bin[p], st);
+      (void)hipStreamWaitEvent(st2, ev_bin[p], 0);
+      ss = st2;
+    }
+    hipLaunchKernelGGL(m2dp_svd_kernel, dim3(nc * 8), dim3(256), SVD_LDS, ss, m, c0, out, flags, svd_rows);
+    if (two) (void)hipEventRecord(ev_svd[p], st2);
+  }
+  if (two) {
+    (void)hipStreamWaitEvent(st, ev_svd[0], 0);
+    (void)hipStreamWaitEvent(st, ev_svd[1], 0);
   }
 }
 

@@ -1213,10 +1213,14 @@ static int m2dp_generate_impl(pr_ctx* ctx, const double* xyz, const float* inten
   if (frames_in && own_ave) { if (int rc = launch_ave_only(ctx, inten, offs, N, ave.as<float>())) return rc; }
   else if (!frames_in) { if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc; }
   PR_HIP(ctx, hipMemsetAsync(ctx->d_svd_rows, 0, sizeof(int), ctx->stream));
+  hipEvent_t evs[4] = {nullptr, nullptr, nullptr, nullptr};     // two batches in flight (binning | singular pairs): see launch_m2dp_bin_svd
+  for (auto& e : evs) PR_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   pr::launch_m2dp_bin_svd(ctx->stream, xyz, inten, offs, N, max_rho, frames_in ? frames_in : frames.as<double>(), own_ave ? ave.as<float>() : nullptr, ctx->d_planes,
-                          mats.as<double>(), out, ctx->d_flags, ctx->d_svd_rows);
-  PR_HIP(ctx, hipGetLastError());
-  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                          mats.as<double>(), out, ctx->d_flags, ctx->d_svd_rows, ctx->side2, evs, evs + 2);
+  const hipError_t le = hipGetLastError(), se = hipStreamSynchronize(ctx->stream);
+  for (auto& e : evs) (void)hipEventDestroy(e);
+  PR_HIP(ctx, le);
+  PR_HIP(ctx, se);
   return PR_OK;
 }
 int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
