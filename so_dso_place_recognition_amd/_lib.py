@@ -37,6 +37,8 @@ SYMBOLS = {
     "pr_rerank_width": (C.c_int, [_vp, _i32]),
     "pr_f16_margin_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _i32, _vp, _vp, _vp]),
     "pr_rerank_finish_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "pr_rerank_parts_dev": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "pr_f16_order_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pr_widen_scores_dev": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "pr_merge_topk_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "pr_group_create": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
@@ -118,6 +120,26 @@ class PRError(RuntimeError):
         self.code = code
 
 
+def _one_hip_runtime():
+    """A process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same SONAME as /opt/rocm's, which
+    libpr_amd.so is linked against): whichever copy is loaded first serves both, and torch does not find its GPUs on the other one
+    ("No HIP GPUs are available" when libpr_amd.so came first).  So when torch is installed but not imported yet, its copy is loaded
+    here - without importing torch - and both end up on it whatever the import order.  PR_AMD_SYSTEM_HIP=1 keeps /opt/rocm's."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("PR_AMD_SYSTEM_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    for d in (spec.submodule_search_locations or []) if spec else []:
+        p = os.path.join(d, "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+            return
+
+
 def load() -> C.CDLL:
     """Loads libpr_amd.so and binds every declared symbol (raises if the library or a symbol is missing)."""
     global _lib
@@ -126,6 +148,7 @@ def load() -> C.CDLL:
     if not os.path.exists(LIB_PATH):
         raise OSError(f"{LIB_PATH} not found: build it with `make -C so_dso_place_recognition_amd/csrc` "
                       "(or __graft_entry__.build()); there is no CPU fallback")
+    _one_hip_runtime()
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)      # AttributeError if the export is missing

@@ -39,6 +39,10 @@ struct pr_ctx {
   double* d_twiddle = nullptr;   // cos[60], sin[60] of 2*pi*t/60
   float* d_cst = nullptr;        // SC stage-2 constants [31][2][64]
   int32_t* d_margin = nullptr;    // [1] count of margin flags (PR_SC_ARITH_F16)
+  int32_t* d_order = nullptr;     // [order_cap] order flags of the last re-evaluation (PR_SC_ARITH_F16; pr_f16_margin_dev takes them)
+  size_t order_cap = 0;
+  int32_t order_m = -1;           // rows of d_order that are valid, -1: none
+  size_t parts_count = 0;         // entries of rr_scratch that hold the channel-0 parts of the last pr_rerank_partial_dev
   void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16] (sc_match_h.hip)
   int sc_kernel = 2;             // split-f16 SC matcher for m > 8: 2 = sc_match_e.hip (default); PR_SC_KERNEL=d | h selects sc_match_d.hip (1, the round-2 default) / sc_match_h.hip (0, round 1; always the kernel for m <= 8)
   int sc_mode = PR_SC_ARITH_F16X2;   // PR_SC_ARITH_*: split-f16 MFMA (sc_match_h.hip) | fp32 MFMA (sc_match.hip); PR_SC_MATCH=f32 selects the latter
@@ -265,6 +269,7 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->ev_b) (void)hipEventDestroy(ctx->ev_b);
   if (ctx->sc_scratch) (void)hipFree(ctx->sc_scratch);
   if (ctx->rr_scratch) (void)hipFree(ctx->rr_scratch);
+  if (ctx->d_order) (void)hipFree(ctx->d_order);
   if (ctx->sel_scratch) (void)hipFree(ctx->sel_scratch);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -642,8 +647,25 @@ int pr_f16_margin_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, i
     PR_FAIL(ctx, PR_EINVAL, "pr_f16_margin_dev: bad arguments (m=%d, G=%d, k=%d, k_in=%d)", m, G, k, k_in);
   if (int rc = set_device(ctx)) return rc;
   pr::launch_zero_ints(ctx->stream, count, 1);
-  pr::launch_margin_check(ctx->stream, mom_sc, mom_m2, G, m, p_weight, k_in, cand_score, k, score, PR_F16_DISTANCE_BOUND, flags, count);
+  pr::launch_margin_check(ctx->stream, mom_sc, mom_m2, G, m, p_weight, k_in, cand_score, k, score, PR_F16_DISTANCE_BOUND, flags, count,
+                          ctx->order_m == m ? ctx->d_order : nullptr);
+  ctx->order_m = -1;
   PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+// grow-only scratch of the re-evaluation: `need` doubles of candidate scores (+ as many channel-0 parts in PR_SC_ARITH_F16), m order flags
+static int rerank_scratch(pr_ctx* ctx, size_t need, int32_t m) {
+  if (need > ctx->rr_cap) {
+    if (ctx->rr_scratch) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->rr_scratch)); ctx->rr_scratch = nullptr; ctx->rr_cap = 0; }
+    PR_HIP(ctx, hipMalloc((void**)&ctx->rr_scratch, need * sizeof(double)));
+    ctx->rr_cap = need;
+  }
+  if ((size_t)m > ctx->order_cap) {
+    if (ctx->d_order) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->d_order)); ctx->d_order = nullptr; ctx->order_cap = 0; }
+    PR_HIP(ctx, hipMalloc((void**)&ctx->d_order, (size_t)m * sizeof(int32_t)));
+    ctx->order_cap = (size_t)m;
+  }
   return PR_OK;
 }
 
@@ -662,13 +684,16 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   const size_t need = (size_t)m * k_in;
-  if (need > ctx->rr_cap) {
-    if (ctx->rr_scratch) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->rr_scratch)); ctx->rr_scratch = nullptr; ctx->rr_cap = 0; }
-    PR_HIP(ctx, hipMalloc((void**)&ctx->rr_scratch, need * sizeof(double)));
-    ctx->rr_cap = need;
-  }
+  const bool f16 = ctx->sc_mode == PR_SC_ARITH_F16;             // the order of the re-evaluated candidates is checked too (pr_f16_margin_dev)
+  if (int rc = rerank_scratch(ctx, f16 ? 2 * need : need, m)) return rc;
+  double* parts = f16 ? ctx->rr_scratch + need : nullptr;
+  ctx->parts_count = 0;
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
-                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in, pass_eps(ctx));
+                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in, pass_eps(ctx), parts);
+  if (f16) {
+    pr::launch_order_check(ctx->stream, idx_in, ctx->rr_scratch, parts, 1, m, k_in, k, idx, PR_F16_SIGMA_REL, ctx->d_order);
+    ctx->order_m = m;
+  }
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -685,8 +710,35 @@ int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int 
     PR_FAIL(ctx, PR_EINVAL, "pr_rerank_partial_dev: bad arguments (m=%d, n_local=%d, G=%d, k_in=%d)", m, n_local, G, k_in);
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
+  const bool f16 = ctx->sc_mode == PR_SC_ARITH_F16;             // the channel-0 parts stay in the context for pr_rerank_parts_dev
+  if (f16) { if (int rc = rerank_scratch(ctx, (size_t)m * k_in, m)) return rc; }
   pr::launch_rerank_partial(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0,
-                            mask_width, p_weight, k_in, cand_idx, part, cand_score, k, pass_eps(ctx));
+                            mask_width, p_weight, k_in, cand_idx, part, cand_score, k, pass_eps(ctx), f16 ? ctx->rr_scratch : nullptr);
+  ctx->parts_count = f16 ? (size_t)m * k_in : 0;
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+int pr_rerank_parts_dev(pr_ctx* ctx, int32_t m, int32_t k_in, double* parts) {
+  if (!ctx) return PR_EINVAL;
+  if (!parts || m < 0 || k_in < 1 || (size_t)m * k_in != ctx->parts_count)
+    PR_FAIL(ctx, PR_EINVAL, "pr_rerank_parts_dev: no parts of a [%d][%d] pr_rerank_partial_dev call in PR_SC_ARITH_F16 on this context", m, k_in);
+  if (m == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  PR_HIP(ctx, hipMemcpyAsync(parts, ctx->rr_scratch, ctx->parts_count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+  return PR_OK;
+}
+
+int pr_f16_order_dev(pr_ctx* ctx, const int32_t* cand_idx, const double* score_all, const double* parts_all, int32_t G, int32_t m, int32_t k_in,
+                     int32_t k, const int32_t* idx) {
+  if (!ctx) return PR_EINVAL;
+  if (!cand_idx || !score_all || !parts_all || !idx || G < 1 || m < 0 || k < 1 || k_in < k || k_in > 128)
+    PR_FAIL(ctx, PR_EINVAL, "pr_f16_order_dev: bad arguments (G=%d, m=%d, k=%d, k_in=%d)", G, m, k, k_in);
+  if (m == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  if (int rc = rerank_scratch(ctx, 0, m)) return rc;
+  pr::launch_order_check(ctx->stream, cand_idx, score_all, parts_all, G, m, k_in, k, idx, PR_F16_SIGMA_REL, ctx->d_order);
+  ctx->order_m = m;
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }

@@ -162,6 +162,7 @@ struct RerankArgs {
   double p_weight;
   const double* cand_sc; int k;                                 // fp32-pass scores of the candidates [m][kin], ascending, or null; the k wanted
   double eps_d, eps_mult;                                       // distance error bound of the all-pairs pass per channel, and the safety factor on it
+  double* cand_part;                                            // [m][kin] or null: the weighted structure / count-channel z-scores of the evaluated candidates (order_check_kernel)
 };
 
 // |all-pairs-pass score - exact score| <= this for a pair whose exact score is s, given the row statistics: distance error eps_d per
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
   const int tid = threadIdx.x, q = blockIdx.x / A.kin, t = blockIdx.x % A.kin;
   const int jg = idx_in[(size_t)q * A.kin + t];
   double* out = cand_score + (size_t)q * A.kin + t;
+  if (A.cand_part && tid == 0) A.cand_part[(size_t)q * A.kin + t] = __builtin_nan("");   // stays NaN unless the pair is evaluated
   if (jg < 0) { if (tid == 0) *out = __builtin_nan(""); return; }
   int dij = (A.q_row0 + q) - jg;
   if (dij < 0) dij = -dij;
@@ -212,14 +214,16 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
     const double delta = A.eps_mult * score_err_bound(A.eps_d, w, sk, cn);
     if (st > sk + delta) { if (tid == 0) *out = st; return; }   // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
   }
-  double f = 0.0;
+  double f = 0.0, fp = 0.0;                                     // fp: the channel-0 terms alone (weight p)
   if (A.q_sc) {
     for (int ch = 0; ch < 2; ch++) {
       const double d = sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + ch * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + ch * 1200,
                                      buf, red, tid);
       double mean, sd;
       chan_combine(A.mom_sc, A.G, A.m, q, ch, mean, sd);
-      f += (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);    // run_test.m:40
+      const double z = (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);    // run_test.m:40
+      f += z;
+      if (ch == 0) fp += z;
     }
   }
   if (A.q_m2) {
@@ -227,10 +231,15 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
       const double d = m2dp_pair_exact(A.q_m2, A.m2_dt, (size_t)q * 4 * 384, A.db_m2, A.m2_dt, (size_t)jl * 4 * 384, ch, red, tid);
       double mean, sd;
       chan_combine(A.mom_m2, A.G, A.m, q, ch, mean, sd);
-      f += (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);
+      const double z = (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);
+      f += z;
+      if (ch == 0) fp += z;
     }
   }
-  if (tid == 0) *out = f;
+  if (tid == 0) {
+    *out = f;
+    if (A.cand_part) A.cand_part[(size_t)q * A.kin + t] = fp;
+  }
 }
 
 __device__ double row_weight(const double* mom_sc, const double* mom_m2, int G, int m, int q, double p_weight, double* cn_out) {
@@ -251,11 +260,11 @@ __device__ double row_weight(const double* mom_sc, const double* mom_m2, int G, 
 __global__ __launch_bounds__(64) void margin_check_kernel(const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int G, int m,
                                                            double p_weight, int kin, const double* __restrict__ cand_sc, int k,
                                                            const double* __restrict__ score, double eps_d, int32_t* __restrict__ flags,
-                                                           int32_t* __restrict__ count) {
+                                                           int32_t* __restrict__ count, const int32_t* __restrict__ order_flags) {
   const int q = blockIdx.x * 64 + threadIdx.x;
   if (q >= m) return;
   const double* cs = cand_sc + (size_t)q * kin;
-  int flag = 0;
+  int flag = order_flags ? (order_flags[q] != 0) : 0;          // order_check_kernel: the re-evaluated order hangs on the pass's sigmas
   const double T = cs[kin - 1];
   if (T == T) {                                       // a full candidate list (NaN = fewer than k_in entries exist: nothing is outside it)
     double cn = 2.0;
@@ -361,6 +370,59 @@ __global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __rest
   select_k(ci, cs, kin, k, idx + (size_t)q * k, score + (size_t)q * k, nullptr);
 }
 
+// PR_SC_ARITH_F16: is the ORDER of the re-evaluated candidates certain?  Their exact scores are s = P + I with the pair's distances exact
+// (fp64) but the row statistics those of the single-product pass: P (cand_part, the weight-p channel-0 z-scores) scales with 1 / sigma_p,
+// I = s - P with 1 / sigma_i, and the pass's sigmas are off by a relative eps_sigma at most (PR_F16_SIGMA_REL).  Two candidates a, b with
+// s_a <= s_b keep that order under the true sigmas if  s_b - s_a > eps_sigma (|P_b - P_a| + |I_b - I_a|)  (always true when both channels
+// agree on the order); walking the selected k and the best candidate left out, every ADJACENT pair must pass - then the whole chain is in
+// its true order and the k-th / (k+1)-th boundary is the true one.  Pairs with equal P and equal I (duplicated signatures) are ordered by
+// index and certain; candidates that were not evaluated (pruned: their pass score is beyond the k-th by more than the pass's error) are
+// certain by that bound.  Anything else flags the query for the split-f16 pass.  One thread per query; score_all / part_all [G][m][kin]
+// hold a value at the candidate's owner and NaN elsewhere (G = 1: the scratch arrays of pr_rerank_dev).
+__global__ __launch_bounds__(64) void order_check_kernel(const int32_t* __restrict__ cand_idx, const double* __restrict__ score_all,
+                                                          const double* __restrict__ part_all, int G, int m, int kin, int k,
+                                                          const int32_t* __restrict__ idx_sel, double eps_sigma, int32_t* __restrict__ flags) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= m) return;
+  int32_t ci[128];
+  double cs[128], cp[128];
+  for (int t = 0; t < kin; t++) {
+    ci[t] = cand_idx[(size_t)q * kin + t];
+    double v = __builtin_nan(""), pv = __builtin_nan("");
+    for (int g = 0; g < G; g++) {
+      const size_t o = ((size_t)g * m + q) * kin + t;
+      const double x = score_all[o];
+      if (x == x) { v = x; pv = part_all[o]; break; }
+    }
+    cs[t] = v; cp[t] = pv;
+  }
+  int flag = 0, prev = -1;
+  for (int t = 0; t <= k && !flag; t++) {
+    int cur = -1;
+    if (t < k) {
+      const int want = idx_sel[(size_t)q * k + t];
+      if (want < 0) break;                                     // fewer than k entries exist
+      for (int c = 0; c < kin; c++) if (ci[c] == want) { cur = c; break; }
+    } else {                                                   // the best candidate that was left out
+      for (int c = 0; c < kin; c++) {
+        if (ci[c] < 0 || cs[c] != cs[c]) continue;
+        bool sel = false;
+        for (int u = 0; u < k; u++) if (idx_sel[(size_t)q * k + u] == ci[c]) { sel = true; break; }
+        if (sel) continue;
+        if (cur < 0 || cand_before(cs[c], ci[c], cs[cur], ci[cur])) cur = c;
+      }
+    }
+    if (cur < 0) break;
+    if (prev >= 0 && cp[prev] == cp[prev] && cp[cur] == cp[cur]) {   // both evaluated (masked pairs are +Inf with a NaN part)
+      const double ds = cs[cur] - cs[prev], dp = cp[cur] - cp[prev], di = ds - dp;
+      const double span = fabs(dp) + fabs(di);
+      if (span > 0.0 && !(ds > eps_sigma * span)) flag = 1;
+    }
+    prev = cur;
+  }
+  flags[q] = flag;
+}
+
 __global__ __launch_bounds__(256) void widen_kernel(const float* __restrict__ a, long long n, double* __restrict__ b) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   if (i < n) b[i] = (double)a[i];
@@ -405,10 +467,10 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
                    double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
-                   float* score32, const double* cand_sc32, double eps_d) {
+                   float* score32, const double* cand_sc32, double eps_d, double* cand_part) {
   if (m <= 0) return;
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
-               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0};
+               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, cand_part};
   hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
   if (m <= 64 && kin <= 128)
     hipLaunchKernelGGL(rerank_sort_wave_kernel, dim3(m), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
@@ -418,18 +480,27 @@ void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_d
 
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                           double p_weight, int kin, const int32_t* idx_in, double* cand_score, const double* cand_sc32, int k, double eps_d) {
+                           double p_weight, int kin, const int32_t* idx_in, double* cand_score, const double* cand_sc32, int k, double eps_d,
+                           double* cand_part) {
   if (m <= 0) return;
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
-               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0};
+               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, cand_part};
   hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
 }
 
 void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,
-                         const double* cand_sc, int k, const double* score, double eps_d, int32_t* flags, int32_t* count) {
+                         const double* cand_sc, int k, const double* score, double eps_d, int32_t* flags, int32_t* count,
+                         const int32_t* order_flags) {
   if (m <= 0) return;
   hipLaunchKernelGGL(margin_check_kernel, dim3((m + 63) / 64), dim3(64), 0, st, mom_sc, mom_m2, G, m, p_weight, kin, cand_sc, k, score, eps_d,
-                     flags, count);
+                     flags, count, order_flags);
+}
+
+void launch_order_check(hipStream_t st, const int32_t* cand_idx, const double* score_all, const double* part_all, int G, int m, int kin, int k,
+                        const int32_t* idx_sel, double eps_sigma, int32_t* flags) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(order_check_kernel, dim3((m + 63) / 64), dim3(64), 0, st, cand_idx, score_all, part_all, G, m, kin, k, idx_sel, eps_sigma,
+                     flags);
 }
 
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,

@@ -232,6 +232,7 @@ class Matcher(_Base):
             part = self._buf("part", (m, kin), torch.float64)
             self.ctx.check(self.lib.pr_rerank_partial_dev(self.ctx.h, *self._raw_args(), m, n, G, q_row0, db_row0, mask_width, p_weight, kin,
                                                           _dptr(cand_idx), csc, int(k), _dptr(part)))
+            part = _with_parts(self, part)
             self._leave()
             return part
         idx = self._buf("idx", (m, k), torch.int32)
@@ -269,8 +270,8 @@ class Matcher(_Base):
         if f16 and f16_fallback:
             def run_rows(rows, qr0):
                 fb = self._split_twin()
-                return fb.match(queries[rows].contiguous(), mask_width, p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group,
-                                force_exchange)
+                qsel = queries.view(-1, self.rows_per_sig, self.sig_len)[rows].reshape(-1, self.sig_len).contiguous()   # M2DP: 4 rows per query
+                return fb.match(qsel, mask_width, p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group, force_exchange)
             idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
         return idx, score
 
@@ -394,6 +395,7 @@ class FusedMatcher(_Base):
             part = self._buf("part", (m, kin), torch.float64)
             self.ctx.check(self.lib.pr_rerank_partial_dev(self.ctx.h, *raw, m, n, G, q_row0, db_row0, mask_width, p_weight, kin, _dptr(cand_idx),
                                                           csc, int(k), _dptr(part)))
+            part = _with_parts(self, part)
             self._leave()
             return part
         idx = self._buf("idx", (m, k), torch.int32)
@@ -456,14 +458,36 @@ def _merge_dev(owner, idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
     return idx, score
 
 
+def _with_parts(owner, part: torch.Tensor) -> torch.Tensor:
+    """PR_SC_ARITH_F16: the partial scores [m, kin] travel with their channel-0 parts (pr_rerank_parts_dev) as [m, 2, kin], so that the
+    order check after the finish (pr_f16_order_dev) sees them for every shard's candidates; other arithmetics: unchanged."""
+    if owner.ctx.sc_arith != "f16":
+        return part
+    m, kin = part.shape
+    both = torch.empty((m, 2, kin), dtype=torch.float64, device=part.device)
+    both[:, 0] = part
+    parts = torch.empty((m, kin), dtype=torch.float64, device=part.device)
+    owner.ctx.check(owner.lib.pr_rerank_parts_dev(owner.ctx.h, m, kin, _dptr(parts)))
+    both[:, 1] = parts
+    return both
+
+
 def _finish_dev(owner, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int):
-    """pr_rerank_finish_dev: candidates [m, kin] + the shards' partial scores [G, m, kin] -> (idx [m,k], score [m,k])."""
+    """pr_rerank_finish_dev: candidates [m, kin] + the shards' partial scores [G, m, kin] -> (idx [m,k], score [m,k]).
+    PR_SC_ARITH_F16: part_all is [G, m, 2, kin] (_with_parts) and the order of the result is checked (pr_f16_order_dev)."""
+    parts_all = None
+    if part_all.dim() == 4:
+        parts_all = part_all[:, :, 1].contiguous()
+        part_all = part_all[:, :, 0].contiguous()
     G, m, kin = part_all.shape
     idx = torch.empty((m, k), dtype=torch.int32, device=cand_idx.device)
     score = torch.empty((m, k), dtype=torch.float64, device=cand_idx.device)
+    cand_idx = cand_idx.contiguous()
+    part_all = part_all.contiguous()
     owner._enter()
-    owner.ctx.check(owner.lib.pr_rerank_finish_dev(owner.ctx.h, _dptr(cand_idx.contiguous()), _dptr(part_all.contiguous()), G, m, kin, k,
-                                                   _dptr(idx), _dptr(score)))
+    owner.ctx.check(owner.lib.pr_rerank_finish_dev(owner.ctx.h, _dptr(cand_idx), _dptr(part_all), G, m, kin, k, _dptr(idx), _dptr(score)))
+    if parts_all is not None:
+        owner.ctx.check(owner.lib.pr_f16_order_dev(owner.ctx.h, _dptr(cand_idx), _dptr(part_all), _dptr(parts_all), G, m, kin, k, _dptr(idx)))
     owner._leave()
     return idx, score
 

@@ -71,3 +71,37 @@ def test_inline_asm_mfma_operands_are_not_written_right_before_use():
     good = ["v_mov_b32_e32 v5, v30", "s_nop 1", ";;#ASMSTART", "v_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[8:11], 0", ";;#ASMEND",
             ";;#ASMSTART", "v_mfma_f32_16x16x32_f16 v[0:3], v[4:7], v[12:15], v[0:3]", ";;#ASMEND", "s_nop 9", "v_add_f32_e32 v20, v2, v3"]
     assert aud.audit_lines("x", bad_before) == 1 and aud.audit_lines("x", bad_after) == 1 and aud.audit_lines("x", good) == 0
+
+
+def _run_py(code):
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    return subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+
+
+def test_loader_leaves_one_hip_runtime_whatever_the_import_order():
+    """torch bundles its own libamdhip64.so.7; the loader maps that copy first when torch is installed, so that torch still sees its
+    runtime after libpr_amd.so was loaded (CPU box: only that both load and that the mapped copy is torch's)."""
+    r = _run_py("from so_dso_place_recognition_amd import _lib; _lib.load(); import torch\n"
+                "maps = open('/proc/self/maps').read()\n"
+                "hip = sorted({l.split()[-1] for l in maps.splitlines() if 'libamdhip64' in l})\n"
+                "print(hip); assert len(hip) == 1 and '/torch/lib/' in hip[0], hip")
+    assert r.returncode == 0, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+def test_torch_finds_its_gpu_after_the_library_was_used_first():
+    r = _run_py("import numpy as np\n"
+                "from so_dso_place_recognition_amd import api, synth\n"
+                "db = synth.sc_database(45, 64); q, planted = synth.sc_queries(46, db, 8)\n"
+                "idx, sc = api.match_topk('sc', q, db)\n"
+                "import torch\n"
+                "assert torch.cuda.is_available()\n"
+                "x = torch.arange(8, device='cuda', dtype=torch.float64).sum().item(); assert x == 28.0\n"
+                "from so_dso_place_recognition_amd.matcher import Matcher\n"
+                "mt = Matcher('sc', 8, 64); mt.pack_database(torch.from_numpy(db).cuda())\n"
+                "i2, s2 = mt.match(torch.from_numpy(q).cuda())\n"
+                "assert np.array_equal(i2.cpu().numpy(), idx), (i2, idx)\n"
+                "print('ok')")
+    assert r.returncode == 0, r.stdout + r.stderr

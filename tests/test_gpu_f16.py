@@ -215,3 +215,35 @@ def test_merge_topk_has_no_cap_on_shards_times_width(api):
         ri, rs = merge_topk(idx[:, :, :kk].contiguous(), sc[:, :, :kk].contiguous(), kk)
         assert torch.equal(di.cpu(), ri) and torch.equal(ds.cpu(), rs)
     mt.close()
+
+
+def test_f16_order_check_sends_sigma_sensitive_rows_to_the_split_pass(api):
+    """Found by tools/fuzz_all.py (seed 1, case 6): M2DP, 60 x 3498, k = 57.  Deep in a list the fused scores of neighbours differ by less
+    than what the f16 pass's sigma error (~1e-4 relative) moves them when their two channels disagree about the order: the re-evaluated
+    pairs came out swapped at ranks 31 / 32 of one row.  The order check (pr_rerank_dev + pr_f16_margin_dev) now flags such queries and the
+    split-f16 pass answers them - through the host call and through the device-resident Matcher (whose fallback used to index the query
+    rows of an M2DP batch as if a signature were one row)."""
+    from so_dso_place_recognition_amd.matcher import Matcher
+    m, n, k = 60, 3498, 57
+    db = synth.m2dp_database(3000 + 7 * 6 + 1, n)
+    q, _ = synth.m2dp_queries(4000 + 6 + 1, db, m)
+    rc, oidx, osc = oracle_lib.match_topk(1, q, db, 0, 2.0, k)
+    assert rc == 0
+    ctx = api.Context(0, sc_arith="f16")
+    idx, sc = api.match_topk("m2dp", q, db, 0, 2.0, k, ctx=ctx)
+    assert ctx.take_warnings() & _lib.WARN_F16_FALLBACK
+    assert np.array_equal(idx, oidx)
+    assert (np.abs(sc - osc) <= score_tol_f16(osc)).all()
+    ctx.close()
+    dev = torch.device("cuda", 0)
+    mt = Matcher("m2dp", m, n, ctx=api.Context(0, sc_arith="f16", stream=int(torch.cuda.current_stream(dev).cuda_stream)))
+    mt.pack_database(torch.from_numpy(db).to(dev))
+    i2, s2 = mt.match(torch.from_numpy(q).to(dev), 0, 2.0, k)
+    assert mt.f16_fallbacks > 0
+    assert np.array_equal(i2.cpu().numpy(), oidx)
+    # without the fallback the f16 answer differs in at least one of the flagged rows: the check has teeth
+    i3, _ = mt.match(torch.from_numpy(q).to(dev), 0, 2.0, k, f16_fallback=False)
+    flagged = mt.f16_flags.cpu().numpy().astype(bool)
+    diff = (i3.cpu().numpy() != oidx).any(axis=1)
+    assert diff.any() and not (diff & ~flagged).any()
+    mt.close()
