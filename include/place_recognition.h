@@ -35,7 +35,8 @@ enum { PR_HOST = 0, PR_DEVICE = 1 };
  * contain the exact top-k, or whose re-evaluated candidates could change places under the sigma error of the f16 pass (pr_f16_margin_dev),
  * is recomputed in split-f16 (host calls: automatically, PR_WARN_F16_FALLBACK is raised) */
 #define PR_F16_DISTANCE_BOUND 2e-3   /* |d_f16 - d| per channel: 8 u (u = 2^-11) on the correlation of unit-norm rows, halved */
-#define PR_F16_SIGMA_REL 1e-3        /* relative error allowed for a row sigma of the f16 pass in the order check: 10 x the largest observed (1e-4) */
+#define PR_F16_SIGMA_REL 2e-4        /* order check: floor of the relative error allowed for a row sigma of the f16 pass ... */
+#define PR_F16_NOISE 1e-4            /* ... which is max(floor, 4 PR_F16_NOISE / (sigma sqrt(n - 1))): rms distance noise of the pass, 3 x the observed 3e-5 */
 enum { PR_SC_ARITH_F16X2 = 0, PR_SC_ARITH_F32 = 1, PR_SC_ARITH_F16 = 2 };
 /* What a zero-norm SC row does.  MATLAB divides 0/0 (processSC.m:16,19): every distance to or from that signature is NaN, and
  * normalize(.,2) / min (run_test.m:40,57) leave NaNs out [normalize's 'omitnan' from memory], so the signature simply never matches.
@@ -179,10 +180,11 @@ int pr_rerank_width(const pr_ctx* ctx, int32_t k);
  * return them) does not provably contain the exact top-k: exact k-th score (score: DEVICE f64 [m][k]) >= last candidate's pass score
  * minus the score error bound that PR_F16_DISTANCE_BOUND implies with the row's statistics (mom_*: as for pr_rerank_dev).
  * count: DEVICE i32 [1], set to the number of flags.  Flagged queries must be recomputed in PR_SC_ARITH_F16X2.
- * Also flagged: queries whose re-evaluated ORDER is not certain.  A re-evaluated score is exact in the pair's distances, but its two
+ * Also flagged: queries whose re-evaluated ORDER is not certain.  A re-evaluated score is exact in the pair's distances, but its
  * channel terms are divided by the f16 pass's row sigmas; two candidates whose channels disagree about their order can change places
- * when those sigmas move by PR_F16_SIGMA_REL.  pr_rerank_dev (one shard) / pr_f16_order_dev (sharded) check every adjacent pair of the
- * selected k and the best candidate left out and leave the result in the context; this call takes it (once). */
+ * when those sigmas move by what the pass's distance noise allows (PR_F16_SIGMA_REL, PR_F16_NOISE: a relative noise / (sigma sqrt(n))).
+ * pr_rerank_dev (one shard) / pr_f16_order_dev (sharded) check every adjacent pair of the selected k and the best candidate left out and
+ * leave the result in the context; this call takes it (once). */
 int pr_f16_margin_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t m, int32_t G, double p_weight, int32_t k_in,
                       const double* cand_score, int32_t k, const double* score, int32_t* flags, int32_t* count);
 int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
@@ -202,13 +204,15 @@ int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int 
                           double* part);
 int pr_rerank_finish_dev(pr_ctx* ctx, const int32_t* cand_idx, const double* part_all, int32_t G, int32_t m, int32_t k_in, int32_t k,
                          int32_t* idx, double* score);
-/* PR_SC_ARITH_F16, sharded form of the order check: pr_rerank_parts_dev copies the channel-0 share (weight p: SC structure + M2DP count
- * z-scores) of every score the LAST pr_rerank_partial_dev of this context evaluated (parts DEVICE f64 [m][k_in], NaN elsewhere); the
- * shards' parts are gathered like their scores (parts_all DEVICE [G][m][k_in]) and pr_f16_order_dev checks the order of the result of
- * pr_rerank_finish_dev (idx DEVICE [m][k]); the following pr_f16_margin_dev reports the outcome. */
+/* PR_SC_ARITH_F16, sharded form of the order check: pr_rerank_parts_dev copies the four weighted channel z-scores (SC structure, SC
+ * intensity, M2DP count, M2DP intensity; 0 for an absent type) of every candidate the LAST pr_rerank_partial_dev of this context
+ * evaluated (parts DEVICE f64 [m][4][k_in], NaN in [q][0][t] for the others); the shards' parts are gathered like their scores
+ * (score_all DEVICE [G][m][k_in], parts_all DEVICE [G][m][4][k_in]) and pr_f16_order_dev checks the order of the result of
+ * pr_rerank_finish_dev (idx DEVICE [m][k]) with the row statistics mom_* [G_mom][m][2][3]; the following pr_f16_margin_dev reports
+ * the outcome. */
 int pr_rerank_parts_dev(pr_ctx* ctx, int32_t m, int32_t k_in, double* parts);
-int pr_f16_order_dev(pr_ctx* ctx, const int32_t* cand_idx, const double* score_all, const double* parts_all, int32_t G, int32_t m, int32_t k_in,
-                     int32_t k, const int32_t* idx);
+int pr_f16_order_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t G_mom, const int32_t* cand_idx, const double* score_all,
+                     const double* parts_all, int32_t G, int32_t m, int32_t k_in, int32_t k, const int32_t* idx);
 /* fp32 scores of pr_fuse_select_dev as doubles (the merge works on doubles): DEVICE score32 [count] -> score64 [count] */
 int pr_widen_scores_dev(pr_ctx* ctx, const float* score32, int64_t count, double* score64);
 /* k-way merge of the per-shard results of G shards (SURVEY.md §8-e collective B's second half): idx_all DEVICE [G][m][k],

@@ -38,7 +38,7 @@ SYMBOLS = {
     "pr_f16_margin_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _i32, _vp, _vp, _vp]),
     "pr_rerank_finish_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pr_rerank_parts_dev": (C.c_int, [_vp, _i32, _i32, _vp]),
-    "pr_f16_order_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pr_f16_order_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pr_widen_scores_dev": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "pr_merge_topk_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "pr_group_create": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),

@@ -77,7 +77,7 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
                    double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
-                   float* score32, const double* cand_sc32, double eps_d = 0.0, double* cand_part = nullptr);   // cand_part [m][kin]: the channel-0 share of every evaluated score (order check of PR_SC_ARITH_F16); cand_sc32: the candidates' all-pairs-pass scores (ascending) or null: prunes hopeless candidates; eps_d: that pass's distance error bound (0: the fp32-grade 1e-6 with a 64x margin)
+                   float* score32, const double* cand_sc32, double eps_d = 0.0, double* cand_part = nullptr);   // cand_part [m][4][kin]: the channel z-scores of every evaluated candidate (order check of PR_SC_ARITH_F16); cand_sc32: the candidates' all-pairs-pass scores (ascending) or null: prunes hopeless candidates; eps_d: that pass's distance error bound (0: the fp32-grade 1e-6 with a 64x margin)
 // the sharded form: scores of the candidates THIS shard owns (NaN elsewhere), then owner-wise combination + selection
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
@@ -88,9 +88,11 @@ void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom
                          const double* cand_sc, int k, const double* score, double eps_d, int32_t* flags, int32_t* count,
                          const int32_t* order_flags = nullptr);
 // PR_SC_ARITH_F16: flags[q] = 1 where the order of the re-evaluated candidates (the selected k and the best one left out) could change
-// under a relative error eps_sigma of the pass's row sigmas; score_all / part_all [G][m][kin], NaN where the shard is not the owner
-void launch_order_check(hipStream_t st, const int32_t* cand_idx, const double* score_all, const double* part_all, int G, int m, int kin, int k,
-                        const int32_t* idx_sel, double eps_sigma, int32_t* flags);
+// under the sigma error of the single-product pass (per channel max(eps_floor, 4 noise / (sigma sqrt(n - 1))), statistics from mom_*
+// [Gmom][m][2][3]); score_all [G][m][kin] / part_all [G][m][4][kin], NaN where the shard is not the owner
+void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int Gmom, const int32_t* cand_idx, const double* score_all,
+                        const double* part_all, int G, int m, int kin, int k, const int32_t* idx_sel, double eps_floor, double noise,
+                        int32_t* flags);
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,
                           double* score);
 void launch_widen(hipStream_t st, const float* a, long long n, double* b);

@@ -685,13 +685,14 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
   if (int rc = set_device(ctx)) return rc;
   const size_t need = (size_t)m * k_in;
   const bool f16 = ctx->sc_mode == PR_SC_ARITH_F16;             // the order of the re-evaluated candidates is checked too (pr_f16_margin_dev)
-  if (int rc = rerank_scratch(ctx, f16 ? 2 * need : need, m)) return rc;
+  if (int rc = rerank_scratch(ctx, f16 ? 5 * need : need, m)) return rc;
   double* parts = f16 ? ctx->rr_scratch + need : nullptr;
   ctx->parts_count = 0;
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
                     p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in, pass_eps(ctx), parts);
   if (f16) {
-    pr::launch_order_check(ctx->stream, idx_in, ctx->rr_scratch, parts, 1, m, k_in, k, idx, PR_F16_SIGMA_REL, ctx->d_order);
+    pr::launch_order_check(ctx->stream, mom_sc, mom_m2, G, idx_in, ctx->rr_scratch, parts, 1, m, k_in, k, idx, PR_F16_SIGMA_REL, PR_F16_NOISE,
+                           ctx->d_order);
     ctx->order_m = m;
   }
   PR_HIP(ctx, hipGetLastError());
@@ -711,17 +712,17 @@ int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int 
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   const bool f16 = ctx->sc_mode == PR_SC_ARITH_F16;             // the channel-0 parts stay in the context for pr_rerank_parts_dev
-  if (f16) { if (int rc = rerank_scratch(ctx, (size_t)m * k_in, m)) return rc; }
+  if (f16) { if (int rc = rerank_scratch(ctx, (size_t)4 * m * k_in, m)) return rc; }
   pr::launch_rerank_partial(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0,
                             mask_width, p_weight, k_in, cand_idx, part, cand_score, k, pass_eps(ctx), f16 ? ctx->rr_scratch : nullptr);
-  ctx->parts_count = f16 ? (size_t)m * k_in : 0;
+  ctx->parts_count = f16 ? (size_t)4 * m * k_in : 0;
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
 
 int pr_rerank_parts_dev(pr_ctx* ctx, int32_t m, int32_t k_in, double* parts) {
   if (!ctx) return PR_EINVAL;
-  if (!parts || m < 0 || k_in < 1 || (size_t)m * k_in != ctx->parts_count)
+  if (!parts || m < 0 || k_in < 1 || (size_t)4 * m * k_in != ctx->parts_count)
     PR_FAIL(ctx, PR_EINVAL, "pr_rerank_parts_dev: no parts of a [%d][%d] pr_rerank_partial_dev call in PR_SC_ARITH_F16 on this context", m, k_in);
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
@@ -729,15 +730,16 @@ int pr_rerank_parts_dev(pr_ctx* ctx, int32_t m, int32_t k_in, double* parts) {
   return PR_OK;
 }
 
-int pr_f16_order_dev(pr_ctx* ctx, const int32_t* cand_idx, const double* score_all, const double* parts_all, int32_t G, int32_t m, int32_t k_in,
-                     int32_t k, const int32_t* idx) {
+int pr_f16_order_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t G_mom, const int32_t* cand_idx, const double* score_all,
+                     const double* parts_all, int32_t G, int32_t m, int32_t k_in, int32_t k, const int32_t* idx) {
   if (!ctx) return PR_EINVAL;
-  if (!cand_idx || !score_all || !parts_all || !idx || G < 1 || m < 0 || k < 1 || k_in < k || k_in > 128)
+  if ((!mom_sc && !mom_m2) || !cand_idx || !score_all || !parts_all || !idx || G < 1 || G > 254 || G_mom < 1 || m < 0 || k < 1 || k_in < k || k_in > 128)
     PR_FAIL(ctx, PR_EINVAL, "pr_f16_order_dev: bad arguments (G=%d, m=%d, k=%d, k_in=%d)", G, m, k, k_in);
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   if (int rc = rerank_scratch(ctx, 0, m)) return rc;
-  pr::launch_order_check(ctx->stream, cand_idx, score_all, parts_all, G, m, k_in, k, idx, PR_F16_SIGMA_REL, ctx->d_order);
+  pr::launch_order_check(ctx->stream, mom_sc, mom_m2, G_mom, cand_idx, score_all, parts_all, G, m, k_in, k, idx, PR_F16_SIGMA_REL, PR_F16_NOISE,
+                         ctx->d_order);
   ctx->order_m = m;
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;

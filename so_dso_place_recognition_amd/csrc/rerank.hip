@@ -162,7 +162,7 @@ struct RerankArgs {
   double p_weight;
   const double* cand_sc; int k;                                 // fp32-pass scores of the candidates [m][kin], ascending, or null; the k wanted
   double eps_d, eps_mult;                                       // distance error bound of the all-pairs pass per channel, and the safety factor on it
-  double* cand_part;                                            // [m][kin] or null: the weighted structure / count-channel z-scores of the evaluated candidates (order_check_kernel)
+  double* cand_part;                                            // [m][4][kin] or null: the four weighted channel z-scores (SC structure, SC intensity, M2DP count, M2DP intensity; 0 for an absent type) of every evaluated candidate, NaN in [0] otherwise (order_check_kernel)
 };
 
 // |all-pairs-pass score - exact score| <= this for a pair whose exact score is s, given the row statistics: distance error eps_d per
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
   const int tid = threadIdx.x, q = blockIdx.x / A.kin, t = blockIdx.x % A.kin;
   const int jg = idx_in[(size_t)q * A.kin + t];
   double* out = cand_score + (size_t)q * A.kin + t;
-  if (A.cand_part && tid == 0) A.cand_part[(size_t)q * A.kin + t] = __builtin_nan("");   // stays NaN unless the pair is evaluated
+  if (A.cand_part && tid < 4) A.cand_part[((size_t)q * 4 + tid) * A.kin + t] = __builtin_nan("");   // stays NaN unless the pair is evaluated (tid 0 overwrites its own store below: program order)
   if (jg < 0) { if (tid == 0) *out = __builtin_nan(""); return; }
   int dij = (A.q_row0 + q) - jg;
   if (dij < 0) dij = -dij;
@@ -214,16 +214,15 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
     const double delta = A.eps_mult * score_err_bound(A.eps_d, w, sk, cn);
     if (st > sk + delta) { if (tid == 0) *out = st; return; }   // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
   }
-  double f = 0.0, fp = 0.0;                                     // fp: the channel-0 terms alone (weight p)
+  double f = 0.0, z4[4] = {0.0, 0.0, 0.0, 0.0};
   if (A.q_sc) {
     for (int ch = 0; ch < 2; ch++) {
       const double d = sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + ch * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + ch * 1200,
                                      buf, red, tid);
       double mean, sd;
       chan_combine(A.mom_sc, A.G, A.m, q, ch, mean, sd);
-      const double z = (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);    // run_test.m:40
-      f += z;
-      if (ch == 0) fp += z;
+      z4[ch] = (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);    // run_test.m:40
+      f += z4[ch];
     }
   }
   if (A.q_m2) {
@@ -231,15 +230,12 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
       const double d = m2dp_pair_exact(A.q_m2, A.m2_dt, (size_t)q * 4 * 384, A.db_m2, A.m2_dt, (size_t)jl * 4 * 384, ch, red, tid);
       double mean, sd;
       chan_combine(A.mom_m2, A.G, A.m, q, ch, mean, sd);
-      const double z = (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);
-      f += z;
-      if (ch == 0) fp += z;
+      z4[2 + ch] = (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);
+      f += z4[2 + ch];
     }
   }
-  if (tid == 0) {
-    *out = f;
-    if (A.cand_part) A.cand_part[(size_t)q * A.kin + t] = fp;
-  }
+  if (tid == 0) *out = f;
+  if (A.cand_part && tid < 4) A.cand_part[((size_t)q * 4 + tid) * A.kin + t] = z4[tid];    // (every thread holds the reduced values)
 }
 
 __device__ double row_weight(const double* mom_sc, const double* mom_m2, int G, int m, int q, double p_weight, double* cn_out) {
@@ -370,31 +366,46 @@ __global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __rest
   select_k(ci, cs, kin, k, idx + (size_t)q * k, score + (size_t)q * k, nullptr);
 }
 
-// PR_SC_ARITH_F16: is the ORDER of the re-evaluated candidates certain?  Their exact scores are s = P + I with the pair's distances exact
-// (fp64) but the row statistics those of the single-product pass: P (cand_part, the weight-p channel-0 z-scores) scales with 1 / sigma_p,
-// I = s - P with 1 / sigma_i, and the pass's sigmas are off by a relative eps_sigma at most (PR_F16_SIGMA_REL).  Two candidates a, b with
-// s_a <= s_b keep that order under the true sigmas if  s_b - s_a > eps_sigma (|P_b - P_a| + |I_b - I_a|)  (always true when both channels
-// agree on the order); walking the selected k and the best candidate left out, every ADJACENT pair must pass - then the whole chain is in
-// its true order and the k-th / (k+1)-th boundary is the true one.  Pairs with equal P and equal I (duplicated signatures) are ordered by
-// index and certain; candidates that were not evaluated (pruned: their pass score is beyond the k-th by more than the pass's error) are
-// certain by that bound.  Anything else flags the query for the split-f16 pass.  One thread per query; score_all / part_all [G][m][kin]
-// hold a value at the candidate's owner and NaN elsewhere (G = 1: the scratch arrays of pr_rerank_dev).
-__global__ __launch_bounds__(64) void order_check_kernel(const int32_t* __restrict__ cand_idx, const double* __restrict__ score_all,
+// PR_SC_ARITH_F16: is the ORDER of the re-evaluated candidates certain?  Their exact scores are s = sum_c z_c over the (two or four)
+// channels with the pair's distances exact (fp64) but the row statistics those of the single-product pass: z_c scales with 1 / sigma_c,
+// and the pass's sigma_c is off by a relative eps_c.  Two candidates a, b with s_a <= s_b keep that order under the true sigmas if
+//      s_b - s_a > sum_c eps_c |z_c(b) - z_c(a)|
+// (always true when all channels agree on the order; the means shift both alike).  Walking the selected k and the best candidate left
+// out, every ADJACENT pair must pass - then the whole chain is in its true order and the k-th / (k+1)-th boundary is the true one.
+// eps_c: the pass's distance noise e (rms nu ~ 3e-5, |e| < 1.3e-4 observed) enters sigma^2 as (2 / n) sum (d_j - mu) e_j, i.e. a relative
+// nu / (sigma_c sqrt(n)) on sigma - 1e-4 at n = 10^4, 1e-2 on a row of 24 - so eps_c = max(PR_F16_SIGMA_REL, 4 PR_F16_NOISE / (sigma_c
+// sqrt(n - 1))) with PR_F16_NOISE = 1e-4 (include/place_recognition.h).  Pairs equal in every channel (duplicated signatures) are ordered
+// by index and certain; candidates that were not evaluated (pruned: their pass score is beyond the k-th by more than the pass's error)
+// are certain by that bound.  Anything else flags the query for the split-f16 pass.  One thread per query; score_all [G][m][kin] /
+// part_all [G][m][4][kin] hold values at the candidate's owner, NaN elsewhere (G = 1: the scratch arrays of pr_rerank_dev).
+__global__ __launch_bounds__(64) void order_check_kernel(const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int Gmom,
+                                                          const int32_t* __restrict__ cand_idx, const double* __restrict__ score_all,
                                                           const double* __restrict__ part_all, int G, int m, int kin, int k,
-                                                          const int32_t* __restrict__ idx_sel, double eps_sigma, int32_t* __restrict__ flags) {
+                                                          const int32_t* __restrict__ idx_sel, double eps_floor, double noise,
+                                                          int32_t* __restrict__ flags) {
   const int q = blockIdx.x * 64 + threadIdx.x;
   if (q >= m) return;
+  double eps[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int c = 0; c < 4; c++) {
+    const double* mom = c < 2 ? mom_sc : mom_m2;
+    if (!mom) continue;
+    double mean, sd, cn = 2.0;
+    chan_combine(mom, Gmom, m, q, c & 1, mean, sd, &cn);
+    const double e = 4.0 * noise / (sd * sqrt(fmax(cn - 1.0, 1.0)));
+    eps[c] = (e == e) ? fmax(eps_floor, e) : 1.0;             // (sigma = 0 or NaN: nothing about the order is certain)
+  }
   int32_t ci[128];
-  double cs[128], cp[128];
+  double cs[128];
+  unsigned char own[128];                                      // shard that evaluated the candidate, 255: nobody
   for (int t = 0; t < kin; t++) {
     ci[t] = cand_idx[(size_t)q * kin + t];
-    double v = __builtin_nan(""), pv = __builtin_nan("");
+    double v = __builtin_nan("");
+    own[t] = 255;
     for (int g = 0; g < G; g++) {
-      const size_t o = ((size_t)g * m + q) * kin + t;
-      const double x = score_all[o];
-      if (x == x) { v = x; pv = part_all[o]; break; }
+      const double x = score_all[((size_t)g * m + q) * kin + t];
+      if (x == x) { v = x; own[t] = (unsigned char)g; break; }
     }
-    cs[t] = v; cp[t] = pv;
+    cs[t] = v;
   }
   int flag = 0, prev = -1;
   for (int t = 0; t <= k && !flag; t++) {
@@ -413,10 +424,17 @@ __global__ __launch_bounds__(64) void order_check_kernel(const int32_t* __restri
       }
     }
     if (cur < 0) break;
-    if (prev >= 0 && cp[prev] == cp[prev] && cp[cur] == cp[cur]) {   // both evaluated (masked pairs are +Inf with a NaN part)
-      const double ds = cs[cur] - cs[prev], dp = cp[cur] - cp[prev], di = ds - dp;
-      const double span = fabs(dp) + fabs(di);
-      if (span > 0.0 && !(ds > eps_sigma * span)) flag = 1;
+    if (prev >= 0 && own[prev] != 255 && own[cur] != 255) {
+      const double* pa = part_all + (((size_t)own[prev] * m + q) * 4) * kin + prev;
+      const double* pb = part_all + (((size_t)own[cur] * m + q) * 4) * kin + cur;
+      if (pa[0] == pa[0] && pb[0] == pb[0]) {                  // both evaluated (masked pairs are +Inf, pruned ones keep their pass score: NaN parts)
+        double lim = 0.0, span = 0.0;
+        for (int c = 0; c < 4; c++) {
+          const double dz = fabs(pb[(size_t)c * kin] - pa[(size_t)c * kin]);
+          lim += eps[c] * dz; span += dz;
+        }
+        if (span > 0.0 && !(cs[cur] - cs[prev] > lim)) flag = 1;
+      }
     }
     prev = cur;
   }
@@ -496,11 +514,12 @@ void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom
                      flags, count, order_flags);
 }
 
-void launch_order_check(hipStream_t st, const int32_t* cand_idx, const double* score_all, const double* part_all, int G, int m, int kin, int k,
-                        const int32_t* idx_sel, double eps_sigma, int32_t* flags) {
+void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int Gmom, const int32_t* cand_idx, const double* score_all,
+                        const double* part_all, int G, int m, int kin, int k, const int32_t* idx_sel, double eps_floor, double noise,
+                        int32_t* flags) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(order_check_kernel, dim3((m + 63) / 64), dim3(64), 0, st, cand_idx, score_all, part_all, G, m, kin, k, idx_sel, eps_sigma,
-                     flags);
+  hipLaunchKernelGGL(order_check_kernel, dim3((m + 63) / 64), dim3(64), 0, st, mom_sc, mom_m2, Gmom, cand_idx, score_all, part_all, G, m, kin, k,
+                     idx_sel, eps_floor, noise, flags);
 }
 
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,

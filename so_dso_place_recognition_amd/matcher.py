@@ -243,7 +243,8 @@ class Matcher(_Base):
         return idx, score
 
     def finish(self, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int):
-        return _finish_dev(self, cand_idx, part_all, k)
+        sc = self.type == _lib.TYPE_SC
+        return _finish_dev(self, cand_idx, part_all, k, (self._mom_all if sc else None, None if sc else self._mom_all, self._args[0]))
 
     def local_phase2(self, mom_all: torch.Tensor, G: int, mask_width, p_weight, k, db_row0, q_row0):
         """Selection + re-evaluation of this shard alone -> its own top-k (what rank g would answer by itself)."""
@@ -406,7 +407,7 @@ class FusedMatcher(_Base):
         return idx, score
 
     def finish(self, cand_idx, part_all, k):
-        return _finish_dev(self, cand_idx, part_all, k)
+        return _finish_dev(self, cand_idx, part_all, k, (self._m1, self._m2, self._args[0]))
 
     def local_phase2(self, mom_all, G, mask_width, p_weight, k, db_row0, q_row0):
         idx_in, sc = self.local_select(mom_all, G, mask_width, p_weight, k, db_row0, q_row0)
@@ -459,25 +460,27 @@ def _merge_dev(owner, idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
 
 
 def _with_parts(owner, part: torch.Tensor) -> torch.Tensor:
-    """PR_SC_ARITH_F16: the partial scores [m, kin] travel with their channel-0 parts (pr_rerank_parts_dev) as [m, 2, kin], so that the
-    order check after the finish (pr_f16_order_dev) sees them for every shard's candidates; other arithmetics: unchanged."""
+    """PR_SC_ARITH_F16: the partial scores [m, kin] travel with their four channel z-scores (pr_rerank_parts_dev, [m, 4, kin]) as one
+    [m, 5, kin] tensor, so that the order check after the finish (pr_f16_order_dev) sees them for every shard's candidates; other
+    arithmetics: unchanged."""
     if owner.ctx.sc_arith != "f16":
         return part
     m, kin = part.shape
-    both = torch.empty((m, 2, kin), dtype=torch.float64, device=part.device)
-    both[:, 0] = part
-    parts = torch.empty((m, kin), dtype=torch.float64, device=part.device)
+    both = torch.empty((m, 5, kin), dtype=torch.float64, device=part.device)
+    parts = torch.empty((m, 4, kin), dtype=torch.float64, device=part.device)
     owner.ctx.check(owner.lib.pr_rerank_parts_dev(owner.ctx.h, m, kin, _dptr(parts)))
-    both[:, 1] = parts
+    both[:, 0] = part
+    both[:, 1:] = parts
     return both
 
 
-def _finish_dev(owner, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int):
+def _finish_dev(owner, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int, moms=None):
     """pr_rerank_finish_dev: candidates [m, kin] + the shards' partial scores [G, m, kin] -> (idx [m,k], score [m,k]).
-    PR_SC_ARITH_F16: part_all is [G, m, 2, kin] (_with_parts) and the order of the result is checked (pr_f16_order_dev)."""
+    PR_SC_ARITH_F16: part_all is [G, m, 5, kin] (_with_parts) and the order of the result is checked (pr_f16_order_dev) with the row
+    statistics moms = (mom_sc | None, mom_m2 | None, shards in them)."""
     parts_all = None
     if part_all.dim() == 4:
-        parts_all = part_all[:, :, 1].contiguous()
+        parts_all = part_all[:, :, 1:].contiguous()
         part_all = part_all[:, :, 0].contiguous()
     G, m, kin = part_all.shape
     idx = torch.empty((m, k), dtype=torch.int32, device=cand_idx.device)
@@ -487,7 +490,9 @@ def _finish_dev(owner, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int):
     owner._enter()
     owner.ctx.check(owner.lib.pr_rerank_finish_dev(owner.ctx.h, _dptr(cand_idx), _dptr(part_all), G, m, kin, k, _dptr(idx), _dptr(score)))
     if parts_all is not None:
-        owner.ctx.check(owner.lib.pr_f16_order_dev(owner.ctx.h, _dptr(cand_idx), _dptr(part_all), _dptr(parts_all), G, m, kin, k, _dptr(idx)))
+        mom_sc, mom_m2, g_mom = moms
+        owner.ctx.check(owner.lib.pr_f16_order_dev(owner.ctx.h, _dptr(mom_sc), _dptr(mom_m2), int(g_mom), _dptr(cand_idx), _dptr(part_all),
+                                                   _dptr(parts_all), G, m, kin, k, _dptr(idx)))
     owner._leave()
     return idx, score
 

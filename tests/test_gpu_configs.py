@@ -141,7 +141,9 @@ def _sharded_run(make_matcher, shards, pack, phase1_args, mask, k):
     kin = sel[0][0].shape[1]
     cand, _ = ms[0].merge(torch.stack([p[0] for p in sel]), torch.stack([p[1] for p in sel]), kin)
     part_all = torch.stack([mt.local_rerank(cand, k, True).clone() for mt in ms])
-    assert (torch.isnan(part_all).sum(0) == G - 1).all() or mask > 0          # exactly one owner per candidate (masked pairs: +Inf everywhere)
+    # exactly one owner per candidate (masked pairs: +Inf everywhere); PR_SC_ARITH_F16: [G, m, 5, kin] - scores + the four channel parts
+    assert (torch.isnan(part_all).sum(0) == G - 1).all() or mask > 0 or part_all.dim() == 4
+    assert part_all.dim() == 3 or (torch.isnan(part_all[:, :, 0]).sum(0) == G - 1).all() or mask > 0
     idx, sc = ms[0].finish(cand, part_all, k)
     per = [tuple(t.clone() for t in mt.local_rerank(a, k, False)) for mt, (a, b) in zip(ms, sel)]
     return ms, per, idx.cpu().numpy(), sc.cpu().numpy()
