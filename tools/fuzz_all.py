@@ -1,7 +1,7 @@
 """Wide random parity sweep against the CPU oracle (GPU box): every matcher entry point (host calls, pr_group with virtual shards, the
 device-resident Matcher / FusedMatcher), the three SC arithmetics, k up to 60, wide masks, zero-norm rows, duplicated rows (exact ties),
 ragged shapes; and the three generators on ragged batches with empty / one-point / collinear clouds.
-usage: python tools/fuzz_all.py [seed] [cases] [what: match,group,matcher,fused,gen]
+usage: python tools/fuzz_all.py [seed] [cases] [what: match,group,matcher,fused,gen[,big]]   (big: rows of 16k - 130k entries, 1 - 40 queries)
 Prints one line per case; exits 1 if any case differed (indices must be equal, scores inside tests/helpers.score_tol)."""
 import sys
 import time
@@ -19,11 +19,21 @@ rng = np.random.default_rng(seed)
 bad = []
 
 
+BIG = "big" in what          # long rows, few queries: the sliced moments / selection / merge of an online call, many shards
+what.discard("big")
+
+
 def shapes():
-    m = int(rng.choice([rng.integers(1, 9), rng.integers(9, 70), rng.integers(70, 300)]))
-    n = int(rng.choice([rng.integers(2, 40), rng.integers(40, 700), rng.integers(700, 5000)]))
-    while m * n > 250_000:
-        m = max(1, m // 2)
+    if BIG:
+        m = int(rng.choice([1, 1, 2, rng.integers(3, 9), rng.integers(9, 40)]))
+        n = int(rng.choice([rng.integers(16384, 40000), rng.integers(40000, 130000)]))
+        while m * n > 600_000:
+            m = max(1, m // 2)
+    else:
+        m = int(rng.choice([rng.integers(1, 9), rng.integers(9, 70), rng.integers(70, 300)]))
+        n = int(rng.choice([rng.integers(2, 40), rng.integers(40, 700), rng.integers(700, 5000)]))
+        while m * n > 250_000:
+            m = max(1, m // 2)
     k = int(min(n, rng.choice([1, 1, rng.integers(2, 6), rng.integers(6, 61)])))
     mask = int(rng.choice([0, 0, rng.integers(1, 6), rng.integers(6, 160)]))
     return m, n, k, mask
@@ -100,7 +110,7 @@ for it in range(cases):
                     ctx.close()
                     line.append(f"{type_}/{arith}:{'ok' if ok else 'BAD'}")
             if "group" in what and n >= 8 * div:
-                G = int(rng.integers(2, 5))
+                G = int(rng.integers(2, 9 if BIG else 5))
                 g = api.Group([0] * G)
                 g.set_database(type_, db)
                 idx, sc = g.match_topk(q, mask, 2.0, k)
