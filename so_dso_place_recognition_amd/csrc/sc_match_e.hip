@@ -21,6 +21,29 @@
 //    8 query groups of the compact image (SCF_*: 64 queries in 160 KB of LDS); for m <= 8 (an online call) all eight waves share ONE query
 //    group and split the DB groups (NQG = 1: 20 KB of LDS, several workgroups per CU, 0.11 ms per 100k-entry DB = 5.3 TB/s).
 #include "kernels.hpp"
+// Split-f16 form, register placement (round 3): one wave per SIMD owns 256 ArchVGPRs + 256 AccVGPRs, and everything an MFMA only READS can
+// live in the AccVGPR half without ever passing through a VALU instruction: vector-memory and LDS loads write AccVGPRs directly and MFMAs
+// take A / B operands from there.  So the DB operand ring (E_BACC), the query operand ring (E_AACC) and the stage-2 constants are loaded
+// straight into AccVGPRs (hipcc does this by itself once every reader of the loaded value is an asm operand with an "a" constraint) - 136
+// ArchVGPRs free, which (a) lets the rings run deeper (5 / 3 walk positions instead of 4 / 2), (b) keeps the first half's hi operand
+// tuples and the lo tuples of register 0 in ArchVGPRs - 48 v_accvgpr_write per unit instead of 128 - and (c) leaves hipcc no reason to
+// shuffle values through AccVGPRs on its own (it had parked 16 registers and restored them right in front of asm MFMAs).  Measured
+// (alternating runs, three boxes): 40.3 -> 39.1, 41.2 -> 39.6, 41.5 -> 39.9 ms per 4096 x 100k launch (-3.9 %); -DE_NO_ACC_OPERANDS builds the
+// previous placement.
+#ifndef E_NO_ACC_OPERANDS
+#define E_BACC
+#define E_AACC
+#define E_SPLIT3
+#ifndef E_BD
+#define E_BD 5
+#endif
+#ifndef E_AD
+#define E_AD 3
+#endif
+#ifndef E_PARKR
+#define E_PARKR 1
+#endif
+#endif
 #ifndef E_BD
 #define E_BD 4          // depth of the DB operand ring, split-f16 form
 #endif
@@ -63,22 +86,56 @@ __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int v
 
 // MFMAs as asm statements (VGPR form; hipcc pads nothing around asm, cdna_hip_programming.md §5.7): every VALU reader of a result sits
 // behind a DRAIN() or at least two further MFMAs + their fillers
-#define MF0(d, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b))
-#define MFA(d, a, b) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b))
-#define M32Z(d, a, b, BC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : "v"(a), BC(b))
-#define M32A(d, a, b, BC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : "v"(a), BC(b))
+#define MF0_(d, a, b, AC, BC) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, 0" : "=&v"(d) : AC(a), BC(b))
+#define MFA_(d, a, b, AC, BC) asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(d) : AC(a), BC(b))
+#ifdef E_BACC      // split-f16 form: DB operands loaded straight into AccVGPRs (one wave per SIMD: the AccVGPR half is otherwise idle)
+#ifdef E_AACC      // ... and the query operands
+#define E_AC "a"
+#else
+#define E_AC "v"
+#endif
+#define MF0(d, a, b) { if constexpr (LO) MF0_(d, a, b, E_AC, "a"); else MF0_(d, a, b, "v", "v"); }
+#define MFA(d, a, b) { if constexpr (LO) MFA_(d, a, b, E_AC, "a"); else MFA_(d, a, b, "v", "v"); }
+#else
+#define MF0(d, a, b) MF0_(d, a, b, "v", "v")
+#define MFA(d, a, b) MFA_(d, a, b, "v", "v")
+#endif
+#ifndef E_AD
+#define E_AD 2
+#endif
+#ifndef E_PARKR
+#define E_PARKR 0
+#endif
+#ifdef E_BACC      // (split-f16 form) the stage-2 constants are loaded into AccVGPRs as well
+#define E_CC "a"
+#else
+#define E_CC "v"
+#endif
+#define M32Z_(d, a, b, AC, BC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, 0" : "=&v"(d) : AC(a), BC(b))
+#define M32A_(d, a, b, AC, BC) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(d) : AC(a), BC(b))
+#define M32Z(d, a, b, BC) { if constexpr (LO) M32Z_(d, a, b, E_CC, BC); else M32Z_(d, a, b, "v", BC); }
+#define M32A(d, a, b, BC) { if constexpr (LO) M32A_(d, a, b, E_CC, BC); else M32A_(d, a, b, "v", BC); }
 #define DRAIN() asm volatile("s_nop 9")
 #define SB() __builtin_amdgcn_sched_barrier(0)
 
 __device__ __forceinline__ void split2(float x, float y, unsigned& hi, unsigned& lo) {   // see sc_match_h.hip
   const f32x2 v = {x, y};
   hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+#ifdef E_SPLIT3   // the conversion of the residuals inside the asm: hipcc pads an s_nop between an asm result and its first reader (110 per unit)
+  float r0, r1;
+  asm volatile("v_fma_mix_f32 %1, %3, -1.0, %4 op_sel_hi:[1,0,0]\n\t"      // volatile: stays where the schedule puts it (no PIN(lo) behind it)
+      "v_fma_mix_f32 %2, %3, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\t"
+      "v_cvt_pk_f16_f32 %0, %1, %2"
+      : "=v"(lo), "=&v"(r0), "=&v"(r1)
+      : "v"(hi), "v"(x), "v"(y));
+#else
   f32x2 r;
   asm("v_fma_mix_f32 %0, %2, -1.0, %3 op_sel_hi:[1,0,0]\n\t"
       "v_fma_mix_f32 %1, %2, -1.0, %4 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
       : "=&v"(r[0]), "=&v"(r[1])
       : "v"(hi), "v"(x), "v"(y));
   lo = __builtin_bit_cast(unsigned, __builtin_convertvector(r, f16x2));
+#endif
 }
 __device__ __forceinline__ unsigned pack2(float x, float y) {
   const f32x2 v = {x, y};
@@ -122,8 +179,13 @@ __device__ __forceinline__ void s2_one(const Half<LO>& h0, const Half<LO>& h1, c
                          : (V ? (T == 2 ? h.reMl[LO ? R : 0] : h.reMh[R]) : (T == 2 ? h.reFl[LO ? R : 0] : h.reFh[R]));
   f32x16& d = PART ? o : e;
   // PARK: the first half's operands live in AccVGPRs (parked there by park_half, read by the MFMA directly)
-  if constexpr (PARK && HF == 0) { if (I < 2) M32Z(d, ca, op, "a"); else M32A(d, ca, op, "a"); }
-  else { if (I < 2) M32Z(d, ca, op, "v"); else M32A(d, ca, op, "v"); }
+#ifdef E_BACC
+  constexpr bool in_acc = PARK && HF == 0 && T == 2 && R >= E_PARKR;   // only the lo tuples of the first half (registers E_PARKR..3) are parked
+#else
+  constexpr bool in_acc = PARK && HF == 0;
+#endif
+  if constexpr (in_acc) { if constexpr (I < 2) { M32Z(d, ca, op, "a"); } else { M32A(d, ca, op, "a"); } }
+  else { if constexpr (I < 2) { M32Z(d, ca, op, "v"); } else { M32A(d, ca, op, "v"); } }
 }
 // parks the operand tuples of a finished half in AccVGPRs (an empty asm whose operand must be an AccVGPR tuple: one v_accvgpr_write per
 // register, placed by hipcc right here)
@@ -131,8 +193,12 @@ template <bool LO>
 __device__ __forceinline__ void park_half(Half<LO>& h) {
 #pragma unroll
   for (int r = 0; r < 4; r++) {
+#ifndef E_BACC
     asm volatile("" : "+a"(h.reFh[r]), "+a"(h.imFh[r]), "+a"(h.reMh[r]), "+a"(h.imMh[r]));
     if constexpr (LO) asm volatile("" : "+a"(h.reFl[r]), "+a"(h.imFl[r]), "+a"(h.reMl[r]), "+a"(h.imMl[r]));
+#else
+    if (LO && r >= E_PARKR) asm volatile("" : "+a"(h.reFl[r]), "+a"(h.imFl[r]), "+a"(h.reMl[r]), "+a"(h.imMl[r]));
+#endif
   }
 }
 // one step of the reduction of a finished (E, O) tile pair: shift rows 2 i, 2 i + 1
@@ -170,7 +236,11 @@ template <bool LO, int E, int R, int KIND>
 __device__ __forceinline__ void split_piece(Half<LO>& hb, const f32x4 (&t)[8]) {
   constexpr int ia = KIND == 0 ? 0 : KIND == 1 ? 2 : KIND == 2 ? 3 : 1;     // Re S: t1a|t1c, Im S: t1b|t1d, Re P: t2b|t2d, Im P: t2a|t2c
   unsigned h, l = 0;
+#ifdef E_SPLIT3
+  if constexpr (LO) { split2(t[ia][R], t[ia + 4][R], h, l); }
+#else
   if constexpr (LO) { split2(t[ia][R], t[ia + 4][R], h, l); PIN(h); PIN(l); }
+#endif
   else { h = pack2(t[ia][R], t[ia + 4][R]); PIN(h); }
   if constexpr (KIND == 0) { hb.reFh[R][E] = h; if constexpr (LO) hb.reFl[R][E] = l; }
   if constexpr (KIND == 1) { hb.imFh[R][E] = h; if constexpr (LO) hb.imFl[R][E] = l; }
@@ -236,7 +306,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   constexpr int GSTEP = NW / NQG;
   const int gcnt = g1 - g0;
   constexpr int BD = LO ? E_BD : E_BD1;            // depth of the DB operand ring: the tiles of BD - 1 walk positions are in flight
-  constexpr int AD = LO ? 2 : 3;                   // the same for the query tiles
+  constexpr int AD = LO ? E_AD : 3;                // the same for the query tiles
   const unsigned nat0 = lds0 + wq * QIMG + row * QROW + (row >= 8 ? 8 : 0) + kg * 16;
   const int voff = (lane < 48) ? lane * 16 : (int)0x80000000;     // lanes 48-63: out of range -> zeros (K = 24..31)
   float* dist = ch ? dist_i : dist_p;
