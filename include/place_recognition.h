@@ -37,12 +37,14 @@ enum { PR_HOST = 0, PR_DEVICE = 1 };
 #define PR_F16_DISTANCE_BOUND 2e-3   /* |d_f16 - d| per channel: 8 u (u = 2^-11) on the correlation of unit-norm rows, halved */
 #define PR_F16_SIGMA_REL 2e-4        /* order check: floor of the relative error allowed for a row sigma of the f16 pass ... */
 #define PR_F16_NOISE 1e-4            /* ... which is max(floor, 4 PR_F16_NOISE / (sigma sqrt(n - 1))): rms distance noise of the pass, 3 x the observed 3e-5 */
+#define PR_F32_SIGMA_REL 5e-7        /* the same for the split-f16 / fp32 passes: sigma is off by 2.5e-7 relative whatever the row length ... */
+#define PR_F32_NOISE 1e-7            /* ... and their distance noise is 2.5e-8 rms, 1.3e-7 at most */
 enum { PR_SC_ARITH_F16X2 = 0, PR_SC_ARITH_F32 = 1, PR_SC_ARITH_F16 = 2 };
 /* What a zero-norm SC row does.  MATLAB divides 0/0 (processSC.m:16,19): every distance to or from that signature is NaN, and
  * normalize(.,2) / min (run_test.m:40,57) leave NaNs out [normalize's 'omitnan' from memory], so the signature simply never matches.
  * PR_NAN_EXCLUDE (default) does exactly that and reports PR_WARN_NAN_ROWS; PR_NAN_FAIL turns it into the error PR_ENAN at pr_sync. */
 enum { PR_NAN_EXCLUDE = 0, PR_NAN_FAIL = 1 };
-enum { PR_WARN_NAN_ROWS = 1, PR_WARN_M2DP_SVD = 2, PR_WARN_F16_FALLBACK = 4 };   /* bits of pr_take_warnings */
+enum { PR_WARN_NAN_ROWS = 1, PR_WARN_M2DP_SVD = 2, PR_WARN_F16_FALLBACK = 4, PR_WARN_ORDER_RESOLVED = 8 };   /* bits of pr_take_warnings */
 
 #define PR_SC_SIG_LEN 2400    /* 2 x numS*numR = 2 x 60*20, SC/SC.h:7-8, test_sc.cpp:37-38 */
 #define PR_M2DP_SIG_LEN 384   /* 2 x (numP*numQ + numS*numR) = 2 x 192, M2DP/M2DP.h:7-10, test_m2dp.cpp:37-39 */
@@ -204,6 +206,19 @@ int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int 
                           double* part);
 int pr_rerank_finish_dev(pr_ctx* ctx, const int32_t* cand_idx, const double* part_all, int32_t G, int32_t m, int32_t k_in, int32_t k,
                          int32_t* idx, double* score);
+/* Order check in every arithmetic.  pr_rerank_dev leaves in the context one flag per query: set when two neighbours among the re-evaluated
+ * candidates (the selected k and the best one left out) could change places under the sigma error of the all-pairs pass (their channels
+ * disagree about the order and the scores are closer than sum_c eps_c |z_c(a) - z_c(b)|, eps_c = max(PR_F32_SIGMA_REL, 4 PR_F32_NOISE /
+ * (sigma_c sqrt(n - 1))); PR_SC_ARITH_F16: the PR_F16_* constants, and pr_f16_margin_dev takes the flags).  pr_order_resolve_dev - called
+ * right after pr_rerank_dev with the same arguments, single-shard calls (the moments are those of the whole row, db_row0 = 0) - reads the
+ * flags back (it synchronises the stream) and, for every flagged query, evaluates the distances of the query to ALL n entries in fp64,
+ * overwrites the query's row of mom_sc / mom_m2 with the exact (count, mean, M2) and re-evaluates its candidates: indices and scores of
+ * that query are then those of fp64 arithmetic throughout (run_test.m:38-57), ~2.3 ms per flagged query and 100 000 entries.  *resolved
+ * (may be NULL) = number of such queries; PR_WARN_ORDER_RESOLVED is raised when there was one.  The host top-k calls do this by themselves;
+ * for the sharded protocol a flagged query keeps the order of the fp32-statistics scores. */
+int pr_order_resolve_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
+                         double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight, int32_t k_in,
+                         const int32_t* idx_in, const double* score_in, int32_t k, int32_t* idx, double* score, int32_t* resolved);
 /* PR_SC_ARITH_F16, sharded form of the order check: pr_rerank_parts_dev copies the four weighted channel z-scores (SC structure, SC
  * intensity, M2DP count, M2DP intensity; 0 for an absent type) of every candidate the LAST pr_rerank_partial_dev of this context
  * evaluated (parts DEVICE f64 [m][4][k_in], NaN in [q][0][t] for the others); the shards' parts are gathered like their scores

@@ -12,7 +12,7 @@ PR_OK, PR_EINVAL, PR_ENOMEM, PR_EHIP, PR_EIO, PR_ENAN = 0, -1, -2, -3, -4, -5
 TYPE_SC, TYPE_M2DP, TYPE_DELIGHT, TYPE_GIST, TYPE_BOW = 0, 1, 2, 3, 4
 SC_ARITH_F16X2, SC_ARITH_F32, SC_ARITH_F16 = 0, 1, 2
 NAN_EXCLUDE, NAN_FAIL = 0, 1
-WARN_NAN_ROWS, WARN_M2DP_SVD, WARN_F16_FALLBACK = 1, 2, 4
+WARN_NAN_ROWS, WARN_M2DP_SVD, WARN_F16_FALLBACK, WARN_ORDER_RESOLVED = 1, 2, 4, 8
 ROLE_QUERY, ROLE_DB = 0, 1
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
@@ -38,6 +38,8 @@ SYMBOLS = {
     "pr_f16_margin_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _i32, _vp, _vp, _vp]),
     "pr_rerank_finish_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pr_rerank_parts_dev": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "pr_order_resolve_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _i32, _vp, _vp,
+                                       _vp]),
     "pr_f16_order_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pr_widen_scores_dev": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "pr_merge_topk_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),

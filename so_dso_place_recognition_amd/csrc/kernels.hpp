@@ -93,6 +93,9 @@ void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom
 void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int Gmom, const int32_t* cand_idx, const double* score_all,
                         const double* part_all, int G, int m, int kin, int k, const int32_t* idx_sel, double eps_floor, double noise,
                         int32_t* flags);
+// one query row against n entries in fp64 (d64: scratch [4][n]) -> its exact row moments, written over mom_sc / mom_m2 [2][3] (null: type absent)
+void launch_exact_row_moments(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
+                              int n, double* d64, double* mom_sc, double* mom_m2);
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,
                           double* score);
 void launch_widen(hipStream_t st, const float* a, long long n, double* b);

@@ -43,6 +43,8 @@ struct pr_ctx {
   size_t order_cap = 0;
   int32_t order_m = -1;           // rows of d_order that are valid, -1: none
   size_t parts_count = 0;         // entries of rr_scratch that hold the channel-0 parts of the last pr_rerank_partial_dev
+  double* d64 = nullptr;          // [4][d64_cap] exact distances of one query row (pr_order_resolve_dev)
+  size_t d64_cap = 0;
   void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16] (sc_match_h.hip)
   int sc_kernel = 2;             // split-f16 SC matcher for m > 8: 2 = sc_match_e.hip (default); PR_SC_KERNEL=d | h selects sc_match_d.hip (1, the round-2 default) / sc_match_h.hip (0, round 1; always the kernel for m <= 8)
   int sc_mode = PR_SC_ARITH_F16X2;   // PR_SC_ARITH_*: split-f16 MFMA (sc_match_h.hip) | fp32 MFMA (sc_match.hip); PR_SC_MATCH=f32 selects the latter
@@ -270,6 +272,7 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->sc_scratch) (void)hipFree(ctx->sc_scratch);
   if (ctx->rr_scratch) (void)hipFree(ctx->rr_scratch);
   if (ctx->d_order) (void)hipFree(ctx->d_order);
+  if (ctx->d64) (void)hipFree(ctx->d64);
   if (ctx->sel_scratch) (void)hipFree(ctx->sel_scratch);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -684,18 +687,60 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   const size_t need = (size_t)m * k_in;
-  const bool f16 = ctx->sc_mode == PR_SC_ARITH_F16;             // the order of the re-evaluated candidates is checked too (pr_f16_margin_dev)
-  if (int rc = rerank_scratch(ctx, f16 ? 5 * need : need, m)) return rc;
-  double* parts = f16 ? ctx->rr_scratch + need : nullptr;
+  // the order of the re-evaluated candidates is checked too (pr_f16_margin_dev / pr_order_resolve_dev take the flags)
+  const bool f16 = ctx->sc_mode == PR_SC_ARITH_F16;
+  if (int rc = rerank_scratch(ctx, 5 * need, m)) return rc;
+  double* parts = ctx->rr_scratch + need;
   ctx->parts_count = 0;
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
                     p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in, pass_eps(ctx), parts);
-  if (f16) {
-    pr::launch_order_check(ctx->stream, mom_sc, mom_m2, G, idx_in, ctx->rr_scratch, parts, 1, m, k_in, k, idx, PR_F16_SIGMA_REL, PR_F16_NOISE,
-                           ctx->d_order);
-    ctx->order_m = m;
+  pr::launch_order_check(ctx->stream, mom_sc, mom_m2, G, idx_in, ctx->rr_scratch, parts, 1, m, k_in, k, idx, f16 ? PR_F16_SIGMA_REL : PR_F32_SIGMA_REL,
+                         f16 ? PR_F16_NOISE : PR_F32_NOISE, ctx->d_order);
+  ctx->order_m = m;
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+int pr_order_resolve_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
+                         double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight, int32_t k_in,
+                         const int32_t* idx_in, const double* score_in, int32_t k, int32_t* idx, double* score, int32_t* resolved) {
+  if (!ctx) return PR_EINVAL;
+  const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
+  if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !idx_in || !idx || !score || m < 0 || n < 1 ||
+      k < 1 || k_in < k || k_in > 128 || (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
+    PR_FAIL(ctx, PR_EINVAL, "pr_order_resolve_dev: bad arguments (m=%d, n=%d, k=%d, k_in=%d)", m, n, k, k_in);
+  if (resolved) *resolved = 0;
+  if (m == 0 || ctx->order_m != m) { ctx->order_m = -1; return PR_OK; }          // no (fresh) order flags of a call of this size: nothing to do
+  if (int rc = set_device(ctx)) return rc;
+  std::vector<int32_t> fl(m);
+  PR_HIP(ctx, hipMemcpyAsync(fl.data(), ctx->d_order, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->order_m = -1;
+  int cnt = 0;
+  for (int32_t q = 0; q < m; q++) cnt += fl[q] != 0;
+  if (cnt == 0) return PR_OK;
+  if ((size_t)n > ctx->d64_cap) {
+    if (ctx->d64) { PR_HIP(ctx, hipFree(ctx->d64)); ctx->d64 = nullptr; ctx->d64_cap = 0; }
+    PR_HIP(ctx, hipMalloc((void**)&ctx->d64, (size_t)4 * n * sizeof(double)));
+    ctx->d64_cap = (size_t)n;
+  }
+  if (int rc = rerank_scratch(ctx, (size_t)5 * k_in, 1)) return rc;
+  const size_t esc = sc_dtype == PR_F64 ? 8 : 4, em2 = m2_dtype == PR_F64 ? 8 : 4;
+  for (int32_t q = 0; q < m; q++) {
+    if (!fl[q]) continue;
+    const void* qs = sc ? static_cast<const char*>(q_sc) + (size_t)q * 2400 * esc : nullptr;
+    const void* qm = m2 ? static_cast<const char*>(q_m2) + (size_t)q * 4 * 384 * em2 : nullptr;
+    double* ms = sc ? mom_sc + (size_t)q * 6 : nullptr;
+    double* mm = m2 ? mom_m2 + (size_t)q * 6 : nullptr;
+    pr::launch_exact_row_moments(ctx->stream, qs, db_sc, sc_dtype, qm, db_m2, m2_dtype, n, ctx->d64, ms, mm);
+    pr::launch_rerank(ctx->stream, qs, db_sc, sc_dtype, qm, db_m2, m2_dtype, ms, mm, 1, n, 1, q_row0 + q, 0, mask_width, p_weight, k_in,
+                      idx_in + (size_t)q * k_in, ctx->rr_scratch, k, idx + (size_t)q * k, score + (size_t)q * k, nullptr,
+                      score_in ? score_in + (size_t)q * k_in : nullptr, pass_eps(ctx), ctx->rr_scratch + k_in);
   }
   PR_HIP(ctx, hipGetLastError());
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  ctx->warnings |= PR_WARN_ORDER_RESOLVED;
+  if (resolved) *resolved = cnt;
   return PR_OK;
 }
 
@@ -840,6 +885,12 @@ static int f16_fallback(pr_ctx* ctx, const double* hq_sc, const double* hq_m2, c
                          hq_m2 ? rq[1].as<double>() + (size_t)i * 4 * 384 : nullptr, hq_m2 ? ddb_m2 : nullptr, PR_F64,
                          hq_sc ? mo[0].as<double>() + (size_t)i * 6 : nullptr, hq_m2 ? mo[1].as<double>() + (size_t)i * 6 : nullptr, 1, n, 1, q0, 0,
                          mask_width, p_weight, kin2, didx.as<int32_t>(), dsw.as<double>(), k, dcand + (size_t)q0 * k, dsc64 + (size_t)q0 * k);
+      if (rc == PR_OK)                                            // (the split pass's own order check: exact row statistics if it fails)
+        rc = pr_order_resolve_dev(ctx, hq_sc ? rq[0].as<double>() + (size_t)i * 2400 : nullptr, hq_sc ? ddb_sc : nullptr, PR_F64,
+                                  hq_m2 ? rq[1].as<double>() + (size_t)i * 4 * 384 : nullptr, hq_m2 ? ddb_m2 : nullptr, PR_F64,
+                                  hq_sc ? mo[0].as<double>() + (size_t)i * 6 : nullptr, hq_m2 ? mo[1].as<double>() + (size_t)i * 6 : nullptr, 1, n, q0,
+                                  mask_width, p_weight, kin2, didx.as<int32_t>(), dsw.as<double>(), k, dcand + (size_t)q0 * k, dsc64 + (size_t)q0 * k,
+                                  nullptr);
     }
     if (rc == PR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "f16 fallback failed"; rc = PR_EHIP; }
   } while (0);
@@ -910,6 +961,12 @@ static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, con
                               didx.as<int32_t>(), dsw.as<double>(), k, dcand.as<int32_t>(), dsc64.as<double>()))) break;
       std::vector<double> t64;
       if (score32) t64.resize((size_t)m * k);
+      // queries whose re-evaluated order hangs on the fp32 pass's sigmas get their row statistics in fp64 (PR_SC_ARITH_F16: the margin
+      // check below takes the flags instead and sends them to the split pass, which resolves its own)
+      if (ctx->sc_mode != PR_SC_ARITH_F16 &&
+          (rc = pr_order_resolve_dev(ctx, sc ? raw1.p : nullptr, sc ? raw2.p : nullptr, PR_F64, sc ? nullptr : raw1.p, sc ? nullptr : raw2.p, PR_F64,
+                                     sc ? mom.as<double>() : nullptr, sc ? nullptr : mom.as<double>(), m, n, 0, mask_width, p_weight, kin,
+                                     didx.as<int32_t>(), dsw.as<double>(), k, dcand.as<int32_t>(), dsc64.as<double>(), nullptr))) break;
       if (ctx->sc_mode == PR_SC_ARITH_F16 &&
           (rc = f16_fallback(ctx, sc ? h1 : nullptr, sc ? nullptr : h1, sc ? raw2.p : nullptr, sc ? nullptr : raw2.p, m, n, mask_width, p_weight, k,
                              sc ? mom.as<double>() : nullptr, sc ? nullptr : mom.as<double>(), kin, dsw.as<double>(), dcand.as<int32_t>(),
@@ -1009,6 +1066,9 @@ static int fused_host(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32
                             0, 0, mask_width, p_weight, kin, didx.as<int32_t>(), dsw.as<double>(), k, dcand.as<int32_t>(), dsc64.as<double>()))) break;
     std::vector<double> t64;
     if (score32) t64.resize((size_t)m * k);
+    if (ctx->sc_mode != PR_SC_ARITH_F16 &&
+        (rc = pr_order_resolve_dev(ctx, raw[0].p, raw[1].p, PR_F64, raw[2].p, raw[3].p, PR_F64, mom[0].as<double>(), mom[1].as<double>(), m, n, 0,
+                                   mask_width, p_weight, kin, didx.as<int32_t>(), dsw.as<double>(), k, dcand.as<int32_t>(), dsc64.as<double>(), nullptr))) break;
     if (ctx->sc_mode == PR_SC_ARITH_F16 &&
         (rc = f16_fallback(ctx, sc1, m2dp1, raw[1].p, raw[3].p, m, n, mask_width, p_weight, k, mom[0].as<double>(), mom[1].as<double>(), kin,
                            dsw.as<double>(), dcand.as<int32_t>(), dsc64.as<double>()))) break;

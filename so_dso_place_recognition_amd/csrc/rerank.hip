@@ -376,15 +376,19 @@ __global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __rest
 // nu / (sigma_c sqrt(n)) on sigma - 1e-4 at n = 10^4, 1e-2 on a row of 24 - so eps_c = max(PR_F16_SIGMA_REL, 4 PR_F16_NOISE / (sigma_c
 // sqrt(n - 1))) with PR_F16_NOISE = 1e-4 (include/place_recognition.h).  Pairs equal in every channel (duplicated signatures) are ordered
 // by index and certain; candidates that were not evaluated (pruned: their pass score is beyond the k-th by more than the pass's error)
-// are certain by that bound.  Anything else flags the query for the split-f16 pass.  One thread per query; score_all [G][m][kin] /
+// are certain by that bound.  Anything else flags the query for the split-f16 pass.  One wave per query; score_all [G][m][kin] /
 // part_all [G][m][4][kin] hold values at the candidate's owner, NaN elsewhere (G = 1: the scratch arrays of pr_rerank_dev).
 __global__ __launch_bounds__(64) void order_check_kernel(const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int Gmom,
                                                           const int32_t* __restrict__ cand_idx, const double* __restrict__ score_all,
                                                           const double* __restrict__ part_all, int G, int m, int kin, int k,
                                                           const int32_t* __restrict__ idx_sel, double eps_floor, double noise,
                                                           int32_t* __restrict__ flags) {
-  const int q = blockIdx.x * 64 + threadIdx.x;
-  if (q >= m) return;
+  // one WAVE per query (a thread walking its 57 - 128 candidates alone is ~0.1 ms of dependent loads - an online call has one query):
+  // lane l holds candidates l and l + 64; the members of S = selected k + best one left out are ranked by (score, index) through an LDS
+  // copy, scattered to their rank, and lane p checks the adjacent pair (p, p + 1)
+  __shared__ double s_v[128], t_v[129], t_z[4][129];
+  __shared__ int s_j[128], s_in[128], t_ev[129];
+  const int q = blockIdx.x, lane = threadIdx.x;
   double eps[4] = {0.0, 0.0, 0.0, 0.0};
   for (int c = 0; c < 4; c++) {
     const double* mom = c < 2 ? mom_sc : mom_m2;
@@ -394,51 +398,113 @@ __global__ __launch_bounds__(64) void order_check_kernel(const double* __restric
     const double e = 4.0 * noise / (sd * sqrt(fmax(cn - 1.0, 1.0)));
     eps[c] = (e == e) ? fmax(eps_floor, e) : 1.0;             // (sigma = 0 or NaN: nothing about the order is certain)
   }
-  int32_t ci[128];
-  double cs[128];
-  unsigned char own[128];                                      // shard that evaluated the candidate, 255: nobody
-  for (int t = 0; t < kin; t++) {
-    ci[t] = cand_idx[(size_t)q * kin + t];
-    double v = __builtin_nan("");
-    own[t] = 255;
-    for (int g = 0; g < G; g++) {
-      const double x = score_all[((size_t)g * m + q) * kin + t];
-      if (x == x) { v = x; own[t] = (unsigned char)g; break; }
-    }
-    cs[t] = v;
-  }
-  int flag = 0, prev = -1;
-  for (int t = 0; t <= k && !flag; t++) {
-    int cur = -1;
-    if (t < k) {
-      const int want = idx_sel[(size_t)q * k + t];
-      if (want < 0) break;                                     // fewer than k entries exist
-      for (int c = 0; c < kin; c++) if (ci[c] == want) { cur = c; break; }
-    } else {                                                   // the best candidate that was left out
-      for (int c = 0; c < kin; c++) {
-        if (ci[c] < 0 || cs[c] != cs[c]) continue;
-        bool sel = false;
-        for (int u = 0; u < k; u++) if (idx_sel[(size_t)q * k + u] == ci[c]) { sel = true; break; }
-        if (sel) continue;
-        if (cur < 0 || cand_before(cs[c], ci[c], cs[cur], ci[cur])) cur = c;
+  double v[2], z[2][4];
+  int j[2], ev[2], sel[2];
+  for (int h = 0; h < 2; h++) {
+    const int c = lane + 64 * h;
+    j[h] = c < kin ? cand_idx[(size_t)q * kin + c] : -1;
+    v[h] = __builtin_nan("");
+    int own = -1;
+    if (j[h] >= 0)
+      for (int g = 0; g < G; g++) {
+        const double x = score_all[((size_t)g * m + q) * kin + c];
+        if (x == x) { v[h] = x; own = g; break; }
       }
-    }
-    if (cur < 0) break;
-    if (prev >= 0 && own[prev] != 255 && own[cur] != 255) {
-      const double* pa = part_all + (((size_t)own[prev] * m + q) * 4) * kin + prev;
-      const double* pb = part_all + (((size_t)own[cur] * m + q) * 4) * kin + cur;
-      if (pa[0] == pa[0] && pb[0] == pb[0]) {                  // both evaluated (masked pairs are +Inf, pruned ones keep their pass score: NaN parts)
-        double lim = 0.0, span = 0.0;
-        for (int c = 0; c < 4; c++) {
-          const double dz = fabs(pb[(size_t)c * kin] - pa[(size_t)c * kin]);
-          lim += eps[c] * dz; span += dz;
-        }
-        if (span > 0.0 && !(cs[cur] - cs[prev] > lim)) flag = 1;
-      }
-    }
-    prev = cur;
+    for (int cc = 0; cc < 4; cc++) z[h][cc] = own >= 0 ? part_all[(((size_t)own * m + q) * 4 + cc) * kin + c] : __builtin_nan("");
+    ev[h] = own >= 0 && z[h][0] == z[h][0];                    // evaluated (masked pairs are +Inf, pruned ones keep their pass score: NaN parts)
+    sel[h] = 0;
   }
-  flags[q] = flag;
+  for (int u = 0; u < k; u++) {                                // (wave-uniform loads)
+    const int want = idx_sel[(size_t)q * k + u];
+    if (want < 0) break;                                       // fewer than k entries exist
+    if (j[0] == want) sel[0] = 1;
+    if (j[1] == want) sel[1] = 1;
+  }
+  {                                                            // the best candidate that was left out joins S
+    const bool c0 = j[0] >= 0 && v[0] == v[0] && !sel[0], c1 = j[1] >= 0 && v[1] == v[1] && !sel[1];
+    const bool first = c0 && (!c1 || cand_before(v[0], j[0], v[1], j[1]));
+    double bv = first ? v[0] : v[1];
+    int bj = (c0 || c1) ? (first ? j[0] : j[1]) : -1;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+      const double ov = __shfl_xor(bv, s, 64);
+      const int oj = __shfl_xor(bj, s, 64);
+      if (oj >= 0 && (bj < 0 || cand_before(ov, oj, bv, bj))) { bv = ov; bj = oj; }
+    }
+    if (bj >= 0) { if (j[0] == bj) sel[0] = 1; if (j[1] == bj) sel[1] = 1; }
+  }
+  for (int h = 0; h < 2; h++) { s_v[lane + 64 * h] = v[h]; s_j[lane + 64 * h] = j[h]; s_in[lane + 64 * h] = sel[h]; }
+  __syncthreads();
+  int rank[2] = {0, 0}, nS = 0;
+  for (int d = 0; d < kin; d++) {                              // (broadcast reads)
+    if (!s_in[d]) continue;
+    nS++;
+    const double dv = s_v[d];
+    const int dj = s_j[d];
+    if (cand_before(dv, dj, v[0], j[0])) rank[0]++;
+    if (cand_before(dv, dj, v[1], j[1])) rank[1]++;
+  }
+  for (int h = 0; h < 2; h++)
+    if (sel[h]) {
+      t_v[rank[h]] = v[h]; t_ev[rank[h]] = ev[h];
+      for (int cc = 0; cc < 4; cc++) t_z[cc][rank[h]] = z[h][cc];
+    }
+  __syncthreads();
+  int flag = 0;
+  for (int p = lane; p + 1 < nS; p += 64) {
+    if (!t_ev[p] || !t_ev[p + 1]) continue;
+    double lim = 0.0, span = 0.0;
+    for (int cc = 0; cc < 4; cc++) {
+      const double dz = fabs(t_z[cc][p + 1] - t_z[cc][p]);
+      lim += eps[cc] * dz; span += dz;
+    }
+    if (span > 0.0 && !(t_v[p + 1] - t_v[p] > lim)) flag = 1;
+  }
+  flag = __any(flag);
+  if (lane == 0) flags[q] = flag ? 1 : 0;
+}
+
+// ---- resolution of a query whose order check failed (single-shard calls): the row statistics of run_test.m:40 EXACTLY.  exact_row_kernel
+// evaluates the distance of the query to every entry of the shard in fp64, in the reference's own formulation (the device functions of
+// rerank_kernel), into d64 [channels: SC p, SC i, M2DP p, M2DP i][n]; moments64_kernel turns each present channel into (count, mean, M2)
+// - two passes over the doubles, NaN left out (zero-norm signatures) - in the layout of pr_row_moments_dev.  ~23 ns per pair: 2.3 ms per
+// flagged query and 100 000 entries.
+__global__ __launch_bounds__(256) void exact_row_kernel(const void* __restrict__ q_sc, const void* __restrict__ db_sc, int sc_dt,
+                                                         const void* __restrict__ q_m2, const void* __restrict__ db_m2, int m2_dt, int n,
+                                                         double* __restrict__ d64) {
+  __shared__ double buf[60 * 21 + 1200];
+  __shared__ double red[256];
+  const int tid = threadIdx.x;
+  for (int j = blockIdx.x; j < n; j += gridDim.x) {
+    if (q_sc)
+      for (int ch = 0; ch < 2; ch++) {
+        const double d = sc_pair_exact(q_sc, sc_dt, (size_t)ch * 1200, db_sc, sc_dt, (size_t)j * 2400 + ch * 1200, buf, red, tid);
+        if (tid == 0) d64[(size_t)ch * n + j] = d;
+      }
+    if (q_m2)
+      for (int ch = 0; ch < 2; ch++) {
+        const double d = m2dp_pair_exact(q_m2, m2_dt, 0, db_m2, m2_dt, (size_t)j * 4 * 384, ch, red, tid);
+        if (tid == 0) d64[(size_t)(2 + ch) * n + j] = d;
+      }
+  }
+}
+
+__global__ __launch_bounds__(256) void moments64_kernel(const double* __restrict__ d64, int n, double* __restrict__ mom_sc,
+                                                         double* __restrict__ mom_m2) {
+  __shared__ double red[256];
+  const int tid = threadIdx.x, c = blockIdx.x;                  // channel 0..3
+  double* out = (c < 2 ? mom_sc : mom_m2);
+  if (!out) return;
+  out += (c & 1) * 3;
+  const double* x = d64 + (size_t)c * n;
+  double s = 0.0, cnt = 0.0;
+  for (int j = tid; j < n; j += 256) { const double v = x[j]; if (v == v) { s += v; cnt += 1.0; } }
+  const double N = block_sum256(cnt, red, tid);
+  const double mean = block_sum256(s, red, tid) / N;
+  double m2 = 0.0;
+  for (int j = tid; j < n; j += 256) { const double v = x[j]; if (v == v) m2 += (v - mean) * (v - mean); }
+  const double M2 = block_sum256(m2, red, tid);
+  if (tid == 0) { out[0] = N; out[1] = N > 0.0 ? mean : 0.0; out[2] = N > 0.0 ? M2 : 0.0; }
 }
 
 __global__ __launch_bounds__(256) void widen_kernel(const float* __restrict__ a, long long n, double* __restrict__ b) {
@@ -518,8 +584,15 @@ void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_
                         const double* part_all, int G, int m, int kin, int k, const int32_t* idx_sel, double eps_floor, double noise,
                         int32_t* flags) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(order_check_kernel, dim3((m + 63) / 64), dim3(64), 0, st, mom_sc, mom_m2, Gmom, cand_idx, score_all, part_all, G, m, kin, k,
+  hipLaunchKernelGGL(order_check_kernel, dim3(m), dim3(64), 0, st, mom_sc, mom_m2, Gmom, cand_idx, score_all, part_all, G, m, kin, k,
                      idx_sel, eps_floor, noise, flags);
+}
+
+void launch_exact_row_moments(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
+                              int n, double* d64, double* mom_sc, double* mom_m2) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(exact_row_kernel, dim3(n < 8192 ? n : 8192), dim3(256), 0, st, q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, n, d64);
+  hipLaunchKernelGGL(moments64_kernel, dim3(4), dim3(256), 0, st, d64, n, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr);
 }
 
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,

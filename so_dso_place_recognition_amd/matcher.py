@@ -103,6 +103,18 @@ class _Base:
         self.f16_flags, self.f16_count = flags, count
         return flags, count
 
+    def _resolve_order(self, raw6, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, cand_idx, cand_sc, k, idx, score):
+        """pr_order_resolve_dev after a single-shard pr_rerank_dev: queries whose re-evaluated order hangs on the fp32 pass's sigmas get
+        exact (fp64) row statistics and are re-evaluated; idx / score are patched in place.  Synchronises the stream (reads the flags)."""
+        cnt = C.c_int32(0)
+        self._enter()
+        self.ctx.check(self.lib.pr_order_resolve_dev(self.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), m, n, int(q_row0), int(mask_width),
+                                                     float(p_weight), cand_idx.shape[1], _dptr(cand_idx), None if cand_sc is None else _dptr(cand_sc),
+                                                     int(k), _dptr(idx), _dptr(score), C.byref(cnt)))
+        self._leave()
+        self.order_resolved = int(cnt.value)
+        return self.order_resolved
+
     def _fallback_rows(self, run_rows, idx, score, mask_width, q_row0):
         """Recomputes the flagged queries through `run_rows(rows tensor, q_row0 or None)` (a split-f16 matcher over the same DB) and
         patches idx / score.  Reads the flag count back: one host synchronisation per call, only in the f16 arithmetic."""
@@ -226,7 +238,9 @@ class Matcher(_Base):
         G, q_row0, db_row0, mask_width, p_weight = self._args
         kin = cand_idx.shape[1]
         cand_idx = cand_idx.contiguous()
-        csc = None if cand_sc is None else _dptr(cand_sc.contiguous())
+        cand_sc = None if cand_sc is None else cand_sc.contiguous()
+        csc = None if cand_sc is None else _dptr(cand_sc)
+        self._last_cand = (cand_idx, cand_sc)
         self._enter()
         if partial:
             part = self._buf("part", (m, kin), torch.float64)
@@ -257,9 +271,12 @@ class Matcher(_Base):
         return _merge_dev(self, idx_all, sc_all, k)
 
     def match(self, queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
-              db_row0: int = 0, q_row0: int = 0, group=None, force_exchange: bool = False, f16_fallback: bool = True):
+              db_row0: int = 0, q_row0: int = 0, group=None, force_exchange: bool = False, f16_fallback: bool = True,
+              exact_order: bool = False):
         """Returns (idx int32 [m,k] GLOBAL DB row indices, score float64 [m,k]) as device tensors.
-        force_exchange: run the two all-gathers and the merge even with one rank (measures the protocol's overhead)."""
+        force_exchange: run the two all-gathers and the merge even with one rank (measures the protocol's overhead).
+        exact_order (one rank, unsharded DB): queries whose re-evaluated order is not certain under the fp32 pass's row sigmas are answered
+        with fp64 row statistics (pr_order_resolve_dev; what the host calls always do) - one stream synchronisation per call."""
         G = _world(group)
         f16 = self.f16 and not self.plain
         post = (lambda cand_sc, idx, score: self._margin(_dptr_mom(self, True), _dptr_mom(self, False), self._args[0], p_weight, cand_sc, k,
@@ -272,8 +289,14 @@ class Matcher(_Base):
             def run_rows(rows, qr0):
                 fb = self._split_twin()
                 qsel = queries.view(-1, self.rows_per_sig, self.sig_len)[rows].reshape(-1, self.sig_len).contiguous()   # M2DP: 4 rows per query
-                return fb.match(qsel, mask_width, p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group, force_exchange)
+                return fb.match(qsel, mask_width, p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group, force_exchange,
+                                exact_order=exact_order)
             idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
+        elif exact_order and not self.plain and G == 1 and not force_exchange and db_row0 == 0:
+            sc = self.type == _lib.TYPE_SC
+            raw = self._raw_args()[:6]
+            self._resolve_order(raw, self._mom_all if sc else None, None if sc else self._mom_all, self._m, self.n, q_row0, mask_width, p_weight,
+                                *self._last_cand, k, idx, score)
         return idx, score
 
     def _split_twin(self):
@@ -390,7 +413,9 @@ class FusedMatcher(_Base):
         cand_idx = cand_idx.contiguous()
         raw = (_dptr(self.sc._q_sig), _dptr(self.sc.db_sig), _torch_dt(self.sc.db_sig), _dptr(self.m2._q_sig), _dptr(self.m2.db_sig),
                _torch_dt(self.m2.db_sig), _dptr(self._m1), _dptr(self._m2))
-        csc = None if cand_sc is None else _dptr(cand_sc.contiguous())
+        cand_sc = None if cand_sc is None else cand_sc.contiguous()
+        csc = None if cand_sc is None else _dptr(cand_sc)
+        self._last_cand = (cand_idx, cand_sc)
         self._enter()
         if partial:
             part = self._buf("part", (m, kin), torch.float64)
@@ -417,7 +442,7 @@ class FusedMatcher(_Base):
         return _merge_dev(self, idx_all, sc_all, k)
 
     def match(self, sc_queries: torch.Tensor, m2dp_queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
-              db_row0: int = 0, q_row0: int = 0, group=None, f16_fallback: bool = True):
+              db_row0: int = 0, q_row0: int = 0, group=None, f16_fallback: bool = True, exact_order: bool = False):
         G = _world(group)
         post = (lambda cand_sc, idx, score: self._margin(self._m1, self._m2, self._args[0], p_weight, cand_sc, k, score)) if self.f16 else None
         idx, score = sharded_topk(lambda: self.local_phase1(sc_queries, m2dp_queries),
@@ -427,8 +452,12 @@ class FusedMatcher(_Base):
             def run_rows(rows, qr0):
                 fb = self._split_twin()
                 return fb.match(sc_queries[rows].contiguous(), m2dp_queries.view(-1, 4, 384)[rows].reshape(-1, 384).contiguous(), mask_width,
-                                p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group)
+                                p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group, exact_order=exact_order)
             idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
+        elif exact_order and G == 1 and db_row0 == 0:
+            raw = (_dptr(self.sc._q_sig), _dptr(self.sc.db_sig), _torch_dt(self.sc.db_sig), _dptr(self.m2._q_sig), _dptr(self.m2.db_sig),
+                   _torch_dt(self.m2.db_sig))
+            self._resolve_order(raw, self._m1, self._m2, self.sc._m, self.sc.n, q_row0, mask_width, p_weight, *self._last_cand, k, idx, score)
         return idx, score
 
     def _split_twin(self):

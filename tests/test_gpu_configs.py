@@ -357,3 +357,36 @@ def test_drive_2000_frames_mask_100(api):
     assert (np.abs(sc[rows] - osc)[flat] < 1e-5).all(), np.abs(sc[rows] - osc)[flat].max()
     second = np.arange(lap + 50, N - 50)
     assert (np.abs(idx[second, 0] - (second - lap)) <= 3).mean() > 0.7           # loop closures onto the first lap
+
+
+@pytest.mark.gpu
+def test_order_that_hangs_on_the_row_sigmas_is_resolved_with_fp64_statistics(api):
+    """Found by tools/fuzz_all.py (seed 1, `match,matcher,fused`, case 1): M2DP, 96 x 1096, k = 35.  Ranks 6 / 7 of one row differ by less
+    than what the fp32 pass's sigma error (2.5e-7 relative) moves them, and their two channels disagree about the order: every arithmetic
+    returned them swapped.  The order check flags such queries and pr_order_resolve_dev answers them with fp64 row statistics (host calls:
+    always; Matcher: exact_order=True) - indices AND scores of that row are then fp64 throughout."""
+    import torch
+    from so_dso_place_recognition_amd import _lib
+    from so_dso_place_recognition_amd.matcher import Matcher
+    m, n, k = 96, 1096, 35
+    db = synth.m2dp_database(3000 + 7 * 1 + 1, n)
+    q, _ = synth.m2dp_queries(4000 + 1 + 1, db, m)
+    rc, oidx, osc = oracle_lib.match_topk(1, q, db, 0, 2.0, k)
+    assert rc == 0
+    for arith in ("f16x2", "f32", "f16"):
+        ctx = api.Context(0, sc_arith=arith)
+        idx, sc = api.match_topk("m2dp", q, db, 0, 2.0, k, ctx=ctx)
+        assert ctx.take_warnings() & _lib.WARN_ORDER_RESOLVED, arith
+        assert np.array_equal(idx, oidx), arith
+        ctx.close()
+    dev = torch.device("cuda", 0)
+    mt = Matcher("m2dp", m, n, ctx=api.Context(0, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
+    mt.pack_database(torch.from_numpy(db).to(dev))
+    i0, s0 = mt.match(torch.from_numpy(q).to(dev), 0, 2.0, k)
+    i0 = i0.cpu().numpy().copy()
+    i1, s1 = mt.match(torch.from_numpy(q).to(dev), 0, 2.0, k, exact_order=True)
+    assert mt.order_resolved >= 1
+    assert np.array_equal(i1.cpu().numpy(), oidx) and not np.array_equal(i0, oidx)
+    rows = np.flatnonzero((i0 != oidx).any(axis=1))                 # the resolved rows: scores exact to fp64 rounding, not to the fp32 model
+    assert np.abs(s1.cpu().numpy()[rows] - osc[rows]).max() < 1e-9
+    mt.close()

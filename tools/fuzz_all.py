@@ -56,10 +56,18 @@ def spoil(q, db, div):
     return q, db, ",".join(notes)
 
 
-def check(tag, idx, sc, oidx, osc, tol):
+sigma_ties = []
+
+
+def check(tag, idx, sc, oidx, osc, tol, resolved=True):
+    """resolved=False (pr_group: sharded, no fp64 row statistics): neighbours whose scores agree to 1e-5 may come out in the other order -
+    the documented limit of fp32 row statistics (pr_order_resolve_dev); such cases are counted apart, not as findings."""
     okm = oidx >= 0
     if not np.array_equal(idx, oidx):
         r = np.argwhere(idx != oidx)
+        if not resolved and all(abs(sc[tuple(x)] - osc[tuple(x)]) < 1e-5 for x in r):
+            sigma_ties.append((tag, len(r)))
+            return True
         bad.append((tag, "indices", r[:3].tolist(), idx[tuple(r[0])], oidx[tuple(r[0])]))
         return False
     fin = okm & np.isfinite(osc)
@@ -114,7 +122,7 @@ for it in range(cases):
                 g = api.Group([0] * G)
                 g.set_database(type_, db)
                 idx, sc = g.match_topk(q, mask, 2.0, k)
-                ok = check((it, type_, "group", G, m, n, k, mask, note), idx, sc, oidx, osc, tol)
+                ok = check((it, type_, "group", G, m, n, k, mask, note), idx, sc, oidx, osc, tol, resolved=False)
                 g.close()
                 line.append(f"{type_}/group{G}:{'ok' if ok else 'BAD'}")
             if "matcher" in what:
@@ -130,7 +138,7 @@ for it in range(cases):
                     else:
                         oidx2, osc2 = oidx, osc
                     mt.pack_database(dbt)
-                    idx, sc = mt.match(qt, mask, 2.0, k)
+                    idx, sc = mt.match(qt, mask, 2.0, k, exact_order=True)
                     ok = check((it, type_, arith, "Matcher", str(dtype), m, n, k, mask, note), idx.cpu().numpy(), sc.cpu().numpy(), oidx2, osc2,
                                f16_tol(osc2, n) if arith == "f16" else tol)
                     mt.close()
@@ -191,5 +199,7 @@ for it in range(cases):
     print(" ".join(line), f"[{time.time() - t_start:.0f}s]", flush=True)
 for b in bad:
     print("BAD", b)
+for t in sigma_ties:
+    print("sigma-level tie (sharded call, not resolved):", t)
 print("fuzz_all:", "ok" if not bad else f"{len(bad)} findings", f"seed {seed}, {cases} cases")
 sys.exit(1 if bad else 0)
