@@ -693,9 +693,8 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
   double* parts = ctx->rr_scratch + need;
   ctx->parts_count = 0;
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
-                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in, pass_eps(ctx), parts);
-  pr::launch_order_check(ctx->stream, mom_sc, mom_m2, G, idx_in, ctx->rr_scratch, parts, 1, m, k_in, k, idx, f16 ? PR_F16_SIGMA_REL : PR_F32_SIGMA_REL,
-                         f16 ? PR_F16_NOISE : PR_F32_NOISE, ctx->d_order);
+                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in, pass_eps(ctx), parts,
+                    f16 ? PR_F16_SIGMA_REL : PR_F32_SIGMA_REL, f16 ? PR_F16_NOISE : PR_F32_NOISE, ctx->d_order);
   ctx->order_m = m;
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;

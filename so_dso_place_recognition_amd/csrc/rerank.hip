@@ -310,19 +310,44 @@ __global__ __launch_bounds__(64) void rerank_sort_kernel(const int32_t* __restri
 
 // The same with one WAVE per query (few query rows - an online call: one thread walking its 57 candidates alone is 16 us of load latency):
 // lane l holds candidates l and l + 64, k rounds of a wave arg-min by cand_before with the winner retired.
+// per-channel relative sigma error the order check allows (order_check_kernel below has the derivation)
+__device__ __forceinline__ void order_eps(const double* mom_sc, const double* mom_m2, int Gmom, int m, int q, double eps_floor, double noise,
+                                          double (&eps)[4]) {
+  for (int c = 0; c < 4; c++) {
+    eps[c] = 0.0;
+    const double* mom = c < 2 ? mom_sc : mom_m2;
+    if (!mom) continue;
+    double mean, sd, cn = 2.0;
+    chan_combine(mom, Gmom, m, q, c & 1, mean, sd, &cn);
+    const double e = 4.0 * noise / (sd * sqrt(fmax(cn - 1.0, 1.0)));
+    eps[c] = (e == e) ? fmax(eps_floor, e) : 1.0;             // (sigma = 0 or NaN: nothing about the order is certain)
+  }
+}
+
 __global__ __launch_bounds__(64) void rerank_sort_wave_kernel(const int32_t* __restrict__ idx_in, const double* __restrict__ cand_score,
                                                                int m, int kin, int k, int32_t* __restrict__ idx, double* __restrict__ score,
-                                                               float* __restrict__ score32) {
+                                                               float* __restrict__ score32, const double* __restrict__ cand_part,
+                                                               const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int Gmom,
+                                                               double eps_floor, double noise, int32_t* __restrict__ order_flags) {
+  // cand_part != null: the order check of order_check_kernel folded into the selection rounds (k + 1 of them: the last one finds the best
+  // candidate left out) - every winner is compared with the previous one; an online call saves a launch
   const int q = blockIdx.x, lane = threadIdx.x;
-  double v[2];
+  double v[2], z[2][4];
   int j[2];
+  double eps[4] = {0.0, 0.0, 0.0, 0.0};
+  if (cand_part) order_eps(mom_sc, mom_m2, Gmom, m, q, eps_floor, noise, eps);
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const int c = lane + 64 * h;
     j[h] = c < kin ? idx_in[(size_t)q * kin + c] : -1;
     v[h] = c < kin ? cand_score[(size_t)q * kin + c] : __builtin_nan("");
+    for (int cc = 0; cc < 4; cc++) z[h][cc] = (cand_part && c < kin) ? cand_part[((size_t)q * 4 + cc) * kin + c] : __builtin_nan("");
   }
-  for (int t = 0; t < k; t++) {
+  double pv = 0.0, pz[4] = {0.0, 0.0, 0.0, 0.0};
+  bool have_prev = false;
+  int flag = 0;
+  const int rounds = cand_part ? k + 1 : k;
+  for (int t = 0; t < rounds; t++) {
     const bool first = cand_before(v[0], j[0], v[1], j[1]) || !cand_before(v[1], j[1], v[0], j[0]);
     double bv = first ? v[0] : v[1];
     int bj = first ? j[0] : j[1];
@@ -334,15 +359,29 @@ __global__ __launch_bounds__(64) void rerank_sort_wave_kernel(const int32_t* __r
       if (cand_before(ov, oj, bv, bj) || (!cand_before(bv, bj, ov, oj) && oc < bc)) { bv = ov; bj = oj; bc = oc; }
     }
     const bool ok = bj >= 0 && bv == bv;
-    if (lane == 0) {
+    if (lane == 0 && t < k) {
       idx[(size_t)q * k + t] = ok ? bj : -1;
       const double o = ok ? bv : __builtin_nan("");
       if (score) score[(size_t)q * k + t] = o;
       if (score32) score32[(size_t)q * k + t] = (float)o;
     }
+    if (cand_part && ok) {                                   // (no further entries: nothing left to compare, -1 / NaN fill the rest)
+      double wz[4];
+      for (int cc = 0; cc < 4; cc++) wz[cc] = __shfl(bc < 64 ? z[0][cc] : z[1][cc], bc & 63, 64);
+      const bool evd = wz[0] == wz[0];                      // evaluated (masked: +Inf, pruned: pass score - NaN parts)
+      if (have_prev && evd) {
+        double lim = 0.0, span = 0.0;
+        for (int cc = 0; cc < 4; cc++) { const double dz = fabs(wz[cc] - pz[cc]); lim += eps[cc] * dz; span += dz; }
+        if (span > 0.0 && !(bv - pv > lim)) flag = 1;
+      }
+      have_prev = evd;
+      pv = bv;
+      for (int cc = 0; cc < 4; cc++) pz[cc] = wz[cc];
+    }
     if (bc == lane) { j[0] = -1; v[0] = __builtin_nan(""); }
     if (bc == lane + 64) { j[1] = -1; v[1] = __builtin_nan(""); }
   }
+  if (order_flags && lane == 0) order_flags[q] = flag;
 }
 
 // cand_idx [m][kin] + the partial evaluations of G shards [G][m][kin] (NaN where the candidate is not the shard's) -> the k best.
@@ -389,15 +428,8 @@ __global__ __launch_bounds__(64) void order_check_kernel(const double* __restric
   __shared__ double s_v[128], t_v[129], t_z[4][129];
   __shared__ int s_j[128], s_in[128], t_ev[129];
   const int q = blockIdx.x, lane = threadIdx.x;
-  double eps[4] = {0.0, 0.0, 0.0, 0.0};
-  for (int c = 0; c < 4; c++) {
-    const double* mom = c < 2 ? mom_sc : mom_m2;
-    if (!mom) continue;
-    double mean, sd, cn = 2.0;
-    chan_combine(mom, Gmom, m, q, c & 1, mean, sd, &cn);
-    const double e = 4.0 * noise / (sd * sqrt(fmax(cn - 1.0, 1.0)));
-    eps[c] = (e == e) ? fmax(eps_floor, e) : 1.0;             // (sigma = 0 or NaN: nothing about the order is certain)
-  }
+  double eps[4];
+  order_eps(mom_sc, mom_m2, Gmom, m, q, eps_floor, noise, eps);
   double v[2], z[2][4];
   int j[2], ev[2], sel[2];
   for (int h = 0; h < 2; h++) {
@@ -551,15 +583,23 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
                    double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
-                   float* score32, const double* cand_sc32, double eps_d, double* cand_part) {
+                   float* score32, const double* cand_sc32, double eps_d, double* cand_part, double order_floor, double order_noise,
+                   int32_t* order_flags) {
   if (m <= 0) return;
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
                eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, cand_part};
   hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
-  if (m <= 64 && kin <= 128)
-    hipLaunchKernelGGL(rerank_sort_wave_kernel, dim3(m), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
-  else
-    hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
+  // order check (order_flags != null, needs cand_part): inside the wave selection for few queries, its own launch otherwise
+  const bool oc = order_flags && cand_part;
+  if (m <= 64 && kin <= 128) {
+    hipLaunchKernelGGL(rerank_sort_wave_kernel, dim3(m), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32,
+                       oc ? cand_part : nullptr, mom_sc, mom_m2, G, order_floor, order_noise, oc ? order_flags : nullptr);
+    return;
+  }
+  hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
+  if (oc)
+    hipLaunchKernelGGL(order_check_kernel, dim3(m), dim3(64), 0, st, mom_sc, mom_m2, G, idx_in, cand_score, cand_part, 1, m, kin, k, idx,
+                       order_floor, order_noise, order_flags);
 }
 
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
