@@ -72,6 +72,7 @@ int main(int argc, char** argv) {
   printf("type = %s\ntm = %g\n", type.c_str(), m ? 1000.0 * secs / m : 0.0);
   const int warn = grp ? pr_group_take_warnings(grp) : pr_take_warnings(ctx);
   if (warn > 0 && (warn & PR_WARN_F16_FALLBACK)) printf("note: some queries were recomputed in split-f16 (PR_SC_ARITH_F16 margin check)\n");
+  if (warn > 0 && (warn & PR_WARN_ORDER_RESOLVED)) printf("note: some queries were answered with fp64 row statistics (order check, pr_order_resolve_dev)\n");
   if (warn > 0 && (warn & PR_WARN_NAN_ROWS)) printf("warning: zero-norm signature rows never match (NaN in MATLAB, processSC.m:16,19)\n");
   std::string g1f, g2f;
   if (prm.get("gt1", g1f) && prm.get("gt2", g2f)) {   // run_test.m:3-22, 58-85
