@@ -30,6 +30,9 @@
 // shuffle values through AccVGPRs on its own (it had parked 16 registers and restored them right in front of asm MFMAs).  Measured
 // (alternating runs, three boxes): 40.3 -> 39.1, 41.2 -> 39.6, 41.5 -> 39.9 ms per 4096 x 100k launch (-3.9 %); -DE_NO_ACC_OPERANDS builds the
 // previous placement.
+#ifndef E_NO_WAIT1
+#define E_WAIT1         // one s_waitcnt per walk position (TOUCH_OPS below): 166 -> 42 s_waitcnt per unit, -2.3 % per launch
+#endif
 #ifndef E_NO_ACC_OPERANDS
 #define E_BACC
 #define E_AACC
@@ -355,12 +358,24 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
 #define VS(P, G) valu_slot<LO, ((P) >> 2), (((P) & 3) * 6 + (G))>(T, hbs)
 // one walk position: its 6 (LO) or 2 MFMAs, the requests for positions P + AD - 1 (query tiles) and P + BD - 1 (DB tiles), the quad's VALU
 // work of these six gaps
+// E_WAIT1: an empty asm that names all six operand tiles of the position in front of its first MFMA - hipcc then waits for them ONCE
+// (the rings are several positions deep: they have long arrived) instead of in front of every MFMA
+#ifdef E_WAIT1
+#ifdef E_WAIT1F
+#define TOUCH_OPS_F(P) asm volatile("" : : "v"(At[(P) % AD].h), "v"(Bt[(P) % BD].reh), "v"(Bt[(P) % BD].imh))
+#else
+#define TOUCH_OPS_F(P)
+#endif
+#define TOUCH_OPS(P) { if constexpr (LO) asm volatile("" : : "a"(At[(P) % AD].h), "a"(At[(P) % AD].l), "a"(Bt[(P) % BD].reh), "a"(Bt[(P) % BD].imh), "a"(Bt[(P) % BD].rel), "a"(Bt[(P) % BD].iml)); else TOUCH_OPS_F(P); }
+#else
+#define TOUCH_OPS(P)
+#endif
 #define FREQ(P)                                                                                                  \
   {                                                                                                              \
     f32x4& t1 = T[((P) >> 2) & 1][2 * ((P) & 3)];                                                                \
     f32x4& t2 = T[((P) >> 2) & 1][2 * ((P) & 3) + 1];                                                            \
     if constexpr (seqf(P) < SC_NF) {                                                                             \
-      SB(); MF0(t1, At[(P) % AD].h, Bt[(P) % BD].reh); SB(); LDA((P) + AD - 1, A_H); VS(P, 0);                   \
+      SB(); TOUCH_OPS(P); MF0(t1, At[(P) % AD].h, Bt[(P) % BD].reh); SB(); LDA((P) + AD - 1, A_H); VS(P, 0);      \
       SB(); MF0(t2, At[(P) % AD].h, Bt[(P) % BD].imh); SB(); LDA((P) + AD - 1, A_L); VS(P, 1);                   \
       SB(); if constexpr (LO) MFA(t1, At[(P) % AD].l, Bt[(P) % BD].reh); SB(); LDB((P) + BD - 1, B_REH); VS(P, 2); \
       SB(); if constexpr (LO) MFA(t2, At[(P) % AD].l, Bt[(P) % BD].imh); SB(); LDB((P) + BD - 1, B_IMH); VS(P, 3); \
