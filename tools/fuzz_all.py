@@ -143,7 +143,7 @@ for it in range(cases):
                                f16_tol(osc2, n) if arith == "f16" else tol)
                     mt.close()
                     line.append(f"{type_}/Matcher/{arith}:{'ok' if ok else 'BAD'}")
-        if "fused" in what:
+        if "fused" in what and n >= 4:        # (n = 2, 3: the four z-scores are +-0.707 each and sum to EXACT ties, which no arithmetic orders reproducibly)
             sq, sdb, _, _ = sigs("sc", it, m, n); mq, mdb, _, _ = sigs("m2dp", it, m, n)
             rc, oidx, osc = oracle_lib.match_topk_fused(sq, mq, sdb, mdb, mask, 2.0, k)
             for arith in ("f16x2", "f16"):
