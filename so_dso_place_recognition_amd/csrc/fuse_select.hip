@@ -76,25 +76,39 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restric
 // by moments_finish_kernel - deterministic for a given (m, n).
 __global__ __launch_bounds__(256) void row_moments_slice_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i, int n, int m, int P,
                                                                  double* __restrict__ part /* [P][m][2][3] */) {
-  __shared__ double red[256];
+  // an online call waits for this kernel: both channels side by side, eight loads of a thread in flight, and ONE reduction tree for the
+  // six sums (the per-thread order of the additions and the tree are those of block_sum, so the sums are bit for bit what three
+  // block_sum calls per channel gave)
+  __shared__ double red[6][256];
   const int tid = threadIdx.x, q = blockIdx.x, sl = blockIdx.y;
   const int c0 = (int)((long long)n * sl / P), c1 = (int)((long long)n * (sl + 1) / P);
-  for (int ch = 0; ch < 2; ch++) {
-    const float* row = (ch ? d_i : d_p) + (size_t)q * n;
-    const float r0 = row[0];
-    const double c = (r0 == r0) ? (double)r0 : 0.5;
-    double s1 = 0.0, s2 = 0.0, cnt = 0.0;
-    for (int j = c0 + tid; j < c1; j += 256) {
-      const float v = row[j];
-      if (v == v) { const double d = (double)v - c; s1 += d; s2 += d * d; cnt += 1.0; }
+  const float* rp = d_p + (size_t)q * n;
+  const float* ri = d_i + (size_t)q * n;
+  const float p0 = rp[0], i0 = ri[0];
+  const double cp = (p0 == p0) ? (double)p0 : 0.5, ci = (i0 == i0) ? (double)i0 : 0.5;
+  double s[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};     // S1, S2, count of d_p; of d_i
+  auto acc = [&](float v, double c, int o) { if (v == v) { const double d = (double)v - c; s[o] += d; s[o + 1] += d * d; s[o + 2] += 1.0; } };
+  int j = c0 + tid;
+  for (; j + 768 < c1; j += 1024) {
+    const float a0 = rp[j], a1 = rp[j + 256], a2 = rp[j + 512], a3 = rp[j + 768];
+    const float b0 = ri[j], b1 = ri[j + 256], b2 = ri[j + 512], b3 = ri[j + 768];
+    acc(a0, cp, 0); acc(a1, cp, 0); acc(a2, cp, 0); acc(a3, cp, 0);
+    acc(b0, ci, 3); acc(b1, ci, 3); acc(b2, ci, 3); acc(b3, ci, 3);
+  }
+  for (; j < c1; j += 256) { acc(rp[j], cp, 0); acc(ri[j], ci, 3); }
+#pragma unroll
+  for (int o = 0; o < 6; o++) red[o][tid] = s[o];
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) {
+#pragma unroll
+      for (int o = 0; o < 6; o++) red[o][tid] += red[o][tid + st];
     }
-    const double S1 = block_sum(s1, red, tid);
-    const double S2 = block_sum(s2, red, tid);
-    const double N = block_sum(cnt, red, tid);
-    if (tid == 0) {
-      double* o = part + (((size_t)sl * m + q) * 2 + ch) * 3;
-      o[0] = N; o[1] = S1; o[2] = S2;
-    }
+    __syncthreads();
+  }
+  if (tid < 2) {
+    double* o = part + (((size_t)sl * m + q) * 2 + tid) * 3;
+    o[0] = red[3 * tid + 2][0]; o[1] = red[3 * tid][0]; o[2] = red[3 * tid + 1][0];
   }
 }
 __global__ __launch_bounds__(64) void moments_finish_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i, int n, int m, int P,
