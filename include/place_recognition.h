@@ -327,7 +327,8 @@ int pr_write_points(const char* path, const int32_t* ids, const double* xyz, con
 /* Replaces the evaluation half of run_test(type, hist1, hist2, gt1, gt2, loop_diff, mask_width) (match_signatures/run_test.m:3-22 ground-truth
  * loop pairs, :58-85 precision / recall sweep): diff_v / diff_idx [m] = the per-query best score and 0-based index (run_test.m:57),
  * gt1 [m][cols], gt2 [n][cols] positions.  auc = trapz(recall, precision), top_recall = recall at the last 100 %-precision point,
- * lp_detected (optional) [m][2] receives the *n_detected pairs (query, match) of that prefix. */
+ * lp_detected (optional) [m][2] receives the *n_detected pairs (query, match) of that prefix.  A diff_idx of -1 (no finite candidate) is
+ * read as index 0: MATLAB's min over an all-NaN / all-Inf row returns index 1 (run_test.m:57). */
 int pr_precision_recall(const double* diff_v, const int32_t* diff_idx, int32_t m, const double* gt1, const double* gt2, int32_t n,
                         int32_t cols, double loop_diff, int32_t mask_width, double* auc, double* top_recall, int32_t* lp_detected,
                         int32_t* n_detected);

@@ -405,8 +405,10 @@ int pr_precision_recall(const double* diff_v, const int32_t* diff_idx, int32_t m
   int top_count = 0;
   double tr = 0.0, area = 0.0, pprev = 0.0, rprev = 0.0;
   for (int i = 0; i < m; i++) {
-    const int a = rank[i], b = diff_idx[a];
-    if (b >= 0 && b < n && d2(a, b) < thr) tp++; else fp++;
+    // a query without a finite candidate (every distance NaN: zero-norm signature; or everything masked) comes back as index -1: MATLAB's
+    // min over an all-NaN / all-Inf row returns index 1 (:57), and the sweep pairs the query with gt2(1,:)
+    const int a = rank[i], b = diff_idx[a] < 0 ? 0 : diff_idx[a];
+    if (b < n && d2(a, b) < thr) tp++; else fp++;
     const double p = (double)tp / (double)(tp + fp);
     const double r = total_lp ? (double)tp / (double)total_lp : NAN;
     if (p == 1.0) { top_count = i + 1; tr = r; }
@@ -417,7 +419,7 @@ int pr_precision_recall(const double* diff_v, const int32_t* diff_idx, int32_t m
   *top_recall = tr;
   if (n_detected) *n_detected = top_count;
   if (lp_detected)
-    for (int i = 0; i < top_count; i++) { lp_detected[2 * i] = rank[i]; lp_detected[2 * i + 1] = diff_idx[rank[i]]; }
+    for (int i = 0; i < top_count; i++) { lp_detected[2 * i] = rank[i]; lp_detected[2 * i + 1] = diff_idx[rank[i]] < 0 ? 0 : diff_idx[rank[i]]; }
   return PR_OK;
 }
 

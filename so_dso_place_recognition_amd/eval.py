@@ -30,6 +30,9 @@ def precision_recall(diff_v, diff_idx, gt1, gt2, loop_diff: float, mask_width: i
     gt2 = np.asarray(gt2, np.float64)
     diff_v = np.asarray(diff_v, np.float64)
     diff_idx = np.asarray(diff_idx, np.int64)
+    # index -1 = no finite candidate (zero-norm signature: every distance NaN; or everything masked): MATLAB's min over an all-NaN /
+    # all-Inf row returns index 1 (run_test.m:57) and the sweep pairs the query with gt2(1,:)
+    diff_idx = np.where(diff_idx < 0, 0, diff_idx)
     lp_gt = ground_truth_pairs(gt1, gt2, loop_diff, mask_width)
     L = lp_gt.shape[0]
     total_lp = 0 if L == 0 else max(L, 2)              # MATLAB length() of an L x 2 matrix (run_test.m:22)

@@ -114,6 +114,13 @@ def test_c_abi_precision_recall_equals_the_python_restatement():
         gt2 = np.concatenate([gt1[:n // 2] + rng.normal(0, 1, (n // 2, 3)), rng.normal(0, 100, (n - n // 2, 3))])[:n]
         v = rng.random(m); idx = rng.integers(0, n, m).astype(np.int32)
         idx[:min(m, n) // 2] = np.arange(min(m, n) // 2); v[:min(m, n) // 2] *= 0.3
+        if m >= 50:                                  # queries without a finite candidate (index -1, NaN score): MATLAB's min gives index 1
+            idx[m - 3:] = -1; v[m - 3:] = np.nan
+            gt1[m - 1] = gt2[0]                      # ... so this one is a true positive at the end of the sweep
+            idx0 = np.where(idx < 0, 0, idx)
+            ref = E.precision_recall(v, idx0, gt1, gt2, ld, mask)
+            got = E.precision_recall(v, idx, gt1, gt2, ld, mask)
+            assert ref[0] == got[0] and np.array_equal(ref[3], got[3]) and ref[3][-1] > ref[3][-2]
         a = E.precision_recall(v, idx, gt1, gt2, ld, mask)
         auc, tr, nd = C.c_double(), C.c_double(), C.c_int32()
         lp = np.zeros((m, 2), np.int32)
