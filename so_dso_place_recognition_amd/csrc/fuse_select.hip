@@ -119,14 +119,21 @@ __global__ __launch_bounds__(64) void moments_finish_kernel(const float* __restr
   const float r0 = ((ch ? d_i : d_p) + (size_t)q * n)[0];
   const double c = (r0 == r0) ? (double)r0 : 0.5;
   double N = 0.0, S1 = 0.0, S2 = 0.0;
-  for (int sl = 0; sl < P; sl++) {
-    const double* o = part + (((size_t)sl * m + q) * 2 + ch) * 3;
-    N += o[0]; S1 += o[1]; S2 += o[2];
+  const size_t step = (size_t)m * 6;                 // doubles between the partials of consecutive slices
+  const double* o = part + ((size_t)q * 2 + ch) * 3;
+  int sl = 0;
+  for (; sl + 8 <= P; sl += 8) {                     // eight slices' partials requested together, added in slice order
+    double a[8][3];
+#pragma unroll
+    for (int u = 0; u < 8; u++) { a[u][0] = o[(sl + u) * step]; a[u][1] = o[(sl + u) * step + 1]; a[u][2] = o[(sl + u) * step + 2]; }
+#pragma unroll
+    for (int u = 0; u < 8; u++) { N += a[u][0]; S1 += a[u][1]; S2 += a[u][2]; }
   }
-  double* o = mom + ((size_t)q * 2 + ch) * 3;
-  o[0] = N;
-  o[1] = N > 0.0 ? c + S1 / N : 0.0;
-  o[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
+  for (; sl < P; sl++) { N += o[sl * step]; S1 += o[sl * step + 1]; S2 += o[sl * step + 2]; }
+  double* w = mom + ((size_t)q * 2 + ch) * 3;
+  w[0] = N;
+  w[1] = N > 0.0 ? c + S1 / N : 0.0;
+  w[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
 }
 
 __device__ __forceinline__ bool cand_less(double av, int aj, double bv, int bj) {   // (a) < (b) lexicographic
@@ -532,7 +539,7 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restr
 // slices per row for m query rows of n columns: 1 = one workgroup per row (enough rows to fill the chip, or short rows)
 int select_slices(int m, int n) {
   if (m > 64 || n < 16384) return 1;
-  int P = (n + FS_CAP - 1) / FS_CAP;                // slices that fit the selection's LDS list skip its sampling phase
+  int P = (n + FS_CAP / 2 - 1) / (FS_CAP / 2);      // slices of half the selection's LDS list (they skip its sampling phase; 2048 columns: 49 slices of a 100k row, measured against 25)
   if (P > 64) P = 64;
   while (P > 1 && m * P > 1024) P >>= 1;            // capacity of the scratch (partial moments: 1024 (row, slice) pairs), ~4 workgroups per CU
   return P;
