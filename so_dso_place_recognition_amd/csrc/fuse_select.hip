@@ -8,6 +8,8 @@
 //                 fused = p_weight*(d_p-mean_p)/std_p + (d_i-mean_i)/std_i  (run_test.m:40), +Inf where
 //                 |i-j| < mask_width on GLOBAL indices (:47-53), and selects the k smallest (value, index)
 //                 pairs in lexicographic order, i.e. ties go to the lower index like MATLAB min (:57).
+#include <cstdlib>
+
 #include "div_rn.hpp"
 #include "kernels.hpp"
 
@@ -539,7 +541,12 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restr
 // slices per row for m query rows of n columns: 1 = one workgroup per row (enough rows to fill the chip, or short rows)
 int select_slices(int m, int n) {
   if (m > 64 || n < 16384) return 1;
-  int P = (n + FS_CAP / 2 - 1) / (FS_CAP / 2);      // slices of half the selection's LDS list (they skip its sampling phase; 2048 columns: 49 slices of a 100k row, measured against 25)
+  // slices that fit the selection's LDS list skip its sampling phase; up to 8 rows (an online call) get slices of half the list: 49 slices
+  // of a 100k row instead of 25 (m = 1: 0.353 -> 0.346 ms, m = 8: 0.374 -> 0.356 ms); from 16 rows up that loses (m = 32, f16 arithmetic:
+  // 0.52 -> 0.59 ms in alternating runs on one box).  PR_SLICE_COLS overrides the width for A/B runs
+  static const int forced = getenv("PR_SLICE_COLS") ? atoi(getenv("PR_SLICE_COLS")) : 0;
+  const int cols = forced > 0 ? forced : (m <= 8 ? FS_CAP / 2 : FS_CAP);
+  int P = (n + cols - 1) / cols;      // slices of half the selection's LDS list (they skip its sampling phase; 2048 columns: 49 slices of a 100k row, measured against 25)
   if (P > 64) P = 64;
   while (P > 1 && m * P > 1024) P >>= 1;            // capacity of the scratch (partial moments: 1024 (row, slice) pairs), ~4 workgroups per CU
   return P;

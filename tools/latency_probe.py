@@ -11,9 +11,9 @@ arith = sys.argv[2] if len(sys.argv) > 2 else None
 n = 100000
 dev = torch.device("cuda", 0)
 db = synth.sc_database_torch(45, n, device=dev)
-q_h, planted = synth.sc_queries(46, np.empty((0, 2400)), 8, db_first=0, n_global=n, db_seed=45)
+q_h, planted = synth.sc_queries(46, np.empty((0, 2400)), max(8, m), db_first=0, n_global=n, db_seed=45)
 q = torch.from_numpy(q_h[:m]).to(dev)
-mt = Matcher("sc", 8, n, ctx=api.Context(0, sc_arith=arith, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
+mt = Matcher("sc", max(8, m), n, ctx=api.Context(0, sc_arith=arith, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
 mt.pack_database(db)
 import time
 for _ in range(5):
