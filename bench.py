@@ -13,7 +13,7 @@ SURVEY.md §8-e); queries are replicated.  value = queries of all steps / max-ov
 `extra` (outside the timed region, N = 1 only): the secondary workloads of BASELINE.json measured in the same run - M2DP matching
 over a 50k-signature DB (config 3), SC generation from 50 000-point clouds (config 2), and the fp32-MFMA arithmetic of the SC matcher.
 
-Extra objects on the JSON line: `roofline` (the dominant kernel - sc_match_d_kernel, split-f16 MFMA, by default;
+Extra objects on the JSON line: `roofline` (the dominant kernel - sc_match_e_kernel, split-f16 MFMA, by default;
 sc_match_kernel, fp32 MFMA, with --sc-arith f32 - timed live with HIP events on the stream it runs on; algorithmic
 FLOPs = 23 856 fp32 FLOP per (query, entry) pair = 71 568 f16 FLOP in the split form), `cpu_baseline` (the CPU oracle =
 a port of the reference, timed on this host's cores on a bounded query sample at N = 1), `parity` (GPU top-1 vs
@@ -121,6 +121,8 @@ def via_group(args):
                       "value": m * args.steps / dt, "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                       "dtype": "f16x2 (fp32 carried as f16 hi + lo, fp32 accumulate)", "data": "synthetic",
+                      "collective": {"backend": "rccl (in-process, ncclCommInitAll)" if g.uses_rccl else "device copies", "world": args.gpus,
+                                     "rccl_ranks_seen": g.rccl_ranks},
                       "config": {"workload": "sc_match_100k", "db_signatures": n, "queries_per_step": m, "via": "pr_group_match_topk",
                                  "uses_rccl": g.uses_rccl, "note": "DB packed once (pr_group_set_database); queries host -> every GPU per step"},
                       "parity": {"planted_top1_correct": int((idx[:, 0] == planted).sum()), "queries": m}}), flush=True)
@@ -437,13 +439,22 @@ def main():
     idx_h = idx.cpu().numpy()[:, 0]
     score_h = score.cpu().numpy()[:, 0]
     planted_ok = int((idx_h == planted).sum())
+    # what the communicator itself says (not argv): every rank contributes its rank through the group's own all-gather
+    coll = {"backend": None, "world": 1, "rccl_ranks_seen": 0}
+    if dist.is_available() and dist.is_initialized():
+        on_dev = dist.get_backend() == "nccl"
+        mine = torch.tensor([rank], dtype=torch.int32, device=dev if on_dev else "cpu")
+        seen = torch.empty((dist.get_world_size(),), dtype=torch.int32, device=mine.device)
+        dist.all_gather_into_tensor(seen, mine)
+        coll = {"backend": "nccl (RCCL %s)" % ".".join(map(str, torch.cuda.nccl.version())) if on_dev else dist.get_backend(),
+                "world": dist.get_world_size(), "rccl_ranks_seen": len(set(seen.cpu().tolist())) if on_dev else 0}
 
     if rank == 0:
         qps = m * args.steps / dt
         kms = float(np.mean(kern_ms))
         pairs = m * (hi - lo)
         f16 = arith in ("f16x2", "f16")
-        kname = {"h": "sc_match_h_kernel", "d": "sc_match_d_kernel"}.get(os.environ.get("PR_SC_KERNEL", "e"), "sc_match_e_kernel") if f16 else "sc_match_kernel"
+        kname = {"h": "sc_match_h_kernel"}.get(os.environ.get("PR_SC_KERNEL", "e"), "sc_match_e_kernel") if f16 else "sc_match_kernel"
         if arith == "f16":
             kname = "sc_match_e_kernel<single product>"
         fpp, peak = (FLOP_PER_PAIR_F16X2 if arith == "f16x2" else FLOP_PER_PAIR, MFMA_F16_PEAK_TFLOPS) if f16 else (FLOP_PER_PAIR, MFMA_F32_PEAK_TFLOPS)
@@ -476,6 +487,7 @@ def main():
                          "fp32_formulation_frac_of_157.3": pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          "dense_equivalent_tflops": pairs * 576000 / (kms * 1e-3) / 1e12},
             "parity": {"planted_top1_correct": planted_ok, "queries": m},
+            "collective": coll,
             "setup_s": gen_s,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -44,7 +44,9 @@ enum { PR_SC_ARITH_F16X2 = 0, PR_SC_ARITH_F32 = 1, PR_SC_ARITH_F16 = 2 };
  * normalize(.,2) / min (run_test.m:40,57) leave NaNs out [normalize's 'omitnan' from memory], so the signature simply never matches.
  * PR_NAN_EXCLUDE (default) does exactly that and reports PR_WARN_NAN_ROWS; PR_NAN_FAIL turns it into the error PR_ENAN at pr_sync. */
 enum { PR_NAN_EXCLUDE = 0, PR_NAN_FAIL = 1 };
-enum { PR_WARN_NAN_ROWS = 1, PR_WARN_M2DP_SVD = 2, PR_WARN_F16_FALLBACK = 4, PR_WARN_ORDER_RESOLVED = 8 };   /* bits of pr_take_warnings */
+enum { PR_WARN_NAN_ROWS = 1, PR_WARN_M2DP_SVD = 2, PR_WARN_F16_FALLBACK = 4, PR_WARN_ORDER_RESOLVED = 8,
+       PR_WARN_ORDER_UNRESOLVED = 16 };   /* bits of pr_take_warnings; the last one: a stream-ordered call met more than 64 queries whose order hangs
+                                            on the all-pairs pass's sigmas - those beyond the 64th keep the order of the fp32-statistics scores */
 
 #define PR_SC_SIG_LEN 2400    /* 2 x numS*numR = 2 x 60*20, SC/SC.h:7-8, test_sc.cpp:37-38 */
 #define PR_M2DP_SIG_LEN 384   /* 2 x (numP*numQ + numS*numR) = 2 x 192, M2DP/M2DP.h:7-10, test_m2dp.cpp:37-39 */
@@ -85,7 +87,7 @@ int pr_m2dp_generate(pr_ctx* ctx, const double* xyz, const float* inten, const i
 /* The rows (cloud * 4 + variant, ascending) of the LAST pr_m2dp_generate / pr_m2dp_generate_dev call of this context whose leading
  * singular pair is not unique (sigma_2 / sigma_1 > ~0.99: M2DP/M2DP.cpp:94-103's JacobiSVD returns whichever of the two near-equal
  * directions its sweeps end on, and so does this library - those rows may differ from the reference's; PR_WARN_M2DP_SVD is the
- * call-wide bit).  At most cap rows are written, *count is the number of such rows (the list holds up to 1024: PR_EINVAL beyond). */
+ * call-wide bit).  At most cap rows are written, *count is the number of such rows (the library records the first 1024 pairs of a call). */
 int pr_m2dp_svd_rows(pr_ctx* ctx, int32_t* rows, int32_t cap, int32_t* count);
 
 /* Replaces DELIGHT::getSignature looped as in DELIGHT/test_delight.cpp:41-56 (DELIGHT/DELIGHT.h:11-18, DELIGHT.cpp:8-24;
@@ -185,7 +187,7 @@ int pr_rerank_width(const pr_ctx* ctx, int32_t k);
  * Also flagged: queries whose re-evaluated ORDER is not certain.  A re-evaluated score is exact in the pair's distances, but its
  * channel terms are divided by the f16 pass's row sigmas; two candidates whose channels disagree about their order can change places
  * when those sigmas move by what the pass's distance noise allows (PR_F16_SIGMA_REL, PR_F16_NOISE: a relative noise / (sigma sqrt(n))).
- * pr_rerank_dev (one shard) / pr_f16_order_dev (sharded) check every adjacent pair of the selected k and the best candidate left out and
+ * pr_rerank_dev (one shard) / pr_rerank_finish_dev (sharded) check every adjacent pair of the selected k and the best candidate left out and
  * leave the result in the context; this call takes it (once). */
 int pr_f16_margin_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t m, int32_t G, double p_weight, int32_t k_in,
                       const double* cand_score, int32_t k, const double* score, int32_t* flags, int32_t* count);
@@ -196,42 +198,58 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
 /* score_in / cand_score (both forms; DEVICE f64 [m][k_in], may be NULL): the candidates' scores from the fp32 pass, ascending as
  * pr_fuse_select_dev / pr_merge_topk_dev deliver them.  With them a candidate beyond the k-th whose fp32 score exceeds the k-th by more than
  * 64 x the error bound of an fp32 score (from the row statistics) is not re-evaluated - it cannot enter the exact top-k; results are identical.
+ *
+ * The "p5" block of a re-evaluation, DEVICE f64 [m][5][k_in] per shard: for every query the candidates' scores [k_in], then their four exact
+ * channel distances [4][k_in] (SC structure, SC intensity, M2DP count, M2DP intensity; 0 for an absent type; NaN in the first = the pair
+ * was not evaluated here: masked (+Inf score), pruned (it keeps its pass score), or another shard's (NaN score)).  pr_rerank_dev keeps its
+ * block in the context; the sharded protocol gathers the shards' blocks ([G][m][5][k_in]): it is all the order check and the fp64-statistics
+ * resolution need.
+ *
  * The sharded form of the re-evaluation (what makes its cost independent of the number of shards): the shards' fp32 top-(k+8) lists
  * are merged FIRST (pr_merge_topk_dev on the gathered lists) into the global candidates cand_idx DEVICE [m][k_in]; every shard then
- * evaluates only the candidates inside its rows [db_row0, db_row0 + n_local) - part DEVICE f64 [m][k_in], NaN for the others -
- * and pr_rerank_finish_dev takes each candidate's score from its owner (part_all DEVICE [G][m][k_in]) and selects the k best. */
+ * evaluates only the candidates inside its rows [db_row0, db_row0 + n_local) (pr_rerank_partial_dev -> its p5 block), the blocks are
+ * all-gathered, and pr_rerank_finish_dev takes each candidate's score from its owner, selects the k best and runs the order check
+ * (mom_*: the statistics the scores were formed with, [G_mom][m][2][3]); the flags stay in the context. */
 int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                           const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
                           int32_t mask_width, double p_weight, int32_t k_in, const int32_t* cand_idx, const double* cand_score, int32_t k,
-                          double* part);
-int pr_rerank_finish_dev(pr_ctx* ctx, const int32_t* cand_idx, const double* part_all, int32_t G, int32_t m, int32_t k_in, int32_t k,
-                         int32_t* idx, double* score);
-/* Order check in every arithmetic.  pr_rerank_dev leaves in the context one flag per query: set when two neighbours among the re-evaluated
- * candidates (the selected k and the best one left out) could change places under the sigma error of the all-pairs pass (their channels
- * disagree about the order and the scores are closer than sum_c eps_c |z_c(a) - z_c(b)|, eps_c = max(PR_F32_SIGMA_REL, 4 PR_F32_NOISE /
- * (sigma_c sqrt(n - 1))); PR_SC_ARITH_F16: the PR_F16_* constants, and pr_f16_margin_dev takes the flags).  pr_order_resolve_dev - called
- * right after pr_rerank_dev with the same arguments, single-shard calls (the moments are those of the whole row, db_row0 = 0) - reads the
- * flags back (it synchronises the stream) and, for every flagged query, evaluates the distances of the query to ALL n entries in fp64,
- * overwrites the query's row of mom_sc / mom_m2 with the exact (count, mean, M2) and re-evaluates its candidates: indices and scores of
- * that query are then those of fp64 arithmetic throughout (run_test.m:38-57), ~2.3 ms per flagged query and 100 000 entries.  *resolved
- * (may be NULL) = number of such queries; PR_WARN_ORDER_RESOLVED is raised when there was one.  The host top-k calls do this by themselves;
- * for the sharded protocol a flagged query keeps the order of the fp32-statistics scores. */
+                          double* p5);
+int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t G_mom, const int32_t* cand_idx, const double* p5_all,
+                         int32_t G, int32_t m, int32_t k_in, int32_t k, double p_weight, int32_t* idx, double* score);
+/* Order check, every arithmetic (run_test.m:38-41,57 are fp64 throughout; the all-pairs pass is not).  pr_rerank_dev / pr_rerank_finish_dev
+ * leave in the context one flag per query: set when two neighbours among the re-evaluated candidates (the selected k and the best one left
+ * out) could change places under the sigma error of the all-pairs pass (their channels disagree about the order and the scores are closer
+ * than sum_c eps_c |z_c(a) - z_c(b)|, eps_c = max(PR_F32_SIGMA_REL, 4 PR_F32_NOISE / (sigma_c sqrt(n - 1))); PR_SC_ARITH_F16: the PR_F16_*
+ * constants, and pr_f16_margin_dev takes the flags - such queries go to the split-f16 pass).  A flagged query is answered with EXACT row
+ * statistics: its distances to ALL n entries in fp64 (the reference's formulation, ~23 ns per pair = 2.3 ms per query and 100 000 entries)
+ * -> (count, mean, M2) per channel -> the candidates' scores again from their exact distances -> the k best: indices and scores of that
+ * query are then those of fp64 arithmetic throughout (run_test.m:38-57).  Three forms:
+ *   pr_order_resolve_async_dev  single shard, right after pr_rerank_dev with the same arguments; STREAM-ORDERED, no host synchronisation
+ *                               (fixed-grid kernels that leave at once when nothing is flagged: ~10 us; hipGraph-capturable).  Resolves up to
+ *                               64 flagged queries per call; beyond that PR_WARN_ORDER_UNRESOLVED.  mom_sc / mom_m2 rows of resolved queries
+ *                               are overwritten with the exact ones.  PR_WARN_ORDER_RESOLVED is raised (at pr_take_warnings) when one was.
+ *   pr_order_resolve_dev        the same with a host round trip (reads the count back): resolves ALL flagged queries, *resolved (may be NULL)
+ *                               = their number.  The host top-k calls use this one.
+ *   sharded                     after pr_rerank_finish_dev: pr_order_exact_moments_dev = this shard's exact (count, mean, M2) of the flagged
+ *                               queries' rows, exact DEVICE f64 [m][4][3] (rows of other queries: unspecified) -> all-gather -> exact_all
+ *                               [G][m][4][3] -> pr_order_rescore_dev on every rank (Chan combination in rank order: identical bits everywhere)
+ *                               patches idx / score of the flagged queries.  Stream-ordered; 64 flagged queries per call as above. */
+int pr_order_resolve_async_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
+                               double* mom_sc, double* mom_m2, int32_t m, int32_t n, double p_weight, int32_t k_in, const int32_t* idx_in,
+                               int32_t k, int32_t* idx, double* score);
 int pr_order_resolve_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                          double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight, int32_t k_in,
                          const int32_t* idx_in, const double* score_in, int32_t k, int32_t* idx, double* score, int32_t* resolved);
-/* PR_SC_ARITH_F16, sharded form of the order check: pr_rerank_parts_dev copies the four weighted channel z-scores (SC structure, SC
- * intensity, M2DP count, M2DP intensity; 0 for an absent type) of every candidate the LAST pr_rerank_partial_dev of this context
- * evaluated (parts DEVICE f64 [m][4][k_in], NaN in [q][0][t] for the others); the shards' parts are gathered like their scores
- * (score_all DEVICE [G][m][k_in], parts_all DEVICE [G][m][4][k_in]) and pr_f16_order_dev checks the order of the result of
- * pr_rerank_finish_dev (idx DEVICE [m][k]) with the row statistics mom_* [G_mom][m][2][3]; the following pr_f16_margin_dev reports
- * the outcome. */
-int pr_rerank_parts_dev(pr_ctx* ctx, int32_t m, int32_t k_in, double* parts);
-int pr_f16_order_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t G_mom, const int32_t* cand_idx, const double* score_all,
-                     const double* parts_all, int32_t G, int32_t m, int32_t k_in, int32_t k, const int32_t* idx);
+int pr_order_exact_moments_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
+                               const double* mom_sc, const double* mom_m2, int32_t G_mom, int32_t m, int32_t n_local, double* exact);
+int pr_order_rescore_dev(pr_ctx* ctx, const double* exact_all, int32_t G, int32_t m, int has_sc, int has_m2, double p_weight,
+                         const int32_t* cand_idx, const double* p5_all, int32_t k_in, int32_t k, int32_t* idx, double* score);
 /* fp32 scores of pr_fuse_select_dev as doubles (the merge works on doubles): DEVICE score32 [count] -> score64 [count] */
 int pr_widen_scores_dev(pr_ctx* ctx, const float* score32, int64_t count, double* score64);
 /* k-way merge of the per-shard results of G shards (SURVEY.md §8-e collective B's second half): idx_all DEVICE [G][m][k],
- * score_all DEVICE f64 [G][m][k] -> idx [m][k], score [m][k] by (score, global index); -1 / NaN entries last (every list ascending, as the selection kernels write them).  G <= 64, k <= 128. */
+ * score_all DEVICE f64 [G][m][k] -> idx [m][k], score [m][k] by (score, global index); -1 / NaN entries last.  PRECONDITION: every shard's list is ASCENDING by (score, index) with its missing entries (-1 / NaN) last - as
+ * pr_fuse_select_dev and pr_rerank_dev write them; the merge walks one cursor per list and does not sort (an unsorted list gives a wrong
+ * result, not an error).  G <= 64, k <= 128. */
 int pr_merge_topk_dev(pr_ctx* ctx, const int32_t* idx_all, const double* score_all, int32_t G, int32_t m, int32_t k,
                       int32_t* idx, double* score);
 
@@ -250,6 +268,7 @@ void pr_group_destroy(pr_group* g);
 const char* pr_group_last_error(const pr_group* g);     /* g may be NULL (creation errors) */
 int32_t pr_group_size(const pr_group* g);
 int pr_group_uses_rccl(const pr_group* g);
+int32_t pr_group_rccl_ranks(const pr_group* g);         /* ncclCommCount of the group's communicator (0: the group exchanges by copies) */
 int pr_group_set_database(pr_group* g, int type, const double* h2, int32_t n);
 int pr_group_take_warnings(pr_group* g);                /* OR of the shards' pr_take_warnings (PR_WARN_* bits), then cleared */
 int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,

@@ -12,7 +12,7 @@ PR_OK, PR_EINVAL, PR_ENOMEM, PR_EHIP, PR_EIO, PR_ENAN = 0, -1, -2, -3, -4, -5
 TYPE_SC, TYPE_M2DP, TYPE_DELIGHT, TYPE_GIST, TYPE_BOW = 0, 1, 2, 3, 4
 SC_ARITH_F16X2, SC_ARITH_F32, SC_ARITH_F16 = 0, 1, 2
 NAN_EXCLUDE, NAN_FAIL = 0, 1
-WARN_NAN_ROWS, WARN_M2DP_SVD, WARN_F16_FALLBACK, WARN_ORDER_RESOLVED = 1, 2, 4, 8
+WARN_NAN_ROWS, WARN_M2DP_SVD, WARN_F16_FALLBACK, WARN_ORDER_RESOLVED, WARN_ORDER_UNRESOLVED = 1, 2, 4, 8, 16
 ROLE_QUERY, ROLE_DB = 0, 1
 F64, F32 = 0, 1
 HOST, DEVICE = 0, 1
@@ -36,11 +36,12 @@ SYMBOLS = {
                                         _vp, _vp, _i32, _vp]),
     "pr_rerank_width": (C.c_int, [_vp, _i32]),
     "pr_f16_margin_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _i32, _vp, _vp, _vp]),
-    "pr_rerank_finish_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "pr_rerank_parts_dev": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "pr_rerank_finish_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _vp, _vp]),
+    "pr_order_resolve_async_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _i32, _vp, _vp]),
+    "pr_order_exact_moments_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "pr_order_rescore_dev": (C.c_int, [_vp, _vp, _i32, _i32, C.c_int, C.c_int, _dbl, _vp, _vp, _i32, _i32, _vp, _vp]),
     "pr_order_resolve_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _i32, _vp, _vp,
                                        _vp]),
-    "pr_f16_order_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "pr_widen_scores_dev": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "pr_merge_topk_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "pr_group_create": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
@@ -48,6 +49,7 @@ SYMBOLS = {
     "pr_group_last_error": (C.c_char_p, [_vp]),
     "pr_group_size": (_i32, [_vp]),
     "pr_group_uses_rccl": (C.c_int, [_vp]),
+    "pr_group_rccl_ranks": (_i32, [_vp]),
     "pr_group_set_database": (C.c_int, [_vp, C.c_int, _vp, _i32]),
     "pr_group_take_warnings": (C.c_int, [_vp]),
     "pr_group_match_topk": (C.c_int, [_vp, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
@@ -114,6 +116,7 @@ SYMBOLS = {
 }
 
 _lib = None
+HIP_RUNTIME = "system"      # which libamdhip64 this process ended up on (_one_hip_runtime)
 
 
 class PRError(RuntimeError):
@@ -126,10 +129,17 @@ def _one_hip_runtime():
     """A process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own libamdhip64.so.7 (same SONAME as /opt/rocm's, which
     libpr_amd.so is linked against): whichever copy is loaded first serves both, and torch does not find its GPUs on the other one
     ("No HIP GPUs are available" when libpr_amd.so came first).  So when torch is installed but not imported yet, its copy is loaded
-    here - without importing torch - and both end up on it whatever the import order.  PR_AMD_SYSTEM_HIP=1 keeps /opt/rocm's."""
+    here - without importing torch - and both end up on it whatever the import order.  This is a process-wide choice made on behalf of a
+    caller who may never import torch: PR_AMD_SYSTEM_HIP=1 keeps /opt/rocm's (the runtime the kernels were built against), HIP_RUNTIME
+    records which one was taken, PR_AMD_VERBOSE=1 prints it."""
     import importlib.util
     import sys
-    if "torch" in sys.modules or os.environ.get("PR_AMD_SYSTEM_HIP"):
+    global HIP_RUNTIME
+    if "torch" in sys.modules:
+        HIP_RUNTIME = "torch's (torch was imported first)"
+        return
+    if os.environ.get("PR_AMD_SYSTEM_HIP"):
+        HIP_RUNTIME = "system (PR_AMD_SYSTEM_HIP)"
         return
     try:
         spec = importlib.util.find_spec("torch")
@@ -139,6 +149,10 @@ def _one_hip_runtime():
         p = os.path.join(d, "lib", "libamdhip64.so")
         if os.path.exists(p):
             C.CDLL(p, mode=C.RTLD_GLOBAL)
+            HIP_RUNTIME = p
+            if os.environ.get("PR_AMD_VERBOSE"):
+                print(f"so_dso_place_recognition_amd: HIP runtime {p} (torch's copy, so that a later `import torch` finds its GPUs; "
+                      "PR_AMD_SYSTEM_HIP=1 keeps /opt/rocm's)", file=sys.stderr)
             return
 
 

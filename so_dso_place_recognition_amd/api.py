@@ -91,6 +91,11 @@ class Group:
     def uses_rccl(self) -> bool:
         return bool(self.lib.pr_group_uses_rccl(self.h))
 
+    @property
+    def rccl_ranks(self) -> int:
+        """Ranks the group's RCCL communicator reports (ncclCommCount); 0 when the group exchanges by device copies."""
+        return int(self.lib.pr_group_rccl_ranks(self.h))
+
     def _check(self, rc):
         if rc != 0:
             raise PRError(rc, self.lib.pr_group_last_error(self.h).decode())

@@ -578,6 +578,9 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
                        mask_width, p_weight, k, sidx, ssc, P);
     int N = 2;
     while (N < P * k) N <<= 1;
+    // (up to 8192 entries = 64 KB of dynamic LDS next to ~4 KB of static arrays: above the 64 KB a launch gets without asking)
+    if ((size_t)N * 8 > 40 * 1024)
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(slice_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)N * 8));
     hipLaunchKernelGGL(slice_merge_kernel, dim3(m), dim3(256), (size_t)N * 8, st, sidx, ssc, P, m, k, idx, score);
     return;
   }

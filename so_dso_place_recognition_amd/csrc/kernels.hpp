@@ -48,9 +48,6 @@ void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int 
 void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p,
                        float* d_i, int nsplit_override);
 size_t sc_match_h_lds_bytes();
-// sc_match_h.hip with stage 2 deferred to the end of the unit and transient tiles (sc_match_d.hip): same images and constants
-void launch_sc_match_d(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
-                       int nsplit_override);
 // sc_match_e.hip — the pair-walk form (no row-exchanged query operand; see the file): single = 0: split-f16 (three products, 4 waves),
 // single = 1: one f16 product per term (PR_SC_ARITH_F16), 8 waves = two per SIMD; same packed images and constants as sc_match_h.hip
 void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
@@ -74,30 +71,38 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
 // rerank.hip — NaN rows / columns of zero-norm signatures (processSC.m:16,19), the fp64 re-evaluation of the fp32
 // selection's survivors (processSC.m:15-33 / processM2DP.m:12-22 + run_test.m:40 per pair) and the k-way shard merge
 void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, const int* qbad, const int* dbad);
+// p5 [m][5][kin] (p5_all [G][m][5][kin]): per query the candidates' scores [kin] and their four exact channel distances [4][kin] (SC structure,
+// SC intensity, M2DP count, M2DP intensity; NaN in the first = not evaluated) - what a shard knows after its re-evaluation (rerank.hip)
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                   double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
-                   float* score32, const double* cand_sc32, double eps_d = 0.0, double* cand_part = nullptr, double order_floor = 0.0,
-                   double order_noise = 0.0, int32_t* order_flags = nullptr);   // order_flags [m] (+ cand_part): the order check of launch_order_check on the result;   // cand_part [m][4][kin]: the channel z-scores of every evaluated candidate (order check of PR_SC_ARITH_F16); cand_sc32: the candidates' all-pairs-pass scores (ascending) or null: prunes hopeless candidates; eps_d: that pass's distance error bound (0: the fp32-grade 1e-6 with a 64x margin)
-// the sharded form: scores of the candidates THIS shard owns (NaN elsewhere), then owner-wise combination + selection
+                   double p_weight, int kin, const int32_t* idx_in, double* p5, int k, int32_t* idx, double* score,
+                   float* score32, const double* cand_sc32, double eps_d = 0.0, double order_floor = 0.0,
+                   double order_noise = 0.0, int32_t* order_flags = nullptr);   // order_flags [m]: the order check of launch_order_check on the result; cand_sc32: the candidates' all-pairs-pass scores (ascending) or null: prunes hopeless candidates; eps_d: that pass's distance error bound (0: the fp32-grade 1e-6 with a 64x margin)
+// the sharded form: scores + distances of the candidates THIS shard owns (NaN elsewhere), then owner-wise combination + selection
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                           double p_weight, int kin, const int32_t* idx_in, double* cand_score, const double* cand_sc32, int k, double eps_d = 0.0,
-                           double* cand_part = nullptr);
+                           double p_weight, int kin, const int32_t* idx_in, double* p5, const double* cand_sc32, int k, double eps_d = 0.0);
 // PR_SC_ARITH_F16: flags[q] = 1 where the candidate list does not provably contain the exact top-k (rerank.hip), count += number of flags
 void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,
                          const double* cand_sc, int k, const double* score, double eps_d, int32_t* flags, int32_t* count,
                          const int32_t* order_flags = nullptr);
-// PR_SC_ARITH_F16: flags[q] = 1 where the order of the re-evaluated candidates (the selected k and the best one left out) could change
-// under the sigma error of the single-product pass (per channel max(eps_floor, 4 noise / (sigma sqrt(n - 1))), statistics from mom_*
-// [Gmom][m][2][3]); score_all [G][m][kin] / part_all [G][m][4][kin], NaN where the shard is not the owner
-void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int Gmom, const int32_t* cand_idx, const double* score_all,
-                        const double* part_all, int G, int m, int kin, int k, const int32_t* idx_sel, double eps_floor, double noise,
-                        int32_t* flags);
-// one query row against n entries in fp64 (d64: scratch [4][n]) -> its exact row moments, written over mom_sc / mom_m2 [2][3] (null: type absent)
-void launch_exact_row_moments(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
-                              int n, double* d64, double* mom_sc, double* mom_m2);
-void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,
+// flags[q] = 1 where the order of the re-evaluated candidates (the selected k and the best one left out) could change under the sigma error
+// of the all-pairs pass (per channel max(eps_floor, 4 noise / (sigma sqrt(n - 1))), statistics from mom_* [Gmom][m][2][3])
+void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int Gmom, const int32_t* cand_idx, const double* p5_all,
+                        int G, int m, int kin, int k, const int32_t* idx_sel, double p_weight, double eps_floor, double noise, int32_t* flags);
+// The flagged queries answered with fp64 row statistics, stream-ordered: flags -> ascending list + count; per pass of RESOLVE_SLOTS list
+// slots the shard's exact (count, mean, M2) of the four channels (exact [m][4][3]; partial: scratch [RESOLVE_SLOTS][RESOLVE_NB][4][3]);
+// then the candidates' scores again from their exact distances with the exact statistics of all shards, and the k best (rerank.hip)
+constexpr int RESOLVE_SLOTS = 64;
+constexpr int RESOLVE_NB = 2048;
+void launch_flag_compact(hipStream_t st, const int32_t* flags, int m, int32_t* list, int32_t* cnt, int cap, int* dflags);
+void launch_exact_moments(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
+                          const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* list, const int32_t* cnt,
+                          int offset, double* partial, double* exact);
+void launch_rescore(hipStream_t st, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G, int m, int has_sc,
+                    int has_m2, double p_weight, const int32_t* cand_idx, const double* p5_all, int kin, int k, int32_t* idx, double* score,
+                    double* mom_sc /* single shard: overwritten with the exact rows, else null */, double* mom_m2);
+void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* p5_all, int G, int m, int kin, int k, int32_t* idx,
                           double* score);
 void launch_widen(hipStream_t st, const float* a, long long n, double* b);
 void launch_merge_topk(hipStream_t st, const int32_t* idx_all, const double* score_all, int G, int m, int k, int32_t* idx, double* score);

@@ -33,20 +33,22 @@ struct pr_ctx {
   double* rr_scratch = nullptr;  // candidate scores of pr_rerank_dev (grow-only: a steady-state call allocates nothing and can be graph-captured)
   size_t rr_cap = 0;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_m2[4] = {nullptr, nullptr, nullptr, nullptr};   // M2DP generation: two batches in flight (binning | singular pairs), launch_m2dp_bin_svd
   std::string err;
   int* d_svd_rows = nullptr;     // [1 + M2DP_SVD_ROWS_CAP] rows of the last pr_m2dp_generate* call whose leading singular pair did not converge
-  int* d_flags = nullptr;        // [4] deferred bits: [0] zero-norm row at pack time, [1] M2DP singular pair not converged
+  int* d_flags = nullptr;        // [4] deferred bits: [0] zero-norm row at pack time, [1] M2DP singular pair not converged, [2] a query was answered with fp64 row statistics, [3] more flagged queries than one stream-ordered pass resolves
   double* d_twiddle = nullptr;   // cos[60], sin[60] of 2*pi*t/60
   float* d_cst = nullptr;        // SC stage-2 constants [31][2][64]
   int32_t* d_margin = nullptr;    // [1] count of margin flags (PR_SC_ARITH_F16)
-  int32_t* d_order = nullptr;     // [order_cap] order flags of the last re-evaluation (PR_SC_ARITH_F16; pr_f16_margin_dev takes them)
+  int32_t* d_order = nullptr;     // [2 order_cap + 2] order flags of the last re-evaluation | ascending list of the flagged queries | its length (pr_order_resolve*_dev / pr_f16_margin_dev take them)
   size_t order_cap = 0;
   int32_t order_m = -1;           // rows of d_order that are valid, -1: none
-  size_t parts_count = 0;         // entries of rr_scratch that hold the channel-0 parts of the last pr_rerank_partial_dev
-  double* d64 = nullptr;          // [4][d64_cap] exact distances of one query row (pr_order_resolve_dev)
-  size_t d64_cap = 0;
+  int32_t order_kin = 0;          // candidate-list width of the call that left them
+  double* res_partial = nullptr;  // [RESOLVE_SLOTS][RESOLVE_NB][4][3] workgroup partials of the fp64-statistics resolution (rerank.hip), allocated on first use
+  double* res_exact = nullptr;    // [res_exact_cap][4][3] exact row moments of the flagged queries (single-shard calls)
+  size_t res_exact_cap = 0;
   void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16] (sc_match_h.hip)
-  int sc_kernel = 2;             // split-f16 SC matcher for m > 8: 2 = sc_match_e.hip (default); PR_SC_KERNEL=d | h selects sc_match_d.hip (1, the round-2 default) / sc_match_h.hip (0, round 1; always the kernel for m <= 8)
+  int sc_kernel = 2;             // split-f16 SC matcher for m > 8: 2 = sc_match_e.hip (default); PR_SC_KERNEL=h selects sc_match_h.hip (0, round 1; always the kernel for m <= 8)
   int sc_mode = PR_SC_ARITH_F16X2;   // PR_SC_ARITH_*: split-f16 MFMA (sc_match_h.hip) | fp32 MFMA (sc_match.hip); PR_SC_MATCH=f32 selects the latter
   double* d_planes = nullptr;    // M2DP xProj[64][3], yProj[64][3]
   int sc_nsplit = 0;             // PR_SC_NSPLIT override (experiments)
@@ -83,7 +85,8 @@ namespace {
 
 struct DevBuf {   // RAII device scratch for the host-buffer entry points
   void* p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  // (an error return may leave work of a forked side stream in flight that still touches the buffer: the whole device is idle before it goes)
+  ~DevBuf() { if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); } }
   hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
   template <typename T> T* as() { return static_cast<T*>(p); }
 };
@@ -119,8 +122,10 @@ int check_flags(pr_ctx* ctx) {
   int h[4];
   PR_HIP(ctx, hipMemcpyAsync(h, ctx->d_flags, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  if (h[0] || h[1]) PR_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof h, ctx->stream));
+  if (h[0] || h[1] || h[2] || h[3]) PR_HIP(ctx, hipMemsetAsync(ctx->d_flags, 0, sizeof h, ctx->stream));
   if (h[1]) ctx->warnings |= PR_WARN_M2DP_SVD;
+  if (h[2]) ctx->warnings |= PR_WARN_ORDER_RESOLVED;
+  if (h[3]) ctx->warnings |= PR_WARN_ORDER_UNRESOLVED;
   if (h[0]) {
     if (ctx->nan_policy == PR_NAN_FAIL)
       PR_FAIL(ctx, PR_ENAN, "a signature row has zero L2 norm (MATLAB would produce NaN distances, processSC.m:16,19)");
@@ -168,6 +173,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
     TRY(hipEventCreateWithFlags(&ctx->ev_b, hipEventDisableTiming));
     TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
     TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
+    for (auto& e : ctx->ev_m2) TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     TRY(hipMalloc(&ctx->sel_scratch, pr::select_scratch_bytes()));
     TRY(hipMalloc((void**)&ctx->d_flags, 4 * sizeof(int)));
     TRY(hipMemset(ctx->d_flags, 0, 4 * sizeof(int)));
@@ -251,7 +257,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
   if (rc != PR_OK) { pr_destroy(ctx); return rc; }
   if (const char* s = getenv("PR_SC_NSPLIT")) ctx->sc_nsplit = atoi(s);
   if (const char* s = getenv("PR_SC_MATCH")) ctx->sc_mode = (strcmp(s, "f32") == 0) ? PR_SC_ARITH_F32 : (strcmp(s, "f16") == 0) ? PR_SC_ARITH_F16 : PR_SC_ARITH_F16X2;
-  if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel = (strcmp(s, "h") == 0) ? 0 : (strcmp(s, "d") == 0) ? 1 : 2;
+  if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel = (strcmp(s, "h") == 0) ? 0 : 2;
   *out = ctx;
   return PR_OK;
 }
@@ -272,10 +278,12 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->sc_scratch) (void)hipFree(ctx->sc_scratch);
   if (ctx->rr_scratch) (void)hipFree(ctx->rr_scratch);
   if (ctx->d_order) (void)hipFree(ctx->d_order);
-  if (ctx->d64) (void)hipFree(ctx->d64);
+  if (ctx->res_partial) (void)hipFree(ctx->res_partial);
+  if (ctx->res_exact) (void)hipFree(ctx->res_exact);
   if (ctx->sel_scratch) (void)hipFree(ctx->sel_scratch);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+  for (auto& e : ctx->ev_m2) if (e) (void)hipEventDestroy(e);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_svd_rows) (void)hipFree(ctx->d_svd_rows);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
@@ -600,8 +608,6 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
     pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 1);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && q->count > 8)
     pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 0);
-  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 1 && q->count > 8)
-    pr::launch_sc_match_d(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0)
     pr::launch_sc_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit);
   else if (q->type == PR_TYPE_SC)
@@ -657,7 +663,8 @@ int pr_f16_margin_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, i
   return PR_OK;
 }
 
-// grow-only scratch of the re-evaluation: `need` doubles of candidate scores (+ as many channel-0 parts in PR_SC_ARITH_F16), m order flags
+// grow-only scratch of the re-evaluation: `need` doubles (the p5 block of a single-shard call), m order flags + the list of flagged queries
+// + its count ([3 cap + 2] ints: flags | list | count)
 static int rerank_scratch(pr_ctx* ctx, size_t need, int32_t m) {
   if (need > ctx->rr_cap) {
     if (ctx->rr_scratch) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->rr_scratch)); ctx->rr_scratch = nullptr; ctx->rr_cap = 0; }
@@ -666,13 +673,32 @@ static int rerank_scratch(pr_ctx* ctx, size_t need, int32_t m) {
   }
   if ((size_t)m > ctx->order_cap) {
     if (ctx->d_order) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->d_order)); ctx->d_order = nullptr; ctx->order_cap = 0; }
-    PR_HIP(ctx, hipMalloc((void**)&ctx->d_order, (size_t)m * sizeof(int32_t)));
+    PR_HIP(ctx, hipMalloc((void**)&ctx->d_order, ((size_t)2 * m + 2) * sizeof(int32_t)));
     ctx->order_cap = (size_t)m;
+  }
+  return PR_OK;
+}
+static int32_t* res_list(pr_ctx* ctx) { return ctx->d_order + ctx->order_cap; }
+static int32_t* res_cnt(pr_ctx* ctx) { return ctx->d_order + 2 * ctx->order_cap; }
+// scratch of the fp64-statistics resolution: the workgroup partials of one pass + exact [m][4][3] (single-shard calls)
+static int resolve_scratch(pr_ctx* ctx, int32_t m) {
+  if (!ctx->res_partial) PR_HIP(ctx, hipMalloc((void**)&ctx->res_partial, (size_t)pr::RESOLVE_SLOTS * pr::RESOLVE_NB * 12 * sizeof(double)));
+  if ((size_t)m > ctx->res_exact_cap) {
+    if (ctx->res_exact) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->res_exact)); ctx->res_exact = nullptr; ctx->res_exact_cap = 0; }
+    PR_HIP(ctx, hipMalloc((void**)&ctx->res_exact, (size_t)m * 12 * sizeof(double)));
+    ctx->res_exact_cap = (size_t)m;
   }
   return PR_OK;
 }
 
 int pr_rerank_width(const pr_ctx* ctx, int32_t k) { return ctx ? rerank_width(k, ctx->sc_mode) : PR_EINVAL; }
+
+static bool order_consts(const pr_ctx* ctx, double& fl, double& noise) {
+  const bool f16 = ctx->sc_mode == PR_SC_ARITH_F16;
+  fl = f16 ? PR_F16_SIGMA_REL : PR_F32_SIGMA_REL;
+  noise = f16 ? PR_F16_NOISE : PR_F32_NOISE;
+  return f16;
+}
 
 int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                   const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
@@ -686,16 +712,50 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
     PR_FAIL(ctx, PR_EINVAL, "pr_rerank_dev: bad arguments (m=%d, n_local=%d, G=%d, k=%d, k_in=%d)", m, n_local, G, k, k_in);
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
-  const size_t need = (size_t)m * k_in;
-  // the order of the re-evaluated candidates is checked too (pr_f16_margin_dev / pr_order_resolve_dev take the flags)
-  const bool f16 = ctx->sc_mode == PR_SC_ARITH_F16;
-  if (int rc = rerank_scratch(ctx, 5 * need, m)) return rc;
-  double* parts = ctx->rr_scratch + need;
-  ctx->parts_count = 0;
+  // the candidates' scores and exact distances stay in the context (p5 layout) with one order flag per query: pr_order_resolve*_dev /
+  // pr_f16_margin_dev take them
+  if (int rc = rerank_scratch(ctx, (size_t)5 * m * k_in, m)) return rc;
+  double fl, noise;
+  order_consts(ctx, fl, noise);
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
-                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in, pass_eps(ctx), parts,
-                    f16 ? PR_F16_SIGMA_REL : PR_F32_SIGMA_REL, f16 ? PR_F16_NOISE : PR_F32_NOISE, ctx->d_order);
+                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in, pass_eps(ctx), fl, noise, ctx->d_order);
   ctx->order_m = m;
+  ctx->order_kin = k_in;
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+// one pass (RESOLVE_SLOTS list slots from `offset`) of the single-shard resolution behind pr_rerank_dev
+static void resolve_pass(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
+                         double* mom_sc, double* mom_m2, int32_t m, int32_t n, double p_weight, int32_t k_in, const int32_t* idx_in, int32_t k,
+                         int32_t* idx, double* score, int offset) {
+  pr::launch_exact_moments(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, 1, m, n, res_list(ctx), res_cnt(ctx), offset,
+                           ctx->res_partial, ctx->res_exact);
+  pr::launch_rescore(ctx->stream, res_list(ctx), res_cnt(ctx), offset, ctx->res_exact, 1, m, q_sc != nullptr, q_m2 != nullptr, p_weight, idx_in,
+                     ctx->rr_scratch, k_in, k, idx, score, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr);
+}
+
+static int resolve_args_ok(pr_ctx* ctx, const char* who, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2,
+                           int m2_dtype, const double* mom_sc, const double* mom_m2, int32_t m, int32_t n, int32_t k_in, const int32_t* idx_in,
+                           int32_t k, const int32_t* idx, const double* score) {
+  const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
+  if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !idx_in || !idx || !score || m < 0 || n < 1 ||
+      k < 1 || k_in < k || k_in > 128 || (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
+    PR_FAIL(ctx, PR_EINVAL, "%s: bad arguments (m=%d, n=%d, k=%d, k_in=%d)", who, m, n, k, k_in);
+  return PR_OK;
+}
+
+int pr_order_resolve_async_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
+                               double* mom_sc, double* mom_m2, int32_t m, int32_t n, double p_weight, int32_t k_in, const int32_t* idx_in,
+                               int32_t k, int32_t* idx, double* score) {
+  if (!ctx) return PR_EINVAL;
+  if (int rc = resolve_args_ok(ctx, "pr_order_resolve_async_dev", q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, k_in, idx_in, k, idx, score)) return rc;
+  if (m == 0 || ctx->order_m != m || ctx->order_kin != k_in) { ctx->order_m = -1; return PR_OK; }   // no (fresh) order flags of a call of this shape
+  if (int rc = set_device(ctx)) return rc;
+  if (int rc = resolve_scratch(ctx, m)) return rc;
+  ctx->order_m = -1;
+  pr::launch_flag_compact(ctx->stream, ctx->d_order, m, res_list(ctx), res_cnt(ctx), pr::RESOLVE_SLOTS, ctx->d_flags);
+  resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, p_weight, k_in, idx_in, k, idx, score, 0);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -704,41 +764,21 @@ int pr_order_resolve_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int s
                          double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight, int32_t k_in,
                          const int32_t* idx_in, const double* score_in, int32_t k, int32_t* idx, double* score, int32_t* resolved) {
   if (!ctx) return PR_EINVAL;
-  const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
-  if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !idx_in || !idx || !score || m < 0 || n < 1 ||
-      k < 1 || k_in < k || k_in > 128 || (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
-    PR_FAIL(ctx, PR_EINVAL, "pr_order_resolve_dev: bad arguments (m=%d, n=%d, k=%d, k_in=%d)", m, n, k, k_in);
+  (void)q_row0; (void)mask_width; (void)score_in;           // (the candidates' scores and distances of pr_rerank_dev are in the context: masked and pruned ones keep theirs)
+  if (int rc = resolve_args_ok(ctx, "pr_order_resolve_dev", q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, k_in, idx_in, k, idx, score)) return rc;
   if (resolved) *resolved = 0;
-  if (m == 0 || ctx->order_m != m) { ctx->order_m = -1; return PR_OK; }          // no (fresh) order flags of a call of this size: nothing to do
+  if (m == 0 || ctx->order_m != m || ctx->order_kin != k_in) { ctx->order_m = -1; return PR_OK; }
   if (int rc = set_device(ctx)) return rc;
-  std::vector<int32_t> fl(m);
-  PR_HIP(ctx, hipMemcpyAsync(fl.data(), ctx->d_order, (size_t)m * 4, hipMemcpyDeviceToHost, ctx->stream));
-  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (int rc = resolve_scratch(ctx, m)) return rc;
   ctx->order_m = -1;
-  int cnt = 0;
-  for (int32_t q = 0; q < m; q++) cnt += fl[q] != 0;
-  if (cnt == 0) return PR_OK;
-  if ((size_t)n > ctx->d64_cap) {
-    if (ctx->d64) { PR_HIP(ctx, hipFree(ctx->d64)); ctx->d64 = nullptr; ctx->d64_cap = 0; }
-    PR_HIP(ctx, hipMalloc((void**)&ctx->d64, (size_t)4 * n * sizeof(double)));
-    ctx->d64_cap = (size_t)n;
-  }
-  if (int rc = rerank_scratch(ctx, (size_t)5 * k_in, 1)) return rc;
-  const size_t esc = sc_dtype == PR_F64 ? 8 : 4, em2 = m2_dtype == PR_F64 ? 8 : 4;
-  for (int32_t q = 0; q < m; q++) {
-    if (!fl[q]) continue;
-    const void* qs = sc ? static_cast<const char*>(q_sc) + (size_t)q * 2400 * esc : nullptr;
-    const void* qm = m2 ? static_cast<const char*>(q_m2) + (size_t)q * 4 * 384 * em2 : nullptr;
-    double* ms = sc ? mom_sc + (size_t)q * 6 : nullptr;
-    double* mm = m2 ? mom_m2 + (size_t)q * 6 : nullptr;
-    pr::launch_exact_row_moments(ctx->stream, qs, db_sc, sc_dtype, qm, db_m2, m2_dtype, n, ctx->d64, ms, mm);
-    pr::launch_rerank(ctx->stream, qs, db_sc, sc_dtype, qm, db_m2, m2_dtype, ms, mm, 1, n, 1, q_row0 + q, 0, mask_width, p_weight, k_in,
-                      idx_in + (size_t)q * k_in, ctx->rr_scratch, k, idx + (size_t)q * k, score + (size_t)q * k, nullptr,
-                      score_in ? score_in + (size_t)q * k_in : nullptr, pass_eps(ctx), ctx->rr_scratch + k_in);
-  }
-  PR_HIP(ctx, hipGetLastError());
+  pr::launch_flag_compact(ctx->stream, ctx->d_order, m, res_list(ctx), res_cnt(ctx), m, ctx->d_flags);   // (cap = m: every flagged query is resolved below)
+  int32_t cnt = 0;
+  PR_HIP(ctx, hipMemcpyAsync(&cnt, res_cnt(ctx), 4, hipMemcpyDeviceToHost, ctx->stream));
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-  ctx->warnings |= PR_WARN_ORDER_RESOLVED;
+  for (int off = 0; off < cnt; off += pr::RESOLVE_SLOTS)
+    resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, p_weight, k_in, idx_in, k, idx, score, off);
+  PR_HIP(ctx, hipGetLastError());
+  if (cnt > 0) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); ctx->warnings |= PR_WARN_ORDER_RESOLVED; }
   if (resolved) *resolved = cnt;
   return PR_OK;
 }
@@ -746,56 +786,68 @@ int pr_order_resolve_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int s
 int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                           const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
                           int32_t mask_width, double p_weight, int32_t k_in, const int32_t* cand_idx, const double* cand_score, int32_t k,
-                          double* part) {
+                          double* p5) {
   if (!ctx) return PR_EINVAL;
   const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
-  if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !cand_idx || !part ||
+  if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !cand_idx || !p5 ||
       m < 0 || n_local < 1 || G < 1 || k_in < 1 || k_in > 128 || k < 1 || k > k_in ||
       (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
     PR_FAIL(ctx, PR_EINVAL, "pr_rerank_partial_dev: bad arguments (m=%d, n_local=%d, G=%d, k_in=%d)", m, n_local, G, k_in);
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
-  const bool f16 = ctx->sc_mode == PR_SC_ARITH_F16;             // the channel-0 parts stay in the context for pr_rerank_parts_dev
-  if (f16) { if (int rc = rerank_scratch(ctx, (size_t)4 * m * k_in, m)) return rc; }
   pr::launch_rerank_partial(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0,
-                            mask_width, p_weight, k_in, cand_idx, part, cand_score, k, pass_eps(ctx), f16 ? ctx->rr_scratch : nullptr);
-  ctx->parts_count = f16 ? (size_t)4 * m * k_in : 0;
+                            mask_width, p_weight, k_in, cand_idx, p5, cand_score, k, pass_eps(ctx));
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
 
-int pr_rerank_parts_dev(pr_ctx* ctx, int32_t m, int32_t k_in, double* parts) {
+int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t G_mom, const int32_t* cand_idx, const double* p5_all,
+                         int32_t G, int32_t m, int32_t k_in, int32_t k, double p_weight, int32_t* idx, double* score) {
   if (!ctx) return PR_EINVAL;
-  if (!parts || m < 0 || k_in < 1 || (size_t)4 * m * k_in != ctx->parts_count)
-    PR_FAIL(ctx, PR_EINVAL, "pr_rerank_parts_dev: no parts of a [%d][%d] pr_rerank_partial_dev call in PR_SC_ARITH_F16 on this context", m, k_in);
-  if (m == 0) return PR_OK;
-  if (int rc = set_device(ctx)) return rc;
-  PR_HIP(ctx, hipMemcpyAsync(parts, ctx->rr_scratch, ctx->parts_count * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
-  return PR_OK;
-}
-
-int pr_f16_order_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t G_mom, const int32_t* cand_idx, const double* score_all,
-                     const double* parts_all, int32_t G, int32_t m, int32_t k_in, int32_t k, const int32_t* idx) {
-  if (!ctx) return PR_EINVAL;
-  if ((!mom_sc && !mom_m2) || !cand_idx || !score_all || !parts_all || !idx || G < 1 || G > 254 || G_mom < 1 || m < 0 || k < 1 || k_in < k || k_in > 128)
-    PR_FAIL(ctx, PR_EINVAL, "pr_f16_order_dev: bad arguments (G=%d, m=%d, k=%d, k_in=%d)", G, m, k, k_in);
+  if ((!mom_sc && !mom_m2) || !cand_idx || !p5_all || !idx || !score || G < 1 || G > 254 || G_mom < 1 || m < 0 || k < 1 || k_in < k || k_in > 128)
+    PR_FAIL(ctx, PR_EINVAL, "pr_rerank_finish_dev: bad arguments (G=%d, m=%d, k=%d, k_in=%d)", G, m, k, k_in);
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   if (int rc = rerank_scratch(ctx, 0, m)) return rc;
-  pr::launch_order_check(ctx->stream, mom_sc, mom_m2, G_mom, cand_idx, score_all, parts_all, G, m, k_in, k, idx, PR_F16_SIGMA_REL, PR_F16_NOISE,
-                         ctx->d_order);
+  double fl, noise;
+  order_consts(ctx, fl, noise);
+  pr::launch_rerank_finish(ctx->stream, cand_idx, p5_all, G, m, k_in, k, idx, score);
+  pr::launch_order_check(ctx->stream, mom_sc, mom_m2, G_mom, cand_idx, p5_all, G, m, k_in, k, idx, p_weight, fl, noise, ctx->d_order);
   ctx->order_m = m;
+  ctx->order_kin = k_in;
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
 
-int pr_rerank_finish_dev(pr_ctx* ctx, const int32_t* cand_idx, const double* part_all, int32_t G, int32_t m, int32_t k_in, int32_t k,
-                         int32_t* idx, double* score) {
+int pr_order_exact_moments_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
+                               const double* mom_sc, const double* mom_m2, int32_t G_mom, int32_t m, int32_t n_local, double* exact) {
   if (!ctx) return PR_EINVAL;
-  if (!cand_idx || !part_all || !idx || !score || G < 1 || m < 0 || k < 1 || k_in < k || k_in > 128)
-    PR_FAIL(ctx, PR_EINVAL, "pr_rerank_finish_dev: bad arguments (G=%d, m=%d, k=%d, k_in=%d)", G, m, k, k_in);
+  const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
+  if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !exact || m < 0 || n_local < 1 || G_mom < 1 ||
+      (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
+    PR_FAIL(ctx, PR_EINVAL, "pr_order_exact_moments_dev: bad arguments (m=%d, n_local=%d, G=%d)", m, n_local, G_mom);
+  if (m == 0) return PR_OK;
+  if (ctx->order_m != m) PR_FAIL(ctx, PR_EINVAL, "pr_order_exact_moments_dev: no order flags of a %d-query pr_rerank_finish_dev on this context", m);
   if (int rc = set_device(ctx)) return rc;
-  pr::launch_rerank_finish(ctx->stream, cand_idx, part_all, G, m, k_in, k, idx, score);
+  if (int rc = resolve_scratch(ctx, 0)) return rc;
+  pr::launch_flag_compact(ctx->stream, ctx->d_order, m, res_list(ctx), res_cnt(ctx), pr::RESOLVE_SLOTS, ctx->d_flags);
+  pr::launch_exact_moments(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, G_mom, m, n_local, res_list(ctx), res_cnt(ctx), 0,
+                           ctx->res_partial, exact);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+int pr_order_rescore_dev(pr_ctx* ctx, const double* exact_all, int32_t G, int32_t m, int has_sc, int has_m2, double p_weight,
+                         const int32_t* cand_idx, const double* p5_all, int32_t k_in, int32_t k, int32_t* idx, double* score) {
+  if (!ctx) return PR_EINVAL;
+  if (!exact_all || (!has_sc && !has_m2) || !cand_idx || !p5_all || !idx || !score || G < 1 || G > 254 || m < 0 || k < 1 || k_in < k || k_in > 128)
+    PR_FAIL(ctx, PR_EINVAL, "pr_order_rescore_dev: bad arguments (G=%d, m=%d, k=%d, k_in=%d)", G, m, k, k_in);
+  if (m == 0) return PR_OK;
+  if (ctx->order_m != m) PR_FAIL(ctx, PR_EINVAL, "pr_order_rescore_dev: no flagged-query list of a %d-query pr_order_exact_moments_dev on this context", m);
+  if (int rc = set_device(ctx)) return rc;
+  ctx->order_m = -1;
+  pr::launch_rescore(ctx->stream, res_list(ctx), res_cnt(ctx), 0, exact_all, G, m, has_sc, has_m2, p_weight, cand_idx, p5_all, k_in, k, idx, score,
+                     nullptr, nullptr);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -1326,14 +1378,10 @@ static int m2dp_generate_impl(pr_ctx* ctx, const double* xyz, const float* inten
   if (frames_in && own_ave) { if (int rc = launch_ave_only(ctx, inten, offs, N, ave.as<float>())) return rc; }
   else if (!frames_in) { if (int rc = launch_frames_and_ave(ctx, xyz, inten, offs, N, frames.as<double>(), ave.as<float>())) return rc; }
   PR_HIP(ctx, hipMemsetAsync(ctx->d_svd_rows, 0, sizeof(int), ctx->stream));
-  hipEvent_t evs[4] = {nullptr, nullptr, nullptr, nullptr};     // two batches in flight (binning | singular pairs): see launch_m2dp_bin_svd
-  for (auto& e : evs) PR_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   pr::launch_m2dp_bin_svd(ctx->stream, xyz, inten, offs, N, max_rho, frames_in ? frames_in : frames.as<double>(), own_ave ? ave.as<float>() : nullptr, ctx->d_planes,
-                          mats.as<double>(), out, ctx->d_flags, ctx->d_svd_rows, ctx->side2, evs, evs + 2);
-  const hipError_t le = hipGetLastError(), se = hipStreamSynchronize(ctx->stream);
-  for (auto& e : evs) (void)hipEventDestroy(e);
-  PR_HIP(ctx, le);
-  PR_HIP(ctx, se);
+                          mats.as<double>(), out, ctx->d_flags, ctx->d_svd_rows, ctx->side2, ctx->ev_m2, ctx->ev_m2 + 2);
+  PR_HIP(ctx, hipGetLastError());
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PR_OK;
 }
 int pr_m2dp_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const int64_t* offs, int32_t N, double max_rho, double* out) {
@@ -1355,8 +1403,7 @@ int pr_m2dp_svd_rows(pr_ctx* ctx, int32_t* rows, int32_t cap, int32_t* count) {
   std::sort(h.begin() + 1, h.begin() + 1 + nl);                      // both channels of a row may be listed
   const int nu = (int)(std::unique(h.begin() + 1, h.begin() + 1 + nl) - (h.begin() + 1));
   for (int i = 0; i < nu && i < cap; i++) rows[i] = h[1 + i];
-  *count = nu;
-  if (h[0] > pr::M2DP_SVD_ROWS_CAP) PR_FAIL(ctx, PR_EINVAL, "pr_m2dp_svd_rows: %d pairs did not converge, the list holds %d", h[0], pr::M2DP_SVD_ROWS_CAP);
+  *count = nu;                                                       // (more than M2DP_SVD_ROWS_CAP pairs: the first ones recorded; the call-wide PR_WARN_M2DP_SVD bit stands for the rest)
   return PR_OK;
 }
 

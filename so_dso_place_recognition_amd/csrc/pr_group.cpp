@@ -11,8 +11,12 @@
 //      the list an unsharded run selects                                                              ncclAllGather, pr_merge_topk_dev
 //   3. per device: fp64 re-evaluation of the candidates inside its own rows (on average (k+8)/G per query: the cost does not
 //      grow with G)                                                                                   pr_rerank_partial_dev
-//   C. all-gather of the partial scores; device 0 takes every candidate's score from its owner and keeps the k best
-//                                                                                                     ncclAllGather, pr_rerank_finish_dev
+//   C. all-gather of the shards' evaluations (p5 blocks: scores + exact channel distances); every device takes each candidate's score
+//      from its owner, keeps the k best and checks their order                                        ncclAllGather, pr_rerank_finish_dev
+//   4. per device: exact (fp64) row moments of the queries whose order hangs on the fp32 pass's sigmas - none, as a rule: the kernels
+//      leave at once                                                                                  pr_order_exact_moments_dev
+//   D. all-gather of those moments (96 B per query per rank); every device re-scores the flagged queries' candidates with the exact
+//      statistics of the whole row (Chan combination in rank order)                                   ncclAllGather, pr_order_rescore_dev
 //
 // One host thread drives all devices; everything is asynchronous on each context's stream, the two collectives are
 // enqueued on those same streams between the kernels (one ncclGroupStart/End per collective, communicators from
@@ -39,6 +43,7 @@ struct Rccl {
   void* h = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*GroupStart)() = nullptr;
   ncclResult_t (*GroupEnd)() = nullptr;
@@ -51,7 +56,7 @@ struct Rccl {
     }
     if (!h) { err = std::string("cannot load RCCL: ") + dlerror(); return false; }
 #define SYM(field, name) field = reinterpret_cast<decltype(field)>(dlsym(h, name)); if (!field) { err = "RCCL lacks " name; return false; }
-    SYM(CommInitAll, "ncclCommInitAll") SYM(CommDestroy, "ncclCommDestroy") SYM(AllGather, "ncclAllGather")
+    SYM(CommInitAll, "ncclCommInitAll") SYM(CommDestroy, "ncclCommDestroy") SYM(CommCount, "ncclCommCount") SYM(AllGather, "ncclAllGather")
     SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
 #undef SYM
     return true;
@@ -68,6 +73,7 @@ struct Shard {
   void *raw_db = nullptr, *raw_q = nullptr;   // f64 signatures (the re-evaluation reads them)
   float *d_p = nullptr, *d_i = nullptr;
   double *mom = nullptr, *mom_all = nullptr, *score = nullptr, *score_all = nullptr, *sc64 = nullptr, *part = nullptr, *dump = nullptr;
+  double *p5_all = nullptr, *exact = nullptr, *exact_all = nullptr;
   int32_t *idx_in = nullptr, *idx = nullptr, *idx_all = nullptr, *cand = nullptr;
   float* sc32 = nullptr;
 };
@@ -113,10 +119,12 @@ static thread_local std::string g_gerr;
 static void free_match_buffers(Shard& sh) {
   (void)hipSetDevice(sh.device);
   for (void* p : {(void*)sh.raw_q, (void*)sh.d_p, (void*)sh.d_i, (void*)sh.mom, (void*)sh.mom_all, (void*)sh.score, (void*)sh.score_all,
-                  (void*)sh.idx_in, (void*)sh.idx, (void*)sh.idx_all, (void*)sh.sc32, (void*)sh.sc64, (void*)sh.part, (void*)sh.cand, (void*)sh.dump})
+                  (void*)sh.idx_in, (void*)sh.idx, (void*)sh.idx_all, (void*)sh.sc32, (void*)sh.sc64, (void*)sh.part, (void*)sh.cand, (void*)sh.dump,
+                  (void*)sh.p5_all, (void*)sh.exact, (void*)sh.exact_all})
     if (p) (void)hipFree(p);
   sh.raw_q = nullptr; sh.d_p = sh.d_i = sh.sc32 = nullptr; sh.mom = sh.mom_all = sh.score = sh.score_all = sh.sc64 = sh.part = sh.dump = nullptr;
   sh.idx_in = sh.idx = sh.idx_all = sh.cand = nullptr;
+  sh.p5_all = sh.exact = sh.exact_all = nullptr;
   if (sh.q) { pr_sigset_destroy(sh.ctx, sh.q); sh.q = nullptr; }
 }
 
@@ -162,6 +170,11 @@ extern "C" {
 const char* pr_group_last_error(const pr_group* g) { return g ? g->err.c_str() : g_gerr.c_str(); }
 int32_t pr_group_size(const pr_group* g) { return g ? g->G : 0; }
 int pr_group_uses_rccl(const pr_group* g) { return g && g->rccl; }
+int32_t pr_group_rccl_ranks(const pr_group* g) {   // asked of the communicator itself, not of the argument list
+  if (!g || !g->rccl || g->comms.empty() || !g->comms[0]) return 0;
+  int n = 0;
+  return g->nc.CommCount(g->comms[0], &n) == ncclSuccess ? n : -1;
+}
 
 void pr_group_destroy(pr_group* g) {
   if (!g) return;
@@ -290,7 +303,10 @@ static int match_topk_impl(pr_group* g, const double* h1, int32_t m, int32_t mas
       G_HIP(g, hipMalloc((void**)&sh.idx_all, (size_t)G * qc * kinc * 4));
       G_HIP(g, hipMalloc((void**)&sh.score_all, (size_t)G * qc * kinc * 8));
       G_HIP(g, hipMalloc((void**)&sh.sc64, (size_t)qc * kinc * 8));
-      G_HIP(g, hipMalloc((void**)&sh.part, (size_t)qc * kinc * 8));
+      G_HIP(g, hipMalloc((void**)&sh.part, (size_t)qc * 5 * kinc * 8));
+      G_HIP(g, hipMalloc((void**)&sh.p5_all, (size_t)G * qc * 5 * kinc * 8));
+      G_HIP(g, hipMalloc((void**)&sh.exact, (size_t)qc * 12 * 8));
+      G_HIP(g, hipMalloc((void**)&sh.exact_all, (size_t)G * qc * 12 * 8));
       G_HIP(g, hipMalloc((void**)&sh.dump, (size_t)qc * kinc * 8));
       G_HIP(g, hipMalloc((void**)&sh.cand, (size_t)qc * kinc * 4));
     }
@@ -328,12 +344,26 @@ static int match_topk_impl(pr_group* g, const double* h1, int32_t m, int32_t mas
                                       sc ? nullptr : sh.raw_db, PR_F64, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, m, sh.rows, G, 0,
                                       sh.row0, mask_width, p_weight, kin, sh.cand, sh.dump, k, sh.part));
   }
-  // C. partial scores of every shard on every device; device 0 finishes
-  for (int r = 0; r < G; r++) { src[r] = g->s[r].part; dst[r] = g->s[r].score_all; }
-  if (int rc = exchange(g, src, dst, (size_t)m * kin * 8)) return rc;
+  // C. every shard's evaluations (p5 blocks) on every device; every device finishes and checks the order of its result
+  for (int r = 0; r < G; r++) { src[r] = g->s[r].part; dst[r] = g->s[r].p5_all; }
+  if (int rc = exchange(g, src, dst, (size_t)m * 5 * kin * 8)) return rc;
+  // 4. + D. queries whose order hangs on the fp32 pass's sigmas: exact row moments per shard, gathered, candidates re-scored everywhere
+  for (auto& sh : g->s) {
+    G_HIP(g, hipSetDevice(sh.device));
+    G_PR(g, sh, pr_rerank_finish_dev(sh.ctx, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, G, sh.cand, sh.p5_all, G, m, kin, k, p_weight,
+                                     sh.idx, sh.score));
+    G_PR(g, sh, pr_order_exact_moments_dev(sh.ctx, sc ? sh.raw_q : nullptr, sc ? sh.raw_db : nullptr, PR_F64, sc ? nullptr : sh.raw_q,
+                                           sc ? nullptr : sh.raw_db, PR_F64, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, G, m, sh.rows,
+                                           sh.exact));
+  }
+  for (int r = 0; r < G; r++) { src[r] = g->s[r].exact; dst[r] = g->s[r].exact_all; }
+  if (int rc = exchange(g, src, dst, (size_t)m * 12 * 8)) return rc;
+  for (auto& sh : g->s) {
+    G_HIP(g, hipSetDevice(sh.device));
+    G_PR(g, sh, pr_order_rescore_dev(sh.ctx, sh.exact_all, G, m, sc ? 1 : 0, sc ? 0 : 1, p_weight, sh.cand, sh.p5_all, kin, k, sh.idx, sh.score));
+  }
   Shard& s0 = g->s[0];
   G_HIP(g, hipSetDevice(s0.device));
-  G_PR(g, s0, pr_rerank_finish_dev(s0.ctx, s0.cand, s0.score_all, G, m, kin, k, s0.idx, s0.score));
   G_HIP(g, hipMemcpyAsync(idx, s0.idx, (size_t)m * k * 4, hipMemcpyDeviceToHost, s0.stream));
   G_HIP(g, hipMemcpyAsync(score, s0.score, (size_t)m * k * 8, hipMemcpyDeviceToHost, s0.stream));
   for (auto& sh : g->s) { G_HIP(g, hipSetDevice(sh.device)); G_PR(g, sh, pr_sync(sh.ctx)); }

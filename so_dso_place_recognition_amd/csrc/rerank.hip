@@ -162,8 +162,12 @@ struct RerankArgs {
   double p_weight;
   const double* cand_sc; int k;                                 // fp32-pass scores of the candidates [m][kin], ascending, or null; the k wanted
   double eps_d, eps_mult;                                       // distance error bound of the all-pairs pass per channel, and the safety factor on it
-  double* cand_part;                                            // [m][4][kin] or null: the four weighted channel z-scores (SC structure, SC intensity, M2DP count, M2DP intensity; 0 for an absent type) of every evaluated candidate, NaN in [0] otherwise (order_check_kernel)
+  double* p5;                                                   // [m][5][kin]: per query the candidates' scores [kin], then their four exact channel distances [4][kin] (SC structure, SC intensity, M2DP count, M2DP intensity; 0 for an absent type; NaN in the first one = not evaluated: masked, pruned, another shard's)
 };
+// the "p5" layout: what a shard knows about the candidates of a query after its re-evaluation.  Shard g, query q, candidate t:
+//   score = p5[(((size_t)g * m + q) * 5 + 0) * kin + t],   distance of channel c = p5[(((size_t)g * m + q) * 5 + 1 + c) * kin + t]
+// One array travels through the sharded protocol's last all-gather, and it is all the order check and the fp64-statistics resolution need.
+__device__ __forceinline__ size_t p5_at(int g, int m, int q, int c5, int kin, int t) { return (((size_t)g * m + q) * 5 + c5) * kin + t; }
 
 // |all-pairs-pass score - exact score| <= this for a pair whose exact score is s, given the row statistics: distance error eps_d per
 // channel over its sigma (w = sum of weight / sigma over the channels), amplified by 1 + s^2 / (n - 1) through the statistics, + the
@@ -189,14 +193,13 @@ __device__ void chan_combine(const double* mom_all, int G, int m, int q, int ch,
   if (count) *count = cn;
 }
 
-__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t* __restrict__ idx_in,
-                                                      double* __restrict__ cand_score) {
+__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t* __restrict__ idx_in) {
   __shared__ double buf[60 * 21 + 1200];
   __shared__ double red[256];
   const int tid = threadIdx.x, q = blockIdx.x / A.kin, t = blockIdx.x % A.kin;
   const int jg = idx_in[(size_t)q * A.kin + t];
-  double* out = cand_score + (size_t)q * A.kin + t;
-  if (A.cand_part && tid < 4) A.cand_part[((size_t)q * 4 + tid) * A.kin + t] = __builtin_nan("");   // stays NaN unless the pair is evaluated (tid 0 overwrites its own store below: program order)
+  double* out = A.p5 + p5_at(0, A.m, q, 0, A.kin, t);
+  if (tid < 4) A.p5[p5_at(0, A.m, q, 1 + tid, A.kin, t)] = __builtin_nan("");   // stays NaN unless the pair is evaluated (every thread overwrites its own store below: program order)
   if (jg < 0) { if (tid == 0) *out = __builtin_nan(""); return; }
   int dij = (A.q_row0 + q) - jg;
   if (dij < 0) dij = -dij;
@@ -214,13 +217,14 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
     const double delta = A.eps_mult * score_err_bound(A.eps_d, w, sk, cn);
     if (st > sk + delta) { if (tid == 0) *out = st; return; }   // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
   }
-  double f = 0.0, z4[4] = {0.0, 0.0, 0.0, 0.0};
+  double f = 0.0, z4[4] = {0.0, 0.0, 0.0, 0.0}, d4[4] = {0.0, 0.0, 0.0, 0.0};
   if (A.q_sc) {
     for (int ch = 0; ch < 2; ch++) {
       const double d = sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + ch * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + ch * 1200,
                                      buf, red, tid);
       double mean, sd;
       chan_combine(A.mom_sc, A.G, A.m, q, ch, mean, sd);
+      d4[ch] = d;
       z4[ch] = (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);    // run_test.m:40
       f += z4[ch];
     }
@@ -230,12 +234,13 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
       const double d = m2dp_pair_exact(A.q_m2, A.m2_dt, (size_t)q * 4 * 384, A.db_m2, A.m2_dt, (size_t)jl * 4 * 384, ch, red, tid);
       double mean, sd;
       chan_combine(A.mom_m2, A.G, A.m, q, ch, mean, sd);
+      d4[2 + ch] = d;
       z4[2 + ch] = (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);
       f += z4[2 + ch];
     }
   }
   if (tid == 0) *out = f;
-  if (A.cand_part && tid < 4) A.cand_part[((size_t)q * 4 + tid) * A.kin + t] = z4[tid];    // (every thread holds the reduced values)
+  if (tid < 4) A.p5[p5_at(0, A.m, q, 1 + tid, A.kin, t)] = d4[tid];    // (every thread holds the reduced values)
 }
 
 __device__ double row_weight(const double* mom_sc, const double* mom_m2, int G, int m, int q, double p_weight, double* cn_out) {
@@ -299,54 +304,64 @@ __device__ void select_k(const int32_t* idx, const double* sc, int cnt, int k, i
   }
 }
 
-__global__ __launch_bounds__(64) void rerank_sort_kernel(const int32_t* __restrict__ idx_in, const double* __restrict__ cand_score,
+__global__ __launch_bounds__(64) void rerank_sort_kernel(const int32_t* __restrict__ idx_in, const double* __restrict__ p5,
                                                           int m, int kin, int k, int32_t* __restrict__ idx, double* __restrict__ score,
                                                           float* __restrict__ score32) {
   const int q = blockIdx.x * 64 + threadIdx.x;
   if (q >= m) return;
-  select_k(idx_in + (size_t)q * kin, cand_score + (size_t)q * kin, kin, k, idx + (size_t)q * k, score ? score + (size_t)q * k : nullptr,
+  select_k(idx_in + (size_t)q * kin, p5 + p5_at(0, m, q, 0, kin, 0), kin, k, idx + (size_t)q * k, score ? score + (size_t)q * k : nullptr,
            score32 ? score32 + (size_t)q * k : nullptr);
 }
 
-// The same with one WAVE per query (few query rows - an online call: one thread walking its 57 candidates alone is 16 us of load latency):
-// lane l holds candidates l and l + 64, k rounds of a wave arg-min by cand_before with the winner retired.
-// per-channel relative sigma error the order check allows (order_check_kernel below has the derivation)
-__device__ __forceinline__ void order_eps(const double* mom_sc, const double* mom_m2, int Gmom, int m, int q, double eps_floor, double noise,
-                                          double (&eps)[4]) {
+// Row statistics of the (up to) four channels of a query - SC structure, SC intensity, M2DP count, M2DP intensity - from the shards' moments,
+// combined in rank order: weight (p or 1; 0 = channel absent), mean, sigma, and the relative sigma error the order check allows
+// (order_check_kernel below has the derivation)
+struct RowStats { double w[4], mean[4], sd[4], eps[4]; };
+__device__ __forceinline__ void row_stats(const double* mom_sc, const double* mom_m2, int Gmom, int m, int q, double p_weight, double eps_floor,
+                                          double noise, RowStats& S) {
   for (int c = 0; c < 4; c++) {
-    eps[c] = 0.0;
+    S.w[c] = 0.0; S.mean[c] = 0.0; S.sd[c] = 1.0; S.eps[c] = 0.0;
     const double* mom = c < 2 ? mom_sc : mom_m2;
     if (!mom) continue;
-    double mean, sd, cn = 2.0;
-    chan_combine(mom, Gmom, m, q, c & 1, mean, sd, &cn);
-    const double e = 4.0 * noise / (sd * sqrt(fmax(cn - 1.0, 1.0)));
-    eps[c] = (e == e) ? fmax(eps_floor, e) : 1.0;             // (sigma = 0 or NaN: nothing about the order is certain)
+    double cn = 2.0;
+    chan_combine(mom, Gmom, m, q, c & 1, S.mean[c], S.sd[c], &cn);
+    S.w[c] = (c & 1) ? 1.0 : p_weight;
+    const double e = 4.0 * noise / (S.sd[c] * sqrt(fmax(cn - 1.0, 1.0)));
+    S.eps[c] = (e == e) ? fmax(eps_floor, e) : 1.0;             // (sigma = 0 or NaN: nothing about the order is certain)
   }
 }
+// the weighted channel z-score exactly as rerank_kernel forms it (run_test.m:40)
+__device__ __forceinline__ double chan_z(const RowStats& S, int c, double d) { return S.w[c] == 0.0 ? 0.0 : S.w[c] * ((d - S.mean[c]) / S.sd[c]); }
 
-__global__ __launch_bounds__(64) void rerank_sort_wave_kernel(const int32_t* __restrict__ idx_in, const double* __restrict__ cand_score,
+// The same with one WAVE per query (few query rows - an online call: one thread walking its 57 candidates alone is 16 us of load latency):
+// lane l holds candidates l and l + 64, k rounds of a wave arg-min by cand_before with the winner retired.
+__global__ __launch_bounds__(64) void rerank_sort_wave_kernel(const int32_t* __restrict__ idx_in, const double* __restrict__ p5,
                                                                int m, int kin, int k, int32_t* __restrict__ idx, double* __restrict__ score,
-                                                               float* __restrict__ score32, const double* __restrict__ cand_part,
+                                                               float* __restrict__ score32, int check,
                                                                const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int Gmom,
-                                                               double eps_floor, double noise, int32_t* __restrict__ order_flags) {
-  // cand_part != null: the order check of order_check_kernel folded into the selection rounds (k + 1 of them: the last one finds the best
+                                                               double p_weight, double eps_floor, double noise, int32_t* __restrict__ order_flags) {
+  // check: the order check of order_check_kernel folded into the selection rounds (k + 1 of them: the last one finds the best
   // candidate left out) - every winner is compared with the previous one; an online call saves a launch
   const int q = blockIdx.x, lane = threadIdx.x;
   double v[2], z[2][4];
   int j[2];
-  double eps[4] = {0.0, 0.0, 0.0, 0.0};
-  if (cand_part) order_eps(mom_sc, mom_m2, Gmom, m, q, eps_floor, noise, eps);
+  RowStats S;
+  if (check) row_stats(mom_sc, mom_m2, Gmom, m, q, p_weight, eps_floor, noise, S);
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const int c = lane + 64 * h;
     j[h] = c < kin ? idx_in[(size_t)q * kin + c] : -1;
-    v[h] = c < kin ? cand_score[(size_t)q * kin + c] : __builtin_nan("");
-    for (int cc = 0; cc < 4; cc++) z[h][cc] = (cand_part && c < kin) ? cand_part[((size_t)q * 4 + cc) * kin + c] : __builtin_nan("");
+    v[h] = c < kin ? p5[p5_at(0, m, q, 0, kin, c)] : __builtin_nan("");
+    const double d0 = (check && c < kin) ? p5[p5_at(0, m, q, 1, kin, c)] : __builtin_nan("");
+    for (int cc = 0; cc < 4; cc++) {
+      const double d = (check && c < kin) ? p5[p5_at(0, m, q, 1 + cc, kin, c)] : __builtin_nan("");
+      z[h][cc] = (d0 == d0) ? chan_z(S, cc, d) : __builtin_nan("");
+    }
   }
   double pv = 0.0, pz[4] = {0.0, 0.0, 0.0, 0.0};
   bool have_prev = false;
   int flag = 0;
-  const int rounds = cand_part ? k + 1 : k;
+  const int rounds = check ? k + 1 : k;
   for (int t = 0; t < rounds; t++) {
     const bool first = cand_before(v[0], j[0], v[1], j[1]) || !cand_before(v[1], j[1], v[0], j[0]);
     double bv = first ? v[0] : v[1];
@@ -365,13 +380,13 @@ __global__ __launch_bounds__(64) void rerank_sort_wave_kernel(const int32_t* __r
       if (score) score[(size_t)q * k + t] = o;
       if (score32) score32[(size_t)q * k + t] = (float)o;
     }
-    if (cand_part && ok) {                                   // (no further entries: nothing left to compare, -1 / NaN fill the rest)
+    if (check && ok) {                                       // (no further entries: nothing left to compare, -1 / NaN fill the rest)
       double wz[4];
       for (int cc = 0; cc < 4; cc++) wz[cc] = __shfl(bc < 64 ? z[0][cc] : z[1][cc], bc & 63, 64);
-      const bool evd = wz[0] == wz[0];                      // evaluated (masked: +Inf, pruned: pass score - NaN parts)
+      const bool evd = wz[0] == wz[0];                      // evaluated (masked: +Inf, pruned: pass score - NaN distances)
       if (have_prev && evd) {
         double lim = 0.0, span = 0.0;
-        for (int cc = 0; cc < 4; cc++) { const double dz = fabs(wz[cc] - pz[cc]); lim += eps[cc] * dz; span += dz; }
+        for (int cc = 0; cc < 4; cc++) { const double dz = fabs(wz[cc] - pz[cc]); lim += S.eps[cc] * dz; span += dz; }
         if (span > 0.0 && !(bv - pv > lim)) flag = 1;
       }
       have_prev = evd;
@@ -384,9 +399,9 @@ __global__ __launch_bounds__(64) void rerank_sort_wave_kernel(const int32_t* __r
   if (order_flags && lane == 0) order_flags[q] = flag;
 }
 
-// cand_idx [m][kin] + the partial evaluations of G shards [G][m][kin] (NaN where the candidate is not the shard's) -> the k best.
+// cand_idx [m][kin] + the evaluations of G shards, p5_all [G][m][5][kin] (NaN scores where the candidate is not the shard's) -> the k best.
 // Every candidate has exactly one owner; a masked pair is +Inf at its owner.
-__global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __restrict__ cand_idx, const double* __restrict__ part_all,
+__global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __restrict__ cand_idx, const double* __restrict__ p5_all,
                                                             int G, int m, int kin, int k, int32_t* __restrict__ idx,
                                                             double* __restrict__ score) {
   const int q = blockIdx.x * 64 + threadIdx.x;
@@ -397,7 +412,7 @@ __global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __rest
     ci[t] = cand_idx[(size_t)q * kin + t];
     double v = __builtin_nan("");
     for (int g = 0; g < G; g++) {
-      const double x = part_all[((size_t)g * m + q) * kin + t];
+      const double x = p5_all[p5_at(g, m, q, 0, kin, t)];
       if (x == x) { v = x; break; }
     }
     cs[t] = v;
@@ -405,31 +420,30 @@ __global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __rest
   select_k(ci, cs, kin, k, idx + (size_t)q * k, score + (size_t)q * k, nullptr);
 }
 
-// PR_SC_ARITH_F16: is the ORDER of the re-evaluated candidates certain?  Their exact scores are s = sum_c z_c over the (two or four)
-// channels with the pair's distances exact (fp64) but the row statistics those of the single-product pass: z_c scales with 1 / sigma_c,
-// and the pass's sigma_c is off by a relative eps_c.  Two candidates a, b with s_a <= s_b keep that order under the true sigmas if
+// Is the ORDER of the re-evaluated candidates certain?  Their exact scores are s = sum_c z_c over the (two or four) channels with the pair's
+// distances exact (fp64) but the row statistics those of the all-pairs pass: z_c scales with 1 / sigma_c, and the pass's sigma_c is off by a
+// relative eps_c.  Two candidates a, b with s_a <= s_b keep that order under the true sigmas if
 //      s_b - s_a > sum_c eps_c |z_c(b) - z_c(a)|
 // (always true when all channels agree on the order; the means shift both alike).  Walking the selected k and the best candidate left
 // out, every ADJACENT pair must pass - then the whole chain is in its true order and the k-th / (k+1)-th boundary is the true one.
-// eps_c: the pass's distance noise e (rms nu ~ 3e-5, |e| < 1.3e-4 observed) enters sigma^2 as (2 / n) sum (d_j - mu) e_j, i.e. a relative
-// nu / (sigma_c sqrt(n)) on sigma - 1e-4 at n = 10^4, 1e-2 on a row of 24 - so eps_c = max(PR_F16_SIGMA_REL, 4 PR_F16_NOISE / (sigma_c
-// sqrt(n - 1))) with PR_F16_NOISE = 1e-4 (include/place_recognition.h).  Pairs equal in every channel (duplicated signatures) are ordered
-// by index and certain; candidates that were not evaluated (pruned: their pass score is beyond the k-th by more than the pass's error)
-// are certain by that bound.  Anything else flags the query for the split-f16 pass.  One wave per query; score_all [G][m][kin] /
-// part_all [G][m][4][kin] hold values at the candidate's owner, NaN elsewhere (G = 1: the scratch arrays of pr_rerank_dev).
+// eps_c: the pass's distance noise e (single-product f16: rms nu ~ 3e-5, |e| < 1.3e-4 observed) enters sigma^2 as (2 / n) sum (d_j - mu) e_j,
+// i.e. a relative nu / (sigma_c sqrt(n)) on sigma - 1e-4 at n = 10^4, 1e-2 on a row of 24 - so eps_c = max(floor, 4 noise / (sigma_c
+// sqrt(n - 1))) with the PR_F16_* or PR_F32_* constants (include/place_recognition.h).  Pairs equal in every channel (duplicated signatures)
+// are ordered by index and certain; candidates that were not evaluated (pruned: their pass score is beyond the k-th by more than the pass's
+// error) are certain by that bound.  A flagged query is answered with fp64 row statistics (exact_partial_kernel ... rescore_kernel below) or,
+// in PR_SC_ARITH_F16, by the split-f16 pass.  One wave per query; p5_all [G][m][5][kin] holds values at the candidate's owner, NaN elsewhere.
 __global__ __launch_bounds__(64) void order_check_kernel(const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int Gmom,
-                                                          const int32_t* __restrict__ cand_idx, const double* __restrict__ score_all,
-                                                          const double* __restrict__ part_all, int G, int m, int kin, int k,
-                                                          const int32_t* __restrict__ idx_sel, double eps_floor, double noise,
-                                                          int32_t* __restrict__ flags) {
+                                                          const int32_t* __restrict__ cand_idx, const double* __restrict__ p5_all, int G, int m,
+                                                          int kin, int k, const int32_t* __restrict__ idx_sel, double p_weight, double eps_floor,
+                                                          double noise, int32_t* __restrict__ flags) {
   // one WAVE per query (a thread walking its 57 - 128 candidates alone is ~0.1 ms of dependent loads - an online call has one query):
   // lane l holds candidates l and l + 64; the members of S = selected k + best one left out are ranked by (score, index) through an LDS
   // copy, scattered to their rank, and lane p checks the adjacent pair (p, p + 1)
   __shared__ double s_v[128], t_v[129], t_z[4][129];
   __shared__ int s_j[128], s_in[128], t_ev[129];
   const int q = blockIdx.x, lane = threadIdx.x;
-  double eps[4];
-  order_eps(mom_sc, mom_m2, Gmom, m, q, eps_floor, noise, eps);
+  RowStats S;
+  row_stats(mom_sc, mom_m2, Gmom, m, q, p_weight, eps_floor, noise, S);
   double v[2], z[2][4];
   int j[2], ev[2], sel[2];
   for (int h = 0; h < 2; h++) {
@@ -439,11 +453,12 @@ __global__ __launch_bounds__(64) void order_check_kernel(const double* __restric
     int own = -1;
     if (j[h] >= 0)
       for (int g = 0; g < G; g++) {
-        const double x = score_all[((size_t)g * m + q) * kin + c];
+        const double x = p5_all[p5_at(g, m, q, 0, kin, c)];
         if (x == x) { v[h] = x; own = g; break; }
       }
-    for (int cc = 0; cc < 4; cc++) z[h][cc] = own >= 0 ? part_all[(((size_t)own * m + q) * 4 + cc) * kin + c] : __builtin_nan("");
-    ev[h] = own >= 0 && z[h][0] == z[h][0];                    // evaluated (masked pairs are +Inf, pruned ones keep their pass score: NaN parts)
+    const double d0 = own >= 0 ? p5_all[p5_at(own, m, q, 1, kin, c)] : __builtin_nan("");
+    ev[h] = d0 == d0;                                          // evaluated (masked pairs are +Inf, pruned ones keep their pass score: NaN distances)
+    for (int cc = 0; cc < 4; cc++) z[h][cc] = ev[h] ? chan_z(S, cc, p5_all[p5_at(own, m, q, 1 + cc, kin, c)]) : __builtin_nan("");
     sel[h] = 0;
   }
   for (int u = 0; u < k; u++) {                                // (wave-uniform loads)
@@ -488,7 +503,7 @@ __global__ __launch_bounds__(64) void order_check_kernel(const double* __restric
     double lim = 0.0, span = 0.0;
     for (int cc = 0; cc < 4; cc++) {
       const double dz = fabs(t_z[cc][p + 1] - t_z[cc][p]);
-      lim += eps[cc] * dz; span += dz;
+      lim += S.eps[cc] * dz; span += dz;
     }
     if (span > 0.0 && !(t_v[p + 1] - t_v[p] > lim)) flag = 1;
   }
@@ -496,47 +511,187 @@ __global__ __launch_bounds__(64) void order_check_kernel(const double* __restric
   if (lane == 0) flags[q] = flag ? 1 : 0;
 }
 
-// ---- resolution of a query whose order check failed (single-shard calls): the row statistics of run_test.m:40 EXACTLY.  exact_row_kernel
-// evaluates the distance of the query to every entry of the shard in fp64, in the reference's own formulation (the device functions of
-// rerank_kernel), into d64 [channels: SC p, SC i, M2DP p, M2DP i][n]; moments64_kernel turns each present channel into (count, mean, M2)
-// - two passes over the doubles, NaN left out (zero-norm signatures) - in the layout of pr_row_moments_dev.  ~23 ns per pair: 2.3 ms per
-// flagged query and 100 000 entries.
-__global__ __launch_bounds__(256) void exact_row_kernel(const void* __restrict__ q_sc, const void* __restrict__ db_sc, int sc_dt,
-                                                         const void* __restrict__ q_m2, const void* __restrict__ db_m2, int m2_dt, int n,
-                                                         double* __restrict__ d64) {
-  __shared__ double buf[60 * 21 + 1200];
-  __shared__ double red[256];
-  const int tid = threadIdx.x;
-  for (int j = blockIdx.x; j < n; j += gridDim.x) {
-    if (q_sc)
-      for (int ch = 0; ch < 2; ch++) {
-        const double d = sc_pair_exact(q_sc, sc_dt, (size_t)ch * 1200, db_sc, sc_dt, (size_t)j * 2400 + ch * 1200, buf, red, tid);
-        if (tid == 0) d64[(size_t)ch * n + j] = d;
-      }
-    if (q_m2)
-      for (int ch = 0; ch < 2; ch++) {
-        const double d = m2dp_pair_exact(q_m2, m2_dt, 0, db_m2, m2_dt, (size_t)j * 4 * 384, ch, red, tid);
-        if (tid == 0) d64[(size_t)(2 + ch) * n + j] = d;
-      }
+// ---- resolution of the queries whose order check failed: the row statistics of run_test.m:40 EXACTLY, stream-ordered (no host round trip).
+//   flag_compact_kernel   flags [m] -> the ascending list of flagged queries + their count (one workgroup; deterministic)
+//   exact_partial_kernel  for list slots [offset, offset + R): the distances of the query to every entry of THIS shard in fp64, in the
+//                         reference's own formulation (the device functions of rerank_kernel), summed per workgroup as shifted sums
+//                         (count, sum (d - K), sum (d - K)^2) about K = the all-pairs pass's mean of the whole row (the same number on every
+//                         shard): workgroup b takes entries b, b + NB, ..., thread 0 adds them in that order - partial [R][NB][4][3].
+//                         A fixed grid; with nothing flagged every workgroup leaves at once.  ~23 ns per pair.
+//   exact_finish_kernel   the NB partials of a slot added in workgroup order -> this shard's exact (count, mean, M2) per channel,
+//                         exact [m][4][3] (rows of unflagged queries are never read)
+//   rescore_kernel        one wave per slot: the fused score of every evaluated candidate again from its exact distances (p5) with the exact
+//                         statistics of all shards (exact_all [G][m][4][3], Chan combination in rank order, the operation order of
+//                         rerank_kernel), the k best by (score, index) over idx / score; with mom_* given (single shard) the query's rows of
+//                         moments are overwritten with the exact ones.
+// NaN distances (zero-norm signatures) stay out of the statistics, as in row_moments_kernel.
+__global__ __launch_bounds__(256) void flag_compact_kernel(const int32_t* __restrict__ flags, int m, int32_t* __restrict__ list /* [m] */,
+                                                            int32_t* __restrict__ cnt /* [1] */, int cap, int* __restrict__ dflags) {
+  __shared__ int wsum[4], base;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) base = 0;
+  __syncthreads();
+  for (int q0 = 0; q0 < m; q0 += 256) {
+    const int q = q0 + tid;
+    const int f = (q < m && flags[q] != 0) ? 1 : 0;
+    const unsigned long long b = __ballot(f);
+    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) wsum[w] = __popcll(b);
+    __syncthreads();
+    int off = base;
+    for (int u = 0; u < w; u++) off += wsum[u];
+    if (f) list[off + before] = q;
+    __syncthreads();
+    if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    *cnt = base;
+    if (dflags && base > 0) dflags[2] = 1;                     // PR_WARN_ORDER_RESOLVED
+    if (dflags && base > cap) dflags[3] = 1;                   // PR_WARN_ORDER_UNRESOLVED: more flagged queries than one pass resolves
   }
 }
 
-__global__ __launch_bounds__(256) void moments64_kernel(const double* __restrict__ d64, int n, double* __restrict__ mom_sc,
-                                                         double* __restrict__ mom_m2) {
+struct ExactArgs {
+  const void* q_sc; const void* db_sc; int sc_dt;
+  const void* q_m2; const void* db_m2; int m2_dt;
+  const double* mom_sc; const double* mom_m2;                   // [G][m][2][3] the all-pairs pass's moments (the pivot K = their combined mean)
+  int G, m, n_local;
+  const int32_t* list; const int32_t* cnt; int offset, R, NB;
+};
+__device__ __forceinline__ double pivot_of(const double* mom_all, int G, int m, int q, int ch) {
+  double mean, sd;
+  chan_combine(mom_all, G, m, q, ch, mean, sd);
+  return (mean == mean) ? mean : 0.5;
+}
+__global__ __launch_bounds__(256) void exact_partial_kernel(ExactArgs A, double* __restrict__ partial /* [R][NB][4][3] */) {
+  __shared__ double buf[60 * 21 + 1200];
   __shared__ double red[256];
-  const int tid = threadIdx.x, c = blockIdx.x;                  // channel 0..3
-  double* out = (c < 2 ? mom_sc : mom_m2);
-  if (!out) return;
-  out += (c & 1) * 3;
-  const double* x = d64 + (size_t)c * n;
-  double s = 0.0, cnt = 0.0;
-  for (int j = tid; j < n; j += 256) { const double v = x[j]; if (v == v) { s += v; cnt += 1.0; } }
-  const double N = block_sum256(cnt, red, tid);
-  const double mean = block_sum256(s, red, tid) / N;
-  double m2 = 0.0;
-  for (int j = tid; j < n; j += 256) { const double v = x[j]; if (v == v) m2 += (v - mean) * (v - mean); }
-  const double M2 = block_sum256(m2, red, tid);
-  if (tid == 0) { out[0] = N; out[1] = N > 0.0 ? mean : 0.0; out[2] = N > 0.0 ? M2 : 0.0; }
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int cnt = *A.cnt;
+  const size_t esc = A.sc_dt == 0 ? 8 : 4, em2 = A.m2_dt == 0 ? 8 : 4;
+  for (int s = 0; s < A.R && A.offset + s < cnt; s++) {
+    const int q = A.list[A.offset + s];
+    const void* qs = A.q_sc ? static_cast<const char*>(A.q_sc) + (size_t)q * 2400 * esc : nullptr;
+    const void* qm = A.q_m2 ? static_cast<const char*>(A.q_m2) + (size_t)q * 4 * 384 * em2 : nullptr;
+    double K[4] = {0.0, 0.0, 0.0, 0.0}, acc[4][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    if (qs) { K[0] = pivot_of(A.mom_sc, A.G, A.m, q, 0); K[1] = pivot_of(A.mom_sc, A.G, A.m, q, 1); }
+    if (qm) { K[2] = pivot_of(A.mom_m2, A.G, A.m, q, 0); K[3] = pivot_of(A.mom_m2, A.G, A.m, q, 1); }
+    for (int j = b; j < A.n_local; j += A.NB) {
+      if (qs)
+        for (int ch = 0; ch < 2; ch++) {
+          const double d = sc_pair_exact(qs, A.sc_dt, (size_t)ch * 1200, A.db_sc, A.sc_dt, (size_t)j * 2400 + ch * 1200, buf, red, tid);
+          if (d == d) { const double x = d - K[ch]; acc[ch][0] += 1.0; acc[ch][1] += x; acc[ch][2] += x * x; }
+        }
+      if (qm)
+        for (int ch = 0; ch < 2; ch++) {
+          const double d = m2dp_pair_exact(qm, A.m2_dt, 0, A.db_m2, A.m2_dt, (size_t)j * 4 * 384, ch, red, tid);
+          if (d == d) { const double x = d - K[2 + ch]; acc[2 + ch][0] += 1.0; acc[2 + ch][1] += x; acc[2 + ch][2] += x * x; }
+        }
+    }
+    if (tid < 12) {                                             // (every thread holds the same sums: the pair functions return block-wide values)
+      const int c = tid / 3, e = tid % 3;
+      partial[(((size_t)s * A.NB + b) * 4 + c) * 3 + e] = acc[c][e];
+    }
+  }
+}
+__global__ __launch_bounds__(64) void exact_finish_kernel(ExactArgs A, const double* __restrict__ partial, double* __restrict__ exact /* [m][4][3] */) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  if (A.offset + s >= *A.cnt) return;
+  const int q = A.list[A.offset + s];
+  if (lane >= 4) return;
+  const int c = lane;
+  const bool present = c < 2 ? A.q_sc != nullptr : A.q_m2 != nullptr;
+  double N = 0.0, S1 = 0.0, S2 = 0.0;
+  if (present)
+    for (int b = 0; b < A.NB; b++) {                            // workgroup order: deterministic
+      const double* o = partial + (((size_t)s * A.NB + b) * 4 + c) * 3;
+      N += o[0]; S1 += o[1]; S2 += o[2];
+    }
+  const double K = present ? pivot_of(c < 2 ? A.mom_sc : A.mom_m2, A.G, A.m, q, c & 1) : 0.0;
+  double* w = exact + ((size_t)q * 4 + c) * 3;
+  w[0] = N;
+  w[1] = N > 0.0 ? K + S1 / N : 0.0;
+  w[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
+}
+// Chan combination in rank order of exact_all [G][m][4][3] (chan_combine's arithmetic)
+__device__ void exact_combine(const double* exact_all, int G, int m, int q, int c, double& mean, double& sd, double* loc /* [3] or null: the totals */) {
+  double cn = 0.0, mu = 0.0, m2 = 0.0;
+  for (int g = 0; g < G; g++) {
+    const double* o = exact_all + (((size_t)g * m + q) * 4 + c) * 3;
+    const double nb = o[0], mb = o[1], m2b = o[2];
+    if (nb <= 0.0) continue;
+    const double tot = cn + nb, delta = mb - mu;
+    mu += delta * (nb / tot);
+    m2 += m2b + delta * delta * (cn * nb / tot);
+    cn = tot;
+  }
+  mean = mu;
+  sd = sqrt(m2 / (cn - 1.0));
+  if (loc) { loc[0] = cn; loc[1] = mu; loc[2] = m2; }
+}
+__global__ __launch_bounds__(64) void rescore_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt, int offset,
+                                                      const double* __restrict__ exact_all, int G, int m, int has_sc, int has_m2, double p_weight,
+                                                      const int32_t* __restrict__ cand_idx, const double* __restrict__ p5_all, int kin, int k,
+                                                      int32_t* __restrict__ idx, double* __restrict__ score, double* __restrict__ mom_sc,
+                                                      double* __restrict__ mom_m2) {
+  const int s = blockIdx.x, lane = threadIdx.x;
+  if (offset + s >= *cnt) return;
+  const int q = list[offset + s];
+  double w[4] = {has_sc ? p_weight : 0.0, has_sc ? 1.0 : 0.0, has_m2 ? p_weight : 0.0, has_m2 ? 1.0 : 0.0}, mean[4], sd[4];
+  for (int c = 0; c < 4; c++) {
+    mean[c] = 0.0; sd[c] = 1.0;
+    if (w[c] == 0.0) continue;
+    double loc[3];
+    exact_combine(exact_all, G, m, q, c, mean[c], sd[c], loc);
+    double* mo = c < 2 ? mom_sc : mom_m2;                        // single shard: the caller's moments become the exact ones
+    if (mo && lane < 3) mo[((size_t)q * 2 + (c & 1)) * 3 + lane] = loc[lane];
+  }
+  double v[2];
+  int j[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int c = lane + 64 * h;
+    j[h] = c < kin ? cand_idx[(size_t)q * kin + c] : -1;
+    v[h] = __builtin_nan("");
+    int own = -1;
+    if (j[h] >= 0)
+      for (int g = 0; g < G; g++) {
+        const double x = p5_all[p5_at(g, m, q, 0, kin, c)];
+        if (x == x) { v[h] = x; own = g; break; }
+      }
+    if (own >= 0) {
+      const double d0 = p5_all[p5_at(own, m, q, 1, kin, c)];
+      if (d0 == d0) {                                          // evaluated: the score again, in rerank_kernel's operation order
+        double f = 0.0;
+        for (int cc = 0; cc < 4; cc++) {
+          if (w[cc] == 0.0) continue;
+          const double d = p5_all[p5_at(own, m, q, 1 + cc, kin, c)];
+          f += w[cc] * ((d - mean[cc]) / sd[cc]);
+        }
+        v[h] = f;
+      }
+    }
+  }
+  for (int t = 0; t < k; t++) {
+    const bool first = cand_before(v[0], j[0], v[1], j[1]) || !cand_before(v[1], j[1], v[0], j[0]);
+    double bv = first ? v[0] : v[1];
+    int bj = first ? j[0] : j[1];
+    int bc = lane + (first ? 0 : 64);
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+      const double ov = __shfl_xor(bv, sft, 64);
+      const int oj = __shfl_xor(bj, sft, 64), oc = __shfl_xor(bc, sft, 64);
+      if (cand_before(ov, oj, bv, bj) || (!cand_before(bv, bj, ov, oj) && oc < bc)) { bv = ov; bj = oj; bc = oc; }
+    }
+    const bool ok = bj >= 0 && bv == bv;
+    if (lane == 0) {
+      idx[(size_t)q * k + t] = ok ? bj : -1;
+      score[(size_t)q * k + t] = ok ? bv : __builtin_nan("");
+    }
+    if (bc == lane) { j[0] = -1; v[0] = __builtin_nan(""); }
+    if (bc == lane + 64) { j[1] = -1; v[1] = __builtin_nan(""); }
+  }
 }
 
 __global__ __launch_bounds__(256) void widen_kernel(const float* __restrict__ a, long long n, double* __restrict__ b) {
@@ -582,34 +737,31 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
 
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                   double p_weight, int kin, const int32_t* idx_in, double* cand_score, int k, int32_t* idx, double* score,
-                   float* score32, const double* cand_sc32, double eps_d, double* cand_part, double order_floor, double order_noise,
-                   int32_t* order_flags) {
+                   double p_weight, int kin, const int32_t* idx_in, double* p5, int k, int32_t* idx, double* score,
+                   float* score32, const double* cand_sc32, double eps_d, double order_floor, double order_noise, int32_t* order_flags) {
   if (m <= 0) return;
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
-               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, cand_part};
-  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
-  // order check (order_flags != null, needs cand_part): inside the wave selection for few queries, its own launch otherwise
-  const bool oc = order_flags && cand_part;
+               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
+  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in);
+  // order check (order_flags != null): inside the wave selection for few queries, its own launch otherwise
   if (m <= 64 && kin <= 128) {
-    hipLaunchKernelGGL(rerank_sort_wave_kernel, dim3(m), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32,
-                       oc ? cand_part : nullptr, mom_sc, mom_m2, G, order_floor, order_noise, oc ? order_flags : nullptr);
+    hipLaunchKernelGGL(rerank_sort_wave_kernel, dim3(m), dim3(64), 0, st, idx_in, p5, m, kin, k, idx, score, score32, order_flags ? 1 : 0,
+                       q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr, G, p_weight, order_floor, order_noise, order_flags);
     return;
   }
-  hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, cand_score, m, kin, k, idx, score, score32);
-  if (oc)
-    hipLaunchKernelGGL(order_check_kernel, dim3(m), dim3(64), 0, st, mom_sc, mom_m2, G, idx_in, cand_score, cand_part, 1, m, kin, k, idx,
-                       order_floor, order_noise, order_flags);
+  hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, p5, m, kin, k, idx, score, score32);
+  if (order_flags)
+    hipLaunchKernelGGL(order_check_kernel, dim3(m), dim3(64), 0, st, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr, G, idx_in, p5, 1, m, kin, k,
+                       idx, p_weight, order_floor, order_noise, order_flags);
 }
 
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                           double p_weight, int kin, const int32_t* idx_in, double* cand_score, const double* cand_sc32, int k, double eps_d,
-                           double* cand_part) {
+                           double p_weight, int kin, const int32_t* idx_in, double* p5, const double* cand_sc32, int k, double eps_d) {
   if (m <= 0) return;
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
-               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, cand_part};
-  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in, cand_score);
+               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
+  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in);
 }
 
 void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,
@@ -620,25 +772,41 @@ void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom
                      flags, count, order_flags);
 }
 
-void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int Gmom, const int32_t* cand_idx, const double* score_all,
-                        const double* part_all, int G, int m, int kin, int k, const int32_t* idx_sel, double eps_floor, double noise,
-                        int32_t* flags) {
+void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int Gmom, const int32_t* cand_idx, const double* p5_all,
+                        int G, int m, int kin, int k, const int32_t* idx_sel, double p_weight, double eps_floor, double noise, int32_t* flags) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(order_check_kernel, dim3(m), dim3(64), 0, st, mom_sc, mom_m2, Gmom, cand_idx, score_all, part_all, G, m, kin, k,
-                     idx_sel, eps_floor, noise, flags);
+  hipLaunchKernelGGL(order_check_kernel, dim3(m), dim3(64), 0, st, mom_sc, mom_m2, Gmom, cand_idx, p5_all, G, m, kin, k, idx_sel, p_weight,
+                     eps_floor, noise, flags);
 }
 
-void launch_exact_row_moments(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
-                              int n, double* d64, double* mom_sc, double* mom_m2) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(exact_row_kernel, dim3(n < 8192 ? n : 8192), dim3(256), 0, st, q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, n, d64);
-  hipLaunchKernelGGL(moments64_kernel, dim3(4), dim3(256), 0, st, d64, n, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr);
+void launch_flag_compact(hipStream_t st, const int32_t* flags, int m, int32_t* list, int32_t* cnt, int cap, int* dflags) {
+  hipLaunchKernelGGL(flag_compact_kernel, dim3(1), dim3(256), 0, st, flags, m, list, cnt, cap, dflags);
 }
 
-void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* part_all, int G, int m, int kin, int k, int32_t* idx,
+int exact_partial_blocks(int n_local) { return n_local < RESOLVE_NB ? (n_local > 0 ? n_local : 1) : RESOLVE_NB; }
+
+void launch_exact_moments(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
+                          const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* list, const int32_t* cnt,
+                          int offset, double* partial, double* exact) {
+  if (m <= 0 || n_local <= 0) return;
+  const int NB = exact_partial_blocks(n_local);
+  ExactArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, list, cnt, offset, RESOLVE_SLOTS, NB};
+  hipLaunchKernelGGL(exact_partial_kernel, dim3(NB), dim3(256), 0, st, A, partial);
+  hipLaunchKernelGGL(exact_finish_kernel, dim3(RESOLVE_SLOTS), dim3(64), 0, st, A, partial, exact);
+}
+
+void launch_rescore(hipStream_t st, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G, int m, int has_sc,
+                    int has_m2, double p_weight, const int32_t* cand_idx, const double* p5_all, int kin, int k, int32_t* idx, double* score,
+                    double* mom_sc, double* mom_m2) {
+  if (m <= 0) return;
+  hipLaunchKernelGGL(rescore_kernel, dim3(RESOLVE_SLOTS), dim3(64), 0, st, list, cnt, offset, exact_all, G, m, has_sc, has_m2, p_weight, cand_idx,
+                     p5_all, kin, k, idx, score, mom_sc, mom_m2);
+}
+
+void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* p5_all, int G, int m, int kin, int k, int32_t* idx,
                           double* score) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(rerank_finish_kernel, dim3((m + 63) / 64), dim3(64), 0, st, cand_idx, part_all, G, m, kin, k, idx, score);
+  hipLaunchKernelGGL(rerank_finish_kernel, dim3((m + 63) / 64), dim3(64), 0, st, cand_idx, p5_all, G, m, kin, k, idx, score);
 }
 
 void launch_widen(hipStream_t st, const float* a, long long n, double* b) {

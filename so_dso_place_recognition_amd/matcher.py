@@ -18,9 +18,13 @@ Sharding: every rank holds the DB rows [db_row0, db_row0 + n_l
      selects                                                                                           [RCCL + HIP]
   5. local: fp64 re-evaluation, from the raw signatures, of the candidates that lie in this shard
      (pr_rerank_partial_dev; on average (k+8)/G pairs per query: the cost does not grow with G)          [HIP]
-  6. all_gather_into_tensor of the partial scores (8 (k+8) B per query per rank), every candidate's score taken
-     from its owner, the k best by (score, idx) (pr_rerank_finish_dev)                                  [RCCL + HIP]
-With one rank steps 2, 4 and 6 are skipped (pr_rerank_dev does 5 + the selection).
+  6. all_gather_into_tensor of the shards' evaluations (p5 blocks: score + 4 exact channel distances per candidate, 40 (k+8) B per
+     query per rank), every candidate's score taken from its owner, the k best by (score, idx) and the order check
+     (pr_rerank_finish_dev)                                                                             [RCCL + HIP]
+  7. queries whose order hangs on the fp32 pass's sigmas (none, as a rule: the kernels leave at once): this shard's exact fp64 row
+     moments (pr_order_exact_moments_dev), all_gather_into_tensor (96 B per query per rank), candidates re-scored with the exact
+     statistics of the whole row on every rank (pr_order_rescore_dev) - run_test.m:38-41,57 are fp64 throughout   [HIP + RCCL + HIP]
+With one rank steps 2, 4, 6 and 7's gather are skipped (pr_rerank_dev does 5 + the selection, pr_order_resolve_async_dev does 7).
 """
 from __future__ import annotations
 
@@ -103,17 +107,14 @@ class _Base:
         self.f16_flags, self.f16_count = flags, count
         return flags, count
 
-    def _resolve_order(self, raw6, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, cand_idx, cand_sc, k, idx, score):
-        """pr_order_resolve_dev after a single-shard pr_rerank_dev: queries whose re-evaluated order hangs on the fp32 pass's sigmas get
-        exact (fp64) row statistics and are re-evaluated; idx / score are patched in place.  Synchronises the stream (reads the flags)."""
-        cnt = C.c_int32(0)
+    def _resolve_order(self, raw6, mom_sc, mom_m2, m, n, p_weight, cand_idx, k, idx, score):
+        """pr_order_resolve_async_dev after a single-shard pr_rerank_dev: queries whose re-evaluated order hangs on the fp32 pass's sigmas get
+        exact (fp64) row statistics and their candidates are re-scored; idx / score (and the moments rows) are patched in place.
+        Stream-ordered: no host synchronisation (PR_WARN_ORDER_RESOLVED at ctx.take_warnings() tells whether it happened)."""
         self._enter()
-        self.ctx.check(self.lib.pr_order_resolve_dev(self.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), m, n, int(q_row0), int(mask_width),
-                                                     float(p_weight), cand_idx.shape[1], _dptr(cand_idx), None if cand_sc is None else _dptr(cand_sc),
-                                                     int(k), _dptr(idx), _dptr(score), C.byref(cnt)))
+        self.ctx.check(self.lib.pr_order_resolve_async_dev(self.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), m, n, float(p_weight),
+                                                           cand_idx.shape[1], _dptr(cand_idx), int(k), _dptr(idx), _dptr(score)))
         self._leave()
-        self.order_resolved = int(cnt.value)
-        return self.order_resolved
 
     def _fallback_rows(self, run_rows, idx, score, mask_width, q_row0):
         """Recomputes the flagged queries through `run_rows(rows tensor, q_row0 or None)` (a split-f16 matcher over the same DB) and
@@ -243,10 +244,9 @@ class Matcher(_Base):
         self._last_cand = (cand_idx, cand_sc)
         self._enter()
         if partial:
-            part = self._buf("part", (m, kin), torch.float64)
+            part = self._buf("part", (m, 5, kin), torch.float64)           # the shard's p5 block (include/place_recognition.h)
             self.ctx.check(self.lib.pr_rerank_partial_dev(self.ctx.h, *self._raw_args(), m, n, G, q_row0, db_row0, mask_width, p_weight, kin,
                                                           _dptr(cand_idx), csc, int(k), _dptr(part)))
-            part = _with_parts(self, part)
             self._leave()
             return part
         idx = self._buf("idx", (m, k), torch.int32)
@@ -256,9 +256,20 @@ class Matcher(_Base):
         self._leave()
         return idx, score
 
-    def finish(self, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int):
+    def _moms(self):
         sc = self.type == _lib.TYPE_SC
-        return _finish_dev(self, cand_idx, part_all, k, (self._mom_all if sc else None, None if sc else self._mom_all, self._args[0]))
+        return (self._mom_all if sc else None, None if sc else self._mom_all)
+
+    def finish(self, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int):
+        return _finish_dev(self, cand_idx, part_all, k, (*self._moms(), self._args[0]), self._args[4])
+
+    def exact_moments(self):
+        """Step 7, local half: this shard's exact row moments of the queries the last finish() flagged -> [m, 4, 3] f64."""
+        return _exact_moments_dev(self, self._raw_args()[:6], *self._moms(), self._args[0], self._m, self.n)
+
+    def rescore(self, exact_all: torch.Tensor, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int, idx: torch.Tensor, score: torch.Tensor):
+        sc = self.type == _lib.TYPE_SC
+        return _rescore_dev(self, exact_all, sc, not sc, self._args[4], cand_idx, part_all, k, idx, score)
 
     def local_phase2(self, mom_all: torch.Tensor, G: int, mask_width, p_weight, k, db_row0, q_row0):
         """Selection + re-evaluation of this shard alone -> its own top-k (what rank g would answer by itself)."""
@@ -272,19 +283,21 @@ class Matcher(_Base):
 
     def match(self, queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
               db_row0: int = 0, q_row0: int = 0, group=None, force_exchange: bool = False, f16_fallback: bool = True,
-              exact_order: bool = False):
+              exact_order: bool = True):
         """Returns (idx int32 [m,k] GLOBAL DB row indices, score float64 [m,k]) as device tensors.
-        force_exchange: run the two all-gathers and the merge even with one rank (measures the protocol's overhead).
-        exact_order (one rank, unsharded DB): queries whose re-evaluated order is not certain under the fp32 pass's row sigmas are answered
-        with fp64 row statistics (pr_order_resolve_dev; what the host calls always do) - one stream synchronisation per call."""
+        force_exchange: run the all-gathers and the merge even with one rank (measures the protocol's overhead).
+        exact_order (default): queries whose re-evaluated order is not certain under the fp32 pass's row sigmas are answered with fp64 row
+        statistics, sharded or not (run_test.m:38-41,57 are fp64 throughout) - stream-ordered kernels that leave at once when nothing is
+        flagged; False skips them (the order of the fp32-statistics scores; the flags are then simply dropped)."""
         G = _world(group)
         f16 = self.f16 and not self.plain
+        resolve = (self.exact_moments, self.rescore) if (exact_order and not self.plain and not f16) else None
         post = (lambda cand_sc, idx, score: self._margin(_dptr_mom(self, True), _dptr_mom(self, False), self._args[0], p_weight, cand_sc, k,
                                                           score)) if f16 else None
         idx, score = sharded_topk(lambda: self.local_phase1(queries),
                                   lambda mom_all, G_: self.local_select(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
                                   k, group if (G > 1 or force_exchange) else None, G, merge=self.merge, force_exchange=force_exchange,
-                                  rerank=None if self.plain else self.local_rerank, finish=self.finish, post=post)
+                                  rerank=None if self.plain else self.local_rerank, finish=self.finish, post=post, resolve=resolve)
         if f16 and f16_fallback:
             def run_rows(rows, qr0):
                 fb = self._split_twin()
@@ -292,12 +305,14 @@ class Matcher(_Base):
                 return fb.match(qsel, mask_width, p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group, force_exchange,
                                 exact_order=exact_order)
             idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
-        elif exact_order and not self.plain and G == 1 and not force_exchange and db_row0 == 0:
-            sc = self.type == _lib.TYPE_SC
-            raw = self._raw_args()[:6]
-            self._resolve_order(raw, self._mom_all if sc else None, None if sc else self._mom_all, self._m, self.n, q_row0, mask_width, p_weight,
-                                *self._last_cand, k, idx, score)
+        elif resolve is not None and G == 1 and not force_exchange:
+            self._resolve_order(self._raw_args()[:6], *self._moms(), self._m, self.n, p_weight, self._last_cand[0], k, idx, score)
         return idx, score
+
+    def take_warnings(self) -> int:
+        """PR_WARN_* bits of the context since the last call (synchronises its stream): WARN_ORDER_RESOLVED after a match() whose order
+        needed fp64 row statistics, WARN_ORDER_UNRESOLVED when more than 64 queries of one call did."""
+        return self.ctx.take_warnings()
 
     def _split_twin(self):
         """The same matcher in split-f16 over the same (already resident) raw DB, created and packed on first use."""
@@ -418,10 +433,9 @@ class FusedMatcher(_Base):
         self._last_cand = (cand_idx, cand_sc)
         self._enter()
         if partial:
-            part = self._buf("part", (m, kin), torch.float64)
+            part = self._buf("part", (m, 5, kin), torch.float64)
             self.ctx.check(self.lib.pr_rerank_partial_dev(self.ctx.h, *raw, m, n, G, q_row0, db_row0, mask_width, p_weight, kin, _dptr(cand_idx),
                                                           csc, int(k), _dptr(part)))
-            part = _with_parts(self, part)
             self._leave()
             return part
         idx = self._buf("idx", (m, k), torch.int32)
@@ -432,7 +446,17 @@ class FusedMatcher(_Base):
         return idx, score
 
     def finish(self, cand_idx, part_all, k):
-        return _finish_dev(self, cand_idx, part_all, k, (self._m1, self._m2, self._args[0]))
+        return _finish_dev(self, cand_idx, part_all, k, (self._m1, self._m2, self._args[0]), self._args[4])
+
+    def _raw6(self):
+        return (_dptr(self.sc._q_sig), _dptr(self.sc.db_sig), _torch_dt(self.sc.db_sig), _dptr(self.m2._q_sig), _dptr(self.m2.db_sig),
+                _torch_dt(self.m2.db_sig))
+
+    def exact_moments(self):
+        return _exact_moments_dev(self, self._raw6(), self._m1, self._m2, self._args[0], self.sc._m, self.sc.n)
+
+    def rescore(self, exact_all, cand_idx, part_all, k, idx, score):
+        return _rescore_dev(self, exact_all, True, True, self._args[4], cand_idx, part_all, k, idx, score)
 
     def local_phase2(self, mom_all, G, mask_width, p_weight, k, db_row0, q_row0):
         idx_in, sc = self.local_select(mom_all, G, mask_width, p_weight, k, db_row0, q_row0)
@@ -442,23 +466,25 @@ class FusedMatcher(_Base):
         return _merge_dev(self, idx_all, sc_all, k)
 
     def match(self, sc_queries: torch.Tensor, m2dp_queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
-              db_row0: int = 0, q_row0: int = 0, group=None, f16_fallback: bool = True, exact_order: bool = False):
+              db_row0: int = 0, q_row0: int = 0, group=None, f16_fallback: bool = True, exact_order: bool = True):
         G = _world(group)
         post = (lambda cand_sc, idx, score: self._margin(self._m1, self._m2, self._args[0], p_weight, cand_sc, k, score)) if self.f16 else None
+        resolve = (self.exact_moments, self.rescore) if (exact_order and not self.f16) else None
         idx, score = sharded_topk(lambda: self.local_phase1(sc_queries, m2dp_queries),
                                   lambda mom_all, G_: self.local_select(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
-                                  k, group if G > 1 else None, G, merge=self.merge, rerank=self.local_rerank, finish=self.finish, post=post)
+                                  k, group if G > 1 else None, G, merge=self.merge, rerank=self.local_rerank, finish=self.finish, post=post,
+                                  resolve=resolve)
         if self.f16 and f16_fallback:
             def run_rows(rows, qr0):
                 fb = self._split_twin()
                 return fb.match(sc_queries[rows].contiguous(), m2dp_queries.view(-1, 4, 384)[rows].reshape(-1, 384).contiguous(), mask_width,
                                 p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group, exact_order=exact_order)
             idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
-        elif exact_order and G == 1 and db_row0 == 0:
-            raw = (_dptr(self.sc._q_sig), _dptr(self.sc.db_sig), _torch_dt(self.sc.db_sig), _dptr(self.m2._q_sig), _dptr(self.m2.db_sig),
-                   _torch_dt(self.m2.db_sig))
-            self._resolve_order(raw, self._m1, self._m2, self.sc._m, self.sc.n, q_row0, mask_width, p_weight, *self._last_cand, k, idx, score)
+        elif resolve is not None and G == 1:
+            self._resolve_order(self._raw6(), self._m1, self._m2, self.sc._m, self.sc.n, p_weight, self._last_cand[0], k, idx, score)
         return idx, score
+
+    take_warnings = Matcher.take_warnings
 
     def _split_twin(self):
         if getattr(self, "_twin", None) is None or self._twin_of is not self.sc.db_sig:
@@ -488,46 +514,44 @@ def _merge_dev(owner, idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
     return idx, score
 
 
-def _with_parts(owner, part: torch.Tensor) -> torch.Tensor:
-    """PR_SC_ARITH_F16: the partial scores [m, kin] travel with their four channel z-scores (pr_rerank_parts_dev, [m, 4, kin]) as one
-    [m, 5, kin] tensor, so that the order check after the finish (pr_f16_order_dev) sees them for every shard's candidates; other
-    arithmetics: unchanged."""
-    if owner.ctx.sc_arith != "f16":
-        return part
-    m, kin = part.shape
-    both = torch.empty((m, 5, kin), dtype=torch.float64, device=part.device)
-    parts = torch.empty((m, 4, kin), dtype=torch.float64, device=part.device)
-    owner.ctx.check(owner.lib.pr_rerank_parts_dev(owner.ctx.h, m, kin, _dptr(parts)))
-    both[:, 0] = part
-    both[:, 1:] = parts
-    return both
-
-
-def _finish_dev(owner, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int, moms=None):
-    """pr_rerank_finish_dev: candidates [m, kin] + the shards' partial scores [G, m, kin] -> (idx [m,k], score [m,k]).
-    PR_SC_ARITH_F16: part_all is [G, m, 5, kin] (_with_parts) and the order of the result is checked (pr_f16_order_dev) with the row
-    statistics moms = (mom_sc | None, mom_m2 | None, shards in them)."""
-    parts_all = None
-    if part_all.dim() == 4:
-        parts_all = part_all[:, :, 1:].contiguous()
-        part_all = part_all[:, :, 0].contiguous()
-    G, m, kin = part_all.shape
+def _finish_dev(owner, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int, moms, p_weight: float):
+    """pr_rerank_finish_dev: candidates [m, kin] + the shards' p5 blocks [G, m, 5, kin] -> (idx [m,k], score [m,k]); the order check of the
+    result (statistics moms = (mom_sc | None, mom_m2 | None, shards in them)) stays in the context: pr_f16_margin_dev (PR_SC_ARITH_F16) or
+    exact_moments() / rescore() take it."""
+    G, m, five, kin = part_all.shape
+    assert five == 5
     idx = torch.empty((m, k), dtype=torch.int32, device=cand_idx.device)
     score = torch.empty((m, k), dtype=torch.float64, device=cand_idx.device)
     cand_idx = cand_idx.contiguous()
     part_all = part_all.contiguous()
+    mom_sc, mom_m2, g_mom = moms
     owner._enter()
-    owner.ctx.check(owner.lib.pr_rerank_finish_dev(owner.ctx.h, _dptr(cand_idx), _dptr(part_all), G, m, kin, k, _dptr(idx), _dptr(score)))
-    if parts_all is not None:
-        mom_sc, mom_m2, g_mom = moms
-        owner.ctx.check(owner.lib.pr_f16_order_dev(owner.ctx.h, _dptr(mom_sc), _dptr(mom_m2), int(g_mom), _dptr(cand_idx), _dptr(part_all),
-                                                   _dptr(parts_all), G, m, kin, k, _dptr(idx)))
+    owner.ctx.check(owner.lib.pr_rerank_finish_dev(owner.ctx.h, _dptr(mom_sc), _dptr(mom_m2), int(g_mom), _dptr(cand_idx), _dptr(part_all), G, m, kin, k,
+                                                   float(p_weight), _dptr(idx), _dptr(score)))
+    owner._leave()
+    return idx, score
+
+
+def _exact_moments_dev(owner, raw6, mom_sc, mom_m2, g_mom: int, m: int, n_local: int):
+    exact = torch.empty((m, 4, 3), dtype=torch.float64, device=owner.dev)
+    owner._enter()
+    owner.ctx.check(owner.lib.pr_order_exact_moments_dev(owner.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), int(g_mom), m, n_local, _dptr(exact)))
+    owner._leave()
+    return exact
+
+
+def _rescore_dev(owner, exact_all: torch.Tensor, has_sc: bool, has_m2: bool, p_weight: float, cand_idx, part_all, k: int, idx, score):
+    G, m, five, kin = part_all.shape
+    exact_all, cand_idx, part_all = exact_all.contiguous(), cand_idx.contiguous(), part_all.contiguous()
+    owner._enter()
+    owner.ctx.check(owner.lib.pr_order_rescore_dev(owner.ctx.h, _dptr(exact_all), G, m, int(has_sc), int(has_m2), float(p_weight), _dptr(cand_idx),
+                                                   _dptr(part_all), kin, k, _dptr(idx), _dptr(score)))
     owner._leave()
     return idx, score
 
 
 def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None, force_exchange: bool = False, rerank=None, finish=None,
-                 post=None):
+                 post=None, resolve=None):
     """The exchange protocol of SURVEY.md §8-e around two local callables (HIP in production; a numpy stand-in in
     the gloo CPU tests): moments -> all_gather -> select with the moments of all shards -> all_gather -> merge."""
     import torch.distributed as dist
@@ -560,6 +584,9 @@ def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None,
     cand_idx, cand_sc = do_merge(idx_all, sc_all, kin)   # the global top-(k+8) of the fp32 pass, identical on every rank
     part_all = gather(rerank(cand_idx, k, True, cand_sc))
     idx, score = finish(cand_idx, part_all, k)
+    if resolve is not None:                              # step 7: (exact moments of the flagged queries, re-scoring with the gathered ones)
+        exact_all = gather(resolve[0]())
+        idx, score = resolve[1](exact_all, cand_idx, part_all, k, idx, score)
     if post is not None:
         post(cand_sc, idx, score)
     return idx, score

@@ -140,6 +140,15 @@ def test_config1_full_kitti_seq00(ref_sequence, tmp_path):
             named = set(int(t) for t in line[0].split(":")[2].split()) if line else set()
             assert set(np.nonzero(bad.any(1))[0].tolist()) <= named, (np.nonzero(bad.any(1))[0], named)
             assert len(named) <= 8, named
+            # ... and they do not move the matcher: top-1 of every query (mask 100) from the library's signatures == from the oracle's,
+            # except where the query or one of the two answers IS such a cloud
+            dev_sig = api.m2dp_generate(x, it, offs)
+            i_lib, _ = api.match_topk("m2dp", dev_sig, dev_sig, 100, 2.0, 1)
+            i_ora, _ = api.match_topk("m2dp", want, want, 100, 2.0, 1)
+            clouds = set(r // 4 for r in named)
+            diff = np.flatnonzero(i_lib[:, 0] != i_ora[:, 0])
+            assert all((q in clouds) or (int(i_lib[q, 0]) in clouds) or (int(i_ora[q, 0]) in clouds) for q in diff.tolist()), (diff, clouds)
+            assert len(diff) <= 8 * 3
         else:
             assert not bad.any()
         sigs[exe] = (sig, got)
@@ -186,6 +195,12 @@ def test_match_signatures_devices_and_ground_truth(tmp_path):
         outs.append((np.loadtxt(res), r.stdout))
     assert np.array_equal(outs[0][0][:, 0], outs[1][0][:, 0]) and np.abs(outs[0][0][:, 1] - outs[1][0][:, 1]).max() < 1e-9
     assert "devices = 2 (copies)" in outs[1][1]
+    sig6 = np.loadtxt(f)                                                    # (the 6 significant digits the text file holds)
+    rc, oidx, osc = oracle_lib.match_topk(0, sig6, sig6, 20, 2.0, 1)        # ... and both are the oracle's answer (run_test.m:25-57)
+    assert rc == 0
+    for res, _ in outs:
+        assert np.array_equal(res[:, 0].astype(np.int64), oidx[:, 0])
+        assert (np.abs(res[:, 1] - osc[:, 0]) <= 1e-5 + 1e-6 * np.abs(osc[:, 0])).all()
     m = outs[0][0]
     auc, tr, det = ev.precision_recall(m[:, 1], m[:, 0].astype(np.int64), np.loadtxt(g), np.loadtxt(g), 15.0, 20)[:3]
     line = {l.split(" = ")[0]: l.split(" = ")[1] for l in outs[0][1].splitlines() if " = " in l}

@@ -278,11 +278,12 @@ def test_pruned_reevaluation_gives_the_unpruned_result(api):
         a = tuple(x.clone() for x in mt.local_rerank(idx_in, k, False))
         b = tuple(x.clone() for x in mt.local_rerank(idx_in, k, False, sc))
         assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
-        pa = mt.local_rerank(idx_in, k, True).clone()
+        pa = mt.local_rerank(idx_in, k, True).clone()                   # the shard's p5 block [m, 5, kin]: scores | four exact channel distances
         pb = mt.local_rerank(idx_in, k, True, sc).clone()
-        skipped = (pa != pb).sum().item()
+        skipped = (pa[:, 0] != pb[:, 0]).sum().item()
         assert skipped > m * 4                                          # it does skip: most candidates of the planted rows
-        assert torch.equal(pa[:, :k], pb[:, :k])
+        assert torch.isnan(pb[:, 1][pa[:, 0] != pb[:, 0]]).all()        # ... and says so: no distances for a pruned candidate
+        assert torch.equal(pa[:, :, :k], pb[:, :, :k])
         near = torch.arange(2 * m // 3, m, device="cuda")
         near = near[sc[near, k + 7] - sc[near, 0] < 1e-3]               # rows whose candidates are all copies of the match (a few lost theirs to the copy slots)
         assert len(near) > m // 6 and torch.equal(pa[near], pb[near])   # everything inside the margin is evaluated
@@ -363,8 +364,10 @@ def test_drive_2000_frames_mask_100(api):
 def test_order_that_hangs_on_the_row_sigmas_is_resolved_with_fp64_statistics(api):
     """Found by tools/fuzz_all.py (seed 1, `match,matcher,fused`, case 1): M2DP, 96 x 1096, k = 35.  Ranks 6 / 7 of one row differ by less
     than what the fp32 pass's sigma error (2.5e-7 relative) moves them, and their two channels disagree about the order: every arithmetic
-    returned them swapped.  The order check flags such queries and pr_order_resolve_dev answers them with fp64 row statistics (host calls:
-    always; Matcher: exact_order=True) - indices AND scores of that row are then fp64 throughout."""
+    returned them swapped.  The order check flags such queries and they are answered with fp64 row statistics on EVERY path - host calls
+    (pr_order_resolve_dev), the device-resident Matcher by default (pr_order_resolve_async_dev, stream-ordered), pr_group and the
+    torch.distributed Matcher (pr_order_exact_moments_dev + all-gather + pr_order_rescore_dev) - indices AND scores of that row are then
+    fp64 throughout."""
     import torch
     from so_dso_place_recognition_amd import _lib
     from so_dso_place_recognition_amd.matcher import Matcher
@@ -382,11 +385,34 @@ def test_order_that_hangs_on_the_row_sigmas_is_resolved_with_fp64_statistics(api
     dev = torch.device("cuda", 0)
     mt = Matcher("m2dp", m, n, ctx=api.Context(0, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
     mt.pack_database(torch.from_numpy(db).to(dev))
-    i0, s0 = mt.match(torch.from_numpy(q).to(dev), 0, 2.0, k)
+    i0, s0 = mt.match(torch.from_numpy(q).to(dev), 0, 2.0, k, exact_order=False)   # the order of the fp32-statistics scores
     i0 = i0.cpu().numpy().copy()
-    i1, s1 = mt.match(torch.from_numpy(q).to(dev), 0, 2.0, k, exact_order=True)
-    assert mt.order_resolved >= 1
+    assert not (mt.take_warnings() & _lib.WARN_ORDER_RESOLVED)
+    i1, s1 = mt.match(torch.from_numpy(q).to(dev), 0, 2.0, k)                      # the default: stream-ordered fp64-statistics resolution
+    assert mt.take_warnings() & _lib.WARN_ORDER_RESOLVED
     assert np.array_equal(i1.cpu().numpy(), oidx) and not np.array_equal(i0, oidx)
     rows = np.flatnonzero((i0 != oidx).any(axis=1))                 # the resolved rows: scores exact to fp64 rounding, not to the fp32 model
-    assert np.abs(s1.cpu().numpy()[rows] - osc[rows]).max() < 1e-9
+    assert len(rows) >= 1 and np.abs(s1.cpu().numpy()[rows] - osc[rows]).max() < 1e-9
     mt.close()
+    # the sharded protocol resolves too: pr_group with 2 / 3 / 8 virtual shards on this GPU ...
+    for G in (2, 3, 8):
+        g = api.Group([0] * G)
+        g.set_database("m2dp", db)
+        gi, gs = g.match_topk(q, 0, 2.0, k)
+        assert g.take_warnings() & _lib.WARN_ORDER_RESOLVED, G
+        assert np.array_equal(gi, oidx), G
+        assert np.abs(gs[rows] - osc[rows]).max() < 1e-9, G
+        g.close()
+    # ... and the torch.distributed Matcher with two ranks (gloo) on this GPU
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29900 + os.getpid() % 90), os.path.join(root, "tests", "dist_order_case.py")]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["world"] == 2 and d["warnings"] & _lib.WARN_ORDER_RESOLVED
+    assert np.array_equal(np.array(d["idx"]), oidx)
+    assert np.abs(np.array(d["score"])[rows] - osc[rows]).max() < 1e-9

@@ -1,4 +1,4 @@
-// sc_match_d.hip — round 2's default split-f16 SC matcher (PR_SC_KERNEL=d selects it for m > 8; the default is now sc_match_e.hip): sc_match_h.hip
+// sc_match_d.hip — EXPERIMENT since round 4 (not built into libpr_amd.so): round 2's default split-f16 SC matcher, 3 % slower than sc_match_e.hip: sc_match_h.hip
 // with stage 2 DEFERRED to the end of the unit and TRANSIENT stage-2 tiles.
 //
 // sc_match_h.hip runs stage 2 per half of the frequencies into 256 persistent AccVGPR accumulators and then pulls every one of them out in
