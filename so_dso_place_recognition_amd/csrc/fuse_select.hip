@@ -349,13 +349,21 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   // visit(j, f) over this thread's elements of the row
   auto sweep = [&](auto&& visit) {
     if (tid < head) visit(tid, fused(rp[tid], ri[tid], tid));
-    for (int j = tid; j < nv; j += 256) {
-      const f32x4 a = rp4[j], b = ri4[j];
+    auto four = [&](const f32x4& a, const f32x4& b, int j) {
       const int j0 = head + 4 * j;
       visit(j0, fused(a[0], b[0], j0)); visit(j0 + 1, fused(a[1], b[1], j0 + 1));
       visit(j0 + 2, fused(a[2], b[2], j0 + 2)); visit(j0 + 3, fused(a[3], b[3], j0 + 3));
+    };
+    int j = tid;
+    // four 16-byte loads per channel in flight (the kernel runs at ~3 workgroups per CU - its LDS list - so a thread has to cover the
+    // latency of its loads by itself); same elements, same order per thread as the plain loop
+    for (; j + 768 < nv; j += 1024) {
+      const f32x4 a0 = rp4[j], a1 = rp4[j + 256], a2 = rp4[j + 512], a3 = rp4[j + 768];
+      const f32x4 b0 = ri4[j], b1 = ri4[j + 256], b2 = ri4[j + 512], b3 = ri4[j + 768];
+      four(a0, b0, j); four(a1, b1, j + 256); four(a2, b2, j + 512); four(a3, b3, j + 768);
     }
-    for (int j = head + 4 * nv + tid; j < n; j += 256) visit(j, fused(rp[j], ri[j], j));
+    for (; j < nv; j += 256) { const f32x4 a = rp4[j], b = ri4[j]; four(a, b, j); }
+    for (int t = head + 4 * nv + tid; t < n; t += 256) visit(t, fused(rp[t], ri[t], t));
   };
   auto emit = [&](int t, double v, int jg) {
     idx[(size_t)q * k + t] = jg;
@@ -384,21 +392,34 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
     const int r = k + 7 > 16 ? k + 7 : 16;
     long long want = (long long)n * r / 1024;
     const int ns = (int)(want < 4096 ? (n < 4096 ? n : 4096) : (want < n ? want : n));
-    for (int j = tid; j < ns; j += 256) {
-      const double f = fused(rp[j], ri[j], j);
+    auto take = [&](float vp, float vi, int j) {
+      const double f = fused(vp, vi, j);
       const int jg = db_row0 + j;
       if (f == f && (mj < 0 || cand_less(f, jg, mv, mj))) { mv = f; mj = jg; }
+    };
+    int j = tid;
+    for (; j + 768 < ns; j += 1024) {
+      const float p0 = rp[j], p1 = rp[j + 256], p2 = rp[j + 512], p3 = rp[j + 768];
+      const float i0 = ri[j], i1 = ri[j + 256], i2 = ri[j + 512], i3 = ri[j + 768];
+      take(p0, i0, j); take(p1, i1, j + 256); take(p2, i2, j + 512); take(p3, i3, j + 768);
     }
-    for (int t = 0; t < r; t++) {
-      rv[tid] = mv; rj[tid] = mj;
-      block_argmin(rv, rj, tid);
-      const double wv = rv[0];
-      const int wj = rj[0];
-      __syncthreads();
-      if (wj < 0) { tau = __builtin_inf(); break; }                                  // fewer than r sample minima: no bound
-      tau = wv;
-      if (mj == wj) mj = -1;
+    for (; j < ns; j += 256) take(rp[j], ri[j], j);
+    // tau = the r-th smallest of the 256 per-thread sample minima: every thread counts the minima in front of its own (broadcast LDS
+    // reads, ~1 us) - the thread whose count is r - 1 holds it.  (r arg-min rounds of the whole workgroup, two barriers each, were a third
+    // of this kernel's time at k + 56.)  Fewer than r minima: no bound.
+    rv[tid] = mv; rj[tid] = mj;
+    __syncthreads();
+    int before = 0;
+    for (int u = 0; u < 256; u++) {
+      const int oj = rj[u];
+      if (oj >= 0 && (mj < 0 || cand_less(rv[u], oj, mv, mj))) before++;
     }
+    __shared__ double tau_s;
+    if (tid == 0) tau_s = __builtin_inf();
+    __syncthreads();
+    if (mj >= 0 && before == r - 1) tau_s = mv;      // (global indices are unique within a row: exactly one thread, if any)
+    __syncthreads();
+    tau = tau_s;
   }
   // ---- (b) everything at or below tau
   const bool whole = n <= FS_CAP && !(tau < __builtin_inf());   // a row or slice that fits: element j IS list entry j (NaN: padding)

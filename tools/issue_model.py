@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Issue-bound model of the SC matcher (sc_match_e.hip) as code: what one (8 query x 16 entry x 31 frequency) unit costs an in-order
+wavefront on gfx950, from the kernel's own instruction stream and microbenchmarked per-instruction costs - to be held against the measured
+cycles per unit ("write the issue-bound model as code, show measured >= 0.9 x model on two boxes").
+
+What is modelled (DESIGN.md section 4.0 has the measurements behind every rule):
+  * a wave issues IN ORDER, one instruction at a time; an instruction occupies the wave's issue slot for `issue[class]` cycles
+    (tools/ubench/mfma16_fillers.hip: the slope of "K fillers behind every MFMA", one wave per SIMD);
+  * an MFMA also occupies the SIMD's matrix pipe for `pipe[shape]` cycles (K = 0 of the same table): the next MFMA of the wave cannot
+    start earlier, other instructions can (that is all the overlap one in-order wave has);
+  * the first v_pk_* of a gap pays `pk_first` once (the table's intercept for v_pk_add_f32 is ~18 cycles above the other kinds);
+  * vector-memory instructions of the four waves of a CU share one address path: `ta_per_load` cycles per instruction per CU whatever its
+    width (tools/ubench/bufload_rate.hip), LDS reads `lds_per_read` (tools/ubench/lds_rate.hip) - two more bounds of the unit:
+        cycles per unit = max( issue chain of the wave,  4 waves x loads x ta_per_load,  4 waves x LDS reads x lds_per_read )
+  * waits are free (the operand rings are several walk positions deep), s_nop N costs N + 1.
+With two waves per SIMD (the single-product form) the chain of a wave pair is  max( sum of the two issue chains - what hides,  pipe ):
+the model reports both ends - no overlap (sum) and perfect overlap (max(issue total of both, matrix pipe total of both)).
+
+usage:
+  tools/issue_model.py                              # model of sc_match_e_kernel<split-f16> from the committed costs
+  tools/issue_model.py --kernel single              # ... of the single-product form (two waves per SIMD)
+  tools/issue_model.py --fit fillers.txt            # rebuild tools/issue_model_costs.json from a run of tools/ubench/mfma16_fillers
+  tools/issue_model.py --measured-cycles 7.65e7     # GRBM_GUI_ACTIVE / 8 of one launch (rocprofv3 --pmc), m x n as given -> measured / model
+  tools/issue_model.py --measured-ms 38.5 --ghz 1.95
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "so_dso_place_recognition_amd", "csrc", "sc_match_e.hip")
+COSTS = os.path.join(ROOT, "tools", "issue_model_costs.json")
+KERNELS = {"split": "ILb1ELi4ELi4E", "single": "ILb0ELi8ELi8E", "online": "ILb0ELi8ELi1E"}
+
+
+def classify(op):
+    if op.startswith("v_mfma_f32_16x16x32"):
+        return "mfma16"
+    if op.startswith("v_mfma_f32_32x32x16"):
+        return "mfma32"
+    if op.startswith("v_permlane"):
+        return "swap"
+    if op.startswith("v_pk_"):
+        return "pk"
+    if op.startswith("v_accvgpr_write"):
+        return "accw"
+    if op.startswith("v_accvgpr_read"):
+        return "accr"
+    if op.startswith("v_"):
+        return "valu"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith("buffer_load") or op.startswith("global_load"):
+        return "vload"
+    if op.startswith("buffer_store") or op.startswith("global_store"):
+        return "vstore"
+    if op == "s_waitcnt":
+        return "wait"
+    if op == "s_nop":
+        return "nop"
+    if op.startswith("s_"):
+        return "salu"
+    return "other"
+
+
+def unit_stream(kernel_tag, extra_flags=()):
+    """The instructions of the kernel's unit loop (its largest inner loop), in program order: [(class, mnemonic, operand text)]."""
+    with tempfile.NamedTemporaryFile(suffix=".s") as f:
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-S", "--cuda-device-only", *extra_flags, SRC, "-o", f.name],
+                              stderr=subprocess.DEVNULL)
+        lines = open(f.name).read().split("\n")
+    start = next(i for i, l in enumerate(lines) if l.startswith("_ZN") and ("sc_match_e_kernel" + kernel_tag) in l.split(":")[0])
+    end = next(i for i in range(start + 1, len(lines)) if lines[i].startswith("\t.end_amdhsa_kernel") or lines[i].startswith(".Lfunc_end"))
+    body = lines[start:end]
+    best = None
+    labels = {}
+    for i, l in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", l)
+        if m:
+            labels[m.group(1)] = i
+        m = re.match(r"^\s+s_cbranch_\w+\s+(\.LBB\d+_\d+)", l)
+        if m and m.group(1) in labels and (best is None or i - labels[m.group(1)] > best[1] - best[0]):
+            best = (labels[m.group(1)], i)
+    assert best, "no loop found"
+    out = []
+    for l in body[best[0]:best[1] + 1]:
+        t = l.strip()
+        if not t or t.startswith(";") or t.startswith(".") or t.endswith(":"):
+            continue
+        parts = t.split(None, 1)
+        out.append((classify(parts[0]), parts[0], parts[1] if len(parts) > 1 else ""))
+    return out
+
+
+def simulate(stream, c):
+    """In-order issue of one wave: returns (cycles of the issue chain, matrix-pipe busy cycles, histogram)."""
+    t = 0.0
+    pipe_free = 0.0
+    pipe_busy = 0.0
+    pk_in_gap = False
+    hist = {}
+    for cls, op, args in stream:
+        hist[cls] = hist.get(cls, 0) + 1
+        if cls in ("mfma16", "mfma32"):
+            t = max(t, pipe_free)
+            pipe_free = t + c["pipe"][cls]
+            pipe_busy += c["pipe"][cls]
+            t += c["issue"][cls]
+            pk_in_gap = False
+        elif cls == "nop":
+            t += int(args.strip() or 0) + 1
+        elif cls == "pk":
+            t += c["issue"]["pk"] + (0 if pk_in_gap else c["pk_first"])
+            pk_in_gap = True
+        else:
+            t += c["issue"].get(cls, c["issue"]["valu"])
+    t = max(t, pipe_free)
+    return t, pipe_busy, hist
+
+
+def fit(path):
+    """Costs from the table tools/ubench/mfma16_fillers prints: lines `<name> <shape> dst=.. .. : K=0 a  K=2 b  K=4 c  K=6 d ...`."""
+    rows = {}
+    for l in open(path):
+        m = re.match(r"^(\S+(?: \d)?)\s+(16x16x32|32x32x16) dst=(\S+) (\S+)\s*: K=0\s+([\d.]+)\s+K=2\s+([\d.]+)\s+K=4\s+([\d.]+)\s+K=6\s+([\d.]+)", l)
+        if m:
+            rows[(m.group(1), m.group(2), m.group(3), m.group(4))] = [float(m.group(i)) for i in range(5, 9)]
+    if not rows:
+        raise SystemExit("no table rows found in " + path)
+
+    def pick(name, shape="16x16x32"):
+        cands = [v for k, v in rows.items() if k[0] == name and k[1] == shape]
+        return cands[0] if cands else None
+    names = {"valu": "v_add_f32", "pk": "v_pk_add_f32", "swap": "v_permlane32_swap", "accw": "v_accvgpr_write", "lds": "ds_read_b128",
+             "vload": "buffer_load_b128"}
+    issue, raw = {}, {}
+    for cls, nm in names.items():
+        r = pick(nm)
+        if r is None:
+            continue
+        raw[nm] = r
+        issue[cls] = (r[3] - r[2]) / 2.0                      # slope between K = 4 and K = 6: past what the MFMA hides
+    plain = pick("v_add_f32")
+    pkr = pick("v_pk_add_f32")
+    mf_issue = plain[3] - 6 * issue["valu"]                   # intercept of the plain-VALU line = what the MFMA itself takes of the issue slot
+    big = pick("v_add_f32", "32x32x16")
+    c = {"pipe": {"mfma16": plain[0], "mfma32": big[0] if big else 2 * plain[0] - 4.5},
+         "issue": {**issue, "mfma16": mf_issue, "mfma32": mf_issue, "accr": issue.get("accw", 8.0), "vstore": issue.get("vload", 8.0),
+                   "salu": 1.0, "wait": 0.0, "other": issue["valu"]},
+         "pk_first": max(0.0, (pkr[3] - 6 * issue["pk"]) - mf_issue) if pkr else 0.0,
+         "ta_per_load": 16.8, "lds_per_read": 4.0,
+         "source": {"table": os.path.basename(path), "rows": raw,
+                    "ta_per_load": "tools/ubench/bufload_rate.hip: one vector-memory instruction per 16.8 clk per CU, whatever its width (DESIGN.md 4.1)",
+                    "lds_per_read": "tools/ubench/mfma16_fillers.hip ds_read_b128, all four waves: 16 clk per wave-instruction = 4 per CU slot"}}
+    # (vector loads / LDS reads: the table's slope is the SHARED path's rate seen by one of four waves; as issue cost of the wave only a
+    #  plain instruction's worth is charged, the shared path is its own bound)
+    c["issue"]["vload"] = c["issue"]["valu"]
+    c["issue"]["lds"] = c["issue"]["valu"]
+    c["issue"]["vstore"] = c["issue"]["valu"]
+    return c
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kernel", default="split", choices=list(KERNELS))
+    ap.add_argument("--fit", default=None)
+    ap.add_argument("--costs", default=COSTS)
+    ap.add_argument("--m", type=int, default=4096)
+    ap.add_argument("--n", type=int, default=100000)
+    ap.add_argument("--measured-cycles", type=float, default=None, help="GPU cycles of one launch: GRBM_GUI_ACTIVE / 8 XCDs")
+    ap.add_argument("--measured-ms", type=float, default=None)
+    ap.add_argument("--ghz", type=float, default=None, help="sustained shader clock under this kernel (GRBM_GUI_ACTIVE / 8 / duration)")
+    ap.add_argument("--json", action="store_true")
+    a = ap.parse_args()
+    if a.fit:
+        c = fit(a.fit)
+        json.dump(c, open(a.costs, "w"), indent=1)
+        print("wrote", a.costs)
+    c = json.load(open(a.costs))
+    st = unit_stream(KERNELS[a.kernel])
+    chain, pipe, hist = simulate(st, c)
+    waves_per_simd = 1 if a.kernel == "split" else 2
+    waves_per_cu = 4 * waves_per_simd
+    n_load = hist.get("vload", 0) + hist.get("vstore", 0)
+    ta = waves_per_cu * n_load * c["ta_per_load"]
+    lds = waves_per_cu * hist.get("lds", 0) * c["lds_per_read"]
+    issue_total = sum((c["issue"].get(k, c["issue"]["valu"]) * v) for k, v in hist.items() if k != "nop")
+    units_per_simd = 2.0 * ((a.m + 7) // 8) * ((a.n + 15) // 16) / 1024.0            # 2 channels; 256 CUs x 4 SIMDs
+    if waves_per_simd == 1:
+        unit = max(chain, ta, lds)
+        lo = hi = unit
+    else:   # two waves share a SIMD's issue slot and matrix pipe; the CU-wide paths see all eight
+        hi = max(chain, ta / 2, lds / 2)                     # per unit if the two waves never overlap: each waits its turn
+        lo = max(issue_total, pipe, ta / 2, lds / 2)         # perfect overlap: the busier of (issue slot, matrix pipe) of the SIMD
+        unit = hi
+    res = {"kernel": a.kernel, "instructions_per_unit": len(st), "histogram": hist, "issue_chain_cycles": round(chain, 1),
+           "matrix_pipe_cycles": round(pipe, 1), "vector_memory_path_cycles": round(ta, 1), "lds_path_cycles": round(lds, 1),
+           "model_cycles_per_unit": round(unit, 1), "units_per_simd": units_per_simd,
+           "model_cycles_per_launch": round(unit * units_per_simd, 0)}
+    if waves_per_simd == 2:
+        res["model_cycles_per_unit_perfect_overlap"] = round(lo, 1)
+    res["matrix_pipe_share_of_model"] = round(pipe / unit, 3)
+    flop = 71568 if a.kernel == "split" else 23856
+    res["frac_of_2.5PF_at_2.4GHz_if_model_met"] = round(flop * 128 / unit * 1024 * 2.4e9 / 2.5e15, 3)
+    meas = None
+    if a.measured_cycles:
+        meas = a.measured_cycles
+    elif a.measured_ms and a.ghz:
+        meas = a.measured_ms * 1e-3 * a.ghz * 1e9
+    if meas:
+        res["measured_cycles_per_unit"] = round(meas / units_per_simd, 1)
+        res["model_over_measured"] = round(unit * units_per_simd / meas, 3)
+    if a.json:
+        print(json.dumps(res))
+    else:
+        for k, v in res.items():
+            print(f"{k:42s} {v}")
+
+
+if __name__ == "__main__":
+    main()
