@@ -168,6 +168,14 @@ int pr_row_moments_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
 int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n,
                        const double* mom_all, int32_t G, int32_t q_row0, int32_t db_row0, int32_t mask_width,
                        double p_weight, int32_t k, int32_t* idx, float* score);
+/* The same, also leaving the (fp32-rounded) scores widened to doubles in score64 DEVICE [m][k] - the form pr_rerank_dev /
+ * pr_merge_topk_dev take them in (saves a pr_widen_scores_dev launch; pr_fuse_select2_f64_dev likewise). */
+int pr_fuse_select_f64_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n,
+                           const double* mom_all, int32_t G, int32_t q_row0, int32_t db_row0, int32_t mask_width,
+                           double p_weight, int32_t k, int32_t* idx, float* score, double* score64);
+int pr_fuse_select2_f64_dev(pr_ctx* ctx, const float* d_p, const float* d_i, const float* e_p, const float* e_i, int32_t m, int32_t n,
+                            const double* mom_all, const double* mom2_all, int32_t G, int32_t q_row0, int32_t db_row0,
+                            int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score, double* score64);
 
 /* fp64 re-evaluation of the survivors of pr_fuse_select_dev (run with k_in = k + 8): for every (query, idx_in entry of THIS shard)
  * the distances of the pair again from the RAW signatures in fp64, in the reference's own formulation (processSC.m:15-33: rows / L2

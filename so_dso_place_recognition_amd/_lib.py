@@ -69,6 +69,8 @@ SYMBOLS = {
     "pr_bow_distance": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _i32, _vp]),
     "pr_match_topk_fused": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_fuse_select2_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp]),
+    "pr_fuse_select2_f64_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
+    "pr_fuse_select_f64_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
     "pr_match_topk_cols": (C.c_int, [_vp, C.c_int, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pr_delight_generate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "pr_sc_distance": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _vp, _vp]),

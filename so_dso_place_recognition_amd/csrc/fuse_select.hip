@@ -272,7 +272,8 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
                                                            const double* __restrict__ mom2_all,
                                                            int m, int n, const double* __restrict__ mom_all, int G,
                                                            int q_row0, int db_row0, int mask_width, double p_weight,
-                                                           int k, int32_t* __restrict__ idx, float* __restrict__ score, int P) {
+                                                           int k, int32_t* __restrict__ idx, float* __restrict__ score, int P,
+                                                           double* __restrict__ score64) {
   __shared__ double st[8];
   __shared__ double rv[256];
   __shared__ int rj[256];
@@ -365,9 +366,13 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
     for (; j < nv; j += 256) { const f32x4 a = rp4[j], b = ri4[j]; four(a, b, j); }
     for (int t = head + 4 * nv + tid; t < n; t += 256) visit(t, fused(rp[t], ri[t], t));
   };
+  // (score64: the same fp32-rounded score widened - what the fp64 re-evaluation takes as the candidates' pass scores; saves the caller a
+  //  conversion launch, which an online call feels)
   auto emit = [&](int t, double v, int jg) {
     idx[(size_t)q * k + t] = jg;
-    score[(size_t)q * k + t] = (jg >= 0) ? (float)v : __builtin_nanf("");
+    const float f32 = (jg >= 0) ? (float)v : __builtin_nanf("");
+    score[(size_t)q * k + t] = f32;
+    if (score64) score64[(size_t)q * k + t] = (double)f32;
   };
 
   if (k == 1) {
@@ -511,7 +516,7 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
 // P lists of k (score, index) pairs per query [P][m][k] -> the k best [m][k]; missing entries are -1.  One workgroup per query: the P k
 // entries (at most 8192) are sorted in LDS by a bitonic network.
 __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restrict__ sidx, const float* __restrict__ sscore, int P, int m, int k,
-                                                           int32_t* __restrict__ idx, float* __restrict__ score) {
+                                                           int32_t* __restrict__ idx, float* __restrict__ score, double* __restrict__ score64) {
   extern __shared__ __attribute__((aligned(8))) char smem[];
   const int q = blockIdx.x, tid = threadIdx.x, T = P * k;
   int N = 2;
@@ -535,7 +540,9 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restr
     for (int t = tid; t < k; t += 256) {
       const bool ok = rj[t] != NONE_J;
       idx[(size_t)q * k + t] = ok ? rj[t] : -1;
-      score[(size_t)q * k + t] = ok ? (float)rv[t] : __builtin_nanf("");
+      const float f32 = ok ? (float)rv[t] : __builtin_nanf("");
+      score[(size_t)q * k + t] = f32;
+      if (score64) score64[(size_t)q * k + t] = (double)f32;
     }
     return;
   }
@@ -553,7 +560,9 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restr
   for (int t = tid; t < k; t += 256) {
     const bool ok = lj[t] != NONE_J;
     idx[(size_t)q * k + t] = ok ? lj[t] : -1;
-    score[(size_t)q * k + t] = ok ? lv[t] : __builtin_nanf("");
+    const float f32 = ok ? lv[t] : __builtin_nanf("");
+    score[(size_t)q * k + t] = f32;
+    if (score64) score64[(size_t)q * k + t] = (double)f32;
   }
 }
 
@@ -588,7 +597,7 @@ void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int 
 
 void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int m, int n, const double* mom_all,
                         int G, int q_row0, int db_row0, int mask_width, double p_weight, int k, int32_t* idx,
-                        float* score, const float* e_p, const float* e_i, const double* mom2_all, void* scratch) {
+                        float* score, const float* e_p, const float* e_i, const double* mom2_all, void* scratch, double* score64) {
   if (m <= 0) return;
   int P = (scratch && k <= 128) ? select_slices(m, n) : 1;
   if ((size_t)P * m * k > (size_t)64 * 16 * 128) P = 1;      // capacity of the slice lists
@@ -596,17 +605,17 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
     int32_t* sidx = static_cast<int32_t*>(scratch);
     float* ssc = reinterpret_cast<float*>(sidx + (size_t)64 * 16 * 128);
     hipLaunchKernelGGL(fuse_select_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
-                       mask_width, p_weight, k, sidx, ssc, P);
+                       mask_width, p_weight, k, sidx, ssc, P, nullptr);
     int N = 2;
     while (N < P * k) N <<= 1;
     // (up to 8192 entries = 64 KB of dynamic LDS next to ~4 KB of static arrays: above the 64 KB a launch gets without asking)
     if ((size_t)N * 8 > 40 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(slice_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)N * 8));
-    hipLaunchKernelGGL(slice_merge_kernel, dim3(m), dim3(256), (size_t)N * 8, st, sidx, ssc, P, m, k, idx, score);
+    hipLaunchKernelGGL(slice_merge_kernel, dim3(m), dim3(256), (size_t)N * 8, st, sidx, ssc, P, m, k, idx, score, score64);
     return;
   }
   hipLaunchKernelGGL(fuse_select_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
-                     mask_width, p_weight, k, idx, score, 1);
+                     mask_width, p_weight, k, idx, score, 1, score64);
 }
 
 }  // namespace pr

@@ -66,7 +66,8 @@ size_t select_scratch_bytes();
 void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom, void* scratch = nullptr);
 void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int m, int n, const double* mom_all,
                         int G, int q_row0, int db_row0, int mask_width, double p_weight, int k, int32_t* idx,
-                        float* score, const float* e_p = nullptr, const float* e_i = nullptr, const double* mom2_all = nullptr, void* scratch = nullptr);
+                        float* score, const float* e_p = nullptr, const float* e_i = nullptr, const double* mom2_all = nullptr, void* scratch = nullptr,
+                        double* score64 = nullptr /* the same scores widened to f64 [m][k] */);
 
 // rerank.hip — NaN rows / columns of zero-norm signatures (processSC.m:16,19), the fp64 re-evaluation of the fp32
 // selection's survivors (processSC.m:15-33 / processM2DP.m:12-22 + run_test.m:40 per pair) and the k-way shard merge
@@ -75,13 +76,13 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
 // SC intensity, M2DP count, M2DP intensity; NaN in the first = not evaluated) - what a shard knows after its re-evaluation (rerank.hip)
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                   double p_weight, int kin, const int32_t* idx_in, double* p5, int k, int32_t* idx, double* score,
+                   double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick /* [m][kin] zeros (left zero) */, int k, int32_t* idx, double* score,
                    float* score32, const double* cand_sc32, double eps_d = 0.0, double order_floor = 0.0,
                    double order_noise = 0.0, int32_t* order_flags = nullptr);   // order_flags [m]: the order check of launch_order_check on the result; cand_sc32: the candidates' all-pairs-pass scores (ascending) or null: prunes hopeless candidates; eps_d: that pass's distance error bound (0: the fp32-grade 1e-6 with a 64x margin)
 // the sharded form: scores + distances of the candidates THIS shard owns (NaN elsewhere), then owner-wise combination + selection
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                           double p_weight, int kin, const int32_t* idx_in, double* p5, const double* cand_sc32, int k, double eps_d = 0.0);
+                           double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, const double* cand_sc32, int k, double eps_d = 0.0);
 // PR_SC_ARITH_F16: flags[q] = 1 where the candidate list does not provably contain the exact top-k (rerank.hip), count += number of flags
 void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,
                          const double* cand_sc, int k, const double* score, double eps_d, int32_t* flags, int32_t* count,
@@ -95,13 +96,19 @@ void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_
 // then the candidates' scores again from their exact distances with the exact statistics of all shards, and the k best (rerank.hip)
 constexpr int RESOLVE_SLOTS = 64;
 constexpr int RESOLVE_NB = 2048;
-void launch_flag_compact(hipStream_t st, const int32_t* flags, int m, int32_t* list, int32_t* cnt, int cap, int* dflags);
-void launch_exact_moments(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
-                          const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* list, const int32_t* cnt,
-                          int offset, double* partial, double* exact);
-void launch_rescore(hipStream_t st, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G, int m, int has_sc,
-                    int has_m2, double p_weight, const int32_t* cand_idx, const double* p5_all, int kin, int k, int32_t* idx, double* score,
-                    double* mom_sc /* single shard: overwritten with the exact rows, else null */, double* mom_m2);
+constexpr int RESOLVE_SMALL_M = 1024;            // calls of up to this many queries: the kernels scan the flags themselves (no compaction launch)
+// one pass of the resolution on this shard: exact moments of the flagged queries' rows (-> exact [m][4][3]); rescore: single-shard calls,
+// the candidates are re-scored and idx / score / out_mom_* patched in the same launch.  compacted: list / cnt are already there
+// (launch_flag_compact: the host-synchronising form runs several passes over one list)
+void launch_flag_compact(hipStream_t st, const int32_t* flags, int m, int32_t* list, int32_t* cnt);
+void launch_resolve(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
+                    const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* flags, int32_t* list, int32_t* cnt,
+                    int offset, bool compacted, double* partial, double* exact, unsigned* tick, int* dflags, bool rescore, double p_weight,
+                    const int32_t* cand_idx, const double* p5, int kin, int k, int32_t* idx, double* score, double* out_mom_sc, double* out_mom_m2);
+// sharded calls, after the all-gather of the shards' exact moments (flags / list: as left by launch_resolve on this context)
+void launch_rescore(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G, int m,
+                    int has_sc, int has_m2, double p_weight, const int32_t* cand_idx, const double* p5_all, int kin, int k, int32_t* idx,
+                    double* score);
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* p5_all, int G, int m, int kin, int k, int32_t* idx,
                           double* score);
 void launch_widen(hipStream_t st, const float* a, long long n, double* b);

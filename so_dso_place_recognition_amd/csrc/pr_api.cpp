@@ -44,6 +44,8 @@ struct pr_ctx {
   size_t order_cap = 0;
   int32_t order_m = -1;           // rows of d_order that are valid, -1: none
   int32_t order_kin = 0;          // candidate-list width of the call that left them
+  unsigned* rr_tick = nullptr;    // [tick_cap] per-pair tickets of rerank_kernel (zero between launches)
+  size_t tick_cap = 0;
   double* res_partial = nullptr;  // [RESOLVE_SLOTS][RESOLVE_NB][4][3] workgroup partials of the fp64-statistics resolution (rerank.hip), allocated on first use
   double* res_exact = nullptr;    // [res_exact_cap][4][3] exact row moments of the flagged queries (single-shard calls)
   size_t res_exact_cap = 0;
@@ -278,6 +280,7 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->sc_scratch) (void)hipFree(ctx->sc_scratch);
   if (ctx->rr_scratch) (void)hipFree(ctx->rr_scratch);
   if (ctx->d_order) (void)hipFree(ctx->d_order);
+  if (ctx->rr_tick) (void)hipFree(ctx->rr_tick);
   if (ctx->res_partial) (void)hipFree(ctx->res_partial);
   if (ctx->res_exact) (void)hipFree(ctx->res_exact);
   if (ctx->sel_scratch) (void)hipFree(ctx->sel_scratch);
@@ -630,15 +633,26 @@ int pr_row_moments_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t 
   return PR_OK;
 }
 
-int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n, const double* mom_all,
-                       int32_t G, int32_t q_row0, int32_t db_row0, int32_t mask_width, double p_weight, int32_t k,
-                       int32_t* idx, float* score) {
+static int fuse_select_impl(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n, const double* mom_all,
+                            int32_t G, int32_t q_row0, int32_t db_row0, int32_t mask_width, double p_weight, int32_t k,
+                            int32_t* idx, float* score, double* score64) {
   if (!ctx || !d_p || (d_i && !mom_all) || !idx || !score || m < 0 || n < 1 || G < 1 || k < 1)
     return PR_EINVAL;
   if (int rc = set_device(ctx)) return rc;
-  pr::launch_fuse_select(ctx->stream, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, nullptr, nullptr, nullptr, ctx->sel_scratch);
+  pr::launch_fuse_select(ctx->stream, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, nullptr, nullptr, nullptr, ctx->sel_scratch, score64);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
+}
+int pr_fuse_select_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n, const double* mom_all,
+                       int32_t G, int32_t q_row0, int32_t db_row0, int32_t mask_width, double p_weight, int32_t k,
+                       int32_t* idx, float* score) {
+  return fuse_select_impl(ctx, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, nullptr);
+}
+int pr_fuse_select_f64_dev(pr_ctx* ctx, const float* d_p, const float* d_i, int32_t m, int32_t n, const double* mom_all,
+                           int32_t G, int32_t q_row0, int32_t db_row0, int32_t mask_width, double p_weight, int32_t k,
+                           int32_t* idx, float* score, double* score64) {
+  if (!score64) return PR_EINVAL;
+  return fuse_select_impl(ctx, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, score64);
 }
 
 // survivors of the all-pairs selection that the fp64 re-evaluation looks at: k + 8 (fp32-grade passes), k + 56 in the single-product
@@ -678,11 +692,25 @@ static int rerank_scratch(pr_ctx* ctx, size_t need, int32_t m) {
   }
   return PR_OK;
 }
+// the per-pair tickets of rerank_kernel ([pairs] zeros; the kernel leaves them zero)
+static int rerank_ticks(pr_ctx* ctx, size_t pairs) {
+  if (pairs > ctx->tick_cap) {
+    if (ctx->rr_tick) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->rr_tick)); ctx->rr_tick = nullptr; ctx->tick_cap = 0; }
+    PR_HIP(ctx, hipMalloc((void**)&ctx->rr_tick, pairs * sizeof(unsigned)));
+    PR_HIP(ctx, hipMemsetAsync(ctx->rr_tick, 0, pairs * sizeof(unsigned), ctx->stream));
+    ctx->tick_cap = pairs;
+  }
+  return PR_OK;
+}
 static int32_t* res_list(pr_ctx* ctx) { return ctx->d_order + ctx->order_cap; }
 static int32_t* res_cnt(pr_ctx* ctx) { return ctx->d_order + 2 * ctx->order_cap; }
+static unsigned* res_tick(pr_ctx* ctx) { return reinterpret_cast<unsigned*>(ctx->res_partial + (size_t)pr::RESOLVE_SLOTS * pr::RESOLVE_NB * 12); }
 // scratch of the fp64-statistics resolution: the workgroup partials of one pass + exact [m][4][3] (single-shard calls)
 static int resolve_scratch(pr_ctx* ctx, int32_t m) {
-  if (!ctx->res_partial) PR_HIP(ctx, hipMalloc((void**)&ctx->res_partial, (size_t)pr::RESOLVE_SLOTS * pr::RESOLVE_NB * 12 * sizeof(double)));
+  if (!ctx->res_partial) {                                    // (+ the ticket of the last-workgroup hand-off, zero between launches)
+    PR_HIP(ctx, hipMalloc((void**)&ctx->res_partial, ((size_t)pr::RESOLVE_SLOTS * pr::RESOLVE_NB * 12 + 1) * sizeof(double)));
+    PR_HIP(ctx, hipMemsetAsync(ctx->res_partial + (size_t)pr::RESOLVE_SLOTS * pr::RESOLVE_NB * 12, 0, sizeof(double), ctx->stream));
+  }
   if ((size_t)m > ctx->res_exact_cap) {
     if (ctx->res_exact) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->res_exact)); ctx->res_exact = nullptr; ctx->res_exact_cap = 0; }
     PR_HIP(ctx, hipMalloc((void**)&ctx->res_exact, (size_t)m * 12 * sizeof(double)));
@@ -715,24 +743,25 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
   // the candidates' scores and exact distances stay in the context (p5 layout) with one order flag per query: pr_order_resolve*_dev /
   // pr_f16_margin_dev take them
   if (int rc = rerank_scratch(ctx, (size_t)5 * m * k_in, m)) return rc;
+  if (int rc = rerank_ticks(ctx, (size_t)m * k_in)) return rc;
   double fl, noise;
   order_consts(ctx, fl, noise);
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
-                    p_weight, k_in, idx_in, ctx->rr_scratch, k, idx, score, nullptr, score_in, pass_eps(ctx), fl, noise, ctx->d_order);
+                    p_weight, k_in, idx_in, ctx->rr_scratch, ctx->rr_tick, k, idx, score, nullptr, score_in, pass_eps(ctx), fl, noise, ctx->d_order);
   ctx->order_m = m;
   ctx->order_kin = k_in;
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
 
-// one pass (RESOLVE_SLOTS list slots from `offset`) of the single-shard resolution behind pr_rerank_dev
+// one pass (RESOLVE_SLOTS list slots from `offset`) of the single-shard resolution behind pr_rerank_dev: ONE launch (+ the compaction
+// of the flags for calls of more than RESOLVE_SMALL_M queries)
 static void resolve_pass(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                          double* mom_sc, double* mom_m2, int32_t m, int32_t n, double p_weight, int32_t k_in, const int32_t* idx_in, int32_t k,
-                         int32_t* idx, double* score, int offset) {
-  pr::launch_exact_moments(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, 1, m, n, res_list(ctx), res_cnt(ctx), offset,
-                           ctx->res_partial, ctx->res_exact);
-  pr::launch_rescore(ctx->stream, res_list(ctx), res_cnt(ctx), offset, ctx->res_exact, 1, m, q_sc != nullptr, q_m2 != nullptr, p_weight, idx_in,
-                     ctx->rr_scratch, k_in, k, idx, score, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr);
+                         int32_t* idx, double* score, int offset, bool compacted, int* dflags) {
+  pr::launch_resolve(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, 1, m, n, ctx->d_order, res_list(ctx), res_cnt(ctx),
+                     offset, compacted, ctx->res_partial, ctx->res_exact, res_tick(ctx), dflags, true, p_weight, idx_in, ctx->rr_scratch, k_in, k,
+                     idx, score, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr);
 }
 
 static int resolve_args_ok(pr_ctx* ctx, const char* who, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2,
@@ -754,8 +783,7 @@ int pr_order_resolve_async_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc,
   if (int rc = set_device(ctx)) return rc;
   if (int rc = resolve_scratch(ctx, m)) return rc;
   ctx->order_m = -1;
-  pr::launch_flag_compact(ctx->stream, ctx->d_order, m, res_list(ctx), res_cnt(ctx), pr::RESOLVE_SLOTS, ctx->d_flags);
-  resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, p_weight, k_in, idx_in, k, idx, score, 0);
+  resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, p_weight, k_in, idx_in, k, idx, score, 0, false, ctx->d_flags);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -771,12 +799,12 @@ int pr_order_resolve_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int s
   if (int rc = set_device(ctx)) return rc;
   if (int rc = resolve_scratch(ctx, m)) return rc;
   ctx->order_m = -1;
-  pr::launch_flag_compact(ctx->stream, ctx->d_order, m, res_list(ctx), res_cnt(ctx), m, ctx->d_flags);   // (cap = m: every flagged query is resolved below)
+  pr::launch_flag_compact(ctx->stream, ctx->d_order, m, res_list(ctx), res_cnt(ctx));
   int32_t cnt = 0;
   PR_HIP(ctx, hipMemcpyAsync(&cnt, res_cnt(ctx), 4, hipMemcpyDeviceToHost, ctx->stream));
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int off = 0; off < cnt; off += pr::RESOLVE_SLOTS)
-    resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, p_weight, k_in, idx_in, k, idx, score, off);
+    resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, p_weight, k_in, idx_in, k, idx, score, off, true, nullptr);
   PR_HIP(ctx, hipGetLastError());
   if (cnt > 0) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); ctx->warnings |= PR_WARN_ORDER_RESOLVED; }
   if (resolved) *resolved = cnt;
@@ -795,8 +823,9 @@ int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int 
     PR_FAIL(ctx, PR_EINVAL, "pr_rerank_partial_dev: bad arguments (m=%d, n_local=%d, G=%d, k_in=%d)", m, n_local, G, k_in);
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
+  if (int rc = rerank_ticks(ctx, (size_t)m * k_in)) return rc;
   pr::launch_rerank_partial(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0,
-                            mask_width, p_weight, k_in, cand_idx, p5, cand_score, k, pass_eps(ctx));
+                            mask_width, p_weight, k_in, cand_idx, p5, ctx->rr_tick, cand_score, k, pass_eps(ctx));
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -830,9 +859,9 @@ int pr_order_exact_moments_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc,
   if (ctx->order_m != m) PR_FAIL(ctx, PR_EINVAL, "pr_order_exact_moments_dev: no order flags of a %d-query pr_rerank_finish_dev on this context", m);
   if (int rc = set_device(ctx)) return rc;
   if (int rc = resolve_scratch(ctx, 0)) return rc;
-  pr::launch_flag_compact(ctx->stream, ctx->d_order, m, res_list(ctx), res_cnt(ctx), pr::RESOLVE_SLOTS, ctx->d_flags);
-  pr::launch_exact_moments(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, G_mom, m, n_local, res_list(ctx), res_cnt(ctx), 0,
-                           ctx->res_partial, exact);
+  pr::launch_resolve(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, G_mom, m, n_local, ctx->d_order, res_list(ctx),
+                     res_cnt(ctx), 0, false, ctx->res_partial, exact, res_tick(ctx), ctx->d_flags, false, 0.0, nullptr, nullptr, 0, 0, nullptr, nullptr,
+                     nullptr, nullptr);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -846,8 +875,8 @@ int pr_order_rescore_dev(pr_ctx* ctx, const double* exact_all, int32_t G, int32_
   if (ctx->order_m != m) PR_FAIL(ctx, PR_EINVAL, "pr_order_rescore_dev: no flagged-query list of a %d-query pr_order_exact_moments_dev on this context", m);
   if (int rc = set_device(ctx)) return rc;
   ctx->order_m = -1;
-  pr::launch_rescore(ctx->stream, res_list(ctx), res_cnt(ctx), 0, exact_all, G, m, has_sc, has_m2, p_weight, cand_idx, p5_all, k_in, k, idx, score,
-                     nullptr, nullptr);
+  pr::launch_rescore(ctx->stream, ctx->d_order, res_list(ctx), res_cnt(ctx), 0, exact_all, G, m, has_sc, has_m2, p_weight, cand_idx, p5_all, k_in, k,
+                     idx, score);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -1066,14 +1095,25 @@ int pr_match_topk_f64(pr_ctx* ctx, int type, const double* h1, int32_t m, const 
   return distance_host(ctx, type, h1, m, h2, n, nullptr, nullptr, mask_width, p_weight, k, idx, nullptr, score, true);
 }
 
+static int fuse_select2_impl(pr_ctx* ctx, const float* d_p, const float* d_i, const float* e_p, const float* e_i, int32_t m, int32_t n,
+                             const double* mom_all, const double* mom2_all, int32_t G, int32_t q_row0, int32_t db_row0,
+                             int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score, double* score64) {
+  if (!ctx || !d_p || !d_i || !e_p || !e_i || !mom_all || !mom2_all || !idx || !score || m < 0 || n < 1 || G < 1 || k < 1) return PR_EINVAL;
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_fuse_select(ctx->stream, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, e_p, e_i, mom2_all, ctx->sel_scratch, score64);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
 int pr_fuse_select2_dev(pr_ctx* ctx, const float* d_p, const float* d_i, const float* e_p, const float* e_i, int32_t m, int32_t n,
                         const double* mom_all, const double* mom2_all, int32_t G, int32_t q_row0, int32_t db_row0,
                         int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score) {
-  if (!ctx || !d_p || !d_i || !e_p || !e_i || !mom_all || !mom2_all || !idx || !score || m < 0 || n < 1 || G < 1 || k < 1) return PR_EINVAL;
-  if (int rc = set_device(ctx)) return rc;
-  pr::launch_fuse_select(ctx->stream, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, e_p, e_i, mom2_all, ctx->sel_scratch);
-  PR_HIP(ctx, hipGetLastError());
-  return PR_OK;
+  return fuse_select2_impl(ctx, d_p, d_i, e_p, e_i, m, n, mom_all, mom2_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, nullptr);
+}
+int pr_fuse_select2_f64_dev(pr_ctx* ctx, const float* d_p, const float* d_i, const float* e_p, const float* e_i, int32_t m, int32_t n,
+                            const double* mom_all, const double* mom2_all, int32_t G, int32_t q_row0, int32_t db_row0,
+                            int32_t mask_width, double p_weight, int32_t k, int32_t* idx, float* score, double* score64) {
+  if (!score64) return PR_EINVAL;
+  return fuse_select2_impl(ctx, d_p, d_i, e_p, e_i, m, n, mom_all, mom2_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, score64);
 }
 
 // BASELINE.json config 5: SC and M2DP signatures of the same places scored together (build-defined)

@@ -36,30 +36,27 @@ __device__ __forceinline__ double ld(const void* p, int dtype, size_t i) {
   return dtype == 0 ? static_cast<const double*>(p)[i] : (double)static_cast<const float*>(p)[i];
 }
 
+// Sum over the 256 threads: inside a wave by lane exchanges (an xor butterfly: both partners add the same two numbers, so all 64 lanes hold
+// the same bits - no barrier), the four wave sums through LDS, added in wave order by every thread.  Two barriers instead of ten: the pair
+// functions below are chains of such reductions, and an online call waits for one pair per workgroup.
 __device__ __forceinline__ double block_sum256(double v, double* red, int tid) {
-  red[tid] = v;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
-    __syncthreads();
-  }
-  const double r = red[0];
+  const double r = (red[0] + red[1]) + (red[2] + red[3]);
   __syncthreads();
   return r;
 }
 
 // MATLAB min: NaN only if every element is NaN
+__device__ __forceinline__ double nanmin(double a, double b) { return (a != a) ? b : ((b != b) ? a : (b < a ? b : a)); }
 __device__ __forceinline__ double block_min256(double v, double* red, int tid) {
-  red[tid] = v;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v = nanmin(v, __shfl_xor(v, s, 64));
+  if ((tid & 63) == 0) red[tid >> 6] = v;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) {
-      const double a = red[tid], b = red[tid + s];
-      red[tid] = (a != a) ? b : ((b != b) ? a : (b < a ? b : a));
-    }
-    __syncthreads();
-  }
-  const double r = red[0];
+  const double r = nanmin(nanmin(red[0], red[1]), nanmin(red[2], red[3]));
   __syncthreads();
   return r;
 }
@@ -193,19 +190,27 @@ __device__ void chan_combine(const double* mom_all, int G, int m, int q, int ch,
   if (count) *count = cn;
 }
 
-__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t* __restrict__ idx_in) {
+// One workgroup per (query, candidate, CHANNEL): the exact distance of that channel into the pair's p5 slot; the last of the pair's
+// workgroups to finish (a self-resetting ticket per pair) forms the fused score from the four stored distances in channel order - an online
+// call waits for ONE channel's chain of reductions instead of two or four in a row, a batch gets twice the workgroups of half the length.
+__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t* __restrict__ idx_in, unsigned* __restrict__ tick) {
   __shared__ double buf[60 * 21 + 1200];
   __shared__ double red[256];
-  const int tid = threadIdx.x, q = blockIdx.x / A.kin, t = blockIdx.x % A.kin;
+  __shared__ int s_last;
+  const int nch = (A.q_sc ? 2 : 0) + (A.q_m2 ? 2 : 0);
+  const int tid = threadIdx.x, pair = blockIdx.x / nch, cl = blockIdx.x % nch, q = pair / A.kin, t = pair % A.kin;
+  const int c = A.q_sc ? cl : 2 + cl;                          // the channel (0, 1: SC structure / intensity; 2, 3: M2DP count / intensity)
   const int jg = idx_in[(size_t)q * A.kin + t];
   double* out = A.p5 + p5_at(0, A.m, q, 0, A.kin, t);
-  if (tid < 4) A.p5[p5_at(0, A.m, q, 1 + tid, A.kin, t)] = __builtin_nan("");   // stays NaN unless the pair is evaluated (every thread overwrites its own store below: program order)
-  if (jg < 0) { if (tid == 0) *out = __builtin_nan(""); return; }
+  double* dout = A.p5 + p5_at(0, A.m, q, 1, A.kin, t);         // + c * kin: channel c
+  // not evaluated: the first distance slot is NaN, the score says why (the pair's first workgroup writes, the others just leave)
+  auto skip = [&](double v) { if (cl == 0 && tid == 0) { *out = v; dout[0] = __builtin_nan(""); } };
+  if (jg < 0) { skip(__builtin_nan("")); return; }
   int dij = (A.q_row0 + q) - jg;
   if (dij < 0) dij = -dij;
-  if (dij < A.mask_width) { if (tid == 0) *out = __builtin_inf(); return; }   // run_test.m:47-53
+  if (dij < A.mask_width) { skip(__builtin_inf()); return; }   // run_test.m:47-53
   const int jl = jg - A.db_row0;
-  if (jl < 0 || jl >= A.n_local) { if (tid == 0) *out = __builtin_nan(""); return; }   // another shard's row: its owner evaluates it
+  if (jl < 0 || jl >= A.n_local) { skip(__builtin_nan("")); return; }   // another shard's row: its owner evaluates it
   if (A.cand_sc && t >= A.k) {
     // Candidates beyond the k-th of the fp32 pass whose fp32 score is above the k-th by more than 64 x the error bound of an fp32
     // score cannot enter the exact top-k: they keep their fp32 score (it only has to sort behind the evaluated ones).  Bound of
@@ -215,32 +220,39 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
     double cn = 2.0;
     const double w = row_weight(A.q_sc ? A.mom_sc : nullptr, A.q_m2 ? A.mom_m2 : nullptr, A.G, A.m, q, A.p_weight, &cn);
     const double delta = A.eps_mult * score_err_bound(A.eps_d, w, sk, cn);
-    if (st > sk + delta) { if (tid == 0) *out = st; return; }   // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
+    if (st > sk + delta) { skip(st); return; }                  // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
   }
-  double f = 0.0, z4[4] = {0.0, 0.0, 0.0, 0.0}, d4[4] = {0.0, 0.0, 0.0, 0.0};
-  if (A.q_sc) {
-    for (int ch = 0; ch < 2; ch++) {
-      const double d = sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + ch * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + ch * 1200,
-                                     buf, red, tid);
-      double mean, sd;
-      chan_combine(A.mom_sc, A.G, A.m, q, ch, mean, sd);
-      d4[ch] = d;
-      z4[ch] = (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);    // run_test.m:40
-      f += z4[ch];
-    }
+  double d;
+  if (c < 2) d = sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + c * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + c * 1200, buf, red, tid);
+  else d = m2dp_pair_exact(A.q_m2, A.m2_dt, (size_t)q * 4 * 384, A.db_m2, A.m2_dt, (size_t)jl * 4 * 384, c - 2, red, tid);
+  if (tid == 0) {
+    dout[(size_t)c * A.kin] = d;
+    if (cl == 0) for (int a = 0; a < 4; a++) if (a < 2 ? !A.q_sc : !A.q_m2) dout[(size_t)a * A.kin] = 0.0;   // absent descriptor type
+    __threadfence();
+    const unsigned old = atomicAdd(&tick[pair], 1u);
+    s_last = (old == (unsigned)nch - 1u);
+    if (s_last) tick[pair] = 0u;                                // ready for the next launch
   }
-  if (A.q_m2) {
-    for (int ch = 0; ch < 2; ch++) {
-      const double d = m2dp_pair_exact(A.q_m2, A.m2_dt, (size_t)q * 4 * 384, A.db_m2, A.m2_dt, (size_t)jl * 4 * 384, ch, red, tid);
-      double mean, sd;
-      chan_combine(A.mom_m2, A.G, A.m, q, ch, mean, sd);
-      d4[2 + ch] = d;
-      z4[2 + ch] = (ch == 0 ? A.p_weight : 1.0) * ((d - mean) / sd);
-      f += z4[2 + ch];
-    }
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (tid == 0) {                                               // the fused score, channels in order (run_test.m:40)
+    const volatile double* dv = dout;
+    double f = 0.0;
+    if (A.q_sc)
+      for (int ch = 0; ch < 2; ch++) {
+        double mean, sd;
+        chan_combine(A.mom_sc, A.G, A.m, q, ch, mean, sd);
+        f += (ch == 0 ? A.p_weight : 1.0) * ((dv[(size_t)ch * A.kin] - mean) / sd);
+      }
+    if (A.q_m2)
+      for (int ch = 0; ch < 2; ch++) {
+        double mean, sd;
+        chan_combine(A.mom_m2, A.G, A.m, q, ch, mean, sd);
+        f += (ch == 0 ? A.p_weight : 1.0) * ((dv[(size_t)(2 + ch) * A.kin] - mean) / sd);
+      }
+    *out = f;
   }
-  if (tid == 0) *out = f;
-  if (tid < 4) A.p5[p5_at(0, A.m, q, 1 + tid, A.kin, t)] = d4[tid];    // (every thread holds the reduced values)
 }
 
 __device__ double row_weight(const double* mom_sc, const double* mom_m2, int G, int m, int q, double p_weight, double* cn_out) {
@@ -512,21 +524,21 @@ __global__ __launch_bounds__(64) void order_check_kernel(const double* __restric
 }
 
 // ---- resolution of the queries whose order check failed: the row statistics of run_test.m:40 EXACTLY, stream-ordered (no host round trip).
-//   flag_compact_kernel   flags [m] -> the ascending list of flagged queries + their count (one workgroup; deterministic)
-//   exact_partial_kernel  for list slots [offset, offset + R): the distances of the query to every entry of THIS shard in fp64, in the
-//                         reference's own formulation (the device functions of rerank_kernel), summed per workgroup as shifted sums
-//                         (count, sum (d - K), sum (d - K)^2) about K = the all-pairs pass's mean of the whole row (the same number on every
-//                         shard): workgroup b takes entries b, b + NB, ..., thread 0 adds them in that order - partial [R][NB][4][3].
-//                         A fixed grid; with nothing flagged every workgroup leaves at once.  ~23 ns per pair.
-//   exact_finish_kernel   the NB partials of a slot added in workgroup order -> this shard's exact (count, mean, M2) per channel,
-//                         exact [m][4][3] (rows of unflagged queries are never read)
-//   rescore_kernel        one wave per slot: the fused score of every evaluated candidate again from its exact distances (p5) with the exact
-//                         statistics of all shards (exact_all [G][m][4][3], Chan combination in rank order, the operation order of
-//                         rerank_kernel), the k best by (score, index) over idx / score; with mom_* given (single shard) the query's rows of
-//                         moments are overwritten with the exact ones.
+// The flagged queries form an ascending list (deterministic): calls of up to RESOLVE_SMALL_M queries build it inside the kernels that need
+// it (every workgroup scans the flags - no extra launch, what an online call wants), larger calls run flag_compact_kernel first.
+//   resolve_kernel   for list slots [offset, offset + R): the distances of the query to every entry of THIS shard in fp64, in the
+//                    reference's own formulation (the device functions of rerank_kernel), summed per workgroup as shifted sums
+//                    (count, sum (d - K), sum (d - K)^2) about K = the all-pairs pass's mean of the whole row (the same number on every
+//                    shard): workgroup b takes entries b, b + NB, ... in that order - partial [R][NB][4][3].  A fixed grid; with nothing
+//                    flagged every workgroup leaves at once.  ~23 ns per pair.  The LAST workgroup to finish (a ticket) adds the NB partials
+//                    of every slot in workgroup order -> this shard's exact (count, mean, M2) per channel, exact [m][4][3] (rows of
+//                    unflagged queries are never read) and - single-shard calls (RESCORE) - re-scores the slot's candidates right away.
+//   rescore_kernel   (sharded calls, after the all-gather of `exact`) one wave per slot: the fused score of every evaluated candidate again
+//                    from its exact distances (p5) with the exact statistics of all shards (exact_all [G][m][4][3], Chan combination in rank
+//                    order, the operation order of rerank_kernel), the k best by (score, index) over idx / score.
 // NaN distances (zero-norm signatures) stay out of the statistics, as in row_moments_kernel.
 __global__ __launch_bounds__(256) void flag_compact_kernel(const int32_t* __restrict__ flags, int m, int32_t* __restrict__ list /* [m] */,
-                                                            int32_t* __restrict__ cnt /* [1] */, int cap, int* __restrict__ dflags) {
+                                                            int32_t* __restrict__ cnt /* [1] */) {
   __shared__ int wsum[4], base;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) base = 0;
@@ -545,11 +557,38 @@ __global__ __launch_bounds__(256) void flag_compact_kernel(const int32_t* __rest
     if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     __syncthreads();
   }
-  if (tid == 0) {
-    *cnt = base;
-    if (dflags && base > 0) dflags[2] = 1;                     // PR_WARN_ORDER_RESOLVED
-    if (dflags && base > cap) dflags[3] = 1;                   // PR_WARN_ORDER_UNRESOLVED: more flagged queries than one pass resolves
+  if (tid == 0) *cnt = base;
+}
+
+// the flagged queries of slots [offset, offset + RESOLVE_SLOTS) into s_list (LDS), their total number as return value: from the flags
+// themselves (flags != null: every thread of the workgroup calls this; nt = its size, a multiple of 64) or from the compacted list
+__device__ int flagged_slots(const int32_t* flags, int m, const int32_t* list, const int32_t* cnt, int offset, int* s_list, int* s_tmp /* [6] */,
+                             int tid, int nt) {
+  if (!flags) {
+    const int total = *cnt;
+    for (int s = tid; s < RESOLVE_SLOTS && offset + s < total; s += nt) s_list[s] = list[offset + s];
+    __syncthreads();
+    return total;
   }
+  const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
+  if (tid == 0) s_tmp[4] = 0;
+  __syncthreads();
+  for (int q0 = 0; q0 < m; q0 += nt) {
+    const int q = q0 + tid;
+    const int f = (q < m && flags[q] != 0) ? 1 : 0;
+    const unsigned long long b = __ballot(f);
+    const int before = __popcll(b & ((1ull << lane) - 1ull));
+    if (lane == 0) s_tmp[w] = __popcll(b);
+    __syncthreads();
+    int off = s_tmp[4];
+    for (int u = 0; u < w; u++) off += s_tmp[u];
+    const int slot = off + before - offset;
+    if (f && slot >= 0 && slot < RESOLVE_SLOTS) s_list[slot] = q;
+    __syncthreads();
+    if (tid == 0) { int t = s_tmp[4]; for (int u = 0; u < nw; u++) t += s_tmp[u]; s_tmp[4] = t; }
+    __syncthreads();
+  }
+  return s_tmp[4];
 }
 
 struct ExactArgs {
@@ -557,62 +596,20 @@ struct ExactArgs {
   const void* q_m2; const void* db_m2; int m2_dt;
   const double* mom_sc; const double* mom_m2;                   // [G][m][2][3] the all-pairs pass's moments (the pivot K = their combined mean)
   int G, m, n_local;
-  const int32_t* list; const int32_t* cnt; int offset, R, NB;
+  const int32_t* flags;                                         // [m] order flags, or null: the compacted list below
+  const int32_t* list; const int32_t* cnt; int offset, NB;
+  double* partial;                                              // [RESOLVE_SLOTS][NB][4][3]
+  double* exact;                                                // [m][4][3]
+  unsigned* tick;                                               // [1] zero between launches
+  int* dflags;                                                  // deferred warning bits of the context ([2] resolved, [3] more flagged than one pass)
+};
+struct RescoreArgs {
+  double p_weight; const int32_t* cand_idx; const double* p5_all; int kin, k; int32_t* idx; double* score; double* mom_sc; double* mom_m2;
 };
 __device__ __forceinline__ double pivot_of(const double* mom_all, int G, int m, int q, int ch) {
   double mean, sd;
   chan_combine(mom_all, G, m, q, ch, mean, sd);
   return (mean == mean) ? mean : 0.5;
-}
-__global__ __launch_bounds__(256) void exact_partial_kernel(ExactArgs A, double* __restrict__ partial /* [R][NB][4][3] */) {
-  __shared__ double buf[60 * 21 + 1200];
-  __shared__ double red[256];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int cnt = *A.cnt;
-  const size_t esc = A.sc_dt == 0 ? 8 : 4, em2 = A.m2_dt == 0 ? 8 : 4;
-  for (int s = 0; s < A.R && A.offset + s < cnt; s++) {
-    const int q = A.list[A.offset + s];
-    const void* qs = A.q_sc ? static_cast<const char*>(A.q_sc) + (size_t)q * 2400 * esc : nullptr;
-    const void* qm = A.q_m2 ? static_cast<const char*>(A.q_m2) + (size_t)q * 4 * 384 * em2 : nullptr;
-    double K[4] = {0.0, 0.0, 0.0, 0.0}, acc[4][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-    if (qs) { K[0] = pivot_of(A.mom_sc, A.G, A.m, q, 0); K[1] = pivot_of(A.mom_sc, A.G, A.m, q, 1); }
-    if (qm) { K[2] = pivot_of(A.mom_m2, A.G, A.m, q, 0); K[3] = pivot_of(A.mom_m2, A.G, A.m, q, 1); }
-    for (int j = b; j < A.n_local; j += A.NB) {
-      if (qs)
-        for (int ch = 0; ch < 2; ch++) {
-          const double d = sc_pair_exact(qs, A.sc_dt, (size_t)ch * 1200, A.db_sc, A.sc_dt, (size_t)j * 2400 + ch * 1200, buf, red, tid);
-          if (d == d) { const double x = d - K[ch]; acc[ch][0] += 1.0; acc[ch][1] += x; acc[ch][2] += x * x; }
-        }
-      if (qm)
-        for (int ch = 0; ch < 2; ch++) {
-          const double d = m2dp_pair_exact(qm, A.m2_dt, 0, A.db_m2, A.m2_dt, (size_t)j * 4 * 384, ch, red, tid);
-          if (d == d) { const double x = d - K[2 + ch]; acc[2 + ch][0] += 1.0; acc[2 + ch][1] += x; acc[2 + ch][2] += x * x; }
-        }
-    }
-    if (tid < 12) {                                             // (every thread holds the same sums: the pair functions return block-wide values)
-      const int c = tid / 3, e = tid % 3;
-      partial[(((size_t)s * A.NB + b) * 4 + c) * 3 + e] = acc[c][e];
-    }
-  }
-}
-__global__ __launch_bounds__(64) void exact_finish_kernel(ExactArgs A, const double* __restrict__ partial, double* __restrict__ exact /* [m][4][3] */) {
-  const int s = blockIdx.x, lane = threadIdx.x;
-  if (A.offset + s >= *A.cnt) return;
-  const int q = A.list[A.offset + s];
-  if (lane >= 4) return;
-  const int c = lane;
-  const bool present = c < 2 ? A.q_sc != nullptr : A.q_m2 != nullptr;
-  double N = 0.0, S1 = 0.0, S2 = 0.0;
-  if (present)
-    for (int b = 0; b < A.NB; b++) {                            // workgroup order: deterministic
-      const double* o = partial + (((size_t)s * A.NB + b) * 4 + c) * 3;
-      N += o[0]; S1 += o[1]; S2 += o[2];
-    }
-  const double K = present ? pivot_of(c < 2 ? A.mom_sc : A.mom_m2, A.G, A.m, q, c & 1) : 0.0;
-  double* w = exact + ((size_t)q * 4 + c) * 3;
-  w[0] = N;
-  w[1] = N > 0.0 ? K + S1 / N : 0.0;
-  w[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
 }
 // Chan combination in rank order of exact_all [G][m][4][3] (chan_combine's arithmetic)
 __device__ void exact_combine(const double* exact_all, int G, int m, int q, int c, double& mean, double& sd, double* loc /* [3] or null: the totals */) {
@@ -630,21 +627,16 @@ __device__ void exact_combine(const double* exact_all, int G, int m, int q, int 
   sd = sqrt(m2 / (cn - 1.0));
   if (loc) { loc[0] = cn; loc[1] = mu; loc[2] = m2; }
 }
-__global__ __launch_bounds__(64) void rescore_kernel(const int32_t* __restrict__ list, const int32_t* __restrict__ cnt, int offset,
-                                                      const double* __restrict__ exact_all, int G, int m, int has_sc, int has_m2, double p_weight,
-                                                      const int32_t* __restrict__ cand_idx, const double* __restrict__ p5_all, int kin, int k,
-                                                      int32_t* __restrict__ idx, double* __restrict__ score, double* __restrict__ mom_sc,
-                                                      double* __restrict__ mom_m2) {
-  const int s = blockIdx.x, lane = threadIdx.x;
-  if (offset + s >= *cnt) return;
-  const int q = list[offset + s];
-  double w[4] = {has_sc ? p_weight : 0.0, has_sc ? 1.0 : 0.0, has_m2 ? p_weight : 0.0, has_m2 ? 1.0 : 0.0}, mean[4], sd[4];
+// one WAVE: the candidates of query q re-scored with the exact statistics, the k best written over idx / score (rerank_sort_wave_kernel's rounds)
+__device__ void rescore_wave(int q, int lane, const double* exact_all, int G, int m, int has_sc, int has_m2, const RescoreArgs& R) {
+  const int kin = R.kin, k = R.k;
+  double w[4] = {has_sc ? R.p_weight : 0.0, has_sc ? 1.0 : 0.0, has_m2 ? R.p_weight : 0.0, has_m2 ? 1.0 : 0.0}, mean[4], sd[4];
   for (int c = 0; c < 4; c++) {
     mean[c] = 0.0; sd[c] = 1.0;
     if (w[c] == 0.0) continue;
     double loc[3];
     exact_combine(exact_all, G, m, q, c, mean[c], sd[c], loc);
-    double* mo = c < 2 ? mom_sc : mom_m2;                        // single shard: the caller's moments become the exact ones
+    double* mo = c < 2 ? R.mom_sc : R.mom_m2;                    // single shard: the caller's moments become the exact ones
     if (mo && lane < 3) mo[((size_t)q * 2 + (c & 1)) * 3 + lane] = loc[lane];
   }
   double v[2];
@@ -652,21 +644,21 @@ __global__ __launch_bounds__(64) void rescore_kernel(const int32_t* __restrict__
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const int c = lane + 64 * h;
-    j[h] = c < kin ? cand_idx[(size_t)q * kin + c] : -1;
+    j[h] = c < kin ? R.cand_idx[(size_t)q * kin + c] : -1;
     v[h] = __builtin_nan("");
     int own = -1;
     if (j[h] >= 0)
       for (int g = 0; g < G; g++) {
-        const double x = p5_all[p5_at(g, m, q, 0, kin, c)];
+        const double x = R.p5_all[p5_at(g, m, q, 0, kin, c)];
         if (x == x) { v[h] = x; own = g; break; }
       }
     if (own >= 0) {
-      const double d0 = p5_all[p5_at(own, m, q, 1, kin, c)];
+      const double d0 = R.p5_all[p5_at(own, m, q, 1, kin, c)];
       if (d0 == d0) {                                          // evaluated: the score again, in rerank_kernel's operation order
         double f = 0.0;
         for (int cc = 0; cc < 4; cc++) {
           if (w[cc] == 0.0) continue;
-          const double d = p5_all[p5_at(own, m, q, 1 + cc, kin, c)];
+          const double d = R.p5_all[p5_at(own, m, q, 1 + cc, kin, c)];
           f += w[cc] * ((d - mean[cc]) / sd[cc]);
         }
         v[h] = f;
@@ -686,12 +678,94 @@ __global__ __launch_bounds__(64) void rescore_kernel(const int32_t* __restrict__
     }
     const bool ok = bj >= 0 && bv == bv;
     if (lane == 0) {
-      idx[(size_t)q * k + t] = ok ? bj : -1;
-      score[(size_t)q * k + t] = ok ? bv : __builtin_nan("");
+      R.idx[(size_t)q * k + t] = ok ? bj : -1;
+      R.score[(size_t)q * k + t] = ok ? bv : __builtin_nan("");
     }
     if (bc == lane) { j[0] = -1; v[0] = __builtin_nan(""); }
     if (bc == lane + 64) { j[1] = -1; v[1] = __builtin_nan(""); }
   }
+}
+
+template <bool RESCORE>
+__global__ __launch_bounds__(256) void resolve_kernel(ExactArgs A, RescoreArgs R) {
+  __shared__ double buf[60 * 21 + 1200];
+  __shared__ double red[256];
+  __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
+  const int tid = threadIdx.x, b = blockIdx.x;
+  const int total = flagged_slots(A.flags, A.m, A.list, A.cnt, A.offset, s_list, s_tmp, tid, 256);
+  const int ns = total - A.offset < RESOLVE_SLOTS ? total - A.offset : RESOLVE_SLOTS;
+  if (ns <= 0) return;                                          // nothing flagged: the usual case
+  const size_t esc = A.sc_dt == 0 ? 8 : 4, em2 = A.m2_dt == 0 ? 8 : 4;
+  for (int s = 0; s < ns; s++) {
+    const int q = s_list[s];
+    const void* qs = A.q_sc ? static_cast<const char*>(A.q_sc) + (size_t)q * 2400 * esc : nullptr;
+    const void* qm = A.q_m2 ? static_cast<const char*>(A.q_m2) + (size_t)q * 4 * 384 * em2 : nullptr;
+    double K[4] = {0.0, 0.0, 0.0, 0.0}, acc[4][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
+    if (qs) { K[0] = pivot_of(A.mom_sc, A.G, A.m, q, 0); K[1] = pivot_of(A.mom_sc, A.G, A.m, q, 1); }
+    if (qm) { K[2] = pivot_of(A.mom_m2, A.G, A.m, q, 0); K[3] = pivot_of(A.mom_m2, A.G, A.m, q, 1); }
+    for (int j = b; j < A.n_local; j += A.NB) {
+      if (qs)
+        for (int ch = 0; ch < 2; ch++) {
+          const double d = sc_pair_exact(qs, A.sc_dt, (size_t)ch * 1200, A.db_sc, A.sc_dt, (size_t)j * 2400 + ch * 1200, buf, red, tid);
+          if (d == d) { const double x = d - K[ch]; acc[ch][0] += 1.0; acc[ch][1] += x; acc[ch][2] += x * x; }
+        }
+      if (qm)
+        for (int ch = 0; ch < 2; ch++) {
+          const double d = m2dp_pair_exact(qm, A.m2_dt, 0, A.db_m2, A.m2_dt, (size_t)j * 4 * 384, ch, red, tid);
+          if (d == d) { const double x = d - K[2 + ch]; acc[2 + ch][0] += 1.0; acc[2 + ch][1] += x; acc[2 + ch][2] += x * x; }
+        }
+    }
+    if (tid < 12) {                                             // (every thread holds the same sums: the pair functions return block-wide values)
+      const int c = tid / 3, e = tid % 3;
+      A.partial[(((size_t)s * A.NB + b) * 4 + c) * 3 + e] = acc[c][e];
+    }
+  }
+  // the last workgroup to arrive finishes: partials -> exact moments (-> re-scored candidates)
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_tmp[5] = (atomicAdd(A.tick, 1u) == (unsigned)gridDim.x - 1u) ? 1 : 0;
+  __syncthreads();
+  if (!s_tmp[5]) return;
+  __threadfence();
+  if (tid == 0) {
+    *A.tick = 0u;                                               // ready for the next launch
+    if (A.dflags) { A.dflags[2] = 1; if (total - A.offset > RESOLVE_SLOTS) A.dflags[3] = 1; }
+  }
+  const volatile double* part = A.partial;                      // written by other workgroups: no cached copies
+  for (int s = 0; s < ns; s++) {
+    const int q = s_list[s];
+    if (tid < 12) {
+      const int c = tid / 3, e = tid % 3;
+      double sum = 0.0;
+      for (int bb = 0; bb < A.NB; bb++) sum += part[(((size_t)s * A.NB + bb) * 4 + c) * 3 + e];   // workgroup order: deterministic
+      red[tid] = sum;
+    }
+    __syncthreads();
+    if (tid < 4) {
+      const int c = tid;
+      const bool present = c < 2 ? A.q_sc != nullptr : A.q_m2 != nullptr;
+      const double N = red[3 * c], S1 = red[3 * c + 1], S2 = red[3 * c + 2];
+      const double K = present ? pivot_of(c < 2 ? A.mom_sc : A.mom_m2, A.G, A.m, q, c & 1) : 0.0;
+      double* w = A.exact + ((size_t)q * 4 + c) * 3;
+      w[0] = N;
+      w[1] = N > 0.0 ? K + S1 / N : 0.0;
+      w[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    if (RESCORE && tid < 64) rescore_wave(q, tid, A.exact, 1, A.m, A.q_sc != nullptr, A.q_m2 != nullptr, R);
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64) void rescore_kernel(const int32_t* __restrict__ flags, const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
+                                                      int offset, const double* __restrict__ exact_all, int G, int m, int has_sc, int has_m2,
+                                                      RescoreArgs R) {
+  __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
+  const int s = blockIdx.x, lane = threadIdx.x;
+  const int total = flagged_slots(flags, m, list, cnt, offset, s_list, s_tmp, lane, 64);
+  if (offset + s >= total) return;
+  rescore_wave(s_list[s], lane, exact_all, G, m, has_sc, has_m2, R);
 }
 
 __global__ __launch_bounds__(256) void widen_kernel(const float* __restrict__ a, long long n, double* __restrict__ b) {
@@ -737,12 +811,13 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
 
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                   double p_weight, int kin, const int32_t* idx_in, double* p5, int k, int32_t* idx, double* score,
+                   double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, int k, int32_t* idx, double* score,
                    float* score32, const double* cand_sc32, double eps_d, double order_floor, double order_noise, int32_t* order_flags) {
   if (m <= 0) return;
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
                eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
-  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in);
+  const unsigned nch = (q_sc ? 2u : 0u) + (q_m2 ? 2u : 0u);
+  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin * nch), dim3(256), 0, st, A, idx_in, tick);
   // order check (order_flags != null): inside the wave selection for few queries, its own launch otherwise
   if (m <= 64 && kin <= 128) {
     hipLaunchKernelGGL(rerank_sort_wave_kernel, dim3(m), dim3(64), 0, st, idx_in, p5, m, kin, k, idx, score, score32, order_flags ? 1 : 0,
@@ -757,11 +832,12 @@ void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_d
 
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                           double p_weight, int kin, const int32_t* idx_in, double* p5, const double* cand_sc32, int k, double eps_d) {
+                           double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, const double* cand_sc32, int k, double eps_d) {
   if (m <= 0) return;
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
                eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
-  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin), dim3(256), 0, st, A, idx_in);
+  const unsigned nch = (q_sc ? 2u : 0u) + (q_m2 ? 2u : 0u);
+  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin * nch), dim3(256), 0, st, A, idx_in, tick);
 }
 
 void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,
@@ -779,28 +855,40 @@ void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_
                      eps_floor, noise, flags);
 }
 
-void launch_flag_compact(hipStream_t st, const int32_t* flags, int m, int32_t* list, int32_t* cnt, int cap, int* dflags) {
-  hipLaunchKernelGGL(flag_compact_kernel, dim3(1), dim3(256), 0, st, flags, m, list, cnt, cap, dflags);
-}
-
 int exact_partial_blocks(int n_local) { return n_local < RESOLVE_NB ? (n_local > 0 ? n_local : 1) : RESOLVE_NB; }
 
-void launch_exact_moments(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
-                          const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* list, const int32_t* cnt,
-                          int offset, double* partial, double* exact) {
-  if (m <= 0 || n_local <= 0) return;
-  const int NB = exact_partial_blocks(n_local);
-  ExactArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, list, cnt, offset, RESOLVE_SLOTS, NB};
-  hipLaunchKernelGGL(exact_partial_kernel, dim3(NB), dim3(256), 0, st, A, partial);
-  hipLaunchKernelGGL(exact_finish_kernel, dim3(RESOLVE_SLOTS), dim3(64), 0, st, A, partial, exact);
+// flags [m] -> the flagged-query list the resolution kernels read: small calls scan the flags themselves (returns flags), larger ones get
+// the compacted list (one more launch; returns null)
+static const int32_t* resolve_list(hipStream_t st, const int32_t* flags, int m, int32_t* list, int32_t* cnt) {
+  if (m <= RESOLVE_SMALL_M) return flags;
+  hipLaunchKernelGGL(flag_compact_kernel, dim3(1), dim3(256), 0, st, flags, m, list, cnt);
+  return nullptr;
 }
 
-void launch_rescore(hipStream_t st, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G, int m, int has_sc,
-                    int has_m2, double p_weight, const int32_t* cand_idx, const double* p5_all, int kin, int k, int32_t* idx, double* score,
-                    double* mom_sc, double* mom_m2) {
+void launch_resolve(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
+                    const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* flags, int32_t* list, int32_t* cnt,
+                    int offset, bool compacted, double* partial, double* exact, unsigned* tick, int* dflags, bool rescore, double p_weight,
+                    const int32_t* cand_idx, const double* p5, int kin, int k, int32_t* idx, double* score, double* out_mom_sc, double* out_mom_m2) {
+  if (m <= 0 || n_local <= 0) return;
+  const int32_t* fl = compacted ? nullptr : resolve_list(st, flags, m, list, cnt);
+  const int NB = exact_partial_blocks(n_local);
+  ExactArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, fl, list, cnt, offset, NB, partial, exact, tick, dflags};
+  RescoreArgs R{p_weight, cand_idx, p5, kin, k, idx, score, out_mom_sc, out_mom_m2};
+  if (rescore) hipLaunchKernelGGL(resolve_kernel<true>, dim3(NB), dim3(256), 0, st, A, R);
+  else hipLaunchKernelGGL(resolve_kernel<false>, dim3(NB), dim3(256), 0, st, A, R);
+}
+
+void launch_flag_compact(hipStream_t st, const int32_t* flags, int m, int32_t* list, int32_t* cnt) {
+  hipLaunchKernelGGL(flag_compact_kernel, dim3(1), dim3(256), 0, st, flags, m, list, cnt);
+}
+
+void launch_rescore(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G, int m,
+                    int has_sc, int has_m2, double p_weight, const int32_t* cand_idx, const double* p5_all, int kin, int k, int32_t* idx,
+                    double* score) {
   if (m <= 0) return;
-  hipLaunchKernelGGL(rescore_kernel, dim3(RESOLVE_SLOTS), dim3(64), 0, st, list, cnt, offset, exact_all, G, m, has_sc, has_m2, p_weight, cand_idx,
-                     p5_all, kin, k, idx, score, mom_sc, mom_m2);
+  RescoreArgs R{p_weight, cand_idx, p5_all, kin, k, idx, score, nullptr, nullptr};
+  hipLaunchKernelGGL(rescore_kernel, dim3(RESOLVE_SLOTS), dim3(64), 0, st, m <= RESOLVE_SMALL_M ? flags : nullptr, list, cnt, offset, exact_all, G, m,
+                     has_sc, has_m2, R);
 }
 
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* p5_all, int G, int m, int kin, int k, int32_t* idx,

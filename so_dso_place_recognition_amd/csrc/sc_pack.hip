@@ -18,6 +18,8 @@
 namespace pr {
 namespace {
 
+constexpr int SC_PACK_FEW = 8;    // signatures up to which a set is packed one workgroup per (signature, channel): see sc_pack_h_few_kernel
+
 template <typename T>
 __global__ __launch_bounds__(256) void sc_pack_kernel(const T* __restrict__ sig, int rows, int role,
                                                        float* __restrict__ packed, int groups,
@@ -282,8 +284,85 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
   }
 }
 
+// A handful of signatures (the queries of an online call): the kernel above is built for throughput - its twiddles come through the scalar
+// cache, 15 dependent cold misses per workgroup when nothing has warmed it: 16 - 21 us for ONE query.  Here one workgroup per (signature,
+// channel), 320 threads = (frequency f <= 15, ring): column and twiddles staged in LDS once, then EXACTLY the arithmetic of the kernel above
+// - raw sums over the even / odd sectors in sector order, the column's square sum in the same order, the 20 column sums added in ring order,
+// one scale factor - so the image is bit for bit the one that kernel writes.  The workgroup writes only its own row of the group image (the
+// caller has zeroed the image).
+template <typename T, int ROLE, bool LO>
+__global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict__ sig, int rows, unsigned short* __restrict__ packed, int groups,
+                                                             const double* __restrict__ tw, int* __restrict__ flags, int* __restrict__ bad) {
+  constexpr int SL = ROLE == 0 ? (LO ? SCH_QBLK : SCF_QBLK) : (LO ? SCH_DFREQ : SCF_DFREQ);
+  constexpr int IMGB = ROLE == 0 ? (LO ? SCH_QIMG : SCF_QIMG) : (LO ? SCH_DIMG : SCF_DIMG);
+  constexpr int QROW = LO ? 80 : 40;
+  __shared__ double x[1200];
+  __shared__ double tws[120];
+  __shared__ double part[20];
+  const int tid = threadIdx.x, f = tid / 20, ring = tid - 20 * f;
+  const int row = blockIdx.x >> 1, ch = blockIdx.x & 1;
+  const T* src = sig + (size_t)row * 2400 + ch * 1200;
+  for (int i = tid; i < 1200; i += 320) x[i] = (double)src[i];
+  if (tid < 120) tws[tid] = tw[tid];
+  __syncthreads();
+  double ce = 0.0, co = 0.0, se = 0.0, so = 0.0, nsq = 0.0;
+  int t = 0;  // (f*s) mod 60
+  for (int s2 = 0; s2 < 60; s2 += 2) {
+    const double x0 = x[s2 * 20 + ring], x1 = x[(s2 + 1) * 20 + ring];
+    nsq += x0 * x0;
+    nsq += x1 * x1;
+    ce += x0 * tws[t];
+    se += x0 * tws[60 + t];
+    t += f; if (t >= 60) t -= 60;
+    co += x1 * tws[t];
+    so += x1 * tws[60 + t];
+    t += f; if (t >= 60) t -= 60;
+  }
+  if (f == 0) part[ring] = nsq;
+  __syncthreads();
+  double n2 = 0.0;
+#pragma unroll
+  for (int r = 0; r < 20; r++) n2 += part[r];
+  const double nr = sqrt(n2);
+  const bool isbad = !(nr > 0.0) || !(nr < __builtin_inf());
+  if (tid == 0 && isbad) { atomicOr(flags, 1); atomicOr(bad + row, 1 << ch); }
+  const double sc = isbad ? 0.0 : 0.12909944487358055 * (ROLE == 0 ? 256.0 : 128.0) / nr;
+  char* out = reinterpret_cast<char*>(packed);
+  auto put = [&](double val, int ff, int im) {
+    if (isbad) val = 0.0;
+    float vf = (float)val;
+    asm volatile("" : "+v"(vf));
+    const _Float16 hi = (_Float16)vf;
+    float rf = (float)(val - (double)hi);
+    asm volatile("" : "+v"(rf));
+    const _Float16 lo = (_Float16)rf;
+    size_t bh;
+    if (ROLE == 0) {
+      const int g = row >> 3, rr = (im << 3) | (row & 7);
+      bh = ((size_t)ch * groups + g) * IMGB + (size_t)ff * SL + rr * QROW + (rr >= 8 ? 8 : 0) + ring * 2;
+      *reinterpret_cast<_Float16*>(out + bh) = hi;
+      if (LO) *reinterpret_cast<_Float16*>(out + bh + 40) = lo;
+    } else {
+      const int g = row >> 4, j = row & 15;
+      bh = ((size_t)ch * groups + g) * IMGB + (size_t)ff * SL + (size_t)im * (LO ? 2 : 1) * SCH_DTILE + (((ring >> 3) << 4) | j) * 16 + (ring & 7) * 2;
+      *reinterpret_cast<_Float16*>(out + bh) = hi;
+      if (LO) *reinterpret_cast<_Float16*>(out + bh + SCH_DTILE) = lo;
+    }
+  };
+  put((ce + co) * sc, f, 0);
+  put(-(se + so) * sc, f, 1);
+  if (f != 15) {                                          // 30 - 15 = 15: the same bin
+    put((ce - co) * sc, 30 - f, 0);
+    put((se - so) * sc, 30 - f, 1);
+  }
+}
+
 template <typename T, int ROLE, bool LO = true>
 void launch_pack_col(hipStream_t st, const T* sig, int rows, unsigned short* packed, int groups, const double* tw, int* flags, int* bad) {
+  if (rows <= SC_PACK_FEW) {
+    hipLaunchKernelGGL((sc_pack_h_few_kernel<T, ROLE, LO>), dim3((unsigned)rows * 2), dim3(320), 0, st, sig, rows, packed, groups, tw, flags, bad);
+    return;
+  }
   hipLaunchKernelGGL((sc_pack_h_col_kernel<T, ROLE, LO>), dim3((unsigned)(((rows + 15) / 16 + 7) / 8) * 64), dim3(320), 0, st, sig, rows, packed,
                      groups, tw, flags, bad);
 }

@@ -216,13 +216,15 @@ class Matcher(_Base):
         kin = self._kin(k)
         idx_in = self._buf("idx_in", (m, kin), torch.int32)
         sc32 = self._buf("sc32", (m, kin), torch.float32)
+        sc64 = self._buf("sc64", (m, kin), torch.float64)
         self._mom_all = mom_all.contiguous()
         self._args = (G, q_row0, db_row0, int(mask_width), float(p_weight))
         self._enter()
-        self.ctx.check(self.lib.pr_fuse_select_dev(self.ctx.h, _dptr(d_p), None if self.plain else _dptr(d_i), m, n, _dptr(self._mom_all), G,
-                                                   q_row0, db_row0, int(mask_width), float(p_weight), int(kin), _dptr(idx_in), _dptr(sc32)))
+        self.ctx.check(self.lib.pr_fuse_select_f64_dev(self.ctx.h, _dptr(d_p), None if self.plain else _dptr(d_i), m, n, _dptr(self._mom_all), G,
+                                                       q_row0, db_row0, int(mask_width), float(p_weight), int(kin), _dptr(idx_in), _dptr(sc32),
+                                                       _dptr(sc64)))
         self._leave()
-        return idx_in, sc32.to(torch.float64)
+        return idx_in, sc64
 
     def _raw_args(self):
         sc = self.type == _lib.TYPE_SC
@@ -415,11 +417,13 @@ class FusedMatcher(_Base):
         kin = int(self.lib.pr_rerank_width(self.ctx.h, int(k)))
         idx_in = self._buf("idx_in", (m, kin), torch.int32)
         sc32 = self._buf("sc32", (m, kin), torch.float32)
+        sc64 = self._buf("sc64", (m, kin), torch.float64)
         self._enter()
-        self.ctx.check(lib.pr_fuse_select2_dev(h, _dptr(d[0]), _dptr(d[1]), _dptr(d[2]), _dptr(d[3]), m, n, _dptr(self._m1), _dptr(self._m2), G,
-                                               q_row0, db_row0, int(mask_width), float(p_weight), int(kin), _dptr(idx_in), _dptr(sc32)))
+        self.ctx.check(lib.pr_fuse_select2_f64_dev(h, _dptr(d[0]), _dptr(d[1]), _dptr(d[2]), _dptr(d[3]), m, n, _dptr(self._m1), _dptr(self._m2), G,
+                                                   q_row0, db_row0, int(mask_width), float(p_weight), int(kin), _dptr(idx_in), _dptr(sc32),
+                                                   _dptr(sc64)))
         self._leave()
-        return idx_in, sc32.to(torch.float64)
+        return idx_in, sc64
 
     def local_rerank(self, cand_idx, k, partial, cand_sc=None):
         m, n = self.sc._m, self.sc.n

@@ -470,6 +470,26 @@ def test_sc_experiment_kernels_vs_oracle(api, monkeypatch, kernel):
         ctx.close()
 
 
+@pytest.mark.parametrize("arith", ["f16x2", "f16"])
+def test_sc_pack_of_a_few_signatures_is_the_batch_pack_bit_for_bit(api, monkeypatch, arith):
+    """Up to 8 signatures are packed by a latency-oriented kernel (sc_pack_h_few_kernel: one workgroup per signature and channel), larger
+    sets by the throughput kernel: the operand images must agree bit for bit.  Seen through the distances: rows 0..m-1 of a 20-query
+    call == the m-query call, with the matcher pinned to one kernel (PR_SC_KERNEL=h serves any m in split-f16; the single-product
+    kernel's two forms walk the same operands in the same order)."""
+    monkeypatch.setenv("PR_SC_KERNEL", "h")
+    db = synth.sc_database(61, 700)
+    q, _ = synth.sc_queries(161, db, 20)
+    ctx = api.Context(0, sc_arith=arith)
+    big = api.processSC(q, db, ctx)
+    for m in (1, 3, 8):
+        few = api.processSC(q[:m], db, ctx)
+        if arith == "f16x2":
+            assert np.array_equal(few[0], big[0][:m]) and np.array_equal(few[1], big[1][:m])
+        else:        # (the 8-wave online form of the single-product kernel orders nothing differently, but allow the last bit)
+            assert np.abs(few[0] - big[0][:m]).max() < 1e-7 and np.abs(few[1] - big[1][:m]).max() < 1e-7
+    ctx.close()
+
+
 def test_sc_mixed_arithmetic_sets_are_rejected(api):
     import ctypes as C
     from so_dso_place_recognition_amd import _lib

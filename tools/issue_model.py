@@ -204,8 +204,11 @@ def main():
     if waves_per_simd == 2:
         res["model_cycles_per_unit_perfect_overlap"] = round(lo, 1)
     res["matrix_pipe_share_of_model"] = round(pipe / unit, 3)
-    flop = 71568 if a.kernel == "split" else 23856
-    res["frac_of_2.5PF_at_2.4GHz_if_model_met"] = round(flop * 128 / unit * 1024 * 2.4e9 / 2.5e15, 3)
+    flop_unit = (71568 if a.kernel == "split" else 23856) / 2 * 128          # algorithmic f16 FLOP of one unit (128 pairs of ONE channel)
+    frac = lambda cyc, ghz: flop_unit / cyc * 1024 * ghz * 1e9 / 2.5e15
+    res["frac_of_2.5PF_if_model_met"] = {"at_2.4GHz": round(frac(unit, 2.4), 3)}
+    res["frac_of_2.5PF_at_100pct_matrix_pipe"] = {"at_2.4GHz": round(frac(pipe, 2.4), 3)}
+    res["cycles_per_unit_for_0.60"] = {"at_2.4GHz": round(flop_unit * 1024 * 2.4e9 / (0.6 * 2.5e15), 0)}
     meas = None
     if a.measured_cycles:
         meas = a.measured_cycles
@@ -214,6 +217,12 @@ def main():
     if meas:
         res["measured_cycles_per_unit"] = round(meas / units_per_simd, 1)
         res["model_over_measured"] = round(unit * units_per_simd / meas, 3)
+    if a.ghz:
+        res["frac_of_2.5PF_if_model_met"]["at_sustained_%.2fGHz" % a.ghz] = round(frac(unit, a.ghz), 3)
+        res["frac_of_2.5PF_at_100pct_matrix_pipe"]["at_sustained_%.2fGHz" % a.ghz] = round(frac(pipe, a.ghz), 3)
+        res["cycles_per_unit_for_0.60"]["at_sustained_%.2fGHz" % a.ghz] = round(flop_unit * 1024 * a.ghz * 1e9 / (0.6 * 2.5e15), 0)
+        if meas:
+            res["measured_frac_of_2.5PF"] = round(frac(meas / units_per_simd, a.ghz), 3)
     if a.json:
         print(json.dumps(res))
     else:

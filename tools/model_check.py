@@ -62,7 +62,8 @@ for arith, kern, pat in (("f16x2", "split", "sc_match_e_kernel<true"), ("f16", "
             e["matrix_pipe_busy"] = pmc["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
         if pmc.get("SQ_INSTS_MFMA"):
             e["valu_per_mfma"] = pmc.get("SQ_INSTS_VALU", 0.0) / pmc["SQ_INSTS_MFMA"]
-        m = sh(f"python {ROOT}/tools/issue_model.py --kernel {kern} --fit {fillers} --costs {costs} --measured-cycles {cyc} --json")
+        ghz = f" --ghz {e['sustained_ghz']:.4f}" if e.get("sustained_ghz") else ""
+        m = sh(f"python {ROOT}/tools/issue_model.py --kernel {kern} --fit {fillers} --costs {costs} --measured-cycles {cyc}{ghz} --json")
         try:
             e["model"] = json.loads([l for l in m.stdout.splitlines() if l.startswith("{")][-1])
         except Exception:
