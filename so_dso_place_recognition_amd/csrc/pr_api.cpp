@@ -63,7 +63,9 @@ struct pr_sigset {
   int sc_mode = 0;               // SC: arithmetic the image was packed for (pr_ctx::sc_mode at creation)
   float* packed = nullptr;
   size_t floats = 0;
-  int* bad = nullptr;            // SC: [max_sigs] bit c = channel c of that row has zero norm (NaN row in MATLAB, processSC.m:16,19)
+  int* bad = nullptr;            // SC: [max_sigs + 1][2], entry [row][c] = 1 << c when channel c of that row has zero norm (NaN row in MATLAB, processSC.m:16,19), else 0; every pack writes all of its rows' entries
+  int32_t hw = 0;                // rows ever written since the image was last all-zero, and the group count (= channel stride) they were written for
+  int packed_groups = -1;        // -1: the image is all-zero
 };
 
 static thread_local std::string g_err;   // errors without a context
@@ -541,9 +543,13 @@ int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigse
   hipError_t e = hipMalloc((void**)&s->packed, s->floats * sizeof(float) + 16);
   if (e != hipSuccess) { delete s; PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: hipMalloc(%zu B) failed: %s", s->floats * 4, hipGetErrorString(e)); }
   if (type == PR_TYPE_SC) {
-    e = hipMalloc((void**)&s->bad, ((size_t)max_sigs + 1) * sizeof(int));
+    e = hipMalloc((void**)&s->bad, ((size_t)max_sigs + 1) * 2 * sizeof(int));
     if (e != hipSuccess) { (void)hipFree(s->packed); delete s; PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: hipMalloc failed: %s", hipGetErrorString(e)); }
   }
+  // the operand image starts out all-zero: padding rows / groups must be zero (they yield dot = 0 and are masked on store), and a pack
+  // only writes the rows it is given - see pr_sigset_pack
+  e = hipMemsetAsync(s->packed, 0, s->floats * sizeof(float), ctx->stream);
+  if (e != hipSuccess) { (void)hipFree(s->packed); if (s->bad) (void)hipFree(s->bad); delete s; PR_FAIL(ctx, PR_EHIP, "pr_sigset_create: hipMemsetAsync failed: %s", hipGetErrorString(e)); }
   *out = s;
   return PR_OK;
 }
@@ -574,15 +580,17 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
     PR_HIP(ctx, hipMemcpyAsync(stage.p, sig, rows * cols * esz, hipMemcpyHostToDevice, ctx->stream));
     dsig = stage.p;
   }
-  // padding rows/tiles must be zero: they yield dot = 0 and are masked on store
-  PR_HIP(ctx, hipMemsetAsync(s->packed, 0, s->floats * sizeof(float), ctx->stream));
-  // (a kernel, not hipMemsetAsync: captured into a hipGraph, the memset node of this small array - 20 bytes for a 4-query set - did
-  // not take effect on every replay on ROCm 7.0 / 7.2, and stale flags turn into NaN rows; tests/test_gpu_parity.py, hipgraph test)
-  if (s->bad) pr::launch_zero_ints(ctx->stream, s->bad, s->max_sigs + 1);
   // the channel stride must match the matcher's view of THIS count (not the capacity)
   int groups;
   (void)sigset_floats(s->type, s->role, n_sigs, &groups, s->sc_mode);
   s->groups = groups;
+  // Padding rows / tiles must be zero: they yield dot = 0 and are masked on store.  The image is zeroed at creation and a pack writes
+  // only its own rows (the throughput kernels: whole groups, their padding rows as zeros), so a re-pack of at least as many rows in the
+  // same geometry - every step of a steady workload - needs no 1.2 GB fill in front of it; anything else starts from zeros again.
+  // (DELIGHT sets keep the unconditional fill.)  The zero-norm flags need no clearing either: every pack writes all of its rows' entries.
+  const bool keep = s->type != PR_TYPE_DELIGHT && (s->packed_groups < 0 || (s->packed_groups == groups && n_sigs >= s->hw));
+  if (!keep) { PR_HIP(ctx, hipMemsetAsync(s->packed, 0, s->floats * sizeof(float), ctx->stream)); s->hw = 0; }
+  if (n_sigs > 0) { s->packed_groups = groups; if (n_sigs > s->hw) s->hw = n_sigs; }
   if (s->type == PR_TYPE_SC && (s->sc_mode == PR_SC_ARITH_F16X2 || s->sc_mode == PR_SC_ARITH_F16))
     pr::launch_sc_pack_h(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags, s->bad,
                          s->sc_mode == PR_SC_ARITH_F16);

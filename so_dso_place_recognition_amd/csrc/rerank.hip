@@ -22,10 +22,10 @@ __global__ __launch_bounds__(256) void nan_fixup_kernel(float* __restrict__ d_p,
                                                          const int* __restrict__ qbad, const int* __restrict__ dbad) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n) return;
-  const int bc = dbad ? dbad[j] : 0;
+  const int bc = dbad ? (dbad[2 * j] | dbad[2 * j + 1]) : 0;          // [row][channel] entries, see sc_pack.hip
   const float nanv = __builtin_nanf("");
   for (int q = blockIdx.y; q < m; q += gridDim.y) {
-    const int b = bc | (qbad ? qbad[q] : 0);
+    const int b = bc | (qbad ? (qbad[2 * q] | qbad[2 * q + 1]) : 0);
     if (!b) continue;
     if (b & 1) d_p[(size_t)q * n + j] = nanv;
     if ((b & 2) && d_i) d_i[(size_t)q * n + j] = nanv;
@@ -190,16 +190,17 @@ __device__ void chan_combine(const double* mom_all, int G, int m, int q, int ch,
   if (count) *count = cn;
 }
 
-// One workgroup per (query, candidate, CHANNEL): the exact distance of that channel into the pair's p5 slot; the last of the pair's
-// workgroups to finish (a self-resetting ticket per pair) forms the fused score from the four stored distances in channel order - an online
-// call waits for ONE channel's chain of reductions instead of two or four in a row, a batch gets twice the workgroups of half the length.
+// One workgroup per (query, candidate) - or, SPLIT (calls of few queries: an online call waits for ONE channel's chain of reductions instead
+// of two or four in a row), per (query, candidate, CHANNEL): the exact distance(s) into the pair's p5 slots.  SPLIT: the last of the pair's
+// workgroups to finish (a self-resetting ticket per pair) forms the fused score from the stored distances; either way the score is the sum
+// of the channel terms in channel order (run_test.m:40), bit for bit the same.
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t* __restrict__ idx_in, unsigned* __restrict__ tick) {
   __shared__ double buf[60 * 21 + 1200];
   __shared__ double red[256];
   __shared__ int s_last;
-  const int nch = (A.q_sc ? 2 : 0) + (A.q_m2 ? 2 : 0);
+  const int nch = SPLIT ? (A.q_sc ? 2 : 0) + (A.q_m2 ? 2 : 0) : 1;
   const int tid = threadIdx.x, pair = blockIdx.x / nch, cl = blockIdx.x % nch, q = pair / A.kin, t = pair % A.kin;
-  const int c = A.q_sc ? cl : 2 + cl;                          // the channel (0, 1: SC structure / intensity; 2, 3: M2DP count / intensity)
   const int jg = idx_in[(size_t)q * A.kin + t];
   double* out = A.p5 + p5_at(0, A.m, q, 0, A.kin, t);
   double* dout = A.p5 + p5_at(0, A.m, q, 1, A.kin, t);         // + c * kin: channel c
@@ -222,36 +223,48 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
     const double delta = A.eps_mult * score_err_bound(A.eps_d, w, sk, cn);
     if (st > sk + delta) { skip(st); return; }                  // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
   }
-  double d;
-  if (c < 2) d = sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + c * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + c * 1200, buf, red, tid);
-  else d = m2dp_pair_exact(A.q_m2, A.m2_dt, (size_t)q * 4 * 384, A.db_m2, A.m2_dt, (size_t)jl * 4 * 384, c - 2, red, tid);
-  if (tid == 0) {
-    dout[(size_t)c * A.kin] = d;
-    if (cl == 0) for (int a = 0; a < 4; a++) if (a < 2 ? !A.q_sc : !A.q_m2) dout[(size_t)a * A.kin] = 0.0;   // absent descriptor type
+  auto one = [&](int c) -> double {                              // channel 0, 1: SC structure / intensity; 2, 3: M2DP count / intensity
+    if (c < 2) return sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + c * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + c * 1200, buf, red, tid);
+    return m2dp_pair_exact(A.q_m2, A.m2_dt, (size_t)q * 4 * 384, A.db_m2, A.m2_dt, (size_t)jl * 4 * 384, c - 2, red, tid);
+  };
+  auto term = [&](int c, double d) -> double {
+    double mean, sd;
+    chan_combine(c < 2 ? A.mom_sc : A.mom_m2, A.G, A.m, q, c & 1, mean, sd);
+    return ((c & 1) ? 1.0 : A.p_weight) * ((d - mean) / sd);
+  };
+  if constexpr (!SPLIT) {
+    double f = 0.0, d4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int c = 0; c < 4; c++) {
+      if (c < 2 ? !A.q_sc : !A.q_m2) continue;
+      d4[c] = one(c);
+      f += term(c, d4[c]);
+    }
+    if (tid == 0) *out = f;
+    if (tid < 4) dout[(size_t)tid * A.kin] = d4[tid];            // (every thread holds the reduced values)
+    return;
+  } else {
+    const int c = A.q_sc ? cl : 2 + cl;
+    const double d = one(c);
+    if (tid == 0) {
+      dout[(size_t)c * A.kin] = d;
+      if (cl == 0) for (int a = 0; a < 4; a++) if (a < 2 ? !A.q_sc : !A.q_m2) dout[(size_t)a * A.kin] = 0.0;   // absent descriptor type
+      __threadfence();
+      const unsigned old = atomicAdd(&tick[pair], 1u);
+      s_last = (old == (unsigned)nch - 1u);
+      if (s_last) tick[pair] = 0u;                              // ready for the next launch
+    }
+    __syncthreads();
+    if (!s_last) return;
     __threadfence();
-    const unsigned old = atomicAdd(&tick[pair], 1u);
-    s_last = (old == (unsigned)nch - 1u);
-    if (s_last) tick[pair] = 0u;                                // ready for the next launch
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  if (tid == 0) {                                               // the fused score, channels in order (run_test.m:40)
-    const volatile double* dv = dout;
-    double f = 0.0;
-    if (A.q_sc)
-      for (int ch = 0; ch < 2; ch++) {
-        double mean, sd;
-        chan_combine(A.mom_sc, A.G, A.m, q, ch, mean, sd);
-        f += (ch == 0 ? A.p_weight : 1.0) * ((dv[(size_t)ch * A.kin] - mean) / sd);
+    if (tid == 0) {
+      const volatile double* dv = dout;
+      double f = 0.0;
+      for (int a = 0; a < 4; a++) {
+        if (a < 2 ? !A.q_sc : !A.q_m2) continue;
+        f += term(a, dv[(size_t)a * A.kin]);
       }
-    if (A.q_m2)
-      for (int ch = 0; ch < 2; ch++) {
-        double mean, sd;
-        chan_combine(A.mom_m2, A.G, A.m, q, ch, mean, sd);
-        f += (ch == 0 ? A.p_weight : 1.0) * ((dv[(size_t)(2 + ch) * A.kin] - mean) / sd);
-      }
-    *out = f;
+      *out = f;
+    }
   }
 }
 
@@ -809,6 +822,13 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
     hipLaunchKernelGGL(nan_fixup_kernel, dim3((n + 255) / 256, m < 64 ? m : 64), dim3(256), 0, st, d_p, d_i, m, n, qbad, dbad);
 }
 
+// few queries: one workgroup per (pair, channel); otherwise per pair (the batch's time is its workgroup count)
+static void launch_rerank_kernel(hipStream_t st, const RerankArgs& A, const int32_t* idx_in, unsigned* tick) {
+  const unsigned nch = (A.q_sc ? 2u : 0u) + (A.q_m2 ? 2u : 0u);
+  if (A.m <= 64) hipLaunchKernelGGL(rerank_kernel<true>, dim3((unsigned)A.m * A.kin * nch), dim3(256), 0, st, A, idx_in, tick);
+  else hipLaunchKernelGGL(rerank_kernel<false>, dim3((unsigned)A.m * A.kin), dim3(256), 0, st, A, idx_in, tick);
+}
+
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
                    double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, int k, int32_t* idx, double* score,
@@ -816,8 +836,7 @@ void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_d
   if (m <= 0) return;
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
                eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
-  const unsigned nch = (q_sc ? 2u : 0u) + (q_m2 ? 2u : 0u);
-  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin * nch), dim3(256), 0, st, A, idx_in, tick);
+  launch_rerank_kernel(st, A, idx_in, tick);
   // order check (order_flags != null): inside the wave selection for few queries, its own launch otherwise
   if (m <= 64 && kin <= 128) {
     hipLaunchKernelGGL(rerank_sort_wave_kernel, dim3(m), dim3(64), 0, st, idx_in, p5, m, kin, k, idx, score, score32, order_flags ? 1 : 0,
@@ -836,8 +855,7 @@ void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, 
   if (m <= 0) return;
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
                eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
-  const unsigned nch = (q_sc ? 2u : 0u) + (q_m2 ? 2u : 0u);
-  hipLaunchKernelGGL(rerank_kernel, dim3((unsigned)m * kin * nch), dim3(256), 0, st, A, idx_in, tick);
+  launch_rerank_kernel(st, A, idx_in, tick);
 }
 
 void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void sc_pack_kernel(const T* __restrict__ sig,
   // zero (or NaN) norm: MATLAB produces a NaN row (processSC.m:16,19).  The row is packed as zeros and
   // marked in bad[row] (bit = channel); launch_nan_fixup writes the NaN distances behind the matcher.
   const bool isbad = !(nr > 0.0) || !(nr < __builtin_inf());
-  if (isbad && tid == 0) { atomicOr(flags, 1); atomicOr(bad + row, 1 << ch); }
+  if (tid == 0) { bad[2 * row + ch] = isbad ? (1 << ch) : 0; if (isbad) atomicOr(flags, 1); }
   for (int i = tid; i < 1200; i += 256) x[i] = isbad ? 0.0 : x[i] / nr;   // processSC.m:16,19
   __syncthreads();
   const double scale = 0.12909944487358055;  // 1/sqrt(60)
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(320) void sc_pack_h_kernel(const T* __restrict__ si
   }
   const double nr = sqrt(red[0]);
   const bool isbad = !(nr > 0.0) || !(nr < __builtin_inf());   // see sc_pack_kernel
-  if (isbad && tid == 0) { atomicOr(flags, 1); atomicOr(bad + row, 1 << ch); }
+  if (tid == 0) { bad[2 * row + ch] = isbad ? (1 << ch) : 0; if (isbad) atomicOr(flags, 1); }
   for (int i = tid; i < 1200; i += 320) x[i] = isbad ? 0.0 : x[i] / nr;   // processSC.m:16,19
   __syncthreads();
   const double scale = 0.12909944487358055 * (role == 0 ? 256.0 : 128.0);  // 1/sqrt(60) x 2^8 | 2^7
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
   for (int r = 0; r < 20; r++) n2 += part[lrow * 20 + r];
   const double nr = sqrt(n2);
   const bool isbad = !(nr > 0.0) || !(nr < __builtin_inf());   // MATLAB: NaN row -> zeros here + bad[row], see sc_pack_kernel
-  if (valid && ring == 0 && fb == 0 && isbad) { atomicOr(flags, 1); atomicOr(bad + row, 1 << ch); }
+  if (valid && ring == 0 && fb == 0) { bad[2 * row + ch] = isbad ? (1 << ch) : 0; if (isbad) atomicOr(flags, 1); }
   const double sc = isbad ? 0.0 : 0.12909944487358055 * (ROLE == 0 ? 256.0 : 128.0) / nr;   // 1/sqrt(60) x 2^8 | 2^7, over the norm (processSC.m:16,19)
   auto put = [&](double val, int slice, int im) {
     if (isbad) val = 0.0;
@@ -307,7 +307,8 @@ __global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict_
   __syncthreads();
   double ce = 0.0, co = 0.0, se = 0.0, so = 0.0, nsq = 0.0;
   int t = 0;  // (f*s) mod 60
-  for (int s2 = 0; s2 < 60; s2 += 2) {
+#pragma unroll 1
+  for (int s2 = 0; s2 < 60; s2 += 2) {      // (rolled: a cold kernel's instructions come from HBM too, ~1 us per few hundred bytes)
     const double x0 = x[s2 * 20 + ring], x1 = x[(s2 + 1) * 20 + ring];
     nsq += x0 * x0;
     nsq += x1 * x1;
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict_
   for (int r = 0; r < 20; r++) n2 += part[r];
   const double nr = sqrt(n2);
   const bool isbad = !(nr > 0.0) || !(nr < __builtin_inf());
-  if (tid == 0 && isbad) { atomicOr(flags, 1); atomicOr(bad + row, 1 << ch); }
+  if (tid == 0) { bad[2 * row + ch] = isbad ? (1 << ch) : 0; if (isbad) atomicOr(flags, 1); }
   const double sc = isbad ? 0.0 : 0.12909944487358055 * (ROLE == 0 ? 256.0 : 128.0) / nr;
   char* out = reinterpret_cast<char*>(packed);
   auto put = [&](double val, int ff, int im) {

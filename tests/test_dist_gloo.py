@@ -44,6 +44,37 @@ def _worker(rank, world, port, n, m, k, mask, q):
         return torch.from_numpy(idx), torch.from_numpy(sc)
 
     idx, sc = sharded_topk(local_moments, local_select, k, None, world)
+    # the full protocol (steps 5 - 7 of matcher.py) with stand-ins: owner-wise re-evaluation blocks [m, 5, kin], finish, and the
+    # exact-moments exchange of the order resolution - every rank's [m, 4, 3] block must arrive at its rank's slot on every rank
+    seen = {}
+
+    def rerank(cand_idx, kk, partial, cand_sc):
+        assert partial
+        ci = cand_idx.numpy()
+        own = (ci >= lo) & (ci < hi)
+        p5 = np.full((m, 5, ci.shape[1]), np.nan)
+        p5[:, 0][own] = cand_sc.numpy()[own]                 # (the stand-in "exact" score = the pass score)
+        p5[:, 1:][np.repeat(own[:, None, :], 4, 1)] = 0.25
+        return torch.from_numpy(p5)
+
+    def finish(cand_idx, part_all, kk):
+        pa = part_all.numpy()
+        assert pa.shape == (world, m, 5, cand_idx.shape[1])
+        owners = (~np.isnan(pa[:, :, 0])).sum(0)
+        assert (owners[cand_idx.numpy() >= 0] == 1).all()    # every candidate has exactly one owner
+        sc_ = np.nanmax(np.where(np.isnan(pa[:, :, 0]), -np.inf, pa[:, :, 0]), axis=0)
+        return cand_idx[:, :kk].clone(), torch.from_numpy(sc_[:, :kk].copy())
+
+    def exact():
+        return torch.full((m, 4, 3), float(rank + 1), dtype=torch.float64)
+
+    def rescore(exact_all, cand_idx, part_all, kk, i_, s_):
+        seen["exact"] = exact_all.numpy().copy()
+        return i_, s_
+
+    idx2, sc2 = sharded_topk(local_moments, local_select, k, None, world, rerank=rerank, finish=finish, resolve=(exact, rescore))
+    assert seen["exact"].shape == (world, m, 4, 3) and all((seen["exact"][g] == g + 1).all() for g in range(world))
+    assert torch.equal(idx2, idx) and np.abs(sc2.numpy() - sc.numpy()).max() == 0.0
     if rank == 0:
         q.put((idx.numpy(), sc.numpy()))
     dist.barrier()
