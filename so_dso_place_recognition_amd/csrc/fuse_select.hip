@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restric
 // cut into P slices, one workgroup each (grid m x P): raw sums (count, S1, S2) about the row's first element per slice, added in slice order
 // by moments_finish_kernel - deterministic for a given (m, n).
 __global__ __launch_bounds__(256) void row_moments_slice_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i, int n, int m, int P,
-                                                                 double* __restrict__ part /* [P][m][2][3] */) {
+                                                                 double* __restrict__ part /* [P][m][2][3] */, double* __restrict__ mom,
+                                                                 unsigned* __restrict__ tick /* [m] zeros, left zero */) {
   // an online call waits for this kernel: both channels side by side, eight loads of a thread in flight, and ONE reduction tree for the
   // six sums (the per-thread order of the additions and the tree are those of block_sum, so the sums are bit for bit what three
   // block_sum calls per channel gave)
@@ -112,30 +113,37 @@ __global__ __launch_bounds__(256) void row_moments_slice_kernel(const float* __r
     double* o = part + (((size_t)sl * m + q) * 2 + tid) * 3;
     o[0] = red[3 * tid + 2][0]; o[1] = red[3 * tid][0]; o[2] = red[3 * tid + 1][0];
   }
-}
-__global__ __launch_bounds__(64) void moments_finish_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i, int n, int m, int P,
-                                                             const double* __restrict__ part, double* __restrict__ mom) {
-  const int t = blockIdx.x * 64 + threadIdx.x;
-  if (t >= 2 * m) return;
-  const int q = t >> 1, ch = t & 1;
-  const float r0 = ((ch ? d_i : d_p) + (size_t)q * n)[0];
-  const double c = (r0 == r0) ? (double)r0 : 0.5;
-  double N = 0.0, S1 = 0.0, S2 = 0.0;
-  const size_t step = (size_t)m * 6;                 // doubles between the partials of consecutive slices
-  const double* o = part + ((size_t)q * 2 + ch) * 3;
-  int sl = 0;
-  for (; sl + 8 <= P; sl += 8) {                     // eight slices' partials requested together, added in slice order
-    double a[8][3];
-#pragma unroll
-    for (int u = 0; u < 8; u++) { a[u][0] = o[(sl + u) * step]; a[u][1] = o[(sl + u) * step + 1]; a[u][2] = o[(sl + u) * step + 2]; }
-#pragma unroll
-    for (int u = 0; u < 8; u++) { N += a[u][0]; S1 += a[u][1]; S2 += a[u][2]; }
+  // the last slice of the query to finish adds the P partials in slice order -> (count, mean, M2): no second launch for an online call to wait for
+  __shared__ int s_last;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    s_last = (atomicAdd(&tick[q], 1u) == (unsigned)P - 1u);
+    if (s_last) tick[q] = 0u;
   }
-  for (; sl < P; sl++) { N += o[sl * step]; S1 += o[sl * step + 1]; S2 += o[sl * step + 2]; }
-  double* w = mom + ((size_t)q * 2 + ch) * 3;
-  w[0] = N;
-  w[1] = N > 0.0 ? c + S1 / N : 0.0;
-  w[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
+  __syncthreads();
+  if (!s_last) return;
+  __threadfence();
+  if (tid < 2) {
+    const int ch = tid;
+    const double c = ch ? ci : cp;
+    double N = 0.0, S1 = 0.0, S2 = 0.0;
+    const size_t step = (size_t)m * 6;                 // doubles between the partials of consecutive slices
+    const volatile double* o = part + ((size_t)q * 2 + ch) * 3;
+    int s8 = 0;
+    for (; s8 + 8 <= P; s8 += 8) {                     // eight slices' partials requested together, added in slice order
+      double a[8][3];
+#pragma unroll
+      for (int u = 0; u < 8; u++) { a[u][0] = o[(s8 + u) * step]; a[u][1] = o[(s8 + u) * step + 1]; a[u][2] = o[(s8 + u) * step + 2]; }
+#pragma unroll
+      for (int u = 0; u < 8; u++) { N += a[u][0]; S1 += a[u][1]; S2 += a[u][2]; }
+    }
+    for (; s8 < P; s8++) { N += o[s8 * step]; S1 += o[s8 * step + 1]; S2 += o[s8 * step + 2]; }
+    double* w = mom + ((size_t)q * 2 + ch) * 3;
+    w[0] = N;
+    w[1] = N > 0.0 ? c + S1 / N : 0.0;
+    w[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
+  }
 }
 
 __device__ __forceinline__ bool cand_less(double av, int aj, double bv, int bj) {   // (a) < (b) lexicographic
@@ -267,21 +275,34 @@ __device__ bool list_topk(const V* lv, const int* lj, int L, int k, double* rv, 
 // Rows that overflow the list (masses of equal scores, e.g. +Inf of the mask) fall back to one sweep per selected element.
 // (Measured at 4096 x 100k, k = 9: 0.65 ms against 0.59 ms for k = 1; keeping the 3 best per thread in one sweep instead cost
 // 2.5 ms - in a 64-lane wave some lane inserts at nearly every element - and a threshold from a full first sweep 1.13 ms.)
-__global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i,
-                                                           const float* __restrict__ e_p, const float* __restrict__ e_i,
-                                                           const double* __restrict__ mom2_all,
-                                                           int m, int n, const double* __restrict__ mom_all, int G,
-                                                           int q_row0, int db_row0, int mask_width, double p_weight,
-                                                           int k, int32_t* __restrict__ idx, float* __restrict__ score, int P,
-                                                           double* __restrict__ score64) {
-  __shared__ double st[8];
-  __shared__ double rv[256];
-  __shared__ int rj[256];
-  __shared__ double lv[FS_CAP];
-  __shared__ int lj[FS_CAP];
-  __shared__ int lcnt;
-  __shared__ unsigned hist[256];
-  __shared__ int ctl[4];
+struct SelLds {      // the workgroup's LDS (53 KB: ~3 workgroups per CU)
+  double st[8];
+  double rv[256];
+  int rj[256];
+  double lv[FS_CAP];
+  int lj[FS_CAP];
+  int lcnt;
+  unsigned hist[256];
+  int ctl[4];
+  double tau_s;
+  int last;
+};
+
+__device__ __forceinline__ void select_row(const float* __restrict__ d_p, const float* __restrict__ d_i,
+                                           const float* __restrict__ e_p, const float* __restrict__ e_i,
+                                           const double* __restrict__ mom2_all,
+                                           int m, int n, const double* __restrict__ mom_all, int G,
+                                           int q_row0, int db_row0, int mask_width, double p_weight,
+                                           int k, int32_t* __restrict__ idx, float* __restrict__ score, int P,
+                                           double* __restrict__ score64, SelLds& W) {
+  double* st = W.st;
+  double* rv = W.rv;
+  int* rj = W.rj;
+  double* lv = W.lv;
+  int* lj = W.lj;
+  int& lcnt = W.lcnt;
+  unsigned* hist = W.hist;
+  int* ctl = W.ctl;
   const int tid = threadIdx.x, q = blockIdx.x;
   const bool plain = (d_i == nullptr);   // single distance matrix, no z-score fusion (run_test.m types other than m2dp/sc)
   const bool two = (e_p != nullptr);
@@ -419,12 +440,11 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
       const int oj = rj[u];
       if (oj >= 0 && (mj < 0 || cand_less(rv[u], oj, mv, mj))) before++;
     }
-    __shared__ double tau_s;
-    if (tid == 0) tau_s = __builtin_inf();
+    if (tid == 0) W.tau_s = __builtin_inf();
     __syncthreads();
-    if (mj >= 0 && before == r - 1) tau_s = mv;      // (global indices are unique within a row: exactly one thread, if any)
+    if (mj >= 0 && before == r - 1) W.tau_s = mv;    // (global indices are unique within a row: exactly one thread, if any)
     __syncthreads();
-    tau = tau_s;
+    tau = W.tau_s;
   }
   // ---- (b) everything at or below tau
   const bool whole = n <= FS_CAP && !(tau < __builtin_inf());   // a row or slice that fits: element j IS list entry j (NaN: padding)
@@ -513,37 +533,39 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
   }
 }
 
-// P lists of k (score, index) pairs per query [P][m][k] -> the k best [m][k]; missing entries are -1.  One workgroup per query: the P k
-// entries (at most 8192) are sorted in LDS by a bitonic network.
-__global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restrict__ sidx, const float* __restrict__ sscore, int P, int m, int k,
-                                                           int32_t* __restrict__ idx, float* __restrict__ score, double* __restrict__ score64) {
-  extern __shared__ __attribute__((aligned(8))) char smem[];
-  const int q = blockIdx.x, tid = threadIdx.x, T = P * k;
+// P lists of k (score, index) pairs per query [P][m][k] -> the k best [m][k]; missing entries are -1.  The P k entries (at most 8192) go
+// through a radix selection / a bitonic network in LDS (lv: N floats, lj: N ints, N = the next power of two).  COHERENT: the lists were
+// written by other workgroups of THIS launch (the fused form below) - agent-scope loads, no line of this CU's L1 may stand in for them.
+template <bool COHERENT>
+__device__ void merge_slices(const int32_t* sidx, const float* sscore, int P, int m, int k, int q, float* lv, int* lj, double* rv, int* rj,
+                             unsigned* hist, int* ctl, int32_t* __restrict__ idx, float* __restrict__ score, double* __restrict__ score64,
+                             int tid) {
+  const int T = P * k;
   int N = 2;
   while (N < T) N <<= 1;
-  float* lv = reinterpret_cast<float*>(smem);
-  int* lj = reinterpret_cast<int*>(smem) + N;
-  __shared__ double rv[256];
-  __shared__ int rj[256];
-  __shared__ unsigned hist[256];
-  __shared__ int ctl[4];
   for (int s = tid; s < N; s += 256) {
     int j = -1;
     float v = 0.f;
-    if (s < T) { const size_t o = ((size_t)(s / k) * m + q) * k + (s % k); j = sidx[o]; v = sscore[o]; }
+    if (s < T) {
+      const size_t o = ((size_t)(s / k) * m + q) * k + (s % k);
+      if (COHERENT) {
+        j = __hip_atomic_load(sidx + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v = __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(sscore) + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      } else { j = sidx[o]; v = sscore[o]; }
+    }
     const bool ok = j >= 0 && v == v;
     lv[s] = ok ? v : __builtin_inff();
     lj[s] = ok ? j : NONE_J;
   }
   __syncthreads();
+  auto put = [&](int t, bool ok, float v, int j) {
+    idx[(size_t)q * k + t] = ok ? j : -1;
+    const float f32 = ok ? v : __builtin_nanf("");
+    score[(size_t)q * k + t] = f32;
+    if (score64) score64[(size_t)q * k + t] = (double)f32;
+  };
   if (k <= 249 && list_topk(lv, lj, T, k, rv, rj, hist, ctl, tid)) {      // radix selection + a 256-entry sort (see list_topk)
-    for (int t = tid; t < k; t += 256) {
-      const bool ok = rj[t] != NONE_J;
-      idx[(size_t)q * k + t] = ok ? rj[t] : -1;
-      const float f32 = ok ? (float)rv[t] : __builtin_nanf("");
-      score[(size_t)q * k + t] = f32;
-      if (score64) score64[(size_t)q * k + t] = (double)f32;
-    }
+    for (int t = tid; t < k; t += 256) put(t, rj[t] != NONE_J, (float)rv[t], rj[t]);
     return;
   }
   for (int size = 2; size <= N; size <<= 1)
@@ -557,13 +579,48 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restr
       }
       __syncthreads();
     }
-  for (int t = tid; t < k; t += 256) {
-    const bool ok = lj[t] != NONE_J;
-    idx[(size_t)q * k + t] = ok ? lj[t] : -1;
-    const float f32 = ok ? lv[t] : __builtin_nanf("");
-    score[(size_t)q * k + t] = f32;
-    if (score64) score64[(size_t)q * k + t] = (double)f32;
+  for (int t = tid; t < k; t += 256) put(t, lj[t] != NONE_J, lv[t], lj[t]);
+}
+
+__global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restrict__ sidx, const float* __restrict__ sscore, int P, int m, int k,
+                                                           int32_t* __restrict__ idx, float* __restrict__ score, double* __restrict__ score64) {
+  extern __shared__ __attribute__((aligned(8))) char smem[];
+  int N = 2;
+  while (N < P * k) N <<= 1;
+  __shared__ double rv[256];
+  __shared__ int rj[256];
+  __shared__ unsigned hist[256];
+  __shared__ int ctl[4];
+  merge_slices<false>(sidx, sscore, P, m, k, blockIdx.x, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + N, rv, rj, hist, ctl, idx, score,
+                      score64, threadIdx.x);
+}
+
+// The selection of a row or - few query rows, grid m x P - of one slice of it.  Sliced and `tick` given (the P k entries fit the list's
+// LDS): the last slice of the query to finish (a self-resetting ticket) merges the P lists right here, final_idx / final_score / score64 -
+// an online call waits for one launch instead of two.
+__global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i,
+                                                           const float* __restrict__ e_p, const float* __restrict__ e_i,
+                                                           const double* __restrict__ mom2_all,
+                                                           int m, int n, const double* __restrict__ mom_all, int G,
+                                                           int q_row0, int db_row0, int mask_width, double p_weight,
+                                                           int k, int32_t* __restrict__ idx, float* __restrict__ score, int P,
+                                                           double* __restrict__ score64, unsigned* __restrict__ tick,
+                                                           int32_t* __restrict__ final_idx, float* __restrict__ final_score) {
+  __shared__ SelLds L;
+  const bool fused = P > 1 && tick != nullptr;
+  select_row(d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, P, fused ? nullptr : score64, L);
+  if (!fused) return;
+  const int tid = threadIdx.x, q = blockIdx.x;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) {
+    L.last = (atomicAdd(&tick[q], 1u) == (unsigned)P - 1u);
+    if (L.last) tick[q] = 0u;
   }
+  __syncthreads();
+  if (!L.last) return;
+  __threadfence();
+  merge_slices<true>(idx, score, P, m, k, q, reinterpret_cast<float*>(L.lv), L.lj, L.rv, L.rj, L.hist, L.ctl, final_idx, final_score, score64, tid);
 }
 
 }  // namespace
@@ -581,15 +638,16 @@ int select_slices(int m, int n) {
   while (P > 1 && m * P > 1024) P >>= 1;            // capacity of the scratch (partial moments: 1024 (row, slice) pairs), ~4 workgroups per CU
   return P;
 }
-size_t select_scratch_bytes() { return (size_t)64 * 16 * 128 * 8 + (size_t)64 * 16 * 6 * 8; }
+// slice lists (index + score) | partial moments of 1024 (row, slice) pairs | two tickets per row (moments, selection; zero between launches)
+size_t select_scratch_bytes() { return (size_t)64 * 16 * 128 * 8 + (size_t)64 * 16 * 6 * 8 + (size_t)2 * 64 * sizeof(unsigned); }
+static unsigned* select_ticks(void* scratch) { return reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + (size_t)64 * 16 * 128 * 8 + (size_t)64 * 16 * 6 * 8); }
 
 void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom, void* scratch) {
   if (m <= 0) return;
   const int P = scratch ? select_slices(m, n) : 1;
   if (P > 1) {
     double* part = reinterpret_cast<double*>(static_cast<char*>(scratch) + (size_t)64 * 16 * 128 * 8);
-    hipLaunchKernelGGL(row_moments_slice_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, n, m, P, part);
-    hipLaunchKernelGGL(moments_finish_kernel, dim3((2 * m + 63) / 64), dim3(64), 0, st, d_p, d_i, n, m, P, part, mom);
+    hipLaunchKernelGGL(row_moments_slice_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, n, m, P, part, mom, select_ticks(scratch));
     return;
   }
   hipLaunchKernelGGL(row_moments_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, n, mom);
@@ -604,10 +662,15 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
   if (P > 1) {
     int32_t* sidx = static_cast<int32_t*>(scratch);
     float* ssc = reinterpret_cast<float*>(sidx + (size_t)64 * 16 * 128);
-    hipLaunchKernelGGL(fuse_select_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
-                       mask_width, p_weight, k, sidx, ssc, P, nullptr);
     int N = 2;
     while (N < P * k) N <<= 1;
+    if (N <= FS_CAP) {       // the P lists fit the selection's own LDS: merged by the query's last slice, one launch
+      hipLaunchKernelGGL(fuse_select_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
+                         mask_width, p_weight, k, sidx, ssc, P, score64, select_ticks(scratch) + 64, idx, score);
+      return;
+    }
+    hipLaunchKernelGGL(fuse_select_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
+                       mask_width, p_weight, k, sidx, ssc, P, nullptr, nullptr, nullptr, nullptr);
     // (up to 8192 entries = 64 KB of dynamic LDS next to ~4 KB of static arrays: above the 64 KB a launch gets without asking)
     if ((size_t)N * 8 > 40 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(slice_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)N * 8));
@@ -615,7 +678,7 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
     return;
   }
   hipLaunchKernelGGL(fuse_select_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
-                     mask_width, p_weight, k, idx, score, 1, score64);
+                     mask_width, p_weight, k, idx, score, 1, score64, nullptr, nullptr, nullptr);
 }
 
 }  // namespace pr

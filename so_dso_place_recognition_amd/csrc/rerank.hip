@@ -151,6 +151,17 @@ __device__ double m2dp_pair_exact(const void* qsig, int qdt, size_t qoff, const 
   return block_min256(diff, red, tid);                          // processM2DP.m:19
 }
 
+// the wave-per-query selection + order check behind the re-evaluation (sort_wave_body below)
+struct SortArgs {
+  const int32_t* idx_in; const double* p5; int m, kin, k;
+  int32_t* idx; double* score; float* score32;                  // [m][k] outputs (score / score32 may be null)
+  int check;                                                    // fold the order check into the selection rounds
+  const double* mom_sc; const double* mom_m2; int Gmom;
+  double p_weight, eps_floor, noise;
+  int32_t* order_flags;
+};
+template <bool COH> __device__ void sort_wave_body(const SortArgs& a, int q, int lane);
+
 struct RerankArgs {
   const void* q_sc; const void* db_sc; int sc_dt;               // raw SC signatures [m][2400] / [n_local][2400] or null
   const void* q_m2; const void* db_m2; int m2_dt;               // raw M2DP signatures [4 m][384] / [4 n_local][384] or null
@@ -159,6 +170,8 @@ struct RerankArgs {
   double p_weight;
   const double* cand_sc; int k;                                 // fp32-pass scores of the candidates [m][kin], ascending, or null; the k wanted
   double eps_d, eps_mult;                                       // distance error bound of the all-pairs pass per channel, and the safety factor on it
+  SortArgs sort;                                                // SPLIT launches: the query's last pair to finish runs the selection too
+  unsigned* qtick;                                              // [m] zeros (left zero): pairs of the query that are done
   double* p5;                                                   // [m][5][kin]: per query the candidates' scores [kin], then their four exact channel distances [4][kin] (SC structure, SC intensity, M2DP count, M2DP intensity; 0 for an absent type; NaN in the first one = not evaluated: masked, pruned, another shard's)
 };
 // the "p5" layout: what a shard knows about the candidates of a query after its re-evaluation.  Shard g, query q, candidate t:
@@ -205,14 +218,16 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
   double* out = A.p5 + p5_at(0, A.m, q, 0, A.kin, t);
   double* dout = A.p5 + p5_at(0, A.m, q, 1, A.kin, t);         // + c * kin: channel c
   // not evaluated: the first distance slot is NaN, the score says why (the pair's first workgroup writes, the others just leave)
-  auto skip = [&](double v) { if (cl == 0 && tid == 0) { *out = v; dout[0] = __builtin_nan(""); } };
-  if (jg < 0) { skip(__builtin_nan("")); return; }
+  bool skipped = false;
+  double skipv = 0.0;
+  auto skip = [&](double v) { skipped = true; skipv = v; };
+  if (jg < 0) skip(__builtin_nan(""));
   int dij = (A.q_row0 + q) - jg;
   if (dij < 0) dij = -dij;
-  if (dij < A.mask_width) { skip(__builtin_inf()); return; }   // run_test.m:47-53
+  if (!skipped && dij < A.mask_width) skip(__builtin_inf());   // run_test.m:47-53
   const int jl = jg - A.db_row0;
-  if (jl < 0 || jl >= A.n_local) { skip(__builtin_nan("")); return; }   // another shard's row: its owner evaluates it
-  if (A.cand_sc && t >= A.k) {
+  if (!skipped && (jl < 0 || jl >= A.n_local)) skip(__builtin_nan(""));   // another shard's row: its owner evaluates it
+  if (!skipped && A.cand_sc && t >= A.k) {
     // Candidates beyond the k-th of the fp32 pass whose fp32 score is above the k-th by more than 64 x the error bound of an fp32
     // score cannot enter the exact top-k: they keep their fp32 score (it only has to sort behind the evaluated ones).  Bound of
     // |fp32 score - exact score| given the row statistics: distance error 1e-6 per channel over its sigma,
@@ -221,7 +236,29 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
     double cn = 2.0;
     const double w = row_weight(A.q_sc ? A.mom_sc : nullptr, A.q_m2 ? A.mom_m2 : nullptr, A.G, A.m, q, A.p_weight, &cn);
     const double delta = A.eps_mult * score_err_bound(A.eps_d, w, sk, cn);
-    if (st > sk + delta) { skip(st); return; }                  // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
+    if (st > sk + delta) skip(st);                              // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
+  }
+  // SPLIT: the workgroup that completes a pair - the last of its channels, or the first one of a pair that is not evaluated - reports it
+  // to the query's ticket; the one that completes the query's last pair runs the selection (+ order check) with its first wave
+  auto pair_done = [&]() {
+    if constexpr (SPLIT) {
+      if (!A.qtick) return;                                     // (the sharded form: nothing behind the re-evaluation in this launch)
+      if (tid == 0) {
+        __threadfence();
+        s_last = (atomicAdd(&A.qtick[q], 1u) == (unsigned)A.kin - 1u);
+        if (s_last) A.qtick[q] = 0u;
+      }
+      __syncthreads();
+      if (!s_last) return;
+      __threadfence();
+      if (tid < 64) sort_wave_body<true>(A.sort, q, tid);
+    }
+  };
+  if (skipped) {
+    if (cl != 0) return;
+    if (tid == 0) { *out = skipv; dout[0] = __builtin_nan(""); }
+    pair_done();
+    return;
   }
   auto one = [&](int c) -> double {                              // channel 0, 1: SC structure / intensity; 2, 3: M2DP count / intensity
     if (c < 2) return sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + c * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + c * 1200, buf, red, tid);
@@ -265,6 +302,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
       }
       *out = f;
     }
+    __syncthreads();
+    pair_done();
   }
 }
 
@@ -360,26 +399,30 @@ __device__ __forceinline__ double chan_z(const RowStats& S, int c, double d) { r
 
 // The same with one WAVE per query (few query rows - an online call: one thread walking its 57 candidates alone is 16 us of load latency):
 // lane l holds candidates l and l + 64, k rounds of a wave arg-min by cand_before with the winner retired.
-__global__ __launch_bounds__(64) void rerank_sort_wave_kernel(const int32_t* __restrict__ idx_in, const double* __restrict__ p5,
-                                                               int m, int kin, int k, int32_t* __restrict__ idx, double* __restrict__ score,
-                                                               float* __restrict__ score32, int check,
-                                                               const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int Gmom,
-                                                               double p_weight, double eps_floor, double noise, int32_t* __restrict__ order_flags) {
+// COH: the p5 block was written by other workgroups of THIS launch (rerank_kernel<SPLIT>): agent-scope loads
+template <bool COH>
+__device__ __forceinline__ double ldd(const double* p) {
+  if (COH) return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  return *p;
+}
+template <bool COH>
+__device__ void sort_wave_body(const SortArgs& a, int q, int lane) {
   // check: the order check of order_check_kernel folded into the selection rounds (k + 1 of them: the last one finds the best
   // candidate left out) - every winner is compared with the previous one; an online call saves a launch
-  const int q = blockIdx.x, lane = threadIdx.x;
+  const int m = a.m, kin = a.kin, k = a.k, check = a.check;
+  const double* p5 = a.p5;
   double v[2], z[2][4];
   int j[2];
   RowStats S;
-  if (check) row_stats(mom_sc, mom_m2, Gmom, m, q, p_weight, eps_floor, noise, S);
+  if (check) row_stats(a.mom_sc, a.mom_m2, a.Gmom, m, q, a.p_weight, a.eps_floor, a.noise, S);
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const int c = lane + 64 * h;
-    j[h] = c < kin ? idx_in[(size_t)q * kin + c] : -1;
-    v[h] = c < kin ? p5[p5_at(0, m, q, 0, kin, c)] : __builtin_nan("");
-    const double d0 = (check && c < kin) ? p5[p5_at(0, m, q, 1, kin, c)] : __builtin_nan("");
+    j[h] = c < kin ? a.idx_in[(size_t)q * kin + c] : -1;
+    v[h] = c < kin ? ldd<COH>(p5 + p5_at(0, m, q, 0, kin, c)) : __builtin_nan("");
+    const double d0 = (check && c < kin) ? ldd<COH>(p5 + p5_at(0, m, q, 1, kin, c)) : __builtin_nan("");
     for (int cc = 0; cc < 4; cc++) {
-      const double d = (check && c < kin) ? p5[p5_at(0, m, q, 1 + cc, kin, c)] : __builtin_nan("");
+      const double d = (d0 == d0) ? ldd<COH>(p5 + p5_at(0, m, q, 1 + cc, kin, c)) : __builtin_nan("");
       z[h][cc] = (d0 == d0) ? chan_z(S, cc, d) : __builtin_nan("");
     }
   }
@@ -400,10 +443,10 @@ __global__ __launch_bounds__(64) void rerank_sort_wave_kernel(const int32_t* __r
     }
     const bool ok = bj >= 0 && bv == bv;
     if (lane == 0 && t < k) {
-      idx[(size_t)q * k + t] = ok ? bj : -1;
+      a.idx[(size_t)q * k + t] = ok ? bj : -1;
       const double o = ok ? bv : __builtin_nan("");
-      if (score) score[(size_t)q * k + t] = o;
-      if (score32) score32[(size_t)q * k + t] = (float)o;
+      if (a.score) a.score[(size_t)q * k + t] = o;
+      if (a.score32) a.score32[(size_t)q * k + t] = (float)o;
     }
     if (check && ok) {                                       // (no further entries: nothing left to compare, -1 / NaN fill the rest)
       double wz[4];
@@ -421,9 +464,8 @@ __global__ __launch_bounds__(64) void rerank_sort_wave_kernel(const int32_t* __r
     if (bc == lane) { j[0] = -1; v[0] = __builtin_nan(""); }
     if (bc == lane + 64) { j[1] = -1; v[1] = __builtin_nan(""); }
   }
-  if (order_flags && lane == 0) order_flags[q] = flag;
+  if (a.order_flags && lane == 0) a.order_flags[q] = flag;
 }
-
 // cand_idx [m][kin] + the evaluations of G shards, p5_all [G][m][5][kin] (NaN scores where the candidate is not the shard's) -> the k best.
 // Every candidate has exactly one owner; a masked pair is +Inf at its owner.
 __global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __restrict__ cand_idx, const double* __restrict__ p5_all,
@@ -822,10 +864,12 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
     hipLaunchKernelGGL(nan_fixup_kernel, dim3((n + 255) / 256, m < 64 ? m : 64), dim3(256), 0, st, d_p, d_i, m, n, qbad, dbad);
 }
 
-// few queries: one workgroup per (pair, channel); otherwise per pair (the batch's time is its workgroup count)
+// few queries: one workgroup per (pair, channel) - and, sort given, the selection behind it in the same launch; otherwise per pair (the
+// batch's time is its workgroup count)
+static bool rerank_split(int m) { return m <= 64; }
 static void launch_rerank_kernel(hipStream_t st, const RerankArgs& A, const int32_t* idx_in, unsigned* tick) {
   const unsigned nch = (A.q_sc ? 2u : 0u) + (A.q_m2 ? 2u : 0u);
-  if (A.m <= 64) hipLaunchKernelGGL(rerank_kernel<true>, dim3((unsigned)A.m * A.kin * nch), dim3(256), 0, st, A, idx_in, tick);
+  if (rerank_split(A.m)) hipLaunchKernelGGL(rerank_kernel<true>, dim3((unsigned)A.m * A.kin * nch), dim3(256), 0, st, A, idx_in, tick);
   else hipLaunchKernelGGL(rerank_kernel<false>, dim3((unsigned)A.m * A.kin), dim3(256), 0, st, A, idx_in, tick);
 }
 
@@ -834,15 +878,12 @@ void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_d
                    double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, int k, int32_t* idx, double* score,
                    float* score32, const double* cand_sc32, double eps_d, double order_floor, double order_noise, int32_t* order_flags) {
   if (m <= 0) return;
+  SortArgs S{idx_in, p5, m, kin, k, idx, score, score32, order_flags ? 1 : 0, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr, G, p_weight,
+             order_floor, order_noise, order_flags};
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
-               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
+               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, S, tick + (size_t)m * kin, p5};
   launch_rerank_kernel(st, A, idx_in, tick);
-  // order check (order_flags != null): inside the wave selection for few queries, its own launch otherwise
-  if (m <= 64 && kin <= 128) {
-    hipLaunchKernelGGL(rerank_sort_wave_kernel, dim3(m), dim3(64), 0, st, idx_in, p5, m, kin, k, idx, score, score32, order_flags ? 1 : 0,
-                       q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr, G, p_weight, order_floor, order_noise, order_flags);
-    return;
-  }
+  if (rerank_split(m) && kin <= 128) return;      // (the selection + order check ran inside: the query's last pair)
   hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, p5, m, kin, k, idx, score, score32);
   if (order_flags)
     hipLaunchKernelGGL(order_check_kernel, dim3(m), dim3(64), 0, st, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr, G, idx_in, p5, 1, m, kin, k,
@@ -853,8 +894,10 @@ void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, 
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
                            double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, const double* cand_sc32, int k, double eps_d) {
   if (m <= 0) return;
+  // (the sharded form: no selection behind it - the blocks of all shards are gathered first; sort.k = 0 keeps the SPLIT kernel from running one)
+  SortArgs S{};
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
-               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
+               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, S, nullptr, p5};
   launch_rerank_kernel(st, A, idx_in, tick);
 }
 
@@ -889,7 +932,8 @@ void launch_resolve(hipStream_t st, const void* q_sc, const void* db_sc, int sc_
                     const int32_t* cand_idx, const double* p5, int kin, int k, int32_t* idx, double* score, double* out_mom_sc, double* out_mom_m2) {
   if (m <= 0 || n_local <= 0) return;
   const int32_t* fl = compacted ? nullptr : resolve_list(st, flags, m, list, cnt);
-  const int NB = exact_partial_blocks(n_local);
+  int NB = exact_partial_blocks(n_local);
+  if (m <= 64 && NB > 256) NB = 256;      // an online call pays for the launch every time and for the resolution once in 10^5 calls: a small grid
   ExactArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, fl, list, cnt, offset, NB, partial, exact, tick, dflags};
   RescoreArgs R{p_weight, cand_idx, p5, kin, k, idx, score, out_mom_sc, out_mom_m2};
   if (rescore) hipLaunchKernelGGL(resolve_kernel<true>, dim3(NB), dim3(256), 0, st, A, R);
