@@ -460,12 +460,16 @@ def main():
         fpp, peak = (FLOP_PER_PAIR_F16X2 if arith == "f16x2" else FLOP_PER_PAIR, MFMA_F16_PEAK_TFLOPS) if f16 else (FLOP_PER_PAIR, MFMA_F32_PEAK_TFLOPS)
         ach = pairs * fpp / (kms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
-        try:
-            tr = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
-            if tr["workload"] == {"db": n, "queries": m, "n_gpus": world}:
-                traffic = next(v["hbm_bytes_per_launch"] for kk, v in tr.items() if kk.startswith(kname.split("<")[0]) and (arith != "f16") == ("<false" not in kk))
-        except Exception:
-            pass
+        traffic_file = None
+        for cand in ("r04_traffic.json", "r03_traffic.json"):            # the newest committed PMC passes of this command
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", cand)))
+                if tr["workload"] == {"db": n, "queries": m, "n_gpus": world}:
+                    traffic = next(v["hbm_bytes_per_launch"] for kk, v in tr.items() if kk.startswith(kname.split("<")[0]) and (arith != "f16") == ("<false" not in kk))
+                    traffic_file = cand
+                    break
+            except Exception:
+                pass
         out = {
             "metric": "queries/sec over 100k-signature DB (SC 20x60, z-score fusion, top-1)",
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -475,12 +479,12 @@ def main():
             "data": "synthetic",
             "config": {"workload": "sc_match_100k", "db_signatures": n, "queries_per_step": m, "descriptor": "SC 20x60 x 2 channels",
                        "mask_width": 0, "p_weight": 2.0, "k": 1, "db_rows_per_gpu": hi - lo,
-                       "step": "pack(q)+pack(db)+distances+moments+select(k+8)+fp64 re-evaluation"
-                               + ("+3 all_gathers+merge" if (world > 1 or args.force_exchange) else "")},
+                       "step": "pack(q)+pack(db)+distances+moments+select(k+8)+fp64 re-evaluation+order check+fp64-statistics resolution of flagged queries"
+                               + ("+4 all_gathers+merge" if (world > 1 or args.force_exchange) else "")},
             "roofline": {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak,
                          "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
-                         "traffic_source": ("profiles/r03_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE passes of this command, per launch"
-                                            if traffic is not None else None),
+                         "traffic_source": (f"profiles/{traffic_file}: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE passes of this command, per launch "
+                                            "(a committed measurement of one box, not a live counter)" if traffic is not None else None),
                          "flop_per_pair": fpp, "pairs_per_launch": pairs, "ms_per_launch": kms,
                          # the same launch priced as the fp32 formulation it replaces (what an fp32-MFMA kernel would need)
                          "fp32_formulation_tflops": pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12,

@@ -77,8 +77,7 @@ __global__ __launch_bounds__(256) void row_moments_kernel(const float* __restric
 // cut into P slices, one workgroup each (grid m x P): raw sums (count, S1, S2) about the row's first element per slice, added in slice order
 // by moments_finish_kernel - deterministic for a given (m, n).
 __global__ __launch_bounds__(256) void row_moments_slice_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i, int n, int m, int P,
-                                                                 double* __restrict__ part /* [P][m][2][3] */, double* __restrict__ mom,
-                                                                 unsigned* __restrict__ tick /* [m] zeros, left zero */) {
+                                                                 double* __restrict__ part /* [P][m][2][3] */) {
   // an online call waits for this kernel: both channels side by side, eight loads of a thread in flight, and ONE reduction tree for the
   // six sums (the per-thread order of the additions and the tree are those of block_sum, so the sums are bit for bit what three
   // block_sum calls per channel gave)
@@ -113,37 +112,30 @@ __global__ __launch_bounds__(256) void row_moments_slice_kernel(const float* __r
     double* o = part + (((size_t)sl * m + q) * 2 + tid) * 3;
     o[0] = red[3 * tid + 2][0]; o[1] = red[3 * tid][0]; o[2] = red[3 * tid + 1][0];
   }
-  // the last slice of the query to finish adds the P partials in slice order -> (count, mean, M2): no second launch for an online call to wait for
-  __shared__ int s_last;
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) {
-    s_last = (atomicAdd(&tick[q], 1u) == (unsigned)P - 1u);
-    if (s_last) tick[q] = 0u;
-  }
-  __syncthreads();
-  if (!s_last) return;
-  __threadfence();
-  if (tid < 2) {
-    const int ch = tid;
-    const double c = ch ? ci : cp;
-    double N = 0.0, S1 = 0.0, S2 = 0.0;
-    const size_t step = (size_t)m * 6;                 // doubles between the partials of consecutive slices
-    const volatile double* o = part + ((size_t)q * 2 + ch) * 3;
-    int s8 = 0;
-    for (; s8 + 8 <= P; s8 += 8) {                     // eight slices' partials requested together, added in slice order
-      double a[8][3];
+}
+__global__ __launch_bounds__(64) void moments_finish_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i, int n, int m, int P,
+                                                             const double* __restrict__ part, double* __restrict__ mom) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  if (t >= 2 * m) return;
+  const int q = t >> 1, ch = t & 1;
+  const float r0 = ((ch ? d_i : d_p) + (size_t)q * n)[0];
+  const double c = (r0 == r0) ? (double)r0 : 0.5;
+  double N = 0.0, S1 = 0.0, S2 = 0.0;
+  const size_t step = (size_t)m * 6;                 // doubles between the partials of consecutive slices
+  const double* o = part + ((size_t)q * 2 + ch) * 3;
+  int sl = 0;
+  for (; sl + 8 <= P; sl += 8) {                     // eight slices' partials requested together, added in slice order
+    double a[8][3];
 #pragma unroll
-      for (int u = 0; u < 8; u++) { a[u][0] = o[(s8 + u) * step]; a[u][1] = o[(s8 + u) * step + 1]; a[u][2] = o[(s8 + u) * step + 2]; }
+    for (int u = 0; u < 8; u++) { a[u][0] = o[(sl + u) * step]; a[u][1] = o[(sl + u) * step + 1]; a[u][2] = o[(sl + u) * step + 2]; }
 #pragma unroll
-      for (int u = 0; u < 8; u++) { N += a[u][0]; S1 += a[u][1]; S2 += a[u][2]; }
-    }
-    for (; s8 < P; s8++) { N += o[s8 * step]; S1 += o[s8 * step + 1]; S2 += o[s8 * step + 2]; }
-    double* w = mom + ((size_t)q * 2 + ch) * 3;
-    w[0] = N;
-    w[1] = N > 0.0 ? c + S1 / N : 0.0;
-    w[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
+    for (int u = 0; u < 8; u++) { N += a[u][0]; S1 += a[u][1]; S2 += a[u][2]; }
   }
+  for (; sl < P; sl++) { N += o[sl * step]; S1 += o[sl * step + 1]; S2 += o[sl * step + 2]; }
+  double* w = mom + ((size_t)q * 2 + ch) * 3;
+  w[0] = N;
+  w[1] = N > 0.0 ? c + S1 / N : 0.0;
+  w[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
 }
 
 __device__ __forceinline__ bool cand_less(double av, int aj, double bv, int bj) {   // (a) < (b) lexicographic
@@ -534,9 +526,7 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
 }
 
 // P lists of k (score, index) pairs per query [P][m][k] -> the k best [m][k]; missing entries are -1.  The P k entries (at most 8192) go
-// through a radix selection / a bitonic network in LDS (lv: N floats, lj: N ints, N = the next power of two).  COHERENT: the lists were
-// written by other workgroups of THIS launch (the fused form below) - agent-scope loads, no line of this CU's L1 may stand in for them.
-template <bool COHERENT>
+// through a radix selection / a bitonic network in LDS (lv: N floats, lj: N ints, N = the next power of two).
 __device__ void merge_slices(const int32_t* sidx, const float* sscore, int P, int m, int k, int q, float* lv, int* lj, double* rv, int* rj,
                              unsigned* hist, int* ctl, int32_t* __restrict__ idx, float* __restrict__ score, double* __restrict__ score64,
                              int tid) {
@@ -548,10 +538,7 @@ __device__ void merge_slices(const int32_t* sidx, const float* sscore, int P, in
     float v = 0.f;
     if (s < T) {
       const size_t o = ((size_t)(s / k) * m + q) * k + (s % k);
-      if (COHERENT) {
-        j = __hip_atomic_load(sidx + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = __int_as_float(__hip_atomic_load(reinterpret_cast<const int*>(sscore) + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      } else { j = sidx[o]; v = sscore[o]; }
+      j = sidx[o]; v = sscore[o];
     }
     const bool ok = j >= 0 && v == v;
     lv[s] = ok ? v : __builtin_inff();
@@ -591,36 +578,24 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restr
   __shared__ int rj[256];
   __shared__ unsigned hist[256];
   __shared__ int ctl[4];
-  merge_slices<false>(sidx, sscore, P, m, k, blockIdx.x, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + N, rv, rj, hist, ctl, idx, score,
+  merge_slices(sidx, sscore, P, m, k, blockIdx.x, reinterpret_cast<float*>(smem), reinterpret_cast<int*>(smem) + N, rv, rj, hist, ctl, idx, score,
                       score64, threadIdx.x);
 }
 
-// The selection of a row or - few query rows, grid m x P - of one slice of it.  Sliced and `tick` given (the P k entries fit the list's
-// LDS): the last slice of the query to finish (a self-resetting ticket) merges the P lists right here, final_idx / final_score / score64 -
-// an online call waits for one launch instead of two.
+// The selection of a row or - few query rows, grid m x P - of one slice of it (slice_merge_kernel then merges the P lists).
+// (Round 4 measured the merge - and the moments' finish, and the wave selection behind the re-evaluation - as last-workgroup hand-offs
+//  inside the launch in front of them, self-resetting tickets: an online call of one query gained nothing, 8 - 32 queries lost 10 - 15 % -
+//  the fence, the ticket and the agent-scope re-reads cost what a launch costs, and the finishing workgroup starts later than a fresh
+//  kernel would.  tools/experiments/README.md.)
 __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i,
                                                            const float* __restrict__ e_p, const float* __restrict__ e_i,
                                                            const double* __restrict__ mom2_all,
                                                            int m, int n, const double* __restrict__ mom_all, int G,
                                                            int q_row0, int db_row0, int mask_width, double p_weight,
                                                            int k, int32_t* __restrict__ idx, float* __restrict__ score, int P,
-                                                           double* __restrict__ score64, unsigned* __restrict__ tick,
-                                                           int32_t* __restrict__ final_idx, float* __restrict__ final_score) {
+                                                           double* __restrict__ score64) {
   __shared__ SelLds L;
-  const bool fused = P > 1 && tick != nullptr;
-  select_row(d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, P, fused ? nullptr : score64, L);
-  if (!fused) return;
-  const int tid = threadIdx.x, q = blockIdx.x;
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) {
-    L.last = (atomicAdd(&tick[q], 1u) == (unsigned)P - 1u);
-    if (L.last) tick[q] = 0u;
-  }
-  __syncthreads();
-  if (!L.last) return;
-  __threadfence();
-  merge_slices<true>(idx, score, P, m, k, q, reinterpret_cast<float*>(L.lv), L.lj, L.rv, L.rj, L.hist, L.ctl, final_idx, final_score, score64, tid);
+  select_row(d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, P, score64, L);
 }
 
 }  // namespace
@@ -638,16 +613,16 @@ int select_slices(int m, int n) {
   while (P > 1 && m * P > 1024) P >>= 1;            // capacity of the scratch (partial moments: 1024 (row, slice) pairs), ~4 workgroups per CU
   return P;
 }
-// slice lists (index + score) | partial moments of 1024 (row, slice) pairs | two tickets per row (moments, selection; zero between launches)
-size_t select_scratch_bytes() { return (size_t)64 * 16 * 128 * 8 + (size_t)64 * 16 * 6 * 8 + (size_t)2 * 64 * sizeof(unsigned); }
-static unsigned* select_ticks(void* scratch) { return reinterpret_cast<unsigned*>(static_cast<char*>(scratch) + (size_t)64 * 16 * 128 * 8 + (size_t)64 * 16 * 6 * 8); }
+// slice lists (index + score) | partial moments of 1024 (row, slice) pairs
+size_t select_scratch_bytes() { return (size_t)64 * 16 * 128 * 8 + (size_t)64 * 16 * 6 * 8; }
 
 void launch_row_moments(hipStream_t st, const float* d_p, const float* d_i, int m, int n, double* mom, void* scratch) {
   if (m <= 0) return;
   const int P = scratch ? select_slices(m, n) : 1;
   if (P > 1) {
     double* part = reinterpret_cast<double*>(static_cast<char*>(scratch) + (size_t)64 * 16 * 128 * 8);
-    hipLaunchKernelGGL(row_moments_slice_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, n, m, P, part, mom, select_ticks(scratch));
+    hipLaunchKernelGGL(row_moments_slice_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, n, m, P, part);
+    hipLaunchKernelGGL(moments_finish_kernel, dim3((2 * m + 63) / 64), dim3(64), 0, st, d_p, d_i, n, m, P, part, mom);
     return;
   }
   hipLaunchKernelGGL(row_moments_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, n, mom);
@@ -664,13 +639,8 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
     float* ssc = reinterpret_cast<float*>(sidx + (size_t)64 * 16 * 128);
     int N = 2;
     while (N < P * k) N <<= 1;
-    if (N <= FS_CAP) {       // the P lists fit the selection's own LDS: merged by the query's last slice, one launch
-      hipLaunchKernelGGL(fuse_select_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
-                         mask_width, p_weight, k, sidx, ssc, P, score64, select_ticks(scratch) + 64, idx, score);
-      return;
-    }
     hipLaunchKernelGGL(fuse_select_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
-                       mask_width, p_weight, k, sidx, ssc, P, nullptr, nullptr, nullptr, nullptr);
+                       mask_width, p_weight, k, sidx, ssc, P, nullptr);
     // (up to 8192 entries = 64 KB of dynamic LDS next to ~4 KB of static arrays: above the 64 KB a launch gets without asking)
     if ((size_t)N * 8 > 40 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(slice_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)N * 8));
@@ -678,7 +648,7 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
     return;
   }
   hipLaunchKernelGGL(fuse_select_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
-                     mask_width, p_weight, k, idx, score, 1, score64, nullptr, nullptr, nullptr);
+                     mask_width, p_weight, k, idx, score, 1, score64);
 }
 
 }  // namespace pr

@@ -215,26 +215,34 @@ __global__ __launch_bounds__(256) void m2dp_bin_kernel(const double* __restrict_
   }
 }
 
+// Sum / maximum over the 256 threads: inside a wave by lane exchanges (an xor butterfly: both partners combine the same two numbers, so
+// all 64 lanes hold the same bits, no barrier), the four wave results through LDS, combined in wave order by every thread: two barriers
+// instead of ten.  (Round 4: the leading-pair iteration below is a chain of such reductions; with the tree in LDS it spent most of its
+// time in barriers.)
 __device__ __forceinline__ double block_sum256(double v, double* red, int tid) {
-  red[tid] = v;
+#pragma unroll
+  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
+  if ((tid & 63) == 0) red[tid >> 6] = v;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
-    if (tid < s) red[tid] += red[tid + s];
-    __syncthreads();
-  }
-  const double r = red[0];
+  const double r = (red[0] + red[1]) + (red[2] + red[3]);
   __syncthreads();
   return r;
 }
 
+// The leading singular pair of one 64 x 128 bin matrix (M2DP.cpp:94-103).  One LDS buffer serves A (64 x 129, padded rows), then the Gram
+// matrix G (64 x 65) and its eight squarings, then A again (re-read from global memory: 64 KB out of L2) for the polish on the original
+// matrix - 70 KB of LDS instead of 103, so that TWO workgroups share a CU (the Gram product keeps its 4 x 4 block per thread in registers
+// until every read of A is done).  The polish step u <- A (A^T u) runs on all 256 threads (A^T u: two half-sums per column, A v: four
+// quarter-sums per row, added in a fixed order) with three barriers per iteration.
 __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict__ mats, int c0, double* __restrict__ out,
                                                         int* __restrict__ flags, int* __restrict__ svd_rows) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* A = sm;               // 64 x 129 (padded rows)
-  double* G = A + 64 * 129;     // 64 x 65
-  double* u = G + 64 * 65;      // 64
+  double* A = sm;               // 64 x 129 (padded rows) | G: 64 x 65
+  double* G = sm;
+  double* u = A + 64 * 129;     // 64
   double* v = u + 64;           // 128
-  double* red = v + 128;        // 256
+  double* red = v + 128;        // 256 (partial sums of the polish; [0..3] the wave results of block_sum256)
+  double* bc = red + 256;       // 4: broadcast of (norm, max difference)
   const int tid = threadIdx.x;
   const int ch = blockIdx.x & 1, var = (blockIdx.x >> 1) & 3, cl = blockIdx.x >> 3;
   const double* src = mats + (((size_t)cl * 4 + var) * 2 + ch) * MAT;
@@ -251,7 +259,7 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
     return;
   }
   // G = A A^T / fro.  Every thread owns a 4 x 4 block of the 64 x 64 result: 8 LDS reads per 16 multiply-adds instead
-  // of 32 (the kernel is LDS-bound); every entry is still summed over k in ascending order, so the values do not change.
+  // of 32 (the kernel is LDS-bound); every entry is summed over k in ascending order.
   const int i0 = (tid >> 4) * 4, j0 = (tid & 15) * 4;
   {
     double acc[4][4] = {};
@@ -264,6 +272,7 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] += ai[a] * aj[b];
     }
+    __syncthreads();                   // every read of A is done: G takes its place
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -281,9 +290,7 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] += gi[a] * gj[b];
     }
-    // Frobenius norm: the per-thread partial sums run over the thread's entries in the order e = tid, tid + 256, ... of
-    // the first version of this kernel is NOT kept (another fixed order); the norm only scales G, u is renormalised below
-    double part = 0.0;
+    double part = 0.0;                 // Frobenius norm (it only scales G; u is renormalised below)
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -305,40 +312,46 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
   {
     const double nn = sqrt(block_sum256(tid < 64 ? u[tid] * u[tid] : 0.0, red, tid));
     if (tid < 64) u[tid] = u[tid] / nn;
-    __syncthreads();
   }
+  // A again, over G (the sums above have passed block_sum256's barriers: nobody reads G any more)
+  for (int e = tid; e < MAT; e += 256) A[(e >> 7) * 129 + (e & 127)] = src[e];
+  __syncthreads();
   double sigma = 0.0;
   bool converged = false;
+  const int col = tid & 127, hv = tid >> 7;          // A^T u: column col, rows 32 hv .. 32 hv + 31
+  const int row = tid & 63, qv = tid >> 6;           // A v:   row row, columns 32 qv .. 32 qv + 31
   for (int it = 0; it < 400; it++) {   // polish on the original matrix: u <- A (A^T u)
-    if (tid < 128) {
+    {
       double s = 0.0;
-      for (int i = 0; i < 64; i++) s += A[i * 129 + tid] * u[i];
-      v[tid] = s;
+      for (int i = 32 * hv; i < 32 * hv + 32; i++) s += A[i * 129 + col] * u[i];
+      red[tid] = s;
+    }
+    __syncthreads();
+    if (tid < 128) v[tid] = red[tid] + red[tid + 128];
+    __syncthreads();
+    {
+      double s = 0.0;
+      for (int k = 32 * qv; k < 32 * qv + 32; k++) s += A[row * 129 + k] * v[k];
+      red[tid] = s;
     }
     __syncthreads();
     double un = 0.0;
-    if (tid < 64) {
-      double s = 0.0;
-      for (int k = 0; k < 128; k++) s += A[tid * 129 + k] * v[k];
-      un = s;
-    }
-    const double nn = sqrt(block_sum256(tid < 64 ? un * un : 0.0, red, tid));   // = sigma^2 at convergence
-    double diff = 0.0;
-    if (tid < 64) {
+    if (tid < 64) {                    // one wave: norm and largest change by lane exchanges
+      un = (red[tid] + red[tid + 64]) + (red[tid + 128] + red[tid + 192]);
+      double n2 = un * un;
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) n2 += __shfl_xor(n2, s, 64);
+      const double nn = sqrt(n2);      // = sigma^2 at convergence
       un = un / nn;
-      diff = fabs(un - u[tid]);
+      double df = fabs(un - u[tid]);
+#pragma unroll
+      for (int s = 32; s > 0; s >>= 1) df = fmax(df, __shfl_xor(df, s, 64));
+      u[tid] = un;
+      if (tid == 0) { bc[0] = nn; bc[1] = df; }
     }
-    red[tid] = diff;
     __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) {
-      if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
-      __syncthreads();
-    }
-    const double dmax = red[0];
-    __syncthreads();
-    if (tid < 64) u[tid] = un;
-    sigma = sqrt(nn);
-    __syncthreads();
+    sigma = sqrt(bc[0]);
+    const double dmax = bc[1];
     if (dmax < 4e-15 && it >= 1) { converged = true; break; }
   }
   // sigma_2 / sigma_1 > ~0.99: the leading pair is ill-defined in the reference too (JacobiSVD returns whichever of the two
@@ -350,18 +363,22 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
     if (slot < M2DP_SVD_ROWS_CAP) svd_rows[1 + slot] = (c0 + cl) * 4 + var;
   }
   // v = A^T u / sigma, sign so that sum(u) >= 0
-  if (tid < 128) {
+  __syncthreads();
+  {
     double s = 0.0;
-    for (int i = 0; i < 64; i++) s += A[i * 129 + tid] * u[i];
-    v[tid] = s / sigma;
+    for (int i = 32 * hv; i < 32 * hv + 32; i++) s += A[i * 129 + col] * u[i];
+    red[tid] = s;
   }
+  __syncthreads();
+  if (tid < 128) v[tid] = (red[tid] + red[tid + 128]) / sigma;
+  __syncthreads();
   const double su = block_sum256(tid < 64 ? u[tid] : 0.0, red, tid);
   const double sg = (su < 0.0) ? -1.0 : 1.0;
   if (tid < 64) o[tid] = sg * u[tid];
   if (tid < 128) o[64 + tid] = sg * v[tid];
 }
 
-constexpr size_t SVD_LDS = (size_t)(64 * 129 + 64 * 65 + 64 + 128 + 256) * sizeof(double);
+constexpr size_t SVD_LDS = (size_t)(64 * 129 + 64 + 128 + 256 + 4) * sizeof(double);   // 69 856 B: two workgroups per CU
 constexpr int GEN_BATCH = 256;   // clouds per scratch batch (256 * 4 * 2 * 64 KiB = 128 MiB)
 
 }  // namespace

@@ -179,7 +179,6 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
     TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     for (auto& e : ctx->ev_m2) TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     TRY(hipMalloc(&ctx->sel_scratch, pr::select_scratch_bytes()));
-    TRY(hipMemset(ctx->sel_scratch, 0, pr::select_scratch_bytes()));        // (its tickets start at zero and leave every launch at zero)
     TRY(hipMalloc((void**)&ctx->d_flags, 4 * sizeof(int)));
     TRY(hipMemset(ctx->d_flags, 0, 4 * sizeof(int)));
     TRY(hipMalloc((void**)&ctx->d_svd_rows, (1 + pr::M2DP_SVD_ROWS_CAP) * sizeof(int)));
@@ -752,7 +751,7 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
   // the candidates' scores and exact distances stay in the context (p5 layout) with one order flag per query: pr_order_resolve*_dev /
   // pr_f16_margin_dev take them
   if (int rc = rerank_scratch(ctx, (size_t)5 * m * k_in, m)) return rc;
-  if (int rc = rerank_ticks(ctx, (size_t)m * k_in + m)) return rc;   // per-pair tickets, then per-query ones
+  if (int rc = rerank_ticks(ctx, (size_t)m * k_in)) return rc;
   double fl, noise;
   order_consts(ctx, fl, noise);
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,

@@ -160,8 +160,6 @@ struct SortArgs {
   double p_weight, eps_floor, noise;
   int32_t* order_flags;
 };
-template <bool COH> __device__ void sort_wave_body(const SortArgs& a, int q, int lane);
-
 struct RerankArgs {
   const void* q_sc; const void* db_sc; int sc_dt;               // raw SC signatures [m][2400] / [n_local][2400] or null
   const void* q_m2; const void* db_m2; int m2_dt;               // raw M2DP signatures [4 m][384] / [4 n_local][384] or null
@@ -170,8 +168,6 @@ struct RerankArgs {
   double p_weight;
   const double* cand_sc; int k;                                 // fp32-pass scores of the candidates [m][kin], ascending, or null; the k wanted
   double eps_d, eps_mult;                                       // distance error bound of the all-pairs pass per channel, and the safety factor on it
-  SortArgs sort;                                                // SPLIT launches: the query's last pair to finish runs the selection too
-  unsigned* qtick;                                              // [m] zeros (left zero): pairs of the query that are done
   double* p5;                                                   // [m][5][kin]: per query the candidates' scores [kin], then their four exact channel distances [4][kin] (SC structure, SC intensity, M2DP count, M2DP intensity; 0 for an absent type; NaN in the first one = not evaluated: masked, pruned, another shard's)
 };
 // the "p5" layout: what a shard knows about the candidates of a query after its re-evaluation.  Shard g, query q, candidate t:
@@ -238,26 +234,8 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
     const double delta = A.eps_mult * score_err_bound(A.eps_d, w, sk, cn);
     if (st > sk + delta) skip(st);                              // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
   }
-  // SPLIT: the workgroup that completes a pair - the last of its channels, or the first one of a pair that is not evaluated - reports it
-  // to the query's ticket; the one that completes the query's last pair runs the selection (+ order check) with its first wave
-  auto pair_done = [&]() {
-    if constexpr (SPLIT) {
-      if (!A.qtick) return;                                     // (the sharded form: nothing behind the re-evaluation in this launch)
-      if (tid == 0) {
-        __threadfence();
-        s_last = (atomicAdd(&A.qtick[q], 1u) == (unsigned)A.kin - 1u);
-        if (s_last) A.qtick[q] = 0u;
-      }
-      __syncthreads();
-      if (!s_last) return;
-      __threadfence();
-      if (tid < 64) sort_wave_body<true>(A.sort, q, tid);
-    }
-  };
   if (skipped) {
-    if (cl != 0) return;
-    if (tid == 0) { *out = skipv; dout[0] = __builtin_nan(""); }
-    pair_done();
+    if (cl == 0 && tid == 0) { *out = skipv; dout[0] = __builtin_nan(""); }
     return;
   }
   auto one = [&](int c) -> double {                              // channel 0, 1: SC structure / intensity; 2, 3: M2DP count / intensity
@@ -294,16 +272,14 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
     if (!s_last) return;
     __threadfence();
     if (tid == 0) {
-      const volatile double* dv = dout;
-      double f = 0.0;
+      double f = 0.0;                                           // (the other channels' distances: agent-scope loads, out of L2)
       for (int a = 0; a < 4; a++) {
         if (a < 2 ? !A.q_sc : !A.q_m2) continue;
-        f += term(a, dv[(size_t)a * A.kin]);
+        f += term(a, __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(dout + (size_t)a * A.kin), __ATOMIC_RELAXED,
+                                                             __HIP_MEMORY_SCOPE_AGENT)));
       }
       *out = f;
     }
-    __syncthreads();
-    pair_done();
   }
 }
 
@@ -399,13 +375,6 @@ __device__ __forceinline__ double chan_z(const RowStats& S, int c, double d) { r
 
 // The same with one WAVE per query (few query rows - an online call: one thread walking its 57 candidates alone is 16 us of load latency):
 // lane l holds candidates l and l + 64, k rounds of a wave arg-min by cand_before with the winner retired.
-// COH: the p5 block was written by other workgroups of THIS launch (rerank_kernel<SPLIT>): agent-scope loads
-template <bool COH>
-__device__ __forceinline__ double ldd(const double* p) {
-  if (COH) return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  return *p;
-}
-template <bool COH>
 __device__ void sort_wave_body(const SortArgs& a, int q, int lane) {
   // check: the order check of order_check_kernel folded into the selection rounds (k + 1 of them: the last one finds the best
   // candidate left out) - every winner is compared with the previous one; an online call saves a launch
@@ -419,10 +388,10 @@ __device__ void sort_wave_body(const SortArgs& a, int q, int lane) {
   for (int h = 0; h < 2; h++) {
     const int c = lane + 64 * h;
     j[h] = c < kin ? a.idx_in[(size_t)q * kin + c] : -1;
-    v[h] = c < kin ? ldd<COH>(p5 + p5_at(0, m, q, 0, kin, c)) : __builtin_nan("");
-    const double d0 = (check && c < kin) ? ldd<COH>(p5 + p5_at(0, m, q, 1, kin, c)) : __builtin_nan("");
+    v[h] = c < kin ? p5[p5_at(0, m, q, 0, kin, c)] : __builtin_nan("");
+    const double d0 = (check && c < kin) ? p5[p5_at(0, m, q, 1, kin, c)] : __builtin_nan("");
     for (int cc = 0; cc < 4; cc++) {
-      const double d = (d0 == d0) ? ldd<COH>(p5 + p5_at(0, m, q, 1 + cc, kin, c)) : __builtin_nan("");
+      const double d = (d0 == d0) ? p5[p5_at(0, m, q, 1 + cc, kin, c)] : __builtin_nan("");
       z[h][cc] = (d0 == d0) ? chan_z(S, cc, d) : __builtin_nan("");
     }
   }
@@ -466,6 +435,7 @@ __device__ void sort_wave_body(const SortArgs& a, int q, int lane) {
   }
   if (a.order_flags && lane == 0) a.order_flags[q] = flag;
 }
+__global__ __launch_bounds__(64) void rerank_sort_wave_kernel(SortArgs a) { sort_wave_body(a, blockIdx.x, threadIdx.x); }
 // cand_idx [m][kin] + the evaluations of G shards, p5_all [G][m][5][kin] (NaN scores where the candidate is not the shard's) -> the k best.
 // Every candidate has exactly one owner; a masked pair is +Inf at its owner.
 __global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __restrict__ cand_idx, const double* __restrict__ p5_all,
@@ -786,13 +756,15 @@ __global__ __launch_bounds__(256) void resolve_kernel(ExactArgs A, RescoreArgs R
     *A.tick = 0u;                                               // ready for the next launch
     if (A.dflags) { A.dflags[2] = 1; if (total - A.offset > RESOLVE_SLOTS) A.dflags[3] = 1; }
   }
-  const volatile double* part = A.partial;                      // written by other workgroups: no cached copies
+  auto part_at = [&](size_t i) {                                 // written by other workgroups: agent-scope loads (L2), no copy of this CU's L1
+    return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(A.partial + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  };
   for (int s = 0; s < ns; s++) {
     const int q = s_list[s];
     if (tid < 12) {
       const int c = tid / 3, e = tid % 3;
       double sum = 0.0;
-      for (int bb = 0; bb < A.NB; bb++) sum += part[(((size_t)s * A.NB + bb) * 4 + c) * 3 + e];   // workgroup order: deterministic
+      for (int bb = 0; bb < A.NB; bb++) sum += part_at((((size_t)s * A.NB + bb) * 4 + c) * 3 + e);   // workgroup order: deterministic
       red[tid] = sum;
     }
     __syncthreads();
@@ -864,8 +836,7 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
     hipLaunchKernelGGL(nan_fixup_kernel, dim3((n + 255) / 256, m < 64 ? m : 64), dim3(256), 0, st, d_p, d_i, m, n, qbad, dbad);
 }
 
-// few queries: one workgroup per (pair, channel) - and, sort given, the selection behind it in the same launch; otherwise per pair (the
-// batch's time is its workgroup count)
+// few queries: one workgroup per (pair, channel); otherwise per pair (the batch's time is its workgroup count)
 static bool rerank_split(int m) { return m <= 64; }
 static void launch_rerank_kernel(hipStream_t st, const RerankArgs& A, const int32_t* idx_in, unsigned* tick) {
   const unsigned nch = (A.q_sc ? 2u : 0u) + (A.q_m2 ? 2u : 0u);
@@ -881,9 +852,9 @@ void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_d
   SortArgs S{idx_in, p5, m, kin, k, idx, score, score32, order_flags ? 1 : 0, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr, G, p_weight,
              order_floor, order_noise, order_flags};
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
-               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, S, tick + (size_t)m * kin, p5};
+               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
   launch_rerank_kernel(st, A, idx_in, tick);
-  if (rerank_split(m) && kin <= 128) return;      // (the selection + order check ran inside: the query's last pair)
+  if (m <= 64) { hipLaunchKernelGGL(rerank_sort_wave_kernel, dim3(m), dim3(64), 0, st, S); return; }
   hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, p5, m, kin, k, idx, score, score32);
   if (order_flags)
     hipLaunchKernelGGL(order_check_kernel, dim3(m), dim3(64), 0, st, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr, G, idx_in, p5, 1, m, kin, k,
@@ -894,10 +865,8 @@ void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, 
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
                            double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, const double* cand_sc32, int k, double eps_d) {
   if (m <= 0) return;
-  // (the sharded form: no selection behind it - the blocks of all shards are gathered first; sort.k = 0 keeps the SPLIT kernel from running one)
-  SortArgs S{};
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
-               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, S, nullptr, p5};
+               eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
   launch_rerank_kernel(st, A, idx_in, tick);
 }
 
