@@ -167,6 +167,7 @@ __device__ __forceinline__ void block_argmin(double* rv, int* rj, int tid) {
 }
 
 constexpr int FS_CAP = 4096;   // survivors of the threshold pass kept in LDS (a power of two: the fallback of list_topk sorts it whole)
+constexpr int FS_CAP_SMALL = 1024;
 constexpr int NONE_J = 0x7fffffff;   // index of a padding entry (value +Inf): sorts behind every real candidate
 
 __device__ __forceinline__ unsigned long long order_key(double x) {   // order-preserving map double -> u64 (no NaN in the lists)
@@ -267,12 +268,16 @@ __device__ bool list_topk(const V* lv, const int* lj, int L, int k, double* rv, 
 // Rows that overflow the list (masses of equal scores, e.g. +Inf of the mask) fall back to one sweep per selected element.
 // (Measured at 4096 x 100k, k = 9: 0.65 ms against 0.59 ms for k = 1; keeping the 3 best per thread in one sweep instead cost
 // 2.5 ms - in a 64-lane wave some lane inserts at nearly every element - and a threshold from a full first sweep 1.13 ms.)
-struct SelLds {      // the workgroup's LDS (53 KB: ~3 workgroups per CU)
+// CAP = capacity of the survivors' list: FS_CAP (53 KB of LDS: ~3 workgroups per CU) wherever a slice has to fit it whole or k is large;
+// FS_CAP_SMALL for whole rows with up to 16 results (~390 survivors expected: 17 KB, ~9 workgroups per CU - the sweep is a latency chain
+// per thread, so resident waves are its bandwidth)
+template <int CAP>
+struct SelLds {
   double st[8];
   double rv[256];
   int rj[256];
-  double lv[FS_CAP];
-  int lj[FS_CAP];
+  double lv[CAP];
+  int lj[CAP];
   int lcnt;
   unsigned hist[256];
   int ctl[4];
@@ -280,13 +285,14 @@ struct SelLds {      // the workgroup's LDS (53 KB: ~3 workgroups per CU)
   int last;
 };
 
+template <int CAP>
 __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const float* __restrict__ d_i,
                                            const float* __restrict__ e_p, const float* __restrict__ e_i,
                                            const double* __restrict__ mom2_all,
                                            int m, int n, const double* __restrict__ mom_all, int G,
                                            int q_row0, int db_row0, int mask_width, double p_weight,
                                            int k, int32_t* __restrict__ idx, float* __restrict__ score, int P,
-                                           double* __restrict__ score64, SelLds& W) {
+                                           double* __restrict__ score64, SelLds<CAP>& W) {
   double* st = W.st;
   double* rv = W.rv;
   int* rj = W.rj;
@@ -402,7 +408,7 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
   }
   // ---- (a) threshold from a sample
   double tau = __builtin_inf();
-  if (k <= 249 && n > FS_CAP) {                    // (a row or slice that fits the list needs no threshold)
+  if (k <= 249 && n > CAP) {                    // (a row or slice that fits the list needs no threshold)
     double mv = 0.0;
     int mj = -1;
     // sample size: ~r n / ns elements pass the threshold - 4096 columns for the k + 8 <= 16 of the fp32-grade arithmetics (~24 r), more for
@@ -439,7 +445,7 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
     tau = W.tau_s;
   }
   // ---- (b) everything at or below tau
-  const bool whole = n <= FS_CAP && !(tau < __builtin_inf());   // a row or slice that fits: element j IS list entry j (NaN: padding)
+  const bool whole = n <= CAP && !(tau < __builtin_inf());   // a row or slice that fits: element j IS list entry j (NaN: padding)
   if (whole)
     sweep([&](int j, double f) {
       const bool ok = f == f;
@@ -450,12 +456,12 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
     sweep([&](int j, double f) {
       if (f <= tau) {
         const int slot = atomicAdd(&lcnt, 1);
-        if (slot < FS_CAP) { lv[slot] = f; lj[slot] = db_row0 + j; }
+        if (slot < CAP) { lv[slot] = f; lj[slot] = db_row0 + j; }
       }
     });
   __syncthreads();
   const int L = whole ? n : lcnt;
-  if (L <= FS_CAP && (k > 12 || whole)) {
+  if (L <= CAP && (k > 12 || whole)) {
     // many results (or a whole slice in the list): the k best by radix selection + a 256-entry sort ...
     if (k <= 249 && list_topk(lv, lj, L, k, rv, rj, hist, ctl, tid)) {
       for (int t = tid; t < k; t += 256) emit(t, rv[t], rj[t] == NONE_J ? -1 : rj[t]);
@@ -480,7 +486,7 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
     for (int t = tid; t < k; t += 256) emit(t, lv[t < L ? t : 0], (t < L && lj[t] != NONE_J) ? lj[t] : -1);
     return;
   }
-  if (L <= FS_CAP) {
+  if (L <= CAP) {
     for (int t = 0; t < k; t++) {
       double cv = 0.0;
       int cj = -1, cs = -1;
@@ -587,6 +593,7 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restr
 //  inside the launch in front of them, self-resetting tickets: an online call of one query gained nothing, 8 - 32 queries lost 10 - 15 % -
 //  the fence, the ticket and the agent-scope re-reads cost what a launch costs, and the finishing workgroup starts later than a fresh
 //  kernel would.  tools/experiments/README.md.)
+template <int CAP>
 __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i,
                                                            const float* __restrict__ e_p, const float* __restrict__ e_i,
                                                            const double* __restrict__ mom2_all,
@@ -594,8 +601,8 @@ __global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restric
                                                            int q_row0, int db_row0, int mask_width, double p_weight,
                                                            int k, int32_t* __restrict__ idx, float* __restrict__ score, int P,
                                                            double* __restrict__ score64) {
-  __shared__ SelLds L;
-  select_row(d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, P, score64, L);
+  __shared__ SelLds<CAP> L;
+  select_row<CAP>(d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0, mask_width, p_weight, k, idx, score, P, score64, L);
 }
 
 }  // namespace
@@ -639,7 +646,7 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
     float* ssc = reinterpret_cast<float*>(sidx + (size_t)64 * 16 * 128);
     int N = 2;
     while (N < P * k) N <<= 1;
-    hipLaunchKernelGGL(fuse_select_kernel, dim3(m, P), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
+    hipLaunchKernelGGL(fuse_select_kernel<FS_CAP>, dim3(m, P), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
                        mask_width, p_weight, k, sidx, ssc, P, nullptr);
     // (up to 8192 entries = 64 KB of dynamic LDS next to ~4 KB of static arrays: above the 64 KB a launch gets without asking)
     if ((size_t)N * 8 > 40 * 1024)
@@ -647,8 +654,14 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
     hipLaunchKernelGGL(slice_merge_kernel, dim3(m), dim3(256), (size_t)N * 8, st, sidx, ssc, P, m, k, idx, score, score64);
     return;
   }
-  hipLaunchKernelGGL(fuse_select_kernel, dim3(m), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
-                     mask_width, p_weight, k, idx, score, 1, score64);
+  // whole rows, few results, long rows: the small list (an overflow - masses of equal scores - falls back to one sweep per result, as ever)
+  static const bool small_ok = !(getenv("PR_SELECT_CAP") && atoi(getenv("PR_SELECT_CAP")) == FS_CAP);
+  if (small_ok && k <= 16 && n > 4 * FS_CAP && n <= 131072)      // (~16 n / 4096 survivors expected: under half the small list up to 131k columns)
+    hipLaunchKernelGGL(fuse_select_kernel<FS_CAP_SMALL>, dim3(m), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
+                       mask_width, p_weight, k, idx, score, 1, score64);
+  else
+    hipLaunchKernelGGL(fuse_select_kernel<FS_CAP>, dim3(m), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
+                       mask_width, p_weight, k, idx, score, 1, score64);
 }
 
 }  // namespace pr

@@ -16,17 +16,28 @@
 namespace pr {
 namespace {
 
-// zero-norm signatures (processSC.m:16,19: MATLAB divides by zero, the row / column of distances is NaN): thread = DB column, walking the
-// query rows of its grid row; one launch for both kinds of flag
+// zero-norm signatures (processSC.m:16,19: MATLAB divides by zero, the row / column of distances is NaN).  One launch: workgroups [0, m)
+// look at one QUERY each and leave at once unless it is flagged (then the workgroup writes the NaN row), the workgroups behind them look at
+// 256 DB columns each and walk the rows only for a flagged column - m + n / 256 workgroups that read one flag each (the first version gave
+// every column thread the whole list of query flags to read: 0.16 ms per 4096 x 100k step for nothing)
 __global__ __launch_bounds__(256) void nan_fixup_kernel(float* __restrict__ d_p, float* __restrict__ d_i, int m, int n,
                                                          const int* __restrict__ qbad, const int* __restrict__ dbad) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  const int bc = dbad ? (dbad[2 * j] | dbad[2 * j + 1]) : 0;          // [row][channel] entries, see sc_pack.hip
   const float nanv = __builtin_nanf("");
-  for (int q = blockIdx.y; q < m; q += gridDim.y) {
-    const int b = bc | (qbad ? (qbad[2 * q] | qbad[2 * q + 1]) : 0);
-    if (!b) continue;
+  if ((int)blockIdx.x < m) {
+    const int q = blockIdx.x;
+    const int b = qbad ? (qbad[2 * q] | qbad[2 * q + 1]) : 0;          // [row][channel] entries, see sc_pack.hip
+    if (!b) return;
+    for (int j = threadIdx.x; j < n; j += 256) {
+      if (b & 1) d_p[(size_t)q * n + j] = nanv;
+      if ((b & 2) && d_i) d_i[(size_t)q * n + j] = nanv;
+    }
+    return;
+  }
+  const int j = (blockIdx.x - m) * 256 + threadIdx.x;
+  if (j >= n || !dbad) return;
+  const int b = dbad[2 * j] | dbad[2 * j + 1];
+  if (!b) return;
+  for (int q = 0; q < m; q++) {
     if (b & 1) d_p[(size_t)q * n + j] = nanv;
     if ((b & 2) && d_i) d_i[(size_t)q * n + j] = nanv;
   }
@@ -833,7 +844,7 @@ __global__ __launch_bounds__(64) void merge_topk_kernel(const int32_t* __restric
 void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, const int* qbad, const int* dbad) {
   if (m <= 0 || n <= 0) return;
   if (qbad || dbad)
-    hipLaunchKernelGGL(nan_fixup_kernel, dim3((n + 255) / 256, m < 64 ? m : 64), dim3(256), 0, st, d_p, d_i, m, n, qbad, dbad);
+    hipLaunchKernelGGL(nan_fixup_kernel, dim3(m + (n + 255) / 256), dim3(256), 0, st, d_p, d_i, m, n, qbad, dbad);
 }
 
 // few queries: one workgroup per (pair, channel); otherwise per pair (the batch's time is its workgroup count)
