@@ -167,7 +167,6 @@ __device__ __forceinline__ void block_argmin(double* rv, int* rj, int tid) {
 }
 
 constexpr int FS_CAP = 4096;   // survivors of the threshold pass kept in LDS (a power of two: the fallback of list_topk sorts it whole)
-constexpr int FS_CAP_SMALL = 1024;
 constexpr int NONE_J = 0x7fffffff;   // index of a padding entry (value +Inf): sorts behind every real candidate
 
 __device__ __forceinline__ unsigned long long order_key(double x) {   // order-preserving map double -> u64 (no NaN in the lists)
@@ -268,9 +267,7 @@ __device__ bool list_topk(const V* lv, const int* lj, int L, int k, double* rv, 
 // Rows that overflow the list (masses of equal scores, e.g. +Inf of the mask) fall back to one sweep per selected element.
 // (Measured at 4096 x 100k, k = 9: 0.65 ms against 0.59 ms for k = 1; keeping the 3 best per thread in one sweep instead cost
 // 2.5 ms - in a 64-lane wave some lane inserts at nearly every element - and a threshold from a full first sweep 1.13 ms.)
-// CAP = capacity of the survivors' list: FS_CAP (53 KB of LDS: ~3 workgroups per CU) wherever a slice has to fit it whole or k is large;
-// FS_CAP_SMALL for whole rows with up to 16 results (~390 survivors expected: 17 KB, ~9 workgroups per CU - the sweep is a latency chain
-// per thread, so resident waves are its bandwidth)
+// CAP = capacity of the survivors' list (FS_CAP: 53 KB of LDS, ~3 workgroups per CU)
 template <int CAP>
 struct SelLds {
   double st[8];
@@ -654,14 +651,10 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
     hipLaunchKernelGGL(slice_merge_kernel, dim3(m), dim3(256), (size_t)N * 8, st, sidx, ssc, P, m, k, idx, score, score64);
     return;
   }
-  // whole rows, few results, long rows: the small list (an overflow - masses of equal scores - falls back to one sweep per result, as ever)
-  static const bool small_ok = !(getenv("PR_SELECT_CAP") && atoi(getenv("PR_SELECT_CAP")) == FS_CAP);
-  if (small_ok && k <= 16 && n > 4 * FS_CAP && n <= 131072)      // (~16 n / 4096 survivors expected: under half the small list up to 131k columns)
-    hipLaunchKernelGGL(fuse_select_kernel<FS_CAP_SMALL>, dim3(m), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
-                       mask_width, p_weight, k, idx, score, 1, score64);
-  else
-    hipLaunchKernelGGL(fuse_select_kernel<FS_CAP>, dim3(m), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
-                       mask_width, p_weight, k, idx, score, 1, score64);
+  // (a 1024-entry list - 17 KB of LDS, 9 workgroups per CU instead of 3 - for whole rows with few results measured the same 0.87 ms per
+  //  4096 x 100k: the sweep is bound by its ~30 fp64 instructions per element, not by resident waves)
+  hipLaunchKernelGGL(fuse_select_kernel<FS_CAP>, dim3(m), dim3(256), 0, st, d_p, d_i, e_p, e_i, mom2_all, m, n, mom_all, G, q_row0, db_row0,
+                     mask_width, p_weight, k, idx, score, 1, score64);
 }
 
 }  // namespace pr

@@ -321,18 +321,26 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
   const int col = tid & 127, hv = tid >> 7;          // A^T u: column col, rows 32 hv .. 32 hv + 31
   const int row = tid & 63, qv = tid >> 6;           // A v:   row row, columns 32 qv .. 32 qv + 31
   for (int it = 0; it < 400; it++) {   // polish on the original matrix: u <- A (A^T u)
-    {
-      double s = 0.0;
-      for (int i = 32 * hv; i < 32 * hv + 32; i++) s += A[i * 129 + col] * u[i];
-      red[tid] = s;
+    {                                   // (four independent partial sums: the chain of 32 dependent LDS read -> multiply-adds was the iteration's time)
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      const double* ac = A + (32 * hv) * 129 + col;
+      const double* uc = u + 32 * hv;
+#pragma unroll
+      for (int i = 0; i < 32; i += 4) {
+        s0 += ac[i * 129] * uc[i]; s1 += ac[(i + 1) * 129] * uc[i + 1]; s2 += ac[(i + 2) * 129] * uc[i + 2]; s3 += ac[(i + 3) * 129] * uc[i + 3];
+      }
+      red[tid] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     if (tid < 128) v[tid] = red[tid] + red[tid + 128];
     __syncthreads();
     {
-      double s = 0.0;
-      for (int k = 32 * qv; k < 32 * qv + 32; k++) s += A[row * 129 + k] * v[k];
-      red[tid] = s;
+      double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+      const double* ar = A + row * 129 + 32 * qv;
+      const double* vc = v + 32 * qv;
+#pragma unroll
+      for (int k = 0; k < 32; k += 4) { s0 += ar[k] * vc[k]; s1 += ar[k + 1] * vc[k + 1]; s2 += ar[k + 2] * vc[k + 2]; s3 += ar[k + 3] * vc[k + 3]; }
+      red[tid] = (s0 + s1) + (s2 + s3);
     }
     __syncthreads();
     double un = 0.0;
