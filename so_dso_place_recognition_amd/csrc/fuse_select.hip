@@ -341,6 +341,10 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
   // zero, denormal or not finite keep the plain division (uniform per workgroup).
   const bool fastdiv = !plain && sp > 1e-290 && sp < 1e290 && si > 1e-290 && si < 1e290;
   const double rsp = 1.0 / sp, rsi = 1.0 / si;
+  // (the second channel pair of the fused form the same way: two software fp64 divisions per element were most of its sweep)
+  const bool fastdiv2 = two && st[5] > 1e-290 && st[5] < 1e290 && st[7] > 1e-290 && st[7] < 1e290;
+  const double m2p = two ? st[4] : 0.0, s2p = two ? st[5] : 1.0, m2i = two ? st[6] : 0.0, s2i = two ? st[7] : 1.0;
+  const double rs2p = 1.0 / s2p, rs2i = 1.0 / s2i;
   int head = (int)((4 - ((reinterpret_cast<size_t>(rp) >> 2) & 3)) & 3);
   if (head > n) head = n;
   // rows not co-aligned mod 16 B (d_p and d_i carved out of one allocation with m*n % 4 != 0): no vector body, the scalar
@@ -357,7 +361,10 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
     if (plain) f = (double)vp;
     else if (fastdiv) f = p_weight * div_rn((double)vp - mp, sp, rsp) + div_rn((double)vi - mi, si, rsi);        // run_test.m:40
     else f = p_weight * (((double)vp - mp) / sp) + ((double)vi - mi) / si;
-    if (two) f += p_weight * (((double)e_p[(size_t)q * n + j] - st[4]) / st[5]) + ((double)e_i[(size_t)q * n + j] - st[6]) / st[7];
+    if (two) {
+      const double xp = (double)e_p[(size_t)q * n + j] - m2p, xi = (double)e_i[(size_t)q * n + j] - m2i;
+      f += fastdiv2 ? p_weight * div_rn(xp, s2p, rs2p) + div_rn(xi, s2i, rs2i) : p_weight * (xp / s2p) + xi / s2i;
+    }
     int dij = ig - jg;
     if (dij < 0) dij = -dij;
     if (dij < mask_width) f = __builtin_inf();                                      // run_test.m:47-53

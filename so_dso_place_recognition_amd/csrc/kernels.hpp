@@ -76,13 +76,14 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
 // SC intensity, M2DP count, M2DP intensity; NaN in the first = not evaluated) - what a shard knows after its re-evaluation (rerank.hip)
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                   double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick /* [m][kin] zeros (left zero) */, int k, int32_t* idx, double* score,
+                   double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick /* [cap] zeros (left zero) | [cap] work list | [1] */, size_t tick_cap /* >= m kin */, int k, int32_t* idx, double* score,
                    float* score32, const double* cand_sc32, double eps_d = 0.0, double order_floor = 0.0,
                    double order_noise = 0.0, int32_t* order_flags = nullptr);   // order_flags [m]: the order check of launch_order_check on the result; cand_sc32: the candidates' all-pairs-pass scores (ascending) or null: prunes hopeless candidates; eps_d: that pass's distance error bound (0: the fp32-grade 1e-6 with a 64x margin)
 // the sharded form: scores + distances of the candidates THIS shard owns (NaN elsewhere), then owner-wise combination + selection
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                           double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, const double* cand_sc32, int k, double eps_d = 0.0);
+                           double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, size_t tick_cap, const double* cand_sc32, int k,
+                           double eps_d = 0.0);
 // PR_SC_ARITH_F16: flags[q] = 1 where the candidate list does not provably contain the exact top-k (rerank.hip), count += number of flags
 void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,
                          const double* cand_sc, int k, const double* score, double eps_d, int32_t* flags, int32_t* count,

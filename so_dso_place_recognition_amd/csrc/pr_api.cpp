@@ -700,12 +700,12 @@ static int rerank_scratch(pr_ctx* ctx, size_t need, int32_t m) {
   }
   return PR_OK;
 }
-// the per-pair tickets of rerank_kernel ([pairs] zeros; the kernel leaves them zero)
+// the per-pair tickets of rerank_kernel ([pairs] zeros; the kernel leaves them zero), the work list of a batch ([pairs]) and its length
 static int rerank_ticks(pr_ctx* ctx, size_t pairs) {
   if (pairs > ctx->tick_cap) {
     if (ctx->rr_tick) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->rr_tick)); ctx->rr_tick = nullptr; ctx->tick_cap = 0; }
-    PR_HIP(ctx, hipMalloc((void**)&ctx->rr_tick, pairs * sizeof(unsigned)));
-    PR_HIP(ctx, hipMemsetAsync(ctx->rr_tick, 0, pairs * sizeof(unsigned), ctx->stream));
+    PR_HIP(ctx, hipMalloc((void**)&ctx->rr_tick, (2 * pairs + 1) * sizeof(unsigned)));
+    PR_HIP(ctx, hipMemsetAsync(ctx->rr_tick, 0, (2 * pairs + 1) * sizeof(unsigned), ctx->stream));
     ctx->tick_cap = pairs;
   }
   return PR_OK;
@@ -755,7 +755,7 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
   double fl, noise;
   order_consts(ctx, fl, noise);
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
-                    p_weight, k_in, idx_in, ctx->rr_scratch, ctx->rr_tick, k, idx, score, nullptr, score_in, pass_eps(ctx), fl, noise, ctx->d_order);
+                    p_weight, k_in, idx_in, ctx->rr_scratch, ctx->rr_tick, ctx->tick_cap, k, idx, score, nullptr, score_in, pass_eps(ctx), fl, noise, ctx->d_order);
   ctx->order_m = m;
   ctx->order_kin = k_in;
   PR_HIP(ctx, hipGetLastError());
@@ -833,7 +833,7 @@ int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int 
   if (int rc = set_device(ctx)) return rc;
   if (int rc = rerank_ticks(ctx, (size_t)m * k_in)) return rc;
   pr::launch_rerank_partial(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0,
-                            mask_width, p_weight, k_in, cand_idx, p5, ctx->rr_tick, cand_score, k, pass_eps(ctx));
+                            mask_width, p_weight, k_in, cand_idx, p5, ctx->rr_tick, ctx->tick_cap, cand_score, k, pass_eps(ctx));
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }

@@ -210,31 +210,18 @@ __device__ void chan_combine(const double* mom_all, int G, int m, int q, int ch,
   if (count) *count = cn;
 }
 
-// One workgroup per (query, candidate) - or, SPLIT (calls of few queries: an online call waits for ONE channel's chain of reductions instead
-// of two or four in a row), per (query, candidate, CHANNEL): the exact distance(s) into the pair's p5 slots.  SPLIT: the last of the pair's
-// workgroups to finish (a self-resetting ticket per pair) forms the fused score from the stored distances; either way the score is the sum
-// of the channel terms in channel order (run_test.m:40), bit for bit the same.
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t* __restrict__ idx_in, unsigned* __restrict__ tick) {
-  __shared__ double buf[60 * 21 + 1200];
-  __shared__ double red[256];
-  __shared__ int s_last;
-  const int nch = SPLIT ? (A.q_sc ? 2 : 0) + (A.q_m2 ? 2 : 0) : 1;
-  const int tid = threadIdx.x, pair = blockIdx.x / nch, cl = blockIdx.x % nch, q = pair / A.kin, t = pair % A.kin;
+// Is candidate t of query q evaluated by this shard?  false: *skipv is the score it keeps (NaN: no such candidate / another shard's row,
+// +Inf: masked, its pass score: pruned).
+__device__ __forceinline__ bool pair_is_evaluated(const RerankArgs& A, const int32_t* idx_in, int q, int t, int* jl_out, double* skipv) {
   const int jg = idx_in[(size_t)q * A.kin + t];
-  double* out = A.p5 + p5_at(0, A.m, q, 0, A.kin, t);
-  double* dout = A.p5 + p5_at(0, A.m, q, 1, A.kin, t);         // + c * kin: channel c
-  // not evaluated: the first distance slot is NaN, the score says why (the pair's first workgroup writes, the others just leave)
-  bool skipped = false;
-  double skipv = 0.0;
-  auto skip = [&](double v) { skipped = true; skipv = v; };
-  if (jg < 0) skip(__builtin_nan(""));
+  if (jg < 0) { *skipv = __builtin_nan(""); return false; }
   int dij = (A.q_row0 + q) - jg;
   if (dij < 0) dij = -dij;
-  if (!skipped && dij < A.mask_width) skip(__builtin_inf());   // run_test.m:47-53
+  if (dij < A.mask_width) { *skipv = __builtin_inf(); return false; }   // run_test.m:47-53
   const int jl = jg - A.db_row0;
-  if (!skipped && (jl < 0 || jl >= A.n_local)) skip(__builtin_nan(""));   // another shard's row: its owner evaluates it
-  if (!skipped && A.cand_sc && t >= A.k) {
+  *jl_out = jl;
+  if (jl < 0 || jl >= A.n_local) { *skipv = __builtin_nan(""); return false; }   // another shard's row: its owner evaluates it
+  if (A.cand_sc && t >= A.k) {
     // Candidates beyond the k-th of the fp32 pass whose fp32 score is above the k-th by more than 64 x the error bound of an fp32
     // score cannot enter the exact top-k: they keep their fp32 score (it only has to sort behind the evaluated ones).  Bound of
     // |fp32 score - exact score| given the row statistics: distance error 1e-6 per channel over its sigma,
@@ -243,53 +230,98 @@ __global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t
     double cn = 2.0;
     const double w = row_weight(A.q_sc ? A.mom_sc : nullptr, A.q_m2 ? A.mom_m2 : nullptr, A.G, A.m, q, A.p_weight, &cn);
     const double delta = A.eps_mult * score_err_bound(A.eps_d, w, sk, cn);
-    if (st > sk + delta) skip(st);                              // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
+    if (st > sk + delta) { *skipv = st; return false; }         // (NaN / Inf statistics or scores: the comparison is false, the pair is evaluated)
   }
-  if (skipped) {
-    if (cl == 0 && tid == 0) { *out = skipv; dout[0] = __builtin_nan(""); }
-    return;
+  return true;
+}
+
+// Batches: one WAVE per query decides for all of its candidates (lane = candidate), writes the scores of those that are not evaluated and
+// appends the others to a work list - most candidates of a query with a clear winner are pruned, and a workgroup of 256 threads that only
+// finds that out costs what ~10 us of dependent loads cost (8 of 9 workgroups of the metric workload, 56 of 57 in PR_SC_ARITH_F16).
+__global__ __launch_bounds__(64) void rerank_plan_kernel(RerankArgs A, const int32_t* __restrict__ idx_in, int32_t* __restrict__ work,
+                                                          unsigned* __restrict__ count) {
+  const int q = blockIdx.x, lane = threadIdx.x;
+  for (int t = lane; t < A.kin; t += 64) {
+    int jl = 0;
+    double skipv = 0.0;
+    if (pair_is_evaluated(A, idx_in, q, t, &jl, &skipv)) work[atomicAdd(count, 1u)] = q * A.kin + t;
+    else { A.p5[p5_at(0, A.m, q, 0, A.kin, t)] = skipv; A.p5[p5_at(0, A.m, q, 1, A.kin, t)] = __builtin_nan(""); }
   }
-  auto one = [&](int c) -> double {                              // channel 0, 1: SC structure / intensity; 2, 3: M2DP count / intensity
-    if (c < 2) return sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + c * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + c * 1200, buf, red, tid);
-    return m2dp_pair_exact(A.q_m2, A.m2_dt, (size_t)q * 4 * 384, A.db_m2, A.m2_dt, (size_t)jl * 4 * 384, c - 2, red, tid);
-  };
-  auto term = [&](int c, double d) -> double {
-    double mean, sd;
-    chan_combine(c < 2 ? A.mom_sc : A.mom_m2, A.G, A.m, q, c & 1, mean, sd);
-    return ((c & 1) ? 1.0 : A.p_weight) * ((d - mean) / sd);
-  };
-  if constexpr (!SPLIT) {
-    double f = 0.0, d4[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int c = 0; c < 4; c++) {
-      if (c < 2 ? !A.q_sc : !A.q_m2) continue;
-      d4[c] = one(c);
-      f += term(c, d4[c]);
-    }
-    if (tid == 0) *out = f;
-    if (tid < 4) dout[(size_t)tid * A.kin] = d4[tid];            // (every thread holds the reduced values)
-    return;
-  } else {
-    const int c = A.q_sc ? cl : 2 + cl;
-    const double d = one(c);
-    if (tid == 0) {
-      dout[(size_t)c * A.kin] = d;
-      if (cl == 0) for (int a = 0; a < 4; a++) if (a < 2 ? !A.q_sc : !A.q_m2) dout[(size_t)a * A.kin] = 0.0;   // absent descriptor type
-      __threadfence();
-      const unsigned old = atomicAdd(&tick[pair], 1u);
-      s_last = (old == (unsigned)nch - 1u);
-      if (s_last) tick[pair] = 0u;                              // ready for the next launch
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();
-    if (tid == 0) {
-      double f = 0.0;                                           // (the other channels' distances: agent-scope loads, out of L2)
-      for (int a = 0; a < 4; a++) {
-        if (a < 2 ? !A.q_sc : !A.q_m2) continue;
-        f += term(a, __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(dout + (size_t)a * A.kin), __ATOMIC_RELAXED,
-                                                             __HIP_MEMORY_SCOPE_AGENT)));
+}
+
+// The exact distance(s) of a pair into its p5 slots, and its fused score = the sum of the channel terms in channel order (run_test.m:40).
+//   MODE 0  one workgroup per (query, candidate), decision included (few queries per call would not fill the chip otherwise - unused now)
+//   MODE 1  SPLIT, calls of few queries: one workgroup per (query, candidate, CHANNEL) - an online call waits for ONE channel's chain of
+//           reductions instead of two or four in a row; the last of the pair's workgroups to finish (a self-resetting ticket per pair)
+//           forms the score from the stored distances: bit for bit the same sum
+//   MODE 2  batches: a fixed grid walks the work list of rerank_plan_kernel
+template <int MODE>
+__global__ __launch_bounds__(256) void rerank_kernel(RerankArgs A, const int32_t* __restrict__ idx_in, unsigned* __restrict__ tick,
+                                                      const int32_t* __restrict__ work, const unsigned* __restrict__ count) {
+  __shared__ double buf[60 * 21 + 1200];
+  __shared__ double red[256];
+  __shared__ int s_last;
+  constexpr bool SPLIT = MODE == 1;
+  const int tid = threadIdx.x;
+  const int nch = SPLIT ? (A.q_sc ? 2 : 0) + (A.q_m2 ? 2 : 0) : 1;
+  const unsigned total = MODE == 2 ? *count : 1u;
+  for (unsigned w = MODE == 2 ? blockIdx.x : 0u; w < total; w += gridDim.x) {
+    const int pair = MODE == 2 ? work[w] : (int)(blockIdx.x / nch), cl = MODE == 2 ? 0 : (int)(blockIdx.x % nch);
+    const int q = pair / A.kin, t = pair % A.kin;
+    double* out = A.p5 + p5_at(0, A.m, q, 0, A.kin, t);
+    double* dout = A.p5 + p5_at(0, A.m, q, 1, A.kin, t);       // + c * kin: channel c
+    int jl;
+    if constexpr (MODE == 2) jl = idx_in[(size_t)q * A.kin + t] - A.db_row0;
+    else {
+      // not evaluated: the first distance slot is NaN, the score says why (the pair's first workgroup writes, the others just leave)
+      double skipv = 0.0;
+      if (!pair_is_evaluated(A, idx_in, q, t, &jl, &skipv)) {
+        if (cl == 0 && tid == 0) { *out = skipv; dout[0] = __builtin_nan(""); }
+        return;
       }
-      *out = f;
+    }
+    auto one = [&](int c) -> double {                            // channel 0, 1: SC structure / intensity; 2, 3: M2DP count / intensity
+      if (c < 2) return sc_pair_exact(A.q_sc, A.sc_dt, (size_t)q * 2400 + c * 1200, A.db_sc, A.sc_dt, (size_t)jl * 2400 + c * 1200, buf, red, tid);
+      return m2dp_pair_exact(A.q_m2, A.m2_dt, (size_t)q * 4 * 384, A.db_m2, A.m2_dt, (size_t)jl * 4 * 384, c - 2, red, tid);
+    };
+    auto term = [&](int c, double d) -> double {
+      double mean, sd;
+      chan_combine(c < 2 ? A.mom_sc : A.mom_m2, A.G, A.m, q, c & 1, mean, sd);
+      return ((c & 1) ? 1.0 : A.p_weight) * ((d - mean) / sd);
+    };
+    if constexpr (!SPLIT) {
+      double f = 0.0, d4[4] = {0.0, 0.0, 0.0, 0.0};
+      for (int c = 0; c < 4; c++) {
+        if (c < 2 ? !A.q_sc : !A.q_m2) continue;
+        d4[c] = one(c);
+        f += term(c, d4[c]);
+      }
+      if (tid == 0) *out = f;
+      if (tid < 4) dout[(size_t)tid * A.kin] = d4[tid];          // (every thread holds the reduced values)
+      __syncthreads();                                           // (MODE 2: buf / red serve the next pair)
+    } else {
+      const int c = A.q_sc ? cl : 2 + cl;
+      const double d = one(c);
+      if (tid == 0) {
+        dout[(size_t)c * A.kin] = d;
+        if (cl == 0) for (int a = 0; a < 4; a++) if (a < 2 ? !A.q_sc : !A.q_m2) dout[(size_t)a * A.kin] = 0.0;   // absent descriptor type
+        __threadfence();
+        const unsigned old = atomicAdd(&tick[pair], 1u);
+        s_last = (old == (unsigned)nch - 1u);
+        if (s_last) tick[pair] = 0u;                            // ready for the next launch
+      }
+      __syncthreads();
+      if (!s_last) return;
+      __threadfence();
+      if (tid == 0) {
+        double f = 0.0;                                         // (the other channels' distances: agent-scope loads, out of L2)
+        for (int a = 0; a < 4; a++) {
+          if (a < 2 ? !A.q_sc : !A.q_m2) continue;
+          f += term(a, __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(dout + (size_t)a * A.kin), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_AGENT)));
+        }
+        *out = f;
+      }
     }
   }
 }
@@ -847,24 +879,34 @@ void launch_nan_fixup(hipStream_t st, float* d_p, float* d_i, int m, int n, cons
     hipLaunchKernelGGL(nan_fixup_kernel, dim3(m + (n + 255) / 256), dim3(256), 0, st, d_p, d_i, m, n, qbad, dbad);
 }
 
-// few queries: one workgroup per (pair, channel); otherwise per pair (the batch's time is its workgroup count)
+// few queries: one workgroup per (pair, channel); batches: a plan (one wave per query) + a fixed grid over the pairs that ARE evaluated
 static bool rerank_split(int m) { return m <= 64; }
-static void launch_rerank_kernel(hipStream_t st, const RerankArgs& A, const int32_t* idx_in, unsigned* tick) {
+static void launch_rerank_kernel(hipStream_t st, const RerankArgs& A, const int32_t* idx_in, unsigned* tick, size_t tick_cap) {
   const unsigned nch = (A.q_sc ? 2u : 0u) + (A.q_m2 ? 2u : 0u);
-  if (rerank_split(A.m)) hipLaunchKernelGGL(rerank_kernel<true>, dim3((unsigned)A.m * A.kin * nch), dim3(256), 0, st, A, idx_in, tick);
-  else hipLaunchKernelGGL(rerank_kernel<false>, dim3((unsigned)A.m * A.kin), dim3(256), 0, st, A, idx_in, tick);
+  if (rerank_split(A.m)) {
+    hipLaunchKernelGGL(rerank_kernel<1>, dim3((unsigned)A.m * A.kin * nch), dim3(256), 0, st, A, idx_in, tick, (const int32_t*)nullptr, (const unsigned*)nullptr);
+    return;
+  }
+  // tick: [cap] tickets | [cap] work list | [1] its length
+  const size_t pairs = (size_t)A.m * A.kin;
+  int32_t* work = reinterpret_cast<int32_t*>(tick + tick_cap);
+  unsigned* count = tick + 2 * tick_cap;
+  launch_zero_ints(st, reinterpret_cast<int*>(count), 1);     // (a kernel: tiny memset nodes of a captured graph have been seen not to replay, see pr_sigset_pack)
+  hipLaunchKernelGGL(rerank_plan_kernel, dim3(A.m), dim3(64), 0, st, A, idx_in, work, count);
+  const unsigned grid = pairs < 7168 ? (unsigned)pairs : 7168u;      // 256 CUs x 7 workgroups (their LDS) x 4 rounds
+  hipLaunchKernelGGL(rerank_kernel<2>, dim3(grid), dim3(256), 0, st, A, idx_in, tick, work, count);
 }
 
 void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                    const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                   double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, int k, int32_t* idx, double* score,
+                   double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, size_t tick_cap, int k, int32_t* idx, double* score,
                    float* score32, const double* cand_sc32, double eps_d, double order_floor, double order_noise, int32_t* order_flags) {
   if (m <= 0) return;
   SortArgs S{idx_in, p5, m, kin, k, idx, score, score32, order_flags ? 1 : 0, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr, G, p_weight,
              order_floor, order_noise, order_flags};
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
                eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
-  launch_rerank_kernel(st, A, idx_in, tick);
+  launch_rerank_kernel(st, A, idx_in, tick, tick_cap);
   if (m <= 64) { hipLaunchKernelGGL(rerank_sort_wave_kernel, dim3(m), dim3(64), 0, st, S); return; }
   hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, p5, m, kin, k, idx, score, score32);
   if (order_flags)
@@ -874,11 +916,12 @@ void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_d
 
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                            const double* mom_sc, const double* mom_m2, int m, int n_local, int G, int q_row0, int db_row0, int mask_width,
-                           double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, const double* cand_sc32, int k, double eps_d) {
+                           double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, size_t tick_cap, const double* cand_sc32, int k,
+                           double eps_d) {
   if (m <= 0) return;
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
                eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
-  launch_rerank_kernel(st, A, idx_in, tick);
+  launch_rerank_kernel(st, A, idx_in, tick, tick_cap);
 }
 
 void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,

@@ -229,6 +229,16 @@ template <bool LO>
 __device__ __forceinline__ void swp2(f32x4& x, f32x4& y, f32x4& u, f32x4& v, int e) { swap32f(x, y, e); swap32f(u, v, e); }
 // X, Y, U, V -> Re S = X + V (in x), Re P = X - V (in v), Im S = Y - U (in y), Im P = Y + U (in u), registers r0, r0 + 1
 __device__ __forceinline__ void cmb2(f32x4& x, f32x4& y, f32x4& u, f32x4& v, int r0) {
+#ifdef E_PLAIN_CMB   // A/B: eight plain adds (asm: hipcc would pack them again) instead of four v_pk_add_f32
+#pragma unroll
+  for (int e = r0; e < r0 + 2; e++) {
+    float sr, pr, si, pi;
+    asm volatile("v_add_f32 %0, %4, %7\n\tv_sub_f32 %1, %4, %7\n\tv_sub_f32 %2, %5, %6\n\tv_add_f32 %3, %5, %6"
+                 : "=&v"(sr), "=&v"(pr), "=&v"(si), "=&v"(pi) : "v"(x[e]), "v"(y[e]), "v"(u[e]), "v"(v[e]));
+    x[e] = sr; v[e] = pr; y[e] = si; u[e] = pi;
+  }
+  return;
+#endif
   const f32x2 _x = {x[r0], x[r0 + 1]}, _y = {y[r0], y[r0 + 1]}, _u = {u[r0], u[r0 + 1]}, _v = {v[r0], v[r0 + 1]};
   const f32x2 _sr = _x + _v, _pr = _x - _v, _si = _y - _u, _pi = _y + _u;
   x[r0] = _sr[0]; x[r0 + 1] = _sr[1]; v[r0] = _pr[0]; v[r0 + 1] = _pr[1];
