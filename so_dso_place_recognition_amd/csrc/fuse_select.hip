@@ -349,20 +349,24 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
   if (head > n) head = n;
   // rows not co-aligned mod 16 B (d_p and d_i carved out of one allocation with m*n % 4 != 0): no vector body, the scalar
   // tail loop below walks the whole row
-  const bool coaligned = !((reinterpret_cast<size_t>(rp) ^ reinterpret_cast<size_t>(ri)) & 15);
+  const bool coaligned = !((reinterpret_cast<size_t>(rp) ^ reinterpret_cast<size_t>(ri)) & 15) &&
+                         !(e_p && (((reinterpret_cast<size_t>(rp) ^ reinterpret_cast<size_t>(e_p + (size_t)q * n)) |
+                                    (reinterpret_cast<size_t>(rp) ^ reinterpret_cast<size_t>(e_i + (size_t)q * n))) & 15));
   if (!coaligned) head = 0;
   const int nv = coaligned ? (n - head) >> 2 : 0;
   const f32x4* rp4 = reinterpret_cast<const f32x4*>(rp + head);
   const f32x4* ri4 = reinterpret_cast<const f32x4*>(ri + head);
 
-  auto fused = [&](float vp, float vi, int j) -> double {
+  const float* rep = two ? e_p + (size_t)q * n : rp;      // the second channel pair's rows (the fused form), else any valid address
+  const float* rei = two ? e_i + (size_t)q * n : rp;
+  auto fused4 = [&](float vp, float vi, float wp, float wi, int j) -> double {
     const int jg = db_row0 + j;
     double f;
     if (plain) f = (double)vp;
     else if (fastdiv) f = p_weight * div_rn((double)vp - mp, sp, rsp) + div_rn((double)vi - mi, si, rsi);        // run_test.m:40
     else f = p_weight * (((double)vp - mp) / sp) + ((double)vi - mi) / si;
     if (two) {
-      const double xp = (double)e_p[(size_t)q * n + j] - m2p, xi = (double)e_i[(size_t)q * n + j] - m2i;
+      const double xp = (double)wp - m2p, xi = (double)wi - m2i;
       f += fastdiv2 ? p_weight * div_rn(xp, s2p, rs2p) + div_rn(xi, s2i, rs2i) : p_weight * (xp / s2p) + xi / s2i;
     }
     int dij = ig - jg;
@@ -370,23 +374,35 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
     if (dij < mask_width) f = __builtin_inf();                                      // run_test.m:47-53
     return f;                                                                        // NaN never wins (MATLAB min)
   };
+  auto fused = [&](float vp, float vi, int j) -> double { return fused4(vp, vi, two ? rep[j] : 0.f, two ? rei[j] : 0.f, j); };
   // visit(j, f) over this thread's elements of the row
+  const f32x4* ep4 = reinterpret_cast<const f32x4*>(rep + head);
+  const f32x4* ei4 = reinterpret_cast<const f32x4*>(rei + head);
   auto sweep = [&](auto&& visit) {
     if (tid < head) visit(tid, fused(rp[tid], ri[tid], tid));
-    auto four = [&](const f32x4& a, const f32x4& b, int j) {
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto four = [&](const f32x4& a, const f32x4& b, const f32x4& c, const f32x4& d, int j) {
       const int j0 = head + 4 * j;
-      visit(j0, fused(a[0], b[0], j0)); visit(j0 + 1, fused(a[1], b[1], j0 + 1));
-      visit(j0 + 2, fused(a[2], b[2], j0 + 2)); visit(j0 + 3, fused(a[3], b[3], j0 + 3));
+      visit(j0, fused4(a[0], b[0], c[0], d[0], j0)); visit(j0 + 1, fused4(a[1], b[1], c[1], d[1], j0 + 1));
+      visit(j0 + 2, fused4(a[2], b[2], c[2], d[2], j0 + 2)); visit(j0 + 3, fused4(a[3], b[3], c[3], d[3], j0 + 3));
     };
     int j = tid;
     // four 16-byte loads per channel in flight (the kernel runs at ~3 workgroups per CU - its LDS list - so a thread has to cover the
-    // latency of its loads by itself); same elements, same order per thread as the plain loop
+    // latency of its loads by itself); same elements, same order per thread as the plain loop.  The fused form's second channel pair
+    // comes the same way (its element-wise 4-byte loads were most of that form's 2.65 ms sweep)
     for (; j + 768 < nv; j += 1024) {
       const f32x4 a0 = rp4[j], a1 = rp4[j + 256], a2 = rp4[j + 512], a3 = rp4[j + 768];
       const f32x4 b0 = ri4[j], b1 = ri4[j + 256], b2 = ri4[j + 512], b3 = ri4[j + 768];
-      four(a0, b0, j); four(a1, b1, j + 256); four(a2, b2, j + 512); four(a3, b3, j + 768);
+      if (two) {
+        const f32x4 c0 = ep4[j], c1 = ep4[j + 256], c2 = ep4[j + 512], c3 = ep4[j + 768];
+        const f32x4 d0 = ei4[j], d1 = ei4[j + 256], d2 = ei4[j + 512], d3 = ei4[j + 768];
+        four(a0, b0, c0, d0, j); four(a1, b1, c1, d1, j + 256); four(a2, b2, c2, d2, j + 512); four(a3, b3, c3, d3, j + 768);
+      } else { four(a0, b0, z4, z4, j); four(a1, b1, z4, z4, j + 256); four(a2, b2, z4, z4, j + 512); four(a3, b3, z4, z4, j + 768); }
     }
-    for (; j < nv; j += 256) { const f32x4 a = rp4[j], b = ri4[j]; four(a, b, j); }
+    for (; j < nv; j += 256) {
+      const f32x4 a = rp4[j], b = ri4[j];
+      if (two) { const f32x4 c = ep4[j], d = ei4[j]; four(a, b, c, d, j); } else four(a, b, z4, z4, j);
+    }
     for (int t = head + 4 * nv + tid; t < n; t += 256) visit(t, fused(rp[t], ri[t], t));
   };
   // (score64: the same fp32-rounded score widened - what the fp64 re-evaluation takes as the candidates' pass scores; saves the caller a
