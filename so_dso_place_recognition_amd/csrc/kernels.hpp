@@ -42,6 +42,7 @@ void launch_sc_match(hipStream_t st, const float* qpk, int m, const float* dpk, 
                      float* d_p, float* d_i, int nsplit_override);
 size_t sc_match_lds_bytes();
 void launch_zero_ints(hipStream_t st, int* p, int n);
+void launch_fill_ints(hipStream_t st, int* p, int n, int v);
 // sc_match_h.hip — the same on the f16 matrix cores with split (hi + lo) operands; packed images from launch_sc_pack_h
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
                       const double* twiddle, int* flags, int* bad, int single = 0);   // single: hi halves only (SCF_* layout)

@@ -54,6 +54,7 @@ struct pr_ctx {
   int sc_mode = PR_SC_ARITH_F16X2;   // PR_SC_ARITH_*: split-f16 MFMA (sc_match_h.hip) | fp32 MFMA (sc_match.hip); PR_SC_MATCH=f32 selects the latter
   double* d_planes = nullptr;    // M2DP xProj[64][3], yProj[64][3]
   int sc_nsplit = 0;             // PR_SC_NSPLIT override (experiments)
+  bool force_order = false;      // PR_FORCE_ORDER_FLAGS=1 (tests): every query counts as flagged by the order check, i.e. every query gets fp64 row statistics
 };
 
 struct pr_sigset {
@@ -260,6 +261,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
   } while (0);
   if (rc != PR_OK) { pr_destroy(ctx); return rc; }
   if (const char* s = getenv("PR_SC_NSPLIT")) ctx->sc_nsplit = atoi(s);
+  if (const char* s = getenv("PR_FORCE_ORDER_FLAGS")) ctx->force_order = atoi(s) != 0;
   if (const char* s = getenv("PR_SC_MATCH")) ctx->sc_mode = (strcmp(s, "f32") == 0) ? PR_SC_ARITH_F32 : (strcmp(s, "f16") == 0) ? PR_SC_ARITH_F16 : PR_SC_ARITH_F16X2;
   if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel = (strcmp(s, "h") == 0) ? 0 : 2;
   *out = ctx;
@@ -756,6 +758,7 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
   order_consts(ctx, fl, noise);
   pr::launch_rerank(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width,
                     p_weight, k_in, idx_in, ctx->rr_scratch, ctx->rr_tick, ctx->tick_cap, k, idx, score, nullptr, score_in, pass_eps(ctx), fl, noise, ctx->d_order);
+  if (ctx->force_order) pr::launch_fill_ints(ctx->stream, ctx->d_order, m, 1);
   ctx->order_m = m;
   ctx->order_kin = k_in;
   PR_HIP(ctx, hipGetLastError());
@@ -850,6 +853,7 @@ int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2
   order_consts(ctx, fl, noise);
   pr::launch_rerank_finish(ctx->stream, cand_idx, p5_all, G, m, k_in, k, idx, score);
   pr::launch_order_check(ctx->stream, mom_sc, mom_m2, G_mom, cand_idx, p5_all, G, m, k_in, k, idx, p_weight, fl, noise, ctx->d_order);
+  if (ctx->force_order) pr::launch_fill_ints(ctx->stream, ctx->d_order, m, 1);
   ctx->order_m = m;
   ctx->order_kin = k_in;
   PR_HIP(ctx, hipGetLastError());

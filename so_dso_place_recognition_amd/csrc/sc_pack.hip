@@ -373,10 +373,18 @@ __global__ __launch_bounds__(256) void zero_ints_kernel(int* __restrict__ p, int
   if (i < n) p[i] = 0;
 }
 
+__global__ __launch_bounds__(256) void fill_ints_kernel(int* __restrict__ p, int n, int v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
 }  // namespace
 
 void launch_zero_ints(hipStream_t st, int* p, int n) {
   if (n > 0) hipLaunchKernelGGL(zero_ints_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, n);
+}
+void launch_fill_ints(hipStream_t st, int* p, int n, int v) {
+  if (n > 0) hipLaunchKernelGGL(fill_ints_kernel, dim3((n + 255) / 256), dim3(256), 0, st, p, n, v);
 }
 
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,

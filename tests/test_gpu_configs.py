@@ -416,3 +416,54 @@ def test_order_that_hangs_on_the_row_sigmas_is_resolved_with_fp64_statistics(api
     assert d["world"] == 2 and d["warnings"] & _lib.WARN_ORDER_RESOLVED
     assert np.array_equal(np.array(d["idx"]), oidx)
     assert np.abs(np.array(d["score"])[rows] - osc[rows]).max() < 1e-9
+
+
+@pytest.mark.gpu
+def test_fp64_statistics_for_every_query_give_the_oracles_scores(api, monkeypatch):
+    """PR_FORCE_ORDER_FLAGS=1 makes the order check flag every query, so the fp64-statistics resolution - normally a 1-in-10^5 path - answers
+    all of them: every returned score must then be the oracle's to fp64 rounding (exact pair distances AND exact row statistics,
+    run_test.m:38-57), on every path: the host calls (all queries: several passes of 64), the stream-ordered device-resident call (its first
+    64 flagged queries; PR_WARN_ORDER_UNRESOLVED for the rest), pr_group with virtual shards, and the fused SC + M2DP form."""
+    import torch
+    from so_dso_place_recognition_amd.matcher import Matcher, FusedMatcher
+    monkeypatch.setenv("PR_FORCE_ORDER_FLAGS", "1")
+    m, n, k = 150, 700, 3
+    db = synth.sc_database(81, n)
+    q, _ = synth.sc_queries(181, db, m)
+    rc, oidx, osc = oracle_lib.match_topk(0, q, db, 5, 2.0, k)
+    assert rc == 0
+    ctx = api.Context(0)
+    idx, sc = api.match_topk("sc", q, db, 5, 2.0, k, ctx=ctx)
+    assert ctx.take_warnings() & _lib.WARN_ORDER_RESOLVED
+    assert np.array_equal(idx, oidx) and np.abs(sc - osc).max() < 1e-9
+    ctx.close()
+    dev = torch.device("cuda", 0)
+    mt = Matcher("sc", m, n, ctx=api.Context(0, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
+    mt.pack_database(torch.from_numpy(db).to(dev))
+    i1, s1 = mt.match(torch.from_numpy(q).to(dev), 5, 2.0, k)
+    w = mt.take_warnings()
+    assert (w & _lib.WARN_ORDER_RESOLVED) and (w & _lib.WARN_ORDER_UNRESOLVED)          # 150 flagged, one stream-ordered pass resolves 64
+    i1, s1 = i1.cpu().numpy(), s1.cpu().numpy()
+    assert np.array_equal(i1, oidx)
+    assert np.abs(s1[:64] - osc[:64]).max() < 1e-9                                       # the resolved ones: fp64 throughout
+    rc, odp, odi = oracle_lib.sc_distance(q[64:], db)
+    assert (np.abs(s1[64:] - osc[64:]) <= helpers.score_tol(osc[64:], helpers.row_sigmas(odp, odi))).all()   # the others: the fp32-statistics model
+    i2, s2 = mt.match(torch.from_numpy(q[:40]).to(dev), 5, 2.0, k)                       # an online-sized call: everything resolved
+    assert not (mt.take_warnings() & _lib.WARN_ORDER_UNRESOLVED)
+    assert np.array_equal(i2.cpu().numpy(), oidx[:40]) and np.abs(s2.cpu().numpy() - osc[:40]).max() < 1e-9
+    mt.close()
+    g = api.Group([0, 0, 0])
+    g.set_database("sc", db)
+    gi, gs = g.match_topk(q[:60], 5, 2.0, k)
+    assert np.array_equal(gi, oidx[:60]) and np.abs(gs - osc[:60]).max() < 1e-9
+    g.close()
+    # fused SC + M2DP (config 5's score): both descriptor types through the resolution
+    mdb = synth.m2dp_database(83, n)
+    mq, _ = synth.m2dp_queries(183, mdb, 48)
+    rc, fidx, fsc = oracle_lib.match_topk_fused(q[:48], mq, db, mdb, 5, 2.0, k)
+    assert rc == 0
+    fm = FusedMatcher(48, n, ctx=api.Context(0, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
+    fm.pack_database(torch.from_numpy(db).to(dev), torch.from_numpy(mdb).to(dev))
+    i3, s3 = fm.match(torch.from_numpy(q[:48]).to(dev), torch.from_numpy(mq).to(dev), 5, 2.0, k)
+    assert np.array_equal(i3.cpu().numpy(), fidx) and np.abs(s3.cpu().numpy() - fsc).max() < 1e-9
+    fm.close()
