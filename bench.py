@@ -521,9 +521,21 @@ def main():
             except Exception as e:
                 out["cpu_baseline"]["blas"] = {"error": repr(e)[:200]}
             err = np.abs(osc[:, 0] - score_h[:S])
+            # the same sample with fp64 row statistics for every query (pr_set_exact_statistics; 2.3 ms per query, outside the timed region):
+            # what is left of the score error when nothing of the fp32 pass enters the returned score
+            mx = Matcher("sc", S, hi - lo, ctx=Context(local, sc_arith=args.sc_arith, exact_statistics=True,
+                                                       stream=int(torch.cuda.current_stream(dev).cuda_stream)))
+            mx.pack_database(db)
+            xi, xs = mx.match(q[:S].contiguous(), 0, 2.0, 1, db_row0=lo)
+            torch.cuda.synchronize()
+            exact_err = float(np.abs(xs.cpu().numpy()[:, 0] - osc[:, 0]).max()) if S <= 64 and arith != "f16" else None
+            exact_idx_ok = bool((xi.cpu().numpy()[:, 0] == oidx[:, 0]).all())
+            mx.close()
             out["parity"].update({"oracle_queries": S, "oracle_top1_equal": bool((oidx[:, 0] == idx_h[:S]).all()),
                                   "oracle_max_abs_score_err": float(err.max()),
                                   "oracle_max_rel_score_err": float((err / np.abs(osc[:, 0])).max()),
+                                  "oracle_max_abs_score_err_with_exact_statistics": exact_err,
+                                  "oracle_top1_equal_with_exact_statistics": exact_idx_ok,
                                   "score_note": "planted matches sit at z ~ -160; the returned score is exact in the pair's distances (fp64 re-evaluation), "
                                                 "its row statistics carry the fp32 pass's ~2e-7 relative error (DESIGN.md)"})
         if world == 1 and not args.no_extra:

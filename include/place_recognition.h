@@ -69,6 +69,12 @@ int pr_get_sc_arith(const pr_ctx* ctx);
 int pr_sync(pr_ctx* ctx);                            /* waits for the context's stream; reports deferred errors */
 int pr_set_nan_policy(pr_ctx* ctx, int policy);      /* PR_NAN_EXCLUDE | PR_NAN_FAIL */
 int pr_get_nan_policy(const pr_ctx* ctx);
+/* on != 0: EVERY query of a top-k call is treated as flagged by the order check, i.e. answered with fp64 row statistics (DESIGN.md section 2
+ * "Returned order"): returned scores are then the reference's doubles to rounding (|score - oracle| < 1e-9 whatever |z|; by default they carry
+ * the fp32 pass's ~2e-7 relative error of the row sigma, 3e-5 absolute at z = -160) - at ~23 ns per (query, DB entry) pair: 2.3 ms per query
+ * and 100 000 entries.  The host calls resolve all queries; a stream-ordered call its first 64 (PR_WARN_ORDER_UNRESOLVED beyond).  Off by
+ * default; the environment variable PR_FORCE_ORDER_FLAGS=1 sets it at creation (tests). */
+int pr_set_exact_statistics(pr_ctx* ctx, int on);
 int pr_take_warnings(pr_ctx* ctx);                   /* PR_WARN_* bits raised since the last call (synchronises the stream), then cleared */
 void* pr_stream(pr_ctx* ctx);                        /* the context's hipStream_t (for event timing by the caller) */
 

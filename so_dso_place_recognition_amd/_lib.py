@@ -27,6 +27,7 @@ SYMBOLS = {
     "pr_create_on_stream": (C.c_int, [C.c_int, _vp, C.POINTER(_vp)]),
     "pr_set_nan_policy": (C.c_int, [_vp, C.c_int]),
     "pr_get_nan_policy": (C.c_int, [_vp]),
+    "pr_set_exact_statistics": (C.c_int, [_vp, C.c_int]),
     "pr_take_warnings": (C.c_int, [_vp]),
     "pr_match_topk_f64": (C.c_int, [_vp, C.c_int, _vp, _i32, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_match_topk_fused_f64": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),

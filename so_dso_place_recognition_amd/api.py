@@ -23,8 +23,11 @@ def _ptr(a):
 class Context:
     """One HIP device + stream (pr_ctx)."""
 
-    def __init__(self, device: int = 0, sc_arith: str | None = None, stream: int | None = None, nan_policy: str | None = None):
+    def __init__(self, device: int = 0, sc_arith: str | None = None, stream: int | None = None, nan_policy: str | None = None,
+                 exact_statistics: bool | None = None):
         """sc_arith: None (library default: "f16x2", or PR_SC_MATCH=f32 from the environment), "f16x2" or "f32".
+        exact_statistics: True = every query of a top-k call gets fp64 row statistics (pr_set_exact_statistics: scores are the reference's
+        doubles to rounding, at 2.3 ms per query and 100k entries).
         stream: a hipStream_t the caller owns (e.g. torch.cuda.current_stream().cuda_stream; 0 = the null stream): the
         context's kernels are enqueued there (pr_create_on_stream).  nan_policy: "exclude" (default, MATLAB's behaviour for
         zero-norm SC rows) or "fail" (PR_ENAN)."""
@@ -42,6 +45,8 @@ class Context:
             self.check(self.lib.pr_set_sc_arith(h, {"f16x2": _lib.SC_ARITH_F16X2, "f32": _lib.SC_ARITH_F32, "f16": _lib.SC_ARITH_F16}[sc_arith]))
         if nan_policy is not None:
             self.check(self.lib.pr_set_nan_policy(h, {"exclude": _lib.NAN_EXCLUDE, "fail": _lib.NAN_FAIL}[nan_policy]))
+        if exact_statistics is not None:
+            self.check(self.lib.pr_set_exact_statistics(h, int(bool(exact_statistics))))
 
     def take_warnings(self) -> int:
         """PR_WARN_* bits raised since the last call (1: zero-norm SC rows excluded, 2: an M2DP singular pair did not converge)."""

@@ -318,6 +318,12 @@ int pr_set_nan_policy(pr_ctx* ctx, int policy) {
 
 int pr_get_nan_policy(const pr_ctx* ctx) { return ctx ? ctx->nan_policy : PR_EINVAL; }
 
+int pr_set_exact_statistics(pr_ctx* ctx, int on) {
+  if (!ctx) return PR_EINVAL;
+  ctx->force_order = on != 0;
+  return PR_OK;
+}
+
 int pr_take_warnings(pr_ctx* ctx) {
   if (!ctx) return 0;
   if (set_device(ctx) == PR_OK) (void)check_flags(ctx);

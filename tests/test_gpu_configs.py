@@ -437,6 +437,16 @@ def test_fp64_statistics_for_every_query_give_the_oracles_scores(api, monkeypatc
     assert ctx.take_warnings() & _lib.WARN_ORDER_RESOLVED
     assert np.array_equal(idx, oidx) and np.abs(sc - osc).max() < 1e-9
     ctx.close()
+    monkeypatch.delenv("PR_FORCE_ORDER_FLAGS")                   # the same through the API switch (pr_set_exact_statistics) ...
+    ctx = api.Context(0, exact_statistics=True)
+    idx, sc = api.match_topk("sc", q[:20], db, 5, 2.0, k, ctx=ctx)
+    assert np.array_equal(idx, oidx[:20]) and np.abs(sc - osc[:20]).max() < 1e-9
+    ctx.close()
+    ctx = api.Context(0)                                          # ... and the default: exact pair distances, fp32-pass row statistics
+    idx, sc = api.match_topk("sc", q[:20], db, 5, 2.0, k, ctx=ctx)
+    assert np.array_equal(idx, oidx[:20]) and np.abs(sc - osc[:20]).max() > 1e-9
+    ctx.close()
+    monkeypatch.setenv("PR_FORCE_ORDER_FLAGS", "1")
     dev = torch.device("cuda", 0)
     mt = Matcher("sc", m, n, ctx=api.Context(0, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
     mt.pack_database(torch.from_numpy(db).to(dev))
