@@ -378,13 +378,16 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
   // visit(j, f) over this thread's elements of the row
   const f32x4* ep4 = reinterpret_cast<const f32x4*>(rep + head);
   const f32x4* ei4 = reinterpret_cast<const f32x4*>(rei + head);
-  auto sweep = [&](auto&& visit) {
-    if (tid < head) visit(tid, fused(rp[tid], ri[tid], tid));
+  // `maybe(vp, vi, wp, wi)`: a cheap test in front of the exact score - false only where the element cannot be wanted (sweep_if), or
+  // always true (sweep)
+  auto sweep_if = [&](auto&& maybe, auto&& visit) {
+    if (tid < head && maybe(rp[tid], ri[tid], two ? rep[tid] : 0.f, two ? rei[tid] : 0.f)) visit(tid, fused(rp[tid], ri[tid], tid));
     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
     auto four = [&](const f32x4& a, const f32x4& b, const f32x4& c, const f32x4& d, int j) {
       const int j0 = head + 4 * j;
-      visit(j0, fused4(a[0], b[0], c[0], d[0], j0)); visit(j0 + 1, fused4(a[1], b[1], c[1], d[1], j0 + 1));
-      visit(j0 + 2, fused4(a[2], b[2], c[2], d[2], j0 + 2)); visit(j0 + 3, fused4(a[3], b[3], c[3], d[3], j0 + 3));
+#pragma unroll
+      for (int e = 0; e < 4; e++)
+        if (maybe(a[e], b[e], c[e], d[e])) visit(j0 + e, fused4(a[e], b[e], c[e], d[e], j0 + e));
     };
     int j = tid;
     // four 16-byte loads per channel in flight (the kernel runs at ~3 workgroups per CU - its LDS list - so a thread has to cover the
@@ -403,8 +406,10 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
       const f32x4 a = rp4[j], b = ri4[j];
       if (two) { const f32x4 c = ep4[j], d = ei4[j]; four(a, b, c, d, j); } else four(a, b, z4, z4, j);
     }
-    for (int t = head + 4 * nv + tid; t < n; t += 256) visit(t, fused(rp[t], ri[t], t));
+    for (int t = head + 4 * nv + tid; t < n; t += 256)
+      if (maybe(rp[t], ri[t], two ? rep[t] : 0.f, two ? rei[t] : 0.f)) visit(t, fused(rp[t], ri[t], t));
   };
+  auto sweep = [&](auto&& visit) { sweep_if([](float, float, float, float) { return true; }, visit); };
   // (score64: the same fp32-rounded score widened - what the fp64 re-evaluation takes as the candidates' pass scores; saves the caller a
   //  conversion launch, which an online call feels)
   auto emit = [&](int t, double v, int jg) {
@@ -472,13 +477,32 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
       lv[j] = ok ? f : __builtin_inf();
       lj[j] = ok ? db_row0 + j : NONE_J;
     });
-  else
-    sweep([&](int j, double f) {
+  else {
+    // Only ~r n / 4096 elements of the row are at or below tau, and the exact score is ~11 fp64 instructions (two correctly rounded
+    // divisions).  In front of it: the same score as ONE affine form fa = a d_p + b d_i + c (two fp64 fmas; a = p / s_p, b = 1 / s_i,
+    // c = -(p m_p / s_p + m_i / s_i); the fused form adds its second pair), which differs from the exact score by rounding only
+    // (< 1e-13 for the usual row statistics: |a d_p|, |c| ~ 50).  fa > tau + E with E = 1e-10 (1 + |a| + |b| + |c| ...) - five orders above
+    // that difference - cannot be wanted: the list is what the unfiltered sweep collects, element for element, and a wave evaluates
+    // the exact score only where one of its lanes may pass (~1 element group in 5).  The mask only removes elements, NaN compares false.
+    const bool pre = !plain && fastdiv && (!two || fastdiv2) && tau < __builtin_inf();
+    const double a1 = p_weight / sp, b1 = 1.0 / si, c1 = -(p_weight * mp / sp + mi / si);
+    const double a2 = two ? p_weight / s2p : 0.0, b2 = two ? 1.0 / s2i : 0.0, c2 = two ? -(p_weight * m2p / s2p + m2i / s2i) : 0.0;
+    const double tauE = tau + 1e-10 * (1.0 + fabs(a1) + fabs(b1) + fabs(c1) + fabs(a2) + fabs(b2) + fabs(c2) + fabs(tau));
+    auto collect = [&](int j, double f) {
       if (f <= tau) {
         const int slot = atomicAdd(&lcnt, 1);
         if (slot < CAP) { lv[slot] = f; lj[slot] = db_row0 + j; }
       }
-    });
+    };
+    if (pre)
+      sweep_if([&](float vp, float vi, float wp, float wi) {
+        double fa = __builtin_fma(a1, (double)vp, __builtin_fma(b1, (double)vi, c1));
+        if (two) fa += __builtin_fma(a2, (double)wp, __builtin_fma(b2, (double)wi, c2));
+        return fa <= tauE;
+      }, collect);
+    else
+      sweep(collect);
+  }
   __syncthreads();
   const int L = whole ? n : lcnt;
   if (L <= CAP && (k > 12 || whole)) {
