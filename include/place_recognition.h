@@ -75,6 +75,25 @@ int pr_get_nan_policy(const pr_ctx* ctx);
  * and 100 000 entries.  The host calls resolve all queries; a stream-ordered call its first 64 (PR_WARN_ORDER_UNRESOLVED beyond).  Off by
  * default; the environment variable PR_FORCE_ORDER_FLAGS=1 sets it at creation (tests). */
 int pr_set_exact_statistics(pr_ctx* ctx, int on);
+/* Binary intensity channel (no reference counterpart as a switch; the arithmetic is processSC.m:15-33 on the values SC/SC.cpp:67-72 writes:
+ * channel 1 of an SC signature is 0 / 1).  In PR_SC_ARITH_F16X2 the pack notices whether every channel-1 row of a set has all of its non-zero
+ * entries equal and positive; the normalised row is then 1/sqrt(ones) on `ones` bins and every one of the 120 products of processSC.m:30 is
+ * count / sqrt(ones_q ones_d) with an INTEGER count.  pr_distances_dev / the top-k calls then compute channel 1 with ONE f16 product per
+ * term on the hi halves of the same packed images and round max x sqrt(ones_q ones_d) to the nearest integer: the distance is exact (to the
+ * fp32 rounding of the final expression, ~1e-7) whenever |x - rint(x)| + b < 1 for the pair, x the computed count of its best variant and b a
+ * rigorous bound of the pass's error evaluated ON THE DEVICE from statistics of the two sets (rounding residual norms of the packed spectra) and
+ * the pair's ones; the kernel tests every pair.  Sets with non-binary rows or too many ones (beyond ~550 per signature), or a call in which a
+ * pair fails the test, get channel 1 from the split-f16 kernel as channel 0 does - same results to 1e-7, no host round trip either way.  on = 0 always takes the split-f16 kernel for both channels (environment: PR_SC_BINARY=0). */
+int pr_set_sc_binary(pr_ctx* ctx, int on);
+/* *state = 1 when a pr_distances_dev call on these two packed sets takes the binary path for channel 1, 2 when it did and the last call's
+ * per-pair rounding test failed somewhere (channel 1 was then redone in split-f16), 0 when the bound rules the path out (reads the sets'
+ * statistics back: synchronises; the device takes its own decision from the same numbers). */
+int pr_sc_binary_state(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, int32_t* state);
+/* Measurement hooks (bench.py): on != 0 records HIP events on the context's stream around the matcher launches of every pr_distances_dev call;
+ * pr_last_distance_timing waits for the last call's events and returns ms[3] = {channel-0 (or the only) launch, channel-1 single-product
+ * launch, channel-1 split-f16 launch}; of the two channel-1 launches one has left at once. */
+int pr_set_kernel_timing(pr_ctx* ctx, int on);
+int pr_last_distance_timing(pr_ctx* ctx, float* ms);
 int pr_take_warnings(pr_ctx* ctx);                   /* PR_WARN_* bits raised since the last call (synchronises the stream), then cleared */
 void* pr_stream(pr_ctx* ctx);                        /* the context's hipStream_t (for event timing by the caller) */
 

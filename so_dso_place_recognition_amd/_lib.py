@@ -29,6 +29,10 @@ SYMBOLS = {
     "pr_get_nan_policy": (C.c_int, [_vp]),
     "pr_set_exact_statistics": (C.c_int, [_vp, C.c_int]),
     "pr_take_warnings": (C.c_int, [_vp]),
+    "pr_set_sc_binary": (C.c_int, [_vp, C.c_int]),
+    "pr_sc_binary_state": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "pr_set_kernel_timing": (C.c_int, [_vp, C.c_int]),
+    "pr_last_distance_timing": (C.c_int, [_vp, _vp]),
     "pr_match_topk_f64": (C.c_int, [_vp, C.c_int, _vp, _i32, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_match_topk_fused_f64": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_rerank_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, _i32, _vp,

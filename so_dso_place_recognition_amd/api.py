@@ -24,7 +24,7 @@ class Context:
     """One HIP device + stream (pr_ctx)."""
 
     def __init__(self, device: int = 0, sc_arith: str | None = None, stream: int | None = None, nan_policy: str | None = None,
-                 exact_statistics: bool | None = None):
+                 exact_statistics: bool | None = None, sc_binary: bool | None = None):
         """sc_arith: None (library default: "f16x2", or PR_SC_MATCH=f32 from the environment), "f16x2" or "f32".
         exact_statistics: True = every query of a top-k call gets fp64 row statistics (pr_set_exact_statistics: scores are the reference's
         doubles to rounding, at 2.3 ms per query and 100k entries).
@@ -47,6 +47,18 @@ class Context:
             self.check(self.lib.pr_set_nan_policy(h, {"exclude": _lib.NAN_EXCLUDE, "fail": _lib.NAN_FAIL}[nan_policy]))
         if exact_statistics is not None:
             self.check(self.lib.pr_set_exact_statistics(h, int(bool(exact_statistics))))
+        if sc_binary is not None:      # False: a binary intensity channel goes through the split-f16 kernel like any other (pr_set_sc_binary)
+            self.check(self.lib.pr_set_sc_binary(h, int(bool(sc_binary))))
+
+    def kernel_timing(self, on: bool):
+        """HIP events around the matcher launches of pr_distances_dev (pr_set_kernel_timing)."""
+        self.check(self.lib.pr_set_kernel_timing(self.h, int(bool(on))))
+
+    def last_distance_timing(self):
+        """(ms channel-0 or only launch, ms channel-1 single-product launch, ms channel-1 split-f16 launch) of the last timed call."""
+        ms = (C.c_float * 3)()
+        self.check(self.lib.pr_last_distance_timing(self.h, ms))
+        return float(ms[0]), float(ms[1]), float(ms[2])
 
     def take_warnings(self) -> int:
         """PR_WARN_* bits raised since the last call (1: zero-norm SC rows excluded, 2: an M2DP singular pair did not converge)."""

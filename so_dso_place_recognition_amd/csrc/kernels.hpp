@@ -45,7 +45,27 @@ void launch_zero_ints(hipStream_t st, int* p, int n);
 void launch_fill_ints(hipStream_t st, int* p, int n, int v);
 // sc_match_h.hip — the same on the f16 matrix cores with split (hi + lo) operands; packed images from launch_sc_pack_h
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
-                      const double* twiddle, int* flags, int* bad, int single = 0);   // single: hi halves only (SCF_* layout)
+                      const double* twiddle, int* flags, int* bad, int single = 0,   // single: hi halves only (SCF_* layout)
+                      float* binfo = nullptr, int* bstat = nullptr);                 // binary-channel statistics, see below
+// Binary intensity channel (SC.cpp:67-72 writes 0 / 1 there): when every row of channel 1 has all of its non-zero entries equal (and
+// positive), the row normalised as processSC.m:15-20 does is 1/sqrt(ones) on `ones` bins and every one of the 120 variant products of
+// processSC.m:30 is count / sqrt(ones_q ones_d) with an INTEGER count.  The split-f16 pack then also leaves
+//   binfo[row] = {sqrt(ones), 1/sqrt(ones)} (floats; {1, 1} for a zero-norm row)
+//   bstat[0] |= 1 when a row of channel 1 is not of that form, bstat[1] = max ones, bstat[2..5] = max over the rows of the
+//   w-weighted square sum of the f16 rounding residuals of the row's hi spectra (float bits; one slot per frequency block of the pack kernel:
+//   their sum bounds the largest row's residual norm^2)
+// (bstat is zeroed by the caller in front of every pack) and the matcher runs channel 1 with ONE f16 product per term on the hi halves
+// of the same images and rounds count = max x sqrt(ones_q ones_d) to the nearest integer - exact when the error bound sc_bin_fast()
+// evaluates from these numbers stays below half a count (sc_match_e.hip), the split-f16 kernel otherwise.
+constexpr int SC_BSTAT_INTS = 8;
+struct ScBin {                    // what the matcher needs of the two sets (device pointers), by value in the kernel arguments
+  const int* qstat; const int* dstat;
+  const float* qinfo; const float* dinfo;     // [rows][2]
+  int* viol;                      // [1] raised by the single-product pass when a pair fails its rounding test (ep_store_round); zeroed by the channel-0 launch
+  float bconst;                   // (u + gamma)(1 + u) + slack: S and stage-2 constant rounding (pr_api.cpp: create_common)
+  int gate;                       // 0: always run; 1: the single-product pass (runs when the bound predicts success); 2: the split-f16 pass behind it (runs when that one did not, or raised viol)
+  int chsel;                      // -1: both channels (channel = XCD & 1); 0 / 1: this channel on all XCDs
+};
 void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p,
                        float* d_i, int nsplit_override);
 size_t sc_match_h_lds_bytes();
@@ -53,6 +73,12 @@ size_t sc_match_h_lds_bytes();
 // single = 1: one f16 product per term (PR_SC_ARITH_F16), 8 waves = two per SIMD; same packed images and constants as sc_match_h.hip
 void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                        int nsplit_override, int single);
+// split-f16 images whose channel 1 may be binary (ScBin above): channel 0 in split-f16; channel 1 by the single-product kernel on the hi
+// halves with integer rounding when the sets' statistics allow it, in split-f16 otherwise - the decision is taken ON THE DEVICE by every
+// workgroup from the same numbers (no host round trip: the two channel-1 launches are both issued, one of them leaves at once).
+// ev (or null): four events recorded around the launches (channel 0 | channel 1 single product | channel 1 split)
+void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
+                           int nsplit_override, ScBin bin, hipEvent_t* ev);
 
 // m2dp_match.hip — processM2DP.m:12-22 for both channels.
 void launch_m2dp_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed, int tiles);

@@ -55,6 +55,11 @@ struct pr_ctx {
   double* d_planes = nullptr;    // M2DP xProj[64][3], yProj[64][3]
   int sc_nsplit = 0;             // PR_SC_NSPLIT override (experiments)
   bool force_order = false;      // PR_FORCE_ORDER_FLAGS=1 (tests): every query counts as flagged by the order check, i.e. every query gets fp64 row statistics
+  bool sc_binary = true;         // split-f16 arithmetic: a binary intensity channel goes through the single-product kernel with integer rounding (kernels.hpp: ScBin); PR_SC_BINARY=0 / pr_set_sc_binary turn it off
+  float sc_bconst = 0.f;         // (u + gamma)(1 + u) + slack of that pass's error bound (create_common)
+  bool timing = false;           // pr_set_kernel_timing: events around the launches of pr_distances_dev
+  hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};
+  int timing_valid = 0;          // 0: nothing recorded; 1: ev_t[0], ev_t[3] only (one launch); 3: all four (channel 0 | channel 1 split | channel 1 single)
 };
 
 struct pr_sigset {
@@ -65,6 +70,7 @@ struct pr_sigset {
   float* packed = nullptr;
   size_t floats = 0;
   int* bad = nullptr;            // SC: [max_sigs + 1][2], entry [row][c] = 1 << c when channel c of that row has zero norm (NaN row in MATLAB, processSC.m:16,19), else 0; every pack writes all of its rows' entries
+  float* binfo = nullptr;        // SC split-f16 sets: [max_sigs + 1][2] {sqrt(ones), 1/sqrt(ones)} of channel 1, then SC_BSTAT_INTS ints of set statistics (kernels.hpp: ScBin)
   int32_t hw = 0;                // rows ever written since the image was last all-zero, and the group count (= channel stride) they were written for
   int packed_groups = -1;        // -1: the image is all-zero
 };
@@ -180,8 +186,8 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
     TRY(hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming));
     for (auto& e : ctx->ev_m2) TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     TRY(hipMalloc(&ctx->sel_scratch, pr::select_scratch_bytes()));
-    TRY(hipMalloc((void**)&ctx->d_flags, 4 * sizeof(int)));
-    TRY(hipMemset(ctx->d_flags, 0, 4 * sizeof(int)));
+    TRY(hipMalloc((void**)&ctx->d_flags, 8 * sizeof(int)));        // [4]: the binary-channel pass's violation flag (kernels.hpp: ScBin), not a deferred bit
+    TRY(hipMemset(ctx->d_flags, 0, 8 * sizeof(int)));
     TRY(hipMalloc((void**)&ctx->d_svd_rows, (1 + pr::M2DP_SVD_ROWS_CAP) * sizeof(int)));
     TRY(hipMemset(ctx->d_svd_rows, 0, (1 + pr::M2DP_SVD_ROWS_CAP) * sizeof(int)));
     double tw[120 + 4 * 60 * 8];
@@ -242,6 +248,20 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
             }
       TRY(hipMalloc(&ctx->d_cst_h, ch.size() * sizeof(_Float16)));
       TRY(hipMemcpy(ctx->d_cst_h, ch.data(), ch.size() * sizeof(_Float16), hipMemcpyHostToDevice));
+      // error constant of the single-product pass over a binary channel (sc_match_e.hip: sc_bin_fast): u = 2^-11 for the
+      // rounding of S_f to f16, gamma = the largest rounding residual of a (cos, -sin) hi pair relative to its weight w_f, 1e-5 for the
+      // fp32 accumulations, the fp32 epilogue and the fp64 DFT
+      double gamma = 0.0;
+      for (int k = 0; k <= 30; k++)
+        for (int f = 0; f < pr::SC_NF; f++) {
+          const int t = (f * k) % 60;
+          const double w = (f == 0 || f == 30) ? 1.0 : 2.0;
+          const double c = w * tw[t] * 1024.0, sn = -w * tw[60 + t] * 1024.0;
+          const double dc = c - (double)(_Float16)c, ds = sn - (double)(_Float16)sn;
+          gamma = std::max(gamma, std::sqrt(dc * dc + ds * ds) / (w * 1024.0));
+        }
+      const double u = 0x1p-11;
+      ctx->sc_bconst = (float)(((u + gamma) * (1.0 + u) + 1e-5) * (1.0 + 1e-6));
     }
     // M2DP plane table from the frozen float normals (M2DP/M2DP.cpp:9-30)
     double pl[2][64][3];
@@ -264,6 +284,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
   if (const char* s = getenv("PR_FORCE_ORDER_FLAGS")) ctx->force_order = atoi(s) != 0;
   if (const char* s = getenv("PR_SC_MATCH")) ctx->sc_mode = (strcmp(s, "f32") == 0) ? PR_SC_ARITH_F32 : (strcmp(s, "f16") == 0) ? PR_SC_ARITH_F16 : PR_SC_ARITH_F16X2;
   if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel = (strcmp(s, "h") == 0) ? 0 : 2;
+  if (const char* s = getenv("PR_SC_BINARY")) ctx->sc_binary = atoi(s) != 0;
   *out = ctx;
   return PR_OK;
 }
@@ -291,6 +312,7 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   for (auto& e : ctx->ev_m2) if (e) (void)hipEventDestroy(e);
+  for (auto& e : ctx->ev_t) if (e) (void)hipEventDestroy(e);
   if (ctx->d_flags) (void)hipFree(ctx->d_flags);
   if (ctx->d_svd_rows) (void)hipFree(ctx->d_svd_rows);
   if (ctx->d_twiddle) (void)hipFree(ctx->d_twiddle);
@@ -533,6 +555,7 @@ int pr_pts_preprocess_gpu(pr_ctx* ctx, const char* poses_file, const char* pts_f
 }
 
 // ------------------------------------------------------------------------------------------- signature sets
+static int* sigset_bstat(const pr_sigset* s) { return reinterpret_cast<int*>(s->binfo + ((size_t)s->max_sigs + 1) * 2); }
 // DELIGHT sets: [capacity][4096] f32 histograms, then [capacity][64 lanes][2] u32 empty-bin masks
 static unsigned* delight_masks(const pr_sigset* s) { return reinterpret_cast<unsigned*>(s->packed + (size_t)s->max_sigs * 4096); }
 int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigset** out) {
@@ -553,11 +576,17 @@ int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigse
   if (type == PR_TYPE_SC) {
     e = hipMalloc((void**)&s->bad, ((size_t)max_sigs + 1) * 2 * sizeof(int));
     if (e != hipSuccess) { (void)hipFree(s->packed); delete s; PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: hipMalloc failed: %s", hipGetErrorString(e)); }
+    if (s->sc_mode == PR_SC_ARITH_F16X2) {
+      const size_t bytes = ((size_t)max_sigs + 1) * 2 * sizeof(float) + pr::SC_BSTAT_INTS * sizeof(int);
+      e = hipMalloc((void**)&s->binfo, bytes);
+      if (e != hipSuccess) { (void)hipFree(s->packed); (void)hipFree(s->bad); delete s; PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: hipMalloc failed: %s", hipGetErrorString(e)); }
+      (void)hipMemsetAsync(s->binfo, 0, bytes, ctx->stream);
+    }
   }
   // the operand image starts out all-zero: padding rows / groups must be zero (they yield dot = 0 and are masked on store), and a pack
   // only writes the rows it is given - see pr_sigset_pack
   e = hipMemsetAsync(s->packed, 0, s->floats * sizeof(float), ctx->stream);
-  if (e != hipSuccess) { (void)hipFree(s->packed); if (s->bad) (void)hipFree(s->bad); delete s; PR_FAIL(ctx, PR_EHIP, "pr_sigset_create: hipMemsetAsync failed: %s", hipGetErrorString(e)); }
+  if (e != hipSuccess) { (void)hipFree(s->packed); if (s->bad) (void)hipFree(s->bad); if (s->binfo) (void)hipFree(s->binfo); delete s; PR_FAIL(ctx, PR_EHIP, "pr_sigset_create: hipMemsetAsync failed: %s", hipGetErrorString(e)); }
   *out = s;
   return PR_OK;
 }
@@ -567,6 +596,7 @@ void pr_sigset_destroy(pr_ctx* ctx, pr_sigset* s) {
   if (ctx) { (void)hipSetDevice(ctx->device); (void)hipStreamSynchronize(ctx->stream); }
   if (s->packed) (void)hipFree(s->packed);
   if (s->bad) (void)hipFree(s->bad);
+  if (s->binfo) (void)hipFree(s->binfo);
   delete s;
 }
 
@@ -599,9 +629,12 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
   const bool keep = s->type != PR_TYPE_DELIGHT && (s->packed_groups < 0 || (s->packed_groups == groups && n_sigs >= s->hw));
   if (!keep) { PR_HIP(ctx, hipMemsetAsync(s->packed, 0, s->floats * sizeof(float), ctx->stream)); s->hw = 0; }
   if (n_sigs > 0) { s->packed_groups = groups; if (n_sigs > s->hw) s->hw = n_sigs; }
-  if (s->type == PR_TYPE_SC && (s->sc_mode == PR_SC_ARITH_F16X2 || s->sc_mode == PR_SC_ARITH_F16))
+  if (s->type == PR_TYPE_SC && (s->sc_mode == PR_SC_ARITH_F16X2 || s->sc_mode == PR_SC_ARITH_F16)) {
+    int* bstat = s->binfo ? sigset_bstat(s) : nullptr;
+    if (bstat) PR_HIP(ctx, hipMemsetAsync(bstat, 0, pr::SC_BSTAT_INTS * sizeof(int), ctx->stream));     // every pack starts its statistics afresh
     pr::launch_sc_pack_h(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags, s->bad,
-                         s->sc_mode == PR_SC_ARITH_F16);
+                         s->sc_mode == PR_SC_ARITH_F16, s->binfo, bstat);
+  }
   else if (s->type == PR_TYPE_SC)
     pr::launch_sc_pack(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags, s->bad);
   else if (s->type == PR_TYPE_M2DP)
@@ -623,8 +656,15 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
   if (int rc = set_device(ctx)) return rc;
   if (q->type != PR_TYPE_DELIGHT && q->sc_mode != db->sc_mode)
     PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: the two sets were packed for different arithmetic modes");
+  if (ctx->timing) { ctx->timing_valid = 1; PR_HIP(ctx, hipEventRecord(ctx->ev_t[0], ctx->stream)); }
   if (q->type == PR_TYPE_SC && q->sc_mode == PR_SC_ARITH_F16)
     pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 1);
+  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && q->count > 8 && ctx->sc_binary && q->binfo && db->binfo) {
+    const pr::ScBin bin = {sigset_bstat(q), sigset_bstat(db), q->binfo, db->binfo, ctx->d_flags + 4, ctx->sc_bconst, 0, -1};
+    pr::launch_sc_match_e_bin(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, bin,
+                              ctx->timing ? ctx->ev_t : nullptr);
+    if (ctx->timing) ctx->timing_valid = 3;
+  }
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && q->count > 8)
     pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 0);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0)
@@ -636,8 +676,63 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
     else pr::launch_m2dp_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
   else
     pr::launch_delight_match(ctx->stream, q->packed, q->count, db->packed, delight_masks(db), db->count, d_p);
+  if (ctx->timing && ctx->timing_valid == 1) PR_HIP(ctx, hipEventRecord(ctx->ev_t[3], ctx->stream));
   if (q->type == PR_TYPE_SC) pr::launch_nan_fixup(ctx->stream, d_p, d_i, q->count, db->count, q->bad, db->bad);   // processSC.m:16,19
   PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+int pr_set_sc_binary(pr_ctx* ctx, int on) {
+  if (!ctx) return PR_EINVAL;
+  ctx->sc_binary = on != 0;
+  return PR_OK;
+}
+
+int pr_set_kernel_timing(pr_ctx* ctx, int on) {
+  if (!ctx) return PR_EINVAL;
+  if (int rc = set_device(ctx)) return rc;
+  if (on) for (auto& e : ctx->ev_t) if (!e) PR_HIP(ctx, hipEventCreate(&e));
+  ctx->timing = on != 0;
+  ctx->timing_valid = 0;
+  return PR_OK;
+}
+
+int pr_last_distance_timing(pr_ctx* ctx, float* ms) {
+  if (!ctx || !ms) return PR_EINVAL;
+  if (!ctx->timing || !ctx->timing_valid) PR_FAIL(ctx, PR_EINVAL, "pr_last_distance_timing: no timed pr_distances_dev call (pr_set_kernel_timing)");
+  if (int rc = set_device(ctx)) return rc;
+  PR_HIP(ctx, hipEventSynchronize(ctx->ev_t[3]));
+  ms[0] = ms[1] = ms[2] = 0.f;
+  if (ctx->timing_valid == 3) {
+    PR_HIP(ctx, hipEventElapsedTime(&ms[0], ctx->ev_t[0], ctx->ev_t[1]));
+    PR_HIP(ctx, hipEventElapsedTime(&ms[1], ctx->ev_t[1], ctx->ev_t[2]));
+    PR_HIP(ctx, hipEventElapsedTime(&ms[2], ctx->ev_t[2], ctx->ev_t[3]));
+  } else {
+    PR_HIP(ctx, hipEventElapsedTime(&ms[0], ctx->ev_t[0], ctx->ev_t[3]));
+  }
+  return PR_OK;
+}
+
+int pr_sc_binary_state(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, int32_t* state) {
+  if (!ctx || !q || !db || !state) return PR_EINVAL;
+  if (int rc = set_device(ctx)) return rc;
+  *state = 0;
+  if (!q->binfo || !db->binfo || !ctx->sc_binary) return PR_OK;
+  int hq[pr::SC_BSTAT_INTS], hd[pr::SC_BSTAT_INTS];
+  PR_HIP(ctx, hipMemcpyAsync(hq, sigset_bstat(q), sizeof hq, hipMemcpyDeviceToHost, ctx->stream));
+  PR_HIP(ctx, hipMemcpyAsync(hd, sigset_bstat(db), sizeof hd, hipMemcpyDeviceToHost, ctx->stream));
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  auto fl = [](int b) { float f; memcpy(&f, &b, 4); return f; };
+  // the arithmetic of sc_bin_fast (sc_match_e.hip), float for float
+  const float eq = std::sqrt(((fl(hq[2]) + fl(hq[3])) + fl(hq[4])) + fl(hq[5])), ed = std::sqrt(((fl(hd[2]) + fl(hd[3])) + fl(hd[4])) + fl(hd[5]));
+  const float bound = (eq + ed + eq * ed + ctx->sc_bconst * (1.f + eq) * (1.f + ed)) * 1.001f;
+  *state = (hq[0] == 0 && hd[0] == 0 && bound * std::sqrt((float)hq[1] * (float)hd[1]) < 0.72f) ? 1 : 0;
+  if (*state) {      // ... and what the last call's rounding tests said (the flag lives until the next call's channel-0 launch)
+    int viol = 0;
+    PR_HIP(ctx, hipMemcpyAsync(&viol, ctx->d_flags + 4, sizeof viol, hipMemcpyDeviceToHost, ctx->stream));
+    PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (viol) *state = 2;
+  }
   return PR_OK;
 }
 

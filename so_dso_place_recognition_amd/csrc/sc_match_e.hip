@@ -79,12 +79,14 @@ __device__ __forceinline__ void load_a(AOps& a, unsigned addr) {   // addr = thi
   const u32x4 v = *reinterpret_cast<lds_tile_p>(addr + T * 40);
   if (T == A_H) a.h = v; else a.l = v;
 }
-template <bool LO, int F, int T>
+template <bool LO, int F, int T, bool SV = false>
 __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int voff) {
   // split-f16 image: [f][Re hi | Re lo | Im hi | Im lo]; single-product image: [f][Re | Im]
   // split-f16 form: the frequency in the scalar offset (one SGPR per walk position, kept), the tile added to the lane offset - 64 s_mov per
   // unit less, -0.6 %; the single-product form (registers are scarcer there) keeps everything in the scalar offset
-  constexpr int soff = LO ? F * SCH_DFREQ : F * SCF_DFREQ + (T == B_IMH ? 1 : 0) * SCH_DTILE, ioff = LO ? T * SCH_DTILE : 0;
+  // SV: the single-product form reading the hi tiles of a split-f16 image
+  constexpr int soff = LO ? F * SCH_DFREQ : SV ? F * SCH_DFREQ + (T == B_IMH ? 2 : 0) * SCH_DTILE : F * SCF_DFREQ + (T == B_IMH ? 1 : 0) * SCH_DTILE,
+                ioff = LO ? T * SCH_DTILE : 0;
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ioff, soff, 0);
   if (T == B_REH) b.reh = v; else if (T == B_REL) b.rel = v; else if (T == B_IMH) b.imh = v; else b.iml = v;
 }
@@ -216,6 +218,31 @@ __device__ __forceinline__ void ep_store(float mx, __amdgpu_buffer_rsrc_t rd, in
   mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));     // max over the two lane halves (shift rows +0..3 | +4..7)
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(mx, -0x1p-26f, 0.5f)), rd, st_off, 0, 0);
 }
+// the same for a binary channel (kernels.hpp: ScBin): x = max x 2^-25 x sqrt(ones_q ones_d) is the integer count of the best variant up to the
+// pass's error, which is at most b = bnd x sqrt(ones_q ones_d) for EVERY variant of the pair (sc_bin_bound).  If |x - rint(x)| + b < 1, then
+// rint(x) is the largest count: the best variant's own count is the only integer within b of x, and no other variant's count (at most its
+// value + b <= x + b < rint(x) + 1) exceeds it.  d = (1 - count / sqrt(ones_q ones_d)) / 2 from that integer (processSC.m:30); a pair that
+// fails the test raises `viol` and the whole channel is redone by the split-f16 kernel behind this one.
+// qi = {sqrt(ones_q) 2^-25, 1/sqrt(ones_q)} of this lane's query, di = {sqrt(ones_d), 1/sqrt(ones_d)} of its entry, bnd = bound x 2^25
+__device__ __forceinline__ void ep_store_round(float mx, f32x2 qi, f32x2 di, float bnd, int& viol, __amdgpu_buffer_rsrc_t rd, int st_off) {
+  const u32x2 sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+  mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  const float nn = qi[0] * di[0], x = mx * nn, cnt = __builtin_rintf(x);
+  viol |= (st_off >= 0 && !(__builtin_fmaf(bnd, nn, __builtin_fabsf(x - cnt)) < 0.98f)) ? 1 : 0;      // (lanes without a store: st_off < 0)
+  __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(cnt * (qi[1] * di[1]), -0.5f, 0.5f)), rd, st_off, 0, 0);
+}
+// The error bound of the single-product pass over a binary channel, evaluated by every workgroup from the same numbers (kernels.hpp: ScBin;
+// derivation in DESIGN.md §4.0b): with eq, ed the largest w-weighted residual norms of the hi spectra of the two sets, every variant product
+// of a pair is within sqrt(ones_q ones_d) x bound of its integer count, bound = eq + ed + eq ed + bconst (1 + eq)(1 + ed).  Returns whether
+// the pass is worth running: both sets binary and the largest pair's bound below 0.72 of a count (the pass's actual error, ~6 x 7.6e-5 per
+// unit of sqrt(ones_q ones_d) at most, then leaves the per-pair test of ep_store_round room).
+__device__ __forceinline__ bool sc_bin_bound(const ScBin& b, float& bound) {
+  const int q0 = b.qstat[0], q1 = b.qstat[1], d0 = b.dstat[0], d1 = b.dstat[1];
+  const float eq = __builtin_sqrtf(((__int_as_float(b.qstat[2]) + __int_as_float(b.qstat[3])) + __int_as_float(b.qstat[4])) + __int_as_float(b.qstat[5]));
+  const float ed = __builtin_sqrtf(((__int_as_float(b.dstat[2]) + __int_as_float(b.dstat[3])) + __int_as_float(b.dstat[4])) + __int_as_float(b.dstat[5]));
+  bound = (eq + ed + eq * ed + b.bconst * (1.f + eq) * (1.f + ed)) * 1.001f;
+  return q0 == 0 && d0 == 0 && bound * __builtin_sqrtf((float)q1 * (float)d1) < 0.72f;
+}
 
 // ---------------------------------------------------------------------------------------------------------------- stage-1 schedule
 // The 32 walk positions of a unit form 8 quads (4 per half); quad QD computes T1 / T2' of frequencies (2E, 2E+8, 2E+1, 2E+9) of its half
@@ -286,27 +313,60 @@ __device__ __forceinline__ void valu_slot(f32x4 (&T)[2][8], Half<LO> (&hbs)[2]) 
 
 // NQG = query groups (of 8) a workgroup holds in LDS: 4 (split-f16), 8 (single product), or 1 (single product, m <= 8: an online call - all
 // eight waves share the one group and split the DB groups, 20 KB of LDS, several workgroups per CU)
-template <bool LO, int NW, int NQG>
+// SV (single-product form only): the kernel reads the hi halves of SPLIT-f16 images (the query groups are gathered into the compact LDS
+// image, the DB loads address the hi tiles) and rounds the result to the integer count of a binary channel (ep_store_round)
+template <bool LO, int NW, int NQG, bool SV = false>
 __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char* __restrict__ qpk,   // [2][QG32][4][31][1288 B]
                                                             const char* __restrict__ dpk,   // [2][DG][31][4][768 B] + zero groups
                                                             const u32x4* __restrict__ cst,  // [2][2][2][64] x 16 B
                                                             float* __restrict__ dist_p, float* __restrict__ dist_i,
-                                                            int m, int n, int QG8, int DG, int nsplit) {
+                                                            int m, int n, int QG8, int DG, int nsplit, ScBin bin) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  static_assert(!SV || !LO, "SV: single-product form");
+  float bbound = 0.f;
+  if (bin.gate) {      // (workgroup-uniform: scalar loads of six numbers per set)
+    const bool pred = sc_bin_bound(bin, bbound);
+    if (bin.gate == 1 ? !pred : (pred && *bin.viol == 0)) return;      // gate 2: the split-f16 kernel behind the single-product one
+  } else if (bin.viol && blockIdx.x == 0 && threadIdx.x == 0) {
+    *bin.viol = 0;       // the channel-0 launch in front of the two: nothing violated yet
+  }
+  [[maybe_unused]] const float bnd25 = bbound * 0x1p25f;
+  [[maybe_unused]] int viol = 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-  // XCD-aware mapping as in sc_match_d.hip: all workgroups of an XCD work on ONE channel and the same quarter of the DB ranges
+  // XCD-aware mapping as in sc_match_d.hip: all workgroups of an XCD work on ONE channel and the same quarter of the DB ranges;
+  // chsel >= 0: one channel on all eight XCDs, an eighth of the ranges each
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int ch = xcd & 1;
-  const int range = (xcd >> 1) + 4 * (idx % nsplit), qg32 = idx / nsplit;
-  const int nrange = 4 * nsplit;
+  const int ch = bin.chsel < 0 ? (xcd & 1) : bin.chsel;
+  const int range = (bin.chsel < 0 ? (xcd >> 1) + 4 * (idx % nsplit) : xcd + 8 * (idx % nsplit)), qg32 = idx / nsplit;
+  const int nrange = (bin.chsel < 0 ? 4 : 8) * nsplit;
   const int g0 = (int)((long long)DG * range / nrange), g1 = (int)((long long)DG * (range + 1) / nrange);
 
   // image geometry: split-f16 (4 query groups per workgroup) | single product (hi halves only: 8 query groups, kernels.hpp SCF_*)
-  constexpr int QBLK = LO ? SCH_QBLK : SCF_QBLK, QIMG = LO ? SCH_QIMG : SCF_QIMG, DIMG = LO ? SCH_DIMG : SCF_DIMG;
+  constexpr int QBLK = LO ? SCH_QBLK : SCF_QBLK, QIMG = LO ? SCH_QIMG : SCF_QIMG, DIMG = (LO || SV) ? SCH_DIMG : SCF_DIMG;
   constexpr int QROW = LO ? 80 : 40;
   static_assert(NW == 4 || !LO, "two waves per SIMD: single-product form only (a split-f16 unit needs all 512 registers)");
-  {  // the query groups of this workgroup -> LDS (linear copy; the packed image IS the LDS image) + zeroed tail
+  if constexpr (SV) {  // the hi halves of this workgroup's query groups of the split image -> the compact LDS image, 8 bytes at a time:
+    // compact block (group, f) = 81 words: rows 0..7 (5 words each), one pad word, rows 8..15; split block = 1288 B, row = 80 B (hi | lo)
+    constexpr int WPG = SC_NF * 81;
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(lds);
+    for (int i = tid; i < NQG * WPG + 8; i += 64 * NW) {
+      const int grp = i / WPG, rem = i - grp * WPG, f = rem / 81, j = rem - f * 81;
+      const int gq = qg32 * NQG + grp;
+      const int jj = j > 40 ? j - 41 : j, rr = (j > 40 ? 8 : 0) + jj / 5, c = jj - (jj / 5) * 5;
+      unsigned long long v = 0ull;
+      if (i < NQG * WPG && gq < QG8 && j != 40)
+        v = *reinterpret_cast<const unsigned long long*>(qpk + ((size_t)ch * QG8 + gq) * SCH_QIMG + (size_t)f * SCH_QBLK + rr * 80 + (rr >= 8 ? 8 : 0) + c * 8);
+      dst[i] = v;
+    }
+    // ... and behind the image {sqrt(ones) 2^-25, 1/sqrt(ones)} of the workgroup's 8 NQG queries (ep_store_round)
+    float* qi = reinterpret_cast<float*>(lds + NQG * QIMG + 64);
+    for (int i = tid; i < 8 * NQG; i += 64 * NW) {
+      const int r = qg32 * (8 * NQG) + i;
+      qi[2 * i] = r < m ? bin.qinfo[2 * r] * 0x1p-25f : 0.f;
+      qi[2 * i + 1] = r < m ? bin.qinfo[2 * r + 1] : 0.f;
+    }
+  } else {  // the query groups of this workgroup -> LDS (linear copy; the packed image IS the LDS image) + zeroed tail
     const u32x4* src = reinterpret_cast<const u32x4*>(qpk + ((size_t)ch * QG8 + (size_t)qg32 * NQG) * QIMG);
     u32x4* dst = reinterpret_cast<u32x4*>(lds);
     constexpr int NV = NQG * QIMG / 16;
@@ -330,10 +390,16 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
       dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 8 ? m - qrow0 : 8) : 0) * n * 4, 0x00020000);
   const int pf_slot = (qg32 & 31) * NW + w;                                  // this wave's share of the group(s) it helps to prefetch
-  constexpr int PFL = LO ? 6 : 2;                                            // cache lines per wave: 32 NW waves cover the GSTEP x DIMG / 128 lines
+  constexpr int PFL = LO ? 6 : 2;                                            // cache lines per wave: 32 NW waves cover the GSTEP x DIMG / 128 lines (SV: the 372 lines of the hi tiles)
   unsigned pf_sink = 0;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(cst), 0, 8192, 0x00020000);
   if (dpar >= gcnt) return;
+  f32x2 qinf[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};      // SV: of this lane's query of store R: row R (lanes 0-15) | 4 + R (16-31)
+  if constexpr (SV) {
+    const f32x2* qi = reinterpret_cast<const f32x2*>(lds + NQG * QIMG + 64);
+#pragma unroll
+    for (int r = 0; r < 4; r++) qinf[r] = qi[wq * 8 + r + ((lane & 16) ? 4 : 0)];
+  }
 
   AOps At[AD];
   BOps Bt[BD];
@@ -346,7 +412,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   { if constexpr ((K) < (BD - 1) * TPB) {                                                                          \
       constexpr int _p = (K) / TPB, _t = LO ? (K) % TPB : 2 * ((K) % TPB);      /* order Re hi, (Re lo), Im hi, (Im lo) */ \
       constexpr int _tt = LO ? (_t == 1 ? B_IMH : _t == 2 ? B_REL : _t == 3 ? B_IML : B_REH) : _t;                 \
-      load_b<LO, seqf(_p), _tt>(Bt[_p % BD], RSRC, voff);                                                              \
+      load_b<LO, seqf(_p), _tt, SV>(Bt[_p % BD], RSRC, voff);                                                          \
     } else if constexpr ((K) < NREQ) {                                                                             \
       constexpr int _k = (K) - (BD - 1) * TPB, _p = _k / TPA, _t = _k % TPA;                                       \
       load_a<_t>(At[_p % AD], nat0 + seqf(_p) * QBLK);                                                         \
@@ -365,7 +431,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
     f32x4 T[2][8];
 
 // request tile T of walk position Q of this unit (Q >= 31: nothing)
-#define LDB(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || (TT == B_REH || TT == B_IMH))) load_b<LO, seqf((Q) < 32 ? (Q) : 0), TT>(Bt[(Q) % BD], rs, voff); }
+#define LDB(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || (TT == B_REH || TT == B_IMH))) load_b<LO, seqf((Q) < 32 ? (Q) : 0), TT, SV>(Bt[(Q) % BD], rs, voff); }
 #define LDA(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || TT == A_H)) load_a<TT>(At[(Q) % AD], nat0 + seqf((Q) < 32 ? (Q) : 0) * QBLK); }
 #define VS(P, G) valu_slot<LO, ((P) >> 2), (((P) & 3) * 6 + (G))>(T, hbs)
 // one walk position: its 6 (LO) or 2 MFMAs, the requests for positions P + AD - 1 (query tiles) and P + BD - 1 (DB tiles), the quad's VALU
@@ -422,7 +488,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
       const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)gp * DIMG), 0, pf_bytes, 0x00020000);
       int lp = lane;
       asm volatile("" : "+v"(lp));
-      const int pf_off = (lp < PFL) ? (pf_slot * PFL + lp) * 128 : (int)0x80000000;   // waves x PFL lines >= 744 lines per group
+      int pf_off = (lp < PFL) ? (pf_slot * PFL + lp) * 128 : (int)0x80000000;   // waves x PFL lines >= 744 lines per group
+      if constexpr (SV) {                      // line L of the group's 31 x 2 hi tiles (6 lines each) -> its place in the split image
+        const int L = pf_slot * PFL + lp, f = L / 12, r = L - f * 12;
+        pf_off = (lp < PFL && L < SC_NF * 12) ? f * SCH_DFREQ + (r >= 6 ? 2 * SCH_DTILE : 0) + (r >= 6 ? r - 6 : r) * 128 : (int)0x80000000;
+      }
       pf_sink = __builtin_amdgcn_raw_buffer_load_b32(rp, pf_off, 0, 0);
     }
     // ---------------------------------------------------------------- stage 2: group S = 2 R + V, its MFMAs into a fresh (E, O) tile pair;
@@ -433,6 +503,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
     asm volatile("" : "+v"(le));
     const int st_lane = ((le & 16) ? 4 * n : 0) * 4 + (le & 15) * 4;
     const int st_base = (le < 32 && g * 16 + (le & 15) < n) ? st_lane : (int)0x80000000;
+    f32x2 dinf = {0.f, 0.f};
+    if constexpr (SV) {                        // {sqrt(ones), 1/sqrt(ones)} of this lane's entry (entries past n: 0 -> count 0, store out of range)
+      const int e = g * 16 + (le & 15);
+      const float* dp = bin.dinfo + 2 * (size_t)(e < n ? e : 0);
+      dinf = f32x2{dp[0], dp[1]};
+    }
 #define S2I(S, I) s2_one<LO, (NW == 4), ((S) >> 1), ((S) & 1), I>(hbs[0], hbs[1], c0, c1, tE[(S) & 1], tO[(S) & 1])
 #define S2G(S, W0, W1, W2, W3, W4, W5, W6, W7, W8, W9, W10, W11)                                   \
   { if constexpr (LO) {                                                                            \
@@ -443,8 +519,14 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   } else {                                                                                         \
     SB(); S2I(S, 0); SB(); W0; W1; W2; SB(); S2I(S, 1); SB(); S2I(S, 2); SB(); W3; W4; W5;         \
     W6; W7; W8; SB(); S2I(S, 3); SB(); W9; W10; W11; SB(); } }
-#define RP(S, i) mx = red_piece(mx, tE[(S) & 1], tO[(S) & 1], i)
-#define ST(S) { ep_store(mx, rd, st_base + ((S) >> 1) * 4 * n + g * 64); mx = -__builtin_inff(); }
+// (single-product form: the first piece of a tile pair's reduction carries an empty volatile asm that names the tiles - volatile statements
+// keep their order, so the reduction stays behind the three MFMAs of the next group that the schedule puts in front of it; hipcc otherwise
+// hoisted the pure reduction up to the tile's last MFMA in the SV form and reused the registers for the next group: a read 5 wait states
+// behind an asm MFMA that nothing pads - tools/audit_asm_hazards.py)
+#define RP(S, i) { if constexpr (!LO && (i) == 0) asm volatile("" : "+v"(tE[(S) & 1]), "+v"(tO[(S) & 1])); mx = red_piece(mx, tE[(S) & 1], tO[(S) & 1], i); }
+#define ST(S) { if constexpr (SV) ep_store_round(mx, qinf[(S) >> 1], dinf, bnd25, viol, rd, st_base + ((S) >> 1) * 4 * n + g * 64);   \
+                else ep_store(mx, rd, st_base + ((S) >> 1) * 4 * n + g * 64);                                                  \
+                mx = -__builtin_inff(); }
 #define NX(K) FIRST_REQ(K, rsn)
 #define NONE ((void)0)
     S2G(0, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE, NONE)
@@ -455,17 +537,20 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
     S2G(5, NX(7), NX(8), NX(9), RP(4, 0), RP(4, 1), RP(4, 2), RP(4, 3), RP(4, 4), RP(4, 5), RP(4, 6), RP(4, 7), NX(23))
     S2G(6, NX(10), NX(11), NX(12), RP(5, 0), RP(5, 1), RP(5, 2), RP(5, 3), RP(5, 4), RP(5, 5), RP(5, 6), RP(5, 7), ST(5))
     S2G(7, NX(13), NX(14), NX(15), RP(6, 0), RP(6, 1), RP(6, 2), RP(6, 3), RP(6, 4), RP(6, 5), RP(6, 6), RP(6, 7), NONE)
-    asm volatile("s_nop 15\n\ts_nop 15");          // the last tiles are read next: nothing pads an asm MFMA
+    // the last tiles are read next and nothing pads an asm MFMA; the tiles are operands of the statement, so their readers stay behind it
+    // (without them hipcc hoisted the reduction above the nops in the SV form: stale tiles for the unit's last two queries)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+v"(tE[1]), "+v"(tO[1]));
     SB();
     RP(7, 0); RP(7, 1); RP(7, 2); RP(7, 3); RP(7, 4); RP(7, 5); RP(7, 6); RP(7, 7);
     ST(7)
     rs = rsn;
   }
+  if constexpr (SV) { if (__any(viol)) { if (lane == 0) atomicOr(bin.viol, 1); } }
 }
 
 }  // namespace
 
-size_t sc_match_e_lds_bytes(int single, int nqg) { return (single ? (size_t)nqg * SCF_QIMG : (size_t)4 * SCH_QIMG) + 64; }
+size_t sc_match_e_lds_bytes(int single, int nqg) { return (single ? (size_t)nqg * SCF_QIMG : (size_t)4 * SCH_QIMG) + 64 + (single ? 64 * nqg : 0); }
 
 void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                        int nsplit_override, int single) {
@@ -478,14 +563,46 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
   if (nsplit < 1) nsplit = 1;
   if (nqg == 1) nsplit = DG / 128 > 0 ? DG / 128 : 1;   // an online call: ~32 DB groups per workgroup, 4 per wave; ~400 workgroups at n = 100k
   if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
+  const ScBin none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, -1};
   auto go = [&](auto kern, int nw) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(single, nqg));
     hipLaunchKernelGGL(kern, dim3(8 * QGW * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(single, nqg), st, static_cast<const char*>(qpk),
-                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit);
+                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, none);
   };
   if (single && m <= 8) go(sc_match_e_kernel<false, 8, 1>, 8);
   else if (single) go(sc_match_e_kernel<false, 8, 8>, 8);
   else go(sc_match_e_kernel<true, 4, 4>, 4);
+}
+
+// (kernels.hpp) split-f16 images, m > 8: channel 0 in split-f16 on all XCDs; channel 1 twice -
+// the single-product kernel on the hi halves with integer rounding (leaves at once when the bound does not hold), then the split-f16 kernel
+// (leaves at once when that pass ran and every pair passed its rounding test)
+void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
+                           int nsplit_override, ScBin bin, hipEvent_t* ev) {
+  if (m <= 0 || n <= 0) return;
+  const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n);
+  auto grid = [&](int QGW) {     // ranges per XCD: >= ~4 workgroups per CU in total, >= 8 DB groups per workgroup (an eighth of the ranges per XCD)
+    int nsplit = (128 + QGW - 1) / QGW;
+    if (nsplit > DG / 64) nsplit = DG / 64;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit_override > 0) nsplit = nsplit_override * 8 <= DG ? nsplit_override : (DG >= 8 ? DG / 8 : 1);
+    return nsplit;
+  };
+  auto go = [&](auto kern, int nw, int nqg, int single, int chsel, int gate) {
+    const int QGW = (QG8 + nqg - 1) / nqg, nsplit = grid(QGW);
+    ScBin b = bin;
+    b.chsel = chsel; b.gate = gate;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(single, nqg));
+    hipLaunchKernelGGL(kern, dim3(8 * QGW * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(single, nqg), st, static_cast<const char*>(qpk),
+                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, b);
+  };
+  if (ev) (void)hipEventRecord(ev[0], st);
+  go(sc_match_e_kernel<true, 4, 4>, 4, 4, 0, 0, 0);                 // channel 0 (and *viol = 0)
+  if (ev) (void)hipEventRecord(ev[1], st);
+  go(sc_match_e_kernel<false, 8, 8, true>, 8, 8, 1, 1, 1);          // channel 1, one product per term + rounding: runs when the bound predicts success
+  if (ev) (void)hipEventRecord(ev[2], st);
+  go(sc_match_e_kernel<true, 4, 4>, 4, 4, 0, 1, 2);                 // channel 1 in split-f16: runs when it did not run, or a pair failed its test
+  if (ev) (void)hipEventRecord(ev[3], st);
 }
 
 }  // namespace pr

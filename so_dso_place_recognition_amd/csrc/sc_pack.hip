@@ -177,11 +177,15 @@ __global__ __launch_bounds__(320) void sc_pack_h_kernel(const T* __restrict__ si
 //   norm      = every lane sums the squares of its column, the 20 partial sums of a signature are added in ring order
 //   output    = hi / lo halves scattered into an LDS copy of the workgroup's 8 frequency slices of the group image
 //               (a slice is contiguous: 3072 B per DB group, 1288 B per query group), then copied out linearly.
+// Binary-channel statistics (kernels.hpp: ScBin; LO images only, channel 1, binfo != null): the frequency-block-0 workgroup of a row block
+// decides whether each row is binary (all non-zero entries equal and positive) and leaves binfo / bstat[0..1]; every workgroup adds up the
+// w-weighted squares of the rounding residuals val - hi of its own frequencies (in units of the normalised spectrum) per row and keeps the
+// largest in bstat[2 + fb] - all by atomicOr / atomicMax, whose result does not depend on the order.
 template <typename T, int ROLE, bool LO>
 __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict__ sig, int rows,
                                                              unsigned short* __restrict__ packed, int groups,
                                                              const double* __restrict__ tw, int* __restrict__ flags,
-                                                             int* __restrict__ bad) {
+                                                             int* __restrict__ bad, float* __restrict__ binfo, int* __restrict__ bstat) {
   // LO = false: the single-product images (hi halves only, kernels.hpp SCF_*)
   constexpr int SL = ROLE == 0 ? (LO ? SCH_QBLK : SCF_QBLK) : (LO ? SCH_DFREQ : SCF_DFREQ);   // bytes of one (group, frequency) slice
   constexpr int NG = ROLE == 0 ? 2 : 1;                         // groups per 16 signatures
@@ -189,6 +193,8 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
   constexpr int QROW = LO ? 80 : 40;                            // bytes per query row: Q hi | Q lo
   __shared__ __attribute__((aligned(16))) char img[NG * 8 * SL];
   __shared__ double part[16 * 20];
+  __shared__ double bmn[LO ? 320 : 1], bmx[LO ? 320 : 1], epart[LO ? 320 : 1];
+  __shared__ int bnz[LO ? 320 : 1];
   const int tid = threadIdx.x, lrow = tid / 20, ring = tid - 20 * lrow;
   // workgroups go round-robin to the 8 XCDs (each with its own L2): the four frequency blocks of the same 16 signatures -
   // which read the same input - are consecutive workgroups of ONE XCD, so HBM sees the input once
@@ -201,6 +207,9 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
   const T* src = sig + (size_t)(valid ? row : 0) * 2400 + ch * 1200 + ring;   // lanes past the end redo signature 0 and drop it
   double ce[4] = {0, 0, 0, 0}, co[4] = {0, 0, 0, 0}, se[4] = {0, 0, 0, 0}, so[4] = {0, 0, 0, 0};
   double nsq = 0.0;
+  const bool do_eps = LO && binfo != nullptr && ch == 1, do_bin = do_eps && fb == 0;     // workgroup-uniform
+  int nz = 0;
+  double vmn = __builtin_inf(), vmx = -__builtin_inf(), e2 = 0.0;
   const double* twc = tw + 120 + (size_t)fb * 60 * 8;           // [sector][j]{cos, sin}, wave-uniform
   // rolled loop over 4 sectors at a time, the column values requested two rounds (8 sectors) ahead of their use
   T xq[3][4];
@@ -218,6 +227,10 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
       const double x0 = (double)xq[it % 3][2 * h], x1 = (double)xq[it % 3][2 * h + 1];
       nsq += x0 * x0;
       nsq += x1 * x1;
+      if (do_bin) {
+        if (x0 != 0.0) { nz++; vmn = fmin(vmn, x0); vmx = fmax(vmx, x0); }
+        if (x1 != 0.0) { nz++; vmn = fmin(vmn, x1); vmx = fmax(vmx, x1); }
+      }
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         ce[j] += x0 * tp[h * 16 + 2 * j];
@@ -228,6 +241,7 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
     }
   }
   part[tid] = nsq;
+  if (LO && do_bin) { bnz[tid] = nz; bmn[tid] = vmn; bmx[tid] = vmx; }
   __syncthreads();
   double n2 = 0.0;
 #pragma unroll
@@ -235,6 +249,16 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
   const double nr = sqrt(n2);
   const bool isbad = !(nr > 0.0) || !(nr < __builtin_inf());   // MATLAB: NaN row -> zeros here + bad[row], see sc_pack_kernel
   if (valid && ring == 0 && fb == 0) { bad[2 * row + ch] = isbad ? (1 << ch) : 0; if (isbad) atomicOr(flags, 1); }
+  if (LO && do_bin && valid && ring == 0) {
+    int ones = 0;
+    double mn = __builtin_inf(), mx = -__builtin_inf();
+    for (int r = 0; r < 20; r++) { ones += bnz[lrow * 20 + r]; mn = fmin(mn, bmn[lrow * 20 + r]); mx = fmax(mx, bmx[lrow * 20 + r]); }
+    const bool binary = ones > 0 && mn == mx && mn > 0.0;
+    float s = 1.f, rs = 1.f;
+    if (!isbad && binary) { s = (float)sqrt((double)ones); rs = (float)(1.0 / sqrt((double)ones)); atomicMax(bstat + 1, ones); }
+    if (!isbad && !binary) atomicOr(bstat, 1);
+    binfo[2 * row] = s; binfo[2 * row + 1] = rs;
+  }
   const double sc = isbad ? 0.0 : 0.12909944487358055 * (ROLE == 0 ? 256.0 : 128.0) / nr;   // 1/sqrt(60) x 2^8 | 2^7, over the norm (processSC.m:16,19)
   auto put = [&](double val, int slice, int im) {
     if (isbad) val = 0.0;
@@ -258,6 +282,11 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
     }
     *reinterpret_cast<_Float16*>(img + bh) = hi;
     if (LO) *reinterpret_cast<_Float16*>(img + bl) = lo;
+    if (LO && do_eps) {                                   // residual of the hi half, weight w_f = 1 (f = 0, 30) | 2
+      const double r = (val - (double)hi) * (ROLE == 0 ? 0x1p-8 : 0x1p-7);
+      const bool edge = (fb == 0 && (slice & 3) == 0);    // slice 0 of block 0: f = 0, slice 4: f = 30
+      e2 += (edge ? 1.0 : 2.0) * r * r;
+    }
   };
   if (valid) {
 #pragma unroll
@@ -270,7 +299,13 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
       }
     }
   }
+  if (LO && do_eps) epart[tid] = e2;
   __syncthreads();
+  if (LO && do_eps && valid && ring == 0 && !isbad) {
+    double e = 0.0;
+    for (int r = 0; r < 20; r++) e += epart[lrow * 20 + r];
+    atomicMax(bstat + 2 + fb, __float_as_int((float)(e * (1.0 + 0x1p-20))));     // (non-negative floats order like their bit patterns)
+  }
   // slice (group gg, k) -> frequency (k < 4 ? 4 fb + k : 30 - 4 fb - (k - 4)) of group NG blk + gg
   constexpr int W = SL / 8;                               // 8-byte words per slice
   for (int i = tid; i < NG * 8 * W; i += 320) {
@@ -290,19 +325,37 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
 // - raw sums over the even / odd sectors in sector order, the column's square sum in the same order, the 20 column sums added in ring order,
 // one scale factor - so the image is bit for bit the one that kernel writes.  The workgroup writes only its own row of the group image (the
 // caller has zeroed the image).
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
 template <typename T, int ROLE, bool LO>
 __global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict__ sig, int rows, unsigned short* __restrict__ packed, int groups,
-                                                             const double* __restrict__ tw, int* __restrict__ flags, int* __restrict__ bad) {
+                                                             const double* __restrict__ tw, int* __restrict__ flags, int* __restrict__ bad,
+                                                             float* __restrict__ binfo, int* __restrict__ bstat) {
   constexpr int SL = ROLE == 0 ? (LO ? SCH_QBLK : SCF_QBLK) : (LO ? SCH_DFREQ : SCF_DFREQ);
   constexpr int IMGB = ROLE == 0 ? (LO ? SCH_QIMG : SCF_QIMG) : (LO ? SCH_DIMG : SCF_DIMG);
   constexpr int QROW = LO ? 80 : 40;
   __shared__ double x[1200];
   __shared__ double tws[120];
   __shared__ double part[20];
+  __shared__ double wred[5][3];
   const int tid = threadIdx.x, f = tid / 20, ring = tid - 20 * f;
   const int row = blockIdx.x >> 1, ch = blockIdx.x & 1;
   const T* src = sig + (size_t)row * 2400 + ch * 1200;
-  for (int i = tid; i < 1200; i += 320) x[i] = (double)src[i];
+  const bool do_bin = LO && binfo != nullptr && ch == 1;    // binary-channel statistics, as in sc_pack_h_col_kernel (the row's whole residual
+  double bz = 0.0, bmn_ = __builtin_inf(), bmx_ = -__builtin_inf();   // sum goes to bstat[2])
+  for (int i = tid; i < 1200; i += 320) {
+    const double v = (double)src[i];
+    x[i] = v;
+    if (do_bin && v != 0.0) { bz += 1.0; bmn_ = fmin(bmn_, v); bmx_ = fmax(bmx_, v); }
+  }
+  if (do_bin) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { bz += __shfl_xor(bz, o); bmn_ = fmin(bmn_, __shfl_xor(bmn_, o)); bmx_ = fmax(bmx_, __shfl_xor(bmx_, o)); }
+    if ((tid & 63) == 0) { wred[tid >> 6][0] = bz; wred[tid >> 6][1] = bmn_; wred[tid >> 6][2] = bmx_; }
+  }
   if (tid < 120) tws[tid] = tw[tid];
   __syncthreads();
   double ce = 0.0, co = 0.0, se = 0.0, so = 0.0, nsq = 0.0;
@@ -327,8 +380,18 @@ __global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict_
   const double nr = sqrt(n2);
   const bool isbad = !(nr > 0.0) || !(nr < __builtin_inf());
   if (tid == 0) { bad[2 * row + ch] = isbad ? (1 << ch) : 0; if (isbad) atomicOr(flags, 1); }
+  if (do_bin && tid == 0) {
+    double ones = 0.0, mn = __builtin_inf(), mx = -__builtin_inf();
+    for (int w5 = 0; w5 < 5; w5++) { ones += wred[w5][0]; mn = fmin(mn, wred[w5][1]); mx = fmax(mx, wred[w5][2]); }
+    const bool binary = ones > 0.0 && mn == mx && mn > 0.0;
+    float s = 1.f, rs = 1.f;
+    if (!isbad && binary) { s = (float)sqrt(ones); rs = (float)(1.0 / sqrt(ones)); atomicMax(bstat + 1, (int)ones); }
+    if (!isbad && !binary) atomicOr(bstat, 1);
+    binfo[2 * row] = s; binfo[2 * row + 1] = rs;
+  }
   const double sc = isbad ? 0.0 : 0.12909944487358055 * (ROLE == 0 ? 256.0 : 128.0) / nr;
   char* out = reinterpret_cast<char*>(packed);
+  double e2 = 0.0;
   auto put = [&](double val, int ff, int im) {
     if (isbad) val = 0.0;
     float vf = (float)val;
@@ -337,6 +400,10 @@ __global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict_
     float rf = (float)(val - (double)hi);
     asm volatile("" : "+v"(rf));
     const _Float16 lo = (_Float16)rf;
+    if (do_bin) {
+      const double r = (val - (double)hi) * (ROLE == 0 ? 0x1p-8 : 0x1p-7);
+      e2 += ((ff == 0 || ff == 30) ? 1.0 : 2.0) * r * r;
+    }
     size_t bh;
     if (ROLE == 0) {
       const int g = row >> 3, rr = (im << 3) | (row & 7);
@@ -356,16 +423,29 @@ __global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict_
     put((ce - co) * sc, 30 - f, 0);
     put((se - so) * sc, 30 - f, 1);
   }
+  if (do_bin) {                                           // (workgroup-uniform)
+    e2 = wave_sum(e2);
+    __syncthreads();                                      // wred was read by thread 0 above
+    if ((tid & 63) == 0) wred[tid >> 6][0] = e2;
+    __syncthreads();
+    if (tid == 0 && !isbad) {
+      double e = 0.0;
+      for (int w5 = 0; w5 < 5; w5++) e += wred[w5][0];
+      atomicMax(bstat + 2, __float_as_int((float)(e * (1.0 + 0x1p-20))));
+    }
+  }
 }
 
 template <typename T, int ROLE, bool LO = true>
-void launch_pack_col(hipStream_t st, const T* sig, int rows, unsigned short* packed, int groups, const double* tw, int* flags, int* bad) {
+void launch_pack_col(hipStream_t st, const T* sig, int rows, unsigned short* packed, int groups, const double* tw, int* flags, int* bad,
+                     float* binfo = nullptr, int* bstat = nullptr) {
   if (rows <= SC_PACK_FEW) {
-    hipLaunchKernelGGL((sc_pack_h_few_kernel<T, ROLE, LO>), dim3((unsigned)rows * 2), dim3(320), 0, st, sig, rows, packed, groups, tw, flags, bad);
+    hipLaunchKernelGGL((sc_pack_h_few_kernel<T, ROLE, LO>), dim3((unsigned)rows * 2), dim3(320), 0, st, sig, rows, packed, groups, tw, flags, bad,
+                       binfo, bstat);
     return;
   }
   hipLaunchKernelGGL((sc_pack_h_col_kernel<T, ROLE, LO>), dim3((unsigned)(((rows + 15) / 16 + 7) / 8) * 64), dim3(320), 0, st, sig, rows, packed,
-                     groups, tw, flags, bad);
+                     groups, tw, flags, bad, binfo, bstat);
 }
 
 __global__ __launch_bounds__(256) void zero_ints_kernel(int* __restrict__ p, int n) {
@@ -388,7 +468,7 @@ void launch_fill_ints(hipStream_t st, int* p, int n, int v) {
 }
 
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
-                      const double* twiddle, int* flags, int* bad, int single) {
+                      const double* twiddle, int* flags, int* bad, int single, float* binfo, int* bstat) {
   if (rows <= 0) return;
   if (single) {
     if (dtype == 0 && role == 0) launch_pack_col<double, 0, false>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
@@ -398,16 +478,17 @@ void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int 
     return;
   }
   static const bool valu = getenv("PR_SC_PACK") && !strcmp(getenv("PR_SC_PACK"), "valu");   // the per-thread DFT, kept for A/B runs
+  if (valu && bstat) hipLaunchKernelGGL(fill_ints_kernel, dim3(1), dim3(256), 0, st, bstat, 1, 1);   // (no statistics there: "not binary")
   if (valu && dtype == 0)
     hipLaunchKernelGGL(sc_pack_h_kernel<double>, dim3(rows * 2), dim3(320), 0, st, (const double*)sig, rows, role,
                        (unsigned short*)packed, groups, twiddle, flags, bad);
   else if (valu)
     hipLaunchKernelGGL(sc_pack_h_kernel<float>, dim3(rows * 2), dim3(320), 0, st, (const float*)sig, rows, role,
                        (unsigned short*)packed, groups, twiddle, flags, bad);
-  else if (dtype == 0 && role == 0) launch_pack_col<double, 0>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
-  else if (dtype == 0) launch_pack_col<double, 1>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
-  else if (role == 0) launch_pack_col<float, 0>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
-  else launch_pack_col<float, 1>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad);
+  else if (dtype == 0 && role == 0) launch_pack_col<double, 0>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad, binfo, bstat);
+  else if (dtype == 0) launch_pack_col<double, 1>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad, binfo, bstat);
+  else if (role == 0) launch_pack_col<float, 0>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad, binfo, bstat);
+  else launch_pack_col<float, 1>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad, binfo, bstat);
 }
 
 void launch_sc_pack(hipStream_t st, const void* sig, int dtype, int rows, int role, float* packed, int groups,
