@@ -15,7 +15,10 @@ over a 50k-signature DB (config 3), SC generation from 50 000-point clouds (conf
 
 Extra objects on the JSON line: `roofline` (the dominant kernel - sc_match_e_kernel, split-f16 MFMA, by default;
 sc_match_kernel, fp32 MFMA, with --sc-arith f32 - timed live with HIP events on the stream it runs on; algorithmic
-FLOPs = 23 856 fp32 FLOP per (query, entry) pair = 71 568 f16 FLOP in the split form), `cpu_baseline` (the CPU oracle =
+FLOPs = 23 856 fp32 FLOP per (query, entry) pair = 71 568 f16 FLOP in the split form; since round 4 the binary intensity
+channel of the synthetic signatures - SC/SC.cpp:67-72 writes 0 / 1 there - takes a launch of its own with one f16 product per term and
+exact integer rounding, so the dominant kernel is the split-f16 launch of the structure channel: 35 784 f16 FLOP per
+pair, timed by the library's own events around that launch, pr_set_kernel_timing), `cpu_baseline` (the CPU oracle =
 a port of the reference, timed on this host's cores on a bounded query sample at N = 1), `parity` (GPU top-1 vs
 that oracle on the sample and vs the planted ground truth on all queries).
 """
@@ -431,6 +434,18 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = [ev.elapsed_ms(a, b) for a, b in evs]
+    # per-launch times of the matcher (pr_set_kernel_timing: the library's own events between its launches), outside the timed region
+    launch_ms = None
+    if arith == "f16x2":
+        mt.ctx.kernel_timing(True)
+        acc = []
+        for _ in range(min(5, max(2, args.steps))):
+            step(None)
+            acc.append(mt.ctx.last_distance_timing())
+        mt.ctx.kernel_timing(False)
+        launch_ms = [float(np.mean([a[i] for a in acc])) for i in range(3)]
+        st_bin = C.c_int32(0)
+        mt.ctx.check(mt.lib.pr_sc_binary_state(mt.ctx.h, mt.q, mt.db, C.byref(st_bin)))
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -458,14 +473,28 @@ def main():
         if arith == "f16":
             kname = "sc_match_e_kernel<single product>"
         fpp, peak = (FLOP_PER_PAIR_F16X2 if arith == "f16x2" else FLOP_PER_PAIR, MFMA_F16_PEAK_TFLOPS) if f16 else (FLOP_PER_PAIR, MFMA_F32_PEAK_TFLOPS)
+        kms_all = kms
+        launches = None
+        binary = launch_ms is not None and launch_ms[1] + launch_ms[2] > 0
+        if binary:     # three launches: structure channel in split-f16 | intensity channel with one product per term + rounding | the same in split-f16
+            # (one of the last two has left at once: the gate of DESIGN.md §4.0b).  The dominant kernel is the first one: one channel's FLOPs.
+            fast = launch_ms[1] > launch_ms[2]
+            kname = "sc_match_e_kernel<split-f16>, structure channel"
+            fpp, kms = FLOP_PER_PAIR_F16X2 // 2, launch_ms[0]
+            launches = [{"kernel": kname, "ms": launch_ms[0], "flop_per_pair": fpp, "frac": pairs * fpp / (launch_ms[0] * 1e-3) / 1e12 / peak},
+                        {"kernel": "sc_match_e_kernel<single product on the hi halves + integer rounding>, intensity channel (binary)", "ms": launch_ms[1],
+                         "flop_per_pair": FLOP_PER_PAIR // 2, "frac": (pairs * (FLOP_PER_PAIR // 2) / (launch_ms[1] * 1e-3) / 1e12 / peak) if fast else None},
+                        {"kernel": "sc_match_e_kernel<split-f16>, intensity channel", "ms": launch_ms[2], "flop_per_pair": FLOP_PER_PAIR_F16X2 // 2,
+                         "frac": None if fast else pairs * (FLOP_PER_PAIR_F16X2 // 2) / (launch_ms[2] * 1e-3) / 1e12 / peak}]
         ach = pairs * fpp / (kms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
         traffic_file = None
-        for cand in ("r04_traffic.json", "r03_traffic.json"):            # the newest committed PMC passes of this command
+        for cand in (("r04b_traffic.json",) if binary else ("r04_traffic.json", "r03_traffic.json")):   # the newest committed PMC passes of this command
             try:
                 tr = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if tr["workload"] == {"db": n, "queries": m, "n_gpus": world}:
-                    traffic = next(v["hbm_bytes_per_launch"] for kk, v in tr.items() if kk.startswith(kname.split("<")[0]) and (arith != "f16") == ("<false" not in kk))
+                    traffic = next(v["hbm_bytes_per_launch"] for kk, v in tr.items() if kk.startswith(kname.split("<")[0]) and (arith != "f16") == ("<false" not in kk)
+                                   and (not binary or v.get("launch") == "structure channel"))
                     traffic_file = cand
                     break
             except Exception:
@@ -475,7 +504,8 @@ def main():
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * dt / args.steps, "ms_per_query": 1e3 * dt / (args.steps * m),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": {"f16x2": "f16x2 (fp32 carried as f16 hi + lo, fp32 accumulate)", "f16": "f16 (one f16 per value, fp32 accumulate; exact top-k through fp64 re-evaluation)"}.get(arith, "f32"),
+            "dtype": {"f16x2": "f16x2 (fp32 carried as f16 hi + lo, fp32 accumulate)" + ("; binary intensity channel: one f16 product per term, rounded to its exact integer count" if binary and fast else ""),
+                      "f16": "f16 (one f16 per value, fp32 accumulate; exact top-k through fp64 re-evaluation)"}.get(arith, "f32"),
             "data": "synthetic",
             "config": {"workload": "sc_match_100k", "db_signatures": n, "queries_per_step": m, "descriptor": "SC 20x60 x 2 channels",
                        "mask_width": 0, "p_weight": 2.0, "k": 1, "db_rows_per_gpu": hi - lo,
@@ -486,10 +516,12 @@ def main():
                          "traffic_source": (f"profiles/{traffic_file}: rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) + WRITE_SIZE passes of this command, per launch "
                                             "(a committed measurement of one box, not a live counter)" if traffic is not None else None),
                          "flop_per_pair": fpp, "pairs_per_launch": pairs, "ms_per_launch": kms,
+                         "matcher_ms_per_step": kms_all, "launches": launches,
+                         "binary_channel_state": (int(st_bin.value) if launch_ms is not None else None),
                          # the same launch priced as the fp32 formulation it replaces (what an fp32-MFMA kernel would need)
-                         "fp32_formulation_tflops": pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12,
-                         "fp32_formulation_frac_of_157.3": pairs * FLOP_PER_PAIR / (kms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
-                         "dense_equivalent_tflops": pairs * 576000 / (kms * 1e-3) / 1e12},
+                         "fp32_formulation_tflops": pairs * FLOP_PER_PAIR / (kms_all * 1e-3) / 1e12,
+                         "fp32_formulation_frac_of_157.3": pairs * FLOP_PER_PAIR / (kms_all * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                         "dense_equivalent_tflops": pairs * 576000 / (kms_all * 1e-3) / 1e12},
             "parity": {"planted_top1_correct": planted_ok, "queries": m},
             "collective": coll,
             "setup_s": gen_s,

@@ -32,6 +32,39 @@ inline int sc_dgroups(int n) { return (n + 15) / 16; }
 inline int m2_tiles(int sigs) { return (sigs + 7) / 8; }      // 8 signatures x 4 variants = 32 rows
 inline int m2_qtiles(int sigs) { return ((m2_tiles(sigs) + 11) / 12) * 12; }   // query tiles: workgroups take 3 or 4 of them
 
+// Binary intensity channel (SC.cpp:67-72 writes 0 / 1 there): when every row of channel 1 has all of its non-zero entries equal (and
+// positive), the row normalised as processSC.m:15-20 does is 1/sqrt(ones) on `ones` bins and every one of the 120 variant products of
+// processSC.m:30 is count / sqrt(ones_q ones_d) with an INTEGER count.  The split-f16 pack then also leaves
+//   binfo[row] = {sqrt(ones), 1/sqrt(ones)} (floats; {1, 1} for a zero-norm row)
+//   bstat[0] |= 1 when a row of channel 1 is not of that form, bstat[1] = max ones, bstat[2..5] = max over the rows of the
+//   w-weighted square sum of the f16 rounding residuals of the row's hi spectra (float bits; one slot per frequency block of the pack kernel:
+//   their sum bounds the largest row's residual norm^2)
+// (bstat is zeroed by the caller in front of every pack) and the matcher runs channel 1 with ONE f16 product per term on the hi halves
+// of the same images and rounds count = max x sqrt(ones_q ones_d) to the nearest integer - exact for every pair that passes the test of
+// ep_store_round (sc_match_e.hip) under the error bound sc_bin_bound() evaluates from these numbers; the split-f16 kernel otherwise.
+constexpr int SC_BSTAT_INTS = 8;
+struct ScBin {                    // what the matcher needs of the two sets (device pointers), by value in the kernel arguments
+  const int* qstat; const int* dstat;
+  const float* qinfo; const float* dinfo;     // [rows][2]
+  int* viol;                      // [1] raised by the single-product pass when a pair fails its rounding test (ep_store_round); zeroed by the channel-0 launch
+  float bconst;                   // (u + gamma)(1 + u) + slack: S and stage-2 constant rounding (pr_api.cpp: create_common)
+  int gate;                       // 0: always run; 1: the single-product pass (runs when the bound predicts success); 2: the split-f16 pass behind it (runs when that one did not, or raised viol)
+  int chsel;                      // -1: both channels (channel = XCD & 1); 0 / 1: this channel on all XCDs
+};
+#ifdef __HIPCC__
+// The error bound of the single-product pass over a binary channel, evaluated by every workgroup from the same numbers (derivation in
+// DESIGN.md §4.0b): with eq, ed the largest w-weighted residual norms of the hi spectra of the two sets, every variant product of a pair is
+// within sqrt(ones_q ones_d) x bound of its integer count, bound = eq + ed + eq ed + bconst (1 + eq)(1 + ed).  Returns whether the pass is
+// worth running: both sets binary and the largest pair's bound below 0.72 of a count (the pass's actual error, ~6 x 7.6e-5 per unit of
+// sqrt(ones_q ones_d) at most, then leaves the per-pair test of ep_store_round room).
+__device__ __forceinline__ bool sc_bin_bound(const ScBin& b, float& bound) {
+  const int q0 = b.qstat[0], q1 = b.qstat[1], d0 = b.dstat[0], d1 = b.dstat[1];
+  const float eq = __builtin_sqrtf(((__int_as_float(b.qstat[2]) + __int_as_float(b.qstat[3])) + __int_as_float(b.qstat[4])) + __int_as_float(b.qstat[5]));
+  const float ed = __builtin_sqrtf(((__int_as_float(b.dstat[2]) + __int_as_float(b.dstat[3])) + __int_as_float(b.dstat[4])) + __int_as_float(b.dstat[5]));
+  bound = (eq + ed + eq * ed + b.bconst * (1.f + eq) * (1.f + ed)) * 1.001f;
+  return q0 == 0 && d0 == 0 && bound * __builtin_sqrtf((float)q1 * (float)d1) < 0.72f;
+}
+#endif
 // sc_pack.hip — processSC.m:15-20 (row L2 normalisation) + per-ring rfft over the 60 sectors, written in the
 // MFMA operand layout of `role`.  sig: device [rows][2400] of T.  flags[0] |= 1 if a row has zero norm.
 // bad[row] |= 1 << channel for such rows (they are packed as zeros; launch_nan_fixup writes their NaN distances).
@@ -46,28 +79,9 @@ void launch_fill_ints(hipStream_t st, int* p, int n, int v);
 // sc_match_h.hip — the same on the f16 matrix cores with split (hi + lo) operands; packed images from launch_sc_pack_h
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
                       const double* twiddle, int* flags, int* bad, int single = 0,   // single: hi halves only (SCF_* layout)
-                      float* binfo = nullptr, int* bstat = nullptr);                 // binary-channel statistics, see below
-// Binary intensity channel (SC.cpp:67-72 writes 0 / 1 there): when every row of channel 1 has all of its non-zero entries equal (and
-// positive), the row normalised as processSC.m:15-20 does is 1/sqrt(ones) on `ones` bins and every one of the 120 variant products of
-// processSC.m:30 is count / sqrt(ones_q ones_d) with an INTEGER count.  The split-f16 pack then also leaves
-//   binfo[row] = {sqrt(ones), 1/sqrt(ones)} (floats; {1, 1} for a zero-norm row)
-//   bstat[0] |= 1 when a row of channel 1 is not of that form, bstat[1] = max ones, bstat[2..5] = max over the rows of the
-//   w-weighted square sum of the f16 rounding residuals of the row's hi spectra (float bits; one slot per frequency block of the pack kernel:
-//   their sum bounds the largest row's residual norm^2)
-// (bstat is zeroed by the caller in front of every pack) and the matcher runs channel 1 with ONE f16 product per term on the hi halves
-// of the same images and rounds count = max x sqrt(ones_q ones_d) to the nearest integer - exact when the error bound sc_bin_fast()
-// evaluates from these numbers stays below half a count (sc_match_e.hip), the split-f16 kernel otherwise.
-constexpr int SC_BSTAT_INTS = 8;
-struct ScBin {                    // what the matcher needs of the two sets (device pointers), by value in the kernel arguments
-  const int* qstat; const int* dstat;
-  const float* qinfo; const float* dinfo;     // [rows][2]
-  int* viol;                      // [1] raised by the single-product pass when a pair fails its rounding test (ep_store_round); zeroed by the channel-0 launch
-  float bconst;                   // (u + gamma)(1 + u) + slack: S and stage-2 constant rounding (pr_api.cpp: create_common)
-  int gate;                       // 0: always run; 1: the single-product pass (runs when the bound predicts success); 2: the split-f16 pass behind it (runs when that one did not, or raised viol)
-  int chsel;                      // -1: both channels (channel = XCD & 1); 0 / 1: this channel on all XCDs
-};
+                      float* binfo = nullptr, int* bstat = nullptr);                 // binary-channel statistics (ScBin above)
 void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p,
-                       float* d_i, int nsplit_override);
+                       float* d_i, int nsplit_override, const struct ScBin* bin = nullptr);   // bin: channel selection / gate of a binary-channel call
 size_t sc_match_h_lds_bytes();
 // sc_match_e.hip — the pair-walk form (no row-exchanged query operand; see the file): single = 0: split-f16 (three products, 4 waves),
 // single = 1: one f16 product per term (PR_SC_ARITH_F16), 8 waves = two per SIMD; same packed images and constants as sc_match_h.hip

@@ -659,7 +659,7 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
   if (ctx->timing) { ctx->timing_valid = 1; PR_HIP(ctx, hipEventRecord(ctx->ev_t[0], ctx->stream)); }
   if (q->type == PR_TYPE_SC && q->sc_mode == PR_SC_ARITH_F16)
     pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 1);
-  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && q->count > 8 && ctx->sc_binary && q->binfo && db->binfo) {
+  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && ctx->sc_binary && q->binfo && db->binfo) {
     const pr::ScBin bin = {sigset_bstat(q), sigset_bstat(db), q->binfo, db->binfo, ctx->d_flags + 4, ctx->sc_bconst, 0, -1};
     pr::launch_sc_match_e_bin(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, bin,
                               ctx->timing ? ctx->ev_t : nullptr);

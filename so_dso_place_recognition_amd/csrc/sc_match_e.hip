@@ -231,19 +231,6 @@ __device__ __forceinline__ void ep_store_round(float mx, f32x2 qi, f32x2 di, flo
   viol |= (st_off >= 0 && !(__builtin_fmaf(bnd, nn, __builtin_fabsf(x - cnt)) < 0.98f)) ? 1 : 0;      // (lanes without a store: st_off < 0)
   __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_fmaf(cnt * (qi[1] * di[1]), -0.5f, 0.5f)), rd, st_off, 0, 0);
 }
-// The error bound of the single-product pass over a binary channel, evaluated by every workgroup from the same numbers (kernels.hpp: ScBin;
-// derivation in DESIGN.md §4.0b): with eq, ed the largest w-weighted residual norms of the hi spectra of the two sets, every variant product
-// of a pair is within sqrt(ones_q ones_d) x bound of its integer count, bound = eq + ed + eq ed + bconst (1 + eq)(1 + ed).  Returns whether
-// the pass is worth running: both sets binary and the largest pair's bound below 0.72 of a count (the pass's actual error, ~6 x 7.6e-5 per
-// unit of sqrt(ones_q ones_d) at most, then leaves the per-pair test of ep_store_round room).
-__device__ __forceinline__ bool sc_bin_bound(const ScBin& b, float& bound) {
-  const int q0 = b.qstat[0], q1 = b.qstat[1], d0 = b.dstat[0], d1 = b.dstat[1];
-  const float eq = __builtin_sqrtf(((__int_as_float(b.qstat[2]) + __int_as_float(b.qstat[3])) + __int_as_float(b.qstat[4])) + __int_as_float(b.qstat[5]));
-  const float ed = __builtin_sqrtf(((__int_as_float(b.dstat[2]) + __int_as_float(b.dstat[3])) + __int_as_float(b.dstat[4])) + __int_as_float(b.dstat[5]));
-  bound = (eq + ed + eq * ed + b.bconst * (1.f + eq) * (1.f + ed)) * 1.001f;
-  return q0 == 0 && d0 == 0 && bound * __builtin_sqrtf((float)q1 * (float)d1) < 0.72f;
-}
-
 // ---------------------------------------------------------------------------------------------------------------- stage-1 schedule
 // The 32 walk positions of a unit form 8 quads (4 per half); quad QD computes T1 / T2' of frequencies (2E, 2E+8, 2E+1, 2E+9) of its half
 // into register set QD & 1:  T[set][0..7] = t1a, t2a, t1b, t2b (first pair), t1c, t2c, t1d, t2d (second pair).  A position has 6 gaps
@@ -596,10 +583,34 @@ void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* d
     hipLaunchKernelGGL(kern, dim3(8 * QGW * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(single, nqg), st, static_cast<const char*>(qpk),
                        static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, b);
   };
+  if (m <= 8) {      // an online call: sc_match_h.hip's one-group form for the split-f16 launches, all eight waves on one query group here
+    ScBin b = bin;
+    if (ev) (void)hipEventRecord(ev[0], st);
+    b.chsel = 0; b.gate = 0;
+    launch_sc_match_h(st, qpk, m, dpk, n, cst, d_p, d_i, nsplit_override, &b);
+    if (ev) (void)hipEventRecord(ev[1], st);
+    {
+      int nsplit = DG / 256 > 0 ? DG / 256 : 1;                      // ~32 DB groups per workgroup, 4 per wave (launch_sc_match_e: DG / 128 with four XCDs per channel)
+      if (nsplit_override > 0) nsplit = nsplit_override * 8 <= DG ? nsplit_override : (DG >= 8 ? DG / 8 : 1);
+      b.chsel = 1; b.gate = 1;
+      auto kern = sc_match_e_kernel<false, 8, 1, true>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(1, 1));
+      hipLaunchKernelGGL(kern, dim3(8 * nsplit), dim3(512), sc_match_e_lds_bytes(1, 1), st, static_cast<const char*>(qpk),
+                         static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, b);
+    }
+    if (ev) (void)hipEventRecord(ev[2], st);
+    b.chsel = 1; b.gate = 2;
+    launch_sc_match_h(st, qpk, m, dpk, n, cst, d_p, d_i, nsplit_override, &b);
+    if (ev) (void)hipEventRecord(ev[3], st);
+    return;
+  }
   if (ev) (void)hipEventRecord(ev[0], st);
   go(sc_match_e_kernel<true, 4, 4>, 4, 4, 0, 0, 0);                 // channel 0 (and *viol = 0)
   if (ev) (void)hipEventRecord(ev[1], st);
-  go(sc_match_e_kernel<false, 8, 8, true>, 8, 8, 1, 1, 1);          // channel 1, one product per term + rounding: runs when the bound predicts success
+  // channel 1, one product per term + rounding: runs when the bound predicts success (up to 32 queries: four query groups per workgroup,
+  // two DB groups at a time - with eight, half of the waves would multiply padding)
+  if (QG8 <= 4) go(sc_match_e_kernel<false, 8, 4, true>, 8, 4, 1, 1, 1);
+  else go(sc_match_e_kernel<false, 8, 8, true>, 8, 8, 1, 1, 1);
   if (ev) (void)hipEventRecord(ev[2], st);
   go(sc_match_e_kernel<true, 4, 4>, 4, 4, 0, 1, 2);                 // channel 1 in split-f16: runs when it did not run, or a pair failed its test
   if (ev) (void)hipEventRecord(ev[3], st);

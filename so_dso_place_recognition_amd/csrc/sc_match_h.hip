@@ -184,17 +184,26 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
                                                             const char* __restrict__ dpk,   // [2][DG][31][4][768 B] + one zero group
                                                             const u32x4* __restrict__ cst,  // [2][2][2][64] x 16 B
                                                             float* __restrict__ dist_p, float* __restrict__ dist_i,
-                                                            int m, int n, int QG8, int DG, int nsplit) {
+                                                            int m, int n, int QG8, int DG, int nsplit, ScBin bin) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
+  // binary-channel launches (kernels.hpp: ScBin; sc_match_e.hip): gate 2 = the split-f16 pass of channel 1 behind the single-product one -
+  // it runs when that one did not (the bound rules it out) or a pair failed its rounding test; gate 0 with a flag pointer = the channel-0
+  // launch in front of both, which clears the flag
+  if (bin.gate == 2) {
+    float bound;
+    if (sc_bin_bound(bin, bound) && *bin.viol == 0) return;
+  } else if (bin.viol && blockIdx.x == 0 && threadIdx.x == 0) {
+    *bin.viol = 0;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
   // XCD-aware mapping (workgroups go round-robin to the 8 XCDs, each with its own L2): all workgroups of one XCD work
   // on ONE channel and on the same quarter of the DB ranges, consecutive workgroups of an XCD on consecutive 32-query
   // blocks - so the ~32 resident workgroups of an XCD sweep the same DB range together and share it through that L2.
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
-  const int ch = xcd & 1;
-  const int range = (xcd >> 1) + 4 * (idx % nsplit), qg32 = idx / nsplit;      // nsplit = ranges per XCD slice
-  const int nrange = 4 * nsplit;
+  const int ch = bin.chsel < 0 ? (xcd & 1) : bin.chsel;                         // chsel >= 0: one channel on all eight XCDs
+  const int range = (bin.chsel < 0 ? (xcd >> 1) + 4 * (idx % nsplit) : xcd + 8 * (idx % nsplit)), qg32 = idx / nsplit;      // nsplit = ranges per XCD slice
+  const int nrange = (bin.chsel < 0 ? 4 : 8) * nsplit;
   const int g0 = (int)((long long)DG * range / nrange), g1 = (int)((long long)DG * (range + 1) / nrange);
 
   {  // the 4 query groups of this workgroup -> LDS (linear copy; the packed image IS the LDS image) + zeroed tail
@@ -390,29 +399,35 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
 size_t sc_match_h_lds_bytes() { return (size_t)4 * SCH_QIMG + 64; }
 
 void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p,
-                       float* d_i, int nsplit_override) {
+                       float* d_i, int nsplit_override, const ScBin* binp) {
   if (m <= 0 || n <= 0) return;
   const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n);
   const int QG32 = QG8 / 4;
+  const ScBin bin = binp ? *binp : ScBin{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, -1};
   // grid = 8 XCD slices (channel x quarter of the ranges) x QG32 query blocks x nsplit ranges per slice
   int nsplit = (128 + QG32 - 1) / QG32;            // >= ~4 workgroups per CU in total, for tail balance
   if (nsplit > DG / 32) nsplit = DG / 32;          // keep >= 8 DB groups (128 entries) per workgroup
   if (nsplit < 1) nsplit = 1;
   if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
+  const int per = bin.chsel < 0 ? 4 : 8;          // ranges per unit of nsplit: a channel takes four of the eight XCDs, or all of them
+  if (bin.chsel >= 0) {
+    if (nsplit > DG / 64) nsplit = DG / 64 > 0 ? DG / 64 : 1;
+    if (nsplit_override > 0) nsplit = nsplit_override * 8 <= DG ? nsplit_override : (DG >= 8 ? DG / 8 : 1);
+  }
   if (m <= 8) {   // one query group: the four waves of a workgroup split the DB groups of its range
-    nsplit = DG / 32 < 32 ? (DG / 32 > 0 ? DG / 32 : 1) : 32;        // 8 x nsplit workgroups = one per CU, >= 8 units per wave
-    if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
+    nsplit = DG / (8 * per) < 32 ? (DG / (8 * per) > 0 ? DG / (8 * per) : 1) : 32;        // 8 x nsplit workgroups = one per CU, >= 8 units per wave
+    if (nsplit_override > 0) nsplit = nsplit_override * per <= DG ? nsplit_override : (DG >= per ? DG / per : 1);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_match_h_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)sc_match_h_lds_bytes());
     hipLaunchKernelGGL(sc_match_h_kernel<true>, dim3(8 * nsplit), dim3(256), sc_match_h_lds_bytes(), st, static_cast<const char*>(qpk),
-                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit);
+                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, bin);
     return;
   }
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sc_match_h_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)sc_match_h_lds_bytes());
   hipLaunchKernelGGL(sc_match_h_kernel<false>, dim3(8 * QG32 * nsplit), dim3(256), sc_match_h_lds_bytes(), st,
                      static_cast<const char*>(qpk), static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i,
-                     m, n, QG8, DG, nsplit);
+                     m, n, QG8, DG, nsplit, bin);
 }
 
 }  // namespace pr

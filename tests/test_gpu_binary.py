@@ -40,7 +40,7 @@ def _counts(di, q, db):
     return (1.0 - 2.0 * di.astype(np.float64)) * np.sqrt(np.outer(oq, od))
 
 
-@pytest.mark.parametrize("m,n", [(37, 101), (70, 1500), (130, 1000), (64, 4096)])
+@pytest.mark.parametrize("m,n", [(37, 101), (70, 1500), (130, 1000), (64, 4096), (1, 300), (5, 77), (8, 5000)])
 def test_binary_channel_is_exact_and_matches_the_split_kernel(api, m, n):
     db = synth.sc_database(45, n)
     q, _ = synth.sc_queries(46, db, m)
