@@ -631,7 +631,9 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
   if (n_sigs > 0) { s->packed_groups = groups; if (n_sigs > s->hw) s->hw = n_sigs; }
   if (s->type == PR_TYPE_SC && (s->sc_mode == PR_SC_ARITH_F16X2 || s->sc_mode == PR_SC_ARITH_F16)) {
     int* bstat = s->binfo ? sigset_bstat(s) : nullptr;
-    if (bstat) PR_HIP(ctx, hipMemsetAsync(bstat, 0, pr::SC_BSTAT_INTS * sizeof(int), ctx->stream));     // every pack starts its statistics afresh
+    // every pack starts its statistics afresh (a kernel, not hipMemsetAsync: a 32-byte memset node of a captured call was seen to leave the
+    // statistics of the previous replay in place - tests/test_gpu_parity.py::test_match_as_hipgraph_replay)
+    if (bstat) pr::launch_zero_ints(ctx->stream, bstat, pr::SC_BSTAT_INTS);
     pr::launch_sc_pack_h(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags, s->bad,
                          s->sc_mode == PR_SC_ARITH_F16, s->binfo, bstat);
   }
