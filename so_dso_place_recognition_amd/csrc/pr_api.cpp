@@ -249,8 +249,9 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
       TRY(hipMalloc(&ctx->d_cst_h, ch.size() * sizeof(_Float16)));
       TRY(hipMemcpy(ctx->d_cst_h, ch.data(), ch.size() * sizeof(_Float16), hipMemcpyHostToDevice));
       // error constant of the single-product pass over a binary channel (sc_match_e.hip: sc_bin_fast): u = 2^-11 for the
-      // rounding of S_f to f16, gamma = the largest rounding residual of a (cos, -sin) hi pair relative to its weight w_f, 1e-5 for the
-      // fp32 accumulations, the fp32 epilogue and the fp64 DFT
+      // rounding of S_f to f16, gamma = the largest rounding residual of a (cos, -sin) hi pair relative to its weight w_f, 2e-5 for the
+      // fp32 accumulations inside the MFMAs (exact 22-bit products; K <= 32 terms, <= 32 x 2^-23 of the absolute sum per stage even if the
+      // adder truncates: 3.8e-6 each), the fp32 combination and epilogue and the fp64 DFT
       double gamma = 0.0;
       for (int k = 0; k <= 30; k++)
         for (int f = 0; f < pr::SC_NF; f++) {
@@ -261,7 +262,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
           gamma = std::max(gamma, std::sqrt(dc * dc + ds * ds) / (w * 1024.0));
         }
       const double u = 0x1p-11;
-      ctx->sc_bconst = (float)(((u + gamma) * (1.0 + u) + 1e-5) * (1.0 + 1e-6));
+      ctx->sc_bconst = (float)(((u + gamma) * (1.0 + u) + 2e-5) * (1.0 + 1e-6));
     }
     // M2DP plane table from the frozen float normals (M2DP/M2DP.cpp:9-30)
     double pl[2][64][3];
@@ -577,7 +578,7 @@ int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigse
     e = hipMalloc((void**)&s->bad, ((size_t)max_sigs + 1) * 2 * sizeof(int));
     if (e != hipSuccess) { (void)hipFree(s->packed); delete s; PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: hipMalloc failed: %s", hipGetErrorString(e)); }
     if (s->sc_mode == PR_SC_ARITH_F16X2) {
-      const size_t bytes = ((size_t)max_sigs + 1) * 2 * sizeof(float) + pr::SC_BSTAT_INTS * sizeof(int);
+      const size_t bytes = ((size_t)max_sigs + 1) * 2 * sizeof(float) + (pr::SC_BSTAT_INTS + 6 * ((size_t)max_sigs / 16 + 1)) * sizeof(int);   // + one slot per 16-row block of the pack kernel
       e = hipMalloc((void**)&s->binfo, bytes);
       if (e != hipSuccess) { (void)hipFree(s->packed); (void)hipFree(s->bad); delete s; PR_FAIL(ctx, PR_ENOMEM, "pr_sigset_create: hipMalloc failed: %s", hipGetErrorString(e)); }
       (void)hipMemsetAsync(s->binfo, 0, bytes, ctx->stream);
@@ -633,7 +634,7 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
     int* bstat = s->binfo ? sigset_bstat(s) : nullptr;
     // every pack starts its statistics afresh (a kernel, not hipMemsetAsync: a 32-byte memset node of a captured call was seen to leave the
     // statistics of the previous replay in place - tests/test_gpu_parity.py::test_match_as_hipgraph_replay)
-    if (bstat) pr::launch_zero_ints(ctx->stream, bstat, pr::SC_BSTAT_INTS);
+    if (bstat && n_sigs <= 8) pr::launch_zero_ints(ctx->stream, bstat, pr::SC_BSTAT_INTS);   // (the few-rows kernel adds with atomics; the block kernel's statistics are folded by a kernel of their own)
     pr::launch_sc_pack_h(ctx->stream, dsig, dtype, n_sigs, s->role, s->packed, groups, ctx->d_twiddle, ctx->d_flags, s->bad,
                          s->sc_mode == PR_SC_ARITH_F16, s->binfo, bstat);
   }
@@ -728,6 +729,9 @@ int pr_sc_binary_state(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, int
   // the arithmetic of sc_bin_fast (sc_match_e.hip), float for float
   const float eq = std::sqrt(((fl(hq[2]) + fl(hq[3])) + fl(hq[4])) + fl(hq[5])), ed = std::sqrt(((fl(hd[2]) + fl(hd[3])) + fl(hd[4])) + fl(hd[5]));
   const float bound = (eq + ed + eq * ed + ctx->sc_bconst * (1.f + eq) * (1.f + ed)) * 1.001f;
+  if (getenv("PR_AMD_VERBOSE"))
+    fprintf(stderr, "pr_sc_binary_state: queries {nonbinary %d, max ones %d, eps %.3g} db {nonbinary %d, max ones %d, eps %.3g} bound %.4g x %.1f\n",
+            hq[0], hq[1], eq, hd[0], hd[1], ed, bound, std::sqrt((float)hq[1] * (float)hd[1]));
   *state = (hq[0] == 0 && hd[0] == 0 && bound * std::sqrt((float)hq[1] * (float)hd[1]) < 0.72f) ? 1 : 0;
   if (*state) {      // ... and what the last call's rounding tests said (the flag lives until the next call's channel-0 launch)
     int viol = 0;

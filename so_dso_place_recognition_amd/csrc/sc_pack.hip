@@ -193,8 +193,8 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
   constexpr int QROW = LO ? 80 : 40;                            // bytes per query row: Q hi | Q lo
   __shared__ __attribute__((aligned(16))) char img[NG * 8 * SL];
   __shared__ double part[16 * 20];
-  __shared__ double bmn[LO ? 320 : 1], bmx[LO ? 320 : 1], epart[LO ? 320 : 1];
-  __shared__ int bnz[LO ? 320 : 1];
+  __shared__ int bnz[LO ? 320 : 1];                      // the columns' non-zero counts
+  __shared__ float epart[LO ? 320 : 1];                  // ... and residual sums (not the same array: the statistics lanes still read bnz while the others store)
   const int tid = threadIdx.x, lrow = tid / 20, ring = tid - 20 * lrow;
   // workgroups go round-robin to the 8 XCDs (each with its own L2): the four frequency blocks of the same 16 signatures -
   // which read the same input - are consecutive workgroups of ONE XCD, so HBM sees the input once
@@ -209,7 +209,8 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
   double nsq = 0.0;
   const bool do_eps = LO && binfo != nullptr && ch == 1, do_bin = do_eps && fb == 0;     // workgroup-uniform
   int nz = 0;
-  double vmn = __builtin_inf(), vmx = -__builtin_inf(), e2 = 0.0;
+  double vmn = __builtin_inf(), vmx = -__builtin_inf();
+  float e2 = 0.f;
   const double* twc = tw + 120 + (size_t)fb * 60 * 8;           // [sector][j]{cos, sin}, wave-uniform
   // rolled loop over 4 sectors at a time, the column values requested two rounds (8 sectors) ahead of their use
   T xq[3][4];
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
     }
   }
   part[tid] = nsq;
-  if (LO && do_bin) { bnz[tid] = nz; bmn[tid] = vmn; bmx[tid] = vmx; }
+  if (LO && do_bin) bnz[tid] = (nz == 0 || (vmn == vmx && vmn > 0.0)) ? nz : -1;      // this column: its non-zero entries are one positive value | not
   __syncthreads();
   double n2 = 0.0;
 #pragma unroll
@@ -249,15 +250,41 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
   const double nr = sqrt(n2);
   const bool isbad = !(nr > 0.0) || !(nr < __builtin_inf());   // MATLAB: NaN row -> zeros here + bad[row], see sc_pack_kernel
   if (valid && ring == 0 && fb == 0) { bad[2 * row + ch] = isbad ? (1 << ch) : 0; if (isbad) atomicOr(flags, 1); }
-  if (LO && do_bin && valid && ring == 0) {
-    int ones = 0;
-    double mn = __builtin_inf(), mx = -__builtin_inf();
-    for (int r = 0; r < 20; r++) { ones += bnz[lrow * 20 + r]; mn = fmin(mn, bmn[lrow * 20 + r]); mx = fmax(mx, bmx[lrow * 20 + r]); }
-    const bool binary = ones > 0 && mn == mx && mn > 0.0;
-    float s = 1.f, rs = 1.f;
-    if (!isbad && binary) { s = (float)sqrt((double)ones); rs = (float)(1.0 / sqrt((double)ones)); atomicMax(bstat + 1, ones); }
-    if (!isbad && !binary) atomicOr(bstat, 1);
-    binfo[2 * row] = s; binfo[2 * row + 1] = rs;
+  // the statistics lanes: thread t < 16 speaks for row t of the block (one wave: their results are combined by shuffles) and the workgroup
+  // leaves them in its own slot behind bstat - plain stores; sc_bstat_finalize_kernel folds the slots into bstat[0..5].  (Atomics on the
+  // set's six numbers cost 0.7 - 0.9 ms per 100 000 rows: same-address atomics from eight XCDs serialise at ~25 ns each.)
+  const int srow = blk * 16 + tid;
+  bool sbad = true;
+  if (LO && do_eps && tid < 16) {
+    double n2t = 0.0;
+#pragma unroll
+    for (int r = 0; r < 20; r++) n2t += part[tid * 20 + r];
+    const double nrt = sqrt(n2t);
+    sbad = srow >= rows || !(nrt > 0.0) || !(nrt < __builtin_inf());
+  }
+  if (LO && do_bin) {                                   // (workgroup-uniform) the columns' values through `part` again: two more barriers in one workgroup of eight
+    __syncthreads();
+    part[tid] = vmx;
+    __syncthreads();
+    if (tid < 16) {
+      int ones = 0;
+      bool binary = true;
+      double a = -__builtin_inf();
+      for (int r = 0; r < 20; r++) {
+        const int c = bnz[tid * 20 + r];
+        const double v = part[tid * 20 + r];
+        if (c < 0) binary = false;
+        if (c > 0) { ones += c; if (a == -__builtin_inf()) a = v; else if (v != a) binary = false; }
+      }
+      binary = binary && ones > 0;
+      float s1 = 1.f, rs = 1.f;
+      if (!sbad && binary) { s1 = (float)sqrt((double)ones); rs = (float)(1.0 / sqrt((double)ones)); }
+      if (srow < rows) { binfo[2 * srow] = s1; binfo[2 * srow + 1] = rs; }
+      int mo = (!sbad && binary) ? ones : 0, nb = (!sbad && !binary) ? 1 : 0;
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) { mo = max(mo, __shfl_xor(mo, o)); nb |= __shfl_xor(nb, o); }
+      if (tid == 0) { bstat[SC_BSTAT_INTS + 6 * blk] = nb; bstat[SC_BSTAT_INTS + 6 * blk + 1] = mo; }
+    }
   }
   const double sc = isbad ? 0.0 : 0.12909944487358055 * (ROLE == 0 ? 256.0 : 128.0) / nr;   // 1/sqrt(60) x 2^8 | 2^7, over the norm (processSC.m:16,19)
   auto put = [&](double val, int slice, int im) {
@@ -282,10 +309,9 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
     }
     *reinterpret_cast<_Float16*>(img + bh) = hi;
     if (LO) *reinterpret_cast<_Float16*>(img + bl) = lo;
-    if (LO && do_eps) {                                   // residual of the hi half, weight w_f = 1 (f = 0, 30) | 2
-      const double r = (val - (double)hi) * (ROLE == 0 ? 0x1p-8 : 0x1p-7);
+    if (LO) {                                             // residual of the hi half (rf: what lo is rounded from), weight w_f = 1 (f = 0, 30) | 2, in fp32
       const bool edge = (fb == 0 && (slice & 3) == 0);    // slice 0 of block 0: f = 0, slice 4: f = 30
-      e2 += (edge ? 1.0 : 2.0) * r * r;
+      e2 = __builtin_fmaf(edge ? rf : 2.f * rf, rf, e2);
     }
   };
   if (valid) {
@@ -301,10 +327,16 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
   }
   if (LO && do_eps) epart[tid] = e2;
   __syncthreads();
-  if (LO && do_eps && valid && ring == 0 && !isbad) {
-    double e = 0.0;
-    for (int r = 0; r < 20; r++) e += epart[lrow * 20 + r];
-    atomicMax(bstat + 2 + fb, __float_as_int((float)(e * (1.0 + 0x1p-20))));     // (non-negative floats order like their bit patterns)
+  if (LO && do_eps && tid < 16) {
+    float e = 0.f;
+    for (int r = 0; r < 20; r++) e += epart[tid * 20 + r];
+    if (sbad) e = 0.f;
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) e = fmaxf(e, __shfl_xor(e, o));
+    // (scaled values: 2^-16 | 2^-14 brings the squares back to the normalised spectrum; 1 + 2^-10 covers the fp32 sums and rf's own rounding;
+    // non-negative floats order like their bit patterns)
+    const int eb = __float_as_int(e * (ROLE == 0 ? 0x1p-16f : 0x1p-14f) * (1.f + 0x1p-10f));
+    if (tid == 0) bstat[SC_BSTAT_INTS + 6 * blk + 2 + fb] = eb;
   }
   // slice (group gg, k) -> frequency (k < 4 ? 4 fb + k : 30 - 4 fb - (k - 4)) of group NG blk + gg
   constexpr int W = SL / 8;                               // 8-byte words per slice
@@ -436,6 +468,30 @@ __global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict_
   }
 }
 
+// bstat[0..5] of a set packed by sc_pack_h_col_kernel: OR / max over its blocks' slots (one workgroup)
+__global__ __launch_bounds__(256) void sc_bstat_finalize_kernel(int* __restrict__ bstat, int nblk) {
+  __shared__ int red[6][256];
+  int v[6] = {0, 0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < nblk; b += 256) {
+    const int* w = bstat + SC_BSTAT_INTS + 6 * b;
+    v[0] |= w[0];
+#pragma unroll
+    for (int i = 1; i < 6; i++) v[i] = max(v[i], w[i]);      // (ones, and non-negative floats as their bit patterns)
+  }
+#pragma unroll
+  for (int i = 0; i < 6; i++) red[i][threadIdx.x] = v[i];
+  __syncthreads();
+  for (int s2 = 128; s2 > 0; s2 >>= 1) {
+    if ((int)threadIdx.x < s2) {
+      red[0][threadIdx.x] |= red[0][threadIdx.x + s2];
+#pragma unroll
+      for (int i = 1; i < 6; i++) red[i][threadIdx.x] = max(red[i][threadIdx.x], red[i][threadIdx.x + s2]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < 6) bstat[threadIdx.x] = red[threadIdx.x][0];
+}
+
 template <typename T, int ROLE, bool LO = true>
 void launch_pack_col(hipStream_t st, const T* sig, int rows, unsigned short* packed, int groups, const double* tw, int* flags, int* bad,
                      float* binfo = nullptr, int* bstat = nullptr) {
@@ -446,6 +502,7 @@ void launch_pack_col(hipStream_t st, const T* sig, int rows, unsigned short* pac
   }
   hipLaunchKernelGGL((sc_pack_h_col_kernel<T, ROLE, LO>), dim3((unsigned)(((rows + 15) / 16 + 7) / 8) * 64), dim3(320), 0, st, sig, rows, packed,
                      groups, tw, flags, bad, binfo, bstat);
+  if (LO && bstat) hipLaunchKernelGGL(sc_bstat_finalize_kernel, dim3(1), dim3(256), 0, st, bstat, (rows + 15) / 16);
 }
 
 __global__ __launch_bounds__(256) void zero_ints_kernel(int* __restrict__ p, int n) {
