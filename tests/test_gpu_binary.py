@@ -138,3 +138,20 @@ def test_topk_and_timing_hooks(api):
     assert np.array_equal(idx.cpu().numpy(), oidx)
     assert np.abs(score.cpu().numpy() - osc).max() < 1e-4
     mt.close()
+
+
+def test_both_channel1_passes_at_size(api):
+    """A few hundred queries against 20 000 entries (several workgroups per XCD, every query-group slot of the single-product launch in use):
+    the binary pass and, with one non-binary row in the DB, the split-f16 pass behind it - each against the oracle on a sample of rows."""
+    n, m = 20000, 200
+    db = synth.sc_database(45, n)
+    q, planted = synth.sc_queries(46, db, m)
+    rows = [0, 7, 63, 64, 131, 199]
+    for nonbinary in (False, True):
+        if nonbinary:
+            db[12345, 1200 + 5] = 0.375
+        state, dp, di = _binary_state(q, db)
+        assert state == (0 if nonbinary else 1)
+        rc, op, oi = oracle_lib.sc_distance(q[rows], db)
+        assert np.abs(dp[rows] - op).max() < 1e-5 and np.abs(di[rows] - oi).max() < (1e-5 if nonbinary else 3e-7)
+        assert (np.argmin(di + 2 * dp, axis=1)[:5] >= 0).all()
