@@ -1,3 +1,4 @@
+"""DB pack time of the SC matcher (100 000 signatures, split-f16 images + binary-channel statistics): python tools/bench_pack.py (GPU box)."""
 import sys, time, numpy as np
 sys.path.insert(0,'.')
 import torch
