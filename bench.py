@@ -236,6 +236,30 @@ def extra_workloads(dev, ev, args):
                                       "frac_of_fp32_mfma_peak": m * n * FLOP_PER_PAIR / (k * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                                       "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == planted).sum()), "queries": m}
     mt.close()
+    # the metric workload with the binary-channel path switched off (pr_set_sc_binary(ctx, 0): both channels in ONE split-f16 launch, the
+    # default until the second session of round 4) - what a DB whose intensity channel is not binary costs, and the figure of earlier rounds
+    mt = Matcher("sc", m, n, ctx=Context(dev.index, sc_arith="f16x2", sc_binary=False, stream=cur))
+    mt.pre_distances = lambda: ev.record(pair[0], mt.ctx.stream)
+    mt.post_distances = lambda: ev.record(pair[1], mt.ctx.stream)
+    kms = []
+
+    def split_step():
+        mt.pack_database(db)
+        return mt.match(q, 0, 2.0, 1)
+    split_step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        idx, _ = split_step()
+        kms.append(ev.elapsed_ms(pair[0], pair[1]))
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 4
+    k = float(np.mean(kms))
+    out["sc_match_100k_split_f16_both_channels"] = {"queries_per_s": m / dt, "ms_per_step": 1e3 * dt, "kernel": "sc_match_e_kernel<split-f16>, both channels",
+                                                    "ms_per_launch": k, "flop_per_pair": FLOP_PER_PAIR_F16X2,
+                                                    "frac_of_f16_mfma_peak": m * n * FLOP_PER_PAIR_F16X2 / (k * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
+                                                    "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == planted).sum()), "queries": m}
+    mt.close()
     # PR_SC_ARITH_F16 (BASELINE config 5's "fp16 descriptors": one f16 per value, one MFMA per product) on the metric workload: whole steps
     # (pack(q) + pack(db) + distances + moments + select(k + 56) + fp64 re-evaluation + margin check + split-f16 fallback of flagged queries)
     mt = Matcher("sc", m, n, ctx=Context(dev.index, sc_arith="f16", stream=cur))
