@@ -158,6 +158,9 @@ struct Half {
 };
 
 __device__ __forceinline__ void swap32f(f32x4& a, f32x4& b, int e) {   // lanes 32-63 of a[e] <-> lanes 0-31 of b[e]
+#ifdef E_ABL_NO_SWAP      // ablation (wrong results): what the stage-1 swaps cost
+  return;
+#endif
   const u32x2 v = __builtin_amdgcn_permlane32_swap(__float_as_uint(a[e]), __float_as_uint(b[e]), false, false);
   a[e] = __uint_as_float(v[0]);
   b[e] = __uint_as_float(v[1]);
@@ -243,6 +246,9 @@ template <bool LO>
 __device__ __forceinline__ void swp2(f32x4& x, f32x4& y, f32x4& u, f32x4& v, int e) { swap32f(x, y, e); swap32f(u, v, e); }
 // X, Y, U, V -> Re S = X + V (in x), Re P = X - V (in v), Im S = Y - U (in y), Im P = Y + U (in u), registers r0, r0 + 1
 __device__ __forceinline__ void cmb2(f32x4& x, f32x4& y, f32x4& u, f32x4& v, int r0) {
+#ifdef E_ABL_NO_CMB       // ablation (wrong results): what the combination costs
+  return;
+#endif
 #ifdef E_PLAIN_CMB   // A/B: eight plain adds (asm: hipcc would pack them again) instead of four v_pk_add_f32
 #pragma unroll
   for (int e = r0; e < r0 + 2; e++) {
