@@ -56,7 +56,7 @@ def _check(q, d):
     exact = _max_corr(Q, D, C, S, False) * N
     assert np.abs(exact - np.rint(exact)).max() < 1e-9                 # processSC.m:30 on binary rows: integer counts
     x = _max_corr(Qh, Dh, Ch, Sh, True) * N
-    bconst = (U + gamma) * (1 + U) + 2e-5                              # pr_api.cpp: create_common
+    bconst = (U + gamma) * (1 + U) + 7e-5                              # pr_api.cpp: create_common
     Eq, Ed = eq[:, None], ed[None, :]
     b = N * (Eq + Ed + Eq * Ed + bconst * (1 + Eq) * (1 + Ed))
     err = np.abs(x - exact)
