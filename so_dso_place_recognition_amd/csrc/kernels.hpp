@@ -48,6 +48,7 @@ struct ScBin {                    // what the matcher needs of the two sets (dev
   const float* qinfo; const float* dinfo;     // [rows][2]
   int* viol;                      // [1] raised by the single-product pass when a pair fails its rounding test (ep_store_round); zeroed by the channel-0 launch
   float bconst;                   // (u + gamma)(1 + u) + slack: S and stage-2 constant rounding (pr_api.cpp: create_common)
+  float pair_scale;               // 1; tests: PR_SC_BINARY_PAIR_SCALE inflates the bound of the per-pair test only, so that the pass runs and fails it
   int gate;                       // 0: always run; 1: the single-product pass (runs when the bound predicts success); 2: the split-f16 pass behind it (runs when that one did not, or raised viol)
   int chsel;                      // -1: both channels (channel = XCD & 1); 0 / 1: this channel on all XCDs
 };

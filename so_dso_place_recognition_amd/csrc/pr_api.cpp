@@ -57,6 +57,7 @@ struct pr_ctx {
   bool force_order = false;      // PR_FORCE_ORDER_FLAGS=1 (tests): every query counts as flagged by the order check, i.e. every query gets fp64 row statistics
   bool sc_binary = true;         // split-f16 arithmetic: a binary intensity channel goes through the single-product kernel with integer rounding (kernels.hpp: ScBin); PR_SC_BINARY=0 / pr_set_sc_binary turn it off
   float sc_bconst = 0.f;         // (u + gamma)(1 + u) + slack of that pass's error bound (create_common)
+  float sc_pair_scale = 1.f;     // PR_SC_BINARY_PAIR_SCALE (tests): inflates the bound of the per-pair rounding test, which then fails and sends channel 1 to the split-f16 pass behind
   bool timing = false;           // pr_set_kernel_timing: events around the launches of pr_distances_dev
   hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};
   int timing_valid = 0;          // 0: nothing recorded; 1: ev_t[0], ev_t[3] only (one launch); 3: all four (channel 0 | channel 1 split | channel 1 single)
@@ -288,6 +289,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
   if (const char* s = getenv("PR_SC_MATCH")) ctx->sc_mode = (strcmp(s, "f32") == 0) ? PR_SC_ARITH_F32 : (strcmp(s, "f16") == 0) ? PR_SC_ARITH_F16 : PR_SC_ARITH_F16X2;
   if (const char* s = getenv("PR_SC_KERNEL")) ctx->sc_kernel = (strcmp(s, "h") == 0) ? 0 : 2;
   if (const char* s = getenv("PR_SC_BINARY")) ctx->sc_binary = atoi(s) != 0;
+  if (const char* s = getenv("PR_SC_BINARY_PAIR_SCALE")) ctx->sc_pair_scale = (float)atof(s);
   *out = ctx;
   return PR_OK;
 }
@@ -665,7 +667,7 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
   if (q->type == PR_TYPE_SC && q->sc_mode == PR_SC_ARITH_F16)
     pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 1);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && ctx->sc_binary && q->binfo && db->binfo) {
-    const pr::ScBin bin = {sigset_bstat(q), sigset_bstat(db), q->binfo, db->binfo, ctx->d_flags + 4, ctx->sc_bconst, 0, -1};
+    const pr::ScBin bin = {sigset_bstat(q), sigset_bstat(db), q->binfo, db->binfo, ctx->d_flags + 4, ctx->sc_bconst, ctx->sc_pair_scale, 0, -1};
     pr::launch_sc_match_e_bin(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, bin,
                               ctx->timing ? ctx->ev_t : nullptr);
     if (ctx->timing) ctx->timing_valid = 3;

@@ -323,7 +323,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   } else if (bin.viol && blockIdx.x == 0 && threadIdx.x == 0) {
     *bin.viol = 0;       // the channel-0 launch in front of the two: nothing violated yet
   }
-  [[maybe_unused]] const float bnd25 = bbound * 0x1p25f;
+  [[maybe_unused]] const float bnd25 = bbound * 0x1p25f * bin.pair_scale;
   [[maybe_unused]] int viol = 0;
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -556,7 +556,7 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
   if (nsplit < 1) nsplit = 1;
   if (nqg == 1) nsplit = DG / 128 > 0 ? DG / 128 : 1;   // an online call: ~32 DB groups per workgroup, 4 per wave; ~400 workgroups at n = 100k
   if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
-  const ScBin none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, -1};
+  const ScBin none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1.f, 0, -1};
   auto go = [&](auto kern, int nw) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(single, nqg));
     hipLaunchKernelGGL(kern, dim3(8 * QGW * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(single, nqg), st, static_cast<const char*>(qpk),

@@ -403,7 +403,7 @@ void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, 
   if (m <= 0 || n <= 0) return;
   const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n);
   const int QG32 = QG8 / 4;
-  const ScBin bin = binp ? *binp : ScBin{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 0, -1};
+  const ScBin bin = binp ? *binp : ScBin{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1.f, 0, -1};
   // grid = 8 XCD slices (channel x quarter of the ranges) x QG32 query blocks x nsplit ranges per slice
   int nsplit = (128 + QG32 - 1) / QG32;            // >= ~4 workgroups per CU in total, for tail balance
   if (nsplit > DG / 32) nsplit = DG / 32;          // keep >= 8 DB groups (128 entries) per workgroup

@@ -155,3 +155,21 @@ def test_both_channel1_passes_at_size(api):
         rc, op, oi = oracle_lib.sc_distance(q[rows], db)
         assert np.abs(dp[rows] - op).max() < 1e-5 and np.abs(di[rows] - oi).max() < (1e-5 if nonbinary else 3e-7)
         assert (np.argmin(di + 2 * dp, axis=1)[:5] >= 0).all()
+
+
+@pytest.mark.parametrize("m,n", [(4, 900), (90, 2500)])
+def test_a_failed_rounding_test_sends_the_channel_to_the_split_kernel(api, monkeypatch, m, n):
+    """PR_SC_BINARY_PAIR_SCALE (a test hook) inflates the bound of the per-pair test only: the single-product pass runs, every pair fails,
+    the flag goes up and the split-f16 launch behind it redoes channel 1 - pr_sc_binary_state reports 2, the distances are the split kernel's."""
+    db = synth.sc_database(45, n)
+    q, _ = synth.sc_queries(46, db, m)
+    monkeypatch.setenv("PR_SC_BINARY_PAIR_SCALE", "1000")
+    state, dp, di = _binary_state(q, db)
+    monkeypatch.delenv("PR_SC_BINARY_PAIR_SCALE")
+    assert state == 2
+    sp, si = api.processSC(q, db, api.Context(0, sc_binary=False))
+    assert np.array_equal(dp, sp) and np.array_equal(di, si)
+    state, dp, di = _binary_state(q, db)                                  # ... and the next call starts with a clean flag
+    assert state == 1
+    rc, op, oi = oracle_lib.sc_distance(q, db)
+    assert np.abs(di - oi).max() < 3e-7
