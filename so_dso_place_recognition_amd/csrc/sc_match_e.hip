@@ -382,8 +382,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   const int qrow0 = qg32 * (8 * NQG) + wq * 8;
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
       dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 8 ? m - qrow0 : 8) : 0) * n * 4, 0x00020000);
-  const int pf_slot = (qg32 & 31) * NW + w;                                  // this wave's share of the group(s) it helps to prefetch
-  constexpr int PFL = LO ? 6 : 2;                                            // cache lines per wave: 32 NW waves cover the GSTEP x DIMG / 128 lines (SV: the 372 lines of the hi tiles)
+  // this wave's share of the group(s) it helps to prefetch: the 32 workgroups resident on an XCD are consecutive idx, i.e. rsd = 32 / nsplit
+  // consecutive query blocks per range.  Split-f16 form (nsplit = 1 on the metric workload): 32 NW waves x 6 lines >= the 744 lines of a
+  // group, as tuned.  Single-product form with several query groups per workgroup: rsd NW waves share the GSTEP x 372 lines (hi tiles only
+  // in the SV view) - with the fixed two lines per wave of round 3, nsplit = 2 left half of every group to demand misses.
+  constexpr int GLINES = SC_NF * 12;                                         // 128-byte lines of the Re / Im (hi) tiles of one group
+  const int rsd = (LO || NQG == 1) ? 32 : (nsplit >= 32 ? 1 : 32 / nsplit);
+  const int pf_slot = (LO || NQG == 1) ? (qg32 & 31) * NW + w : (qg32 % rsd) * NW + w;
+  constexpr int PFL = LO ? 6 : 2;
+  const int pfl = (LO || NQG == 1) ? PFL : ((NW / NQG) * GLINES + rsd * NW - 1) / (rsd * NW);
   unsigned pf_sink = 0;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(cst), 0, 8192, 0x00020000);
   if (dpar >= gcnt) return;
@@ -481,10 +488,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
       const __amdgpu_buffer_rsrc_t rp = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)gp * DIMG), 0, pf_bytes, 0x00020000);
       int lp = lane;
       asm volatile("" : "+v"(lp));
-      int pf_off = (lp < PFL) ? (pf_slot * PFL + lp) * 128 : (int)0x80000000;   // waves x PFL lines >= 744 lines per group
-      if constexpr (SV) {                      // line L of the group's 31 x 2 hi tiles (6 lines each) -> its place in the split image
-        const int L = pf_slot * PFL + lp, f = L / 12, r = L - f * 12;
-        pf_off = (lp < PFL && L < SC_NF * 12) ? f * SCH_DFREQ + (r >= 6 ? 2 * SCH_DTILE : 0) + (r >= 6 ? r - 6 : r) * 128 : (int)0x80000000;
+      int pf_off = (lp < pfl) ? (pf_slot * pfl + lp) * 128 : (int)0x80000000;   // waves x lines >= the lines of the step's group(s); past the end: out of range
+      if constexpr (SV) {                      // line L of the 31 x 2 hi tiles (6 lines each) of the step's groups -> its place in the split image
+        const int L0 = pf_slot * pfl + lp, gi = L0 / GLINES, L = L0 - gi * GLINES, f = L / 12, r = L - f * 12;
+        pf_off = (lp < pfl && gi < GSTEP) ? gi * SCH_DIMG + f * SCH_DFREQ + (r >= 6 ? 2 * SCH_DTILE : 0) + (r >= 6 ? r - 6 : r) * 128 : (int)0x80000000;
       }
       pf_sink = __builtin_amdgcn_raw_buffer_load_b32(rp, pf_off, 0, 0);
     }
