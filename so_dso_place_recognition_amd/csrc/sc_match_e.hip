@@ -87,6 +87,9 @@ __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int v
   // SV: the single-product form reading the hi tiles of a split-f16 image
   constexpr int soff = LO ? F * SCH_DFREQ : SV ? F * SCH_DFREQ + (T == B_IMH ? 2 : 0) * SCH_DTILE : F * SCF_DFREQ + (T == B_IMH ? 1 : 0) * SCH_DTILE,
                 ioff = LO ? T * SCH_DTILE : 0;
+#ifdef E_ABL_ONE_B        // ablation (wrong results): the single-product form without its Im tile requests
+  if (!LO && T == B_IMH) { b.imh = b.reh; return; }
+#endif
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ioff, soff, 0);
   if (T == B_REH) b.reh = v; else if (T == B_REL) b.rel = v; else if (T == B_IMH) b.imh = v; else b.iml = v;
 }
