@@ -48,6 +48,18 @@ def spoil(q, db, div):
         j = int(rng.integers(0, n)); db[j, :1200 if rng.random() < 0.5 else 2400] = 0.0; notes.append(f"zero db {j}")
     if div == 1 and rng.random() < 0.15 and m > 1:
         i = int(rng.integers(0, m)); q[i, 1200:] = 0.0; notes.append(f"zero q {i}")
+    if div == 1:                                                            # SC intensity channel (binary as SC.cpp:67-72 writes it): what the
+        r = rng.random()                                                    # binary path's gate sees - scaled rows, real values, dense rows
+        if r < 0.15:
+            db[:, 1200:] *= rng.uniform(0.1, 9.0, (db.shape[0], 1)); notes.append("scaled db")
+        elif r < 0.25:
+            j = int(rng.integers(0, n)); db[j, 1200:] = np.where(db[j, 1200:] != 0, rng.uniform(0.2, 1.0, 1200), 0.0); notes.append(f"real db {j}")
+        elif r < 0.32:
+            i = int(rng.integers(0, m)); q[i, 1200:] = rng.uniform(0.0, 1.0, 1200); notes.append(f"real q {i}")
+        elif r < 0.40:
+            dens = rng.uniform(0.35, 0.95); db[:, 1200:] = (rng.random((db.shape[0], 1200)) < dens).astype(np.float64); notes.append(f"dense db {dens:.2f}")
+        elif r < 0.45:
+            j = int(rng.integers(0, n)); db[j, 1200:] = 1.0; notes.append(f"full db {j}")
     if rng.random() < 0.4 and n > 8:
         for _ in range(int(rng.integers(1, 4))):
             a, b = (int(x) for x in rng.integers(0, n, 2))
