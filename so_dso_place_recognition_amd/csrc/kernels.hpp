@@ -46,7 +46,8 @@ constexpr int SC_BSTAT_INTS = 8;
 struct ScBin {                    // what the matcher needs of the two sets (device pointers), by value in the kernel arguments
   const int* qstat; const int* dstat;
   const float* qinfo; const float* dinfo;     // [rows][2]
-  int* viol;                      // [1] raised by the single-product pass when a pair fails its rounding test (ep_store_round); zeroed by the channel-0 launch
+  int* viol;                      // [1] set to `gen` by the single-product pass when a pair fails its rounding test (ep_store_round)
+  int gen;                        // the call's sequence number (> 0): the split-f16 pass behind looks for exactly this value, so nobody has to clear the word
   float bconst;                   // (u + gamma)(1 + u) + slack: S and stage-2 constant rounding (pr_api.cpp: create_common)
   float pair_scale;               // 1; tests: PR_SC_BINARY_PAIR_SCALE inflates the bound of the per-pair test only, so that the pass runs and fails it
   int gate;                       // 0: always run; 1: the single-product pass (runs when the bound predicts success); 2: the split-f16 pass behind it (runs when that one did not, or raised viol)
@@ -92,6 +93,8 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
 // halves with integer rounding when the sets' statistics allow it, in split-f16 otherwise - the decision is taken ON THE DEVICE by every
 // workgroup from the same numbers (no host round trip: the two channel-1 launches are both issued, one of them leaves at once).
 // ev (or null): four events recorded around the launches (channel 0 | channel 1 single product | channel 1 split)
+// (Measured and dropped: the channel-0 launch of an online call and the binary pass on two streams at once - 0.302 -> 0.308 ms at m = 1,
+// 0.310 -> 0.337 at m = 8: sc_match_h's workgroups fill the LDS of their CUs, the two kernels do not run side by side, and the event hand-offs cost.)
 void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                            int nsplit_override, ScBin bin, hipEvent_t* ev);
 

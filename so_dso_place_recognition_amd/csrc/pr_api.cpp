@@ -57,6 +57,7 @@ struct pr_ctx {
   bool force_order = false;      // PR_FORCE_ORDER_FLAGS=1 (tests): every query counts as flagged by the order check, i.e. every query gets fp64 row statistics
   bool sc_binary = true;         // split-f16 arithmetic: a binary intensity channel goes through the single-product kernel with integer rounding (kernels.hpp: ScBin); PR_SC_BINARY=0 / pr_set_sc_binary turn it off
   float sc_bconst = 0.f;         // (u + gamma)(1 + u) + slack of that pass's error bound (create_common)
+  int bin_gen = 0;               // sequence number of the binary-path calls: what the single-product pass leaves in d_flags[4] when a pair fails its test
   float sc_pair_scale = 1.f;     // PR_SC_BINARY_PAIR_SCALE (tests): inflates the bound of the per-pair rounding test, which then fails and sends channel 1 to the split-f16 pass behind
   bool timing = false;           // pr_set_kernel_timing: events around the launches of pr_distances_dev
   hipEvent_t ev_t[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -667,7 +668,8 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
   if (q->type == PR_TYPE_SC && q->sc_mode == PR_SC_ARITH_F16)
     pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 1);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && ctx->sc_binary && q->binfo && db->binfo) {
-    const pr::ScBin bin = {sigset_bstat(q), sigset_bstat(db), q->binfo, db->binfo, ctx->d_flags + 4, ctx->sc_bconst, ctx->sc_pair_scale, 0, -1};
+    ctx->bin_gen = ctx->bin_gen == 0x7fffffff ? 1 : ctx->bin_gen + 1;
+    const pr::ScBin bin = {sigset_bstat(q), sigset_bstat(db), q->binfo, db->binfo, ctx->d_flags + 4, ctx->bin_gen, ctx->sc_bconst, ctx->sc_pair_scale, 0, -1};
     pr::launch_sc_match_e_bin(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, bin,
                               ctx->timing ? ctx->ev_t : nullptr);
     if (ctx->timing) ctx->timing_valid = 3;
@@ -741,7 +743,7 @@ int pr_sc_binary_state(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, int
     int viol = 0;
     PR_HIP(ctx, hipMemcpyAsync(&viol, ctx->d_flags + 4, sizeof viol, hipMemcpyDeviceToHost, ctx->stream));
     PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (viol) *state = 2;
+    if (viol == ctx->bin_gen && viol != 0) *state = 2;
   }
   return PR_OK;
 }

@@ -322,9 +322,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   float bbound = 0.f;
   if (bin.gate) {      // (workgroup-uniform: scalar loads of six numbers per set)
     const bool pred = sc_bin_bound(bin, bbound);
-    if (bin.gate == 1 ? !pred : (pred && *bin.viol == 0)) return;      // gate 2: the split-f16 kernel behind the single-product one
-  } else if (bin.viol && blockIdx.x == 0 && threadIdx.x == 0) {
-    *bin.viol = 0;       // the channel-0 launch in front of the two: nothing violated yet
+    if (bin.gate == 1 ? !pred : (pred && *bin.viol != bin.gen)) return;      // gate 2: the split-f16 kernel behind the single-product one
   }
   [[maybe_unused]] const float bnd25 = bbound * 0x1p25f * bin.pair_scale;
   [[maybe_unused]] int viol = 0;
@@ -548,7 +546,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
     ST(7)
     rs = rsn;
   }
-  if constexpr (SV) { if (__any(viol)) { if (lane == 0) atomicOr(bin.viol, 1); } }
+  if constexpr (SV) { if (__any(viol)) { if (lane == 0) atomicExch(bin.viol, bin.gen); } }
 }
 
 }  // namespace
@@ -566,7 +564,7 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
   if (nsplit < 1) nsplit = 1;
   if (nqg == 1) nsplit = DG / 128 > 0 ? DG / 128 : 1;   // an online call: ~32 DB groups per workgroup, 4 per wave; ~400 workgroups at n = 100k
   if (nsplit_override > 0) nsplit = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
-  const ScBin none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1.f, 0, -1};
+  const ScBin none = {nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 1.f, 0, -1};
   auto go = [&](auto kern, int nw) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(single, nqg));
     hipLaunchKernelGGL(kern, dim3(8 * QGW * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(single, nqg), st, static_cast<const char*>(qpk),
@@ -621,7 +619,7 @@ void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* d
     return;
   }
   if (ev) (void)hipEventRecord(ev[0], st);
-  go(sc_match_e_kernel<true, 4, 4>, 4, 4, 0, 0, 0);                 // channel 0 (and *viol = 0)
+  go(sc_match_e_kernel<true, 4, 4>, 4, 4, 0, 0, 0);                 // channel 0
   if (ev) (void)hipEventRecord(ev[1], st);
   // channel 1, one product per term + rounding: runs when the bound predicts success (up to 32 queries: four query groups per workgroup,
   // two DB groups at a time - with eight, half of the waves would multiply padding)

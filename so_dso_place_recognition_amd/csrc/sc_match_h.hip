@@ -187,13 +187,10 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
                                                             int m, int n, int QG8, int DG, int nsplit, ScBin bin) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   // binary-channel launches (kernels.hpp: ScBin; sc_match_e.hip): gate 2 = the split-f16 pass of channel 1 behind the single-product one -
-  // it runs when that one did not (the bound rules it out) or a pair failed its rounding test; gate 0 with a flag pointer = the channel-0
-  // launch in front of both, which clears the flag
+  // it runs when that one did not (the bound rules it out) or a pair failed its rounding test (the flag word carries this call's number)
   if (bin.gate == 2) {
     float bound;
-    if (sc_bin_bound(bin, bound) && *bin.viol == 0) return;
-  } else if (bin.viol && blockIdx.x == 0 && threadIdx.x == 0) {
-    *bin.viol = 0;
+    if (sc_bin_bound(bin, bound) && *bin.viol != bin.gen) return;
   }
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -403,7 +400,7 @@ void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, 
   if (m <= 0 || n <= 0) return;
   const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n);
   const int QG32 = QG8 / 4;
-  const ScBin bin = binp ? *binp : ScBin{nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, 1.f, 0, -1};
+  const ScBin bin = binp ? *binp : ScBin{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 1.f, 0, -1};
   // grid = 8 XCD slices (channel x quarter of the ranges) x QG32 query blocks x nsplit ranges per slice
   int nsplit = (128 + QG32 - 1) / QG32;            // >= ~4 workgroups per CU in total, for tail balance
   if (nsplit > DG / 32) nsplit = DG / 32;          // keep >= 8 DB groups (128 entries) per workgroup
