@@ -575,6 +575,196 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------- short rows: one WAVE per row
+// select_row's workgroup spends a fixed ~80 us per row on its barriers and LDS rounds (sample threshold, k arg-min rounds), whatever the
+// row's length: 0.45 ms per 4096 rows of 12 500 entries (the shard of an 8-GPU run, a KITTI-sized DB) against 0.7 - 0.9 ms for 100 000.
+// Here a wave owns a row - four rows per workgroup, no barrier anywhere: the same statistics, the same score expression (bit for bit:
+// fusedw below is select_row's fused4 without the second channel pair), the threshold from the r-th smallest of the 64 lanes' sample
+// minima (rank counting over v_readlane), survivors compacted into the wave's LDS list by ballot / mbcnt, the k best by k wave arg-min
+// rounds; the result is the same k smallest (score, index) pairs in the same order.  For rows of up to 32 768 entries, k <= 16, one channel
+// pair, whole rows (launch_fuse_select decides); a list that overflows (masses of ties at the threshold) falls back to one sweep per
+// selected element, as select_row does.
+constexpr int WS_CAP = 1024;      // survivors per wave: ~r n / 1024 = 16 n / 1024 <= 512 expected at n = 32 768
+__device__ __forceinline__ void wave_argmin(double& v, int& j) {     // all lanes end with the smallest (v, j), j >= 0; j < 0 = none
+#pragma unroll
+  for (int s2 = 32; s2 > 0; s2 >>= 1) {
+    const double ov = __shfl_xor(v, s2, 64);
+    const int oj = __shfl_xor(j, s2, 64);
+    if (oj >= 0 && (j < 0 || cand_less(ov, oj, v, j))) { v = ov; j = oj; }
+  }
+}
+__global__ __launch_bounds__(256) void fuse_select_wave_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i, int m, int n,
+                                                                const double* __restrict__ mom_all, int G, int q_row0, int db_row0,
+                                                                int mask_width, double p_weight, int k, int32_t* __restrict__ idx,
+                                                                float* __restrict__ score, double* __restrict__ score64) {
+  __shared__ double lv_[4][WS_CAP];
+  __shared__ int lj_[4][WS_CAP];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int q = blockIdx.x * 4 + w;
+  if (q >= m) return;                                  // (whole wave; nothing below synchronises across waves)
+  double* lv = lv_[w];
+  int* lj = lj_[w];
+  const bool plain = (d_i == nullptr);
+  double st0 = 0.0, st1 = 1.0;
+  if (!plain && lane < 2) {                            // Chan's combination of the shard moments in rank order, as in select_row
+    double cn = 0.0, mean = 0.0, m2 = 0.0;
+    for (int g = 0; g < G; g++) {
+      const double* o = mom_all + (((size_t)g * m + q) * 2 + lane) * 3;
+      const double nb = o[0], mb = o[1], m2b = o[2];
+      if (nb <= 0.0) continue;
+      const double tot = cn + nb, delta = mb - mean;
+      mean += delta * (nb / tot);
+      m2 += m2b + delta * delta * (cn * nb / tot);
+      cn = tot;
+    }
+    st0 = mean;
+    st1 = sqrt(m2 / (cn - 1.0));
+  }
+  const double mp = plain ? 0.0 : __shfl(st0, 0, 64), sp = plain ? 1.0 : __shfl(st1, 0, 64);
+  const double mi = plain ? 0.0 : __shfl(st0, 1, 64), si = plain ? 1.0 : __shfl(st1, 1, 64);
+  const float* rp = d_p + (size_t)q * n;
+  const float* ri = plain ? rp : d_i + (size_t)q * n;
+  const int ig = q_row0 + q;
+  const bool fastdiv = !plain && sp > 1e-290 && sp < 1e290 && si > 1e-290 && si < 1e290;
+  const double rsp = 1.0 / sp, rsi = 1.0 / si;
+  auto fusedw = [&](float vp, float vi, int j) -> double {
+    const int jg = db_row0 + j;
+    double f;
+    if (plain) f = (double)vp;
+    else if (fastdiv) f = p_weight * div_rn((double)vp - mp, sp, rsp) + div_rn((double)vi - mi, si, rsi);        // run_test.m:40
+    else f = p_weight * (((double)vp - mp) / sp) + ((double)vi - mi) / si;
+    int dij = ig - jg;
+    if (dij < 0) dij = -dij;
+    if (dij < mask_width) f = __builtin_inf();                                      // run_test.m:47-53
+    return f;
+  };
+  auto emit = [&](int t, double v, int jg) {
+    idx[(size_t)q * k + t] = jg;
+    const float f32 = (jg >= 0) ? (float)v : __builtin_nanf("");
+    score[(size_t)q * k + t] = f32;
+    if (score64) score64[(size_t)q * k + t] = (double)f32;
+  };
+  int head = (int)((4 - ((reinterpret_cast<size_t>(rp) >> 2) & 3)) & 3);
+  if (head > n) head = n;
+  const bool coaligned = !((reinterpret_cast<size_t>(rp) ^ reinterpret_cast<size_t>(ri)) & 15);
+  if (!coaligned) head = 0;
+  const int nv = coaligned ? (n - head) >> 2 : 0;
+  const f32x4* rp4 = reinterpret_cast<const f32x4*>(rp + head);
+  const f32x4* ri4 = reinterpret_cast<const f32x4*>(ri + head);
+  // visit(valid, j, vp, vi) over the row, called by ALL lanes together (wave-uniform control flow: the visitors use ballots): the aligned
+  // body in 16-byte loads (four in flight), scalars on the ragged ends
+  auto sweep = [&](auto&& visit) {
+    if (head > 0) { const bool v = lane < head; visit(v, lane, v ? rp[lane] : 0.f, v ? ri[lane] : 0.f); }
+    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+    auto four = [&](bool v, const f32x4& a, const f32x4& b, int j) {
+      const int j0 = head + 4 * j;
+#pragma unroll
+      for (int e = 0; e < 4; e++) visit(v, j0 + e, a[e], b[e]);
+    };
+    for (int j0 = 0; j0 < nv; j0 += 256) {
+      const int j = j0 + lane;
+      const bool v0 = j < nv, v1 = j + 64 < nv, v2 = j + 128 < nv, v3 = j + 192 < nv;
+      const f32x4 a0 = v0 ? rp4[j] : z4, a1 = v1 ? rp4[j + 64] : z4, a2 = v2 ? rp4[j + 128] : z4, a3 = v3 ? rp4[j + 192] : z4;
+      const f32x4 b0 = v0 ? ri4[j] : z4, b1 = v1 ? ri4[j + 64] : z4, b2 = v2 ? ri4[j + 128] : z4, b3 = v3 ? ri4[j + 192] : z4;
+      four(v0, a0, b0, j); four(v1, a1, b1, j + 64); four(v2, a2, b2, j + 128); four(v3, a3, b3, j + 192);
+    }
+    for (int t0 = head + 4 * nv; t0 < n; t0 += 64) {
+      const int t = t0 + lane;
+      const bool v = t < n;
+      visit(v, t, v ? rp[t] : 0.f, v ? ri[t] : 0.f);
+    }
+  };
+  // ---- (a) threshold: the r-th smallest of the lanes' minima over the first ns columns
+  double tau = __builtin_inf();
+  const int r = k + 7 > 16 ? k + 7 : 16;                // <= 23 of 64 lanes
+  if (n > WS_CAP) {
+    double mv = 0.0;
+    int mj = -1;
+    // sample size: ~r n / ns elements pass the threshold - 1024 columns up to 32k entries, more beyond so that ~512 are expected at most
+    long long want = ((long long)n * r / 512 + 63) & ~63ll;
+    const int ns = (int)(want < 1024 ? 1024 : (want < n ? want : n));
+    for (int j = lane; j < ns; j += 64) {
+      const double f = fusedw(rp[j], ri[j], j);
+      const int jg = db_row0 + j;
+      if (f == f && (mj < 0 || cand_less(f, jg, mv, mj))) { mv = f; mj = jg; }
+    }
+    int before = 0;
+#pragma unroll 8
+    for (int u = 0; u < 64; u++) {
+      const double ov = __shfl(mv, u, 64);
+      const int oj = __shfl(mj, u, 64);
+      if (oj >= 0 && (mj < 0 || cand_less(ov, oj, mv, mj))) before++;
+    }
+    const unsigned long long hit = __ballot(mj >= 0 && before == r - 1);    // global indices are unique within a row: one lane, if any
+    if (hit) tau = __shfl(mv, __ffsll((long long)hit) - 1, 64);
+  }
+  // ---- (b) everything at or below tau into the wave's list (a row that fits: every finite element)
+  int L = 0;
+  {
+    const bool pre = !plain && fastdiv && tau < __builtin_inf();          // the affine test in front of the exact score, as in select_row
+    const double a1 = p_weight / sp, b1 = 1.0 / si, c1 = -(p_weight * mp / sp + mi / si);
+    const double tauE = tau + 1e-10 * (1.0 + fabs(a1) + fabs(b1) + fabs(c1) + fabs(tau));
+    sweep([&](bool valid, int j, float vp, float vi) {
+      bool take = false;
+      double f = 0.0;
+      if (valid && (!pre || __builtin_fma(a1, (double)vp, __builtin_fma(b1, (double)vi, c1)) <= tauE)) {
+        f = fusedw(vp, vi, j);
+        take = f <= tau;                                                    // (NaN compares false; tau = +Inf takes every finite or +Inf score)
+      }
+      const unsigned long long mk = __ballot(take);
+      if (take) {
+        const int slot = L + __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
+        if (slot < WS_CAP) { lv[slot] = f; lj[slot] = db_row0 + j; }
+      }
+      L += __popcll(mk);
+    });
+  }
+  if (L <= WS_CAP) {
+    // ---- (c) the k best of the list by (score, index): k rounds, each the smallest entry behind the one selected last
+    double pv = -__builtin_inf();
+    int pj = -1;
+    for (int t = 0; t < k; t++) {
+      double bv = 0.0;
+      int bj = -1;
+      for (int s2 = lane; s2 < L; s2 += 64) {
+        const double v = lv[s2];
+        const int jg = lj[s2];
+        if ((pj < 0 || cand_less(pv, pj, v, jg)) && (bj < 0 || cand_less(v, jg, bv, bj))) { bv = v; bj = jg; }
+      }
+      wave_argmin(bv, bj);
+      if (lane == 0) emit(t, bv, bj);
+      if (bj < 0) {
+        if (lane == 0) for (int u = t + 1; u < k; u++) emit(u, 0.0, -1);
+        break;
+      }
+      pv = bv; pj = bj;
+    }
+    return;
+  }
+  // ---- fallback (the list overflowed): one sweep per selected element
+  double pv = -__builtin_inf();
+  int pj = -1;
+  for (int t = 0; t < k; t++) {
+    double bv = 0.0;
+    int bj = -1;
+    sweep([&](bool valid, int j, float vp, float vi) {
+      if (!valid) return;
+      const double f = fusedw(vp, vi, j);
+      const int jg = db_row0 + j;
+      if (f != f) return;
+      if (pj >= 0 && !cand_less(pv, pj, f, jg)) return;                              // already selected
+      if (bj < 0 || cand_less(f, jg, bv, bj)) { bv = f; bj = jg; }
+    });
+    wave_argmin(bv, bj);
+    if (lane == 0) emit(t, bv, bj);
+    if (bj < 0) {
+      if (lane == 0) for (int u = t + 1; u < k; u++) emit(u, 0.0, -1);
+      break;
+    }
+    pv = bv; pj = bj;
+  }
+}
+
 // P lists of k (score, index) pairs per query [P][m][k] -> the k best [m][k]; missing entries are -1.  The P k entries (at most 8192) go
 // through a radix selection / a bitonic network in LDS (lv: N floats, lj: N ints, N = the next power of two).
 __device__ void merge_slices(const int32_t* sidx, const float* sscore, int P, int m, int k, int q, float* lv, int* lj, double* rv, int* rj,
@@ -696,6 +886,13 @@ void launch_fuse_select(hipStream_t st, const float* d_p, const float* d_i, int 
     if ((size_t)N * 8 > 40 * 1024)
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(slice_merge_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)N * 8));
     hipLaunchKernelGGL(slice_merge_kernel, dim3(m), dim3(256), (size_t)N * 8, st, sidx, ssc, P, m, k, idx, score, score64);
+    return;
+  }
+  static const bool wave_rows = !(getenv("PR_SELECT_WAVE") && atoi(getenv("PR_SELECT_WAVE")) == 0);     // A/B: PR_SELECT_WAVE=0
+  static const int wave_max_n = getenv("PR_SELECT_WAVE_N") ? atoi(getenv("PR_SELECT_WAVE_N")) : 32768;
+  if (wave_rows && !e_p && n <= wave_max_n && k <= 16 && m >= 64) {       // short rows: one wave per row (fuse_select_wave_kernel)
+    hipLaunchKernelGGL(fuse_select_wave_kernel, dim3((m + 3) / 4), dim3(256), 0, st, d_p, d_i, m, n, mom_all, G, q_row0, db_row0, mask_width,
+                       p_weight, k, idx, score, score64);
     return;
   }
   // (a 1024-entry list - 17 KB of LDS, 9 workgroups per CU instead of 3 - for whole rows with few results measured the same 0.87 ms per
