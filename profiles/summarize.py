@@ -22,14 +22,21 @@ def main():
             rows = list(c.execute(q))
             for r in rows:
                 print("%-72s n=%-3d avg=%9.3f min=%9.3f max=%9.3f total=%9.1f vgpr=%s agpr=%s lds=%s grid=%s" % ((r[0][:72],) + r[1:]))
-            # the timed step's launches of a kernel that also serves small calls (same grid size): the launches above half its maximum
-            print("-- launches longer than half the kernel's longest one (the timed steps, where a kernel also serves small calls)")
+            # kernels whose launches differ widely under one (name, grid) - the timed step's launches beside small calls, or the gated
+            # launches of the binary path that leave at once beside the ones that run: one line per duration cluster
+            # (sorted durations, a new cluster wherever the next one is more than 1.5x the last)
+            print("-- duration clusters of the kernels above whose launches differ widely (same name and grid): n, avg / min / max ms")
             for r in rows:
                 if r[4] > 4 * r[3] and r[4] > 1.0:
                     cond = " and %s = %d" % (grid, r[9]) if grid else ""
-                    a = c.execute("select count(*), avg(end-start)/1e6, min(end-start)/1e6, max(end-start)/1e6 from kernels where name = ? and (end-start) > ?" + cond,
-                                  (r[0], r[4] * 0.5e6)).fetchone()
-                    print("%-72s n=%-3d avg=%9.3f min=%9.3f max=%9.3f" % ((r[0][:72],) + a))
+                    ds = sorted(x[0] / 1e6 for x in c.execute("select end-start from kernels where name = ?" + cond, (r[0],)))
+                    cl = [[ds[0]]]
+                    for d in ds[1:]:
+                        if d > 1.5 * cl[-1][-1]:
+                            cl.append([])
+                        cl[-1].append(d)
+                    for g in cl:
+                        print("%-72s n=%-3d avg=%9.3f min=%9.3f max=%9.3f" % (r[0][:72], len(g), sum(g) / len(g), g[0], g[-1]))
         if has_pmc:
             print("-- PMC (rocprofv3 --pmc ...): kernel, counter, sum over dispatches, dispatches")
             q = ("select kernel_name, counter_name, sum(value), count(*) from counters_collection"
