@@ -238,15 +238,35 @@ __device__ __forceinline__ bool pair_is_evaluated(const RerankArgs& A, const int
 // Batches: one WAVE per query decides for all of its candidates (lane = candidate), writes the scores of those that are not evaluated and
 // appends the others to a work list - most candidates of a query with a clear winner are pruned, and a workgroup of 256 threads that only
 // finds that out costs what ~10 us of dependent loads cost (8 of 9 workgroups of the metric workload, 56 of 57 in PR_SC_ARITH_F16).
-__global__ __launch_bounds__(64) void rerank_plan_kernel(RerankArgs A, const int32_t* __restrict__ idx_in, int32_t* __restrict__ work,
-                                                          unsigned* __restrict__ count) {
-  const int q = blockIdx.x, lane = threadIdx.x;
-  for (int t = lane; t < A.kin; t += 64) {
+// (16 queries per workgroup and ONE atomicAdd per workgroup for its share of the work list: one atomic per evaluated pair on the same word
+// cost this kernel 52 - 61 us per 4096 - 5000 queries - same-address atomics from eight XCDs serialise at ~25 ns each)
+constexpr int PLAN_QB = 16;
+__global__ __launch_bounds__(256) void rerank_plan_kernel(RerankArgs A, const int32_t* __restrict__ idx_in, int32_t* __restrict__ work,
+                                                           unsigned* __restrict__ count) {
+  __shared__ unsigned wsum[4];
+  __shared__ unsigned base;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int q0 = blockIdx.x * PLAN_QB, items = PLAN_QB * A.kin;
+  int mine[8];                                         // kin <= 128: at most 16 x 128 / 256 items per thread
+  int nmine = 0;
+  for (int it = tid; it < items; it += 256) {
+    const int q = q0 + it / A.kin, t = it % A.kin;
+    if (q >= A.m) continue;
     int jl = 0;
     double skipv = 0.0;
-    if (pair_is_evaluated(A, idx_in, q, t, &jl, &skipv)) work[atomicAdd(count, 1u)] = q * A.kin + t;
+    if (pair_is_evaluated(A, idx_in, q, t, &jl, &skipv)) mine[nmine++] = q * A.kin + t;
     else { A.p5[p5_at(0, A.m, q, 0, A.kin, t)] = skipv; A.p5[p5_at(0, A.m, q, 1, A.kin, t)] = __builtin_nan(""); }
   }
+  unsigned pre = (unsigned)nmine;                      // inclusive scan over the wave, then over the four waves
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(pre, o, 64); if (lane >= o) pre += v; }
+  if (lane == 63) wsum[wv] = pre;
+  __syncthreads();
+  if (tid == 0) base = atomicAdd(count, wsum[0] + wsum[1] + wsum[2] + wsum[3]);
+  __syncthreads();
+  unsigned off = base + pre - (unsigned)nmine;
+  for (int w2 = 0; w2 < wv; w2++) off += wsum[w2];
+  for (int i = 0; i < nmine; i++) work[off + i] = mine[i];
 }
 
 // The exact distance(s) of a pair into its p5 slots, and its fused score = the sum of the channel terms in channel order (run_test.m:40).
@@ -892,7 +912,7 @@ static void launch_rerank_kernel(hipStream_t st, const RerankArgs& A, const int3
   int32_t* work = reinterpret_cast<int32_t*>(tick + tick_cap);
   unsigned* count = tick + 2 * tick_cap;
   launch_zero_ints(st, reinterpret_cast<int*>(count), 1);     // (a kernel: tiny memset nodes of a captured graph have been seen not to replay, see pr_sigset_pack)
-  hipLaunchKernelGGL(rerank_plan_kernel, dim3(A.m), dim3(64), 0, st, A, idx_in, work, count);
+  hipLaunchKernelGGL(rerank_plan_kernel, dim3((A.m + PLAN_QB - 1) / PLAN_QB), dim3(256), 0, st, A, idx_in, work, count);
   const unsigned grid = pairs < 7168 ? (unsigned)pairs : 7168u;      // 256 CUs x 7 workgroups (their LDS) x 4 rounds
   hipLaunchKernelGGL(rerank_kernel<2>, dim3(grid), dim3(256), 0, st, A, idx_in, tick, work, count);
 }
