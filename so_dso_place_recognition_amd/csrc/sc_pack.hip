@@ -178,9 +178,10 @@ __global__ __launch_bounds__(320) void sc_pack_h_kernel(const T* __restrict__ si
 //   output    = hi / lo halves scattered into an LDS copy of the workgroup's 8 frequency slices of the group image
 //               (a slice is contiguous: 3072 B per DB group, 1288 B per query group), then copied out linearly.
 // Binary-channel statistics (kernels.hpp: ScBin; LO images only, channel 1, binfo != null): the frequency-block-0 workgroup of a row block
-// decides whether each row is binary (all non-zero entries equal and positive) and leaves binfo / bstat[0..1]; every workgroup adds up the
-// w-weighted squares of the rounding residuals val - hi of its own frequencies (in units of the normalised spectrum) per row and keeps the
-// largest in bstat[2 + fb] - all by atomicOr / atomicMax, whose result does not depend on the order.
+// decides whether each row is binary (all non-zero entries equal and positive) and leaves binfo and, in the block's slot behind bstat, the
+// non-binary flag and the largest ones; every workgroup adds up the w-weighted squares of the rounding residuals val - hi of its own
+// frequencies (in units of the normalised spectrum) per row and leaves the largest of its 16 rows in the same slot (entry 2 + fb);
+// sc_bstat_finalize_kernel folds the slots into bstat[0..5] (OR / max: the result does not depend on any order).
 template <typename T, int ROLE, bool LO>
 __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict__ sig, int rows,
                                                              unsigned short* __restrict__ packed, int groups,
