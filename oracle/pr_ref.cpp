@@ -722,4 +722,69 @@ int pr_ref_match_topk_fused(const double* sc1, const double* m2dp1, int32_t m, c
   return pr_ref_select_topk(f.data(), m, n, mask_width, k, idx, score);
 }
 
+// run_test.m:3-22 (ground-truth loop pairs) and :58-85 (precision / recall sweep, top recall at 100 % precision, trapz AUC, lp_detected),
+// line for line.  Input = what run_test.m:57 leaves: diff_v [m] (NaN / +Inf allowed) and diff_idx [m], 0-based; an index of -1 (the build's
+// "no finite candidate") is read as 0: MATLAB's min over an all-NaN / all-Inf row returns index 1.  gt1 [m][cols], gt2 [n][cols].
+// Outputs (any may be NULL): auc, top_recall, lp_gt [m][2] + n_gt (0-based pairs of :19), lp_detected [m][2] + n_detected (:85),
+// precision [m], recall [m].  Divisions are MATLAB's (IEEE): total_lp = 0 gives recall NaN (0/0) or Inf.
+int pr_ref_precision_recall(const double* diff_v, const int32_t* diff_idx, int32_t m, const double* gt1, const double* gt2, int32_t n,
+                            int32_t cols, double loop_diff, int32_t mask_width, double* auc, double* top_recall, int32_t* lp_gt,
+                            int32_t* n_gt, int32_t* lp_detected, int32_t* n_detected, double* precision_out, double* recall_out) {
+  if (m < 0 || n < 0 || cols < 1 || (m > 0 && (!diff_v || !diff_idx || !gt1)) || (n > 0 && !gt2)) return PR_REF_EINVAL;
+  const double inf = std::numeric_limits<double>::infinity();
+  auto sq = [&](int a, int b) {                                   // diff = gt1(a,:) - gt2(b,:); diff = diff*diff'  (:10-11, :70-71)
+    double s = 0.0;
+    for (int c = 0; c < cols; c++) { const double t = gt1[(size_t)a * cols + c] - gt2[(size_t)b * cols + c]; s += t * t; }
+    return s;
+  };
+  // :3-22
+  std::vector<std::array<int, 2>> lp;
+  for (int i = 0; i < m; i++) {                                   // :4  for i=1:size(gt1,1)
+    double min_diff = inf;                                        // :5
+    int min_j = -1;                                               // :6
+    for (int j = 0; j < n; j++) {                                 // :7
+      if (std::abs(i - j) < mask_width) continue;                 // :8-10
+      const double diff = sq(i, j);                               // :11-12
+      if (min_diff > diff) { min_diff = diff; min_j = j; }        // :13-16
+    }
+    if (min_diff < loop_diff * loop_diff) lp.push_back({i, min_j});   // :18-20
+  }
+  const size_t L = lp.size();
+  const double total_lp = L == 0 ? 0.0 : (double)std::max<size_t>(L, 2);   // :22 length() of an L x 2 matrix = max(L, 2); of [] = 0
+  if (n_gt) *n_gt = (int32_t)L;
+  if (lp_gt) for (size_t i = 0; i < L; i++) { lp_gt[2 * i] = lp[i][0]; lp_gt[2 * i + 1] = lp[i][1]; }
+  // :58 [~, diff_rank] = sort(diff_v): ascending, stable, NaN after +Inf
+  std::vector<int> diff_rank((size_t)m);
+  for (int i = 0; i < m; i++) diff_rank[i] = i;
+  std::stable_sort(diff_rank.begin(), diff_rank.end(), [&](int a, int b) {
+    const double x = diff_v[a], y = diff_v[b];
+    if (std::isnan(x) || std::isnan(y)) return !std::isnan(x) && std::isnan(y);
+    return x < y;
+  });
+  // :60-83
+  double tp = 0, fp = 0;                                          // :60-61 (MATLAB doubles)
+  std::vector<double> precision((size_t)m, 0.0), recall((size_t)m, 0.0);   // :62-63
+  double tr = 0.0;                                                // :64
+  int top_count = 0;                                              // :65
+  for (int i = 0; i < m; i++) {                                   // :66
+    const int a = diff_rank[i];                                   // :67
+    const int b = diff_idx[a] < 0 ? 0 : diff_idx[a];              // :68 (min's index 1 for an all-NaN / all-Inf row)
+    const double diff = sq(a, b);                                 // :69-70
+    if (diff < loop_diff * loop_diff) tp = tp + 1; else fp = fp + 1;   // :71-75
+    precision[i] = tp / (tp + fp);                                // :76
+    recall[i] = tp / total_lp;                                    // :77
+    if (precision[i] == 1) { top_count = i + 1; tr = recall[i]; } // :79-82
+  }
+  double area = 0.0;                                              // :84 trapz(recall, precision)
+  for (int i = 0; i + 1 < m; i++) area += (recall[i + 1] - recall[i]) * (precision[i] + precision[i + 1]) / 2.0;
+  if (auc) *auc = area;
+  if (top_recall) *top_recall = tr;
+  if (n_detected) *n_detected = top_count;                        // :85 lp_detected = [diff_rank(1:top_count)', diff_idx(diff_rank(1:top_count))']
+  if (lp_detected)
+    for (int i = 0; i < top_count; i++) { lp_detected[2 * i] = diff_rank[i]; lp_detected[2 * i + 1] = diff_idx[diff_rank[i]] < 0 ? 0 : diff_idx[diff_rank[i]]; }
+  if (precision_out) std::copy(precision.begin(), precision.end(), precision_out);
+  if (recall_out) std::copy(recall.begin(), recall.end(), recall_out);
+  return PR_REF_OK;
+}
+
 }  // extern "C"

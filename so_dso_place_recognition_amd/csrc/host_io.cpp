@@ -410,7 +410,7 @@ int pr_precision_recall(const double* diff_v, const int32_t* diff_idx, int32_t m
     const int a = rank[i], b = diff_idx[a] < 0 ? 0 : diff_idx[a];
     if (b < n && d2(a, b) < thr) tp++; else fp++;
     const double p = (double)tp / (double)(tp + fp);
-    const double r = total_lp ? (double)tp / (double)total_lp : NAN;
+    const double r = (double)tp / (double)total_lp;              // :77 as MATLAB divides: no ground-truth pair -> 0/0 = NaN (x/0 = Inf)
     if (p == 1.0) { top_count = i + 1; tr = r; }
     if (i > 0) area += (r - rprev) * (p + pprev) / 2.0;      // trapz(recall, precision) (:85)
     pprev = p; rprev = r;

@@ -52,12 +52,14 @@ def precision_recall(diff_v, diff_idx, gt1, gt2, loop_diff: float, mask_width: i
         else:
             fp += 1
         precision[i] = tp / (tp + fp)
-        recall[i] = tp / total_lp if total_lp else np.nan
+        recall[i] = tp / total_lp if total_lp else (np.inf if tp else np.nan)   # :77 as MATLAB divides (x/0 = Inf, 0/0 = NaN)
         if precision[i] == 1:
             top_count = i + 1
             top_recall = recall[i]
-    trapz = getattr(np, "trapezoid", None) or np.trapz
-    auc = float(trapz(precision, recall))              # trapz(recall, precision)
+    auc = 0.0                                          # trapz(recall, precision) (:84), summed in sweep order like pr_precision_recall
+    with np.errstate(invalid="ignore"):                # (recall is NaN / Inf without ground-truth pairs)
+        for i in range(m - 1):
+            auc += (recall[i + 1] - recall[i]) * (precision[i] + precision[i + 1]) / 2.0
     lp_detected = np.stack([rank[:top_count], diff_idx[rank[:top_count]]], 1)
     return auc, float(top_recall), lp_detected, precision, recall
 

@@ -52,6 +52,8 @@ def lib():
     L.pr_ref_select_topk.argtypes = [_dp, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _ip, _dp]
     L.pr_ref_fuse_topk.argtypes = [_dp, _dp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_int32, _ip, _dp]
     L.pr_ref_match_topk.argtypes = [C.c_int, _dp, C.c_int32, _dp, C.c_int32, C.c_int32, C.c_double, C.c_int32, _ip, _dp]
+    L.pr_ref_precision_recall.argtypes = [_dp, _ip, C.c_int32, _dp, _dp, C.c_int32, C.c_int32, C.c_double, C.c_int32, C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), _ip, C.POINTER(C.c_int32), _ip, C.POINTER(C.c_int32), _dp, _dp]
     _lib = L
     return L
 
@@ -224,3 +226,22 @@ def unordered_order(keys):
     out = np.empty(len(k), np.int32)
     assert lib().pr_ref_unordered_order(k, len(k), out) == 0
     return out
+
+
+def precision_recall(diff_v, diff_idx, gt1, gt2, loop_diff, mask_width):
+    """run_test.m:3-22, 58-85 -> dict(auc, top_recall, lp_gt [L,2], lp_detected [T,2], precision [m], recall [m]); 0-based indices."""
+    diff_v = np.ascontiguousarray(diff_v, np.float64)
+    diff_idx = np.ascontiguousarray(diff_idx, np.int32)
+    gt1 = np.ascontiguousarray(gt1, np.float64)
+    gt2 = np.ascontiguousarray(gt2, np.float64)
+    m, n, cols = gt1.shape[0], gt2.shape[0], gt1.shape[1]
+    assert diff_v.shape == (m,) and diff_idx.shape == (m,) and gt2.shape[1] == cols
+    auc, tr, ng, nd = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
+    lp_gt = np.zeros((max(m, 1), 2), np.int32)
+    lp_det = np.zeros((max(m, 1), 2), np.int32)
+    prec = np.zeros(max(m, 1)); rec = np.zeros(max(m, 1))
+    rc = lib().pr_ref_precision_recall(diff_v, diff_idx, m, gt1, gt2, n, cols, float(loop_diff), int(mask_width), C.byref(auc), C.byref(tr),
+                                       lp_gt, C.byref(ng), lp_det, C.byref(nd), prec, rec)
+    assert rc == 0, rc
+    return dict(auc=auc.value, top_recall=tr.value, lp_gt=lp_gt[:ng.value].astype(np.int64), lp_detected=lp_det[:nd.value].astype(np.int64),
+                precision=prec[:m], recall=rec[:m])

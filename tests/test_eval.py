@@ -1,6 +1,7 @@
 """run_test.m evaluation part (ground-truth pairs, PR sweep, AUC) against a loop-by-loop restatement."""
 import numpy as np
 
+import oracle_lib
 from so_dso_place_recognition_amd import eval as ev
 
 
@@ -52,7 +53,65 @@ def test_precision_recall_sweep():
         tp += float(d @ d) < 9.0
         p2.append(tp / (i + 1))
     assert np.allclose(prec, p2)
+    o = oracle_lib.precision_recall(diff_v, diff_idx, gt, gt, 3.0, 10)      # the oracle's line-for-line run_test.m:3-22, 58-85
+    assert auc == o["auc"] and top_recall == o["top_recall"] and np.array_equal(det, o["lp_detected"])
+    assert np.array_equal(prec, o["precision"]) and np.array_equal(rec, o["recall"]) and np.array_equal(lp, o["lp_gt"])
     assert 0 < auc <= 1
+
+
+def _c_sweep(v, idx, gt1, gt2, ld, mask):
+    import ctypes as C
+    from so_dso_place_recognition_amd import _lib
+    lib = _lib.load()
+    v = np.ascontiguousarray(v, np.float64); idx = np.ascontiguousarray(idx, np.int32)
+    gt1 = np.ascontiguousarray(gt1, np.float64); gt2 = np.ascontiguousarray(gt2, np.float64)
+    m, n = len(gt1), len(gt2)
+    auc, tr, nd = C.c_double(), C.c_double(), C.c_int32()
+    lp = np.zeros((max(m, 1), 2), np.int32)
+    p = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert lib.pr_precision_recall(p(v), p(idx), m, p(gt1), p(gt2), n, gt1.shape[1], ld, mask, C.byref(auc), C.byref(tr), p(lp), C.byref(nd)) == 0
+    return auc.value, tr.value, lp[:nd.value].astype(np.int64)
+
+
+def _same(a, b):
+    return a == b or (np.isnan(a) and np.isnan(b))
+
+
+def test_auc_top_recall_and_lp_detected_equal_the_oracle_sweep():
+    """eval.precision_recall AND pr_precision_recall against oracle/pr_ref.cpp's literal run_test.m:3-22, 58-85 (sort, tp / fp loop,
+    top_count, trapz): AUC, top_recall and lp_detected must be EQUAL - also with NaN / +Inf scores, index -1 (no finite candidate:
+    a zero-norm query, or a mask that covers the whole DB), ties in diff_v, a single ground-truth pair (length() of a 1 x 2 matrix
+    is 2) and no ground-truth pair at all (recall = 0/0)."""
+    rng = np.random.default_rng(7)
+    cases = []
+    for m, n, mask, ld in ((200, 220, 5, 10.0), (50, 50, 0, 3.0), (7, 3, 2, 1e9), (5, 5, 100, 10.0), (64, 64, 8, 4.0), (40, 90, 0, 1e-9), (1, 1, 0, 1.0)):
+        gt1 = np.cumsum(rng.normal(0, 3, (m, 3)), 0)
+        hn = min(m, n // 2)
+        gt2 = np.concatenate([gt1[:hn] + rng.normal(0, 1, (hn, 3)), rng.normal(0, 100, (n - hn, 3))])
+        v = rng.random(m); idx = rng.integers(0, n, m).astype(np.int32)
+        h = min(m, n) // 2
+        idx[:h] = np.arange(h); v[:h] *= 0.3
+        cases.append((v, idx, gt1, gt2, ld, mask))
+        if m >= 40:
+            v2, i2 = v.copy(), idx.copy()
+            v2[m - 3:] = np.nan; i2[m - 3:] = -1                  # zero-norm queries: every distance NaN
+            v2[m - 6:m - 3] = np.inf                              # MATLAB's all-masked rows: min = +Inf at index 1 ...
+            i2[m - 6:m - 3] = 0
+            v2[5:9] = v2[5]                                       # ties keep their query order (stable sort)
+            g1 = gt1.copy(); g1[m - 1] = gt2[0]                   # ... and the last one is then a true positive at the end of the sweep
+            cases.append((v2, i2, g1, gt2, ld, mask))
+            cases.append((np.full(m, np.nan), np.full(m, -1, np.int32), gt1, gt2, ld, mask))   # nothing matched at all
+    one = np.zeros((6, 3)); one[:, 0] = np.arange(6) * 100.0
+    two = one.copy(); two[3] = one[3] + 0.5; two[[0, 1, 2, 4, 5]] += 1e4         # exactly one ground-truth pair
+    cases.append((np.array([.5, .4, .3, .1, .2, .6]), np.array([1, 2, 0, 3, 3, 3], np.int32), one, two, 1.0, 0))
+    for v, idx, gt1, gt2, ld, mask in cases:
+        o = oracle_lib.precision_recall(v, idx, gt1, gt2, ld, mask)
+        auc, tr, det, prec, rec = ev.precision_recall(v, idx, gt1, gt2, ld, mask)
+        assert _same(auc, o["auc"]) and _same(tr, o["top_recall"]) and np.array_equal(det, o["lp_detected"])
+        assert np.array_equal(prec, o["precision"]) and np.array_equal(rec, o["recall"], equal_nan=True)
+        assert np.array_equal(ev.ground_truth_pairs(gt1, gt2, ld, mask), o["lp_gt"])
+        cauc, ctr, cdet = _c_sweep(v, idx, gt1, gt2, ld, mask)
+        assert _same(cauc, o["auc"]) and _same(ctr, o["top_recall"]) and np.array_equal(cdet, o["lp_detected"])
 
 
 # ------------------------------------------------------------------ the drivers (test_kitti.m, test_robotcar.m) on reference data
@@ -101,6 +160,29 @@ def test_drivers_run_kitti_and_run_robotcar():
     f = _rff(both, scale=40.0)
     auc, top_recall, det = ev.run_robotcar(d1, d2, "gist", hist1=f[: len(g1)], hist2=f[len(g1):])
     assert auc > 0.9 and top_recall > 0.3 and all(((g1[a] - g2[b]) ** 2).sum() < 625.0 for a, b in det)
+
+
+@pytest.mark.gpu
+def test_run_test_end_to_end_equals_the_oracle_chain():
+    """run_test(type, hist1, hist2, gt1, gt2, loop_diff, mask_width) (run_test.m:1-85) on the GPU against the oracle's chain
+    pr_ref_match_topk (k = 1) -> pr_ref_precision_recall: AUC, top_recall and lp_detected equal.  A drive that passes every place twice
+    (signatures of the second lap = perturbed copies of the first), with two zero-norm queries and a mask wider than the lap gap of the
+    first places."""
+    from so_dso_place_recognition_amd import api, synth
+    n = 360
+    base = synth.sc_database(45, n // 2)
+    lap2, _ = synth.sc_queries(46, base, n // 2)                      # query t copies a random entry: reorder to entry order
+    rng = np.random.default_rng(5)
+    hist = np.concatenate([base, base * (1.0 + 0.02 * rng.random(base.shape))])
+    hist[7] = 0.0; hist[200] = 0.0                                   # zero-norm rows: NaN distances, index -1 / MATLAB index 1
+    t = np.linspace(0, 4 * np.pi, n, endpoint=False)
+    gt = np.stack([50 * np.cos(t), np.zeros(n), 50 * np.sin(t)], 1)
+    for mask, ld in ((100, 10.0), (0, 5.0), (190, 10.0)):
+        auc, tr, det = api.run_test("sc", hist, hist, gt, gt, ld, mask)
+        rc, oidx, osc = oracle_lib.match_topk(0, hist, hist, mask, 2.0, 1)
+        o = oracle_lib.precision_recall(osc[:, 0], oidx[:, 0], gt, gt, ld, mask)
+        assert _same(auc, o["auc"]) and _same(tr, o["top_recall"]) and np.array_equal(det, o["lp_detected"])
+        assert mask == 190 or (len(det) > 50 and tr > 0.2)
 
 
 def test_c_abi_precision_recall_equals_the_python_restatement():
