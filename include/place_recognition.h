@@ -45,8 +45,9 @@ enum { PR_SC_ARITH_F16X2 = 0, PR_SC_ARITH_F32 = 1, PR_SC_ARITH_F16 = 2 };
  * PR_NAN_EXCLUDE (default) does exactly that and reports PR_WARN_NAN_ROWS; PR_NAN_FAIL turns it into the error PR_ENAN at pr_sync. */
 enum { PR_NAN_EXCLUDE = 0, PR_NAN_FAIL = 1 };
 enum { PR_WARN_NAN_ROWS = 1, PR_WARN_M2DP_SVD = 2, PR_WARN_F16_FALLBACK = 4, PR_WARN_ORDER_RESOLVED = 8,
-       PR_WARN_ORDER_UNRESOLVED = 16 };   /* bits of pr_take_warnings; the last one: a stream-ordered call met more than 64 queries whose order hangs
-                                            on the all-pairs pass's sigmas - those beyond the 64th keep the order of the fp32-statistics scores */
+       PR_WARN_ORDER_UNRESOLVED = 16 };   /* bits of pr_take_warnings; ORDER_RESOLVED: a query was answered from its exact fp64 row (order or containment
+                                            check, below); the last one: a stream-ordered call met more than 64 such queries - those beyond the 64th keep
+                                            the answer of the re-evaluated candidate list */
 
 #define PR_SC_SIG_LEN 2400    /* 2 x numS*numR = 2 x 60*20, SC/SC.h:7-8, test_sc.cpp:37-38 */
 #define PR_M2DP_SIG_LEN 384   /* 2 x (numP*numQ + numS*numR) = 2 x 192, M2DP/M2DP.h:7-10, test_m2dp.cpp:37-39 */
@@ -69,11 +70,11 @@ int pr_get_sc_arith(const pr_ctx* ctx);
 int pr_sync(pr_ctx* ctx);                            /* waits for the context's stream; reports deferred errors */
 int pr_set_nan_policy(pr_ctx* ctx, int policy);      /* PR_NAN_EXCLUDE | PR_NAN_FAIL */
 int pr_get_nan_policy(const pr_ctx* ctx);
-/* on != 0: EVERY query of a top-k call is treated as flagged by the order check, i.e. answered with fp64 row statistics (DESIGN.md section 2
- * "Returned order"): returned scores are then the reference's doubles to rounding (|score - oracle| < 1e-9 whatever |z|; by default they carry
- * the fp32 pass's ~2e-7 relative error of the row sigma, 3e-5 absolute at z = -160) - at ~23 ns per (query, DB entry) pair: 2.3 ms per query
- * and 100 000 entries.  The host calls resolve all queries; a stream-ordered call its first 64 (PR_WARN_ORDER_UNRESOLVED beyond).  Off by
- * default; the environment variable PR_FORCE_ORDER_FLAGS=1 sets it at creation (tests). */
+/* on != 0: EVERY query of a top-k call is treated as flagged, i.e. answered from its exact fp64 row (DESIGN.md section 2 "Returned order"):
+ * returned scores are then the reference's doubles to rounding (|score - oracle| < 1e-9 whatever |z|; by default they carry the fp32 pass's
+ * ~2e-7 relative error of the row sigma, 3e-5 absolute at z = -160).  The host calls and pr_group resolve all queries (passes of 64); a
+ * stream-ordered call its first 64 (PR_WARN_ORDER_UNRESOLVED beyond).  Off by default; the environment variable PR_FORCE_ORDER_FLAGS=1 sets it
+ * at creation (tests). */
 int pr_set_exact_statistics(pr_ctx* ctx, int on);
 /* Binary intensity channel (no reference counterpart as a switch; the arithmetic is processSC.m:15-33 on the values SC/SC.cpp:67-72 writes:
  * channel 1 of an SC signature is 0 / 1).  In PR_SC_ARITH_F16X2 the pack notices whether every channel-1 row of a set has all of its non-zero
@@ -241,42 +242,55 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
  * The sharded form of the re-evaluation (what makes its cost independent of the number of shards): the shards' fp32 top-(k+8) lists
  * are merged FIRST (pr_merge_topk_dev on the gathered lists) into the global candidates cand_idx DEVICE [m][k_in]; every shard then
  * evaluates only the candidates inside its rows [db_row0, db_row0 + n_local) (pr_rerank_partial_dev -> its p5 block), the blocks are
- * all-gathered, and pr_rerank_finish_dev takes each candidate's score from its owner, selects the k best and runs the order check
- * (mom_*: the statistics the scores were formed with, [G_mom][m][2][3]); the flags stay in the context. */
+ * all-gathered, and pr_rerank_finish_dev takes each candidate's score from its owner, selects the k best and runs the order and containment
+ * checks below (mom_*: the statistics the scores were formed with, [G_mom][m][2][3]; cand_score: the merged pass scores of cand_idx, DEVICE f64
+ * [m][k_in] ascending, or NULL = no containment check); the flags stay in the context. */
 int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                           const double* mom_sc, const double* mom_m2, int32_t m, int32_t n_local, int32_t G, int32_t q_row0, int32_t db_row0,
                           int32_t mask_width, double p_weight, int32_t k_in, const int32_t* cand_idx, const double* cand_score, int32_t k,
                           double* p5);
-int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t G_mom, const int32_t* cand_idx, const double* p5_all,
-                         int32_t G, int32_t m, int32_t k_in, int32_t k, double p_weight, int32_t* idx, double* score);
-/* Order check, every arithmetic (run_test.m:38-41,57 are fp64 throughout; the all-pairs pass is not).  pr_rerank_dev / pr_rerank_finish_dev
- * leave in the context one flag per query: set when two neighbours among the re-evaluated candidates (the selected k and the best one left
- * out) could change places under the sigma error of the all-pairs pass (their channels disagree about the order and the scores are closer
- * than sum_c eps_c |z_c(a) - z_c(b)|, eps_c = max(PR_F32_SIGMA_REL, 4 PR_F32_NOISE / (sigma_c sqrt(n - 1))); PR_SC_ARITH_F16: the PR_F16_*
- * constants, and pr_f16_margin_dev takes the flags - such queries go to the split-f16 pass).  A flagged query is answered with EXACT row
- * statistics: its distances to ALL n entries in fp64 (the reference's formulation, ~23 ns per pair = 2.3 ms per query and 100 000 entries)
- * -> (count, mean, M2) per channel -> the candidates' scores again from their exact distances -> the k best: indices and scores of that
- * query are then those of fp64 arithmetic throughout (run_test.m:38-57).  Three forms:
- *   pr_order_resolve_async_dev  single shard, right after pr_rerank_dev with the same arguments; STREAM-ORDERED, no host synchronisation
- *                               (fixed-grid kernels that leave at once when nothing is flagged: ~10 us; hipGraph-capturable).  Resolves up to
- *                               64 flagged queries per call; beyond that PR_WARN_ORDER_UNRESOLVED.  mom_sc / mom_m2 rows of resolved queries
- *                               are overwritten with the exact ones.  PR_WARN_ORDER_RESOLVED is raised (at pr_take_warnings) when one was.
- *   pr_order_resolve_dev        the same with a host round trip (reads the count back): resolves ALL flagged queries, *resolved (may be NULL)
+int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t G_mom, const int32_t* cand_idx, const double* cand_score,
+                         const double* p5_all, int32_t G, int32_t m, int32_t k_in, int32_t k, double p_weight, int32_t* idx, double* score);
+/* Two checks, every arithmetic (run_test.m:38-41,57 are fp64 over the WHOLE row; the all-pairs pass is neither).  pr_rerank_dev /
+ * pr_rerank_finish_dev leave in the context one word per query:
+ *   bit 0  ORDER: two neighbours among the re-evaluated candidates (the selected k and the best one left out) could change places under the
+ *          sigma error of the all-pairs pass (their channels disagree about the order and the scores are closer than
+ *          sum_c eps_c |z_c(a) - z_c(b)|, eps_c = max(PR_F32_SIGMA_REL, 4 PR_F32_NOISE / (sigma_c sqrt(n - 1))); PR_SC_ARITH_F16: the PR_F16_*
+ *          constants, and pr_f16_margin_dev takes the flags - such queries go to the split-f16 pass);
+ *   bit 1  CONTAINMENT (needs the candidates' pass scores: score_in / cand_score; not in PR_SC_ARITH_F16, whose margin check is
+ *          pr_f16_margin_dev): every entry outside the k_in candidates has a pass score >= the last candidate's, T, hence an exact score
+ *          >= T - err(T) - (what the sigma error can move it against a listed entry); when the exact k-th best is not below that, an entry
+ *          the list does not hold could belong to the top-k - more than k_in entries whose scores agree to the pass's resolution (1e-6 in
+ *          the distances): near-copies of one place.
+ * A flagged query is answered from its EXACT ROW: its distances to ALL n entries in fp64 -> (count, mean, M2) per channel -> fused scores,
+ * mask, the k smallest by (score, index): indices and scores of that query are then those of fp64 arithmetic throughout (run_test.m:38-57),
+ * whatever the all-pairs pass made of it.  Three forms, all in passes of 64 flagged queries (ascending):
+ *   pr_order_resolve_async_dev  single shard, right after pr_rerank_dev; STREAM-ORDERED, no host synchronisation (fixed-grid kernels that
+ *                               leave at once when nothing is flagged; hipGraph-capturable).  One pass: up to 64 flagged queries per call;
+ *                               beyond that PR_WARN_ORDER_UNRESOLVED.  mom_sc / mom_m2 rows of resolved queries are overwritten with the
+ *                               exact ones.  PR_WARN_ORDER_RESOLVED is raised (at pr_take_warnings) when a query was.
+ *   pr_order_resolve_dev        the same with a host round trip (reads the count back): ALL flagged queries, *resolved (may be NULL)
  *                               = their number.  The host top-k calls use this one.
- *   sharded                     after pr_rerank_finish_dev: pr_order_exact_moments_dev = this shard's exact (count, mean, M2) of the flagged
- *                               queries' rows, exact DEVICE f64 [m][4][3] (rows of other queries: unspecified) -> all-gather -> exact_all
- *                               [G][m][4][3] -> pr_order_rescore_dev on every rank (Chan combination in rank order: identical bits everywhere)
- *                               patches idx / score of the flagged queries.  Stream-ordered; 64 flagged queries per call as above. */
+ *   sharded                     after pr_rerank_finish_dev, per pass (offset = 0, 64, ...; pr_order_flagged_count gives the total, with a host
+ *                               synchronisation - a stream-ordered caller runs pass 0 only): pr_order_exact_moments_dev = this shard's rows of
+ *                               the flagged queries (kept in the context) and their exact (count, mean, M2), exact DEVICE f64 [m][4][3] (rows
+ *                               of other queries: unspecified) -> all-gather -> exact_all [G][m][4][3] -> pr_order_exact_select_dev = this
+ *                               shard's k best under the statistics of all shards (Chan combination in rank order), sel DEVICE f64 [64][2][k]
+ *                               (scores | global indices as doubles, -1 / NaN when the shard has fewer) -> all-gather -> sel_all [G][64][2][k] ->
+ *                               pr_order_exact_merge_dev on every rank patches idx / score of the pass's queries (identical inputs, identical
+ *                               results everywhere).  G <= 64. */
 int pr_order_resolve_async_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
-                               double* mom_sc, double* mom_m2, int32_t m, int32_t n, double p_weight, int32_t k_in, const int32_t* idx_in,
+                               double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight,
                                int32_t k, int32_t* idx, double* score);
 int pr_order_resolve_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
-                         double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight, int32_t k_in,
-                         const int32_t* idx_in, const double* score_in, int32_t k, int32_t* idx, double* score, int32_t* resolved);
+                         double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight, int32_t k,
+                         int32_t* idx, double* score, int32_t* resolved);
+int pr_order_flagged_count(pr_ctx* ctx, int32_t m, int32_t* count);   /* flagged queries of the last m-query pr_rerank_dev / pr_rerank_finish_dev (synchronises) */
 int pr_order_exact_moments_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
-                               const double* mom_sc, const double* mom_m2, int32_t G_mom, int32_t m, int32_t n_local, double* exact);
-int pr_order_rescore_dev(pr_ctx* ctx, const double* exact_all, int32_t G, int32_t m, int has_sc, int has_m2, double p_weight,
-                         const int32_t* cand_idx, const double* p5_all, int32_t k_in, int32_t k, int32_t* idx, double* score);
+                               const double* mom_sc, const double* mom_m2, int32_t G_mom, int32_t m, int32_t n_local, int32_t offset, double* exact);
+int pr_order_exact_select_dev(pr_ctx* ctx, const double* exact_all, int32_t G, int32_t m, int32_t n_local, int32_t q_row0, int32_t db_row0,
+                              int32_t mask_width, double p_weight, int has_sc, int has_m2, int32_t k, int32_t offset, double* sel);
+int pr_order_exact_merge_dev(pr_ctx* ctx, const double* sel_all, int32_t G, int32_t m, int32_t k, int32_t offset, int32_t* idx, double* score);
 /* fp32 scores of pr_fuse_select_dev as doubles (the merge works on doubles): DEVICE score32 [count] -> score64 [count] */
 int pr_widen_scores_dev(pr_ctx* ctx, const float* score32, int64_t count, double* score64);
 /* k-way merge of the per-shard results of G shards (SURVEY.md §8-e collective B's second half): idx_all DEVICE [G][m][k],
@@ -302,6 +316,7 @@ const char* pr_group_last_error(const pr_group* g);     /* g may be NULL (creati
 int32_t pr_group_size(const pr_group* g);
 int pr_group_uses_rccl(const pr_group* g);
 int32_t pr_group_rccl_ranks(const pr_group* g);         /* ncclCommCount of the group's communicator (0: the group exchanges by copies) */
+int32_t pr_group_last_flagged(const pr_group* g);       /* queries of the last pr_group_match_topk that were answered from their exact fp64 rows */
 int pr_group_set_database(pr_group* g, int type, const double* h2, int32_t n);
 int pr_group_take_warnings(pr_group* g);                /* OR of the shards' pr_take_warnings (PR_WARN_* bits), then cleared */
 int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,

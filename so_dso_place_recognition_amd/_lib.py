@@ -41,12 +41,13 @@ SYMBOLS = {
                                         _vp, _vp, _i32, _vp]),
     "pr_rerank_width": (C.c_int, [_vp, _i32]),
     "pr_f16_margin_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _i32, _vp, _vp, _vp]),
-    "pr_rerank_finish_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _vp, _vp]),
-    "pr_order_resolve_async_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _dbl, _i32, _vp, _i32, _vp, _vp]),
-    "pr_order_exact_moments_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _vp]),
-    "pr_order_rescore_dev": (C.c_int, [_vp, _vp, _i32, _i32, C.c_int, C.c_int, _dbl, _vp, _vp, _i32, _i32, _vp, _vp]),
-    "pr_order_resolve_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _i32, _vp, _vp,
-                                       _vp]),
+    "pr_rerank_finish_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _vp, _vp]),
+    "pr_order_resolve_async_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp]),
+    "pr_order_resolve_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
+    "pr_order_flagged_count": (C.c_int, [_vp, _i32, _vp]),
+    "pr_order_exact_moments_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pr_order_exact_select_dev": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, C.c_int, C.c_int, _i32, _i32, _vp]),
+    "pr_order_exact_merge_dev": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pr_widen_scores_dev": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
     "pr_merge_topk_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "pr_group_create": (C.c_int, [_vp, _i32, C.POINTER(_vp)]),
@@ -55,6 +56,7 @@ SYMBOLS = {
     "pr_group_size": (_i32, [_vp]),
     "pr_group_uses_rccl": (C.c_int, [_vp]),
     "pr_group_rccl_ranks": (_i32, [_vp]),
+    "pr_group_last_flagged": (_i32, [_vp]),
     "pr_group_set_database": (C.c_int, [_vp, C.c_int, _vp, _i32]),
     "pr_group_take_warnings": (C.c_int, [_vp]),
     "pr_group_match_topk": (C.c_int, [_vp, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),

@@ -113,6 +113,11 @@ class Group:
         """Ranks the group's RCCL communicator reports (ncclCommCount); 0 when the group exchanges by device copies."""
         return int(self.lib.pr_group_rccl_ranks(self.h))
 
+    @property
+    def last_flagged(self) -> int:
+        """Queries of the last match_topk that were answered from their exact fp64 rows (order / containment checks)."""
+        return int(self.lib.pr_group_last_flagged(self.h))
+
     def _check(self, rc):
         if rc != 0:
             raise PRError(rc, self.lib.pr_group_last_error(self.h).decode())

@@ -135,26 +135,33 @@ void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom
                          const int32_t* order_flags = nullptr);
 // flags[q] = 1 where the order of the re-evaluated candidates (the selected k and the best one left out) could change under the sigma error
 // of the all-pairs pass (per channel max(eps_floor, 4 noise / (sigma sqrt(n - 1))), statistics from mom_* [Gmom][m][2][3])
+// + bit 1 where the candidate list (cand_sc [m][kin]: its all-pairs-pass scores, ascending; score_sel [m][k]: the exact scores of the k selected;
+// both or neither) does not provably hold the exact top-k of the whole row
 void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int Gmom, const int32_t* cand_idx, const double* p5_all,
-                        int G, int m, int kin, int k, const int32_t* idx_sel, double p_weight, double eps_floor, double noise, int32_t* flags);
-// The flagged queries answered with fp64 row statistics, stream-ordered: flags -> ascending list + count; per pass of RESOLVE_SLOTS list
-// slots the shard's exact (count, mean, M2) of the four channels (exact [m][4][3]; partial: scratch [RESOLVE_SLOTS][RESOLVE_NB][4][3]);
-// then the candidates' scores again from their exact distances with the exact statistics of all shards, and the k best (rerank.hip)
+                        int G, int m, int kin, int k, const int32_t* idx_sel, double p_weight, double eps_floor, double noise, int32_t* flags,
+                        const double* cand_sc = nullptr, const double* score_sel = nullptr);
+// The flagged queries (order not certain under the pass's sigmas | candidate list not provably complete: rerank.hip) answered from their EXACT
+// rows, stream-ordered (exact_row.hip): flags -> ascending list + count; per pass of RESOLVE_SLOTS list slots from `offset`
+//   launch_xrow         this shard's fp64 distances of the slot's query to every entry (rows [RESOLVE_SLOTS][4][n_local]) and their exact
+//                       (count, mean, M2) per channel (exact [m][4][3]; partial: scratch [RESOLVE_SLOTS][RESOLVE_NB][4][3])
+//   launch_xrow_select  the k smallest (fused fp64 score, global index) of the slot's row under the statistics of all shards (exact_all
+//                       [G][m][4][3]) and the mask -> sel [RESOLVE_SLOTS][2][k] (scores | indices as doubles); with sel = null (one shard)
+//                       straight into idx / score [m][k], out_mom_* rows [m][2][3] patched with the exact moments
+//   launch_xrow_merge   sel_all [G][RESOLVE_SLOTS][2][k] of all shards -> idx / score of the slots' queries
 constexpr int RESOLVE_SLOTS = 64;
 constexpr int RESOLVE_NB = 2048;
 constexpr int RESOLVE_SMALL_M = 1024;            // calls of up to this many queries: the kernels scan the flags themselves (no compaction launch)
-// one pass of the resolution on this shard: exact moments of the flagged queries' rows (-> exact [m][4][3]); rescore: single-shard calls,
-// the candidates are re-scored and idx / score / out_mom_* patched in the same launch.  compacted: list / cnt are already there
-// (launch_flag_compact: the host-synchronising form runs several passes over one list)
+int exact_partial_blocks(int n_local);
 void launch_flag_compact(hipStream_t st, const int32_t* flags, int m, int32_t* list, int32_t* cnt);
-void launch_resolve(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
-                    const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* flags, int32_t* list, int32_t* cnt,
-                    int offset, bool compacted, double* partial, double* exact, unsigned* tick, int* dflags, bool rescore, double p_weight,
-                    const int32_t* cand_idx, const double* p5, int kin, int k, int32_t* idx, double* score, double* out_mom_sc, double* out_mom_m2);
-// sharded calls, after the all-gather of the shards' exact moments (flags / list: as left by launch_resolve on this context)
-void launch_rescore(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G, int m,
-                    int has_sc, int has_m2, double p_weight, const int32_t* cand_idx, const double* p5_all, int kin, int k, int32_t* idx,
-                    double* score);
+// compacted: list / cnt are already there (launch_flag_compact: the host-synchronising form runs several passes over one list)
+void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
+                 const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* flags, int32_t* list, int32_t* cnt,
+                 int offset, bool compacted, double* partial, double* exact, double* rows, unsigned* tick, int* dflags);
+void launch_xrow_select(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G,
+                        int m, int n_local, int q_row0, int db_row0, int mask_width, double p_weight, int has_sc, int has_m2, int k,
+                        const double* rows, double* sel, int32_t* idx, double* score, double* out_mom_sc, double* out_mom_m2);
+void launch_xrow_merge(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* sel_all, int G, int m,
+                       int k, int32_t* idx, double* score);
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* p5_all, int G, int m, int kin, int k, int32_t* idx,
                           double* score);
 void launch_widen(hipStream_t st, const float* a, long long n, double* b);

@@ -43,12 +43,13 @@ struct pr_ctx {
   int32_t* d_order = nullptr;     // [2 order_cap + 2] order flags of the last re-evaluation | ascending list of the flagged queries | its length (pr_order_resolve*_dev / pr_f16_margin_dev take them)
   size_t order_cap = 0;
   int32_t order_m = -1;           // rows of d_order that are valid, -1: none
-  int32_t order_kin = 0;          // candidate-list width of the call that left them
   unsigned* rr_tick = nullptr;    // [tick_cap] per-pair tickets of rerank_kernel (zero between launches)
   size_t tick_cap = 0;
   double* res_partial = nullptr;  // [RESOLVE_SLOTS][RESOLVE_NB][4][3] workgroup partials of the fp64-statistics resolution (rerank.hip), allocated on first use
   double* res_exact = nullptr;    // [res_exact_cap][4][3] exact row moments of the flagged queries (single-shard calls)
   size_t res_exact_cap = 0;
+  double* xrows = nullptr;        // [min(m, RESOLVE_SLOTS)][4][n_local] exact rows of the flagged queries of one pass (exact_row.hip), grow-only
+  size_t xrows_cap = 0;
   void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16] (sc_match_h.hip)
   int sc_kernel = 2;             // split-f16 SC matcher for m > 8: 2 = sc_match_e.hip (default); PR_SC_KERNEL=h selects sc_match_h.hip (0, round 1; always the kernel for m <= 8)
   int sc_mode = PR_SC_ARITH_F16X2;   // PR_SC_ARITH_*: split-f16 MFMA (sc_match_h.hip) | fp32 MFMA (sc_match.hip); PR_SC_MATCH=f32 selects the latter
@@ -314,6 +315,7 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->rr_tick) (void)hipFree(ctx->rr_tick);
   if (ctx->res_partial) (void)hipFree(ctx->res_partial);
   if (ctx->res_exact) (void)hipFree(ctx->res_exact);
+  if (ctx->xrows) (void)hipFree(ctx->xrows);
   if (ctx->sel_scratch) (void)hipFree(ctx->sel_scratch);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -828,16 +830,22 @@ static int rerank_ticks(pr_ctx* ctx, size_t pairs) {
 static int32_t* res_list(pr_ctx* ctx) { return ctx->d_order + ctx->order_cap; }
 static int32_t* res_cnt(pr_ctx* ctx) { return ctx->d_order + 2 * ctx->order_cap; }
 static unsigned* res_tick(pr_ctx* ctx) { return reinterpret_cast<unsigned*>(ctx->res_partial + (size_t)pr::RESOLVE_SLOTS * pr::RESOLVE_NB * 12); }
-// scratch of the fp64-statistics resolution: the workgroup partials of one pass + exact [m][4][3] (single-shard calls)
-static int resolve_scratch(pr_ctx* ctx, int32_t m) {
+// scratch of the exact-row resolution: the workgroup partials of one pass, exact [m][4][3] (single-shard calls) and the rows of one pass
+static int resolve_scratch(pr_ctx* ctx, int32_t m_exact, int32_t m, int32_t n_local) {
   if (!ctx->res_partial) {                                    // (+ the ticket of the last-workgroup hand-off, zero between launches)
     PR_HIP(ctx, hipMalloc((void**)&ctx->res_partial, ((size_t)pr::RESOLVE_SLOTS * pr::RESOLVE_NB * 12 + 1) * sizeof(double)));
     PR_HIP(ctx, hipMemsetAsync(ctx->res_partial + (size_t)pr::RESOLVE_SLOTS * pr::RESOLVE_NB * 12, 0, sizeof(double), ctx->stream));
   }
-  if ((size_t)m > ctx->res_exact_cap) {
+  if ((size_t)m_exact > ctx->res_exact_cap) {
     if (ctx->res_exact) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->res_exact)); ctx->res_exact = nullptr; ctx->res_exact_cap = 0; }
-    PR_HIP(ctx, hipMalloc((void**)&ctx->res_exact, (size_t)m * 12 * sizeof(double)));
-    ctx->res_exact_cap = (size_t)m;
+    PR_HIP(ctx, hipMalloc((void**)&ctx->res_exact, (size_t)m_exact * 12 * sizeof(double)));
+    ctx->res_exact_cap = (size_t)m_exact;
+  }
+  const size_t need = (size_t)(m < pr::RESOLVE_SLOTS ? m : pr::RESOLVE_SLOTS) * 4 * (size_t)n_local;
+  if (need > ctx->xrows_cap) {
+    if (ctx->xrows) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->xrows)); ctx->xrows = nullptr; ctx->xrows_cap = 0; }
+    PR_HIP(ctx, hipMalloc((void**)&ctx->xrows, need * sizeof(double)));
+    ctx->xrows_cap = need;
   }
   return PR_OK;
 }
@@ -873,65 +881,75 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
                     p_weight, k_in, idx_in, ctx->rr_scratch, ctx->rr_tick, ctx->tick_cap, k, idx, score, nullptr, score_in, pass_eps(ctx), fl, noise, ctx->d_order);
   if (ctx->force_order) pr::launch_fill_ints(ctx->stream, ctx->d_order, m, 1);
   ctx->order_m = m;
-  ctx->order_kin = k_in;
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
 
-// one pass (RESOLVE_SLOTS list slots from `offset`) of the single-shard resolution behind pr_rerank_dev: ONE launch (+ the compaction
-// of the flags for calls of more than RESOLVE_SMALL_M queries)
+// one pass (RESOLVE_SLOTS list slots from `offset`) of the single-shard resolution behind pr_rerank_dev: the rows + their moments, then the
+// selection straight into idx / score (+ the compaction of the flags for calls of more than RESOLVE_SMALL_M queries)
 static void resolve_pass(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
-                         double* mom_sc, double* mom_m2, int32_t m, int32_t n, double p_weight, int32_t k_in, const int32_t* idx_in, int32_t k,
+                         double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight, int32_t k,
                          int32_t* idx, double* score, int offset, bool compacted, int* dflags) {
-  pr::launch_resolve(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, 1, m, n, ctx->d_order, res_list(ctx), res_cnt(ctx),
-                     offset, compacted, ctx->res_partial, ctx->res_exact, res_tick(ctx), dflags, true, p_weight, idx_in, ctx->rr_scratch, k_in, k,
-                     idx, score, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr);
+  pr::launch_xrow(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, 1, m, n, ctx->d_order, res_list(ctx), res_cnt(ctx),
+                  offset, compacted, ctx->res_partial, ctx->res_exact, ctx->xrows, res_tick(ctx), dflags);
+  pr::launch_xrow_select(ctx->stream, ctx->d_order, res_list(ctx), res_cnt(ctx), offset, ctx->res_exact, 1, m, n, q_row0, 0, mask_width, p_weight,
+                         q_sc != nullptr, q_m2 != nullptr, k, ctx->xrows, nullptr, idx, score, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr);
 }
 
 static int resolve_args_ok(pr_ctx* ctx, const char* who, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2,
-                           int m2_dtype, const double* mom_sc, const double* mom_m2, int32_t m, int32_t n, int32_t k_in, const int32_t* idx_in,
-                           int32_t k, const int32_t* idx, const double* score) {
+                           int m2_dtype, const double* mom_sc, const double* mom_m2, int32_t m, int32_t n, int32_t k, const int32_t* idx,
+                           const double* score) {
   const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
-  if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !idx_in || !idx || !score || m < 0 || n < 1 ||
-      k < 1 || k_in < k || k_in > 128 || (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
-    PR_FAIL(ctx, PR_EINVAL, "%s: bad arguments (m=%d, n=%d, k=%d, k_in=%d)", who, m, n, k, k_in);
+  if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !idx || !score || m < 0 || n < 1 ||
+      k < 1 || k > 128 || (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
+    PR_FAIL(ctx, PR_EINVAL, "%s: bad arguments (m=%d, n=%d, k=%d)", who, m, n, k);
   return PR_OK;
 }
 
 int pr_order_resolve_async_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
-                               double* mom_sc, double* mom_m2, int32_t m, int32_t n, double p_weight, int32_t k_in, const int32_t* idx_in,
+                               double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight,
                                int32_t k, int32_t* idx, double* score) {
   if (!ctx) return PR_EINVAL;
-  if (int rc = resolve_args_ok(ctx, "pr_order_resolve_async_dev", q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, k_in, idx_in, k, idx, score)) return rc;
-  if (m == 0 || ctx->order_m != m || ctx->order_kin != k_in) { ctx->order_m = -1; return PR_OK; }   // no (fresh) order flags of a call of this shape
+  if (int rc = resolve_args_ok(ctx, "pr_order_resolve_async_dev", q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, k, idx, score)) return rc;
+  if (m == 0 || ctx->order_m != m) { ctx->order_m = -1; return PR_OK; }   // no (fresh) flags of a call of this shape
   if (int rc = set_device(ctx)) return rc;
-  if (int rc = resolve_scratch(ctx, m)) return rc;
+  if (int rc = resolve_scratch(ctx, m, m, n)) return rc;
   ctx->order_m = -1;
-  resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, p_weight, k_in, idx_in, k, idx, score, 0, false, ctx->d_flags);
+  resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, k, idx, score, 0, false, ctx->d_flags);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
 
 int pr_order_resolve_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
-                         double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight, int32_t k_in,
-                         const int32_t* idx_in, const double* score_in, int32_t k, int32_t* idx, double* score, int32_t* resolved) {
+                         double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight, int32_t k,
+                         int32_t* idx, double* score, int32_t* resolved) {
   if (!ctx) return PR_EINVAL;
-  (void)q_row0; (void)mask_width; (void)score_in;           // (the candidates' scores and distances of pr_rerank_dev are in the context: masked and pruned ones keep theirs)
-  if (int rc = resolve_args_ok(ctx, "pr_order_resolve_dev", q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, k_in, idx_in, k, idx, score)) return rc;
+  if (int rc = resolve_args_ok(ctx, "pr_order_resolve_dev", q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, k, idx, score)) return rc;
   if (resolved) *resolved = 0;
-  if (m == 0 || ctx->order_m != m || ctx->order_kin != k_in) { ctx->order_m = -1; return PR_OK; }
+  if (m == 0 || ctx->order_m != m) { ctx->order_m = -1; return PR_OK; }
   if (int rc = set_device(ctx)) return rc;
-  if (int rc = resolve_scratch(ctx, m)) return rc;
+  if (int rc = resolve_scratch(ctx, m, m, n)) return rc;
   ctx->order_m = -1;
   pr::launch_flag_compact(ctx->stream, ctx->d_order, m, res_list(ctx), res_cnt(ctx));
   int32_t cnt = 0;
   PR_HIP(ctx, hipMemcpyAsync(&cnt, res_cnt(ctx), 4, hipMemcpyDeviceToHost, ctx->stream));
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   for (int off = 0; off < cnt; off += pr::RESOLVE_SLOTS)
-    resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, p_weight, k_in, idx_in, k, idx, score, off, true, nullptr);
+    resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, k, idx, score, off, true, nullptr);
   PR_HIP(ctx, hipGetLastError());
   if (cnt > 0) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); ctx->warnings |= PR_WARN_ORDER_RESOLVED; }
   if (resolved) *resolved = cnt;
+  return PR_OK;
+}
+
+int pr_order_flagged_count(pr_ctx* ctx, int32_t m, int32_t* count) {
+  if (!ctx || !count) return PR_EINVAL;
+  *count = 0;
+  if (m <= 0 || ctx->order_m != m) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_flag_compact(ctx->stream, ctx->d_order, m, res_list(ctx), res_cnt(ctx));
+  PR_HIP(ctx, hipMemcpyAsync(count, res_cnt(ctx), 4, hipMemcpyDeviceToHost, ctx->stream));
+  PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return PR_OK;
 }
 
@@ -954,8 +972,8 @@ int pr_rerank_partial_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int 
   return PR_OK;
 }
 
-int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t G_mom, const int32_t* cand_idx, const double* p5_all,
-                         int32_t G, int32_t m, int32_t k_in, int32_t k, double p_weight, int32_t* idx, double* score) {
+int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t G_mom, const int32_t* cand_idx, const double* cand_score,
+                         const double* p5_all, int32_t G, int32_t m, int32_t k_in, int32_t k, double p_weight, int32_t* idx, double* score) {
   if (!ctx) return PR_EINVAL;
   if ((!mom_sc && !mom_m2) || !cand_idx || !p5_all || !idx || !score || G < 1 || G > 254 || G_mom < 1 || m < 0 || k < 1 || k_in < k || k_in > 128)
     PR_FAIL(ctx, PR_EINVAL, "pr_rerank_finish_dev: bad arguments (G=%d, m=%d, k=%d, k_in=%d)", G, m, k, k_in);
@@ -965,43 +983,56 @@ int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2
   double fl, noise;
   order_consts(ctx, fl, noise);
   pr::launch_rerank_finish(ctx->stream, cand_idx, p5_all, G, m, k_in, k, idx, score);
-  pr::launch_order_check(ctx->stream, mom_sc, mom_m2, G_mom, cand_idx, p5_all, G, m, k_in, k, idx, p_weight, fl, noise, ctx->d_order);
+  const bool contain = cand_score && ctx->sc_mode != PR_SC_ARITH_F16;      // (the single-product arithmetic: pr_f16_margin_dev)
+  pr::launch_order_check(ctx->stream, mom_sc, mom_m2, G_mom, cand_idx, p5_all, G, m, k_in, k, idx, p_weight, fl, noise, ctx->d_order,
+                         contain ? cand_score : nullptr, contain ? score : nullptr);
   if (ctx->force_order) pr::launch_fill_ints(ctx->stream, ctx->d_order, m, 1);
   ctx->order_m = m;
-  ctx->order_kin = k_in;
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
 
 int pr_order_exact_moments_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
-                               const double* mom_sc, const double* mom_m2, int32_t G_mom, int32_t m, int32_t n_local, double* exact) {
+                               const double* mom_sc, const double* mom_m2, int32_t G_mom, int32_t m, int32_t n_local, int32_t offset, double* exact) {
   if (!ctx) return PR_EINVAL;
   const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
   if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !exact || m < 0 || n_local < 1 || G_mom < 1 ||
-      (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
+      offset < 0 || (sc && sc_dtype != PR_F64 && sc_dtype != PR_F32) || (m2 && m2_dtype != PR_F64 && m2_dtype != PR_F32))
     PR_FAIL(ctx, PR_EINVAL, "pr_order_exact_moments_dev: bad arguments (m=%d, n_local=%d, G=%d)", m, n_local, G_mom);
   if (m == 0) return PR_OK;
-  if (ctx->order_m != m) PR_FAIL(ctx, PR_EINVAL, "pr_order_exact_moments_dev: no order flags of a %d-query pr_rerank_finish_dev on this context", m);
+  if (ctx->order_m != m) PR_FAIL(ctx, PR_EINVAL, "pr_order_exact_moments_dev: no flags of a %d-query pr_rerank_finish_dev on this context", m);
   if (int rc = set_device(ctx)) return rc;
-  if (int rc = resolve_scratch(ctx, 0)) return rc;
-  pr::launch_resolve(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, G_mom, m, n_local, ctx->d_order, res_list(ctx),
-                     res_cnt(ctx), 0, false, ctx->res_partial, exact, res_tick(ctx), ctx->d_flags, false, 0.0, nullptr, nullptr, 0, 0, nullptr, nullptr,
-                     nullptr, nullptr);
+  if (int rc = resolve_scratch(ctx, 0, m, n_local)) return rc;
+  pr::launch_xrow(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, G_mom, m, n_local, ctx->d_order, res_list(ctx),
+                  res_cnt(ctx), offset, false, ctx->res_partial, exact, ctx->xrows, res_tick(ctx), ctx->d_flags);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
 
-int pr_order_rescore_dev(pr_ctx* ctx, const double* exact_all, int32_t G, int32_t m, int has_sc, int has_m2, double p_weight,
-                         const int32_t* cand_idx, const double* p5_all, int32_t k_in, int32_t k, int32_t* idx, double* score) {
+int pr_order_exact_select_dev(pr_ctx* ctx, const double* exact_all, int32_t G, int32_t m, int32_t n_local, int32_t q_row0, int32_t db_row0,
+                              int32_t mask_width, double p_weight, int has_sc, int has_m2, int32_t k, int32_t offset, double* sel) {
   if (!ctx) return PR_EINVAL;
-  if (!exact_all || (!has_sc && !has_m2) || !cand_idx || !p5_all || !idx || !score || G < 1 || G > 254 || m < 0 || k < 1 || k_in < k || k_in > 128)
-    PR_FAIL(ctx, PR_EINVAL, "pr_order_rescore_dev: bad arguments (G=%d, m=%d, k=%d, k_in=%d)", G, m, k, k_in);
+  if (!exact_all || !sel || (!has_sc && !has_m2) || G < 1 || G > 64 || m < 0 || n_local < 1 || k < 1 || k > 128 || offset < 0)
+    PR_FAIL(ctx, PR_EINVAL, "pr_order_exact_select_dev: bad arguments (G=%d, m=%d, n_local=%d, k=%d; G <= 64, k <= 128)", G, m, n_local, k);
   if (m == 0) return PR_OK;
-  if (ctx->order_m != m) PR_FAIL(ctx, PR_EINVAL, "pr_order_rescore_dev: no flagged-query list of a %d-query pr_order_exact_moments_dev on this context", m);
+  if (ctx->order_m != m || !ctx->xrows ||
+      ctx->xrows_cap < (size_t)(m < pr::RESOLVE_SLOTS ? m : pr::RESOLVE_SLOTS) * 4 * (size_t)n_local)
+    PR_FAIL(ctx, PR_EINVAL, "pr_order_exact_select_dev: no rows of a %d-query pr_order_exact_moments_dev over %d entries on this context", m, n_local);
   if (int rc = set_device(ctx)) return rc;
-  ctx->order_m = -1;
-  pr::launch_rescore(ctx->stream, ctx->d_order, res_list(ctx), res_cnt(ctx), 0, exact_all, G, m, has_sc, has_m2, p_weight, cand_idx, p5_all, k_in, k,
-                     idx, score);
+  pr::launch_xrow_select(ctx->stream, ctx->d_order, res_list(ctx), res_cnt(ctx), offset, exact_all, G, m, n_local, q_row0, db_row0, mask_width,
+                         p_weight, has_sc, has_m2, k, ctx->xrows, sel, nullptr, nullptr, nullptr, nullptr);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+int pr_order_exact_merge_dev(pr_ctx* ctx, const double* sel_all, int32_t G, int32_t m, int32_t k, int32_t offset, int32_t* idx, double* score) {
+  if (!ctx) return PR_EINVAL;
+  if (!sel_all || !idx || !score || G < 1 || G > 64 || m < 0 || k < 1 || k > 128 || offset < 0)
+    PR_FAIL(ctx, PR_EINVAL, "pr_order_exact_merge_dev: bad arguments (G=%d, m=%d, k=%d; G <= 64, k <= 128)", G, m, k);
+  if (m == 0) return PR_OK;
+  if (ctx->order_m != m) PR_FAIL(ctx, PR_EINVAL, "pr_order_exact_merge_dev: no flagged-query list of a %d-query call on this context", m);
+  if (int rc = set_device(ctx)) return rc;
+  pr::launch_xrow_merge(ctx->stream, ctx->d_order, res_list(ctx), res_cnt(ctx), offset, sel_all, G, m, k, idx, score);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -1094,8 +1125,7 @@ static int f16_fallback(pr_ctx* ctx, const double* hq_sc, const double* hq_m2, c
         rc = pr_order_resolve_dev(ctx, hq_sc ? rq[0].as<double>() + (size_t)i * 2400 : nullptr, hq_sc ? ddb_sc : nullptr, PR_F64,
                                   hq_m2 ? rq[1].as<double>() + (size_t)i * 4 * 384 : nullptr, hq_m2 ? ddb_m2 : nullptr, PR_F64,
                                   hq_sc ? mo[0].as<double>() + (size_t)i * 6 : nullptr, hq_m2 ? mo[1].as<double>() + (size_t)i * 6 : nullptr, 1, n, q0,
-                                  mask_width, p_weight, kin2, didx.as<int32_t>(), dsw.as<double>(), k, dcand + (size_t)q0 * k, dsc64 + (size_t)q0 * k,
-                                  nullptr);
+                                  mask_width, p_weight, k, dcand + (size_t)q0 * k, dsc64 + (size_t)q0 * k, nullptr);
     }
     if (rc == PR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "f16 fallback failed"; rc = PR_EHIP; }
   } while (0);
@@ -1170,8 +1200,8 @@ static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, con
       // check below takes the flags instead and sends them to the split pass, which resolves its own)
       if (ctx->sc_mode != PR_SC_ARITH_F16 &&
           (rc = pr_order_resolve_dev(ctx, sc ? raw1.p : nullptr, sc ? raw2.p : nullptr, PR_F64, sc ? nullptr : raw1.p, sc ? nullptr : raw2.p, PR_F64,
-                                     sc ? mom.as<double>() : nullptr, sc ? nullptr : mom.as<double>(), m, n, 0, mask_width, p_weight, kin,
-                                     didx.as<int32_t>(), dsw.as<double>(), k, dcand.as<int32_t>(), dsc64.as<double>(), nullptr))) break;
+                                     sc ? mom.as<double>() : nullptr, sc ? nullptr : mom.as<double>(), m, n, 0, mask_width, p_weight, k,
+                                     dcand.as<int32_t>(), dsc64.as<double>(), nullptr))) break;
       if (ctx->sc_mode == PR_SC_ARITH_F16 &&
           (rc = f16_fallback(ctx, sc ? h1 : nullptr, sc ? nullptr : h1, sc ? raw2.p : nullptr, sc ? nullptr : raw2.p, m, n, mask_width, p_weight, k,
                              sc ? mom.as<double>() : nullptr, sc ? nullptr : mom.as<double>(), kin, dsw.as<double>(), dcand.as<int32_t>(),
@@ -1284,7 +1314,7 @@ static int fused_host(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32
     if (score32) t64.resize((size_t)m * k);
     if (ctx->sc_mode != PR_SC_ARITH_F16 &&
         (rc = pr_order_resolve_dev(ctx, raw[0].p, raw[1].p, PR_F64, raw[2].p, raw[3].p, PR_F64, mom[0].as<double>(), mom[1].as<double>(), m, n, 0,
-                                   mask_width, p_weight, kin, didx.as<int32_t>(), dsw.as<double>(), k, dcand.as<int32_t>(), dsc64.as<double>(), nullptr))) break;
+                                   mask_width, p_weight, k, dcand.as<int32_t>(), dsc64.as<double>(), nullptr))) break;
     if (ctx->sc_mode == PR_SC_ARITH_F16 &&
         (rc = f16_fallback(ctx, sc1, m2dp1, raw[1].p, raw[3].p, m, n, mask_width, p_weight, k, mom[0].as<double>(), mom[1].as<double>(), kin,
                            dsw.as<double>(), dcand.as<int32_t>(), dsc64.as<double>()))) break;

@@ -13,10 +13,12 @@
 //      grow with G)                                                                                   pr_rerank_partial_dev
 //   C. all-gather of the shards' evaluations (p5 blocks: scores + exact channel distances); every device takes each candidate's score
 //      from its owner, keeps the k best and checks their order                                        ncclAllGather, pr_rerank_finish_dev
-//   4. per device: exact (fp64) row moments of the queries whose order hangs on the fp32 pass's sigmas - none, as a rule: the kernels
-//      leave at once                                                                                  pr_order_exact_moments_dev
-//   D. all-gather of those moments (96 B per query per rank); every device re-scores the flagged queries' candidates with the exact
-//      statistics of the whole row (Chan combination in rank order)                                   ncclAllGather, pr_order_rescore_dev
+//   4. the queries the re-evaluated candidates cannot answer for certain (order hangs on the fp32 pass's sigmas | the candidate list does
+//      not provably hold the top-k: none, as a rule - the count is read back and nothing below runs) in passes of 64:
+//      per device the query's exact fp64 distances to every row of the shard and their moments        pr_order_exact_moments_dev
+//   D. all-gather of those moments (96 B per query per rank)                                          ncclAllGather
+//   5. per device: the shard's k best of the exact row under the statistics of the WHOLE row          pr_order_exact_select_dev
+//   E. all-gather of those lists (16 k B per flagged query per rank), merged on every device          ncclAllGather, pr_order_exact_merge_dev
 //
 // One host thread drives all devices; everything is asynchronous on each context's stream, the two collectives are
 // enqueued on those same streams between the kernels (one ncclGroupStart/End per collective, communicators from
@@ -73,7 +75,7 @@ struct Shard {
   void *raw_db = nullptr, *raw_q = nullptr;   // f64 signatures (the re-evaluation reads them)
   float *d_p = nullptr, *d_i = nullptr;
   double *mom = nullptr, *mom_all = nullptr, *score = nullptr, *score_all = nullptr, *sc64 = nullptr, *part = nullptr, *dump = nullptr;
-  double *p5_all = nullptr, *exact = nullptr, *exact_all = nullptr;
+  double *p5_all = nullptr, *exact = nullptr, *exact_all = nullptr, *sel = nullptr, *sel_all = nullptr;
   int32_t *idx_in = nullptr, *idx = nullptr, *idx_all = nullptr, *cand = nullptr;
   float* sc32 = nullptr;
 };
@@ -89,6 +91,7 @@ struct pr_group {
   std::string err;
   int type = -1;
   int32_t n = 0, q_cap = 0, k_cap = 0;
+  int32_t last_flagged = 0;        // queries of the last pr_group_match_topk that were answered from their exact rows
 };
 
 static thread_local std::string g_gerr;
@@ -120,11 +123,11 @@ static void free_match_buffers(Shard& sh) {
   (void)hipSetDevice(sh.device);
   for (void* p : {(void*)sh.raw_q, (void*)sh.d_p, (void*)sh.d_i, (void*)sh.mom, (void*)sh.mom_all, (void*)sh.score, (void*)sh.score_all,
                   (void*)sh.idx_in, (void*)sh.idx, (void*)sh.idx_all, (void*)sh.sc32, (void*)sh.sc64, (void*)sh.part, (void*)sh.cand, (void*)sh.dump,
-                  (void*)sh.p5_all, (void*)sh.exact, (void*)sh.exact_all})
+                  (void*)sh.p5_all, (void*)sh.exact, (void*)sh.exact_all, (void*)sh.sel, (void*)sh.sel_all})
     if (p) (void)hipFree(p);
   sh.raw_q = nullptr; sh.d_p = sh.d_i = sh.sc32 = nullptr; sh.mom = sh.mom_all = sh.score = sh.score_all = sh.sc64 = sh.part = sh.dump = nullptr;
   sh.idx_in = sh.idx = sh.idx_all = sh.cand = nullptr;
-  sh.p5_all = sh.exact = sh.exact_all = nullptr;
+  sh.p5_all = sh.exact = sh.exact_all = sh.sel = sh.sel_all = nullptr;
   if (sh.q) { pr_sigset_destroy(sh.ctx, sh.q); sh.q = nullptr; }
 }
 
@@ -170,6 +173,7 @@ extern "C" {
 const char* pr_group_last_error(const pr_group* g) { return g ? g->err.c_str() : g_gerr.c_str(); }
 int32_t pr_group_size(const pr_group* g) { return g ? g->G : 0; }
 int pr_group_uses_rccl(const pr_group* g) { return g && g->rccl; }
+int32_t pr_group_last_flagged(const pr_group* g) { return g ? g->last_flagged : 0; }
 int32_t pr_group_rccl_ranks(const pr_group* g) {   // asked of the communicator itself, not of the argument list
   if (!g || !g->rccl || g->comms.empty() || !g->comms[0]) return 0;
   int n = 0;
@@ -307,6 +311,8 @@ static int match_topk_impl(pr_group* g, const double* h1, int32_t m, int32_t mas
       G_HIP(g, hipMalloc((void**)&sh.p5_all, (size_t)G * qc * 5 * kinc * 8));
       G_HIP(g, hipMalloc((void**)&sh.exact, (size_t)qc * 12 * 8));
       G_HIP(g, hipMalloc((void**)&sh.exact_all, (size_t)G * qc * 12 * 8));
+      G_HIP(g, hipMalloc((void**)&sh.sel, (size_t)64 * 2 * kc * 8));
+      G_HIP(g, hipMalloc((void**)&sh.sel_all, (size_t)G * 64 * 2 * kc * 8));
       G_HIP(g, hipMalloc((void**)&sh.dump, (size_t)qc * kinc * 8));
       G_HIP(g, hipMalloc((void**)&sh.cand, (size_t)qc * kinc * 4));
     }
@@ -347,20 +353,40 @@ static int match_topk_impl(pr_group* g, const double* h1, int32_t m, int32_t mas
   // C. every shard's evaluations (p5 blocks) on every device; every device finishes and checks the order of its result
   for (int r = 0; r < G; r++) { src[r] = g->s[r].part; dst[r] = g->s[r].p5_all; }
   if (int rc = exchange(g, src, dst, (size_t)m * 5 * kin * 8)) return rc;
-  // 4. + D. queries whose order hangs on the fp32 pass's sigmas: exact row moments per shard, gathered, candidates re-scored everywhere
+  // 4. every device finishes (identical inputs: identical results and flags everywhere) ...
   for (auto& sh : g->s) {
     G_HIP(g, hipSetDevice(sh.device));
-    G_PR(g, sh, pr_rerank_finish_dev(sh.ctx, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, G, sh.cand, sh.p5_all, G, m, kin, k, p_weight,
-                                     sh.idx, sh.score));
-    G_PR(g, sh, pr_order_exact_moments_dev(sh.ctx, sc ? sh.raw_q : nullptr, sc ? sh.raw_db : nullptr, PR_F64, sc ? nullptr : sh.raw_q,
-                                           sc ? nullptr : sh.raw_db, PR_F64, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, G, m, sh.rows,
-                                           sh.exact));
+    G_PR(g, sh, pr_rerank_finish_dev(sh.ctx, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, G, sh.cand, sh.dump, sh.p5_all, G, m, kin, k,
+                                     p_weight, sh.idx, sh.score));
   }
-  for (int r = 0; r < G; r++) { src[r] = g->s[r].exact; dst[r] = g->s[r].exact_all; }
-  if (int rc = exchange(g, src, dst, (size_t)m * 12 * 8)) return rc;
-  for (auto& sh : g->s) {
-    G_HIP(g, hipSetDevice(sh.device));
-    G_PR(g, sh, pr_order_rescore_dev(sh.ctx, sh.exact_all, G, m, sc ? 1 : 0, sc ? 0 : 1, p_weight, sh.cand, sh.p5_all, kin, k, sh.idx, sh.score));
+  // ... D + E. and the flagged queries (order not certain under the fp32 pass's sigmas | candidate list not provably complete: none, as a rule)
+  // are answered from their exact rows, 64 per pass: this is a synchronous host call, so the count is read back and every pass runs
+  int32_t flagged = 0;
+  {
+    Shard& s0 = g->s[0];
+    G_HIP(g, hipSetDevice(s0.device));
+    G_PR(g, s0, pr_order_flagged_count(s0.ctx, m, &flagged));
+  }
+  g->last_flagged = flagged;
+  for (int32_t off = 0; off < flagged; off += 64) {
+    for (auto& sh : g->s) {
+      G_HIP(g, hipSetDevice(sh.device));
+      G_PR(g, sh, pr_order_exact_moments_dev(sh.ctx, sc ? sh.raw_q : nullptr, sc ? sh.raw_db : nullptr, PR_F64, sc ? nullptr : sh.raw_q,
+                                             sc ? nullptr : sh.raw_db, PR_F64, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, G, m, sh.rows,
+                                             off, sh.exact));
+    }
+    for (int r = 0; r < G; r++) { src[r] = g->s[r].exact; dst[r] = g->s[r].exact_all; }
+    if (int rc = exchange(g, src, dst, (size_t)m * 12 * 8)) return rc;
+    for (auto& sh : g->s) {
+      G_HIP(g, hipSetDevice(sh.device));
+      G_PR(g, sh, pr_order_exact_select_dev(sh.ctx, sh.exact_all, G, m, sh.rows, 0, sh.row0, mask_width, p_weight, sc ? 1 : 0, sc ? 0 : 1, k, off, sh.sel));
+    }
+    for (int r = 0; r < G; r++) { src[r] = g->s[r].sel; dst[r] = g->s[r].sel_all; }
+    if (int rc = exchange(g, src, dst, (size_t)64 * 2 * k * 8)) return rc;
+    for (auto& sh : g->s) {
+      G_HIP(g, hipSetDevice(sh.device));
+      G_PR(g, sh, pr_order_exact_merge_dev(sh.ctx, sh.sel_all, G, m, k, off, sh.idx, sh.score));
+    }
   }
   Shard& s0 = g->s[0];
   G_HIP(g, hipSetDevice(s0.device));

@@ -12,6 +12,7 @@
 //                 per query, or one wave per query when there are at most 64 of them (an online call).
 //   merge_topk    k-way merge of the per-shard top-k lists of G database shards by (score, global index).
 #include "kernels.hpp"
+#include "rerank_common.hpp"
 
 namespace pr {
 namespace {
@@ -43,124 +44,6 @@ __global__ __launch_bounds__(256) void nan_fixup_kernel(float* __restrict__ d_p,
   }
 }
 
-__device__ __forceinline__ double ld(const void* p, int dtype, size_t i) {
-  return dtype == 0 ? static_cast<const double*>(p)[i] : (double)static_cast<const float*>(p)[i];
-}
-
-// Sum over the 256 threads: inside a wave by lane exchanges (an xor butterfly: both partners add the same two numbers, so all 64 lanes hold
-// the same bits - no barrier), the four wave sums through LDS, added in wave order by every thread.  Two barriers instead of ten: the pair
-// functions below are chains of such reductions, and an online call waits for one pair per workgroup.
-__device__ __forceinline__ double block_sum256(double v, double* red, int tid) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v += __shfl_xor(v, s, 64);
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  const double r = (red[0] + red[1]) + (red[2] + red[3]);
-  __syncthreads();
-  return r;
-}
-
-// MATLAB min: NaN only if every element is NaN
-__device__ __forceinline__ double nanmin(double a, double b) { return (a != a) ? b : ((b != b) ? a : (b < a ? b : a)); }
-__device__ __forceinline__ double block_min256(double v, double* red, int tid) {
-#pragma unroll
-  for (int s = 32; s > 0; s >>= 1) v = nanmin(v, __shfl_xor(v, s, 64));
-  if ((tid & 63) == 0) red[tid >> 6] = v;
-  __syncthreads();
-  const double r = nanmin(nanmin(red[0], red[1]), nanmin(red[2], red[3]));
-  __syncthreads();
-  return r;
-}
-
-// processSC.m:15-33 for one channel of one pair, fp64.  buf: 60 x 21 (query, padded sector stride) + 1200 (entry) doubles.
-// Thread = (ring r, block of 5 consecutive shifts): it walks the 60 sectors of the entry once and keeps the 5 forward and
-// 5 mirrored variants of its shifts in registers - a sliding window over the query's ring column, so every step costs three
-// LDS reads (entry value, one new query value per direction) for ten multiply-adds; the first version read two operands
-// per multiply-add and was LDS-bound at 3.2 ms per 4096 x 9 pairs.
-__device__ double sc_pair_exact(const void* qsig, int qdt, size_t qoff, const void* dsig, int ddt, size_t doff,
-                                double* buf /*60*21 + 1200*/, double* red, int tid) {
-  double* qs = buf;
-  double* ds = buf + 60 * 21;
-  double pq = 0.0, pd = 0.0;
-  for (int i = tid; i < 1200; i += 256) {
-    const double x = ld(qsig, qdt, qoff + i), y = ld(dsig, ddt, doff + i);
-    qs[(i / 20) * 21 + (i % 20)] = x;
-    ds[i] = y;
-    pq += x * x;
-    pd += y * y;
-  }
-  const double nq = sqrt(block_sum256(pq, red, tid));
-  const double nd = sqrt(block_sum256(pd, red, tid));
-  for (int i = tid; i < 1200; i += 256) {                       // processSC.m:16,19 (0/0 = NaN stays NaN)
-    const int a = (i / 20) * 21 + (i % 20);
-    qs[a] = qs[a] / nq;
-    ds[i] = ds[i] / nd;
-  }
-  __syncthreads();
-  const int r = tid % 20, blk = tid / 20;                        // blk 0..11 (tid < 240): shifts 5 blk .. 5 blk + 4
-  double af[5] = {0, 0, 0, 0, 0}, am[5] = {0, 0, 0, 0, 0};
-  if (tid < 240) {
-    double wf[5], wm[5];
-    const double* qc = qs + r;
-#pragma unroll
-    for (int j = 0; j < 5; j++) { wf[j] = qc[(5 * blk + j) * 21]; wm[j] = wf[j]; }
-    int nf = (5 * blk + 5) % 60;                                 // sector entering the forward window next
-    int nm = (5 * blk + 59) % 60;                                // ... and the mirrored one
-    for (int c0 = 0; c0 < 60; c0 += 5) {
-#pragma unroll
-      for (int u = 0; u < 5; u++) {                              // sector c = c0 + u of the entry (permute_sc, processSC.m:37-45)
-        const double dv = ds[(c0 + u) * 20 + r];
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-          af[j] += wf[(j + u) % 5] * dv;                         // q[(k0 + c) % 60], k0 = 5 blk + j
-          am[j] += wm[(j + 5 - u) % 5] * dv;                     // q[(k0 - c) % 60]
-        }
-        wf[u] = qc[nf * 21];
-        wm[(4 - u + 5) % 5] = qc[nm * 21];
-        nf = nf == 59 ? 0 : nf + 1;
-        nm = nm == 0 ? 59 : nm - 1;
-      }
-    }
-  }
-  __syncthreads();                                               // all reads of qs / ds done: the buffer becomes [variant][ring]
-  if (tid < 240) {
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      buf[(2 * (5 * blk + j)) * 20 + r] = af[j];
-      buf[(2 * (5 * blk + j) + 1) * 20 + r] = am[j];
-    }
-  }
-  __syncthreads();
-  double diff = __builtin_nan("");
-  if (tid < 120) {
-    double dot = 0.0;
-#pragma unroll
-    for (int q = 0; q < 20; q++) dot += buf[tid * 20 + q];
-    diff = (1.0 - dot) / 2.0;                                    // processSC.m:30
-  }
-  const double best = block_min256(diff, red, tid);              // processSC.m:31 (its barriers also free buf for the next channel)
-  return best;
-}
-
-// processM2DP.m:12-22 for one channel of one pair: rows [4][384], channel columns [192 ch, 192 ch + 192)
-__device__ double m2dp_pair_exact(const void* qsig, int qdt, size_t qoff, const void* dsig, int ddt, size_t doff, int ch,
-                                  double* red, int tid) {
-  // thread = (a, b, part of 16 x 12 columns)
-  const int ab = tid >> 4, part = tid & 15, a = ab >> 2, b = ab & 3;
-  double s = 0.0;
-  for (int c = part * 12; c < part * 12 + 12; c++)
-    s += ld(qsig, qdt, qoff + (size_t)a * 384 + ch * 192 + c) * ld(dsig, ddt, doff + (size_t)b * 384 + ch * 192 + c);
-  red[tid] = s;
-  __syncthreads();
-  double diff = __builtin_nan("");
-  if (part == 0) {
-    double dot = 0.0;
-    for (int p = 0; p < 16; p++) dot += red[tid + p];
-    diff = (1.0 - dot) / 2.0;                                   // processM2DP.m:15
-  }
-  __syncthreads();
-  return block_min256(diff, red, tid);                          // processM2DP.m:19
-}
 
 // the wave-per-query selection + order check behind the re-evaluation (sort_wave_body below)
 struct SortArgs {
@@ -170,6 +53,7 @@ struct SortArgs {
   const double* mom_sc; const double* mom_m2; int Gmom;
   double p_weight, eps_floor, noise;
   int32_t* order_flags;
+  const double* cand_sc; double eps_d;                          // containment check: the candidates' all-pairs-pass scores [m][kin] (ascending) or null, the pass's distance error bound
 };
 struct RerankArgs {
   const void* q_sc; const void* db_sc; int sc_dt;               // raw SC signatures [m][2400] / [n_local][2400] or null
@@ -194,21 +78,6 @@ __device__ __forceinline__ double score_err_bound(double eps_d, double w, double
 }
 __device__ double row_weight(const double* mom_sc, const double* mom_m2, int G, int m, int q, double p_weight, double* cn_out);
 
-__device__ void chan_combine(const double* mom_all, int G, int m, int q, int ch, double& mean, double& sd, double* count = nullptr) {
-  double cn = 0.0, mu = 0.0, m2 = 0.0;
-  for (int g = 0; g < G; g++) {                                 // rank order, as fuse_select_kernel
-    const double* o = mom_all + (((size_t)g * m + q) * 2 + ch) * 3;
-    const double nb = o[0], mb = o[1], m2b = o[2];
-    if (nb <= 0.0) continue;
-    const double tot = cn + nb, delta = mb - mu;
-    mu += delta * (nb / tot);
-    m2 += m2b + delta * delta * (cn * nb / tot);
-    cn = tot;
-  }
-  mean = mu;
-  sd = sqrt(m2 / (cn - 1.0));
-  if (count) *count = cn;
-}
 
 // Is candidate t of query q evaluated by this shard?  false: *skipv is the score it keeps (NaN: no such candidate / another shard's row,
 // +Inf: masked, its pass score: pruned).
@@ -381,12 +250,6 @@ __global__ __launch_bounds__(64) void margin_check_kernel(const double* __restri
   if (flag) atomicAdd(count, 1);
 }
 
-__device__ __forceinline__ bool cand_before(double av, int aj, double bv, int bj) {   // NaN / -1 entries sort last
-  const bool abad = (aj < 0) || (av != av), bbad = (bj < 0) || (bv != bv);
-  if (abad != bbad) return bbad;
-  if (abad) return false;
-  return av < bv || (av == bv && aj < bj);
-}
 
 // one thread per query: selection of the k best of `cnt` candidates laid out with the given strides
 __device__ void select_k(const int32_t* idx, const double* sc, int cnt, int k, int32_t* oidx, double* osc, float* osc32) {
@@ -419,19 +282,37 @@ __global__ __launch_bounds__(64) void rerank_sort_kernel(const int32_t* __restri
 // Row statistics of the (up to) four channels of a query - SC structure, SC intensity, M2DP count, M2DP intensity - from the shards' moments,
 // combined in rank order: weight (p or 1; 0 = channel absent), mean, sigma, and the relative sigma error the order check allows
 // (order_check_kernel below has the derivation)
-struct RowStats { double w[4], mean[4], sd[4], eps[4]; };
+struct RowStats { double w[4], mean[4], sd[4], eps[4], cn; };
 __device__ __forceinline__ void row_stats(const double* mom_sc, const double* mom_m2, int Gmom, int m, int q, double p_weight, double eps_floor,
                                           double noise, RowStats& S) {
+  S.cn = 2.0;
   for (int c = 0; c < 4; c++) {
     S.w[c] = 0.0; S.mean[c] = 0.0; S.sd[c] = 1.0; S.eps[c] = 0.0;
     const double* mom = c < 2 ? mom_sc : mom_m2;
     if (!mom) continue;
     double cn = 2.0;
     chan_combine(mom, Gmom, m, q, c & 1, S.mean[c], S.sd[c], &cn);
+    S.cn = cn;
     S.w[c] = (c & 1) ? 1.0 : p_weight;
     const double e = 4.0 * noise / (S.sd[c] * sqrt(fmax(cn - 1.0, 1.0)));
     S.eps[c] = (e == e) ? fmax(eps_floor, e) : 1.0;             // (sigma = 0 or NaN: nothing about the order is certain)
   }
+}
+// Containment (run_test.m:57 takes the minimum over the WHOLE row; the re-evaluation sees the k_in best of the all-pairs pass): every entry
+// outside the candidate list has a pass score >= T = the last candidate's, hence an exact-distance score >= T - err(T) under the pass's row
+// statistics (score_err_bound), and under the TRUE sigmas it moves against a listed entry by at most sum_c eps_c w_c R_c / sigma_c (eps_c: the
+// relative sigma error the order check allows; R_c: the range of a channel's distances - 1 for SC's (1 - cos)/2, 2 for M2DP's [-0.5, 1.5]).
+// If the exact k-th best score sk is not below T by more than both, an entry the list does not hold could belong to the top-k: 1 = not
+// certain -> the query is answered from its exact row (exact_row.hip).  T NaN: fewer than k_in entries exist; T = +Inf: the rest is masked.
+__device__ __forceinline__ int not_contained(const RowStats& S, double eps_d, double T, double sk) {
+  if (!(T == T) || !(T < __builtin_inf())) return 0;
+  double w = 0.0, slack = 0.0;
+  for (int c = 0; c < 4; c++) {
+    if (S.w[c] == 0.0) continue;
+    w += S.w[c] / S.sd[c];
+    slack += S.eps[c] * S.w[c] * (c < 2 ? 1.0 : 2.0) / S.sd[c];
+  }
+  return !(sk < T - score_err_bound(eps_d, w, T, S.cn) - slack) ? 1 : 0;
 }
 // the weighted channel z-score exactly as rerank_kernel forms it (run_test.m:40)
 __device__ __forceinline__ double chan_z(const RowStats& S, int c, double d) { return S.w[c] == 0.0 ? 0.0 : S.w[c] * ((d - S.mean[c]) / S.sd[c]); }
@@ -458,7 +339,7 @@ __device__ void sort_wave_body(const SortArgs& a, int q, int lane) {
       z[h][cc] = (d0 == d0) ? chan_z(S, cc, d) : __builtin_nan("");
     }
   }
-  double pv = 0.0, pz[4] = {0.0, 0.0, 0.0, 0.0};
+  double pv = 0.0, pz[4] = {0.0, 0.0, 0.0, 0.0}, sk = __builtin_nan("");
   bool have_prev = false;
   int flag = 0;
   const int rounds = check ? k + 1 : k;
@@ -474,6 +355,7 @@ __device__ void sort_wave_body(const SortArgs& a, int q, int lane) {
       if (cand_before(ov, oj, bv, bj) || (!cand_before(bv, bj, ov, oj) && oc < bc)) { bv = ov; bj = oj; bc = oc; }
     }
     const bool ok = bj >= 0 && bv == bv;
+    if (t == k - 1 && ok) sk = bv;
     if (lane == 0 && t < k) {
       a.idx[(size_t)q * k + t] = ok ? bj : -1;
       const double o = ok ? bv : __builtin_nan("");
@@ -496,6 +378,7 @@ __device__ void sort_wave_body(const SortArgs& a, int q, int lane) {
     if (bc == lane) { j[0] = -1; v[0] = __builtin_nan(""); }
     if (bc == lane + 64) { j[1] = -1; v[1] = __builtin_nan(""); }
   }
+  if (check && a.cand_sc && not_contained(S, a.eps_d, a.cand_sc[(size_t)q * kin + kin - 1], sk)) flag |= 2;
   if (a.order_flags && lane == 0) a.order_flags[q] = flag;
 }
 __global__ __launch_bounds__(64) void rerank_sort_wave_kernel(SortArgs a) { sort_wave_body(a, blockIdx.x, threadIdx.x); }
@@ -535,7 +418,8 @@ __global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __rest
 __global__ __launch_bounds__(64) void order_check_kernel(const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int Gmom,
                                                           const int32_t* __restrict__ cand_idx, const double* __restrict__ p5_all, int G, int m,
                                                           int kin, int k, const int32_t* __restrict__ idx_sel, double p_weight, double eps_floor,
-                                                          double noise, int32_t* __restrict__ flags) {
+                                                          double noise, int32_t* __restrict__ flags, const double* __restrict__ cand_sc,
+                                                          const double* __restrict__ score_sel, double eps_d) {
   // one WAVE per query (a thread walking its 57 - 128 candidates alone is ~0.1 ms of dependent loads - an online call has one query):
   // lane l holds candidates l and l + 64; the members of S = selected k + best one left out are ranked by (score, index) through an LDS
   // copy, scattered to their rank, and lane p checks the adjacent pair (p, p + 1)
@@ -607,256 +491,12 @@ __global__ __launch_bounds__(64) void order_check_kernel(const double* __restric
     }
     if (span > 0.0 && !(t_v[p + 1] - t_v[p] > lim)) flag = 1;
   }
-  flag = __any(flag);
-  if (lane == 0) flags[q] = flag ? 1 : 0;
+  flag = __any(flag) ? 1 : 0;
+  // (bit 1) the containment check of not_contained(): cand_sc = the candidates' pass scores [m][kin], score_sel = the exact scores of the k selected
+  if (cand_sc && score_sel && not_contained(S, eps_d, cand_sc[(size_t)q * kin + kin - 1], score_sel[(size_t)q * k + k - 1])) flag |= 2;
+  if (lane == 0) flags[q] = flag;
 }
 
-// ---- resolution of the queries whose order check failed: the row statistics of run_test.m:40 EXACTLY, stream-ordered (no host round trip).
-// The flagged queries form an ascending list (deterministic): calls of up to RESOLVE_SMALL_M queries build it inside the kernels that need
-// it (every workgroup scans the flags - no extra launch, what an online call wants), larger calls run flag_compact_kernel first.
-//   resolve_kernel   for list slots [offset, offset + R): the distances of the query to every entry of THIS shard in fp64, in the
-//                    reference's own formulation (the device functions of rerank_kernel), summed per workgroup as shifted sums
-//                    (count, sum (d - K), sum (d - K)^2) about K = the all-pairs pass's mean of the whole row (the same number on every
-//                    shard): workgroup b takes entries b, b + NB, ... in that order - partial [R][NB][4][3].  A fixed grid; with nothing
-//                    flagged every workgroup leaves at once.  ~23 ns per pair.  The LAST workgroup to finish (a ticket) adds the NB partials
-//                    of every slot in workgroup order -> this shard's exact (count, mean, M2) per channel, exact [m][4][3] (rows of
-//                    unflagged queries are never read) and - single-shard calls (RESCORE) - re-scores the slot's candidates right away.
-//   rescore_kernel   (sharded calls, after the all-gather of `exact`) one wave per slot: the fused score of every evaluated candidate again
-//                    from its exact distances (p5) with the exact statistics of all shards (exact_all [G][m][4][3], Chan combination in rank
-//                    order, the operation order of rerank_kernel), the k best by (score, index) over idx / score.
-// NaN distances (zero-norm signatures) stay out of the statistics, as in row_moments_kernel.
-__global__ __launch_bounds__(256) void flag_compact_kernel(const int32_t* __restrict__ flags, int m, int32_t* __restrict__ list /* [m] */,
-                                                            int32_t* __restrict__ cnt /* [1] */) {
-  __shared__ int wsum[4], base;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) base = 0;
-  __syncthreads();
-  for (int q0 = 0; q0 < m; q0 += 256) {
-    const int q = q0 + tid;
-    const int f = (q < m && flags[q] != 0) ? 1 : 0;
-    const unsigned long long b = __ballot(f);
-    const int before = __popcll(b & ((1ull << lane) - 1ull));
-    if (lane == 0) wsum[w] = __popcll(b);
-    __syncthreads();
-    int off = base;
-    for (int u = 0; u < w; u++) off += wsum[u];
-    if (f) list[off + before] = q;
-    __syncthreads();
-    if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-  }
-  if (tid == 0) *cnt = base;
-}
-
-// the flagged queries of slots [offset, offset + RESOLVE_SLOTS) into s_list (LDS), their total number as return value: from the flags
-// themselves (flags != null: every thread of the workgroup calls this; nt = its size, a multiple of 64) or from the compacted list
-__device__ int flagged_slots(const int32_t* flags, int m, const int32_t* list, const int32_t* cnt, int offset, int* s_list, int* s_tmp /* [6] */,
-                             int tid, int nt) {
-  if (!flags) {
-    const int total = *cnt;
-    for (int s = tid; s < RESOLVE_SLOTS && offset + s < total; s += nt) s_list[s] = list[offset + s];
-    __syncthreads();
-    return total;
-  }
-  const int lane = tid & 63, w = tid >> 6, nw = nt >> 6;
-  if (tid == 0) s_tmp[4] = 0;
-  __syncthreads();
-  for (int q0 = 0; q0 < m; q0 += nt) {
-    const int q = q0 + tid;
-    const int f = (q < m && flags[q] != 0) ? 1 : 0;
-    const unsigned long long b = __ballot(f);
-    const int before = __popcll(b & ((1ull << lane) - 1ull));
-    if (lane == 0) s_tmp[w] = __popcll(b);
-    __syncthreads();
-    int off = s_tmp[4];
-    for (int u = 0; u < w; u++) off += s_tmp[u];
-    const int slot = off + before - offset;
-    if (f && slot >= 0 && slot < RESOLVE_SLOTS) s_list[slot] = q;
-    __syncthreads();
-    if (tid == 0) { int t = s_tmp[4]; for (int u = 0; u < nw; u++) t += s_tmp[u]; s_tmp[4] = t; }
-    __syncthreads();
-  }
-  return s_tmp[4];
-}
-
-struct ExactArgs {
-  const void* q_sc; const void* db_sc; int sc_dt;
-  const void* q_m2; const void* db_m2; int m2_dt;
-  const double* mom_sc; const double* mom_m2;                   // [G][m][2][3] the all-pairs pass's moments (the pivot K = their combined mean)
-  int G, m, n_local;
-  const int32_t* flags;                                         // [m] order flags, or null: the compacted list below
-  const int32_t* list; const int32_t* cnt; int offset, NB;
-  double* partial;                                              // [RESOLVE_SLOTS][NB][4][3]
-  double* exact;                                                // [m][4][3]
-  unsigned* tick;                                               // [1] zero between launches
-  int* dflags;                                                  // deferred warning bits of the context ([2] resolved, [3] more flagged than one pass)
-};
-struct RescoreArgs {
-  double p_weight; const int32_t* cand_idx; const double* p5_all; int kin, k; int32_t* idx; double* score; double* mom_sc; double* mom_m2;
-};
-__device__ __forceinline__ double pivot_of(const double* mom_all, int G, int m, int q, int ch) {
-  double mean, sd;
-  chan_combine(mom_all, G, m, q, ch, mean, sd);
-  return (mean == mean) ? mean : 0.5;
-}
-// Chan combination in rank order of exact_all [G][m][4][3] (chan_combine's arithmetic)
-__device__ void exact_combine(const double* exact_all, int G, int m, int q, int c, double& mean, double& sd, double* loc /* [3] or null: the totals */) {
-  double cn = 0.0, mu = 0.0, m2 = 0.0;
-  for (int g = 0; g < G; g++) {
-    const double* o = exact_all + (((size_t)g * m + q) * 4 + c) * 3;
-    const double nb = o[0], mb = o[1], m2b = o[2];
-    if (nb <= 0.0) continue;
-    const double tot = cn + nb, delta = mb - mu;
-    mu += delta * (nb / tot);
-    m2 += m2b + delta * delta * (cn * nb / tot);
-    cn = tot;
-  }
-  mean = mu;
-  sd = sqrt(m2 / (cn - 1.0));
-  if (loc) { loc[0] = cn; loc[1] = mu; loc[2] = m2; }
-}
-// one WAVE: the candidates of query q re-scored with the exact statistics, the k best written over idx / score (rerank_sort_wave_kernel's rounds)
-__device__ void rescore_wave(int q, int lane, const double* exact_all, int G, int m, int has_sc, int has_m2, const RescoreArgs& R) {
-  const int kin = R.kin, k = R.k;
-  double w[4] = {has_sc ? R.p_weight : 0.0, has_sc ? 1.0 : 0.0, has_m2 ? R.p_weight : 0.0, has_m2 ? 1.0 : 0.0}, mean[4], sd[4];
-  for (int c = 0; c < 4; c++) {
-    mean[c] = 0.0; sd[c] = 1.0;
-    if (w[c] == 0.0) continue;
-    double loc[3];
-    exact_combine(exact_all, G, m, q, c, mean[c], sd[c], loc);
-    double* mo = c < 2 ? R.mom_sc : R.mom_m2;                    // single shard: the caller's moments become the exact ones
-    if (mo && lane < 3) mo[((size_t)q * 2 + (c & 1)) * 3 + lane] = loc[lane];
-  }
-  double v[2];
-  int j[2];
-#pragma unroll
-  for (int h = 0; h < 2; h++) {
-    const int c = lane + 64 * h;
-    j[h] = c < kin ? R.cand_idx[(size_t)q * kin + c] : -1;
-    v[h] = __builtin_nan("");
-    int own = -1;
-    if (j[h] >= 0)
-      for (int g = 0; g < G; g++) {
-        const double x = R.p5_all[p5_at(g, m, q, 0, kin, c)];
-        if (x == x) { v[h] = x; own = g; break; }
-      }
-    if (own >= 0) {
-      const double d0 = R.p5_all[p5_at(own, m, q, 1, kin, c)];
-      if (d0 == d0) {                                          // evaluated: the score again, in rerank_kernel's operation order
-        double f = 0.0;
-        for (int cc = 0; cc < 4; cc++) {
-          if (w[cc] == 0.0) continue;
-          const double d = R.p5_all[p5_at(own, m, q, 1 + cc, kin, c)];
-          f += w[cc] * ((d - mean[cc]) / sd[cc]);
-        }
-        v[h] = f;
-      }
-    }
-  }
-  for (int t = 0; t < k; t++) {
-    const bool first = cand_before(v[0], j[0], v[1], j[1]) || !cand_before(v[1], j[1], v[0], j[0]);
-    double bv = first ? v[0] : v[1];
-    int bj = first ? j[0] : j[1];
-    int bc = lane + (first ? 0 : 64);
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) {
-      const double ov = __shfl_xor(bv, sft, 64);
-      const int oj = __shfl_xor(bj, sft, 64), oc = __shfl_xor(bc, sft, 64);
-      if (cand_before(ov, oj, bv, bj) || (!cand_before(bv, bj, ov, oj) && oc < bc)) { bv = ov; bj = oj; bc = oc; }
-    }
-    const bool ok = bj >= 0 && bv == bv;
-    if (lane == 0) {
-      R.idx[(size_t)q * k + t] = ok ? bj : -1;
-      R.score[(size_t)q * k + t] = ok ? bv : __builtin_nan("");
-    }
-    if (bc == lane) { j[0] = -1; v[0] = __builtin_nan(""); }
-    if (bc == lane + 64) { j[1] = -1; v[1] = __builtin_nan(""); }
-  }
-}
-
-template <bool RESCORE>
-__global__ __launch_bounds__(256) void resolve_kernel(ExactArgs A, RescoreArgs R) {
-  __shared__ double buf[60 * 21 + 1200];
-  __shared__ double red[256];
-  __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
-  const int tid = threadIdx.x, b = blockIdx.x;
-  const int total = flagged_slots(A.flags, A.m, A.list, A.cnt, A.offset, s_list, s_tmp, tid, 256);
-  const int ns = total - A.offset < RESOLVE_SLOTS ? total - A.offset : RESOLVE_SLOTS;
-  if (ns <= 0) return;                                          // nothing flagged: the usual case
-  const size_t esc = A.sc_dt == 0 ? 8 : 4, em2 = A.m2_dt == 0 ? 8 : 4;
-  for (int s = 0; s < ns; s++) {
-    const int q = s_list[s];
-    const void* qs = A.q_sc ? static_cast<const char*>(A.q_sc) + (size_t)q * 2400 * esc : nullptr;
-    const void* qm = A.q_m2 ? static_cast<const char*>(A.q_m2) + (size_t)q * 4 * 384 * em2 : nullptr;
-    double K[4] = {0.0, 0.0, 0.0, 0.0}, acc[4][3] = {{0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}, {0.0, 0.0, 0.0}};
-    if (qs) { K[0] = pivot_of(A.mom_sc, A.G, A.m, q, 0); K[1] = pivot_of(A.mom_sc, A.G, A.m, q, 1); }
-    if (qm) { K[2] = pivot_of(A.mom_m2, A.G, A.m, q, 0); K[3] = pivot_of(A.mom_m2, A.G, A.m, q, 1); }
-    for (int j = b; j < A.n_local; j += A.NB) {
-      if (qs)
-        for (int ch = 0; ch < 2; ch++) {
-          const double d = sc_pair_exact(qs, A.sc_dt, (size_t)ch * 1200, A.db_sc, A.sc_dt, (size_t)j * 2400 + ch * 1200, buf, red, tid);
-          if (d == d) { const double x = d - K[ch]; acc[ch][0] += 1.0; acc[ch][1] += x; acc[ch][2] += x * x; }
-        }
-      if (qm)
-        for (int ch = 0; ch < 2; ch++) {
-          const double d = m2dp_pair_exact(qm, A.m2_dt, 0, A.db_m2, A.m2_dt, (size_t)j * 4 * 384, ch, red, tid);
-          if (d == d) { const double x = d - K[2 + ch]; acc[2 + ch][0] += 1.0; acc[2 + ch][1] += x; acc[2 + ch][2] += x * x; }
-        }
-    }
-    if (tid < 12) {                                             // (every thread holds the same sums: the pair functions return block-wide values)
-      const int c = tid / 3, e = tid % 3;
-      A.partial[(((size_t)s * A.NB + b) * 4 + c) * 3 + e] = acc[c][e];
-    }
-  }
-  // the last workgroup to arrive finishes: partials -> exact moments (-> re-scored candidates)
-  __threadfence();
-  __syncthreads();
-  if (tid == 0) s_tmp[5] = (atomicAdd(A.tick, 1u) == (unsigned)gridDim.x - 1u) ? 1 : 0;
-  __syncthreads();
-  if (!s_tmp[5]) return;
-  __threadfence();
-  if (tid == 0) {
-    *A.tick = 0u;                                               // ready for the next launch
-    if (A.dflags) { A.dflags[2] = 1; if (total - A.offset > RESOLVE_SLOTS) A.dflags[3] = 1; }
-  }
-  auto part_at = [&](size_t i) {                                 // written by other workgroups: agent-scope loads (L2), no copy of this CU's L1
-    return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(A.partial + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  };
-  for (int s = 0; s < ns; s++) {
-    const int q = s_list[s];
-    if (tid < 12) {
-      const int c = tid / 3, e = tid % 3;
-      double sum = 0.0;
-      for (int bb = 0; bb < A.NB; bb++) sum += part_at((((size_t)s * A.NB + bb) * 4 + c) * 3 + e);   // workgroup order: deterministic
-      red[tid] = sum;
-    }
-    __syncthreads();
-    if (tid < 4) {
-      const int c = tid;
-      const bool present = c < 2 ? A.q_sc != nullptr : A.q_m2 != nullptr;
-      const double N = red[3 * c], S1 = red[3 * c + 1], S2 = red[3 * c + 2];
-      const double K = present ? pivot_of(c < 2 ? A.mom_sc : A.mom_m2, A.G, A.m, q, c & 1) : 0.0;
-      double* w = A.exact + ((size_t)q * 4 + c) * 3;
-      w[0] = N;
-      w[1] = N > 0.0 ? K + S1 / N : 0.0;
-      w[2] = N > 0.0 ? S2 - S1 * S1 / N : 0.0;
-    }
-    __threadfence_block();
-    __syncthreads();
-    if (RESCORE && tid < 64) rescore_wave(q, tid, A.exact, 1, A.m, A.q_sc != nullptr, A.q_m2 != nullptr, R);
-    __syncthreads();
-  }
-}
-
-__global__ __launch_bounds__(64) void rescore_kernel(const int32_t* __restrict__ flags, const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
-                                                      int offset, const double* __restrict__ exact_all, int G, int m, int has_sc, int has_m2,
-                                                      RescoreArgs R) {
-  __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
-  const int s = blockIdx.x, lane = threadIdx.x;
-  const int total = flagged_slots(flags, m, list, cnt, offset, s_list, s_tmp, lane, 64);
-  if (offset + s >= total) return;
-  rescore_wave(s_list[s], lane, exact_all, G, m, has_sc, has_m2, R);
-}
 
 __global__ __launch_bounds__(256) void widen_kernel(const float* __restrict__ a, long long n, double* __restrict__ b) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -922,8 +562,10 @@ void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_d
                    double p_weight, int kin, const int32_t* idx_in, double* p5, unsigned* tick, size_t tick_cap, int k, int32_t* idx, double* score,
                    float* score32, const double* cand_sc32, double eps_d, double order_floor, double order_noise, int32_t* order_flags) {
   if (m <= 0) return;
+  // (containment: fp32-grade passes only - eps_d = 0; the single-product arithmetic has pr_f16_margin_dev for it)
+  const double* contain_sc = eps_d > 0 ? nullptr : cand_sc32;
   SortArgs S{idx_in, p5, m, kin, k, idx, score, score32, order_flags ? 1 : 0, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr, G, p_weight,
-             order_floor, order_noise, order_flags};
+             order_floor, order_noise, order_flags, contain_sc, 1e-6};
   RerankArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, m, n_local, G, q_row0, db_row0, mask_width, kin, p_weight, cand_sc32, k,
                eps_d > 0 ? eps_d : 1e-6, eps_d > 0 ? 2.0 : 64.0, p5};
   launch_rerank_kernel(st, A, idx_in, tick, tick_cap);
@@ -931,7 +573,7 @@ void launch_rerank(hipStream_t st, const void* q_sc, const void* db_sc, int sc_d
   hipLaunchKernelGGL(rerank_sort_kernel, dim3((m + 63) / 64), dim3(64), 0, st, idx_in, p5, m, kin, k, idx, score, score32);
   if (order_flags)
     hipLaunchKernelGGL(order_check_kernel, dim3(m), dim3(64), 0, st, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr, G, idx_in, p5, 1, m, kin, k,
-                       idx, p_weight, order_floor, order_noise, order_flags);
+                       idx, p_weight, order_floor, order_noise, order_flags, score ? contain_sc : nullptr, (const double*)score, 1e-6);
 }
 
 void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
@@ -953,48 +595,13 @@ void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom
 }
 
 void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int Gmom, const int32_t* cand_idx, const double* p5_all,
-                        int G, int m, int kin, int k, const int32_t* idx_sel, double p_weight, double eps_floor, double noise, int32_t* flags) {
+                        int G, int m, int kin, int k, const int32_t* idx_sel, double p_weight, double eps_floor, double noise, int32_t* flags,
+                        const double* cand_sc, const double* score_sel) {
   if (m <= 0) return;
   hipLaunchKernelGGL(order_check_kernel, dim3(m), dim3(64), 0, st, mom_sc, mom_m2, Gmom, cand_idx, p5_all, G, m, kin, k, idx_sel, p_weight,
-                     eps_floor, noise, flags);
+                     eps_floor, noise, flags, cand_sc, score_sel, 1e-6);
 }
 
-int exact_partial_blocks(int n_local) { return n_local < RESOLVE_NB ? (n_local > 0 ? n_local : 1) : RESOLVE_NB; }
-
-// flags [m] -> the flagged-query list the resolution kernels read: small calls scan the flags themselves (returns flags), larger ones get
-// the compacted list (one more launch; returns null)
-static const int32_t* resolve_list(hipStream_t st, const int32_t* flags, int m, int32_t* list, int32_t* cnt) {
-  if (m <= RESOLVE_SMALL_M) return flags;
-  hipLaunchKernelGGL(flag_compact_kernel, dim3(1), dim3(256), 0, st, flags, m, list, cnt);
-  return nullptr;
-}
-
-void launch_resolve(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
-                    const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* flags, int32_t* list, int32_t* cnt,
-                    int offset, bool compacted, double* partial, double* exact, unsigned* tick, int* dflags, bool rescore, double p_weight,
-                    const int32_t* cand_idx, const double* p5, int kin, int k, int32_t* idx, double* score, double* out_mom_sc, double* out_mom_m2) {
-  if (m <= 0 || n_local <= 0) return;
-  const int32_t* fl = compacted ? nullptr : resolve_list(st, flags, m, list, cnt);
-  int NB = exact_partial_blocks(n_local);
-  if (m <= 64 && NB > 256) NB = 256;      // an online call pays for the launch every time and for the resolution once in 10^5 calls: a small grid
-  ExactArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, fl, list, cnt, offset, NB, partial, exact, tick, dflags};
-  RescoreArgs R{p_weight, cand_idx, p5, kin, k, idx, score, out_mom_sc, out_mom_m2};
-  if (rescore) hipLaunchKernelGGL(resolve_kernel<true>, dim3(NB), dim3(256), 0, st, A, R);
-  else hipLaunchKernelGGL(resolve_kernel<false>, dim3(NB), dim3(256), 0, st, A, R);
-}
-
-void launch_flag_compact(hipStream_t st, const int32_t* flags, int m, int32_t* list, int32_t* cnt) {
-  hipLaunchKernelGGL(flag_compact_kernel, dim3(1), dim3(256), 0, st, flags, m, list, cnt);
-}
-
-void launch_rescore(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G, int m,
-                    int has_sc, int has_m2, double p_weight, const int32_t* cand_idx, const double* p5_all, int kin, int k, int32_t* idx,
-                    double* score) {
-  if (m <= 0) return;
-  RescoreArgs R{p_weight, cand_idx, p5_all, kin, k, idx, score, nullptr, nullptr};
-  hipLaunchKernelGGL(rescore_kernel, dim3(RESOLVE_SLOTS), dim3(64), 0, st, m <= RESOLVE_SMALL_M ? flags : nullptr, list, cnt, offset, exact_all, G, m,
-                     has_sc, has_m2, R);
-}
 
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* p5_all, int G, int m, int kin, int k, int32_t* idx,
                           double* score) {

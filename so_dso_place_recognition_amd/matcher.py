@@ -21,10 +21,13 @@ Sharding: every rank holds the DB rows [db_row0, db_row0 + n_l
   6. all_gather_into_tensor of the shards' evaluations (p5 blocks: score + 4 exact channel distances per candidate, 40 (k+8) B per
      query per rank), every candidate's score taken from its owner, the k best by (score, idx) and the order check
      (pr_rerank_finish_dev)                                                                             [RCCL + HIP]
-  7. queries whose order hangs on the fp32 pass's sigmas (none, as a rule: the kernels leave at once): this shard's exact fp64 row
-     moments (pr_order_exact_moments_dev), all_gather_into_tensor (96 B per query per rank), candidates re-scored with the exact
-     statistics of the whole row on every rank (pr_order_rescore_dev) - run_test.m:38-41,57 are fp64 throughout   [HIP + RCCL + HIP]
-With one rank steps 2, 4, 6 and 7's gather are skipped (pr_rerank_dev does 5 + the selection, pr_order_resolve_async_dev does 7).
+  7. queries the re-evaluated candidates cannot answer for certain - their order hangs on the fp32 pass's sigmas, or the k + 8 candidates do
+     not provably hold the top-k (near-copies of one place) - none, as a rule: the kernels leave at once.  Such a query is answered from
+     its EXACT ROW (run_test.m:38-57 are fp64 over the whole row): this shard's fp64 distances to all of its entries and their moments
+     (pr_order_exact_moments_dev), all_gather_into_tensor (96 B per query per rank), the shard's k best under the statistics of the whole
+     row (pr_order_exact_select_dev), all_gather_into_tensor (64 x 16 k B per rank), merge on every rank (pr_order_exact_merge_dev)
+                                                                                                [HIP + RCCL + HIP + RCCL + HIP]
+With one rank steps 2, 4, 6 and 7's gathers are skipped (pr_rerank_dev does 5 + the selection, pr_order_resolve_async_dev does 7).
 """
 from __future__ import annotations
 
@@ -107,13 +110,14 @@ class _Base:
         self.f16_flags, self.f16_count = flags, count
         return flags, count
 
-    def _resolve_order(self, raw6, mom_sc, mom_m2, m, n, p_weight, cand_idx, k, idx, score):
-        """pr_order_resolve_async_dev after a single-shard pr_rerank_dev: queries whose re-evaluated order hangs on the fp32 pass's sigmas get
-        exact (fp64) row statistics and their candidates are re-scored; idx / score (and the moments rows) are patched in place.
-        Stream-ordered: no host synchronisation (PR_WARN_ORDER_RESOLVED at ctx.take_warnings() tells whether it happened)."""
+    def _resolve_order(self, raw6, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, k, idx, score):
+        """pr_order_resolve_async_dev after a single-shard pr_rerank_dev: queries whose re-evaluated order hangs on the fp32 pass's sigmas, or
+        whose candidate list does not provably hold the top-k, are answered from their exact fp64 rows; idx / score (and the moments rows)
+        are patched in place.  Stream-ordered: no host synchronisation (PR_WARN_ORDER_RESOLVED at ctx.take_warnings() tells whether it
+        happened)."""
         self._enter()
-        self.ctx.check(self.lib.pr_order_resolve_async_dev(self.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), m, n, float(p_weight),
-                                                           cand_idx.shape[1], _dptr(cand_idx), int(k), _dptr(idx), _dptr(score)))
+        self.ctx.check(self.lib.pr_order_resolve_async_dev(self.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), m, n, int(q_row0), int(mask_width),
+                                                           float(p_weight), int(k), _dptr(idx), _dptr(score)))
         self._leave()
 
     def _fallback_rows(self, run_rows, idx, score, mask_width, q_row0):
@@ -262,16 +266,23 @@ class Matcher(_Base):
         sc = self.type == _lib.TYPE_SC
         return (self._mom_all if sc else None, None if sc else self._mom_all)
 
-    def finish(self, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int):
-        return _finish_dev(self, cand_idx, part_all, k, (*self._moms(), self._args[0]), self._args[4])
+    def finish(self, cand_idx: torch.Tensor, cand_sc: torch.Tensor, part_all: torch.Tensor, k: int):
+        return _finish_dev(self, cand_idx, cand_sc, part_all, k, (*self._moms(), self._args[0]), self._args[4])
 
     def exact_moments(self):
-        """Step 7, local half: this shard's exact row moments of the queries the last finish() flagged -> [m, 4, 3] f64."""
+        """Step 7, first local part: this shard's exact rows of the queries the last finish() flagged (kept in the context) and their
+        moments -> [m, 4, 3] f64."""
         return _exact_moments_dev(self, self._raw_args()[:6], *self._moms(), self._args[0], self._m, self.n)
 
-    def rescore(self, exact_all: torch.Tensor, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int, idx: torch.Tensor, score: torch.Tensor):
+    def exact_select(self, exact_all: torch.Tensor, k: int):
+        """Step 7, second local part: this shard's k best of the flagged queries' exact rows under the statistics of all shards
+        -> [64, 2, k] f64 (scores | global indices)."""
         sc = self.type == _lib.TYPE_SC
-        return _rescore_dev(self, exact_all, sc, not sc, self._args[4], cand_idx, part_all, k, idx, score)
+        G, q_row0, db_row0, mask_width, p_weight = self._args
+        return _exact_select_dev(self, exact_all, self._m, self.n, q_row0, db_row0, mask_width, p_weight, sc, not sc, k)
+
+    def exact_merge(self, sel_all: torch.Tensor, k: int, idx: torch.Tensor, score: torch.Tensor):
+        return _exact_merge_dev(self, sel_all, self._m, k, idx, score)
 
     def local_phase2(self, mom_all: torch.Tensor, G: int, mask_width, p_weight, k, db_row0, q_row0):
         """Selection + re-evaluation of this shard alone -> its own top-k (what rank g would answer by itself)."""
@@ -288,12 +299,13 @@ class Matcher(_Base):
               exact_order: bool = True):
         """Returns (idx int32 [m,k] GLOBAL DB row indices, score float64 [m,k]) as device tensors.
         force_exchange: run the all-gathers and the merge even with one rank (measures the protocol's overhead).
-        exact_order (default): queries whose re-evaluated order is not certain under the fp32 pass's row sigmas are answered with fp64 row
-        statistics, sharded or not (run_test.m:38-41,57 are fp64 throughout) - stream-ordered kernels that leave at once when nothing is
-        flagged; False skips them (the order of the fp32-statistics scores; the flags are then simply dropped)."""
+        exact_order (default): queries whose re-evaluated order is not certain under the fp32 pass's row sigmas, or whose k + 8 candidates
+        do not provably hold the top-k of the whole row, are answered from their exact fp64 rows, sharded or not (run_test.m:38-57 are fp64
+        over the whole row) - stream-ordered kernels that leave at once when nothing is flagged, 64 such queries per call
+        (PR_WARN_ORDER_UNRESOLVED beyond); False skips them (the answer of the re-evaluated candidate list; the flags are simply dropped)."""
         G = _world(group)
         f16 = self.f16 and not self.plain
-        resolve = (self.exact_moments, self.rescore) if (exact_order and not self.plain and not f16) else None
+        resolve = (self.exact_moments, self.exact_select, self.exact_merge) if (exact_order and not self.plain and not f16) else None
         post = (lambda cand_sc, idx, score: self._margin(_dptr_mom(self, True), _dptr_mom(self, False), self._args[0], p_weight, cand_sc, k,
                                                           score)) if f16 else None
         idx, score = sharded_topk(lambda: self.local_phase1(queries),
@@ -308,7 +320,7 @@ class Matcher(_Base):
                                 exact_order=exact_order)
             idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
         elif resolve is not None and G == 1 and not force_exchange:
-            self._resolve_order(self._raw_args()[:6], *self._moms(), self._m, self.n, p_weight, self._last_cand[0], k, idx, score)
+            self._resolve_order(self._raw_args()[:6], *self._moms(), self._m, self.n, q_row0, mask_width, p_weight, k, idx, score)
         return idx, score
 
     def take_warnings(self) -> int:
@@ -449,8 +461,8 @@ class FusedMatcher(_Base):
         self._leave()
         return idx, score
 
-    def finish(self, cand_idx, part_all, k):
-        return _finish_dev(self, cand_idx, part_all, k, (self._m1, self._m2, self._args[0]), self._args[4])
+    def finish(self, cand_idx, cand_sc, part_all, k):
+        return _finish_dev(self, cand_idx, cand_sc, part_all, k, (self._m1, self._m2, self._args[0]), self._args[4])
 
     def _raw6(self):
         return (_dptr(self.sc._q_sig), _dptr(self.sc.db_sig), _torch_dt(self.sc.db_sig), _dptr(self.m2._q_sig), _dptr(self.m2.db_sig),
@@ -459,8 +471,12 @@ class FusedMatcher(_Base):
     def exact_moments(self):
         return _exact_moments_dev(self, self._raw6(), self._m1, self._m2, self._args[0], self.sc._m, self.sc.n)
 
-    def rescore(self, exact_all, cand_idx, part_all, k, idx, score):
-        return _rescore_dev(self, exact_all, True, True, self._args[4], cand_idx, part_all, k, idx, score)
+    def exact_select(self, exact_all, k):
+        G, q_row0, db_row0, mask_width, p_weight = self._args
+        return _exact_select_dev(self, exact_all, self.sc._m, self.sc.n, q_row0, db_row0, mask_width, p_weight, True, True, k)
+
+    def exact_merge(self, sel_all, k, idx, score):
+        return _exact_merge_dev(self, sel_all, self.sc._m, k, idx, score)
 
     def local_phase2(self, mom_all, G, mask_width, p_weight, k, db_row0, q_row0):
         idx_in, sc = self.local_select(mom_all, G, mask_width, p_weight, k, db_row0, q_row0)
@@ -473,7 +489,7 @@ class FusedMatcher(_Base):
               db_row0: int = 0, q_row0: int = 0, group=None, f16_fallback: bool = True, exact_order: bool = True):
         G = _world(group)
         post = (lambda cand_sc, idx, score: self._margin(self._m1, self._m2, self._args[0], p_weight, cand_sc, k, score)) if self.f16 else None
-        resolve = (self.exact_moments, self.rescore) if (exact_order and not self.f16) else None
+        resolve = (self.exact_moments, self.exact_select, self.exact_merge) if (exact_order and not self.f16) else None
         idx, score = sharded_topk(lambda: self.local_phase1(sc_queries, m2dp_queries),
                                   lambda mom_all, G_: self.local_select(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
                                   k, group if G > 1 else None, G, merge=self.merge, rerank=self.local_rerank, finish=self.finish, post=post,
@@ -485,7 +501,7 @@ class FusedMatcher(_Base):
                                 p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group, exact_order=exact_order)
             idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
         elif resolve is not None and G == 1:
-            self._resolve_order(self._raw6(), self._m1, self._m2, self.sc._m, self.sc.n, p_weight, self._last_cand[0], k, idx, score)
+            self._resolve_order(self._raw6(), self._m1, self._m2, self.sc._m, self.sc.n, q_row0, mask_width, p_weight, k, idx, score)
         return idx, score
 
     take_warnings = Matcher.take_warnings
@@ -518,38 +534,54 @@ def _merge_dev(owner, idx_all: torch.Tensor, sc_all: torch.Tensor, k: int):
     return idx, score
 
 
-def _finish_dev(owner, cand_idx: torch.Tensor, part_all: torch.Tensor, k: int, moms, p_weight: float):
-    """pr_rerank_finish_dev: candidates [m, kin] + the shards' p5 blocks [G, m, 5, kin] -> (idx [m,k], score [m,k]); the order check of the
-    result (statistics moms = (mom_sc | None, mom_m2 | None, shards in them)) stays in the context: pr_f16_margin_dev (PR_SC_ARITH_F16) or
-    exact_moments() / rescore() take it."""
+def _finish_dev(owner, cand_idx: torch.Tensor, cand_sc: torch.Tensor | None, part_all: torch.Tensor, k: int, moms, p_weight: float):
+    """pr_rerank_finish_dev: candidates [m, kin] (+ their merged pass scores) + the shards' p5 blocks [G, m, 5, kin] -> (idx [m,k], score [m,k]);
+    the order and containment checks of the result (statistics moms = (mom_sc | None, mom_m2 | None, shards in them)) stay in the context:
+    pr_f16_margin_dev (PR_SC_ARITH_F16) or exact_moments() / exact_select() / exact_merge() take them."""
     G, m, five, kin = part_all.shape
     assert five == 5
     idx = torch.empty((m, k), dtype=torch.int32, device=cand_idx.device)
     score = torch.empty((m, k), dtype=torch.float64, device=cand_idx.device)
     cand_idx = cand_idx.contiguous()
+    cand_sc = None if cand_sc is None else cand_sc.contiguous()
     part_all = part_all.contiguous()
     mom_sc, mom_m2, g_mom = moms
     owner._enter()
-    owner.ctx.check(owner.lib.pr_rerank_finish_dev(owner.ctx.h, _dptr(mom_sc), _dptr(mom_m2), int(g_mom), _dptr(cand_idx), _dptr(part_all), G, m, kin, k,
-                                                   float(p_weight), _dptr(idx), _dptr(score)))
+    owner.ctx.check(owner.lib.pr_rerank_finish_dev(owner.ctx.h, _dptr(mom_sc), _dptr(mom_m2), int(g_mom), _dptr(cand_idx), _dptr(cand_sc),
+                                                   _dptr(part_all), G, m, kin, k, float(p_weight), _dptr(idx), _dptr(score)))
     owner._leave()
     return idx, score
 
 
-def _exact_moments_dev(owner, raw6, mom_sc, mom_m2, g_mom: int, m: int, n_local: int):
+RESOLVE_SLOTS = 64      # flagged queries one pass of the exact-row resolution serves (kernels.hpp)
+
+
+def _exact_moments_dev(owner, raw6, mom_sc, mom_m2, g_mom: int, m: int, n_local: int, offset: int = 0):
     exact = torch.empty((m, 4, 3), dtype=torch.float64, device=owner.dev)
     owner._enter()
-    owner.ctx.check(owner.lib.pr_order_exact_moments_dev(owner.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), int(g_mom), m, n_local, _dptr(exact)))
+    owner.ctx.check(owner.lib.pr_order_exact_moments_dev(owner.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), int(g_mom), m, n_local, int(offset),
+                                                         _dptr(exact)))
     owner._leave()
     return exact
 
 
-def _rescore_dev(owner, exact_all: torch.Tensor, has_sc: bool, has_m2: bool, p_weight: float, cand_idx, part_all, k: int, idx, score):
-    G, m, five, kin = part_all.shape
-    exact_all, cand_idx, part_all = exact_all.contiguous(), cand_idx.contiguous(), part_all.contiguous()
+def _exact_select_dev(owner, exact_all: torch.Tensor, m: int, n_local: int, q_row0: int, db_row0: int, mask_width: int, p_weight: float,
+                      has_sc: bool, has_m2: bool, k: int, offset: int = 0):
+    G = exact_all.shape[0]
+    exact_all = exact_all.contiguous()
+    sel = torch.empty((RESOLVE_SLOTS, 2, k), dtype=torch.float64, device=owner.dev)
     owner._enter()
-    owner.ctx.check(owner.lib.pr_order_rescore_dev(owner.ctx.h, _dptr(exact_all), G, m, int(has_sc), int(has_m2), float(p_weight), _dptr(cand_idx),
-                                                   _dptr(part_all), kin, k, _dptr(idx), _dptr(score)))
+    owner.ctx.check(owner.lib.pr_order_exact_select_dev(owner.ctx.h, _dptr(exact_all), G, m, n_local, int(q_row0), int(db_row0), int(mask_width),
+                                                        float(p_weight), int(has_sc), int(has_m2), int(k), int(offset), _dptr(sel)))
+    owner._leave()
+    return sel
+
+
+def _exact_merge_dev(owner, sel_all: torch.Tensor, m: int, k: int, idx, score, offset: int = 0):
+    G = sel_all.shape[0]
+    sel_all = sel_all.contiguous()
+    owner._enter()
+    owner.ctx.check(owner.lib.pr_order_exact_merge_dev(owner.ctx.h, _dptr(sel_all), G, m, int(k), int(offset), _dptr(idx), _dptr(score)))
     owner._leave()
     return idx, score
 
@@ -587,10 +619,11 @@ def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None,
         return do_merge(idx_all, sc_all, k)
     cand_idx, cand_sc = do_merge(idx_all, sc_all, kin)   # the global top-(k+8) of the fp32 pass, identical on every rank
     part_all = gather(rerank(cand_idx, k, True, cand_sc))
-    idx, score = finish(cand_idx, part_all, k)
-    if resolve is not None:                              # step 7: (exact moments of the flagged queries, re-scoring with the gathered ones)
+    idx, score = finish(cand_idx, cand_sc, part_all, k)
+    if resolve is not None:                              # step 7: the flagged queries from their exact rows (moments, per-shard k best, merge)
         exact_all = gather(resolve[0]())
-        idx, score = resolve[1](exact_all, cand_idx, part_all, k, idx, score)
+        sel_all = gather(resolve[1](exact_all, k))
+        idx, score = resolve[2](sel_all, k, idx, score)
     if post is not None:
         post(cand_sc, idx, score)
     return idx, score

@@ -52,3 +52,44 @@ def score_tol(score, sigmas=None, p_weight=2.0, eps=3e-8):
 def row_sigmas(dp, di):
     """(N-1 standard deviations of the rows of two distance matrices, NaN left out, shaped [m, 1]; row length)."""
     return np.nanstd(dp, axis=1, ddof=1)[:, None], np.nanstd(di, axis=1, ddof=1)[:, None], dp.shape[1]
+
+
+def near_copy_clusters(type_, n, m, rows, copies=40, seed=21, db_seed=45, q_seed=46):
+    """A synthetic DB / query set in which, for every query t of `rows`, `copies` DB entries at random positions are NEAR-COPIES of the
+    query's planted entry: the same signature with a handful of values scaled by 1 + c delta (c = 1 .. copies), delta drawn per query
+    from 1e-8.5 .. 1e-5.5 - their distances to the query form an arithmetic progression with a step of ~1e-10 ... 1e-7, at or below
+    what the fp32-grade all-pairs pass resolves (1e-7), so more than k + 8 entries tie in its eyes: the place a vehicle stood at,
+    revisited (the text files carry 6 digits).  Returns (db, queries, planted, members): members[t] = the cluster's DB indices
+    (planted entry first)."""
+    rng = np.random.default_rng(seed)
+    if type_ == "sc":
+        db = synth.sc_database(db_seed, n)
+        q, planted = synth.sc_queries(q_seed, db, m)
+    else:
+        db = synth.m2dp_database(db_seed, n)
+        q, planted = synth.m2dp_queries(q_seed, db, m)
+    pool = np.setdiff1d(np.arange(n), planted)
+    spots = rng.choice(pool, size=len(rows) * copies, replace=False).reshape(len(rows), copies)
+    members = {}
+    for r, t in enumerate(rows):
+        delta = 10.0 ** rng.uniform(-8.5, -5.5)
+        sign = rng.choice([-1.0, 1.0])
+        if type_ == "sc":
+            e = db[planted[t]]
+            pick = rng.choice(np.nonzero(e[:1200] > 0)[0], size=30, replace=False)
+            for c in range(copies):
+                x = e.copy()
+                x[pick] *= 1.0 + sign * (c + 1) * delta
+                db[spots[r, c]] = x
+        else:
+            e = db[4 * planted[t]: 4 * planted[t] + 4]
+            pick = rng.choice(64, size=20, replace=False)
+            for c in range(copies):
+                x = e.copy()
+                x[:, pick] *= 1.0 + sign * (c + 1) * delta * 0.03      # (M2DP rows are unit vectors: a dot moves by ~delta itself)
+                db[4 * spots[r, c]: 4 * spots[r, c] + 4] = x
+        members[int(t)] = np.concatenate([[planted[t]], spots[r]])
+    return db, q, planted, members
+
+
+CLUSTER_CASE = (1400, 48, tuple(range(0, 48, 3)), 40)      # (n, m, queries with a cluster, copies): tests/dist_order_case.py builds the same

@@ -45,7 +45,7 @@ def _worker(rank, world, port, n, m, k, mask, q):
 
     idx, sc = sharded_topk(local_moments, local_select, k, None, world)
     # the full protocol (steps 5 - 7 of matcher.py) with stand-ins: owner-wise re-evaluation blocks [m, 5, kin], finish, and the
-    # exact-moments exchange of the order resolution - every rank's [m, 4, 3] block must arrive at its rank's slot on every rank
+    # two exchanges of the exact-row resolution - every rank's [m, 4, 3] moments and [64, 2, k] list must arrive at its rank's slot on every rank
     seen = {}
 
     def rerank(cand_idx, kk, partial, cand_sc):
@@ -57,7 +57,8 @@ def _worker(rank, world, port, n, m, k, mask, q):
         p5[:, 1:][np.repeat(own[:, None, :], 4, 1)] = 0.25
         return torch.from_numpy(p5)
 
-    def finish(cand_idx, part_all, kk):
+    def finish(cand_idx, cand_sc, part_all, kk):
+        assert cand_sc.shape == cand_idx.shape
         pa = part_all.numpy()
         assert pa.shape == (world, m, 5, cand_idx.shape[1])
         owners = (~np.isnan(pa[:, :, 0])).sum(0)
@@ -68,12 +69,17 @@ def _worker(rank, world, port, n, m, k, mask, q):
     def exact():
         return torch.full((m, 4, 3), float(rank + 1), dtype=torch.float64)
 
-    def rescore(exact_all, cand_idx, part_all, kk, i_, s_):
+    def select(exact_all, kk):                                 # this rank's k best of the flagged queries' exact rows: [64, 2, k]
         seen["exact"] = exact_all.numpy().copy()
+        return torch.full((64, 2, kk), float(10 * (rank + 1)), dtype=torch.float64)
+
+    def merge(sel_all, kk, i_, s_):
+        seen["sel"] = sel_all.numpy().copy()
         return i_, s_
 
-    idx2, sc2 = sharded_topk(local_moments, local_select, k, None, world, rerank=rerank, finish=finish, resolve=(exact, rescore))
+    idx2, sc2 = sharded_topk(local_moments, local_select, k, None, world, rerank=rerank, finish=finish, resolve=(exact, select, merge))
     assert seen["exact"].shape == (world, m, 4, 3) and all((seen["exact"][g] == g + 1).all() for g in range(world))
+    assert seen["sel"].shape == (world, 64, 2, k) and all((seen["sel"][g] == 10 * (g + 1)).all() for g in range(world))
     assert torch.equal(idx2, idx) and np.abs(sc2.numpy() - sc.numpy()).max() == 0.0
     if rank == 0:
         q.put((idx.numpy(), sc.numpy()))

@@ -139,12 +139,12 @@ def _sharded_run(make_matcher, shards, pack, phase1_args, mask, k):
     sel = [mt.local_select(mom_all, G, mask, 2.0, k, lo, 0) for mt, (lo, hi) in zip(ms, shards)]
     sel = [(a.clone(), b.clone()) for a, b in sel]
     kin = sel[0][0].shape[1]
-    cand, _ = ms[0].merge(torch.stack([p[0] for p in sel]), torch.stack([p[1] for p in sel]), kin)
+    cand, cand_sc = ms[0].merge(torch.stack([p[0] for p in sel]), torch.stack([p[1] for p in sel]), kin)
     part_all = torch.stack([mt.local_rerank(cand, k, True).clone() for mt in ms])
     # exactly one owner per candidate (masked pairs: +Inf everywhere); PR_SC_ARITH_F16: [G, m, 5, kin] - scores + the four channel parts
     assert (torch.isnan(part_all).sum(0) == G - 1).all() or mask > 0 or part_all.dim() == 4
     assert part_all.dim() == 3 or (torch.isnan(part_all[:, :, 0]).sum(0) == G - 1).all() or mask > 0
-    idx, sc = ms[0].finish(cand, part_all, k)
+    idx, sc = ms[0].finish(cand, cand_sc, part_all, k)
     per = [tuple(t.clone() for t in mt.local_rerank(a, k, False)) for mt, (a, b) in zip(ms, sel)]
     return ms, per, idx.cpu().numpy(), sc.cpu().numpy()
 
@@ -366,8 +366,8 @@ def test_order_that_hangs_on_the_row_sigmas_is_resolved_with_fp64_statistics(api
     than what the fp32 pass's sigma error (2.5e-7 relative) moves them, and their two channels disagree about the order: every arithmetic
     returned them swapped.  The order check flags such queries and they are answered with fp64 row statistics on EVERY path - host calls
     (pr_order_resolve_dev), the device-resident Matcher by default (pr_order_resolve_async_dev, stream-ordered), pr_group and the
-    torch.distributed Matcher (pr_order_exact_moments_dev + all-gather + pr_order_rescore_dev) - indices AND scores of that row are then
-    fp64 throughout."""
+    torch.distributed Matcher (pr_order_exact_moments_dev, pr_order_exact_select_dev, pr_order_exact_merge_dev around two all-gathers) -
+    indices AND scores of that row are then fp64 throughout."""
     import torch
     from so_dso_place_recognition_amd import _lib
     from so_dso_place_recognition_amd.matcher import Matcher
@@ -416,6 +416,71 @@ def test_order_that_hangs_on_the_row_sigmas_is_resolved_with_fp64_statistics(api
     assert d["world"] == 2 and d["warnings"] & _lib.WARN_ORDER_RESOLVED
     assert np.array_equal(np.array(d["idx"]), oidx)
     assert np.abs(np.array(d["score"])[rows] - osc[rows]).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("type_", ["sc", "m2dp"])
+def test_near_copy_clusters_are_answered_from_the_exact_row(api, type_):
+    """run_test.m:57 takes the minimum over the WHOLE row; the fp64 re-evaluation sees the k + 8 best of an fp32-grade pass.  Forty
+    near-copies of a query's planted entry whose distances differ by 1e-10 ... 1e-7 (helpers.near_copy_clusters) tie in that pass: the
+    exact best need not be among the 9 it hands on.  The containment check flags such a query and it is answered from its exact fp64 row -
+    on every path: host calls (every arithmetic), the device-resident Matcher (stream-ordered), pr_group with three virtual shards, the
+    torch.distributed Matcher with two ranks - with the oracle's indices for k = 1 and k = 5."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from so_dso_place_recognition_amd import _lib
+    from so_dso_place_recognition_amd.matcher import Matcher
+    n, m, rows, copies = helpers.CLUSTER_CASE
+    db, q, planted, members = helpers.near_copy_clusters(type_, n, m, rows, copies)
+    t_id = 0 if type_ == "sc" else 1
+    rc, oidx, osc = oracle_lib.match_topk(t_id, q, db, 0, 2.0, 5)
+    assert rc == 0
+    for t in rows:                                                    # the test has teeth: the oracle's five best are cluster members, a
+        assert set(oidx[t]) <= set(members[t].tolist())              # hair's breadth apart - and distinct
+        gaps = np.diff(osc[t])
+        assert (gaps > 0).all() and gaps.max() < 1e-4
+    others = np.setdiff1d(np.arange(m), rows)
+    dev = torch.device("cuda", 0)
+    rps = 4 if type_ == "m2dp" else 1
+    for k in (1, 5):
+        for arith in ("f16x2", "f32", "f16"):
+            ctx = api.Context(0, sc_arith=arith)
+            idx, sc = api.match_topk(type_, q, db, 0, 2.0, k, ctx=ctx)
+            w = ctx.take_warnings()
+            assert np.array_equal(idx, oidx[:, :k]), (k, arith)
+            assert np.abs(sc[list(rows)] - osc[list(rows), :k]).max() < 1e-9, (k, arith)        # exact rows: fp64 throughout
+            assert (w & _lib.WARN_ORDER_RESOLVED) or arith == "f16", (k, arith)            # (f16: margin check -> split-f16 pass -> its own containment check)
+            ctx.close()
+        mt = Matcher(type_, m, n, ctx=api.Context(0, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
+        mt.pack_database(torch.from_numpy(db).to(dev))
+        i0, s0 = mt.match(torch.from_numpy(q).to(dev), 0, 2.0, k, exact_order=False)       # what the k + 8 candidates alone give
+        i0 = i0.cpu().numpy().copy()
+        i1, s1 = mt.match(torch.from_numpy(q).to(dev), 0, 2.0, k)
+        assert mt.take_warnings() & _lib.WARN_ORDER_RESOLVED
+        i1, s1 = i1.cpu().numpy(), s1.cpu().numpy()
+        assert np.array_equal(i1, oidx[:, :k]) and np.abs(s1[list(rows)] - osc[list(rows), :k]).max() < 1e-9
+        assert np.array_equal(i0[others], oidx[others, :k])
+        if k == 1:
+            assert (i0[list(rows), 0] != oidx[list(rows), 0]).sum() >= 3               # ... is wrong for clusters larger than the list
+        mt.close()
+        g = api.Group([0, 0, 0])
+        g.set_database(type_, db)
+        gi, gs = g.match_topk(q, 0, 2.0, k)
+        assert g.last_flagged >= len(rows) and (g.take_warnings() & _lib.WARN_ORDER_RESOLVED)
+        assert np.array_equal(gi, oidx[:, :k]) and np.abs(gs[list(rows)] - osc[list(rows), :k]).max() < 1e-9
+        g.close()
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(29700 + (os.getpid() + 7 * k + t_id) % 90), os.path.join(root, "tests", "dist_order_case.py"), "f16x2",
+               "cluster_" + type_, str(k)]
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert d["world"] == 2 and d["warnings"] & _lib.WARN_ORDER_RESOLVED
+        assert np.array_equal(np.array(d["idx"]), oidx[:, :k])
+        assert np.abs(np.array(d["score"])[list(rows)] - osc[list(rows), :k]).max() < 1e-9
 
 
 @pytest.mark.gpu

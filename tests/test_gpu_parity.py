@@ -605,9 +605,9 @@ def test_fused_matcher_device_path_and_two_shards(api):
     assert np.array_equal(i3.numpy(), want_idx)
     # the production protocol: fp32 lists merged first, owners re-evaluate, finish
     sel = [tuple(x.clone() for x in f.local_select(mom_all, 2, mask, 2.0, k, lo, 0)) for f, lo in parts]
-    cand, _ = parts[0][0].merge(torch.stack([a for a, b in sel]), torch.stack([b for a, b in sel]), sel[0][0].shape[1])
+    cand, cand_sc = parts[0][0].merge(torch.stack([a for a, b in sel]), torch.stack([b for a, b in sel]), sel[0][0].shape[1])
     part_all = torch.stack([f.local_rerank(cand, k, True).clone() for f, lo in parts])
-    idx4, sc4 = parts[0][0].finish(cand, part_all, k)
+    idx4, sc4 = parts[0][0].finish(cand, cand_sc, part_all, k)
     assert np.array_equal(idx4.cpu().numpy(), want_idx) and np.abs(sc4.cpu().numpy() - want_sc).max() < 1e-9
     for f, lo in parts:
         f.close()
