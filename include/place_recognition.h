@@ -176,6 +176,10 @@ int pr_fuse_select2_dev(pr_ctx* ctx, const float* d_p, const float* d_i, const f
 #define PR_MAX_SIGS 4000000          /* capacity limit of one signature set (32-bit offsets inside the matchers) */
 int pr_sigset_create(pr_ctx* ctx, int type, int role, int32_t max_sigs, pr_sigset** out);
 void pr_sigset_destroy(pr_ctx* ctx, pr_sigset* s);
+/* pr_sigset_pack inside a captured hipGraph: whether the image is zero-filled first is decided on the HOST from the set's history (a re-pack
+ * of at least as many rows in the same geometry needs no fill) and baked into the graph as the presence or absence of a memset node.  A set
+ * packed inside a captured graph must therefore not be re-packed with ANOTHER row count outside it between replays: the replayed pack would
+ * run without the fill it then needs.  (Packing other sets, or this one with the captured count, is fine.) */
 int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int where, int32_t n_sigs);
 int32_t pr_sigset_count(const pr_sigset* s);
 

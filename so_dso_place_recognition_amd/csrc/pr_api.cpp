@@ -97,10 +97,27 @@ static thread_local std::string g_err;   // errors without a context
 
 namespace {
 
-struct DevBuf {   // RAII device scratch for the host-buffer entry points
+// RAII device scratch for the host-buffer entry points.  An error return may leave work in flight that still touches a buffer - on the
+// context's stream or on a side stream it forked: the streams of the context whose call owns the buffer (DevScope, first thing in every
+// such call) are idle before it goes.  Only those: a device-wide synchronisation would stall unrelated streams of the process (torch's,
+// RCCL's) and is illegal while another thread captures a graph in global mode.
+thread_local pr_ctx* g_scope_ctx = nullptr;
+struct DevScope {
+  pr_ctx* prev;
+  explicit DevScope(pr_ctx* c) : prev(g_scope_ctx) { g_scope_ctx = c; }
+  ~DevScope() { g_scope_ctx = prev; }
+};
+struct DevBuf {
   void* p = nullptr;
-  // (an error return may leave work of a forked side stream in flight that still touches the buffer: the whole device is idle before it goes)
-  ~DevBuf() { if (p) { (void)hipDeviceSynchronize(); (void)hipFree(p); } }
+  ~DevBuf() {
+    if (!p) return;
+    if (pr_ctx* c = g_scope_ctx) {
+      (void)hipStreamSynchronize(c->stream);
+      if (c->side) (void)hipStreamSynchronize(c->side);
+      if (c->side2) (void)hipStreamSynchronize(c->side2);
+    } else (void)hipDeviceSynchronize();
+    (void)hipFree(p);
+  }
   hipError_t alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16); }
   template <typename T> T* as() { return static_cast<T*>(p); }
 };
@@ -446,6 +463,7 @@ int pr_pts_preprocess_gpu(pr_ctx* ctx, const char* poses_file, const char* pts_f
   if (!res) { if (idf) fclose(idf); PR_FAIL(ctx, PR_ENOMEM, "out of host memory"); }
   res->offs.assign(1, 0);
   int rc = PR_OK;
+  DevScope scope_(ctx);
   DevBuf dxyz, dint, dbirth, dW, demit, dnr, ddeath, dpose, dfa, dcur, doff, dcnt, dlist, dcell, dval, dtv, dtf, dtb, dkeys, dwin,
       dnk, dscnt, dsnb, dnext, dboff, dbkt, dord, dooff, doxyz, doint, dfr;
 #define PRE_HIP(call) { hipError_t _e = (call); if (_e != hipSuccess) { ctx->err = std::string(#call) + ": " + hipGetErrorString(_e); \
@@ -619,6 +637,7 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
   const size_t rows = (s->type == PR_TYPE_SC) ? (size_t)n_sigs : (s->type == PR_TYPE_M2DP ? (size_t)4 * n_sigs : (size_t)16 * n_sigs);
   const size_t cols = (s->type == PR_TYPE_SC) ? PR_SC_SIG_LEN : (s->type == PR_TYPE_M2DP ? PR_M2DP_SIG_LEN : PR_DELIGHT_SIG_LEN);
   const size_t esz = (dtype == PR_F64) ? 8 : 4;
+  DevScope scope_(ctx);
   DevBuf stage;
   const void* dsig = sig;
   if (where == PR_HOST && n_sigs > 0) {
@@ -741,11 +760,11 @@ int pr_sc_binary_state(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, int
     fprintf(stderr, "pr_sc_binary_state: queries {nonbinary %d, max ones %d, eps %.3g} db {nonbinary %d, max ones %d, eps %.3g} bound %.4g x %.1f\n",
             hq[0], hq[1], eq, hd[0], hd[1], ed, bound, std::sqrt((float)hq[1] * (float)hd[1]));
   *state = (hq[0] == 0 && hd[0] == 0 && bound * std::sqrt((float)hq[1] * (float)hd[1]) < 0.72f) ? 1 : 0;
-  if (*state) {      // ... and what the last call's rounding tests said (the flag lives until the next call's channel-0 launch)
+  if (*state) {      // ... and what the last call's rounding tests said (the word lives until the next call's channel-0 launch clears it)
     int viol = 0;
     PR_HIP(ctx, hipMemcpyAsync(&viol, ctx->d_flags + 4, sizeof viol, hipMemcpyDeviceToHost, ctx->stream));
     PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (viol == ctx->bin_gen && viol != 0) *state = 2;
+    if (viol != 0) *state = 2;                 // (the channel-0 launch of every call clears the word)
   }
   return PR_OK;
 }
@@ -1066,6 +1085,7 @@ int pr_merge_topk_dev(pr_ctx* ctx, const int32_t* idx_all, const double* score_a
 static int f16_fallback(pr_ctx* ctx, const double* hq_sc, const double* hq_m2, const void* ddb_sc, const void* ddb_m2, int32_t m, int32_t n,
                         int32_t mask_width, double p_weight, int32_t k, const double* mom_sc, const double* mom_m2, int32_t kin,
                         const double* cand_sc, int32_t* dcand, double* dsc64) {
+  DevScope scope_(ctx);
   DevBuf dflags, dcount;
   if (dflags.alloc((size_t)m * 4) != hipSuccess || dcount.alloc(4) != hipSuccess) PR_FAIL(ctx, PR_ENOMEM, "out of device memory");
   if (int rc = pr_f16_margin_dev(ctx, mom_sc, mom_m2, m, 1, p_weight, kin, cand_sc, k, dsc64, dflags.as<int32_t>(), dcount.as<int32_t>())) return rc;
@@ -1157,6 +1177,7 @@ static int distance_host(pr_ctx* ctx, int type, const double* h1, int32_t m, con
   pr_sigset *q = nullptr, *d = nullptr;
   int rc = pr_sigset_create(ctx, type, PR_ROLE_QUERY, m, &q);
   if (rc == PR_OK) rc = pr_sigset_create(ctx, type, PR_ROLE_DB, n, &d);
+  DevScope scope_(ctx);
   DevBuf raw1, raw2, dp, di, mom, didx, dsc, dsc64, dcand;
   do {
     if (rc) break;
@@ -1280,6 +1301,7 @@ static int fused_host(pr_ctx* ctx, const double* sc1, const double* m2dp1, int32
   if (m == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
   pr_sigset* ss[4] = {nullptr, nullptr, nullptr, nullptr};   // SC query, SC db, M2DP query, M2DP db
+  DevScope scope_(ctx);
   DevBuf raw[4], d[4], mom[2], didx, dsc, dcand, dsc64, dsw;
   const void* host[4] = {sc1, sc2, m2dp1, m2dp2};
   const size_t bytes[4] = {(size_t)m * 2400 * 8, (size_t)n * 2400 * 8, (size_t)m * 4 * 384 * 8, (size_t)n * 4 * 384 * 8};
@@ -1352,6 +1374,7 @@ static int plain_cols_host(pr_ctx* ctx, int type, const double* h1, int32_t m, c
   if (int rc = set_device(ctx)) return rc;
   const size_t rows1 = (type == PR_TYPE_BOW ? 2 : 1) * (size_t)m, rows2 = (type == PR_TYPE_BOW ? 2 : 1) * (size_t)n;
   const size_t mn = (size_t)m * n;
+  DevScope scope_(ctx);
   DevBuf d1, d2, dd, didx, dsc;
   if (d1.alloc(rows1 * cols * 8) != hipSuccess || d2.alloc(rows2 * cols * 8) != hipSuccess || dd.alloc(mn * 4) != hipSuccess)
     PR_FAIL(ctx, PR_ENOMEM, "out of device memory for %d x %d %s signatures", m, n, type == PR_TYPE_BOW ? "BoW" : "GIST");
@@ -1457,6 +1480,7 @@ int pr_sc_generate_frames_dev(pr_ctx* ctx, const double* xyz, const float* inten
     PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return PR_OK;
   }
+  DevScope scope_(ctx);
   DevBuf ave;
   PR_HIP(ctx, ave.alloc((size_t)N * 4));
   // the binning pass writes bin means and does not wait for the average chain beside it; sc_finish applies the averages
@@ -1473,6 +1497,7 @@ int pr_sc_generate_dev(pr_ctx* ctx, const double* xyz, const float* inten, const
   if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
   if (N == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
+  DevScope scope_(ctx);
   DevBuf frames, ave;
   PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
   PR_HIP(ctx, ave.alloc((size_t)N * 4));
@@ -1565,6 +1590,7 @@ static int m2dp_generate_impl(pr_ctx* ctx, const double* xyz, const float* inten
   if (int rc = check_gen_args(ctx, xyz, inten, offs, N, max_rho, out)) return rc;
   if (N == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
+  DevScope scope_(ctx);
   DevBuf frames, ave, mats;
   if (!frames_in) PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
   const bool own_ave = !(frames_in && frames_have_ave);
@@ -1617,6 +1643,7 @@ static int delight_generate_impl(pr_ctx* ctx, const double* xyz, const float* in
   if (int rc = check_gen_args(ctx, xyz, inten, offs, N, 1.0, out)) return rc;
   if (N == 0) return PR_OK;
   if (int rc = set_device(ctx)) return rc;
+  DevScope scope_(ctx);
   DevBuf frames;
   if (!frames_in) {
     PR_HIP(ctx, frames.alloc((size_t)N * 16 * 8));
@@ -1639,6 +1666,7 @@ static int generate_host(pr_ctx* ctx, int type, const double* xyz, const float* 
   if (T > 0 && (!xyz || !inten)) PR_FAIL(ctx, PR_EINVAL, "generate: xyz/inten are NULL");
   if (int rc = set_device(ctx)) return rc;
   const size_t rowlen = (type == PR_TYPE_SC) ? PR_SC_SIG_LEN : (type == PR_TYPE_M2DP ? (size_t)4 * PR_M2DP_SIG_LEN : (size_t)16 * PR_DELIGHT_SIG_LEN);
+  DevScope scope_(ctx);
   DevBuf dx, di, dof, dout;
   PR_HIP(ctx, dx.alloc(T * 24));
   PR_HIP(ctx, di.alloc(T * 4));
@@ -1682,6 +1710,7 @@ int pr_generate_clouds(pr_ctx* ctx, int type, const pr_clouds* c, double max_rho
   if (N > 0 && !out) PR_FAIL(ctx, PR_EINVAL, "pr_generate_clouds: out is NULL");
   if (int rc = set_device(ctx)) return rc;
   const size_t rowlen = (type == PR_TYPE_SC) ? PR_SC_SIG_LEN : (type == PR_TYPE_M2DP ? (size_t)4 * PR_M2DP_SIG_LEN : (size_t)16 * PR_DELIGHT_SIG_LEN);
+  DevScope scope_(ctx);
   DevBuf dout;
   PR_HIP(ctx, dout.alloc((size_t)N * rowlen * 8));
   const double* x = static_cast<const double*>(c->d_xyz);

@@ -320,6 +320,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   extern __shared__ __attribute__((aligned(16))) char lds[];
   static_assert(!SV || !LO, "SV: single-product form");
   float bbound = 0.f;
+  // the channel-0 launch of a binary-channel call clears the violation word the two channel-1 launches behind it speak through: `gen` is a
+  // kernel argument, i.e. frozen inside a captured hipGraph - without this a replay that once failed a pair would keep finding its own
+  // value there and redo channel 1 in split-f16 for ever
+  if (bin.gate == 0 && bin.chsel == 0 && bin.viol && blockIdx.x == 0 && threadIdx.x == 0) *bin.viol = 0;
   if (bin.gate) {      // (workgroup-uniform: scalar loads of six numbers per set)
     const bool pred = sc_bin_bound(bin, bbound);
     if (bin.gate == 1 ? !pred : (pred && *bin.viol != bin.gen)) return;      // gate 2: the split-f16 kernel behind the single-product one

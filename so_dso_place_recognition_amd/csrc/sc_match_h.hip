@@ -188,6 +188,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   extern __shared__ __attribute__((aligned(16))) char lds[];
   // binary-channel launches (kernels.hpp: ScBin; sc_match_e.hip): gate 2 = the split-f16 pass of channel 1 behind the single-product one -
   // it runs when that one did not (the bound rules it out) or a pair failed its rounding test (the flag word carries this call's number)
+  if (bin.gate == 0 && bin.chsel == 0 && bin.viol && blockIdx.x == 0 && threadIdx.x == 0) *bin.viol = 0;   // (channel-0 launch of a binary-channel call: see sc_match_e_kernel)
   if (bin.gate == 2) {
     float bound;
     if (sc_bin_bound(bin, bound) && *bin.viol != bin.gen) return;
