@@ -191,6 +191,267 @@ __global__ __launch_bounds__(256) void xrow_valu_kernel(XrowArgs A) {
   xrow_finish(A, s_list, ns, total, red, tid);
 }
 
+// ---- the same rows through the sector spectra (the factorisation of sc_match*.hip, here in fp64 on the vector ALUs: gfx950's
+// v_mfma_f64_16x16x4 issues every ~156 cycles = 32 TFLOP/s, v_fma_f64 does 78 - tools/ubench/mfma_f64_rate.hip).  With X_r(f) the DFT over the
+// 60 sectors of ring r (f = 0 .. 30) and Q conj(D) = (ac + bd) + i (bc - ad) =: P + i R, Q D = (ac - bd) + i (ad + bc) =: P' + i R' summed
+// over the 20 rings, the 120 variant products of processSC.m:24-30 are
+//     forward  k: sum_f w_f/60 (P cos(th_f k) - R sin(th_f k)),    mirrored k: the same with (P', R'),    th_f = 2 pi f / 60, w_0 = w_30 = 1, else 2
+// and the values at 60 - k come with the sine sums negated: E = sum w P cos, O = sum w R sin for k = 0 .. 30 give E - O and E + O.
+// 6.3 k multiply-adds per pair and channel instead of 144 k, + 38 k per DB entry and channel for its spectra (once per pass: a workgroup
+// takes a tile of XE entries, transforms it into LDS and walks the pass's slots over it).  Distances agree with the direct form to ~1e-15.
+constexpr int XE = 8;                         // entries per tile
+constexpr int XQ = 20 * 62;                   // doubles of one (slot, channel) query spectrum: [ring][f]{a, b}, scaled by w_f / (60 |q|)
+constexpr size_t XROW_SC_LDS = ((size_t)XE * XQ + XQ + XE * 32 * 4 + XE * 32 + 160 + XE + XE + RESOLVE_SLOTS * 2 * 3 + RESOLVE_SLOTS * 2) * 8;
+
+// query spectra of the pass's slots: qspec [slot][ch][ring][f]{re, im} x w_f / (60 |q_ch|)   (grid: slots x 2)
+__global__ __launch_bounds__(256) void xrow_qspec_kernel(XrowArgs A, const double* __restrict__ tw, double* __restrict__ qspec) {
+  __shared__ double x[20][61];
+  __shared__ double red[256];
+  __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
+  const int s = blockIdx.x, ch = blockIdx.y, tid = threadIdx.x;
+  const int total = flagged_slots(A.flags, A.m, A.list, A.cnt, A.offset, s_list, s_tmp, tid, 256);
+  if (A.offset + s >= total) return;
+  const int q = s_list[s];
+  double ssq = 0.0;
+  for (int i = tid; i < 1200; i += 256) {                       // bin = sector * 20 + ring (SC.cpp:39)
+    const double v = ld(A.q_sc, A.sc_dt, (size_t)q * 2400 + ch * 1200 + i);
+    x[i % 20][i / 20] = v;
+    ssq += v * v;
+  }
+  const double nq = sqrt(block_sum256(ssq, red, tid));         // (its barriers also publish x)
+  for (int it = tid; it < 20 * 31; it += 256) {
+    const int r = it / 31, f = it % 31;
+    double re = 0.0, im = 0.0;
+    int t = 0;
+    for (int sct = 0; sct < 60; sct++) {
+      re += x[r][sct] * tw[t];
+      im -= x[r][sct] * tw[60 + t];
+      t += f; if (t >= 60) t -= 60;
+    }
+    const double sc = ((f == 0 || f == 30) ? 1.0 : 2.0) / (60.0 * nq);      // |q| = 0: inf -> NaN spectra -> NaN distances (processSC.m:16)
+    double* o = qspec + (((size_t)s * 2 + ch) * 20 + r) * 62 + 2 * f;
+    o[0] = re * sc; o[1] = im * sc;
+  }
+}
+
+template <typename T>
+__device__ __forceinline__ void xrow_dft_row(const T* __restrict__ px /* element (ring, sector 0); sectors 20 apart */, const double* __restrict__ twsf,
+                                             double* __restrict__ out /* [31][2] */, double& ssq) {
+  double x[60];
+#pragma unroll
+  for (int sct = 0; sct < 60; sct++) x[sct] = (double)px[sct * 20];
+  double re[31], im[31];
+  ssq = 0.0;
+#pragma unroll
+  for (int sct = 0; sct < 60; sct++) ssq += x[sct] * x[sct];
+#pragma unroll
+  for (int f = 0; f < 31; f++) { re[f] = (f & 1) ? x[0] - x[30] : x[0] + x[30]; im[f] = 0.0; }
+#pragma unroll
+  for (int sct = 1; sct < 30; sct++) {                         // sectors s and 60 - s share their cosine, and their sines are opposite
+    const double xe = x[sct] + x[60 - sct], xo = x[sct] - x[60 - sct];   // (fully unrolled: x[] stays in registers, the twiddles are scalar loads
+    const double* c = twsf + (size_t)sct * 62;                   //  at constant offsets)
+#pragma unroll
+    for (int f = 0; f < 31; f++) { re[f] += xe * c[2 * f]; im[f] -= xo * c[2 * f + 1]; }
+  }
+#pragma unroll
+  for (int f = 0; f < 31; f++) { out[2 * f] = re[f]; out[2 * f + 1] = im[f]; }
+}
+
+// rows + moment partials of the SC channels; `finish`: this launch is the pass's last rows kernel (its last workgroup turns the partials
+// of all four channels into the exact moments)
+__global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* __restrict__ qspec, const double* __restrict__ tw,
+                                                       const double* __restrict__ twsf, int finish) {
+  extern __shared__ __attribute__((aligned(16))) double xl[];
+  double* spec = xl;                                            // [XE][20][31][2]
+  double* qs = spec + (size_t)XE * XQ;                          // [20][31][2]
+  double* ssum = qs + XQ;                                       // [XE][32][4] (P, R, P', R')
+  double* dmax = ssum + XE * 32 * 4;                            // [XE][32]
+  double* part = dmax + XE * 32;                                // [160]
+  double* rnd = part + 160;                                     // [XE] 1 / |d|
+  double* dval = rnd + XE;                                      // [XE]
+  double* acc = dval + XE;                                      // [RESOLVE_SLOTS][2][3]
+  double* piv = acc + RESOLVE_SLOTS * 2 * 3;                    // [RESOLVE_SLOTS][2]
+  __shared__ double red[256];
+  __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
+  const int tid = threadIdx.x, b = blockIdx.x, n = A.n_local;
+  const int total = flagged_slots(A.flags, A.m, A.list, A.cnt, A.offset, s_list, s_tmp, tid, 256);
+  const int ns = total - A.offset < RESOLVE_SLOTS ? total - A.offset : RESOLVE_SLOTS;
+  if (ns <= 0) return;                                          // nothing flagged: the usual case
+  for (int i = tid; i < ns * 6; i += 256) acc[i] = 0.0;
+  for (int i = tid; i < ns * 2; i += 256) piv[i] = pivot_of(A.mom_sc, A.G, A.m, s_list[i >> 1], i & 1);
+  // stage-2 constants of this thread: (entry e1, shift k) = (tid / 31, tid % 31)
+  const int e1 = tid / 31, k1 = tid % 31;
+  double ck[31], sk[31];
+  {
+    int t = 0;
+#pragma unroll
+    for (int f = 0; f < 31; f++) { ck[f] = tw[t]; sk[f] = tw[60 + t]; t += k1; if (t >= 60) t -= 60; }
+  }
+  const int ntile = (n + XE - 1) / XE;
+  for (int tile = b; tile < ntile; tile += A.NB) {
+    const int j0 = tile * XE, ne = n - j0 < XE ? n - j0 : XE;
+    for (int ch = 0; ch < 2; ch++) {
+      __syncthreads();                                          // the previous tile's readers of spec / rnd are done
+      if (tid < 160) {
+        const int e = tid / 20, r = tid % 20;
+        double ssq = 0.0;
+        double* out = spec + (size_t)tid * 62;
+        if (e < ne) {
+          const size_t off = (size_t)(j0 + e) * 2400 + ch * 1200 + r;
+          if (A.sc_dt == 0) xrow_dft_row(static_cast<const double*>(A.db_sc) + off, twsf, out, ssq);
+          else xrow_dft_row(static_cast<const float*>(A.db_sc) + off, twsf, out, ssq);
+        } else {
+          for (int i = 0; i < 62; i++) out[i] = 0.0;
+        }
+        part[tid] = ssq;
+      }
+      __syncthreads();
+      if (tid < XE) {
+        double sum = 0.0;
+        for (int r = 0; r < 20; r++) sum += part[tid * 20 + r];
+        rnd[tid] = 1.0 / sqrt(sum);                              // |d| = 0: inf, and inf x 0 = NaN below (processSC.m:19)
+      }
+      for (int s = 0; s < ns; s++) {
+        const double* qg = qspec + ((size_t)s * 2 + ch) * XQ;
+        for (int i = tid; i < XQ; i += 256) qs[i] = qg[i];
+        __syncthreads();
+        if (tid < 248) {                                         // stage 1: thread (entry e1, frequency k1): the four ring sums
+          double ac = 0.0, bd = 0.0, bc = 0.0, ad = 0.0;
+          const double* qp = qs + 2 * k1;
+          const double* dp = spec + (size_t)e1 * XQ + 2 * k1;
+#pragma unroll
+          for (int r = 0; r < 20; r++) {
+            const double a = qp[r * 62], bq = qp[r * 62 + 1], c = dp[r * 62], d = dp[r * 62 + 1];
+            ac += a * c; bd += bq * d; bc += bq * c; ad += a * d;
+          }
+          double* o = ssum + ((size_t)e1 * 32 + k1) * 4;
+          o[0] = ac + bd; o[1] = bc - ad; o[2] = ac - bd; o[3] = ad + bc;
+        }
+        __syncthreads();
+        if (tid < 248) {                                         // stage 2: thread (entry e1, shift k1)
+          double E1 = 0.0, O1 = 0.0, E2 = 0.0, O2 = 0.0;
+          const double* sp = ssum + (size_t)e1 * 32 * 4;
+#pragma unroll
+          for (int f = 0; f < 31; f++) {
+            E1 += sp[4 * f] * ck[f]; O1 += sp[4 * f + 1] * sk[f]; E2 += sp[4 * f + 2] * ck[f]; O2 += sp[4 * f + 3] * sk[f];
+          }
+          dmax[e1 * 32 + k1] = fmax(fmax(E1 - O1, E1 + O1), fmax(E2 - O2, E2 + O2));
+        }
+        __syncthreads();
+        if (tid < XE) {
+          double mm = dmax[tid * 32];
+          for (int k = 1; k < 31; k++) mm = fmax(mm, dmax[tid * 32 + k]);
+          const double d = (1.0 - mm * rnd[tid]) / 2.0;          // processSC.m:30-31 (a zero-norm row on either side: NaN)
+          dval[tid] = d;
+          if (tid < ne) A.rows[((size_t)s * 4 + ch) * n + j0 + tid] = d;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          const double K = piv[s * 2 + ch];
+          double* a3 = acc + (s * 2 + ch) * 3;
+          for (int e = 0; e < ne; e++) {
+            const double d = dval[e];
+            if (d == d) { const double xd = d - K; a3[0] += 1.0; a3[1] += xd; a3[2] += xd * xd; }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < ns * 6; i += 256) {
+    const int s = i / 6, c = (i % 6) / 3, e = i % 3;
+    A.partial[(((size_t)s * A.NB + b) * 4 + c) * 3 + e] = acc[i];
+  }
+  if (!A.q_m2) for (int i = tid; i < ns * 6; i += 256) A.partial[(((size_t)(i / 6) * A.NB + b) * 4 + 2 + (i % 6) / 3) * 3 + i % 3] = 0.0;
+  if (!finish) return;
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_tmp[5] = (atomicAdd(A.tick, 1u) == (unsigned)gridDim.x - 1u) ? 1 : 0;
+  __syncthreads();
+  if (!s_tmp[5]) return;
+  __threadfence();
+  xrow_finish(A, s_list, ns, total, red, tid);
+}
+
+// processM2DP.m:12-22 for the pass's slots over tiles of XE entries: the 4 x 4 row products of a (slot, entry) pair per channel,
+// thread = (entry, 2 query rows, 2 entry rows, an eighth of the 192 columns)
+constexpr size_t XROW_M2_LDS = ((size_t)XE * 4 * 192 + 4 * 192 + XE + RESOLVE_SLOTS * 2 * 3 + RESOLVE_SLOTS * 2) * 8;
+__global__ __launch_bounds__(256) void xrow_m2dp_kernel(XrowArgs A, int sc_too) {
+  extern __shared__ __attribute__((aligned(16))) double xl[];
+  double* dr = xl;                                              // [XE][4][192]
+  double* qr = dr + (size_t)XE * 4 * 192;                       // [4][192]
+  double* dval = qr + 4 * 192;                                  // [XE]
+  double* acc = dval + XE;                                      // [RESOLVE_SLOTS][2][3]
+  double* piv = acc + RESOLVE_SLOTS * 2 * 3;                    // [RESOLVE_SLOTS][2]
+  __shared__ double red[256];
+  __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
+  const int tid = threadIdx.x, b = blockIdx.x, n = A.n_local;
+  const int total = flagged_slots(A.flags, A.m, A.list, A.cnt, A.offset, s_list, s_tmp, tid, 256);
+  const int ns = total - A.offset < RESOLVE_SLOTS ? total - A.offset : RESOLVE_SLOTS;
+  if (ns <= 0) return;
+  for (int i = tid; i < ns * 6; i += 256) acc[i] = 0.0;
+  for (int i = tid; i < ns * 2; i += 256) piv[i] = pivot_of(A.mom_m2, A.G, A.m, s_list[i >> 1], i & 1);
+  const int cp = tid & 7, bb = (tid >> 3) & 1, ab = (tid >> 4) & 1, e = tid >> 5;
+  const int ntile = (n + XE - 1) / XE;
+  for (int tile = b; tile < ntile; tile += A.NB) {
+    const int j0 = tile * XE, ne = n - j0 < XE ? n - j0 : XE;
+    for (int ch = 0; ch < 2; ch++) {
+      __syncthreads();
+      for (int i = tid; i < XE * 4 * 192; i += 256) {
+        const int ee = i / (4 * 192), rr = (i / 192) & 3, c = i % 192;
+        dr[i] = ee < ne ? ld(A.db_m2, A.m2_dt, ((size_t)(j0 + ee) * 4 + rr) * 384 + ch * 192 + c) : 0.0;
+      }
+      for (int s = 0; s < ns; s++) {
+        const int q = s_list[s];
+        __syncthreads();                                        // (also: the tile is in place, the previous slot's readers of qr are done)
+        for (int i = tid; i < 4 * 192; i += 256) qr[i] = ld(A.q_m2, A.m2_dt, ((size_t)q * 4 + i / 192) * 384 + ch * 192 + i % 192);
+        __syncthreads();
+        double d00 = 0.0, d01 = 0.0, d10 = 0.0, d11 = 0.0;
+        const double* q0 = qr + (2 * ab) * 192 + cp * 24;
+        const double* d0 = dr + ((size_t)e * 4 + 2 * bb) * 192 + cp * 24;
+#pragma unroll
+        for (int c = 0; c < 24; c++) {
+          const double qa = q0[c], qb = q0[192 + c], da = d0[c], db = d0[192 + c];
+          d00 += qa * da; d01 += qa * db; d10 += qb * da; d11 += qb * db;
+        }
+#pragma unroll
+        for (int sft = 1; sft < 8; sft <<= 1) {                  // the eight column parts: an xor butterfly (all lanes end with the same sums)
+          d00 += __shfl_xor(d00, sft, 64); d01 += __shfl_xor(d01, sft, 64); d10 += __shfl_xor(d10, sft, 64); d11 += __shfl_xor(d11, sft, 64);
+        }
+        double mn = nanmin(nanmin((1.0 - d00) / 2.0, (1.0 - d01) / 2.0), nanmin((1.0 - d10) / 2.0, (1.0 - d11) / 2.0));   // processM2DP.m:15,19
+        mn = nanmin(mn, __shfl_xor(mn, 8, 64));
+        mn = nanmin(mn, __shfl_xor(mn, 16, 64));
+        if ((tid & 31) == 0) {
+          dval[e] = mn;
+          if (e < ne) A.rows[((size_t)s * 4 + 2 + ch) * n + j0 + e] = mn;
+        }
+        __syncthreads();
+        if (tid == 0) {
+          const double K = piv[s * 2 + ch];
+          double* a3 = acc + (s * 2 + ch) * 3;
+          for (int ee = 0; ee < ne; ee++) {
+            const double d = dval[ee];
+            if (d == d) { const double xd = d - K; a3[0] += 1.0; a3[1] += xd; a3[2] += xd * xd; }
+          }
+        }
+      }
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < ns * 6; i += 256) {
+    const int s = i / 6, c = (i % 6) / 3, e3 = i % 3;
+    A.partial[(((size_t)s * A.NB + b) * 4 + 2 + c) * 3 + e3] = acc[i];
+    if (!sc_too) A.partial[(((size_t)s * A.NB + b) * 4 + c) * 3 + e3] = 0.0;
+  }
+  __threadfence();
+  __syncthreads();
+  if (tid == 0) s_tmp[5] = (atomicAdd(A.tick, 1u) == (unsigned)gridDim.x - 1u) ? 1 : 0;
+  __syncthreads();
+  if (!s_tmp[5]) return;
+  __threadfence();
+  xrow_finish(A, s_list, ns, total, red, tid);
+}
+
 struct SelArgs {
   const int32_t* flags; const int32_t* list; const int32_t* cnt; int offset;
   const double* exact_all; int G, m, n_local;                   // [G][m][4][3] the shards' exact moments (G = 1: this context's own)
@@ -321,15 +582,34 @@ void launch_flag_compact(hipStream_t st, const int32_t* flags, int m, int32_t* l
   hipLaunchKernelGGL(flag_compact_kernel, dim3(1), dim3(256), 0, st, flags, m, list, cnt);
 }
 
+size_t xrow_qspec_doubles() { return (size_t)RESOLVE_SLOTS * 2 * XQ; }
+
 void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                  const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* flags, int32_t* list, int32_t* cnt,
-                 int offset, bool compacted, double* partial, double* exact, double* rows, unsigned* tick, int* dflags) {
+                 int offset, bool compacted, double* partial, double* exact, double* rows, unsigned* tick, int* dflags, double* qspec,
+                 const double* tw, const double* twsf, int direct) {
   if (m <= 0 || n_local <= 0) return;
   const int32_t* fl = compacted ? nullptr : resolve_list(st, flags, m, list, cnt);
-  int NB = exact_partial_blocks(n_local);
-  if (m <= 64 && NB > 256) NB = 256;      // an online call pays for the launch every time and for the resolution once in 10^5 calls: a small grid
+  if (direct) {                            // PR_XROW=direct: the reference's own formulation (the cross-check of the spectral form)
+    int NB = exact_partial_blocks(n_local);
+    if (m <= 64 && NB > 256) NB = 256;      // an online call pays for the launch every time and for the resolution once in 10^5 calls: a small grid
+    XrowArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, fl, list, cnt, offset, NB, partial, exact, rows, tick, dflags};
+    hipLaunchKernelGGL(xrow_valu_kernel, dim3(NB), dim3(256), 0, st, A);
+    return;
+  }
+  const int ntile = (n_local + XE - 1) / XE;
+  const int NB = ntile < 256 ? ntile : 256;                     // one workgroup per CU (its LDS), each walking tiles b, b + NB, ...
   XrowArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, fl, list, cnt, offset, NB, partial, exact, rows, tick, dflags};
-  hipLaunchKernelGGL(xrow_valu_kernel, dim3(NB), dim3(256), 0, st, A);
+  const int slots = m < RESOLVE_SLOTS ? m : RESOLVE_SLOTS;
+  if (q_sc) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_sc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_SC_LDS);
+    hipLaunchKernelGGL(xrow_qspec_kernel, dim3(slots, 2), dim3(256), 0, st, A, tw, qspec);
+    hipLaunchKernelGGL(xrow_sc_kernel, dim3(NB), dim3(256), XROW_SC_LDS, st, A, (const double*)qspec, tw, twsf, q_m2 ? 0 : 1);
+  }
+  if (q_m2) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_m2dp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_M2_LDS);
+    hipLaunchKernelGGL(xrow_m2dp_kernel, dim3(NB), dim3(256), XROW_M2_LDS, st, A, q_sc ? 1 : 0);
+  }
 }
 
 void launch_xrow_select(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G,
