@@ -120,12 +120,22 @@ def via_group(args):
     for _ in range(args.steps):
         idx, sc = g.match_topk(q, 0, 2.0, 1)
     dt = time.perf_counter() - t0
+    g.set_timing(True)                                             # one more step with events between the phases on every shard's stream
+    g.match_topk(q, 0, 2.0, 1)
+    per_rank = []
+    for r, ph in enumerate(g.last_timing()):
+        coll_ms = sum(v for kk, v in ph.items() if kk.startswith("all_gather"))
+        rows = n * (r + 1) // args.gpus - n * r // args.gpus
+        per_rank.append({"rank": r, "db_rows": rows, "shard_fraction": rows / n, "phases_ms": ph, "collective_ms": coll_ms,
+                         "compute_ms": sum(ph.values()) - coll_ms, "matcher_ns_per_pair": 1e6 * ph["distances"] / (m * rows)})
+    g.set_timing(False)
     print(json.dumps({"metric": "queries/sec over 100k-signature DB (SC 20x60, z-score fusion, top-1), through pr_group (C ABI, host query buffers)",
                       "value": m * args.steps / dt, "unit": "queries/s", "n_gpus": args.gpus, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                       "dtype": "f16x2 (fp32 carried as f16 hi + lo, fp32 accumulate)", "data": "synthetic",
                       "collective": {"backend": "rccl (in-process, ncclCommInitAll)" if g.uses_rccl else "device copies", "world": args.gpus,
-                                     "rccl_ranks_seen": g.rccl_ranks},
+                                     "rccl_ranks_seen": g.rccl_ranks, "exchange_selftest": "passed at pr_group_create" if args.gpus > 1 else None},
+                      "per_rank": per_rank, "flagged_queries_last_step": g.last_flagged,
                       "config": {"workload": "sc_match_100k", "db_signatures": n, "queries_per_step": m, "via": "pr_group_match_topk",
                                  "uses_rccl": g.uses_rccl, "note": "DB packed once (pr_group_set_database); queries host -> every GPU per step"},
                       "parity": {"planted_top1_correct": int((idx[:, 0] == planted).sum()), "queries": m}}), flush=True)
@@ -464,6 +474,32 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     kern_ms = [ev.elapsed_ms(a, b) for a, b in evs]
+    # one more step, outside the timed region, with an event after every phase of the protocol on the stream everything runs on (the
+    # library's kernels, torch's copies and RCCL's all-gathers share it): per-rank phase times, gathered to rank 0 below
+    marks = []
+
+    def mark(name):
+        e = ev.create()
+        ev.record(e, stream)
+        marks.append((name, e))
+    barrier()
+    mark("start")
+    mt.pack_database(db)
+    mark("pack(db)")
+    mt.match(q, 0, 2.0, 1, db_row0=lo, force_exchange=args.force_exchange, mark=mark)
+    mark("end")
+    torch.cuda.synchronize()
+    phases = {}
+    for (_, a), (name, b_) in zip(marks[:-1], marks[1:]):
+        phases[name] = phases.get(name, 0.0) + ev.elapsed_ms(a, b_)
+    coll_ms = sum(v for kk, v in phases.items() if kk.startswith("all_gather"))
+    mine_rank = {"rank": rank, "db_rows": hi - lo, "shard_fraction": (hi - lo) / n, "phases_ms": phases, "collective_ms": coll_ms,
+                 "compute_ms": sum(phases.values()) - coll_ms, "step_ms": ev.elapsed_ms(marks[0][1], marks[-1][1]),
+                 "matcher_ns_per_pair": 1e6 * float(np.mean(kern_ms)) / (m * (hi - lo))}
+    per_rank = [mine_rank]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine_rank)
     # per-launch times of the matcher (pr_set_kernel_timing: the library's own events between its launches), outside the timed region
     launch_ms = None
     if arith == "f16x2":
@@ -554,6 +590,9 @@ def main():
                          "dense_equivalent_tflops": pairs * 576000 / (kms_all * 1e-3) / 1e12},
             "parity": {"planted_top1_correct": planted_ok, "queries": m},
             "collective": coll,
+            # one instrumented step per rank (outside the timed region): where a step's time goes on every GPU - compute scales with
+            # shard_fraction (compare matcher_ns_per_pair with the N = 1 line: the kernel's efficiency at the shard's size), the all-gathers do not
+            "per_rank": per_rank,
             "setup_s": gen_s,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -321,6 +321,17 @@ int32_t pr_group_size(const pr_group* g);
 int pr_group_uses_rccl(const pr_group* g);
 int32_t pr_group_rccl_ranks(const pr_group* g);         /* ncclCommCount of the group's communicator (0: the group exchanges by copies) */
 int32_t pr_group_last_flagged(const pr_group* g);       /* queries of the last pr_group_match_topk that were answered from their exact fp64 rows */
+/* Phase times of a call, per shard (bench.py --via-group: what makes the first multi-GPU curve readable).  on != 0: every following
+ * pr_group_match_topk records HIP events on every shard's stream between its phases; pr_group_last_timing waits for the last call's and
+ * fills ms [G][PR_GROUP_PHASES] (cap = floats ms has room for), phases in this order:
+ *   0 upload + pack(queries) | 1 all-pairs distances | 2 row moments | 3 all-gather A (moments) | 4 fp32 selection | 5 all-gather B (candidate
+ *   lists) | 6 merge + fp64 re-evaluation | 7 all-gather C (evaluations) | 8 finish + order / containment checks | 9 exact rows of the flagged
+ *   queries (count read back, then per pass: rows, all-gather D, selection, all-gather E, merge).
+ * pr_group_create itself runs every exchange size of a one-query call on scratch buffers and checks that every rank's slice arrives in its
+ * slot on every device (G > 1): a topology / RCCL problem fails there, with a message, not inside a step. */
+#define PR_GROUP_PHASES 10
+int pr_group_set_timing(pr_group* g, int on);
+int pr_group_last_timing(pr_group* g, float* ms, int32_t cap);
 int pr_group_set_database(pr_group* g, int type, const double* h2, int32_t n);
 int pr_group_take_warnings(pr_group* g);                /* OR of the shards' pr_take_warnings (PR_WARN_* bits), then cleared */
 int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,

@@ -113,6 +113,20 @@ class Group:
         """Ranks the group's RCCL communicator reports (ncclCommCount); 0 when the group exchanges by device copies."""
         return int(self.lib.pr_group_rccl_ranks(self.h))
 
+    PHASES = ("upload+pack(q)", "distances", "moments", "all_gather A (moments)", "select", "all_gather B (candidates)", "merge+rerank",
+              "all_gather C (evaluations)", "finish+checks", "exact rows (flagged queries)")
+
+    def set_timing(self, on: bool):
+        """HIP events between the phases of every following match_topk, on every shard's stream (pr_group_set_timing)."""
+        self._check(self.lib.pr_group_set_timing(self.h, int(bool(on))))
+
+    def last_timing(self):
+        """[{phase: ms}] per shard for the last timed match_topk (pr_group_last_timing)."""
+        G = int(self.lib.pr_group_size(self.h))
+        ms = (C.c_float * (G * len(self.PHASES)))()
+        self._check(self.lib.pr_group_last_timing(self.h, ms, G * len(self.PHASES)))
+        return [{name: float(ms[r * len(self.PHASES) + p]) for p, name in enumerate(self.PHASES)} for r in range(G)]
+
     @property
     def last_flagged(self) -> int:
         """Queries of the last match_topk that were answered from their exact fp64 rows (order / containment checks)."""

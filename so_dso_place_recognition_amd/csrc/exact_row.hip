@@ -201,7 +201,6 @@ __global__ __launch_bounds__(256) void xrow_valu_kernel(XrowArgs A) {
 // takes a tile of XE entries, transforms it into LDS and walks the pass's slots over it).  Distances agree with the direct form to ~1e-15.
 constexpr int XE = 8;                         // entries per tile
 constexpr int XQ = 20 * 62;                   // doubles of one (slot, channel) query spectrum: [ring][f]{a, b}, scaled by w_f / (60 |q|)
-constexpr size_t XROW_SC_LDS = ((size_t)XE * XQ + XQ + XE * 32 * 4 + XE * 32 + 160 + XE + XE + RESOLVE_SLOTS * 2 * 3 + RESOLVE_SLOTS * 2) * 8;
 
 // query spectra of the pass's slots: qspec [slot][ch][ring][f]{re, im} x w_f / (60 |q_ch|)   (grid: slots x 2)
 __global__ __launch_bounds__(256) void xrow_qspec_kernel(XrowArgs A, const double* __restrict__ tw, double* __restrict__ qspec) {
@@ -234,42 +233,62 @@ __global__ __launch_bounds__(256) void xrow_qspec_kernel(XrowArgs A, const doubl
   }
 }
 
+// One ring row of a DB entry -> its 31 sector frequencies.  Sectors s and 60 - s share their cosine and have opposite sines (even / odd
+// parts xe, xo); s and 30 - s then share both up to (-1)^f: even and odd frequencies see different folded inputs, 14 cosine and 14 sine terms each
+// (868 multiply-adds per row instead of 3600).  The row sits in this lane's registers, the twiddles are wave-uniform (scalar loads at constant
+// offsets: the loops are fully unrolled).  twfs: [f = 0 .. 30][s = 1 .. 14]{cos, sin}(2 pi f s / 60).
+__constant__ double g_twfs[31 * 14 * 2];                       // set per device by xrow_set_twiddles (pr_create): constant address space = scalar loads
 template <typename T>
-__device__ __forceinline__ void xrow_dft_row(const T* __restrict__ px /* element (ring, sector 0); sectors 20 apart */, const double* __restrict__ twsf,
+__device__ __forceinline__ void xrow_dft_row(const T* __restrict__ px /* element (ring, sector 0); sectors 20 apart */,
                                              double* __restrict__ out /* [31][2] */, double& ssq) {
+  int tz = 0;
+  asm volatile("" : "+s"(tz));                                  // (an opaque zero in the index keeps the 868 twiddle loads inside the call: hoisted out of the tile loop they spill ~3000 SGPRs)
+  const double* twfs = g_twfs + tz;
   double x[60];
 #pragma unroll
   for (int sct = 0; sct < 60; sct++) x[sct] = (double)px[sct * 20];
-  double re[31], im[31];
   ssq = 0.0;
 #pragma unroll
   for (int sct = 0; sct < 60; sct++) ssq += x[sct] * x[sct];
+  double ce[15], co[15], se[15], so[15];                       // folded inputs of the even / odd frequencies, s = 1 .. 14 (index 0 unused)
 #pragma unroll
-  for (int f = 0; f < 31; f++) { re[f] = (f & 1) ? x[0] - x[30] : x[0] + x[30]; im[f] = 0.0; }
-#pragma unroll
-  for (int sct = 1; sct < 30; sct++) {                         // sectors s and 60 - s share their cosine, and their sines are opposite
-    const double xe = x[sct] + x[60 - sct], xo = x[sct] - x[60 - sct];   // (fully unrolled: x[] stays in registers, the twiddles are scalar loads
-    const double* c = twsf + (size_t)sct * 62;                   //  at constant offsets)
-#pragma unroll
-    for (int f = 0; f < 31; f++) { re[f] += xe * c[2 * f]; im[f] -= xo * c[2 * f + 1]; }
+  for (int sct = 1; sct < 15; sct++) {
+    const double xe1 = x[sct] + x[60 - sct], xe2 = x[30 - sct] + x[30 + sct];
+    const double xo1 = x[sct] - x[60 - sct], xo2 = x[30 - sct] - x[30 + sct];
+    ce[sct] = xe1 + xe2; co[sct] = xe1 - xe2;                    // cos(th f (30 - s)) = (-1)^f cos(th f s)
+    se[sct] = xo1 - xo2; so[sct] = xo1 + xo2;                    // sin(th f (30 - s)) = -(-1)^f sin(th f s)
   }
+  const double xe15 = x[15] + x[45], xo15 = x[15] - x[45];
+  const double r0e = x[0] + x[30], r0o = x[0] - x[30];
 #pragma unroll
-  for (int f = 0; f < 31; f++) { out[2 * f] = re[f]; out[2 * f + 1] = im[f]; }
+  for (int f = 0; f < 31; f++) {
+    // s = 15: cos(pi f / 2), sin(pi f / 2) in {0, +-1}
+    double re = (f & 1) ? r0o : r0e + ((f & 2) ? -xe15 : xe15);
+    double im = (f & 1) ? ((f & 2) ? xo15 : -xo15) : 0.0;        // Im = - sum xo sin: f = 1 (mod 4): -xo15, f = 3 (mod 4): +xo15
+#pragma unroll
+    for (int sct = 1; sct < 15; sct++) {
+      const double c = twfs[(f * 14 + sct - 1) * 2], sn = twfs[(f * 14 + sct - 1) * 2 + 1];
+      re += ((f & 1) ? co[sct] : ce[sct]) * c;
+      im -= ((f & 1) ? so[sct] : se[sct]) * sn;
+    }
+    out[2 * f] = re; out[2 * f + 1] = im;
+  }
 }
 
 // rows + moment partials of the SC channels; `finish`: this launch is the pass's last rows kernel (its last workgroup turns the partials
-// of all four channels into the exact moments)
-__global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* __restrict__ qspec, const double* __restrict__ tw,
-                                                       const double* __restrict__ twsf, int finish) {
+// of all four channels into the exact moments).  Per (tile, channel): 160 lanes transform the tile's rows into LDS; then per slot ONE
+// barrier: stage 1 (thread = entry x frequency: the four ring sums, into one of two buffers) | stage 2 (thread = entry x shift: the four
+// 31-term sums, the maximum over the shifts by lane exchanges) - the next slot's query spectrum is fetched while stage 1 runs.
+constexpr size_t XROW_SC_LDS = ((size_t)XE * XQ + 2 * XQ + 2 * XE * 32 * 4 + RESOLVE_SLOTS * XE + 160 + XE + RESOLVE_SLOTS * 2 * 3 + RESOLVE_SLOTS * 2) * 8;
+__global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* __restrict__ qspec, const double* __restrict__ tw, int finish) {
   extern __shared__ __attribute__((aligned(16))) double xl[];
   double* spec = xl;                                            // [XE][20][31][2]
-  double* qs = spec + (size_t)XE * XQ;                          // [20][31][2]
-  double* ssum = qs + XQ;                                       // [XE][32][4] (P, R, P', R')
-  double* dmax = ssum + XE * 32 * 4;                            // [XE][32]
-  double* part = dmax + XE * 32;                                // [160]
+  double* qs = spec + (size_t)XE * XQ;                          // [2][20][31][2]
+  double* ssum = qs + 2 * XQ;                                   // [2][XE][32][4] (P, R, P', R')
+  double* dtile = ssum + 2 * XE * 32 * 4;                       // [RESOLVE_SLOTS][XE] this (tile, channel)'s distances
+  double* part = dtile + RESOLVE_SLOTS * XE;                    // [160]
   double* rnd = part + 160;                                     // [XE] 1 / |d|
-  double* dval = rnd + XE;                                      // [XE]
-  double* acc = dval + XE;                                      // [RESOLVE_SLOTS][2][3]
+  double* acc = rnd + XE;                                       // [RESOLVE_SLOTS][2][3]
   double* piv = acc + RESOLVE_SLOTS * 2 * 3;                    // [RESOLVE_SLOTS][2]
   __shared__ double red[256];
   __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
@@ -279,8 +298,9 @@ __global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* 
   if (ns <= 0) return;                                          // nothing flagged: the usual case
   for (int i = tid; i < ns * 6; i += 256) acc[i] = 0.0;
   for (int i = tid; i < ns * 2; i += 256) piv[i] = pivot_of(A.mom_sc, A.G, A.m, s_list[i >> 1], i & 1);
-  // stage-2 constants of this thread: (entry e1, shift k) = (tid / 31, tid % 31)
-  const int e1 = tid / 31, k1 = tid % 31;
+  // this thread in the pair stages: entry e1, frequency / shift k1 (lane 31 of a group of 32 repeats shift 0: harmless for the maximum)
+  const int e1 = tid >> 5, k1 = (tid & 31) == 31 ? 0 : (tid & 31);
+  const bool live = (tid & 31) != 31;
   double ck[31], sk[31];
   {
     int t = 0;
@@ -291,15 +311,28 @@ __global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* 
   for (int tile = b; tile < ntile; tile += A.NB) {
     const int j0 = tile * XE, ne = n - j0 < XE ? n - j0 : XE;
     for (int ch = 0; ch < 2; ch++) {
-      __syncthreads();                                          // the previous tile's readers of spec / rnd are done
+      double qn[5];                                              // the next slot's query spectrum on its way to LDS (1240 doubles / 256 threads)
+      auto q_fetch = [&](int s) {
+        const double* qg = qspec + ((size_t)s * 2 + ch) * XQ;
+#pragma unroll
+        for (int u = 0; u < 5; u++) { const int i = tid + 256 * u; qn[u] = i < XQ ? qg[i] : 0.0; }
+      };
+      auto q_store = [&](int s) {
+        double* qd = qs + (size_t)(s & 1) * XQ;
+#pragma unroll
+        for (int u = 0; u < 5; u++) { const int i = tid + 256 * u; if (i < XQ) qd[i] = qn[u]; }
+      };
+      q_fetch(0);
+      __syncthreads();                                          // the previous (tile, channel)'s readers of spec / rnd / dtile / qs are done
+      q_store(0);
       if (tid < 160) {
         const int e = tid / 20, r = tid % 20;
         double ssq = 0.0;
         double* out = spec + (size_t)tid * 62;
         if (e < ne) {
           const size_t off = (size_t)(j0 + e) * 2400 + ch * 1200 + r;
-          if (A.sc_dt == 0) xrow_dft_row(static_cast<const double*>(A.db_sc) + off, twsf, out, ssq);
-          else xrow_dft_row(static_cast<const float*>(A.db_sc) + off, twsf, out, ssq);
+          if (A.sc_dt == 0) xrow_dft_row(static_cast<const double*>(A.db_sc) + off, out, ssq);
+          else xrow_dft_row(static_cast<const float*>(A.db_sc) + off, out, ssq);
         } else {
           for (int i = 0; i < 62; i++) out[i] = 0.0;
         }
@@ -311,49 +344,52 @@ __global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* 
         for (int r = 0; r < 20; r++) sum += part[tid * 20 + r];
         rnd[tid] = 1.0 / sqrt(sum);                              // |d| = 0: inf, and inf x 0 = NaN below (processSC.m:19)
       }
+      // (rnd is read after the first barrier of the slot loop)
       for (int s = 0; s < ns; s++) {
-        const double* qg = qspec + ((size_t)s * 2 + ch) * XQ;
-        for (int i = tid; i < XQ; i += 256) qs[i] = qg[i];
-        __syncthreads();
-        if (tid < 248) {                                         // stage 1: thread (entry e1, frequency k1): the four ring sums
+        if (s + 1 < ns) q_fetch(s + 1);
+        {                                                        // stage 1: the four ring sums of (entry e1, frequency k1)
           double ac = 0.0, bd = 0.0, bc = 0.0, ad = 0.0;
-          const double* qp = qs + 2 * k1;
+          const double* qp = qs + (size_t)(s & 1) * XQ + 2 * k1;
           const double* dp = spec + (size_t)e1 * XQ + 2 * k1;
 #pragma unroll
           for (int r = 0; r < 20; r++) {
             const double a = qp[r * 62], bq = qp[r * 62 + 1], c = dp[r * 62], d = dp[r * 62 + 1];
             ac += a * c; bd += bq * d; bc += bq * c; ad += a * d;
           }
-          double* o = ssum + ((size_t)e1 * 32 + k1) * 4;
-          o[0] = ac + bd; o[1] = bc - ad; o[2] = ac - bd; o[3] = ad + bc;
+          if (live) {
+            double* o = ssum + (size_t)(s & 1) * XE * 32 * 4 + ((size_t)e1 * 32 + k1) * 4;
+            o[0] = ac + bd; o[1] = bc - ad; o[2] = ac - bd; o[3] = ad + bc;
+          }
         }
+        if (s + 1 < ns) q_store(s + 1);
         __syncthreads();
-        if (tid < 248) {                                         // stage 2: thread (entry e1, shift k1)
+        {                                                        // stage 2: the four shift sums of (entry e1, shift k1), then the maximum over the shifts
           double E1 = 0.0, O1 = 0.0, E2 = 0.0, O2 = 0.0;
-          const double* sp = ssum + (size_t)e1 * 32 * 4;
+          const double* sp = ssum + (size_t)(s & 1) * XE * 32 * 4 + (size_t)e1 * 32 * 4;
 #pragma unroll
           for (int f = 0; f < 31; f++) {
             E1 += sp[4 * f] * ck[f]; O1 += sp[4 * f + 1] * sk[f]; E2 += sp[4 * f + 2] * ck[f]; O2 += sp[4 * f + 3] * sk[f];
           }
-          dmax[e1 * 32 + k1] = fmax(fmax(E1 - O1, E1 + O1), fmax(E2 - O2, E2 + O2));
+          double mm = fmax(fmax(E1 - O1, E1 + O1), fmax(E2 - O2, E2 + O2));
+#pragma unroll
+          for (int sft = 16; sft > 0; sft >>= 1) mm = fmax(mm, __shfl_xor(mm, sft, 64));
+          if ((tid & 31) == 0) dtile[s * XE + e1] = (1.0 - mm * rnd[e1]) / 2.0;   // processSC.m:30-31 (a zero-norm row on either side: NaN)
         }
-        __syncthreads();
-        if (tid < XE) {
-          double mm = dmax[tid * 32];
-          for (int k = 1; k < 31; k++) mm = fmax(mm, dmax[tid * 32 + k]);
-          const double d = (1.0 - mm * rnd[tid]) / 2.0;          // processSC.m:30-31 (a zero-norm row on either side: NaN)
-          dval[tid] = d;
-          if (tid < ne) A.rows[((size_t)s * 4 + ch) * n + j0 + tid] = d;
+      }
+      __syncthreads();
+      for (int i = tid; i < ns * XE; i += 256) {
+        const int s = i / XE, e = i % XE;
+        if (e < ne) A.rows[((size_t)s * 4 + ch) * n + j0 + e] = dtile[i];
+      }
+      if (tid < ns) {                                            // slot tid's moments: the tile's entries in order
+        const double K = piv[tid * 2 + ch];
+        double* a3 = acc + (tid * 2 + ch) * 3;
+        double c0 = a3[0], c1 = a3[1], c2 = a3[2];
+        for (int e = 0; e < ne; e++) {
+          const double d = dtile[tid * XE + e];
+          if (d == d) { const double xd = d - K; c0 += 1.0; c1 += xd; c2 += xd * xd; }
         }
-        __syncthreads();
-        if (tid == 0) {
-          const double K = piv[s * 2 + ch];
-          double* a3 = acc + (s * 2 + ch) * 3;
-          for (int e = 0; e < ne; e++) {
-            const double d = dval[e];
-            if (d == d) { const double xd = d - K; a3[0] += 1.0; a3[1] += xd; a3[2] += xd * xd; }
-          }
-        }
+        a3[0] = c0; a3[1] = c1; a3[2] = c2;
       }
     }
   }
@@ -375,13 +411,13 @@ __global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* 
 
 // processM2DP.m:12-22 for the pass's slots over tiles of XE entries: the 4 x 4 row products of a (slot, entry) pair per channel,
 // thread = (entry, 2 query rows, 2 entry rows, an eighth of the 192 columns)
-constexpr size_t XROW_M2_LDS = ((size_t)XE * 4 * 192 + 4 * 192 + XE + RESOLVE_SLOTS * 2 * 3 + RESOLVE_SLOTS * 2) * 8;
+constexpr size_t XROW_M2_LDS = ((size_t)XE * 4 * 192 + 2 * 4 * 192 + RESOLVE_SLOTS * XE + RESOLVE_SLOTS * 2 * 3 + RESOLVE_SLOTS * 2) * 8;
 __global__ __launch_bounds__(256) void xrow_m2dp_kernel(XrowArgs A, int sc_too) {
   extern __shared__ __attribute__((aligned(16))) double xl[];
-  double* dr = xl;                                              // [XE][4][192]
-  double* qr = dr + (size_t)XE * 4 * 192;                       // [4][192]
-  double* dval = qr + 4 * 192;                                  // [XE]
-  double* acc = dval + XE;                                      // [RESOLVE_SLOTS][2][3]
+  double* dr = xl;                                              // [XE][4][192] the tile's rows of this channel
+  double* qr = dr + (size_t)XE * 4 * 192;                       // [2][4][192] a slot's query rows (two buffers: the next slot's arrive while this one is used)
+  double* dtile = qr + 2 * 4 * 192;                             // [RESOLVE_SLOTS][XE] this (tile, channel)'s distances
+  double* acc = dtile + RESOLVE_SLOTS * XE;                     // [RESOLVE_SLOTS][2][3]
   double* piv = acc + RESOLVE_SLOTS * 2 * 3;                    // [RESOLVE_SLOTS][2]
   __shared__ double red[256];
   __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
@@ -396,18 +432,29 @@ __global__ __launch_bounds__(256) void xrow_m2dp_kernel(XrowArgs A, int sc_too) 
   for (int tile = b; tile < ntile; tile += A.NB) {
     const int j0 = tile * XE, ne = n - j0 < XE ? n - j0 : XE;
     for (int ch = 0; ch < 2; ch++) {
-      __syncthreads();
+      double qn[3];                                              // 768 doubles / 256 threads
+      auto q_fetch = [&](int s) {
+        const int q = s_list[s];
+#pragma unroll
+        for (int u = 0; u < 3; u++) { const int i = tid + 256 * u; qn[u] = ld(A.q_m2, A.m2_dt, ((size_t)q * 4 + i / 192) * 384 + ch * 192 + i % 192); }
+      };
+      auto q_store = [&](int s) {
+        double* qd = qr + (size_t)(s & 1) * 4 * 192;
+#pragma unroll
+        for (int u = 0; u < 3; u++) qd[tid + 256 * u] = qn[u];
+      };
+      q_fetch(0);
+      __syncthreads();                                          // the previous (tile, channel)'s readers of dr / qr / dtile are done
+      q_store(0);
       for (int i = tid; i < XE * 4 * 192; i += 256) {
         const int ee = i / (4 * 192), rr = (i / 192) & 3, c = i % 192;
         dr[i] = ee < ne ? ld(A.db_m2, A.m2_dt, ((size_t)(j0 + ee) * 4 + rr) * 384 + ch * 192 + c) : 0.0;
       }
+      __syncthreads();
       for (int s = 0; s < ns; s++) {
-        const int q = s_list[s];
-        __syncthreads();                                        // (also: the tile is in place, the previous slot's readers of qr are done)
-        for (int i = tid; i < 4 * 192; i += 256) qr[i] = ld(A.q_m2, A.m2_dt, ((size_t)q * 4 + i / 192) * 384 + ch * 192 + i % 192);
-        __syncthreads();
+        if (s + 1 < ns) q_fetch(s + 1);
         double d00 = 0.0, d01 = 0.0, d10 = 0.0, d11 = 0.0;
-        const double* q0 = qr + (2 * ab) * 192 + cp * 24;
+        const double* q0 = qr + (size_t)(s & 1) * 4 * 192 + (2 * ab) * 192 + cp * 24;
         const double* d0 = dr + ((size_t)e * 4 + 2 * bb) * 192 + cp * 24;
 #pragma unroll
         for (int c = 0; c < 24; c++) {
@@ -421,19 +468,23 @@ __global__ __launch_bounds__(256) void xrow_m2dp_kernel(XrowArgs A, int sc_too) 
         double mn = nanmin(nanmin((1.0 - d00) / 2.0, (1.0 - d01) / 2.0), nanmin((1.0 - d10) / 2.0, (1.0 - d11) / 2.0));   // processM2DP.m:15,19
         mn = nanmin(mn, __shfl_xor(mn, 8, 64));
         mn = nanmin(mn, __shfl_xor(mn, 16, 64));
-        if ((tid & 31) == 0) {
-          dval[e] = mn;
-          if (e < ne) A.rows[((size_t)s * 4 + 2 + ch) * n + j0 + e] = mn;
-        }
+        if ((tid & 31) == 0) dtile[s * XE + e] = mn;
+        if (s + 1 < ns) q_store(s + 1);
         __syncthreads();
-        if (tid == 0) {
-          const double K = piv[s * 2 + ch];
-          double* a3 = acc + (s * 2 + ch) * 3;
-          for (int ee = 0; ee < ne; ee++) {
-            const double d = dval[ee];
-            if (d == d) { const double xd = d - K; a3[0] += 1.0; a3[1] += xd; a3[2] += xd * xd; }
-          }
+      }
+      for (int i = tid; i < ns * XE; i += 256) {
+        const int s = i / XE, ee = i % XE;
+        if (ee < ne) A.rows[((size_t)s * 4 + 2 + ch) * n + j0 + ee] = dtile[i];
+      }
+      if (tid < ns) {                                            // slot tid's moments: the tile's entries in order
+        const double K = piv[tid * 2 + ch];
+        double* a3 = acc + (tid * 2 + ch) * 3;
+        double c0 = a3[0], c1 = a3[1], c2 = a3[2];
+        for (int ee = 0; ee < ne; ee++) {
+          const double d = dtile[tid * XE + ee];
+          if (d == d) { const double xd = d - K; c0 += 1.0; c1 += xd; c2 += xd * xd; }
         }
+        a3[0] = c0; a3[1] = c1; a3[2] = c2;
       }
     }
   }
@@ -504,11 +555,17 @@ __global__ __launch_bounds__(256) void xrow_select_kernel(SelArgs A) {
   for (int t = 0; t < k; t++) {
     double bv = 0.0;
     int bj = -1;
-    for (int j = tid; j < n; j += 256) {
-      const double f = fused(j);
-      const int jg = A.db_row0 + j;
-      if (f != f || !cand_less(pv, pj, f, jg)) continue;       // NaN, or selected already
-      if (bj < 0 || cand_less(f, jg, bv, bj)) { bv = f; bj = jg; }
+    for (int j4 = tid; j4 < n; j4 += 1024) {                   // four entries per round: their loads are in flight together
+      double f4[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) { const int j = j4 + 256 * u; f4[u] = j < n ? fused(j) : __builtin_nan(""); }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const double f = f4[u];
+        const int jg = A.db_row0 + j4 + 256 * u;
+        if (f != f || !cand_less(pv, pj, f, jg)) continue;     // NaN (or past the end), or selected already
+        if (bj < 0 || cand_less(f, jg, bv, bj)) { bv = f; bj = jg; }
+      }
     }
     rv[tid] = bv; rj[tid] = bj;
     __syncthreads();
@@ -584,10 +641,18 @@ void launch_flag_compact(hipStream_t st, const int32_t* flags, int m, int32_t* l
 
 size_t xrow_qspec_doubles() { return (size_t)RESOLVE_SLOTS * 2 * XQ; }
 
+// the DB-side twiddles [f = 0 .. 30][s = 1 .. 14]{cos, sin}(2 pi f s / 60) into the current device's constant memory (pr_create)
+hipError_t xrow_set_twiddles(const double* cos60, const double* sin60) {
+  double t[31 * 14 * 2];
+  for (int f = 0; f < 31; f++)
+    for (int sct = 1; sct < 15; sct++) { const int i = (f * sct) % 60; t[(f * 14 + sct - 1) * 2] = cos60[i]; t[(f * 14 + sct - 1) * 2 + 1] = sin60[i]; }
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_twfs), t, sizeof t);
+}
+
 void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                  const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* flags, int32_t* list, int32_t* cnt,
                  int offset, bool compacted, double* partial, double* exact, double* rows, unsigned* tick, int* dflags, double* qspec,
-                 const double* tw, const double* twsf, int direct) {
+                 const double* tw, int direct) {
   if (m <= 0 || n_local <= 0) return;
   const int32_t* fl = compacted ? nullptr : resolve_list(st, flags, m, list, cnt);
   if (direct) {                            // PR_XROW=direct: the reference's own formulation (the cross-check of the spectral form)
@@ -604,7 +669,7 @@ void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt,
   if (q_sc) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_sc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_SC_LDS);
     hipLaunchKernelGGL(xrow_qspec_kernel, dim3(slots, 2), dim3(256), 0, st, A, tw, qspec);
-    hipLaunchKernelGGL(xrow_sc_kernel, dim3(NB), dim3(256), XROW_SC_LDS, st, A, (const double*)qspec, tw, twsf, q_m2 ? 0 : 1);
+    hipLaunchKernelGGL(xrow_sc_kernel, dim3(NB), dim3(256), XROW_SC_LDS, st, A, (const double*)qspec, tw, q_m2 ? 0 : 1);
   }
   if (q_m2) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_m2dp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_M2_LDS);

@@ -158,8 +158,9 @@ void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt,
                  const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* flags, int32_t* list, int32_t* cnt,
                  int offset, bool compacted, double* partial, double* exact, double* rows, unsigned* tick, int* dflags,
                  double* qspec /* [xrow_qspec_doubles()] scratch: the slots' query spectra */, const double* tw /* cos | sin of 2 pi t / 60 */,
-                 const double* twsf /* [30][31]{cos, sin} of 2 pi f s / 60 */, int direct /* 1: the reference's own formulation instead of the spectral form */);
+                 int direct /* 1: the reference's own formulation instead of the spectral form */);
 size_t xrow_qspec_doubles();
+hipError_t xrow_set_twiddles(const double* cos60, const double* sin60);   // once per device, before the first launch_xrow (constant memory of exact_row.hip)
 void launch_xrow_select(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G,
                         int m, int n_local, int q_row0, int db_row0, int mask_width, double p_weight, int has_sc, int has_m2, int k,
                         const double* rows, double* sel, int32_t* idx, double* score, double* out_mom_sc, double* out_mom_m2);

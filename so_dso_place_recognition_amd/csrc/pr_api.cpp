@@ -51,7 +51,6 @@ struct pr_ctx {
   double* xrows = nullptr;        // [min(m, RESOLVE_SLOTS)][4][n_local] exact rows of the flagged queries of one pass (exact_row.hip), grow-only
   size_t xrows_cap = 0;
   double* xqspec = nullptr;       // query spectra of one pass's slots (exact_row.hip), allocated with res_partial
-  double* d_twsf = nullptr;       // [30][31]{cos, sin} of 2 pi f s / 60: the DB-side DFT of exact_row.hip
   bool xrow_direct = false;       // PR_XROW=direct: exact rows in the reference's own formulation (tests: cross-check of the spectral form)
   void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16] (sc_match_h.hip)
   int sc_kernel = 2;             // split-f16 SC matcher for m > 8: 2 = sc_match_e.hip (default); PR_SC_KERNEL=h selects sc_match_h.hip (0, round 1; always the kernel for m <= 8)
@@ -228,13 +227,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
         }
     TRY(hipMalloc((void**)&ctx->d_twiddle, sizeof tw));
     TRY(hipMemcpy(ctx->d_twiddle, tw, sizeof tw, hipMemcpyHostToDevice));
-    {
-      std::vector<double> sf((size_t)30 * 62);
-      for (int sct = 0; sct < 30; sct++)
-        for (int f = 0; f < 31; f++) { const int t = (f * sct) % 60; sf[(size_t)sct * 62 + 2 * f] = tw[t]; sf[(size_t)sct * 62 + 2 * f + 1] = tw[60 + t]; }
-      TRY(hipMalloc((void**)&ctx->d_twsf, sf.size() * sizeof(double)));
-      TRY(hipMemcpy(ctx->d_twsf, sf.data(), sf.size() * sizeof(double), hipMemcpyHostToDevice));
-    }
+    TRY(pr::xrow_set_twiddles(tw, tw + 60));
     // stage-2 constants per slot, A operand of v_mfma_f32_32x32x2_f32: lane l -> shift k = l & 31 (k = 31 repeats
     // shift 0, harmless for the max), K index = l >> 5.  Slots (fa, fb) = (0,30), (1,2), ..., (27,28): K = {fa, fb},
     // ce = w_f cos(2 pi f k/60), co = -w_f sin(2 pi f k/60), w_0 = w_30 = 1, else 2.  Slot 15 = frequency 29 alone,
@@ -345,7 +338,6 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->res_exact) (void)hipFree(ctx->res_exact);
   if (ctx->xrows) (void)hipFree(ctx->xrows);
   if (ctx->xqspec) (void)hipFree(ctx->xqspec);
-  if (ctx->d_twsf) (void)hipFree(ctx->d_twsf);
   if (ctx->sel_scratch) (void)hipFree(ctx->sel_scratch);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -924,8 +916,7 @@ static void resolve_pass(pr_ctx* ctx, const void* q_sc, const void* db_sc, int s
                          double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight, int32_t k,
                          int32_t* idx, double* score, int offset, bool compacted, int* dflags) {
   pr::launch_xrow(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, 1, m, n, ctx->d_order, res_list(ctx), res_cnt(ctx),
-                  offset, compacted, ctx->res_partial, ctx->res_exact, ctx->xrows, res_tick(ctx), dflags, ctx->xqspec, ctx->d_twiddle, ctx->d_twsf,
-                  ctx->xrow_direct);
+                  offset, compacted, ctx->res_partial, ctx->res_exact, ctx->xrows, res_tick(ctx), dflags, ctx->xqspec, ctx->d_twiddle, ctx->xrow_direct);
   pr::launch_xrow_select(ctx->stream, ctx->d_order, res_list(ctx), res_cnt(ctx), offset, ctx->res_exact, 1, m, n, q_row0, 0, mask_width, p_weight,
                          q_sc != nullptr, q_m2 != nullptr, k, ctx->xrows, nullptr, idx, score, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr);
 }
@@ -1038,8 +1029,7 @@ int pr_order_exact_moments_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc,
   if (int rc = set_device(ctx)) return rc;
   if (int rc = resolve_scratch(ctx, 0, m, n_local)) return rc;
   pr::launch_xrow(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, G_mom, m, n_local, ctx->d_order, res_list(ctx),
-                  res_cnt(ctx), offset, false, ctx->res_partial, exact, ctx->xrows, res_tick(ctx), ctx->d_flags, ctx->xqspec, ctx->d_twiddle,
-                  ctx->d_twsf, ctx->xrow_direct);
+                  res_cnt(ctx), offset, false, ctx->res_partial, exact, ctx->xrows, res_tick(ctx), ctx->d_flags, ctx->xqspec, ctx->d_twiddle, ctx->xrow_direct);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }

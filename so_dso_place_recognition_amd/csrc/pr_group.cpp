@@ -41,6 +41,9 @@
 
 namespace {
 
+// phases of a pr_group_match_topk call, timed per shard when pr_group_set_timing is on (include/place_recognition.h: PR_GROUP_PHASES)
+enum { PH_PACK = 0, PH_MATCH, PH_MOMENTS, PH_GATHER_A, PH_SELECT, PH_GATHER_B, PH_RERANK, PH_GATHER_C, PH_FINISH, PH_EXACT };
+
 struct Rccl {
   void* h = nullptr;
   ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
@@ -70,6 +73,7 @@ struct Shard {
   pr_ctx* ctx = nullptr;
   hipStream_t stream = nullptr;
   hipEvent_t ev = nullptr, ev_done = nullptr;   // "my slice is ready" / "I have copied every slice" (copy exchange)
+  hipEvent_t ph[PR_GROUP_PHASES + 1] = {};      // pr_group_set_timing: events between the phases of a call
   pr_sigset *q = nullptr, *db = nullptr;
   int32_t row0 = 0, rows = 0;                 // this shard's global DB rows
   void *raw_db = nullptr, *raw_q = nullptr;   // f64 signatures (the re-evaluation reads them)
@@ -92,6 +96,8 @@ struct pr_group {
   int type = -1;
   int32_t n = 0, q_cap = 0, k_cap = 0;
   int32_t last_flagged = 0;        // queries of the last pr_group_match_topk that were answered from their exact rows
+  bool timing = false;             // pr_group_set_timing
+  bool timed = false;              // the last call recorded its phase events
 };
 
 static thread_local std::string g_gerr;
@@ -168,6 +174,46 @@ static int exchange(pr_group* g, std::vector<const void*>& src, std::vector<void
   return PR_OK;
 }
 
+static int exchange_selftest(pr_group* g) {
+  const int G = g->G;
+  const size_t sizes[] = {48, 36, 72, 360, 96, 16, 4096};      // moments | candidate indices | their scores | p5 blocks | exact moments | exact lists of a 1-query call, + a page
+  const size_t maxb = 4096;
+  std::vector<void*> src(G, nullptr), dst(G, nullptr);
+  int rc = PR_OK;
+  for (int r = 0; r < G && rc == PR_OK; r++) {
+    if (hipSetDevice(g->s[r].device) != hipSuccess || hipMalloc(&src[r], maxb) != hipSuccess || hipMalloc(&dst[r], maxb * G) != hipSuccess) {
+      g->err = "pr_group_create: self-test allocation failed"; rc = PR_ENOMEM;
+    }
+  }
+  std::vector<unsigned char> host(maxb * G);
+  for (size_t bytes : sizes) {
+    if (rc != PR_OK) break;
+    for (int r = 0; r < G; r++) {
+      (void)hipSetDevice(g->s[r].device);
+      (void)hipMemsetAsync(src[r], r + 1, bytes, g->s[r].stream);
+      (void)hipMemsetAsync(dst[r], 0xEE, bytes * G, g->s[r].stream);
+    }
+    std::vector<const void*> cs(src.begin(), src.end());
+    if ((rc = exchange(g, cs, dst, bytes)) != PR_OK) break;
+    for (int h = 0; h < G && rc == PR_OK; h++) {
+      (void)hipSetDevice(g->s[h].device);
+      if (hipMemcpyAsync(host.data(), dst[h], bytes * G, hipMemcpyDeviceToHost, g->s[h].stream) != hipSuccess ||
+          hipStreamSynchronize(g->s[h].stream) != hipSuccess) { g->err = "pr_group_create: self-test copy failed"; rc = PR_EHIP; break; }
+      for (int r = 0; r < G && rc == PR_OK; r++)
+        for (size_t i = 0; i < bytes; i++)
+          if (host[(size_t)r * bytes + i] != (unsigned char)(r + 1)) {
+            char b[256];
+            snprintf(b, sizeof b, "pr_group_create: exchange self-test failed (%s, %zu B per rank): device %d (rank %d) holds 0x%02x in rank %d's slot, byte %zu",
+                     g->rccl ? "RCCL all-gather" : "device copies", bytes, g->s[h].device, h, host[(size_t)r * bytes + i], r, i);
+            g->err = b; rc = PR_EHIP;
+            break;
+          }
+    }
+  }
+  for (int r = 0; r < G; r++) { (void)hipSetDevice(g->s[r].device); (void)hipStreamSynchronize(g->s[r].stream); if (src[r]) (void)hipFree(src[r]); if (dst[r]) (void)hipFree(dst[r]); }
+  return rc;
+}
+
 extern "C" {
 
 const char* pr_group_last_error(const pr_group* g) { return g ? g->err.c_str() : g_gerr.c_str(); }
@@ -195,6 +241,7 @@ void pr_group_destroy(pr_group* g) {
     if (sh.raw_db) (void)hipFree(sh.raw_db);
     if (sh.ev) (void)hipEventDestroy(sh.ev);
     if (sh.ev_done) (void)hipEventDestroy(sh.ev_done);
+    for (auto& e : sh.ph) if (e) (void)hipEventDestroy(e);
     pr_destroy(sh.ctx);
   }
   delete g;
@@ -246,7 +293,38 @@ int pr_group_create(const int32_t* device_ids, int32_t G, pr_group** out) {
     }
     (void)hipGetLastError();
   }
+  // self-test of the exchange, before any real step: every rank's slice must arrive in ITS slot on every device, for every payload size the
+  // protocol of a call uses - a topology / RCCL problem fails here with a message instead of inside a step
+  if (G > 1) {
+    const int rc = exchange_selftest(g);
+    if (rc != PR_OK) { g_gerr = g->err; pr_group_destroy(g); return rc; }
+  }
   *out = g;
+  return PR_OK;
+}
+
+int pr_group_set_timing(pr_group* g, int on) {
+  if (!g) return PR_EINVAL;
+  if (on)
+    for (auto& sh : g->s) {
+      G_HIP(g, hipSetDevice(sh.device));
+      for (auto& e : sh.ph) if (!e) G_HIP(g, hipEventCreate(&e));
+    }
+  g->timing = on != 0;
+  g->timed = false;
+  return PR_OK;
+}
+
+int pr_group_last_timing(pr_group* g, float* ms, int32_t cap) {
+  if (!g || !ms) return PR_EINVAL;
+  if (!g->timed) G_FAIL(g, PR_EINVAL, "pr_group_last_timing: no timed pr_group_match_topk call (pr_group_set_timing)");
+  if (cap < g->G * PR_GROUP_PHASES) G_FAIL(g, PR_EINVAL, "pr_group_last_timing: ms needs room for %d x %d floats", g->G, PR_GROUP_PHASES);
+  for (int r = 0; r < g->G; r++) {
+    Shard& sh = g->s[r];
+    G_HIP(g, hipSetDevice(sh.device));
+    G_HIP(g, hipEventSynchronize(sh.ph[PR_GROUP_PHASES]));
+    for (int p = 0; p < PR_GROUP_PHASES; p++) G_HIP(g, hipEventElapsedTime(&ms[r * PR_GROUP_PHASES + p], sh.ph[p], sh.ph[p + 1]));
+  }
   return PR_OK;
 }
 
@@ -318,30 +396,43 @@ static int match_topk_impl(pr_group* g, const double* h1, int32_t m, int32_t mas
     }
     g->q_cap = qc; g->k_cap = kc;
   }
+  g->timed = false;
+  auto mark = [&](int phase_end) -> int {                     // event `phase_end` on every shard's stream: the end of phase phase_end - 1
+    if (!g->timing) return PR_OK;
+    for (auto& sh : g->s) { G_HIP(g, hipSetDevice(sh.device)); G_HIP(g, hipEventRecord(sh.ph[phase_end], sh.stream)); }
+    return PR_OK;
+  };
+  if (int rc = mark(PH_PACK)) return rc;
   // 1. local distances and moments
   for (auto& sh : g->s) {
     G_HIP(g, hipSetDevice(sh.device));
     G_HIP(g, hipMemcpyAsync(sh.raw_q, h1, (size_t)m * row_doubles * 8, hipMemcpyHostToDevice, sh.stream));
     G_PR(g, sh, pr_sigset_pack(sh.ctx, sh.q, sh.raw_q, PR_F64, PR_DEVICE, m));
+    if (g->timing) G_HIP(g, hipEventRecord(sh.ph[PH_MATCH], sh.stream));
     G_PR(g, sh, pr_distances_dev(sh.ctx, sh.q, sh.db, sh.d_p, sh.d_i));
+    if (g->timing) G_HIP(g, hipEventRecord(sh.ph[PH_MOMENTS], sh.stream));
     G_PR(g, sh, pr_row_moments_dev(sh.ctx, sh.d_p, sh.d_i, m, sh.rows, sh.mom));
   }
+  if (int rc = mark(PH_GATHER_A)) return rc;
   std::vector<const void*> src(G);
   std::vector<void*> dst(G);
   // A. moments of every shard on every device
   for (int r = 0; r < G; r++) { src[r] = g->s[r].mom; dst[r] = g->s[r].mom_all; }
   if (int rc = exchange(g, src, dst, (size_t)m * 6 * 8)) return rc;
+  if (int rc = mark(PH_SELECT)) return rc;
   // 2. per-shard fp32 selection with the whole row's statistics
   for (auto& sh : g->s) {
     G_HIP(g, hipSetDevice(sh.device));
     G_PR(g, sh, pr_fuse_select_dev(sh.ctx, sh.d_p, sh.d_i, m, sh.rows, sh.mom_all, G, 0, sh.row0, mask_width, p_weight, kin, sh.idx_in, sh.sc32));
     G_PR(g, sh, pr_widen_scores_dev(sh.ctx, sh.sc32, (int64_t)m * kin, sh.sc64));
   }
+  if (int rc = mark(PH_GATHER_B)) return rc;
   // B. every shard's candidates on every device, merged into the global top-(k+8) of the fp32 pass
   for (int r = 0; r < G; r++) { src[r] = g->s[r].idx_in; dst[r] = g->s[r].idx_all; }
   if (int rc = exchange(g, src, dst, (size_t)m * kin * 4)) return rc;
   for (int r = 0; r < G; r++) { src[r] = g->s[r].sc64; dst[r] = g->s[r].score_all; }
   if (int rc = exchange(g, src, dst, (size_t)m * kin * 8)) return rc;
+  if (int rc = mark(PH_RERANK)) return rc;
   // 3. fp64 re-evaluation of the candidates each shard owns
   for (auto& sh : g->s) {
     G_HIP(g, hipSetDevice(sh.device));
@@ -350,15 +441,18 @@ static int match_topk_impl(pr_group* g, const double* h1, int32_t m, int32_t mas
                                       sc ? nullptr : sh.raw_db, PR_F64, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, m, sh.rows, G, 0,
                                       sh.row0, mask_width, p_weight, kin, sh.cand, sh.dump, k, sh.part));
   }
+  if (int rc = mark(PH_GATHER_C)) return rc;
   // C. every shard's evaluations (p5 blocks) on every device; every device finishes and checks the order of its result
   for (int r = 0; r < G; r++) { src[r] = g->s[r].part; dst[r] = g->s[r].p5_all; }
   if (int rc = exchange(g, src, dst, (size_t)m * 5 * kin * 8)) return rc;
+  if (int rc = mark(PH_FINISH)) return rc;
   // 4. every device finishes (identical inputs: identical results and flags everywhere) ...
   for (auto& sh : g->s) {
     G_HIP(g, hipSetDevice(sh.device));
     G_PR(g, sh, pr_rerank_finish_dev(sh.ctx, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, G, sh.cand, sh.dump, sh.p5_all, G, m, kin, k,
                                      p_weight, sh.idx, sh.score));
   }
+  if (int rc = mark(PH_EXACT)) return rc;
   // ... D + E. and the flagged queries (order not certain under the fp32 pass's sigmas | candidate list not provably complete: none, as a rule)
   // are answered from their exact rows, 64 per pass: this is a synchronous host call, so the count is read back and every pass runs
   int32_t flagged = 0;
@@ -388,6 +482,8 @@ static int match_topk_impl(pr_group* g, const double* h1, int32_t m, int32_t mas
       G_PR(g, sh, pr_order_exact_merge_dev(sh.ctx, sh.sel_all, G, m, k, off, sh.idx, sh.score));
     }
   }
+  if (int rc = mark(PR_GROUP_PHASES)) return rc;
+  g->timed = g->timing;
   Shard& s0 = g->s[0];
   G_HIP(g, hipSetDevice(s0.device));
   G_HIP(g, hipMemcpyAsync(idx, s0.idx, (size_t)m * k * 4, hipMemcpyDeviceToHost, s0.stream));

@@ -296,7 +296,7 @@ class Matcher(_Base):
 
     def match(self, queries: torch.Tensor, mask_width: int = 0, p_weight: float = 2.0, k: int = 1,
               db_row0: int = 0, q_row0: int = 0, group=None, force_exchange: bool = False, f16_fallback: bool = True,
-              exact_order: bool = True):
+              exact_order: bool = True, mark=None):
         """Returns (idx int32 [m,k] GLOBAL DB row indices, score float64 [m,k]) as device tensors.
         force_exchange: run the all-gathers and the merge even with one rank (measures the protocol's overhead).
         exact_order (default): queries whose re-evaluated order is not certain under the fp32 pass's row sigmas, or whose k + 8 candidates
@@ -311,7 +311,7 @@ class Matcher(_Base):
         idx, score = sharded_topk(lambda: self.local_phase1(queries),
                                   lambda mom_all, G_: self.local_select(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
                                   k, group if (G > 1 or force_exchange) else None, G, merge=self.merge, force_exchange=force_exchange,
-                                  rerank=None if self.plain else self.local_rerank, finish=self.finish, post=post, resolve=resolve)
+                                  rerank=None if self.plain else self.local_rerank, finish=self.finish, post=post, resolve=resolve, mark=mark)
         if f16 and f16_fallback:
             def run_rows(rows, qr0):
                 fb = self._split_twin()
@@ -321,6 +321,8 @@ class Matcher(_Base):
             idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
         elif resolve is not None and G == 1 and not force_exchange:
             self._resolve_order(self._raw_args()[:6], *self._moms(), self._m, self.n, q_row0, mask_width, p_weight, k, idx, score)
+            if mark is not None:
+                mark("exact rows (one shard)")
         return idx, score
 
     def take_warnings(self) -> int:
@@ -587,16 +589,22 @@ def _exact_merge_dev(owner, sel_all: torch.Tensor, m: int, k: int, idx, score, o
 
 
 def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None, force_exchange: bool = False, rerank=None, finish=None,
-                 post=None, resolve=None):
+                 post=None, resolve=None, mark=None):
     """The exchange protocol of SURVEY.md §8-e around two local callables (HIP in production; a numpy stand-in in
-    the gloo CPU tests): moments -> all_gather -> select with the moments of all shards -> all_gather -> merge."""
+    the gloo CPU tests): moments -> all_gather -> select with the moments of all shards -> all_gather -> merge.
+    mark (optional): called with a phase name after every phase of the protocol has been ENQUEUED (bench.py records an event on the
+    stream there: the per-rank phase times of a step)."""
     import torch.distributed as dist
+    mark = mark or (lambda name: None)
     mom = local_moments()
+    mark("pack+distances+moments")
     if G == 1 and not force_exchange:
         idx_in, sc = local_select(mom.unsqueeze(0) if mom.dim() == 3 else mom, 1)
+        mark("select")
         if rerank is None:
             return idx_in, sc
         idx, score = rerank(idx_in, k, False, sc)
+        mark("rerank")
         if post is not None:                             # PR_SC_ARITH_F16: margin flags of the candidate list (no synchronisation)
             post(sc, idx, score)
         return idx, score
@@ -611,19 +619,33 @@ def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None,
         return out.view((G,) + tuple(src.shape)).to(t.device)
 
     mom_all = gather(mom)
+    mark("all_gather A (moments)")
     idx_in, sc = local_select(mom_all, G)
+    mark("select")
     kin = idx_in.shape[1]
     idx_all, sc_all = gather(idx_in), gather(sc)
+    mark("all_gather B (candidates)")
     do_merge = merge if (merge is not None and idx_all.is_cuda) else merge_topk
     if rerank is None:                                   # nothing to re-evaluate (numpy stand-ins of the gloo tests, DELIGHT)
         return do_merge(idx_all, sc_all, k)
     cand_idx, cand_sc = do_merge(idx_all, sc_all, kin)   # the global top-(k+8) of the fp32 pass, identical on every rank
-    part_all = gather(rerank(cand_idx, k, True, cand_sc))
+    part = rerank(cand_idx, k, True, cand_sc)
+    mark("merge+rerank")
+    part_all = gather(part)
+    mark("all_gather C (evaluations)")
     idx, score = finish(cand_idx, cand_sc, part_all, k)
+    mark("finish+checks")
     if resolve is not None:                              # step 7: the flagged queries from their exact rows (moments, per-shard k best, merge)
-        exact_all = gather(resolve[0]())
-        sel_all = gather(resolve[1](exact_all, k))
+        ex = resolve[0]()
+        mark("exact rows")
+        exact_all = gather(ex)
+        mark("all_gather D (exact moments)")
+        sel = resolve[1](exact_all, k)
+        mark("exact select")
+        sel_all = gather(sel)
+        mark("all_gather E (exact lists)")
         idx, score = resolve[2](sel_all, k, idx, score)
+        mark("exact merge")
     if post is not None:
         post(cand_sc, idx, score)
     return idx, score

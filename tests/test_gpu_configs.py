@@ -441,9 +441,9 @@ def test_near_copy_clusters_are_answered_from_the_exact_row(api, type_):
         assert set(oidx[t]) <= set(members[t].tolist())              # hair's breadth apart - and distinct
         gaps = np.diff(osc[t])
         assert (gaps > 0).all() and gaps.max() < 1e-4
-    others = np.setdiff1d(np.arange(m), rows)
+    clustered = set(int(planted[t]) for t in rows)                   # (two queries may be planted on the same entry)
+    others = np.array([t for t in range(m) if int(planted[t]) not in clustered])
     dev = torch.device("cuda", 0)
-    rps = 4 if type_ == "m2dp" else 1
     for k in (1, 5):
         for arith in ("f16x2", "f32", "f16"):
             ctx = api.Context(0, sc_arith=arith)
@@ -464,8 +464,8 @@ def test_near_copy_clusters_are_answered_from_the_exact_row(api, type_):
         assert mt.take_warnings() & _lib.WARN_ORDER_RESOLVED
         i1, s1 = i1.cpu().numpy(), s1.cpu().numpy()
         assert np.array_equal(i1, oidx[:, :k]) and np.abs(s1[list(rows)] - osc[list(rows), :k]).max() < 1e-9
-        assert np.array_equal(i0[others], oidx[others, :k])
-        if k == 1:
+        if k == 1:                                                                      # (deeper lists of OTHER queries may hold members of a cluster too)
+            assert np.array_equal(i0[others], oidx[others, :k])
             assert (i0[list(rows), 0] != oidx[list(rows), 0]).sum() >= 3               # ... is wrong for clusters larger than the list
         mt.close()
         g = api.Group([0, 0, 0])
