@@ -496,6 +496,10 @@ def main():
     mine_rank = {"rank": rank, "db_rows": hi - lo, "shard_fraction": (hi - lo) / n, "phases_ms": phases, "collective_ms": coll_ms,
                  "compute_ms": sum(phases.values()) - coll_ms, "step_ms": ev.elapsed_ms(marks[0][1], marks[-1][1]),
                  "matcher_ns_per_pair": 1e6 * float(np.mean(kern_ms)) / (m * (hi - lo))}
+    flagged = None
+    if world == 1 and not args.force_exchange and arith != "f16":   # how many queries of a step the order / containment checks hand to the exact rows
+        mt.match(q, 0, 2.0, 1, db_row0=lo, exact_order=False)
+        flagged = mt.flagged_count()
     per_rank = [mine_rank]
     if world > 1:
         per_rank = [None] * world
@@ -575,7 +579,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "sc_match_100k", "db_signatures": n, "queries_per_step": m, "descriptor": "SC 20x60 x 2 channels",
                        "mask_width": 0, "p_weight": 2.0, "k": 1, "db_rows_per_gpu": hi - lo,
-                       "step": "pack(q)+pack(db)+distances+moments+select(k+8)+fp64 re-evaluation+order check+fp64-statistics resolution of flagged queries"
+                       "step": "pack(q)+pack(db)+distances+moments+select(k+8)+fp64 re-evaluation+order / containment checks+exact fp64 rows of flagged queries"
                                + ("+4 all_gathers+merge" if (world > 1 or args.force_exchange) else "")},
             "roofline": {"kernel": kname, "bound": "mfma", "achieved": ach, "peak": peak,
                          "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
@@ -588,7 +592,7 @@ def main():
                          "fp32_formulation_tflops": pairs * FLOP_PER_PAIR / (kms_all * 1e-3) / 1e12,
                          "fp32_formulation_frac_of_157.3": pairs * FLOP_PER_PAIR / (kms_all * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
                          "dense_equivalent_tflops": pairs * 576000 / (kms_all * 1e-3) / 1e12},
-            "parity": {"planted_top1_correct": planted_ok, "queries": m},
+            "parity": {"planted_top1_correct": planted_ok, "queries": m, "queries_flagged_for_exact_rows": flagged},
             "collective": coll,
             # one instrumented step per rank (outside the timed region): where a step's time goes on every GPU - compute scales with
             # shard_fraction (compare matcher_ns_per_pair with the N = 1 line: the kernel's efficiency at the shard's size), the all-gathers do not

@@ -325,6 +325,15 @@ class Matcher(_Base):
                 mark("exact rows (one shard)")
         return idx, score
 
+    def flagged_count(self) -> int:
+        """Queries the last match(..., exact_order=False) of ONE rank left flagged by the order / containment checks (the ones the default
+        match() answers from their exact rows).  Synchronises (pr_order_flagged_count); 0 once a resolving call has taken the flags."""
+        cnt = C.c_int32(0)
+        self._enter()
+        self.ctx.check(self.lib.pr_order_flagged_count(self.ctx.h, int(self._m if hasattr(self, "_m") else self.sc._m), C.byref(cnt)))
+        self._leave()
+        return int(cnt.value)
+
     def take_warnings(self) -> int:
         """PR_WARN_* bits of the context since the last call (synchronises its stream): WARN_ORDER_RESOLVED after a match() whose order
         needed fp64 row statistics, WARN_ORDER_UNRESOLVED when more than 64 queries of one call did."""
@@ -507,6 +516,7 @@ class FusedMatcher(_Base):
         return idx, score
 
     take_warnings = Matcher.take_warnings
+    flagged_count = Matcher.flagged_count
 
     def _split_twin(self):
         if getattr(self, "_twin", None) is None or self._twin_of is not self.sc.db_sig:

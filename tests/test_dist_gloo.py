@@ -146,6 +146,19 @@ def test_bench_two_ranks_on_one_gpu(tmp_path, arith):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["parity"]["planted_top1_correct"] == 130 and d["scaling"] == "strong"
+    # the per-rank breakdown that makes a multi-GPU curve readable: one entry per rank, every phase of the protocol with its own time,
+    # the all-gathers separated from the compute, the shard's share of the DB and the matcher's time per pair
+    pr_ = d["per_rank"]
+    assert [r["rank"] for r in pr_] == [0, 1] and sum(r["db_rows"] for r in pr_) == 6001
+    for r in pr_:
+        ph = r["phases_ms"]
+        assert {"pack(db)", "pack+distances+moments", "all_gather A (moments)", "select", "all_gather B (candidates)", "merge+rerank",
+                "all_gather C (evaluations)", "finish+checks"} <= set(ph)
+        if arith != "f16":      # (the single-product arithmetic hands its flagged queries to a split-f16 twin instead of the exact-row exchange)
+            assert {"exact rows", "all_gather D (exact moments)", "exact select", "all_gather E (exact lists)", "exact merge"} <= set(ph)
+        assert all(v >= 0 for v in ph.values()) and abs(r["collective_ms"] + r["compute_ms"] - sum(ph.values())) < 1e-6
+        assert 0.49 < r["shard_fraction"] < 0.51 and r["matcher_ns_per_pair"] > 0 and r["step_ms"] >= sum(ph.values()) * 0.99
+    assert d["collective"]["world"] == 2
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--db", "6001",
                           "--queries", "130", "--no-cpu-baseline", "--no-extra", "--sc-arith", arith], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]

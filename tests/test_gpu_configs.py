@@ -419,6 +419,28 @@ def test_order_that_hangs_on_the_row_sigmas_is_resolved_with_fp64_statistics(api
 
 
 @pytest.mark.gpu
+def test_group_selftest_and_phase_timing(api):
+    """pr_group_create runs every exchange of a call on scratch buffers and checks the rank order of what arrives (here: the copy exchange of
+    virtual shards; RCCL on distinct devices); pr_group_set_timing / pr_group_last_timing give every shard's phase times of a call."""
+    n, m = 3000, 40
+    db = synth.sc_database(45, n)
+    q, planted = synth.sc_queries(46, db, m)
+    g = api.Group([0, 0, 0])
+    g.set_database("sc", db)
+    g.set_timing(True)
+    idx, sc = g.match_topk(q, 0, 2.0, 1)
+    assert np.array_equal(idx[:, 0], planted)
+    t = g.last_timing()
+    assert len(t) == 3 and all(set(x) == set(api.Group.PHASES) for x in t)
+    assert all(v >= 0 for x in t for v in x.values()) and all(x["distances"] > 0 for x in t)
+    g.set_timing(False)
+    g.match_topk(q, 0, 2.0, 1)
+    with pytest.raises(api.PRError):
+        g.last_timing()                                        # no timed call since the switch went off
+    g.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("type_", ["sc", "m2dp"])
 def test_near_copy_clusters_are_answered_from_the_exact_row(api, type_):
     """run_test.m:57 takes the minimum over the WHOLE row; the fp64 re-evaluation sees the k + 8 best of an fp32-grade pass.  Forty
