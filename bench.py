@@ -339,10 +339,10 @@ def extra_workloads(dev, ev, args):
     # 47 616 B (one f16 per value); frac_of_8TBps prices the WHOLE call (pack(q) .. re-evaluation, ~10 launches) against that read at 8 TB/s.
     lat = {}
     for arith_l, gbytes in (("f16x2", 95232), ("f16", 47616)):
-        mt = Matcher("sc", 32, n, ctx=Context(dev.index, sc_arith=arith_l, stream=cur))
+        mt = Matcher("sc", 64, n, ctx=Context(dev.index, sc_arith=arith_l, stream=cur))
         mt.pack_database(db)
         img = 2 * ((n + 15) // 16) * gbytes
-        for mq in (1, 8, 32):
+        for mq in (1, 8, 16, 32, 64):
             qq = q[:mq].contiguous()
             for _ in range(3):
                 mt.match(qq, 0, 2.0, 1)

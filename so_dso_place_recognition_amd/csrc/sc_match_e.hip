@@ -564,6 +564,7 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
   const int nqg = single ? (m <= 8 ? 1 : 8) : 4;
   const int QGW = (single && m <= 8) ? 1 : QG8 / nqg;   // workgroups along the queries (8 nqg queries each)
   int nsplit = (128 + QGW - 1) / QGW;
+  if (QGW <= 2) nsplit = 32 / QGW;                      // a few query groups (an online batch of 9 .. 64 keyframes): exactly one workgroup per CU, see launch_sc_match_e_bin
   if (nsplit > DG / 32) nsplit = DG / 32;
   if (nsplit < 1) nsplit = 1;
   if (nqg == 1) nsplit = DG / 128 > 0 ? DG / 128 : 1;   // an online call: ~32 DB groups per workgroup, 4 per wave; ~400 workgroups at n = 100k
@@ -588,6 +589,10 @@ void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* d
   const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n);
   auto grid = [&](int QGW) {     // ranges per XCD: >= ~4 workgroups per CU in total, >= 8 DB groups per workgroup (an eighth of the ranges per XCD)
     int nsplit = (128 + QGW - 1) / QGW;
+    // one or two workgroups along the queries (m <= 64: an online batch): 8 QGW nsplit = 256 workgroups = ONE per CU (a workgroup fills its
+    // CU's LDS), each walking 1 / 256 of the DB groups - the throughput rule's 776 workgroups ran in 3.03 rounds, i.e. four, with four
+    // prologues: 0.60 -> 0.48 ms per call at m = 32, 0.92 -> 0.82 at m = 64 (tools/latency_probe.py)
+    if (QGW <= 2) nsplit = 32 / QGW;
     if (nsplit > DG / 64) nsplit = DG / 64;
     if (nsplit < 1) nsplit = 1;
     if (nsplit_override > 0) nsplit = nsplit_override * 8 <= DG ? nsplit_override : (DG >= 8 ? DG / 8 : 1);

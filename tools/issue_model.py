@@ -122,6 +122,31 @@ def simulate(stream, c):
     return t, pipe_busy, hist
 
 
+def coarse_stage2(stream, cand_per_pair):
+    """The unit's instruction stream if stage 2 ran on the hi halves only and the shifts inside the coarse maximum's error bound were
+    re-evaluated exactly on the vector ALUs (not built: this prices it).  Registers decide the shape: the fp32 S_f of a unit are 248 registers
+    per lane, so the exact values can only come from what is already there - the packed hi + lo stage-2 operands (124 + 124 registers, B-operand
+    layout of v_mfma_f32_32x32x16_f16: a pair's 31 frequencies sit in TWO lanes, 16 each).  Hence: the split VALU work stays (lo is still
+    needed), 64 of the 96 32x32x16 MFMAs go, and per unit come
+      * detection: a second sweep of the 256 stage-2 results of a lane against (maximum - bound): 256 compares + ~44 bookkeeping   = 300 VALU
+      * per candidate (pair, variant, shift) and lane: 16 frequencies x 2 components x (cvt hi, cvt lo, add) = 96, 32 fma, ~12 select /
+        address = 140 VALU, 32 LDS reads (the twiddles of ITS shift: a per-lane gather), 2 permlane swaps + 2 adds for the two half sums
+    with 128 pairs per unit over 32 column lanes x 2 halves: candidates per lane = 4 x cand_per_pair."""
+    out, seen32 = [], 0
+    for ins in stream:
+        if ins[0] == "mfma32":
+            seen32 += 1
+            if seen32 % 3 != 1:
+                continue
+        out.append(ins)
+    per_lane = 4.0 * cand_per_pair
+    n_valu = int(round(300 + per_lane * 140))
+    n_lds = int(round(per_lane * 32))
+    n_swap = int(round(per_lane * 2))
+    out += [("valu", "v_hypothetical", "")] * n_valu + [("lds", "ds_read_b64", "")] * n_lds + [("swap", "v_permlane32_swap", "")] * n_swap
+    return out
+
+
 def fit(path):
     """Costs from the table tools/ubench/mfma16_fillers prints: lines `<name> <shape> dst=.. .. : K=0 a  K=2 b  K=4 c  K=6 d ...`."""
     rows = {}
@@ -175,6 +200,10 @@ def main():
     ap.add_argument("--measured-ms", type=float, default=None)
     ap.add_argument("--ghz", type=float, default=None, help="sustained shader clock under this kernel (GRBM_GUI_ACTIVE / 8 / duration)")
     ap.add_argument("--json", action="store_true")
+    ap.add_argument("--hypothetical", default=None, choices=["coarse-stage2"],
+                    help="price a variant that was NOT built: coarse-stage2 = stage 2 with ONE f16 product per term (32 instead of 96 32x32x16 MFMAs) "
+                         "+ exact refinement of the shifts within its error bound from the packed hi + lo stage-2 operands (VERDICT r04 item 4b)")
+    ap.add_argument("--refine-candidates", type=float, default=1.5, help="coarse-stage2: shifts per pair inside the coarse pass's error bound (>= 1)")
     a = ap.parse_args()
     if a.fit:
         c = fit(a.fit)
@@ -182,6 +211,11 @@ def main():
         print("wrote", a.costs)
     c = json.load(open(a.costs))
     st = unit_stream(KERNELS[a.kernel])
+    base_chain = None
+    if a.hypothetical == "coarse-stage2":
+        assert a.kernel == "split"
+        base_chain = simulate(st, c)[0]
+        st = coarse_stage2(st, a.refine_candidates)
     chain, pipe, hist = simulate(st, c)
     waves_per_simd = 1 if a.kernel == "split" else 2
     waves_per_cu = 4 * waves_per_simd
@@ -203,6 +237,9 @@ def main():
            "model_cycles_per_launch": round(unit * units_per_simd, 0)}
     if waves_per_simd == 2:
         res["model_cycles_per_unit_perfect_overlap"] = round(lo, 1)
+    if base_chain is not None:
+        res["hypothetical"] = {"variant": a.hypothetical, "refine_candidates_per_pair": a.refine_candidates,
+                               "baseline_issue_chain_cycles": round(base_chain, 1), "change_of_the_unit": round(unit / max(base_chain, ta, lds) - 1.0, 4)}
     res["matrix_pipe_share_of_model"] = round(pipe / unit, 3)
     flop_unit = (71568 if a.kernel == "split" else 23856) / 2 * 128          # algorithmic f16 FLOP of one unit (128 pairs of ONE channel)
     frac = lambda cyc, ghz: flop_unit / cyc * 1024 * ghz * 1e9 / 2.5e15
