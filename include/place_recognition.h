@@ -35,10 +35,16 @@ enum { PR_HOST = 0, PR_DEVICE = 1 };
  * contain the exact top-k, or whose re-evaluated candidates could change places under the sigma error of the f16 pass (pr_f16_margin_dev),
  * is recomputed in split-f16 (host calls: automatically, PR_WARN_F16_FALLBACK is raised) */
 #define PR_F16_DISTANCE_BOUND 2e-3   /* |d_f16 - d| per channel: 8 u (u = 2^-11) on the correlation of unit-norm rows, halved */
-#define PR_F16_SIGMA_REL 2e-4        /* order check: floor of the relative error allowed for a row sigma of the f16 pass ... */
-#define PR_F16_NOISE 1e-4            /* ... which is max(floor, 4 PR_F16_NOISE / (sigma sqrt(n - 1))): rms distance noise of the pass, 3 x the observed 3e-5 */
-#define PR_F32_SIGMA_REL 5e-7        /* the same for the split-f16 / fp32 passes: sigma is off by 2.5e-7 relative whatever the row length ... */
-#define PR_F32_NOISE 1e-7            /* ... and their distance noise is 2.5e-8 rms, 1.3e-7 at most */
+/* Order check: the relative error allowed for a row sigma of the all-pairs pass is eps = SIGMA_REL + DIST_ERR / sigma.  SIGMA_REL: the
+ * systematic part (the minimum over 120 noisy variants compresses a row by 2.5e-7 relative in the fp32-grade passes, whatever the row length).
+ * DIST_ERR: the largest error of a single distance - |sigma(d + e) - sigma(d)| <= max |e| holds for ANY error pattern (sigma is 1-Lipschitz in
+ * the sup norm), also when the errors of many entries coincide, as they do for near-copies of one place (round 5; before, the term was
+ * 4 x rms noise / (sigma sqrt(n - 1)), which assumes independent errors: tools/fuzz_all.py, seed 13 case 21, a row of 168 entries of which 99
+ * are near-copies of two places, returned ranks 2 / 3 swapped in PR_SC_ARITH_F16 without a flag). */
+#define PR_F16_SIGMA_REL 2e-4
+#define PR_F16_DIST_ERR 2e-4         /* observed < 1.3e-4 (the worst-case bound of the arithmetic is PR_F16_DISTANCE_BOUND) */
+#define PR_F32_SIGMA_REL 5e-7
+#define PR_F32_DIST_ERR 2e-7         /* split-f16 / fp32 passes: 2.5e-8 rms, 1.3e-7 at most (tools/probe_bias.py, n = 20 000) */
 enum { PR_SC_ARITH_F16X2 = 0, PR_SC_ARITH_F32 = 1, PR_SC_ARITH_F16 = 2 };
 /* What a zero-norm SC row does.  MATLAB divides 0/0 (processSC.m:16,19): every distance to or from that signature is NaN, and
  * normalize(.,2) / min (run_test.m:40,57) leave NaNs out [normalize's 'omitnan' from memory], so the signature simply never matches.
@@ -224,7 +230,7 @@ int pr_rerank_width(const pr_ctx* ctx, int32_t k);
  * count: DEVICE i32 [1], set to the number of flags.  Flagged queries must be recomputed in PR_SC_ARITH_F16X2.
  * Also flagged: queries whose re-evaluated ORDER is not certain.  A re-evaluated score is exact in the pair's distances, but its
  * channel terms are divided by the f16 pass's row sigmas; two candidates whose channels disagree about their order can change places
- * when those sigmas move by what the pass's distance noise allows (PR_F16_SIGMA_REL, PR_F16_NOISE: a relative noise / (sigma sqrt(n))).
+ * when those sigmas move by what the pass's distance errors allow (PR_F16_SIGMA_REL + PR_F16_DIST_ERR / sigma).
  * pr_rerank_dev (one shard) / pr_rerank_finish_dev (sharded) check every adjacent pair of the selected k and the best candidate left out and
  * leave the result in the context; this call takes it (once). */
 int pr_f16_margin_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, int32_t m, int32_t G, double p_weight, int32_t k_in,
@@ -259,7 +265,7 @@ int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2
  * pr_rerank_finish_dev leave in the context one word per query:
  *   bit 0  ORDER: two neighbours among the re-evaluated candidates (the selected k and the best one left out) could change places under the
  *          sigma error of the all-pairs pass (their channels disagree about the order and the scores are closer than
- *          sum_c eps_c |z_c(a) - z_c(b)|, eps_c = max(PR_F32_SIGMA_REL, 4 PR_F32_NOISE / (sigma_c sqrt(n - 1))); PR_SC_ARITH_F16: the PR_F16_*
+ *          sum_c eps_c |z_c(a) - z_c(b)|, eps_c = PR_F32_SIGMA_REL + PR_F32_DIST_ERR / sigma_c; PR_SC_ARITH_F16: the PR_F16_*
  *          constants, and pr_f16_margin_dev takes the flags - such queries go to the split-f16 pass);
  *   bit 1  CONTAINMENT (needs the candidates' pass scores: score_in / cand_score; not in PR_SC_ARITH_F16, whose margin check is
  *          pr_f16_margin_dev): every entry outside the k_in candidates has a pass score >= the last candidate's, T, hence an exact score
@@ -320,6 +326,7 @@ const char* pr_group_last_error(const pr_group* g);     /* g may be NULL (creati
 int32_t pr_group_size(const pr_group* g);
 int pr_group_uses_rccl(const pr_group* g);
 int32_t pr_group_rccl_ranks(const pr_group* g);         /* ncclCommCount of the group's communicator (0: the group exchanges by copies) */
+int pr_group_set_exact_statistics(pr_group* g, int on);  /* pr_set_exact_statistics on every shard: all queries answered from their exact fp64 rows */
 int32_t pr_group_last_flagged(const pr_group* g);       /* queries of the last pr_group_match_topk that were answered from their exact fp64 rows */
 /* Phase times of a call, per shard (bench.py --via-group: what makes the first multi-GPU curve readable).  on != 0: every following
  * pr_group_match_topk records HIP events on every shard's stream between its phases; pr_group_last_timing waits for the last call's and

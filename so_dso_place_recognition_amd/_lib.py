@@ -57,6 +57,7 @@ SYMBOLS = {
     "pr_group_uses_rccl": (C.c_int, [_vp]),
     "pr_group_rccl_ranks": (_i32, [_vp]),
     "pr_group_last_flagged": (_i32, [_vp]),
+    "pr_group_set_exact_statistics": (C.c_int, [_vp, C.c_int]),
     "pr_group_set_timing": (C.c_int, [_vp, C.c_int]),
     "pr_group_last_timing": (C.c_int, [_vp, _vp, _i32]),
     "pr_group_set_database": (C.c_int, [_vp, C.c_int, _vp, _i32]),

@@ -180,6 +180,16 @@ def default_context() -> Context:
     return _default_ctx
 
 
+_exact_ctx = None
+
+
+def _exact_context() -> Context:
+    global _exact_ctx
+    if _exact_ctx is None:
+        _exact_ctx = Context(0, exact_statistics=True)
+    return _exact_ctx
+
+
 def _csr(pts_list):
     """list of (xyz [P,3], intensity [P]) -> CSR arrays."""
     offs = np.zeros(len(pts_list) + 1, np.int64)
@@ -392,7 +402,11 @@ def match_topk_fused(sc1, m2dp1, sc2, m2dp2, mask_width=0, p_weight=2.0, k=1, ct
 
 def run_test(type_, hist1, hist2, gt1=None, gt2=None, loop_diff=None, mask_width=0, ctx: Context | None = None):
     """run_test.m:1.  Without ground truth: returns (diff_v, diff_idx) of run_test.m:57 (0-based indices).
-    With gt1/gt2/loop_diff: returns (AUC, top_recall, lp_detected) through eval.precision_recall."""
+    With gt1/gt2/loop_diff: returns (AUC, top_recall, lp_detected) through eval.precision_recall; the sweep ranks the QUERIES by their
+    best score (run_test.m:58), so every query is then answered from its exact fp64 row unless the caller brings a context of its own
+    (pr_set_exact_statistics: scores are the reference's doubles to rounding, two queries whose scores agree to 1e-5 keep their places)."""
+    if gt1 is not None and ctx is None and type_ in ("sc", "m2dp", TYPE_SC, TYPE_M2DP):
+        ctx = _exact_context()
     idx, sc = match_topk(type_, hist1, hist2, mask_width, 2.0, 1, ctx)
     if gt1 is None:
         return sc[:, 0], idx[:, 0]

@@ -4,6 +4,9 @@
 //   [--devices 0,1,...]               hist2 row-sharded over these GPUs (pr_group: RCCL all-gathers between the kernels; sc | m2dp)
 //   [--gt1 F --gt2 F --loop_diff L]   positions of the signatures (text matrices, one row per signature): the evaluation half of
 //                                     run_test (run_test.m:3-22, :58-85) - prints `AUC = ...` and `top_recall = ...`
+//   [--exact_statistics 0|1]          every query answered from its exact fp64 row (scores = the reference's doubles to rounding).  Default: 1
+//                                     with --gt1 / --gt2 - the sweep ranks the QUERIES by score (run_test.m:58), and two queries whose scores
+//                                     agree to 1e-5 must not change places -, else 0
 // Output: one line per query: K pairs "index score" (0-based indices unless --one_based 1), and the reference's
 // console lines `type` / `tm` (ms per query, run_test.m:42-44).  Scores are doubles, as MATLAB holds them.
 #include <chrono>
@@ -54,6 +57,12 @@ int main(int argc, char** argv) {
     if (pr_group_create(dev_ids.data(), (int32_t)dev_ids.size(), &grp) != PR_OK) { fprintf(stderr, "%s\n", pr_group_last_error(nullptr)); return 3; }
     if (pr_group_set_database(grp, t, h2, n) != PR_OK) { fprintf(stderr, "%s\n", pr_group_last_error(grp)); return 4; }
     printf("devices = %d (%s)\n", (int)dev_ids.size(), pr_group_uses_rccl(grp) ? "RCCL" : "copies");
+  }
+  {
+    std::string a, b;
+    const bool exact = prm.num("exact_statistics", (prm.get("gt1", a) && prm.get("gt2", b)) ? 1.0 : 0.0) != 0.0;
+    if (exact && ctx) (void)pr_set_exact_statistics(ctx, 1);
+    if (exact && grp) (void)pr_group_set_exact_statistics(grp, 1);
   }
   const auto t0 = std::chrono::steady_clock::now();
   int rc;

@@ -276,21 +276,32 @@ __device__ __forceinline__ void xrow_dft_row(const T* __restrict__ px /* element
 }
 
 // rows + moment partials of the SC channels; `finish`: this launch is the pass's last rows kernel (its last workgroup turns the partials
-// of all four channels into the exact moments).  Per (tile, channel): 160 lanes transform the tile's rows into LDS; then per slot ONE
-// barrier: stage 1 (thread = entry x frequency: the four ring sums, into one of two buffers) | stage 2 (thread = entry x shift: the four
-// 31-term sums, the maximum over the shifts by lane exchanges) - the next slot's query spectrum is fetched while stage 1 runs.
-constexpr size_t XROW_SC_LDS = ((size_t)XE * XQ + 2 * XQ + 2 * XE * 32 * 4 + RESOLVE_SLOTS * XE + 160 + XE + RESOLVE_SLOTS * 2 * 3 + RESOLVE_SLOTS * 2) * 8;
-__global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* __restrict__ qspec, const double* __restrict__ tw, int finish) {
+// of all four channels into the exact moments).  Per (tile, channel): 160 lanes transform the tile's rows into LDS; then the pass's slots in
+// groups of XG = 4, two barriers per group:
+//   stage 1  thread = (frequency, 2 entries, 2 slots): the four ring sums ac, bd, bc, ad of its four (slot, entry) pairs - every spectrum
+//            value read from LDS feeds two pairs - combined into (P, R) = Q conj(D) and (P', R') = Q D and stored per COLUMN
+//            (slot, entry, variant) = 4 x 8 x 2 = 64 columns of 31 x (X, Y)
+//   stage 2  lane = column, wave w = shifts k = 4 w .. 4 w + 3: the lane takes its column's 62 numbers into registers ONCE and forms, per
+//            shift, the even- and odd-frequency halves of sum X cos and sum Y sin - together they give the correlation at k, 60 - k, 30 - k
+//            and 30 + k (cos(th f (30 - k)) = (-1)^f cos(th f k), sin likewise with the other sign) - with the twiddles wave-uniform, i.e.
+//            scalar loads from constant memory: no LDS traffic for them, and a column's numbers leave LDS four times instead of 32.
+// (The first version - thread = entry x shift, every lane reading its entry's 124 sums - was bound by those LDS reads: 3.3 k cycles of LDS
+// return bandwidth per slot and tile against 0.8 k of fp64 FMAs.)  The next group's query spectra are fetched while stage 1 runs.
+constexpr int XG = 4;                         // slots per group
+constexpr int XT = XG * XE * 2 * 62;          // doubles of the column store [XG][XE][variant][31]{X, Y}
+constexpr size_t XROW_SC_LDS = ((size_t)XE * XQ + XG * XQ + XT + 4 * 64 + RESOLVE_SLOTS * XE + XE + RESOLVE_SLOTS * 2 * 3 + RESOLVE_SLOTS * 2) * 8;   // 160 KB less 2.8 KB
+__constant__ double g_tw2[16 * 31 * 2];       // [k = 0 .. 15][f]{cos, sin}(2 pi f k / 60), set with g_twfs
+__global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* __restrict__ qspec, int finish) {
   extern __shared__ __attribute__((aligned(16))) double xl[];
   double* spec = xl;                                            // [XE][20][31][2]
-  double* qs = spec + (size_t)XE * XQ;                          // [2][20][31][2]
-  double* ssum = qs + 2 * XQ;                                   // [2][XE][32][4] (P, R, P', R')
-  double* dtile = ssum + 2 * XE * 32 * 4;                       // [RESOLVE_SLOTS][XE] this (tile, channel)'s distances
-  double* part = dtile + RESOLVE_SLOTS * XE;                    // [160]
-  double* rnd = part + 160;                                     // [XE] 1 / |d|
+  double* qs = spec + (size_t)XE * XQ;                          // [XG][20][31][2]
+  double* tcol = qs + XG * XQ;                                  // [XG][XE][2][31][2]
+  double* mpart = tcol + XT;                                    // [4 waves][64 columns]
+  double* dtile = mpart + 4 * 64;                               // [RESOLVE_SLOTS][XE] this (tile, channel)'s distances
+  double* part = tcol;                                          // [160] the rows' square sums (before the group loop: the column store is idle)
+  double* rnd = dtile + RESOLVE_SLOTS * XE;                     // [XE] 1 / |d|
   double* acc = rnd + XE;                                       // [RESOLVE_SLOTS][2][3]
   double* piv = acc + RESOLVE_SLOTS * 2 * 3;                    // [RESOLVE_SLOTS][2]
-  __shared__ double red[256];
   __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
   const int tid = threadIdx.x, b = blockIdx.x, n = A.n_local;
   const int total = flagged_slots(A.flags, A.m, A.list, A.cnt, A.offset, s_list, s_tmp, tid, 256);
@@ -298,33 +309,33 @@ __global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* 
   if (ns <= 0) return;                                          // nothing flagged: the usual case
   for (int i = tid; i < ns * 6; i += 256) acc[i] = 0.0;
   for (int i = tid; i < ns * 2; i += 256) piv[i] = pivot_of(A.mom_sc, A.G, A.m, s_list[i >> 1], i & 1);
-  // this thread in the pair stages: entry e1, frequency / shift k1 (lane 31 of a group of 32 repeats shift 0: harmless for the maximum)
-  const int e1 = tid >> 5, k1 = (tid & 31) == 31 ? 0 : (tid & 31);
+  // stage 1: frequency f1 (lane 31 of a group of 32 repeats frequency 30 and stores nothing), entries 2 ep, 2 ep + 1, slots 2 sp, 2 sp + 1 of the group
+  const int f1 = (tid & 31) == 31 ? 30 : (tid & 31), ep = (tid >> 5) & 3, sp = tid >> 7;
   const bool live = (tid & 31) != 31;
-  double ck[31], sk[31];
-  {
-    int t = 0;
-#pragma unroll
-    for (int f = 0; f < 31; f++) { ck[f] = tw[t]; sk[f] = tw[60 + t]; t += k1; if (t >= 60) t -= 60; }
-  }
+  // stage 2: column = lane (slot of the group, entry, variant), shifts 4 wv .. 4 wv + 3
+  const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ngroups = (ns + XG - 1) / XG;
   const int ntile = (n + XE - 1) / XE;
   for (int tile = b; tile < ntile; tile += A.NB) {
     const int j0 = tile * XE, ne = n - j0 < XE ? n - j0 : XE;
     for (int ch = 0; ch < 2; ch++) {
-      double qn[5];                                              // the next slot's query spectrum on its way to LDS (1240 doubles / 256 threads)
-      auto q_fetch = [&](int s) {
-        const double* qg = qspec + ((size_t)s * 2 + ch) * XQ;
+      double qn[XG * XQ / 256 + 1];                              // the next group's query spectra on their way to LDS (4960 doubles / 256 threads)
+      auto q_fetch = [&](int g) {
 #pragma unroll
-        for (int u = 0; u < 5; u++) { const int i = tid + 256 * u; qn[u] = i < XQ ? qg[i] : 0.0; }
+        for (int u = 0; u < XG * XQ / 256 + 1; u++) {
+          const int i = tid + 256 * u;
+          int sl = g * XG + i / XQ;                              // (a ragged last group repeats the pass's last slot: its results are not stored)
+          if (sl >= ns) sl = ns - 1;
+          qn[u] = i < XG * XQ ? qspec[((size_t)sl * 2 + ch) * XQ + i % XQ] : 0.0;
+        }
       };
-      auto q_store = [&](int s) {
-        double* qd = qs + (size_t)(s & 1) * XQ;
+      auto q_store = [&]() {
 #pragma unroll
-        for (int u = 0; u < 5; u++) { const int i = tid + 256 * u; if (i < XQ) qd[i] = qn[u]; }
+        for (int u = 0; u < XG * XQ / 256 + 1; u++) { const int i = tid + 256 * u; if (i < XG * XQ) qs[i] = qn[u]; }
       };
       q_fetch(0);
       __syncthreads();                                          // the previous (tile, channel)'s readers of spec / rnd / dtile / qs are done
-      q_store(0);
+      q_store();
       if (tid < 160) {
         const int e = tid / 20, r = tid % 20;
         double ssq = 0.0;
@@ -344,36 +355,71 @@ __global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* 
         for (int r = 0; r < 20; r++) sum += part[tid * 20 + r];
         rnd[tid] = 1.0 / sqrt(sum);                              // |d| = 0: inf, and inf x 0 = NaN below (processSC.m:19)
       }
-      // (rnd is read after the first barrier of the slot loop)
-      for (int s = 0; s < ns; s++) {
-        if (s + 1 < ns) q_fetch(s + 1);
-        {                                                        // stage 1: the four ring sums of (entry e1, frequency k1)
-          double ac = 0.0, bd = 0.0, bc = 0.0, ad = 0.0;
-          const double* qp = qs + (size_t)(s & 1) * XQ + 2 * k1;
-          const double* dp = spec + (size_t)e1 * XQ + 2 * k1;
-#pragma unroll
+      // (rnd is read behind the barriers of the group loop)
+      for (int g = 0; g < ngroups; g++) {
+        if (g + 1 < ngroups) q_fetch(g + 1);
+        {                                                        // stage 1
+          double ac[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, bd[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, bc[2][2] = {{0.0, 0.0}, {0.0, 0.0}}, ad[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+          const double* q0 = qs + (size_t)(2 * sp) * XQ + 2 * f1;
+          const double* d0 = spec + (size_t)(2 * ep) * XQ + 2 * f1;
+#pragma unroll 4
           for (int r = 0; r < 20; r++) {
-            const double a = qp[r * 62], bq = qp[r * 62 + 1], c = dp[r * 62], d = dp[r * 62 + 1];
-            ac += a * c; bd += bq * d; bc += bq * c; ad += a * d;
+            double qa[2], qb[2], dc[2], dd[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) { qa[u] = q0[u * XQ + r * 62]; qb[u] = q0[u * XQ + r * 62 + 1]; dc[u] = d0[u * XQ + r * 62]; dd[u] = d0[u * XQ + r * 62 + 1]; }
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+              for (int v = 0; v < 2; v++) { ac[u][v] += qa[u] * dc[v]; bd[u][v] += qb[u] * dd[v]; bc[u][v] += qb[u] * dc[v]; ad[u][v] += qa[u] * dd[v]; }
           }
           if (live) {
-            double* o = ssum + (size_t)(s & 1) * XE * 32 * 4 + ((size_t)e1 * 32 + k1) * 4;
-            o[0] = ac + bd; o[1] = bc - ad; o[2] = ac - bd; o[3] = ad + bc;
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+              for (int v = 0; v < 2; v++) {
+                double* o = tcol + ((size_t)((2 * sp + u) * XE + 2 * ep + v) * 2) * 62 + 2 * f1;
+                o[0] = ac[u][v] + bd[u][v]; o[1] = bc[u][v] - ad[u][v];            // forward:  (P, R)   = Q conj(D)
+                o[62] = ac[u][v] - bd[u][v]; o[63] = ad[u][v] + bc[u][v];          // mirrored: (P', R') = Q D
+              }
           }
         }
-        if (s + 1 < ns) q_store(s + 1);
         __syncthreads();
-        {                                                        // stage 2: the four shift sums of (entry e1, shift k1), then the maximum over the shifts
-          double E1 = 0.0, O1 = 0.0, E2 = 0.0, O2 = 0.0;
-          const double* sp = ssum + (size_t)(s & 1) * XE * 32 * 4 + (size_t)e1 * 32 * 4;
+        if (g + 1 < ngroups) q_store();                          // (every reader of this group's spectra is past the barrier)
+        {                                                        // stage 2
+          double X[31], Y[31];
+          const double* cp = tcol + (size_t)lane * 62;
 #pragma unroll
-          for (int f = 0; f < 31; f++) {
-            E1 += sp[4 * f] * ck[f]; O1 += sp[4 * f + 1] * sk[f]; E2 += sp[4 * f + 2] * ck[f]; O2 += sp[4 * f + 3] * sk[f];
+          for (int f = 0; f < 31; f++) { X[f] = cp[2 * f]; Y[f] = cp[2 * f + 1]; }
+          int tz = wv * 4 * 62;
+          asm volatile("" : "+s"(tz));                           // (keeps the twiddle loads inside the group loop)
+          const double* t2 = g_tw2 + tz;
+          double mm = -__builtin_inf();
+          bool isnan_ = false;
+#pragma unroll
+          for (int kk = 0; kk < 4; kk++) {
+            double pe = 0.0, po = 0.0, re = 0.0, ro = 0.0;
+#pragma unroll
+            for (int f = 0; f < 31; f++) {
+              const double c = t2[(kk * 31 + f) * 2], sn = t2[(kk * 31 + f) * 2 + 1];
+              if (f & 1) { po += X[f] * c; ro += Y[f] * sn; } else { pe += X[f] * c; re += Y[f] * sn; }
+            }
+            const double Ek = pe + po, E30 = pe - po, Ok = re + ro, O30 = ro - re;
+            const double c4 = fmax(fmax(Ek - Ok, Ek + Ok), fmax(E30 - O30, E30 + O30));
+            isnan_ = isnan_ || (c4 != c4);
+            mm = fmax(mm, c4);
           }
-          double mm = fmax(fmax(E1 - O1, E1 + O1), fmax(E2 - O2, E2 + O2));
+          mpart[wv * 64 + lane] = isnan_ ? __builtin_nan("") : mm;
+        }
+        __syncthreads();
+        if (tid < XG * XE) {                                     // (slot of the group, entry): the maximum over both variants and the four waves' shifts
+          const int sg = tid / XE, e = tid % XE, sl = g * XG + sg;
+          double mm = -__builtin_inf();
+          bool bad_ = false;
 #pragma unroll
-          for (int sft = 16; sft > 0; sft >>= 1) mm = fmax(mm, __shfl_xor(mm, sft, 64));
-          if ((tid & 31) == 0) dtile[s * XE + e1] = (1.0 - mm * rnd[e1]) / 2.0;   // processSC.m:30-31 (a zero-norm row on either side: NaN)
+          for (int v = 0; v < 2; v++)
+#pragma unroll
+            for (int w = 0; w < 4; w++) { const double x = mpart[w * 64 + tid * 2 + v]; bad_ = bad_ || (x != x); mm = fmax(mm, x); }
+          if (sl < ns) dtile[sl * XE + e] = bad_ ? __builtin_nan("") : (1.0 - mm * rnd[e]) / 2.0;   // processSC.m:30-31 (a zero-norm row on either side: NaN)
         }
       }
       __syncthreads();
@@ -406,7 +452,7 @@ __global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* 
   __syncthreads();
   if (!s_tmp[5]) return;
   __threadfence();
-  xrow_finish(A, s_list, ns, total, red, tid);
+  xrow_finish(A, s_list, ns, total, tcol, tid);
 }
 
 // processM2DP.m:12-22 for the pass's slots over tiles of XE entries: the 4 x 4 row products of a (slot, entry) pair per channel,
@@ -646,7 +692,12 @@ hipError_t xrow_set_twiddles(const double* cos60, const double* sin60) {
   double t[31 * 14 * 2];
   for (int f = 0; f < 31; f++)
     for (int sct = 1; sct < 15; sct++) { const int i = (f * sct) % 60; t[(f * 14 + sct - 1) * 2] = cos60[i]; t[(f * 14 + sct - 1) * 2 + 1] = sin60[i]; }
-  return hipMemcpyToSymbol(HIP_SYMBOL(g_twfs), t, sizeof t);
+  hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_twfs), t, sizeof t);
+  if (e != hipSuccess) return e;
+  double t2[16 * 31 * 2];
+  for (int k = 0; k < 16; k++)
+    for (int f = 0; f < 31; f++) { const int i = (f * k) % 60; t2[(k * 31 + f) * 2] = cos60[i]; t2[(k * 31 + f) * 2 + 1] = sin60[i]; }
+  return hipMemcpyToSymbol(HIP_SYMBOL(g_tw2), t2, sizeof t2);
 }
 
 void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
@@ -669,7 +720,7 @@ void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt,
   if (q_sc) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_sc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_SC_LDS);
     hipLaunchKernelGGL(xrow_qspec_kernel, dim3(slots, 2), dim3(256), 0, st, A, tw, qspec);
-    hipLaunchKernelGGL(xrow_sc_kernel, dim3(NB), dim3(256), XROW_SC_LDS, st, A, (const double*)qspec, tw, q_m2 ? 0 : 1);
+    hipLaunchKernelGGL(xrow_sc_kernel, dim3(NB), dim3(256), XROW_SC_LDS, st, A, (const double*)qspec, q_m2 ? 0 : 1);
   }
   if (q_m2) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_m2dp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_M2_LDS);

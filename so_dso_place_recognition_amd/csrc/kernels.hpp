@@ -134,7 +134,7 @@ void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom
                          const double* cand_sc, int k, const double* score, double eps_d, int32_t* flags, int32_t* count,
                          const int32_t* order_flags = nullptr);
 // flags[q] = 1 where the order of the re-evaluated candidates (the selected k and the best one left out) could change under the sigma error
-// of the all-pairs pass (per channel max(eps_floor, 4 noise / (sigma sqrt(n - 1))), statistics from mom_* [Gmom][m][2][3])
+// of the all-pairs pass (per channel eps_floor + noise / sigma: noise = the largest error of one distance; statistics from mom_* [Gmom][m][2][3])
 // + bit 1 where the candidate list (cand_sc [m][kin]: its all-pairs-pass scores, ascending; score_sel [m][k]: the exact scores of the k selected;
 // both or neither) does not provably hold the exact top-k of the whole row
 void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int Gmom, const int32_t* cand_idx, const double* p5_all,

@@ -880,7 +880,7 @@ int pr_rerank_width(const pr_ctx* ctx, int32_t k) { return ctx ? rerank_width(k,
 static bool order_consts(const pr_ctx* ctx, double& fl, double& noise) {
   const bool f16 = ctx->sc_mode == PR_SC_ARITH_F16;
   fl = f16 ? PR_F16_SIGMA_REL : PR_F32_SIGMA_REL;
-  noise = f16 ? PR_F16_NOISE : PR_F32_NOISE;
+  noise = f16 ? PR_F16_DIST_ERR : PR_F32_DIST_ERR;     // (the largest error of one distance of the pass)
   return f16;
 }
 

@@ -220,6 +220,11 @@ const char* pr_group_last_error(const pr_group* g) { return g ? g->err.c_str() :
 int32_t pr_group_size(const pr_group* g) { return g ? g->G : 0; }
 int pr_group_uses_rccl(const pr_group* g) { return g && g->rccl; }
 int32_t pr_group_last_flagged(const pr_group* g) { return g ? g->last_flagged : 0; }
+int pr_group_set_exact_statistics(pr_group* g, int on) {
+  if (!g) return PR_EINVAL;
+  for (auto& sh : g->s) if (sh.ctx) (void)pr_set_exact_statistics(sh.ctx, on);
+  return PR_OK;
+}
 int32_t pr_group_rccl_ranks(const pr_group* g) {   // asked of the communicator itself, not of the argument list
   if (!g || !g->rccl || g->comms.empty() || !g->comms[0]) return 0;
   int n = 0;

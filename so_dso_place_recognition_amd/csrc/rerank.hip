@@ -294,8 +294,10 @@ __device__ __forceinline__ void row_stats(const double* mom_sc, const double* mo
     chan_combine(mom, Gmom, m, q, c & 1, S.mean[c], S.sd[c], &cn);
     S.cn = cn;
     S.w[c] = (c & 1) ? 1.0 : p_weight;
-    const double e = 4.0 * noise / (S.sd[c] * sqrt(fmax(cn - 1.0, 1.0)));
-    S.eps[c] = (e == e) ? fmax(eps_floor, e) : 1.0;             // (sigma = 0 or NaN: nothing about the order is certain)
+    // |sigma(d + e) - sigma(d)| <= max |e| for ANY error pattern (no independence assumed: the entries of a cluster of near-copies share
+    // their error), + the systematic compression of the row by the minimum over noisy variants
+    const double e = eps_floor + noise / S.sd[c];
+    S.eps[c] = (e == e && e < 1.0) ? e : 1.0;                   // (sigma = 0 or NaN: nothing about the order is certain)
   }
 }
 // Containment (run_test.m:57 takes the minimum over the WHOLE row; the re-evaluation sees the k_in best of the all-pairs pass): every entry
@@ -409,12 +411,12 @@ __global__ __launch_bounds__(64) void rerank_finish_kernel(const int32_t* __rest
 //      s_b - s_a > sum_c eps_c |z_c(b) - z_c(a)|
 // (always true when all channels agree on the order; the means shift both alike).  Walking the selected k and the best candidate left
 // out, every ADJACENT pair must pass - then the whole chain is in its true order and the k-th / (k+1)-th boundary is the true one.
-// eps_c: the pass's distance noise e (single-product f16: rms nu ~ 3e-5, |e| < 1.3e-4 observed) enters sigma^2 as (2 / n) sum (d_j - mu) e_j,
-// i.e. a relative nu / (sigma_c sqrt(n)) on sigma - 1e-4 at n = 10^4, 1e-2 on a row of 24 - so eps_c = max(floor, 4 noise / (sigma_c
-// sqrt(n - 1))) with the PR_F16_* or PR_F32_* constants (include/place_recognition.h).  Pairs equal in every channel (duplicated signatures)
-// are ordered by index and certain; candidates that were not evaluated (pruned: their pass score is beyond the k-th by more than the pass's
-// error) are certain by that bound.  A flagged query is answered with fp64 row statistics (exact_partial_kernel ... rescore_kernel below) or,
-// in PR_SC_ARITH_F16, by the split-f16 pass.  One wave per query; p5_all [G][m][5][kin] holds values at the candidate's owner, NaN elsewhere.
+// eps_c = SIGMA_REL + DIST_ERR / sigma_c (the PR_F16_* or PR_F32_* constants of include/place_recognition.h): the pass's distance errors e_j
+// move sigma by at most max |e_j| whatever their pattern - also when a cluster of near-copies shares ONE error, where the round-4 form
+// 4 rms / (sigma sqrt(n - 1)) (independent errors) was 3 - 40 x too small and let a swapped pair through (tools/fuzz_all.py seed 13 case 21).
+// Pairs equal in every channel (duplicated signatures) are ordered by index and certain; candidates that were not evaluated (pruned: their
+// pass score is beyond the k-th by more than the pass's error) are certain by that bound.  A flagged query is answered from its exact fp64
+// row (exact_row.hip) or, in PR_SC_ARITH_F16, by the split-f16 pass.  One wave per query; p5_all [G][m][5][kin] holds values at the candidate's owner, NaN elsewhere.
 __global__ __launch_bounds__(64) void order_check_kernel(const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int Gmom,
                                                           const int32_t* __restrict__ cand_idx, const double* __restrict__ p5_all, int G, int m,
                                                           int kin, int k, const int32_t* __restrict__ idx_sel, double p_weight, double eps_floor,

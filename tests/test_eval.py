@@ -177,9 +177,8 @@ def test_run_test_end_to_end_equals_the_oracle_chain():
     hist[7] = 0.0; hist[200] = 0.0                                   # zero-norm rows: NaN distances, index -1 / MATLAB index 1
     t = np.linspace(0, 4 * np.pi, n, endpoint=False)
     gt = np.stack([50 * np.cos(t), np.zeros(n), 50 * np.sin(t)], 1)
-    ctx = api.Context(0, exact_statistics=True)                      # the sweep ranks the QUERIES by score (run_test.m:58): two queries whose
-    for mask, ld in ((100, 10.0), (0, 5.0), (190, 10.0)):            # scores agree to 1e-5 must not change places -> fp64 row statistics
-        auc, tr, det = api.run_test("sc", hist, hist, gt, gt, ld, mask, ctx)
+    for mask, ld in ((100, 10.0), (0, 5.0), (190, 10.0)):            # (run_test with ground truth answers every query from its exact fp64 row: the
+        auc, tr, det = api.run_test("sc", hist, hist, gt, gt, ld, mask)   #  sweep ranks the QUERIES by score, run_test.m:58)
         rc, oidx, osc = oracle_lib.match_topk(0, hist, hist, mask, 2.0, 1)
         o = oracle_lib.precision_recall(osc[:, 0], oidx[:, 0], gt, gt, ld, mask)
         assert _same(auc, o["auc"]) and _same(tr, o["top_recall"]) and np.array_equal(det, o["lp_detected"])

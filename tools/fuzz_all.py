@@ -39,8 +39,10 @@ def shapes():
     return m, n, k, mask
 
 
-def spoil(q, db, div):
-    """zero-norm rows (NaN distances in MATLAB) and duplicated DB signatures (exact ties -> the lower index wins)"""
+def spoil(q, db, div, planted=None):
+    """zero-norm rows (NaN distances in MATLAB), duplicated DB signatures (exact ties -> the lower index wins) and clusters of NEAR-copies of
+    a query's planted entry (12 - 60 entries whose distances to the query differ by 1e-11 ... 1e-7: more ties than the k + 8 candidates of the
+    fp32-grade pass hold - the containment check must send such a query to its exact row)"""
     m, n = q.shape[0] // div, db.shape[0] // div
     q = q.copy(); db = db.copy()
     notes = []
@@ -65,6 +67,19 @@ def spoil(q, db, div):
             a, b = (int(x) for x in rng.integers(0, n, 2))
             db[b * div:(b + 1) * div] = db[a * div:(a + 1) * div]
         notes.append("dups")
+    if planted is not None and rng.random() < 0.35 and n > 80:
+        for _ in range(int(rng.integers(1, 3))):
+            a = int(planted[int(rng.integers(0, m))])
+            c = int(rng.integers(12, min(61, n // 2)))
+            spots = rng.choice(np.setdiff1d(np.arange(n), [a]), size=c, replace=False)
+            delta = 10.0 ** rng.uniform(-9.5, -5.5) * (0.03 if div == 4 else 1.0)
+            e = db[a * div:(a + 1) * div].copy()
+            cols = rng.choice(np.nonzero(e[0, :1200] > 0)[0] if div == 1 else np.arange(64), size=20, replace=False)
+            for j, b in enumerate(spots):
+                x = e.copy()
+                x[:, cols] *= 1.0 + (j + 1) * delta
+                db[b * div:(b + 1) * div] = x
+            notes.append(f"cluster {a} x {c} delta {delta:.1e}")
     return q, db, ",".join(notes)
 
 
@@ -92,10 +107,10 @@ def check(tag, idx, sc, oidx, osc, tol, resolved=True):
 
 def sigs(type_, it, m, n):
     if type_ == "sc":
-        db = synth.sc_database(1000 + 7 * it + seed, n); q, _ = synth.sc_queries(2000 + it + seed, db, m)
-        return q, db, 1, 0
-    db = synth.m2dp_database(3000 + 7 * it + seed, n); q, _ = synth.m2dp_queries(4000 + it + seed, db, m)
-    return q, db, 4, 1
+        db = synth.sc_database(1000 + 7 * it + seed, n); q, pl = synth.sc_queries(2000 + it + seed, db, m)
+        return q, db, 1, 0, pl
+    db = synth.m2dp_database(3000 + 7 * it + seed, n); q, pl = synth.m2dp_queries(4000 + it + seed, db, m)
+    return q, db, 4, 1, pl
 
 
 def f16_tol(osc, n=None, note=""):
@@ -105,16 +120,32 @@ def f16_tol(osc, n=None, note=""):
     return (3e-2 + 1e-3 * np.abs(osc)) * (1.0 if (n is None or n >= 32) and "dense db" not in note and "full db" not in note else np.inf)
 
 
+import os
+ONLY = int(os.environ["FUZZ_ONLY"]) if "FUZZ_ONLY" in os.environ else None     # re-run ONE case of a (seed, what) sweep: the others only draw their random numbers
+DUMP = os.environ.get("FUZZ_DUMP")                                            # ... and leave its inputs + oracle answer in this .npz
 t_start = time.time()
 for it in range(cases):
     m, n, k, mask = shapes()
     line = [f"{it}: m={m} n={n} k={k} mask={mask}"]
+    if ONLY is not None and it != ONLY:
+        for type_ in ("sc", "m2dp"):
+            q, db, div, t, pl = sigs(type_, it, m, n)
+            spoil(q, db, div, pl)
+            if "group" in what and n >= 8 * div:
+                rng.integers(2, 9 if BIG else 5)
+            if "matcher" in what:
+                rng.random(); rng.random()
+        if "gen" in what:
+            raise SystemExit("FUZZ_ONLY does not replay the generator cases")
+        continue
     try:
         for type_ in ("sc", "m2dp"):
-            q, db, div, t = sigs(type_, it, m, n)
-            q, db, note = spoil(q, db, div)
+            q, db, div, t, pl = sigs(type_, it, m, n)
+            q, db, note = spoil(q, db, div, pl)
             rc, oidx, osc = oracle_lib.match_topk(t, q, db, mask, 2.0, k)
             assert rc in (0, -5), rc          # -5: zero-norm rows (their NaN distances are in the result, as in MATLAB)
+            if DUMP and ONLY is not None:
+                np.savez(DUMP + "_" + type_ + ".npz", q=q, db=db, oidx=oidx, osc=osc, mask=mask, k=k, note=note)
             rc, odp, odi = oracle_lib.sc_distance(q, db) if type_ == "sc" else oracle_lib.m2dp_distance(q, db)
             with np.errstate(invalid="ignore", divide="ignore"):
                 tol = np.broadcast_to(helpers.score_tol(np.where(np.isfinite(osc), osc, 0.0), helpers.row_sigmas(odp, odi), eps=1e-7), osc.shape)
@@ -122,7 +153,10 @@ for it in range(cases):
                 for arith in ("f16x2", "f32", "f16"):
                     ctx = api.Context(0, sc_arith=arith)
                     idx, sc = api.match_topk(type_, q, db, mask, 2.0, k, ctx=ctx)
-                    ok = check((it, type_, arith, "host", m, n, k, mask, note), idx, sc, oidx, osc, f16_tol(osc, n, note) if arith == "f16" else tol)
+                    # (M2DP rows of near-copies in the fp32-MFMA arithmetic: every dot is ~2 at a 2^16 scaling, the accumulation truncates and the
+                    #  whole cluster shares the ~1e-7 shift - the row MEAN moves by up to 3e-7, tests/helpers.score_tol's eps)
+                    tol_a = 3.0 * tol if (arith == "f32" and type_ == "m2dp" and "cluster" in note) else tol
+                    ok = check((it, type_, arith, "host", m, n, k, mask, note), idx, sc, oidx, osc, f16_tol(osc, n, note) if arith == "f16" else tol_a)
                     if arith != "f16":
                         gp, gi = (api.processSC if type_ == "sc" else api.processM2DP)(q, db, ctx)
                         same_nan = np.array_equal(np.isnan(gp), np.isnan(odp)) and np.array_equal(np.isnan(gi), np.isnan(odi))
@@ -158,7 +192,7 @@ for it in range(cases):
                     mt.close()
                     line.append(f"{type_}/Matcher/{arith}:{'ok' if ok else 'BAD'}")
         if "fused" in what and n >= 4:        # (n = 2, 3: the four z-scores are +-0.707 each and sum to EXACT ties, which no arithmetic orders reproducibly)
-            sq, sdb, _, _ = sigs("sc", it, m, n); mq, mdb, _, _ = sigs("m2dp", it, m, n)
+            sq, sdb, _, _, _ = sigs("sc", it, m, n); mq, mdb, _, _, _ = sigs("m2dp", it, m, n)
             rc, oidx, osc = oracle_lib.match_topk_fused(sq, mq, sdb, mdb, mask, 2.0, k)
             for arith in ("f16x2", "f16"):
                 ctx = api.Context(0, sc_arith=arith)
