@@ -341,8 +341,8 @@ __device__ void sort_wave_body(const SortArgs& a, int q, int lane) {
       z[h][cc] = (d0 == d0) ? chan_z(S, cc, d) : __builtin_nan("");
     }
   }
-  double pv = 0.0, pz[4] = {0.0, 0.0, 0.0, 0.0}, sk = __builtin_nan("");
-  bool have_prev = false;
+  double pv = 0.0, pz[4] = {0.0, 0.0, 0.0, 0.0}, sk = __builtin_nan(""), kth_v = 0.0, kth_z[4] = {0.0, 0.0, 0.0, 0.0};
+  bool have_prev = false, kth_ev = false;
   int flag = 0;
   const int rounds = check ? k + 1 : k;
   for (int t = 0; t < rounds; t++) {
@@ -368,6 +368,7 @@ __device__ void sort_wave_body(const SortArgs& a, int q, int lane) {
       double wz[4];
       for (int cc = 0; cc < 4; cc++) wz[cc] = __shfl(bc < 64 ? z[0][cc] : z[1][cc], bc & 63, 64);
       const bool evd = wz[0] == wz[0];                      // evaluated (masked: +Inf, pruned: pass score - NaN distances)
+      if (t == k - 1) { kth_ev = evd; kth_v = bv; for (int cc = 0; cc < 4; cc++) kth_z[cc] = wz[cc]; }
       if (have_prev && evd) {
         double lim = 0.0, span = 0.0;
         for (int cc = 0; cc < 4; cc++) { const double dz = fabs(wz[cc] - pz[cc]); lim += S.eps[cc] * dz; span += dz; }
@@ -379,6 +380,17 @@ __device__ void sort_wave_body(const SortArgs& a, int q, int lane) {
     }
     if (bc == lane) { j[0] = -1; v[0] = __builtin_nan(""); }
     if (bc == lane + 64) { j[1] = -1; v[1] = __builtin_nan(""); }
+  }
+  if (check && kth_ev) {                                     // no candidate still in the lanes may overtake the k-th selected one (order_check_kernel)
+    int f2 = 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      if (j[h] < 0 || !(z[h][0] == z[h][0])) continue;       // retired, absent, or not evaluated
+      double lim = 0.0, span = 0.0;
+      for (int cc = 0; cc < 4; cc++) { const double dz = fabs(z[h][cc] - kth_z[cc]); lim += S.eps[cc] * dz; span += dz; }
+      if (span > 0.0 && !(v[h] - kth_v > lim)) f2 = 1;
+    }
+    if (__any(f2)) flag |= 1;
   }
   if (check && a.cand_sc && not_contained(S, a.eps_d, a.cand_sc[(size_t)q * kin + kin - 1], sk)) flag |= 2;
   if (a.order_flags && lane == 0) a.order_flags[q] = flag;
@@ -447,6 +459,7 @@ __global__ __launch_bounds__(64) void order_check_kernel(const double* __restric
     for (int cc = 0; cc < 4; cc++) z[h][cc] = ev[h] ? chan_z(S, cc, p5_all[p5_at(own, m, q, 1 + cc, kin, c)]) : __builtin_nan("");
     sel[h] = 0;
   }
+  bool has_out = false;
   for (int u = 0; u < k; u++) {                                // (wave-uniform loads)
     const int want = idx_sel[(size_t)q * k + u];
     if (want < 0) break;                                       // fewer than k entries exist
@@ -465,6 +478,7 @@ __global__ __launch_bounds__(64) void order_check_kernel(const double* __restric
       if (oj >= 0 && (bj < 0 || cand_before(ov, oj, bv, bj))) { bv = ov; bj = oj; }
     }
     if (bj >= 0) { if (j[0] == bj) sel[0] = 1; if (j[1] == bj) sel[1] = 1; }
+    has_out = bj >= 0;
   }
   for (int h = 0; h < 2; h++) { s_v[lane + 64 * h] = v[h]; s_j[lane + 64 * h] = j[h]; s_in[lane + 64 * h] = sel[h]; }
   __syncthreads();
@@ -492,6 +506,19 @@ __global__ __launch_bounds__(64) void order_check_kernel(const double* __restric
       lim += S.eps[cc] * dz; span += dz;
     }
     if (span > 0.0 && !(t_v[p + 1] - t_v[p] > lim)) flag = 1;
+  }
+  // ... and no candidate further down may overtake the k-th selected one: the chain above orders the selected k and the best one left out,
+  // but a candidate of another channel composition anywhere in the list can leap over all of them when the sigmas move (tools/fuzz_all.py
+  // seed 13 case 21: rank 43 of the f16-statistics order was rank 2 of the true one)
+  {
+    const int kk = has_out ? nS - 2 : nS - 1;
+    if (kk >= 0 && t_ev[kk])
+      for (int h = 0; h < 2; h++) {
+        if (sel[h] || !ev[h] || j[h] < 0) continue;
+        double lim = 0.0, span = 0.0;
+        for (int cc = 0; cc < 4; cc++) { const double dz = fabs(z[h][cc] - t_z[cc][kk]); lim += S.eps[cc] * dz; span += dz; }
+        if (span > 0.0 && !(v[h] - t_v[kk] > lim)) flag = 1;
+      }
   }
   flag = __any(flag) ? 1 : 0;
   // (bit 1) the containment check of not_contained(): cand_sc = the candidates' pass scores [m][kin], score_sel = the exact scores of the k selected

@@ -117,6 +117,8 @@ def f16_tol(osc, n=None, note=""):
     """tests/test_gpu_f16.py: score_tol_f16; rows of a handful of entries have no meaningful sigma in the f16 pass (indices still checked).
     The same for the dense intensity channels of spoil(): ~1000 ones per row leave the row's distances a sigma of ~1e-3, which the f16 pass's
     3e-5 of distance noise moves by percents - PR_SC_ARITH_F16 returns exact indices there, its scores only to ~5e-2 (seed 61, case 33)."""
+    if "cluster" in note:       # rows dominated by near-copies have sigma ~ 4e-3: the f16 pass's 1e-4 of (shared) distance error moves it by percents
+        return 1e-1 + 3e-3 * np.abs(osc)
     return (3e-2 + 1e-3 * np.abs(osc)) * (1.0 if (n is None or n >= 32) and "dense db" not in note and "full db" not in note else np.inf)
 
 
