@@ -559,7 +559,7 @@ def main():
         ach = pairs * fpp / (kms * 1e-3) / 1e12
         traffic = None   # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE)
         traffic_file = None
-        for cand in (("r04b_traffic.json",) if binary else ("r04_traffic.json", "r03_traffic.json")):   # the newest committed PMC passes of this command
+        for cand in (("r05_traffic.json", "r04b_traffic.json") if binary else ("r04_traffic.json", "r03_traffic.json")):   # the newest committed PMC passes of this command
             try:
                 tr = json.load(open(os.path.join(ROOT, "profiles", cand)))
                 if tr["workload"] == {"db": n, "queries": m, "n_gpus": world}:
