@@ -238,15 +238,10 @@ __global__ __launch_bounds__(256) void xrow_qspec_kernel(XrowArgs A, const doubl
 // (868 multiply-adds per row instead of 3600).  The row sits in this lane's registers, the twiddles are wave-uniform (scalar loads at constant
 // offsets: the loops are fully unrolled).  twfs: [f = 0 .. 30][s = 1 .. 14]{cos, sin}(2 pi f s / 60).
 __constant__ double g_twfs[31 * 14 * 2];                       // set per device by xrow_set_twiddles (pr_create): constant address space = scalar loads
-template <typename T>
-__device__ __forceinline__ void xrow_dft_row(const T* __restrict__ px /* element (ring, sector 0); sectors 20 apart */,
-                                             double* __restrict__ out /* [31][2] */, double& ssq) {
+__device__ __forceinline__ void xrow_dft_row(const double (&x)[60], double* __restrict__ out /* [31][2] */, double& ssq) {
   int tz = 0;
   asm volatile("" : "+s"(tz));                                  // (an opaque zero in the index keeps the 868 twiddle loads inside the call: hoisted out of the tile loop they spill ~3000 SGPRs)
   const double* twfs = g_twfs + tz;
-  double x[60];
-#pragma unroll
-  for (int sct = 0; sct < 60; sct++) x[sct] = (double)px[sct * 20];
   ssq = 0.0;
 #pragma unroll
   for (int sct = 0; sct < 60; sct++) ssq += x[sct] * x[sct];
@@ -291,6 +286,7 @@ constexpr int XG = 4;                         // slots per group
 constexpr int XT = XG * XE * 2 * 62;          // doubles of the column store [XG][XE][variant][31]{X, Y}
 constexpr size_t XROW_SC_LDS = ((size_t)XE * XQ + XG * XQ + XT + 4 * 64 + RESOLVE_SLOTS * XE + XE + RESOLVE_SLOTS * 2 * 3 + RESOLVE_SLOTS * 2) * 8;   // 160 KB less 2.8 KB
 __constant__ double g_tw2[16 * 31 * 2];       // [k = 0 .. 15][f]{cos, sin}(2 pi f k / 60), set with g_twfs
+template <typename T>
 __global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* __restrict__ qspec, int finish) {
   extern __shared__ __attribute__((aligned(16))) double xl[];
   double* spec = xl;                                            // [XE][20][31][2]
@@ -316,6 +312,9 @@ __global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* 
   const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ngroups = (ns + XG - 1) / XG;
   const int ntile = (n + XE - 1) / XE;
+  // (Holding the NEXT (tile, channel)'s ring row in registers while the current one is worked on - 60 loads under a whole unit of
+  //  arithmetic - was built and measured: with fp64 signatures the 120 extra registers spill 161 VGPRs to scratch and the pass takes 3.2
+  //  instead of 1.3 ms for one slot.  The row is loaded where it is used.)
   for (int tile = b; tile < ntile; tile += A.NB) {
     const int j0 = tile * XE, ne = n - j0 < XE ? n - j0 : XE;
     for (int ch = 0; ch < 2; ch++) {
@@ -337,13 +336,15 @@ __global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* 
       __syncthreads();                                          // the previous (tile, channel)'s readers of spec / rnd / dtile / qs are done
       q_store();
       if (tid < 160) {
-        const int e = tid / 20, r = tid % 20;
+        const int e = tid / 20;
         double ssq = 0.0;
         double* out = spec + (size_t)tid * 62;
         if (e < ne) {
-          const size_t off = (size_t)(j0 + e) * 2400 + ch * 1200 + r;
-          if (A.sc_dt == 0) xrow_dft_row(static_cast<const double*>(A.db_sc) + off, out, ssq);
-          else xrow_dft_row(static_cast<const float*>(A.db_sc) + off, out, ssq);
+          const T* px = static_cast<const T*>(A.db_sc) + (size_t)(j0 + e) * 2400 + ch * 1200 + tid % 20;
+          double x[60];
+#pragma unroll
+          for (int sct = 0; sct < 60; sct++) x[sct] = (double)px[sct * 20];
+          xrow_dft_row(x, out, ssq);
         } else {
           for (int i = 0; i < 62; i++) out[i] = 0.0;
         }
@@ -555,8 +556,8 @@ struct SelArgs {
   int q_row0, db_row0, mask_width;
   double p_weight; int has_sc, has_m2, k;
   const double* rows;                                           // [RESOLVE_SLOTS][4][n_local]
-  double* sel;                                                  // [RESOLVE_SLOTS][2][k] (sharded) or null
-  int32_t* idx; double* score;                                  // [m][k], written when sel is null (single shard)
+  double* part;                                                 // [P][RESOLVE_SLOTS][2][k] the slices' lists (xrow_merge_kernel's input layout: slice = "shard")
+  int P;                                                        // slices per row: workgroup (slot, p) sweeps entries [n p / P, n (p + 1) / P)
   double* mom_sc; double* mom_m2;                               // single shard, or null: the caller's moments rows [m][2][3] become the exact ones
 };
 
@@ -566,10 +567,11 @@ __global__ __launch_bounds__(256) void xrow_select_kernel(SelArgs A) {
   __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
   __shared__ double rv[256];
   __shared__ int rj[256];
-  const int s = blockIdx.x, tid = threadIdx.x;
+  const int s = blockIdx.x, sl = blockIdx.y, tid = threadIdx.x;
   const int total = flagged_slots(A.flags, A.m, A.list, A.cnt, A.offset, s_list, s_tmp, tid, 256);
   if (A.offset + s >= total) return;
   const int q = s_list[s], n = A.n_local, k = A.k;
+  const int j_lo = (int)((long long)n * sl / A.P), j_hi = (int)((long long)n * (sl + 1) / A.P);
   double w[4] = {A.has_sc ? A.p_weight : 0.0, A.has_sc ? 1.0 : 0.0, A.has_m2 ? A.p_weight : 0.0, A.has_m2 ? 1.0 : 0.0}, mean[4], sd[4];
   for (int c = 0; c < 4; c++) {
     mean[c] = 0.0; sd[c] = 1.0;
@@ -577,7 +579,7 @@ __global__ __launch_bounds__(256) void xrow_select_kernel(SelArgs A) {
     double loc[3];
     exact_combine(A.exact_all, A.G, A.m, q, c, mean[c], sd[c], loc);
     double* mo = c < 2 ? A.mom_sc : A.mom_m2;
-    if (mo && tid < 3) mo[((size_t)q * 2 + (c & 1)) * 3 + tid] = loc[tid];
+    if (mo && sl == 0 && tid < 3) mo[((size_t)q * 2 + (c & 1)) * 3 + tid] = loc[tid];
   }
   const double* row = A.rows + (size_t)s * 4 * n;
   const int ig = A.q_row0 + q;
@@ -591,20 +593,18 @@ __global__ __launch_bounds__(256) void xrow_select_kernel(SelArgs A) {
     if (dij < A.mask_width) f = __builtin_inf();
     return f;
   };
-  auto emit = [&](int t, double v, int jg) {
-    if (A.sel) { A.sel[((size_t)s * 2 + 0) * k + t] = jg >= 0 ? v : __builtin_nan(""); A.sel[((size_t)s * 2 + 1) * k + t] = (double)jg; }
-    else { A.idx[(size_t)q * k + t] = jg; A.score[(size_t)q * k + t] = jg >= 0 ? v : __builtin_nan(""); }
-  };
+  double* mine = A.part + (((size_t)sl * RESOLVE_SLOTS + s) * 2) * k;
+  auto emit = [&](int t, double v, int jg) { mine[t] = jg >= 0 ? v : __builtin_nan(""); mine[k + t] = (double)jg; };
   // the k smallest (score, index) pairs, one sweep of the row per element (run_test.m:57: ties -> lower index, NaN never)
   double pv = -__builtin_inf();
   int pj = -1;
   for (int t = 0; t < k; t++) {
     double bv = 0.0;
     int bj = -1;
-    for (int j4 = tid; j4 < n; j4 += 1024) {                   // four entries per round: their loads are in flight together
+    for (int j4 = j_lo + tid; j4 < j_hi; j4 += 1024) {         // four entries per round: their loads are in flight together
       double f4[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) { const int j = j4 + 256 * u; f4[u] = j < n ? fused(j) : __builtin_nan(""); }
+      for (int u = 0; u < 4; u++) { const int j = j4 + 256 * u; f4[u] = j < j_hi ? fused(j) : __builtin_nan(""); }
 #pragma unroll
       for (int u = 0; u < 4; u++) {
         const double f = f4[u];
@@ -633,11 +633,12 @@ __global__ __launch_bounds__(256) void xrow_select_kernel(SelArgs A) {
   }
 }
 
-// sel_all [G][RESOLVE_SLOTS][2][k] -> idx / score [m][k] of the slot's query: every shard's list is ascending by (score, index) with its
-// missing entries (-1 / NaN) last; lane g walks list g
+// sel_all [G][RESOLVE_SLOTS][2][k] -> idx / score [m][k] of the slot's query (or the merged list sel_out [RESOLVE_SLOTS][2][k]): every
+// list is ascending by (score, index) with its missing entries (-1 / NaN) last; lane g walks list g.  Two uses: the G shards' lists of a
+// sharded call, and the P row slices of xrow_select_kernel
 __global__ __launch_bounds__(64) void xrow_merge_kernel(const int32_t* __restrict__ flags, const int32_t* __restrict__ list, const int32_t* __restrict__ cnt,
                                                          int offset, const double* __restrict__ sel_all, int G, int m, int k,
-                                                         int32_t* __restrict__ idx, double* __restrict__ score) {
+                                                         int32_t* __restrict__ idx, double* __restrict__ score, double* __restrict__ sel_out) {
   __shared__ int s_list[RESOLVE_SLOTS], s_tmp[6];
   const int s = blockIdx.x, lane = threadIdx.x;
   const int total = flagged_slots(flags, m, list, cnt, offset, s_list, s_tmp, lane, 64);
@@ -662,8 +663,13 @@ __global__ __launch_bounds__(64) void xrow_merge_kernel(const int32_t* __restric
     }
     const bool ok = bj >= 0 && bv == bv;
     if (lane == 0) {
-      idx[(size_t)q * k + t] = ok ? bj : -1;
-      score[(size_t)q * k + t] = ok ? bv : __builtin_nan("");
+      if (sel_out) {                                            // (a shard's own list, for the all-gather: [RESOLVE_SLOTS][2][k])
+        sel_out[((size_t)s * 2 + 0) * k + t] = ok ? bv : __builtin_nan("");
+        sel_out[((size_t)s * 2 + 1) * k + t] = ok ? (double)bj : -1.0;
+      } else {
+        idx[(size_t)q * k + t] = ok ? bj : -1;
+        score[(size_t)q * k + t] = ok ? bv : __builtin_nan("");
+      }
     }
     if (ok && bl == lane) cur++;
   }
@@ -718,9 +724,14 @@ void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt,
   XrowArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, fl, list, cnt, offset, NB, partial, exact, rows, tick, dflags};
   const int slots = m < RESOLVE_SLOTS ? m : RESOLVE_SLOTS;
   if (q_sc) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_sc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_SC_LDS);
     hipLaunchKernelGGL(xrow_qspec_kernel, dim3(slots, 2), dim3(256), 0, st, A, tw, qspec);
-    hipLaunchKernelGGL(xrow_sc_kernel, dim3(NB), dim3(256), XROW_SC_LDS, st, A, (const double*)qspec, q_m2 ? 0 : 1);
+    if (sc_dt == 0) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_sc_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_SC_LDS);
+      hipLaunchKernelGGL(xrow_sc_kernel<double>, dim3(NB), dim3(256), XROW_SC_LDS, st, A, (const double*)qspec, q_m2 ? 0 : 1);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_sc_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_SC_LDS);
+      hipLaunchKernelGGL(xrow_sc_kernel<float>, dim3(NB), dim3(256), XROW_SC_LDS, st, A, (const double*)qspec, q_m2 ? 0 : 1);
+    }
   }
   if (q_m2) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_m2dp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_M2_LDS);
@@ -728,20 +739,28 @@ void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt,
   }
 }
 
+int xrow_select_slices(int m) { const int slots = m < RESOLVE_SLOTS ? m : RESOLVE_SLOTS; int P = 512 / slots; return P < 1 ? 1 : (P > 64 ? 64 : P); }
+size_t xrow_select_part_doubles(int m, int k) { return (size_t)xrow_select_slices(m) * RESOLVE_SLOTS * 2 * (size_t)k; }
+
+// the row slices' lists, then their merge: into sel (sharded: the shard's list for the all-gather) or, sel = null, straight into idx / score
 void launch_xrow_select(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G,
                         int m, int n_local, int q_row0, int db_row0, int mask_width, double p_weight, int has_sc, int has_m2, int k,
-                        const double* rows, double* sel, int32_t* idx, double* score, double* out_mom_sc, double* out_mom_m2) {
+                        const double* rows, double* part, double* sel, int32_t* idx, double* score, double* out_mom_sc, double* out_mom_m2) {
   if (m <= 0 || n_local <= 0) return;
-  SelArgs A{m <= RESOLVE_SMALL_M ? flags : nullptr, list, cnt, offset, exact_all, G, m, n_local, q_row0, db_row0, mask_width, p_weight, has_sc, has_m2, k,
-            rows, sel, idx, score, out_mom_sc, out_mom_m2};
-  hipLaunchKernelGGL(xrow_select_kernel, dim3(m < RESOLVE_SLOTS ? m : RESOLVE_SLOTS), dim3(256), 0, st, A);
+  const int slots = m < RESOLVE_SLOTS ? m : RESOLVE_SLOTS;
+  int P = xrow_select_slices(m);
+  while (P > 1 && n_local / P < 1024) P >>= 1;                  // (short rows: a slice of under a thousand entries is not worth a workgroup)
+  const int32_t* fl = m <= RESOLVE_SMALL_M ? flags : nullptr;
+  SelArgs A{fl, list, cnt, offset, exact_all, G, m, n_local, q_row0, db_row0, mask_width, p_weight, has_sc, has_m2, k, rows, part, P, out_mom_sc, out_mom_m2};
+  hipLaunchKernelGGL(xrow_select_kernel, dim3(slots, P), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(xrow_merge_kernel, dim3(slots), dim3(64), 0, st, fl, list, cnt, offset, (const double*)part, P, m, k, idx, score, sel);
 }
 
 void launch_xrow_merge(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* sel_all, int G, int m,
                        int k, int32_t* idx, double* score) {
   if (m <= 0) return;
   hipLaunchKernelGGL(xrow_merge_kernel, dim3(m < RESOLVE_SLOTS ? m : RESOLVE_SLOTS), dim3(64), 0, st, m <= RESOLVE_SMALL_M ? flags : nullptr, list, cnt,
-                     offset, sel_all, G, m, k, idx, score);
+                     offset, sel_all, G, m, k, idx, score, (double*)nullptr);
 }
 
 }  // namespace pr

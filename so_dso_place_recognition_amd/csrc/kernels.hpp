@@ -163,7 +163,9 @@ size_t xrow_qspec_doubles();
 hipError_t xrow_set_twiddles(const double* cos60, const double* sin60);   // once per device, before the first launch_xrow (constant memory of exact_row.hip)
 void launch_xrow_select(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* exact_all, int G,
                         int m, int n_local, int q_row0, int db_row0, int mask_width, double p_weight, int has_sc, int has_m2, int k,
-                        const double* rows, double* sel, int32_t* idx, double* score, double* out_mom_sc, double* out_mom_m2);
+                        const double* rows, double* part /* [xrow_select_part_doubles(m, k)] scratch: the row slices' lists */, double* sel, int32_t* idx,
+                        double* score, double* out_mom_sc, double* out_mom_m2);
+size_t xrow_select_part_doubles(int m, int k);
 void launch_xrow_merge(hipStream_t st, const int32_t* flags, const int32_t* list, const int32_t* cnt, int offset, const double* sel_all, int G, int m,
                        int k, int32_t* idx, double* score);
 void launch_rerank_finish(hipStream_t st, const int32_t* cand_idx, const double* p5_all, int G, int m, int kin, int k, int32_t* idx,

@@ -51,6 +51,8 @@ struct pr_ctx {
   double* xrows = nullptr;        // [min(m, RESOLVE_SLOTS)][4][n_local] exact rows of the flagged queries of one pass (exact_row.hip), grow-only
   size_t xrows_cap = 0;
   double* xqspec = nullptr;       // query spectra of one pass's slots (exact_row.hip), allocated with res_partial
+  double* xpart = nullptr;        // the row slices' lists of the exact-row selection, grow-only
+  size_t xpart_cap = 0;
   bool xrow_direct = false;       // PR_XROW=direct: exact rows in the reference's own formulation (tests: cross-check of the spectral form)
   void* d_cst_h = nullptr;       // split-f16 stage-2 constants [E|O][half][hi|lo][64 lanes][8 f16] (sc_match_h.hip)
   int sc_kernel = 2;             // split-f16 SC matcher for m > 8: 2 = sc_match_e.hip (default); PR_SC_KERNEL=h selects sc_match_h.hip (0, round 1; always the kernel for m <= 8)
@@ -338,6 +340,7 @@ void pr_destroy(pr_ctx* ctx) {
   if (ctx->res_exact) (void)hipFree(ctx->res_exact);
   if (ctx->xrows) (void)hipFree(ctx->xrows);
   if (ctx->xqspec) (void)hipFree(ctx->xqspec);
+  if (ctx->xpart) (void)hipFree(ctx->xpart);
   if (ctx->sel_scratch) (void)hipFree(ctx->sel_scratch);
   if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
@@ -875,6 +878,16 @@ static int resolve_scratch(pr_ctx* ctx, int32_t m_exact, int32_t m, int32_t n_lo
   return PR_OK;
 }
 
+static int select_scratch_x(pr_ctx* ctx, int32_t m, int32_t k) {
+  const size_t need = pr::xrow_select_part_doubles(m, k);
+  if (need > ctx->xpart_cap) {
+    if (ctx->xpart) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->xpart)); ctx->xpart = nullptr; ctx->xpart_cap = 0; }
+    PR_HIP(ctx, hipMalloc((void**)&ctx->xpart, need * sizeof(double)));
+    ctx->xpart_cap = need;
+  }
+  return PR_OK;
+}
+
 int pr_rerank_width(const pr_ctx* ctx, int32_t k) { return ctx ? rerank_width(k, ctx->sc_mode) : PR_EINVAL; }
 
 static bool order_consts(const pr_ctx* ctx, double& fl, double& noise) {
@@ -918,7 +931,7 @@ static void resolve_pass(pr_ctx* ctx, const void* q_sc, const void* db_sc, int s
   pr::launch_xrow(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, 1, m, n, ctx->d_order, res_list(ctx), res_cnt(ctx),
                   offset, compacted, ctx->res_partial, ctx->res_exact, ctx->xrows, res_tick(ctx), dflags, ctx->xqspec, ctx->d_twiddle, ctx->xrow_direct);
   pr::launch_xrow_select(ctx->stream, ctx->d_order, res_list(ctx), res_cnt(ctx), offset, ctx->res_exact, 1, m, n, q_row0, 0, mask_width, p_weight,
-                         q_sc != nullptr, q_m2 != nullptr, k, ctx->xrows, nullptr, idx, score, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr);
+                         q_sc != nullptr, q_m2 != nullptr, k, ctx->xrows, ctx->xpart, nullptr, idx, score, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr);
 }
 
 static int resolve_args_ok(pr_ctx* ctx, const char* who, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2,
@@ -939,6 +952,7 @@ int pr_order_resolve_async_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc,
   if (m == 0 || ctx->order_m != m) { ctx->order_m = -1; return PR_OK; }   // no (fresh) flags of a call of this shape
   if (int rc = set_device(ctx)) return rc;
   if (int rc = resolve_scratch(ctx, m, m, n)) return rc;
+  if (int rc = select_scratch_x(ctx, m, k)) return rc;
   ctx->order_m = -1;
   resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, k, idx, score, 0, false, ctx->d_flags);
   PR_HIP(ctx, hipGetLastError());
@@ -954,6 +968,7 @@ int pr_order_resolve_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int s
   if (m == 0 || ctx->order_m != m) { ctx->order_m = -1; return PR_OK; }
   if (int rc = set_device(ctx)) return rc;
   if (int rc = resolve_scratch(ctx, m, m, n)) return rc;
+  if (int rc = select_scratch_x(ctx, m, k)) return rc;
   ctx->order_m = -1;
   pr::launch_flag_compact(ctx->stream, ctx->d_order, m, res_list(ctx), res_cnt(ctx));
   int32_t cnt = 0;
@@ -1044,8 +1059,9 @@ int pr_order_exact_select_dev(pr_ctx* ctx, const double* exact_all, int32_t G, i
       ctx->xrows_cap < (size_t)(m < pr::RESOLVE_SLOTS ? m : pr::RESOLVE_SLOTS) * 4 * (size_t)n_local)
     PR_FAIL(ctx, PR_EINVAL, "pr_order_exact_select_dev: no rows of a %d-query pr_order_exact_moments_dev over %d entries on this context", m, n_local);
   if (int rc = set_device(ctx)) return rc;
+  if (int rc = select_scratch_x(ctx, m, k)) return rc;
   pr::launch_xrow_select(ctx->stream, ctx->d_order, res_list(ctx), res_cnt(ctx), offset, exact_all, G, m, n_local, q_row0, db_row0, mask_width,
-                         p_weight, has_sc, has_m2, k, ctx->xrows, sel, nullptr, nullptr, nullptr, nullptr);
+                         p_weight, has_sc, has_m2, k, ctx->xrows, ctx->xpart, sel, nullptr, nullptr, nullptr, nullptr);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
