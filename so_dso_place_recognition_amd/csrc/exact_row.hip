@@ -458,12 +458,17 @@ __global__ __launch_bounds__(256) void xrow_sc_kernel(XrowArgs A, const double* 
 
 // processM2DP.m:12-22 for the pass's slots over tiles of XE entries: the 4 x 4 row products of a (slot, entry) pair per channel,
 // thread = (entry, 2 query rows, 2 entry rows, an eighth of the 192 columns)
-constexpr size_t XROW_M2_LDS = ((size_t)XE * 4 * 192 + 2 * 4 * 192 + RESOLVE_SLOTS * XE + RESOLVE_SLOTS * 2 * 3 + RESOLVE_SLOTS * 2) * 8;
-__global__ __launch_bounds__(256) void xrow_m2dp_kernel(XrowArgs A, int sc_too) {
+constexpr int XMR = 196;                      // row stride of the LDS copies in doubles: 2 XMR = 8 and 4 XMR = 16 (mod 32 doubles = the 64 banks), so the four
+                                              // (entry, row pair) combinations of a wave and its eight column lanes read 32 different bank pairs (a stride of
+                                              // 192 with contiguous column parts put them on four: 8-way conflicts, 7.4 k cycles per slot and tile)
+constexpr size_t XROW_M2_LDS = ((size_t)XE * 4 * XMR + 2 /* XGM */ * 4 * XMR + RESOLVE_SLOTS * XE + RESOLVE_SLOTS * 2 * 3 + RESOLVE_SLOTS * 2) * 8;
+constexpr int XGM = 2;                        // slots per group here: 71 KB of LDS, two workgroups (two waves per SIMD) per CU - the kernel is latency-bound
+template <typename T>
+__global__ __launch_bounds__(256, 2) void xrow_m2dp_kernel(XrowArgs A, int sc_too) {
   extern __shared__ __attribute__((aligned(16))) double xl[];
-  double* dr = xl;                                              // [XE][4][192] the tile's rows of this channel
-  double* qr = dr + (size_t)XE * 4 * 192;                       // [2][4][192] a slot's query rows (two buffers: the next slot's arrive while this one is used)
-  double* dtile = qr + 2 * 4 * 192;                             // [RESOLVE_SLOTS][XE] this (tile, channel)'s distances
+  double* dr = xl;                                              // [XE][4][XMR] the tile's rows of this channel
+  double* qr = dr + (size_t)XE * 4 * XMR;                       // [XGM][4][XMR] the query rows of a group of slots
+  double* dtile = qr + XGM * 4 * XMR;                             // [RESOLVE_SLOTS][XE] this (tile, channel)'s distances
   double* acc = dtile + RESOLVE_SLOTS * XE;                     // [RESOLVE_SLOTS][2][3]
   double* piv = acc + RESOLVE_SLOTS * 2 * 3;                    // [RESOLVE_SLOTS][2]
   __shared__ double red[256];
@@ -479,45 +484,64 @@ __global__ __launch_bounds__(256) void xrow_m2dp_kernel(XrowArgs A, int sc_too) 
   for (int tile = b; tile < ntile; tile += A.NB) {
     const int j0 = tile * XE, ne = n - j0 < XE ? n - j0 : XE;
     for (int ch = 0; ch < 2; ch++) {
-      double qn[3];                                              // 768 doubles / 256 threads
-      auto q_fetch = [&](int s) {
-        const int q = s_list[s];
+      const T* qsig = static_cast<const T*>(A.q_m2);
+      const T* dsig = static_cast<const T*>(A.db_m2);
+      T qn[3 * XGM];                                             // a group's query rows on their way to LDS: XGM slots x 768 values / 256 threads
+      auto q_fetch = [&](int g) {                                // (one slot per barrier left every iteration waiting for its own ~2 k cycles of load latency)
 #pragma unroll
-        for (int u = 0; u < 3; u++) { const int i = tid + 256 * u; qn[u] = ld(A.q_m2, A.m2_dt, ((size_t)q * 4 + i / 192) * 384 + ch * 192 + i % 192); }
+        for (int u = 0; u < 3 * XGM; u++) {
+          const int i = tid + 256 * u;
+          int sl = g * XGM + i / 768;
+          if (sl >= ns) sl = ns - 1;                             // (a ragged last group repeats the pass's last slot: its results are not stored)
+          qn[u] = qsig[((size_t)s_list[sl] * 4 + (i % 768) / 192) * 384 + ch * 192 + i % 192];
+        }
       };
-      auto q_store = [&](int s) {
-        double* qd = qr + (size_t)(s & 1) * 4 * 192;
+      auto q_store = [&]() {
 #pragma unroll
-        for (int u = 0; u < 3; u++) qd[tid + 256 * u] = qn[u];
+        for (int u = 0; u < 3 * XGM; u++) { const int i = tid + 256 * u; qr[((i / 768) * 4 + (i % 768) / 192) * XMR + i % 192] = (double)qn[u]; }
       };
       q_fetch(0);
       __syncthreads();                                          // the previous (tile, channel)'s readers of dr / qr / dtile are done
-      q_store(0);
-      for (int i = tid; i < XE * 4 * 192; i += 256) {
-        const int ee = i / (4 * 192), rr = (i / 192) & 3, c = i % 192;
-        dr[i] = ee < ne ? ld(A.db_m2, A.m2_dt, ((size_t)(j0 + ee) * 4 + rr) * 384 + ch * 192 + c) : 0.0;
+      q_store();
+      {                                                         // the tile: 24 values per thread, all requested before the first is stored
+        T tv[24];
+#pragma unroll
+        for (int u = 0; u < 24; u++) {
+          const int i = tid + 256 * u, ee = i / (4 * 192), rr = (i / 192) & 3, c = i % 192;
+          tv[u] = ee < ne ? dsig[((size_t)(j0 + ee) * 4 + rr) * 384 + ch * 192 + c] : (T)0;
+        }
+#pragma unroll
+        for (int u = 0; u < 24; u++) {
+          const int i = tid + 256 * u, ee = i / (4 * 192), rr = (i / 192) & 3, c = i % 192;
+          dr[(ee * 4 + rr) * XMR + c] = (double)tv[u];
+        }
       }
       __syncthreads();
-      for (int s = 0; s < ns; s++) {
-        if (s + 1 < ns) q_fetch(s + 1);
-        double d00 = 0.0, d01 = 0.0, d10 = 0.0, d11 = 0.0;
-        const double* q0 = qr + (size_t)(s & 1) * 4 * 192 + (2 * ab) * 192 + cp * 24;
-        const double* d0 = dr + ((size_t)e * 4 + 2 * bb) * 192 + cp * 24;
+      const int ngroups = (ns + XGM - 1) / XGM;
+      for (int g = 0; g < ngroups; g++) {
+        if (g + 1 < ngroups) q_fetch(g + 1);
 #pragma unroll
-        for (int c = 0; c < 24; c++) {
-          const double qa = q0[c], qb = q0[192 + c], da = d0[c], db = d0[192 + c];
-          d00 += qa * da; d01 += qa * db; d10 += qb * da; d11 += qb * db;
-        }
+        for (int sg = 0; sg < XGM; sg++) {
+          double d00 = 0.0, d01 = 0.0, d10 = 0.0, d11 = 0.0;
+          const double* q0 = qr + (size_t)(sg * 4 + 2 * ab) * XMR + cp;     // columns cp, cp + 8, ...: the eight column lanes read 64 contiguous bytes
+          const double* d0 = dr + ((size_t)e * 4 + 2 * bb) * XMR + cp;
 #pragma unroll
-        for (int sft = 1; sft < 8; sft <<= 1) {                  // the eight column parts: an xor butterfly (all lanes end with the same sums)
-          d00 += __shfl_xor(d00, sft, 64); d01 += __shfl_xor(d01, sft, 64); d10 += __shfl_xor(d10, sft, 64); d11 += __shfl_xor(d11, sft, 64);
+          for (int c = 0; c < 192; c += 8) {
+            const double qa = q0[c], qb = q0[XMR + c], da = d0[c], db = d0[XMR + c];
+            d00 += qa * da; d01 += qa * db; d10 += qb * da; d11 += qb * db;
+          }
+#pragma unroll
+          for (int sft = 1; sft < 8; sft <<= 1) {                // the eight column parts: an xor butterfly (all lanes end with the same sums)
+            d00 += __shfl_xor(d00, sft, 64); d01 += __shfl_xor(d01, sft, 64); d10 += __shfl_xor(d10, sft, 64); d11 += __shfl_xor(d11, sft, 64);
+          }
+          double mn = nanmin(nanmin((1.0 - d00) / 2.0, (1.0 - d01) / 2.0), nanmin((1.0 - d10) / 2.0, (1.0 - d11) / 2.0));   // processM2DP.m:15,19
+          mn = nanmin(mn, __shfl_xor(mn, 8, 64));
+          mn = nanmin(mn, __shfl_xor(mn, 16, 64));
+          const int sl = g * XGM + sg;
+          if ((tid & 31) == 0 && sl < ns) dtile[sl * XE + e] = mn;
         }
-        double mn = nanmin(nanmin((1.0 - d00) / 2.0, (1.0 - d01) / 2.0), nanmin((1.0 - d10) / 2.0, (1.0 - d11) / 2.0));   // processM2DP.m:15,19
-        mn = nanmin(mn, __shfl_xor(mn, 8, 64));
-        mn = nanmin(mn, __shfl_xor(mn, 16, 64));
-        if ((tid & 31) == 0) dtile[s * XE + e] = mn;
-        if (s + 1 < ns) q_store(s + 1);
-        __syncthreads();
+        __syncthreads();                                        // every reader of this group's rows is done
+        if (g + 1 < ngroups) { q_store(); __syncthreads(); }
       }
       for (int i = tid; i < ns * XE; i += 256) {
         const int s = i / XE, ee = i % XE;
@@ -733,9 +757,15 @@ void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt,
       hipLaunchKernelGGL(xrow_sc_kernel<float>, dim3(NB), dim3(256), XROW_SC_LDS, st, A, (const double*)qspec, q_m2 ? 0 : 1);
     }
   }
-  if (q_m2) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_m2dp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_M2_LDS);
-    hipLaunchKernelGGL(xrow_m2dp_kernel, dim3(NB), dim3(256), XROW_M2_LDS, st, A, q_sc ? 1 : 0);
+  if (q_m2) {                               // (alone it runs two workgroups per CU; behind the SC kernel it shares that kernel's partial-sum geometry)
+    if (!q_sc) { A.NB = ntile < 512 ? ntile : 512; }
+    if (m2_dt == 0) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_m2dp_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_M2_LDS);
+      hipLaunchKernelGGL(xrow_m2dp_kernel<double>, dim3(A.NB), dim3(256), XROW_M2_LDS, st, A, q_sc ? 1 : 0);
+    } else {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_m2dp_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_M2_LDS);
+      hipLaunchKernelGGL(xrow_m2dp_kernel<float>, dim3(A.NB), dim3(256), XROW_M2_LDS, st, A, q_sc ? 1 : 0);
+    }
   }
 }
 

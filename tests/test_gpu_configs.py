@@ -419,6 +419,30 @@ def test_order_that_hangs_on_the_row_sigmas_is_resolved_with_fp64_statistics(api
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("type_", ["sc", "m2dp"])
+def test_exact_rows_from_float32_signatures(api, type_, monkeypatch):
+    """The exact-row kernels read the signatures in the dtype the caller holds them in: float32 tensors (half the HBM of a resident DB) must
+    give the oracle's answer for the same rounded numbers, every query through the exact rows, spectral form and direct form alike."""
+    import torch
+    from so_dso_place_recognition_amd.matcher import Matcher
+    m, n, k = 40, 900, 4
+    db = (synth.sc_database(61, n) if type_ == "sc" else synth.m2dp_database(61, n)).astype(np.float32)
+    q, _ = (synth.sc_queries if type_ == "sc" else synth.m2dp_queries)(62, db.astype(np.float64), m)
+    q = q.astype(np.float32)
+    rc, oidx, osc = oracle_lib.match_topk(0 if type_ == "sc" else 1, q.astype(np.float64), db.astype(np.float64), 3, 2.0, k)
+    dev = torch.device("cuda", 0)
+    for form in ("spectral", "direct"):
+        if form == "direct":
+            monkeypatch.setenv("PR_XROW", "direct")
+        mt = Matcher(type_, m, n, ctx=api.Context(0, exact_statistics=True, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
+        mt.pack_database(torch.from_numpy(db).to(dev))
+        idx, sc = mt.match(torch.from_numpy(q).to(dev), 3, 2.0, k)
+        assert np.array_equal(idx.cpu().numpy(), oidx), form
+        assert np.abs(sc.cpu().numpy() - osc).max() < 1e-9, form
+        mt.close()
+
+
+@pytest.mark.gpu
 def test_group_selftest_and_phase_timing(api):
     """pr_group_create runs every exchange of a call on scratch buffers and checks the rank order of what arrives (here: the copy exchange of
     virtual shards; RCCL on distinct devices); pr_group_set_timing / pr_group_last_timing give every shard's phase times of a call."""
