@@ -282,7 +282,8 @@ int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2
  *   pr_order_resolve_dev        the same with a host round trip (reads the count back): ALL flagged queries, *resolved (may be NULL)
  *                               = their number.  The host top-k calls use this one.
  *   sharded                     after pr_rerank_finish_dev, per pass (offset = 0, 64, ...; pr_order_flagged_count gives the total, with a host
- *                               synchronisation - a stream-ordered caller runs pass 0 only): pr_order_exact_moments_dev = this shard's rows of
+ *                               synchronisation - a stream-ordered caller runs pass 0 only and finds PR_WARN_ORDER_UNRESOLVED when that was
+ *                               not all; a caller that runs every pass does not): pr_order_exact_moments_dev = this shard's rows of
  *                               the flagged queries (kept in the context) and their exact (count, mean, M2), exact DEVICE f64 [m][4][3] (rows
  *                               of other queries: unspecified) -> all-gather -> exact_all [G][m][4][3] -> pr_order_exact_select_dev = this
  *                               shard's k best under the statistics of all shards (Chan combination in rank order), sel DEVICE f64 [64][2][k]

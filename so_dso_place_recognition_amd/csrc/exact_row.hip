@@ -120,7 +120,8 @@ struct XrowArgs {
 __device__ void xrow_finish(const XrowArgs& A, const int* s_list, int ns, int total, double* red, int tid) {
   if (tid == 0) {
     *A.tick = 0u;                                               // ready for the next launch
-    if (A.dflags) { A.dflags[2] = 1; if (total - A.offset > RESOLVE_SLOTS) A.dflags[3] = 1; }
+    // (a caller that runs every pass leaves [3] clear: the pass that reaches the end of the list takes back what the earlier ones announced)
+    if (A.dflags) { A.dflags[2] = 1; if (total - A.offset > RESOLVE_SLOTS) A.dflags[3] = 1; else if (A.offset > 0) A.dflags[3] = 0; }
   }
   auto part_at = [&](size_t i) {                                 // written by other workgroups: agent-scope loads (L2), no copy of this CU's L1
     return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(A.partial + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));

@@ -19,6 +19,21 @@ constexpr int SCH_QIMG = SC_NF * SCH_QBLK;      // 39 928 per (channel, 8-query 
 constexpr int SCH_DTILE = 768;                  // one 16x16x32 column operand: 48 lanes x 16 B
 constexpr int SCH_DFREQ = 4 * SCH_DTILE;        // Re hi, Re lo, Im hi, Im lo
 constexpr int SCH_DIMG = SC_NF * SCH_DFREQ;     // 95 232 per (channel, 16-entry DB group)
+// The three split products q_hi d_hi + q_hi d_lo + q_lo d_hi of a frequency's 20 rings are 60 terms; two 16x16x32 MFMAs have 64 K-slots, so
+// the matchers run them as TWO operand pairs (not three zero-padded ones) whose 16-byte lane pieces are all contiguous in these images:
+//   query row (80 B)   Q hi ring 0..19 | Q lo ring 16..19, 0..15      (the lo half rotated by four rings: Q hi 16..19 and Q lo 16..19 adjoin)
+//   DB hi tile         lanes 0-15 D hi 0..7 | 16-31 D hi 8..15 | 32-47 D hi 16..19, zero
+//   DB lo tile         lanes 0-15 D lo 0..7 | 16-31 D lo 8..15 | 32-47 D lo 16..19, D hi 16..19   (a copy of the hi values where zeros stood)
+//   pair 1:  A lanes (k = lane >> 4) at row + {0, 16, 32, 0}    x  B = hi tile lanes 0-47, lo tile lanes 0-15
+//            = Qhi Dhi (rings 0..19) + Qhi Dlo (0..7)                                        [k = 2: Q lo 16..19 meets the tile's zeros]
+//   pair 2:  A lanes at row + {48, 64, 32, 16}                 x  B = hi tile lanes 0-31, lo tile lanes 32-47, lo tile lanes 16-31
+//            = Qlo Dhi (0..15) + Qhi Dlo (16..19) + Qlo Dhi (16..19) + Qhi Dlo (8..15)
+// The single-product kernels read the hi tiles' 48 lanes and the first 40 bytes of a query row - unchanged by this.
+__host__ __device__ constexpr int sch_qlo_byte(int ring) { return 40 + ((ring + 4) % 20) * 2; }      // Q lo of a ring, from the row's first byte
+__host__ __device__ constexpr int sch_a1_byte(int k) { return k == 3 ? 0 : 16 * k; }                   // pair 1 / pair 2: this lane group's 16 B of the row
+__host__ __device__ constexpr int sch_a2_byte(int k) { return k == 0 ? 48 : k == 1 ? 64 : k == 2 ? 32 : 16; }
+__host__ __device__ constexpr int sch_b1_byte(int lane) { return lane < 48 ? lane * 16 : SCH_DTILE + (lane - 48) * 16; }   // from the hi tile's first byte
+__host__ __device__ constexpr int sch_b2_byte(int lane) { return lane < 32 ? lane * 16 : lane < 48 ? SCH_DTILE + lane * 16 : SCH_DTILE + (lane - 32) * 16; }
 // single-product f16 images (PR_SC_ARITH_F16, sc_match_e.hip): the hi halves only
 constexpr int SCF_QBLK = 648;                   // (8-query group, frequency): 16 rows x 40 B, rows 8..15 shifted by 8 B
 constexpr int SCF_QIMG = SC_NF * SCF_QBLK;      // 20 088 per (channel, 8-query group); a workgroup holds 8 groups = 64 queries

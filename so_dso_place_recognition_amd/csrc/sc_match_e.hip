@@ -1,5 +1,6 @@
 // sc_match_e.hip — the default SC matcher (processSC.m:22-33) in both f16 arithmetics: split-f16 (PR_SC_ARITH_F16X2: every fp32 factor as
-// f16 hi + lo, three MFMAs per product) and single product (PR_SC_ARITH_F16: hi only).
+// f16 hi + lo, three f16 products per product: in stage 1 as two MFMAs over 60 of 64 K-slots - the operand pairs of kernels.hpp -, in stage 2
+// as three MFMAs) and single product (PR_SC_ARITH_F16: hi only).
 //
 // Same mathematics, packed split images and stage-2 constants as sc_match_h.hip / sc_match_d.hip (read those headers first).  What changes:
 //
@@ -10,12 +11,12 @@
 //        swap32(T1_f, T1_f+8) = (QrDr_f | QrDr_f+8) =: X , (QiDr_f | QiDr_f+8) =: Y        swap32(T2'_f, T2'_f+8) = U (QrDi), V (QiDi)
 //        Re S = X + V   Im S = Y - U   Re P = X - V   Im P = Y + U           each already (f | f + 8) by lane half
 //    which is, after the split, exactly the operand layout sc_match_d reaches with 128 swaps of packed registers.
-//  * the schedule is a function of (quad, gap) - valu_slot<> below - instead of hand-written macro rows: 4 VALU instructions behind every
+//  * the schedule is a function of (quad, slot) - valu_slot<> below - instead of hand-written macro rows: 4 or 8 VALU instructions behind every
 //    stage-1 MFMA, the swaps / combination / split of a quad under the MFMAs of the next; DB tiles three walk positions ahead.
 //  * split-f16 (LO = true): one wave per SIMD, 4 query groups per workgroup; the packed operands of the whole unit are 256 registers, so
 //    the first half's are parked in AccVGPRs (park_half) and read from there by the stage-2 MFMAs.  ~3 % faster than sc_match_d; the
-//    cost model behind that (tools/ubench/mfma16_fillers.hip and the ablation table of DESIGN.md): one in-order wave adds up MFMA time (6 x 17.8 cycles per walk
-//    position), VALU beyond the two an MFMA hides (~4.4 cycles each; 8.5 for a permlane swap or an AccVGPR write), and ~22 cycles per
+//    cost model behind that (tools/ubench/mfma16_fillers.hip and the ablation table of DESIGN.md): one in-order wave adds up MFMA time (4 x 17.8 cycles per walk
+//    position; 6 x until round 5, when the three zero-padded split products became two full operand pairs), VALU beyond the two an MFMA hides (~4.4 cycles each; 8.5 for a permlane swap or an AccVGPR write), and ~22 cycles per
 //    operand request, vector or LDS alike - nothing overlaps much, whatever the placement.
 //  * single product (LO = false): the unit fits 256 registers, so the workgroup has EIGHT waves - two per SIMD, which do overlap - over
 //    8 query groups of the compact image (SCF_*: 64 queries in 160 KB of LDS); for m <= 8 (an online call) all eight waves share ONE query
@@ -75,18 +76,19 @@ __host__ __device__ constexpr int seqf(int P) { return 16 * (P >> 4) + ((P & 15)
 
 typedef const u32x4_a8 __attribute__((address_space(3))) * lds_tile_p;
 template <int T>
-__device__ __forceinline__ void load_a(AOps& a, unsigned addr) {   // addr = this lane's 16 B of the frequency's hi tile; lo tile at + 40
-  const u32x4 v = *reinterpret_cast<lds_tile_p>(addr + T * 40);
+__device__ __forceinline__ void load_a(AOps& a, unsigned addr) {   // addr = this lane's 16 B of the frequency's rows: operand pair 1 (h) | pair 2 (l), kernels.hpp
+  const u32x4 v = *reinterpret_cast<lds_tile_p>(addr);
   if (T == A_H) a.h = v; else a.l = v;
 }
 template <bool LO, int F, int T, bool SV = false>
 __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int voff) {
   // split-f16 image: [f][Re hi | Re lo | Im hi | Im lo]; single-product image: [f][Re | Im]
-  // split-f16 form: the frequency in the scalar offset (one SGPR per walk position, kept), the tile added to the lane offset - 64 s_mov per
-  // unit less, -0.6 %; the single-product form (registers are scarcer there) keeps everything in the scalar offset
+  // split-f16 form: the frequency in the scalar offset (one SGPR per walk position, kept), the Re | Im tile pair added to the lane offset - 64
+  // s_mov per unit less, -0.6 %; voff = the lane's place in the pair's hi + lo tiles for operand pair 1 (reh, imh) | pair 2 (rel, iml),
+  // kernels.hpp: sch_b1_byte / sch_b2_byte.  The single-product form (registers are scarcer there) keeps everything in the scalar offset
   // SV: the single-product form reading the hi tiles of a split-f16 image
   constexpr int soff = LO ? F * SCH_DFREQ : SV ? F * SCH_DFREQ + (T == B_IMH ? 2 : 0) * SCH_DTILE : F * SCF_DFREQ + (T == B_IMH ? 1 : 0) * SCH_DTILE,
-                ioff = LO ? T * SCH_DTILE : 0;
+                ioff = LO ? ((T == B_IMH || T == B_IML) ? 2 * SCH_DTILE : 0) : 0;
 #ifdef E_ABL_ONE_B        // ablation (wrong results): the single-product form without its Im tile requests
   if (!LO && T == B_IMH) { b.imh = b.reh; return; }
 #endif
@@ -239,11 +241,12 @@ __device__ __forceinline__ void ep_store_round(float mx, f32x2 qi, f32x2 di, flo
 }
 // ---------------------------------------------------------------------------------------------------------------- stage-1 schedule
 // The 32 walk positions of a unit form 8 quads (4 per half); quad QD computes T1 / T2' of frequencies (2E, 2E+8, 2E+1, 2E+9) of its half
-// into register set QD & 1:  T[set][0..7] = t1a, t2a, t1b, t2b (first pair), t1c, t2c, t1d, t2d (second pair).  A position has 6 gaps
-// (behind its 6 MFMAs; with one product per term the last four follow each other directly), a quad 24.  VALU work, 4 instructions per gap:
-//   gap 21..23 of quad QD and gap 0 of quad QD+1:  swap + combination of quad QD's FIRST pair  (in place: t1a = Re S, t1b = Im S, t2b = Re P, t2a = Im P)
-//   gap 1..4 of quad QD+1:                         swap + combination of quad QD's SECOND pair (t1c, t1d, t2d, t2c)
-//   gap 5..20 of quad QD+1:                        the 16 splits of quad QD -> element E of the half's 16 (32) operand tuples
+// into register set QD & 1:  T[set][0..7] = t1a, t2a, t1b, t2b (first pair), t1c, t2c, t1d, t2d (second pair).  A position has 6 slots of
+// VALU work, a quad 24 (split-f16: behind its 4 MFMAs as 1, 2, 1, 2 slots; one product per term: the first two behind its 2 MFMAs, the last four
+// follow each other directly).  4 instructions per slot:
+//   slot 21..23 of quad QD and slot 0 of quad QD+1: swap + combination of quad QD's FIRST pair  (in place: t1a = Re S, t1b = Im S, t2b = Re P, t2a = Im P)
+//   slot 1..4 of quad QD+1:                         swap + combination of quad QD's SECOND pair (t1c, t1d, t2d, t2c)
+//   slot 5..20 of quad QD+1:                        the 16 splits of quad QD -> element E of the half's 16 (32) operand tuples
 // so every reader of an MFMA result sits two or more MFMAs + eight VALU behind it, and set QD & 1 is free again when quad QD+2 starts.
 template <bool LO>
 __device__ __forceinline__ void swp2(f32x4& x, f32x4& y, f32x4& u, f32x4& v, int e) { swap32f(x, y, e); swap32f(u, v, e); }
@@ -285,7 +288,7 @@ __device__ __forceinline__ void split_piece(Half<LO>& hb, const f32x4 (&t)[8]) {
   if constexpr (KIND == 2) { hb.reMh[R][E] = h; if constexpr (LO) hb.reMl[R][E] = l; }
   if constexpr (KIND == 3) { hb.imMh[R][E] = h; if constexpr (LO) hb.imMl[R][E] = l; }
 }
-// the VALU work of gap G (0..23) of quad QD (0..8; 8 = the drain behind the last quad)
+// the VALU work of slot G (0..23) of quad QD (0..8; 8 = the drain behind the last quad)
 template <bool LO, int QD, int G>
 __device__ __forceinline__ void valu_slot(f32x4 (&T)[2][8], Half<LO> (&hbs)[2]) {
   constexpr int cur = QD & 1, prv = cur ^ 1;
@@ -380,8 +383,12 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   const int gcnt = g1 - g0;
   constexpr int BD = LO ? E_BD : E_BD1;            // depth of the DB operand ring: the tiles of BD - 1 walk positions are in flight
   constexpr int AD = LO ? E_AD : 3;                // the same for the query tiles
-  const unsigned nat0 = lds0 + wq * QIMG + row * QROW + (row >= 8 ? 8 : 0) + kg * 16;
-  const int voff = (lane < 48) ? lane * 16 : (int)0x80000000;     // lanes 48-63: out of range -> zeros (K = 24..31)
+  // split-f16 form: the two operand pairs of a frequency (kernels.hpp) - this lane's 16 bytes of its query row, and of the DB tiles below
+  const unsigned natr = lds0 + wq * QIMG + row * QROW + (row >= 8 ? 8 : 0);
+  const unsigned nat0 = natr + (LO ? sch_a1_byte(kg) : kg * 16);
+  [[maybe_unused]] const unsigned nat1 = natr + sch_a2_byte(kg);
+  const int voff = LO ? sch_b1_byte(lane) : ((lane < 48) ? lane * 16 : (int)0x80000000);     // single product, lanes 48-63: out of range -> zeros (K = 24..31)
+  [[maybe_unused]] const int voff2 = sch_b2_byte(lane);
   float* dist = ch ? dist_i : dist_p;
   const char* dbase = dpk + ((size_t)ch * DG) * DIMG;
   const int qrow0 = qg32 * (8 * NQG) + wq * 8;
@@ -417,10 +424,10 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   { if constexpr ((K) < (BD - 1) * TPB) {                                                                          \
       constexpr int _p = (K) / TPB, _t = LO ? (K) % TPB : 2 * ((K) % TPB);      /* order Re hi, (Re lo), Im hi, (Im lo) */ \
       constexpr int _tt = LO ? (_t == 1 ? B_IMH : _t == 2 ? B_REL : _t == 3 ? B_IML : B_REH) : _t;                 \
-      load_b<LO, seqf(_p), _tt, SV>(Bt[_p % BD], RSRC, voff);                                                          \
+      load_b<LO, seqf(_p), _tt, SV>(Bt[_p % BD], RSRC, (LO && (_tt == B_REL || _tt == B_IML)) ? voff2 : voff);        \
     } else if constexpr ((K) < NREQ) {                                                                             \
       constexpr int _k = (K) - (BD - 1) * TPB, _p = _k / TPA, _t = _k % TPA;                                       \
-      load_a<_t>(At[_p % AD], nat0 + seqf(_p) * QBLK);                                                         \
+      load_a<_t>(At[_p % AD], (_t == A_L ? nat1 : nat0) + seqf(_p) * QBLK);                                        \
     } }
   FIRST_REQ(0, rs) FIRST_REQ(1, rs) FIRST_REQ(2, rs) FIRST_REQ(3, rs) FIRST_REQ(4, rs) FIRST_REQ(5, rs) FIRST_REQ(6, rs) FIRST_REQ(7, rs)
   FIRST_REQ(8, rs) FIRST_REQ(9, rs) FIRST_REQ(10, rs) FIRST_REQ(11, rs) FIRST_REQ(12, rs) FIRST_REQ(13, rs) FIRST_REQ(14, rs) FIRST_REQ(15, rs)
@@ -436,11 +443,11 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
     f32x4 T[2][8];
 
 // request tile T of walk position Q of this unit (Q >= 31: nothing)
-#define LDB(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || (TT == B_REH || TT == B_IMH))) load_b<LO, seqf((Q) < 32 ? (Q) : 0), TT, SV>(Bt[(Q) % BD], rs, voff); }
-#define LDA(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || TT == A_H)) load_a<TT>(At[(Q) % AD], nat0 + seqf((Q) < 32 ? (Q) : 0) * QBLK); }
+#define LDB(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || (TT == B_REH || TT == B_IMH))) load_b<LO, seqf((Q) < 32 ? (Q) : 0), TT, SV>(Bt[(Q) % BD], rs, (LO && (TT == B_REL || TT == B_IML)) ? voff2 : voff); }
+#define LDA(Q, TT) { if constexpr ((Q) < 32 && seqf((Q) < 32 ? (Q) : 0) < SC_NF && (LO || TT == A_H)) load_a<TT>(At[(Q) % AD], (TT == A_L ? nat1 : nat0) + seqf((Q) < 32 ? (Q) : 0) * QBLK); }
 #define VS(P, G) valu_slot<LO, ((P) >> 2), (((P) & 3) * 6 + (G))>(T, hbs)
 // one walk position: its 6 (LO) or 2 MFMAs, the requests for positions P + AD - 1 (query tiles) and P + BD - 1 (DB tiles), the quad's VALU
-// work of these six gaps
+// work of its six slots
 // E_WAIT1: an empty asm that names all six operand tiles of the position in front of its first MFMA - hipcc then waits for them ONCE
 // (the rings are several positions deep: they have long arrived) instead of in front of every MFMA
 #ifdef E_WAIT1
@@ -457,13 +464,19 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   {                                                                                                              \
     f32x4& t1 = T[((P) >> 2) & 1][2 * ((P) & 3)];                                                                \
     f32x4& t2 = T[((P) >> 2) & 1][2 * ((P) & 3) + 1];                                                            \
-    if constexpr (seqf(P) < SC_NF) {                                                                             \
+    if constexpr (seqf(P) < SC_NF && LO) {            /* operand pair 1, then pair 2, into T1 (Re tiles) and T2' (Im tiles) */ \
       SB(); TOUCH_OPS(P); MF0(t1, At[(P) % AD].h, Bt[(P) % BD].reh); SB(); LDA((P) + AD - 1, A_H); VS(P, 0);      \
-      SB(); MF0(t2, At[(P) % AD].h, Bt[(P) % BD].imh); SB(); LDA((P) + AD - 1, A_L); VS(P, 1);                   \
-      SB(); if constexpr (LO) MFA(t1, At[(P) % AD].l, Bt[(P) % BD].reh); SB(); LDB((P) + BD - 1, B_REH); VS(P, 2); \
-      SB(); if constexpr (LO) MFA(t2, At[(P) % AD].l, Bt[(P) % BD].imh); SB(); LDB((P) + BD - 1, B_IMH); VS(P, 3); \
-      SB(); if constexpr (LO) MFA(t1, At[(P) % AD].h, Bt[(P) % BD].rel); SB(); LDB((P) + BD - 1, B_REL); VS(P, 4); \
-      SB(); if constexpr (LO) MFA(t2, At[(P) % AD].h, Bt[(P) % BD].iml); SB(); LDB((P) + BD - 1, B_IML); VS(P, 5); \
+      SB(); MF0(t2, At[(P) % AD].h, Bt[(P) % BD].imh); SB(); LDA((P) + AD - 1, A_L); VS(P, 1); VS(P, 2);         \
+      SB(); MFA(t1, At[(P) % AD].l, Bt[(P) % BD].rel); SB(); LDB((P) + BD - 1, B_REH); LDB((P) + BD - 1, B_IMH); VS(P, 3); \
+      SB(); MFA(t2, At[(P) % AD].l, Bt[(P) % BD].iml); SB(); LDB((P) + BD - 1, B_REL); LDB((P) + BD - 1, B_IML); VS(P, 4); VS(P, 5); \
+      SB();                                                                                                      \
+    } else if constexpr (seqf(P) < SC_NF) {                                                                      \
+      SB(); TOUCH_OPS(P); MF0(t1, At[(P) % AD].h, Bt[(P) % BD].reh); SB(); LDA((P) + AD - 1, A_H); VS(P, 0);      \
+      SB(); MF0(t2, At[(P) % AD].h, Bt[(P) % BD].imh); SB(); VS(P, 1);                                           \
+      SB(); LDB((P) + BD - 1, B_REH); VS(P, 2);                                                                  \
+      SB(); LDB((P) + BD - 1, B_IMH); VS(P, 3);                                                                  \
+      SB(); VS(P, 4);                                                                                            \
+      SB(); VS(P, 5);                                                                                            \
       SB();                                                                                                      \
     } else {                                                                                                     \
       t1 = f32x4{0.f, 0.f, 0.f, 0.f}; t2 = t1;          /* the ghost frequency 31 */                              \

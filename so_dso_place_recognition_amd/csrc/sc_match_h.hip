@@ -3,15 +3,16 @@
 // inverse transform, max over the 60 + 60 shifts), different arithmetic:
 //
 //   every fp32 factor x is carried as  x = hi + lo,  hi = f16(x), lo = f16(x - hi)  (22 significand bits), and every
-//   product as the three f16 MFMAs  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  accumulated in fp32 (the dropped lo*lo term is
-//   2^-22 relative).  On MI355X the f16 MFMA rate is 16x the fp32 MFMA rate, so the 3x is still a 5x gain in matrix
+//   product as the three f16 products  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  accumulated in fp32 (the dropped lo*lo term is
+//   2^-22 relative); in stage 1 the three are 60 of the 64 K-slots of TWO MFMAs (kernels.hpp: the operand pairs), in stage 2
+//   three MFMAs.  On MI355X the f16 MFMA rate is 16x the fp32 MFMA rate, so the 3x is still a 5x gain in matrix
 //   time, and — unlike v_mfma_f32_*_f32, which occupies the SIMD's fp32 VALU datapath — the f16 MFMAs run beside the
 //   wave's own VALU work (tools/ubench/f16_feed.hip).  Measured distance error vs fp64: same order as the fp32 kernel
 //   (tools/experiments/split_f16_error.py; tests/test_gpu_parity.py).
 //
 // One wave = 8 queries x 16 DB entries of one channel; spectra are pre-scaled (queries 2^8, DB 2^7, constants 2^10) so
 // that hi and lo stay in the normal f16 range; the final correlation is rescaled by 2^-25.
-//   stage 1  v_mfma_f32_16x16x32_f16, K = 20 rings (+12 zero), per frequency f:
+//   stage 1  v_mfma_f32_16x16x32_f16, K = 32 of the 60 ring terms (+4 zero), per frequency f:
 //            rows = {Re,Im} x 8 queries, cols = 16 entries
 //            T1 = [Qr;Qi].Dr^T = (QrDr | QiDr)       T2 = [Qi;Qr].Di^T = (QiDi | QrDi)     lanes <32 | >=32
 //            (T2's row operand = the same LDS image read with row ^ 8)
@@ -23,8 +24,8 @@
 //            (A operand = constant [shift 0..31][16 frequencies] tile, hi and lo; 3 MFMAs per chain; 256 accumulators)
 //   epilogue max over shifts of E + |O|, max(forward, mirror), d = 0.5 - 0.5 * 2^-25 * max           (processSC.m:30)
 // A workgroup (4 waves, one per SIMD) keeps the split spectra of 32 queries of one channel in LDS (159 712 B) and
-// sweeps a range of the DB; DB operands stream L2 -> L1 -> VGPR with raw buffer loads (lanes 48-63 are out of range
-// and read zeros: that is the K padding 24..31; K = 20..23 is stored as zeros in the packed image).
+// sweeps a range of the DB; DB operands stream L2 -> L1 -> VGPR with raw buffer loads (each operand pair takes its 64
+// lane pieces from the Re or Im hi + lo tiles of the frequency: kernels.hpp).
 #include "kernels.hpp"
 
 namespace pr {
@@ -39,24 +40,27 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef u32x4 u32x4_a8 __attribute__((aligned(8)));
 
-struct AOps { u32x4 h, l, rh, rl; };          // query row operands: Q hi, Q lo, and the same with Re/Im rows exchanged
-struct BOps { u32x4 reh, rel, imh, iml; };    // DB column operands: Re hi, Re lo, Im hi, Im lo
+struct AOps { u32x4 h, l, rh, rl; };          // query row operands: operand pair 1, pair 2 (kernels.hpp), and the same with Re/Im rows exchanged
+struct BOps { u32x4 reh, rel, imh, iml; };    // DB column operands: Re pair 1, Re pair 2, Im pair 1, Im pair 2
 
 // one operand tile (4 registers) per call, so that every request can be placed in its own MFMA gap
 enum { A_H = 0, A_L = 1, A_RH = 2, A_RL = 3 };
 enum { B_REH = 0, B_REL = 1, B_IMH = 2, B_IML = 3 };
-// nat / rot: 32-bit LDS byte addresses of this lane's 16 B in the block of frequency (P & ~1); the odd frequency of the
-// pair and the lo tile are immediate offsets of the ds_read2_b64 (8-bit, in units of 8 B: 1288 + 40 + 8 < 2048)
+// nat / rot: 32-bit LDS byte addresses of this lane's 16 B of operand pair 1 in the block of frequency (P & ~1); the odd frequency of
+// the pair is an immediate offset of the ds_read2_b64 (8-bit, in units of 8 B), pair 2 lies dl bytes further (per lane group: kernels.hpp)
 typedef const u32x4_a8 __attribute__((address_space(3))) * lds_tile_p;
 template <int P, int T>
-__device__ __forceinline__ void load_a(AOps& a, unsigned nat, unsigned rot) {
-  const unsigned addr = ((T & 2) ? rot : nat) + (P & 1) * SCH_QBLK + (T & 1) * 40;
+__device__ __forceinline__ void load_a(AOps& a, unsigned nat, unsigned rot, unsigned dl) {
+  unsigned addr = ((T & 2) ? rot : nat) + (P & 1) * SCH_QBLK;
+  if (T & 1) addr += dl;
   const u32x4 v = *reinterpret_cast<lds_tile_p>(addr);
   if (T == A_H) a.h = v; else if (T == A_L) a.l = v; else if (T == A_RH) a.rh = v; else a.rl = v;
 }
 template <int P, int T>
-__device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int voff) {
-  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, P * SCH_DFREQ + T * SCH_DTILE, 0);   // frequency and tile in the scalar offset: ONE lane-offset register (voff + T * 768 cost three more, spilled)
+__device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int voff, int voff2) {
+  // frequency and Re | Im tile pair in the scalar offset; the lane's place in the pair's hi + lo tiles for operand pair 1 | 2 in two registers
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, (T == B_REL || T == B_IML) ? voff2 : voff,
+                                                        P * SCH_DFREQ + ((T == B_IMH || T == B_IML) ? 2 : 0) * SCH_DTILE, 0);
   if (T == B_REH) b.reh = v; else if (T == B_REL) b.rel = v; else if (T == B_IMH) b.imh = v; else b.iml = v;
 }
 
@@ -217,9 +221,10 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)lds;
   constexpr int GS = ONEQ ? 4 : 1;                                  // DB groups between two units of a wave
   const int wq = ONEQ ? 0 : w;                                      // this wave's query group inside the workgroup's image
-  const unsigned nat0 = lds0 + wq * SCH_QIMG + row * 80 + (row >= 8 ? 8 : 0) + kg * 16;
-  const unsigned rot0 = lds0 + wq * SCH_QIMG + (row ^ 8) * 80 + (row >= 8 ? 0 : 8) + kg * 16;
-  const int voff = (lane < 48) ? lane * 16 : (int)0x80000000;     // lanes 48-63: out of range -> zeros (K = 24..31)
+  const unsigned nat0 = lds0 + wq * SCH_QIMG + row * 80 + (row >= 8 ? 8 : 0) + sch_a1_byte(kg);
+  const unsigned rot0 = lds0 + wq * SCH_QIMG + (row ^ 8) * 80 + (row >= 8 ? 0 : 8) + sch_a1_byte(kg);
+  const unsigned dl = sch_a2_byte(kg) - sch_a1_byte(kg);
+  const int voff = sch_b1_byte(lane), voff2 = sch_b2_byte(lane);
   const float sg = (lane < 32) ? 1.0f : -1.0f;
   const f32x2 sg2 = {sg, sg};
   float* dist = ch ? dist_i : dist_p;
@@ -233,7 +238,7 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   unsigned pf_sink = 0;
   const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(cst), 0, 8192, 0x00020000);
 
-  // Software pipeline over the slot sequence (6 stage-1 MFMAs per frequency), per operand TILE: the DB tiles of frequency
+  // Software pipeline over the slot sequence (4 stage-1 MFMAs per frequency), per operand TILE: the DB tiles of frequency
   // q are requested 8-12 MFMA slots ahead (Re hi, Im hi, Re lo during frequency q-2, Im lo during q-1), the query tiles 4
   // slots ahead (during q-1); buffers rotate with period 4 (DB) and 2 (queries) over 32 positions per group, position 31
   // being a ghost whose requests are issued by hand at the start of the stage-2 phase.  hipcc counts all these loads, so
@@ -245,10 +250,10 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
   BOps Bt[4];
   __amdgpu_buffer_rsrc_t rs =
       __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(dbase + (size_t)(g0 + (ONEQ ? w : 0)) * SCH_DIMG), 0, SCH_DIMG, 0x00020000);
-  load_b<0, B_REH>(Bt[0], rs, voff); load_b<0, B_IMH>(Bt[0], rs, voff); load_b<0, B_REL>(Bt[0], rs, voff); load_b<0, B_IML>(Bt[0], rs, voff);
-  load_a<0, A_H>(At[0], nat0, rot0); load_a<0, A_RH>(At[0], nat0, rot0); load_a<0, A_L>(At[0], nat0, rot0); load_a<0, A_RL>(At[0], nat0, rot0);
-  load_b<1, B_REH>(Bt[1], rs, voff); load_b<1, B_IMH>(Bt[1], rs, voff); load_b<1, B_REL>(Bt[1], rs, voff);
-  load_a<1, A_H>(At[1], nat0, rot0); load_a<1, A_RH>(At[1], nat0, rot0);
+  load_b<0, B_REH>(Bt[0], rs, voff, voff2); load_b<0, B_IMH>(Bt[0], rs, voff, voff2); load_b<0, B_REL>(Bt[0], rs, voff, voff2); load_b<0, B_IML>(Bt[0], rs, voff, voff2);
+  load_a<0, A_H>(At[0], nat0, rot0, dl); load_a<0, A_RH>(At[0], nat0, rot0, dl); load_a<0, A_L>(At[0], nat0, rot0, dl); load_a<0, A_RL>(At[0], nat0, rot0, dl);
+  load_b<1, B_REH>(Bt[1], rs, voff, voff2); load_b<1, B_IMH>(Bt[1], rs, voff, voff2); load_b<1, B_REL>(Bt[1], rs, voff, voff2);
+  load_a<1, A_H>(At[1], nat0, rot0, dl); load_a<1, A_RH>(At[1], nat0, rot0, dl);
 #ifdef PR_SCH_TIMING
   unsigned long long tacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tprev));
@@ -265,17 +270,16 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
     TICK(7)
 // request tile T of frequency Q of this group (Q >= 31: nothing - the first requests of the next group are issued by
 // hand late in the stage-2 phase, when half of the packed registers are free again)
-#define LDB(Q, T) { if ((Q) < SC_NF) load_b<((Q) < SC_NF ? (Q) : 0), T>(Bt[(Q) & 3], rs, voff); }
-#define LDA(P, Q, T) { if ((Q) < SC_NF) { if (((Q) >> 1) == ((P) >> 1)) load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], ncur, rcur); \
-                                        else load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], nnxt, rnxt); } }
+#define LDB(Q, T) { if ((Q) < SC_NF) load_b<((Q) < SC_NF ? (Q) : 0), T>(Bt[(Q) & 3], rs, voff, voff2); }
+#define LDA(P, Q, T) { if ((Q) < SC_NF) { if (((Q) >> 1) == ((P) >> 1)) load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], ncur, rcur, dl); \
+                                        else load_a<((Q) < SC_NF ? (Q) : 0), T>(At[(Q) & 3], nnxt, rnxt, dl); } }
+// a frequency: operand pair 1, then pair 2, into T1 (Re tiles) and T2 (Im tiles, row-exchanged queries) - four MFMAs, six VALU pieces
 #define FREQ(P, t1, t2, W0, W1, W2, W3, W4, W5)                                                   \
   {                                                                                               \
     SB(); MF0(t1, At[(P) & 3].h, Bt[(P) & 3].reh);  SB(); LDB((P) + 1, B_IML); LDA(P, (P) + 1, A_L); W0;   \
     SB(); MF0(t2, At[(P) & 3].rh, Bt[(P) & 3].imh); SB(); LDB((P) + 2, B_REH); W1;                \
-    SB(); MFA(t1, At[(P) & 3].l, Bt[(P) & 3].reh);  SB(); LDB((P) + 2, B_IMH); LDA(P, (P) + 1, A_RL); W2;  \
-    SB(); MFA(t2, At[(P) & 3].rl, Bt[(P) & 3].imh); SB(); LDA(P, (P) + 2, A_H); W3;               \
-    SB(); MFA(t1, At[(P) & 3].h, Bt[(P) & 3].rel);  SB(); LDB((P) + 2, B_REL); W4;                \
-    SB(); MFA(t2, At[(P) & 3].rh, Bt[(P) & 3].iml); SB(); LDA(P, (P) + 2, A_RH); W5;              \
+    SB(); MFA(t1, At[(P) & 3].l, Bt[(P) & 3].rel);  SB(); LDB((P) + 2, B_IMH); LDA(P, (P) + 1, A_RL); W2; LDA(P, (P) + 2, A_H); W3;  \
+    SB(); MFA(t2, At[(P) & 3].rl, Bt[(P) & 3].iml); SB(); LDB((P) + 2, B_REL); W4; LDA(P, (P) + 2, A_RH); W5;              \
     SB();                                                                                         \
   }
 #define PKF(J, R) pack_F<J, R>(hb, Fa, Fb)
@@ -358,8 +362,8 @@ __global__ __launch_bounds__(256, 1) void sc_match_h_kernel(const char* __restri
     SB();
     TICK(4)
     // (v_accvgpr_read next to in-flight MFMAs costs ~25 cycles each, so the epilogue is NOT interleaved with stage 2)
-#define NB(P, T) load_b<P, T>(Bt[P], rsn, voff)
-#define NA(P, T) load_a<P, T>(At[P], nbase, rbase)
+#define NB(P, T) load_b<P, T>(Bt[P], rsn, voff, voff2)
+#define NA(P, T) load_a<P, T>(At[P], nbase, rbase, dl)
     S2(false, 0, swap_r<1>(hb, 0, 1), NONE, swap_r<1>(hb, 1, 2), NONE, swap_r<1>(hb, 2, 3), NONE, swap_r<1>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
     S2(false, 1, swap_r<2>(hb, 0, 1), NONE, swap_r<2>(hb, 1, 2), NONE, swap_r<2>(hb, 2, 3), NONE, swap_r<2>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)
     S2(false, 2, swap_r<3>(hb, 0, 1), NONE, swap_r<3>(hb, 1, 2), NONE, swap_r<3>(hb, 2, 3), NONE, swap_r<3>(hb, 3, 4), NONE, NONE, NONE, NONE, NONE)

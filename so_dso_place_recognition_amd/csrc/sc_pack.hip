@@ -82,10 +82,11 @@ __global__ __launch_bounds__(256) void sc_pack_kernel(const T* __restrict__ sig,
 
 // Split-f16 images for sc_match_h.hip: every spectrum value x (queries scaled by 2^8, DB by 2^7) is stored as
 // hi = f16(x), lo = f16(x - hi).
-//   query image  [ch][group of 8][f = 0..30]{ 16 rows x 80 B: Qhi ring 0..19 | Qlo ring 0..19 }, row = (Im<<3) | e,
+//   query image  [ch][group of 8][f = 0..30]{ 16 rows x 80 B: Qhi ring 0..19 | Qlo ring 16..19, 0..15 }, row = (Im<<3) | e,
 //                rows 8..15 shifted by 8 B (LDS bank spread), 1288 B per frequency
 //   DB image     [ch][group of 16][f = 0..30][Re hi | Re lo | Im hi | Im lo]{ 768 B: lane = (ring>>3)<<4 | j, 16 B per
-//                lane = rings 8g..8g+7; rings 20..23 stay zero }
+//                lane = rings 8g..8g+7; rings 20..23 stay zero in the hi tiles and hold D hi 16..19 again in the lo tiles }
+//   (kernels.hpp: how the matchers' two operand pairs per frequency read these)
 template <typename T>
 __global__ __launch_bounds__(320) void sc_pack_h_kernel(const T* __restrict__ sig, int rows, int role,
                                                          unsigned short* __restrict__ packed, int groups,
@@ -145,13 +146,14 @@ __global__ __launch_bounds__(320) void sc_pack_h_kernel(const T* __restrict__ si
         const int g = row >> 3, rr = (im << 3) | (row & 7);
         const size_t base = ((size_t)ch * groups + g) * SCH_QIMG + (size_t)ff * SCH_QBLK + rr * 80 + (rr >= 8 ? 8 : 0);
         bh = base + ring * 2;
-        bl = base + 40 + ring * 2;
+        bl = base + sch_qlo_byte(ring);
       } else {
         const int g = row >> 4, j = row & 15;
         const size_t base = ((size_t)ch * groups + g) * SCH_DIMG + (size_t)ff * SCH_DFREQ + (size_t)im * 2 * SCH_DTILE +
                             (((ring >> 3) << 4) | j) * 16 + (ring & 7) * 2;
         bh = base;
         bl = base + SCH_DTILE;
+        if (ring >= 16) packed[(bl + 8) >> 1] = __builtin_bit_cast(unsigned short, hi);    // D hi 16..19 again, behind D lo 16..19
       }
       packed[bh >> 1] = __builtin_bit_cast(unsigned short, hi);
       packed[bl >> 1] = __builtin_bit_cast(unsigned short, lo);
@@ -303,10 +305,11 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
     if (ROLE == 0) {
       const int rr = (im << 3) | (lrow & 7);
       bh = ((lrow >> 3) * 8 + slice) * SL + rr * QROW + (rr >= 8 ? 8 : 0) + ring * 2;
-      bl = bh + 40;
+      bl = bh - ring * 2 + sch_qlo_byte(ring);
     } else {
       bh = slice * SL + im * (LO ? 2 : 1) * SCH_DTILE + (((ring >> 3) << 4) | lrow) * 16 + (ring & 7) * 2;
       bl = bh + SCH_DTILE;
+      if (LO && ring >= 16) *reinterpret_cast<_Float16*>(img + bl + 8) = hi;      // D hi 16..19 again, behind D lo 16..19 (kernels.hpp)
     }
     *reinterpret_cast<_Float16*>(img + bh) = hi;
     if (LO) *reinterpret_cast<_Float16*>(img + bl) = lo;
@@ -442,12 +445,13 @@ __global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict_
       const int g = row >> 3, rr = (im << 3) | (row & 7);
       bh = ((size_t)ch * groups + g) * IMGB + (size_t)ff * SL + rr * QROW + (rr >= 8 ? 8 : 0) + ring * 2;
       *reinterpret_cast<_Float16*>(out + bh) = hi;
-      if (LO) *reinterpret_cast<_Float16*>(out + bh + 40) = lo;
+      if (LO) *reinterpret_cast<_Float16*>(out + bh - ring * 2 + sch_qlo_byte(ring)) = lo;
     } else {
       const int g = row >> 4, j = row & 15;
       bh = ((size_t)ch * groups + g) * IMGB + (size_t)ff * SL + (size_t)im * (LO ? 2 : 1) * SCH_DTILE + (((ring >> 3) << 4) | j) * 16 + (ring & 7) * 2;
       *reinterpret_cast<_Float16*>(out + bh) = hi;
       if (LO) *reinterpret_cast<_Float16*>(out + bh + SCH_DTILE) = lo;
+      if (LO && ring >= 16) *reinterpret_cast<_Float16*>(out + bh + SCH_DTILE + 8) = hi;
     }
   };
   put((ce + co) * sc, f, 0);

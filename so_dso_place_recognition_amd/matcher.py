@@ -110,15 +110,31 @@ class _Base:
         self.f16_flags, self.f16_count = flags, count
         return flags, count
 
-    def _resolve_order(self, raw6, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, k, idx, score):
-        """pr_order_resolve_async_dev after a single-shard pr_rerank_dev: queries whose re-evaluated order hangs on the fp32 pass's sigmas, or
-        whose candidate list does not provably hold the top-k, are answered from their exact fp64 rows; idx / score (and the moments rows)
-        are patched in place.  Stream-ordered: no host synchronisation (PR_WARN_ORDER_RESOLVED at ctx.take_warnings() tells whether it
-        happened)."""
+    def _resolve_order(self, raw6, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, k, idx, score, exact_order=True):
+        """After a single-shard pr_rerank_dev: queries whose re-evaluated order hangs on the fp32 pass's sigmas, or whose candidate list does
+        not provably hold the top-k, are answered from their exact fp64 rows; idx / score (and the moments rows) are patched in place.
+        One pass takes RESOLVE_SLOTS flagged queries.  Calls of up to that many queries (and exact_order == "async"): pr_order_resolve_async_dev,
+        one stream-ordered pass without host synchronisation (PR_WARN_ORDER_RESOLVED at ctx.take_warnings() tells whether it happened,
+        PR_WARN_ORDER_UNRESOLVED that more queries were flagged than it took).  Larger calls: pr_order_resolve_dev - reads the number of
+        flagged queries back (ONE synchronisation of the stream per call) and runs as many passes as it takes."""
         self._enter()
-        self.ctx.check(self.lib.pr_order_resolve_async_dev(self.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), m, n, int(q_row0), int(mask_width),
-                                                           float(p_weight), int(k), _dptr(idx), _dptr(score)))
+        if m <= RESOLVE_SLOTS or exact_order == "async":
+            self.ctx.check(self.lib.pr_order_resolve_async_dev(self.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), m, n, int(q_row0), int(mask_width),
+                                                               float(p_weight), int(k), _dptr(idx), _dptr(score)))
+        else:
+            cnt = C.c_int32(0)
+            self.ctx.check(self.lib.pr_order_resolve_dev(self.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), m, n, int(q_row0), int(mask_width),
+                                                         float(p_weight), int(k), _dptr(idx), _dptr(score), C.byref(cnt)))
+            self.resolved = int(cnt.value)
         self._leave()
+
+    def _exact_passes(self, m, exact_order=True):
+        """Passes of RESOLVE_SLOTS flagged queries step 7 of the sharded protocol needs (the same number on every rank: the flags are a
+        function of the gathered evaluations).  Up to RESOLVE_SLOTS queries (or exact_order == "async"): one, unconditionally and without
+        synchronisation; more: the flagged count is read back (one synchronisation) - none flagged, no pass and no all-gather."""
+        if m <= RESOLVE_SLOTS or exact_order == "async":
+            return 1
+        return (self.flagged_count() + RESOLVE_SLOTS - 1) // RESOLVE_SLOTS
 
     def _fallback_rows(self, run_rows, idx, score, mask_width, q_row0):
         """Recomputes the flagged queries through `run_rows(rows tensor, q_row0 or None)` (a split-f16 matcher over the same DB) and
@@ -269,20 +285,20 @@ class Matcher(_Base):
     def finish(self, cand_idx: torch.Tensor, cand_sc: torch.Tensor, part_all: torch.Tensor, k: int):
         return _finish_dev(self, cand_idx, cand_sc, part_all, k, (*self._moms(), self._args[0]), self._args[4])
 
-    def exact_moments(self):
-        """Step 7, first local part: this shard's exact rows of the queries the last finish() flagged (kept in the context) and their
-        moments -> [m, 4, 3] f64."""
-        return _exact_moments_dev(self, self._raw_args()[:6], *self._moms(), self._args[0], self._m, self.n)
+    def exact_moments(self, offset: int = 0):
+        """Step 7, first local part: this shard's exact rows of flagged queries offset .. offset + 63 of the last finish() (kept in the
+        context) and their moments -> [m, 4, 3] f64."""
+        return _exact_moments_dev(self, self._raw_args()[:6], *self._moms(), self._args[0], self._m, self.n, offset)
 
-    def exact_select(self, exact_all: torch.Tensor, k: int):
+    def exact_select(self, exact_all: torch.Tensor, k: int, offset: int = 0):
         """Step 7, second local part: this shard's k best of the flagged queries' exact rows under the statistics of all shards
         -> [64, 2, k] f64 (scores | global indices)."""
         sc = self.type == _lib.TYPE_SC
         G, q_row0, db_row0, mask_width, p_weight = self._args
-        return _exact_select_dev(self, exact_all, self._m, self.n, q_row0, db_row0, mask_width, p_weight, sc, not sc, k)
+        return _exact_select_dev(self, exact_all, self._m, self.n, q_row0, db_row0, mask_width, p_weight, sc, not sc, k, offset)
 
-    def exact_merge(self, sel_all: torch.Tensor, k: int, idx: torch.Tensor, score: torch.Tensor):
-        return _exact_merge_dev(self, sel_all, self._m, k, idx, score)
+    def exact_merge(self, sel_all: torch.Tensor, k: int, idx: torch.Tensor, score: torch.Tensor, offset: int = 0):
+        return _exact_merge_dev(self, sel_all, self._m, k, idx, score, offset)
 
     def local_phase2(self, mom_all: torch.Tensor, G: int, mask_width, p_weight, k, db_row0, q_row0):
         """Selection + re-evaluation of this shard alone -> its own top-k (what rank g would answer by itself)."""
@@ -301,11 +317,15 @@ class Matcher(_Base):
         force_exchange: run the all-gathers and the merge even with one rank (measures the protocol's overhead).
         exact_order (default): queries whose re-evaluated order is not certain under the fp32 pass's row sigmas, or whose k + 8 candidates
         do not provably hold the top-k of the whole row, are answered from their exact fp64 rows, sharded or not (run_test.m:38-57 are fp64
-        over the whole row) - stream-ordered kernels that leave at once when nothing is flagged, 64 such queries per call
-        (PR_WARN_ORDER_UNRESOLVED beyond); False skips them (the answer of the re-evaluated candidate list; the flags are simply dropped)."""
+        over the whole row), 64 flagged queries per pass: a call of up to 64 queries runs one pass of stream-ordered kernels that leave at
+        once when nothing is flagged (no host synchronisation: such a call can be captured in a hipGraph); a larger call reads the
+        number of flagged queries back (one synchronisation) and runs the passes it takes.  "async": one such pass whatever the call's size
+        (PR_WARN_ORDER_UNRESOLVED at take_warnings() when more than 64 queries were flagged: their answers are the candidate list's);
+        False skips the resolution (the answer of the re-evaluated candidate list; the flags are simply dropped)."""
         G = _world(group)
         f16 = self.f16 and not self.plain
-        resolve = (self.exact_moments, self.exact_select, self.exact_merge) if (exact_order and not self.plain and not f16) else None
+        resolve = ((self.exact_moments, self.exact_select, self.exact_merge, lambda: self._exact_passes(self._m, exact_order))
+                   if (exact_order and not self.plain and not f16) else None)
         post = (lambda cand_sc, idx, score: self._margin(_dptr_mom(self, True), _dptr_mom(self, False), self._args[0], p_weight, cand_sc, k,
                                                           score)) if f16 else None
         idx, score = sharded_topk(lambda: self.local_phase1(queries),
@@ -320,7 +340,7 @@ class Matcher(_Base):
                                 exact_order=exact_order)
             idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
         elif resolve is not None and G == 1 and not force_exchange:
-            self._resolve_order(self._raw_args()[:6], *self._moms(), self._m, self.n, q_row0, mask_width, p_weight, k, idx, score)
+            self._resolve_order(self._raw_args()[:6], *self._moms(), self._m, self.n, q_row0, mask_width, p_weight, k, idx, score, exact_order)
             if mark is not None:
                 mark("exact rows (one shard)")
         return idx, score
@@ -479,15 +499,15 @@ class FusedMatcher(_Base):
         return (_dptr(self.sc._q_sig), _dptr(self.sc.db_sig), _torch_dt(self.sc.db_sig), _dptr(self.m2._q_sig), _dptr(self.m2.db_sig),
                 _torch_dt(self.m2.db_sig))
 
-    def exact_moments(self):
-        return _exact_moments_dev(self, self._raw6(), self._m1, self._m2, self._args[0], self.sc._m, self.sc.n)
+    def exact_moments(self, offset=0):
+        return _exact_moments_dev(self, self._raw6(), self._m1, self._m2, self._args[0], self.sc._m, self.sc.n, offset)
 
-    def exact_select(self, exact_all, k):
+    def exact_select(self, exact_all, k, offset=0):
         G, q_row0, db_row0, mask_width, p_weight = self._args
-        return _exact_select_dev(self, exact_all, self.sc._m, self.sc.n, q_row0, db_row0, mask_width, p_weight, True, True, k)
+        return _exact_select_dev(self, exact_all, self.sc._m, self.sc.n, q_row0, db_row0, mask_width, p_weight, True, True, k, offset)
 
-    def exact_merge(self, sel_all, k, idx, score):
-        return _exact_merge_dev(self, sel_all, self.sc._m, k, idx, score)
+    def exact_merge(self, sel_all, k, idx, score, offset=0):
+        return _exact_merge_dev(self, sel_all, self.sc._m, k, idx, score, offset)
 
     def local_phase2(self, mom_all, G, mask_width, p_weight, k, db_row0, q_row0):
         idx_in, sc = self.local_select(mom_all, G, mask_width, p_weight, k, db_row0, q_row0)
@@ -500,7 +520,8 @@ class FusedMatcher(_Base):
               db_row0: int = 0, q_row0: int = 0, group=None, f16_fallback: bool = True, exact_order: bool = True):
         G = _world(group)
         post = (lambda cand_sc, idx, score: self._margin(self._m1, self._m2, self._args[0], p_weight, cand_sc, k, score)) if self.f16 else None
-        resolve = (self.exact_moments, self.exact_select, self.exact_merge) if (exact_order and not self.f16) else None
+        resolve = ((self.exact_moments, self.exact_select, self.exact_merge, lambda: self._exact_passes(self.sc._m, exact_order))
+                   if (exact_order and not self.f16) else None)
         idx, score = sharded_topk(lambda: self.local_phase1(sc_queries, m2dp_queries),
                                   lambda mom_all, G_: self.local_select(mom_all, G_, mask_width, p_weight, k, db_row0, q_row0),
                                   k, group if G > 1 else None, G, merge=self.merge, rerank=self.local_rerank, finish=self.finish, post=post,
@@ -512,7 +533,7 @@ class FusedMatcher(_Base):
                                 p_weight, k, db_row0, q_row0 if qr0 is None else qr0, group, exact_order=exact_order)
             idx, score = self._fallback_rows(run_rows, idx, score, mask_width, q_row0)
         elif resolve is not None and G == 1:
-            self._resolve_order(self._raw6(), self._m1, self._m2, self.sc._m, self.sc.n, q_row0, mask_width, p_weight, k, idx, score)
+            self._resolve_order(self._raw6(), self._m1, self._m2, self.sc._m, self.sc.n, q_row0, mask_width, p_weight, k, idx, score, exact_order)
         return idx, score
 
     take_warnings = Matcher.take_warnings
@@ -645,17 +666,20 @@ def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None,
     mark("all_gather C (evaluations)")
     idx, score = finish(cand_idx, cand_sc, part_all, k)
     mark("finish+checks")
-    if resolve is not None:                              # step 7: the flagged queries from their exact rows (moments, per-shard k best, merge)
-        ex = resolve[0]()
-        mark("exact rows")
-        exact_all = gather(ex)
-        mark("all_gather D (exact moments)")
-        sel = resolve[1](exact_all, k)
-        mark("exact select")
-        sel_all = gather(sel)
-        mark("all_gather E (exact lists)")
-        idx, score = resolve[2](sel_all, k, idx, score)
-        mark("exact merge")
+    if resolve is not None:                              # step 7: the flagged queries from their exact rows (moments, per-shard k best, merge),
+        passes = resolve[3]() if len(resolve) > 3 else 1   # 64 per pass; the same number of passes on every rank
+        for p in range(passes):
+            off = p * RESOLVE_SLOTS
+            ex = resolve[0](off) if p else resolve[0]()
+            mark("exact rows")
+            exact_all = gather(ex)
+            mark("all_gather D (exact moments)")
+            sel = resolve[1](exact_all, k, off) if p else resolve[1](exact_all, k)
+            mark("exact select")
+            sel_all = gather(sel)
+            mark("all_gather E (exact lists)")
+            idx, score = resolve[2](sel_all, k, idx, score, off) if p else resolve[2](sel_all, k, idx, score)
+            mark("exact merge")
     if post is not None:
         post(cand_sc, idx, score)
     return idx, score

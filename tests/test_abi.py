@@ -64,7 +64,8 @@ def test_inline_asm_mfma_operands_are_not_written_right_before_use():
     assert r.returncode == 0, r.stdout + r.stderr
     import re
     counts = [int(x) for x in re.findall(r"(\d+) inline-asm MFMAs checked, 0 finding", r.stdout)]
-    assert len(counts) == 3 and counts[0] == 372 and counts[2] >= 470, r.stdout     # (sc_match_e.hip: 94 per single-product instantiation + 282)
+    # sc_match_h.hip: 2 instantiations x 31 frequencies x 4 (two operand pairs x Re | Im); sc_match_e.hip: 94 per single-product instantiation + 220
+    assert len(counts) == 3 and counts[0] == 248 and counts[2] >= 470 + 220, r.stdout
     # the audit itself: a reload in front of an asm MFMA and a copy of its result right behind it are both reported
     sys.path.insert(0, os.path.join(root, "tools"))
     import audit_asm_hazards as aud

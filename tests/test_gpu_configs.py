@@ -536,8 +536,13 @@ def test_near_copy_clusters_are_answered_from_the_exact_row(api, type_):
 def test_fp64_statistics_for_every_query_give_the_oracles_scores(api, monkeypatch):
     """PR_FORCE_ORDER_FLAGS=1 makes the order check flag every query, so the fp64-statistics resolution - normally a 1-in-10^5 path - answers
     all of them: every returned score must then be the oracle's to fp64 rounding (exact pair distances AND exact row statistics,
-    run_test.m:38-57), on every path: the host calls (all queries: several passes of 64), the stream-ordered device-resident call (its first
-    64 flagged queries; PR_WARN_ORDER_UNRESOLVED for the rest), pr_group with virtual shards, and the fused SC + M2DP form."""
+    run_test.m:38-57), on every path: the host calls (all queries: several passes of 64), the device-resident call (150 flagged queries: it
+    reads the count back and runs three passes; with exact_order="async" one stream-ordered pass - its first 64 flagged queries,
+    PR_WARN_ORDER_UNRESOLVED for the rest), pr_group with virtual shards, two torch.distributed ranks (three passes of the exchange), and the
+    fused SC + M2DP form."""
+    import json
+    import subprocess
+    import sys
     import torch
     from so_dso_place_recognition_amd.matcher import Matcher, FusedMatcher
     monkeypatch.setenv("PR_FORCE_ORDER_FLAGS", "1")
@@ -564,7 +569,11 @@ def test_fp64_statistics_for_every_query_give_the_oracles_scores(api, monkeypatc
     dev = torch.device("cuda", 0)
     mt = Matcher("sc", m, n, ctx=api.Context(0, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
     mt.pack_database(torch.from_numpy(db).to(dev))
-    i1, s1 = mt.match(torch.from_numpy(q).to(dev), 5, 2.0, k)
+    i1, s1 = mt.match(torch.from_numpy(q).to(dev), 5, 2.0, k)                            # a call of more than 64 queries: every flagged one
+    w = mt.take_warnings()
+    assert (w & _lib.WARN_ORDER_RESOLVED) and not (w & _lib.WARN_ORDER_UNRESOLVED) and mt.resolved == m
+    assert np.array_equal(i1.cpu().numpy(), oidx) and np.abs(s1.cpu().numpy() - osc).max() < 1e-9
+    i1, s1 = mt.match(torch.from_numpy(q).to(dev), 5, 2.0, k, exact_order="async")
     w = mt.take_warnings()
     assert (w & _lib.WARN_ORDER_RESOLVED) and (w & _lib.WARN_ORDER_UNRESOLVED)          # 150 flagged, one stream-ordered pass resolves 64
     i1, s1 = i1.cpu().numpy(), s1.cpu().numpy()
@@ -581,6 +590,14 @@ def test_fp64_statistics_for_every_query_give_the_oracles_scores(api, monkeypatc
     gi, gs = g.match_topk(q[:60], 5, 2.0, k)
     assert np.array_equal(gi, oidx[:60]) and np.abs(gs - osc[:60]).max() < 1e-9
     g.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))               # two ranks: 150 flagged queries = three passes of all-gathers D, E
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(29800 + os.getpid() % 90), os.path.join(root, "tests", "dist_order_case.py"), "f16x2", "forced", str(k)]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=dict(os.environ, MASTER_ADDR="127.0.0.1"), timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["world"] == 2 and (d["warnings"] & _lib.WARN_ORDER_RESOLVED) and not (d["warnings"] & _lib.WARN_ORDER_UNRESOLVED)
+    assert np.array_equal(np.array(d["idx"]), oidx) and np.abs(np.array(d["score"]) - osc).max() < 1e-9
     # fused SC + M2DP (config 5's score): both descriptor types through the resolution
     mdb = synth.m2dp_database(83, n)
     mq, _ = synth.m2dp_queries(183, mdb, 48)

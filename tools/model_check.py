@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1] if len(sys.argv) > 1 else "model"
 out = os.path.join(ROOT, "gpurun_out")
 os.makedirs(out, exist_ok=True)
-env = dict(os.environ, TMPDIR="/tmp")
+env = dict(os.environ, TMPDIR="/tmp", PR_SC_BINARY="0")      # both channels through the modelled kernel (the model counts 2 channels of units)
 
 
 def sh(cmd, **kw):
