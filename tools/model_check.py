@@ -30,7 +30,7 @@ fillers = os.path.join(out, f"{tag}_fillers.txt")
 open(fillers, "w").write(r.stdout + r.stderr[-2000:])
 costs = os.path.join(out, f"{tag}_costs.json")
 res = {"tag": tag, "host": os.uname().nodename}
-for arith, kern, pat in (("f16x2", "split", "sc_match_e_kernel<true"), ("f16", "single", "sc_match_e_kernel<false, 8, 8>")):
+for arith, kern, pat in (("f16x2", "split", "sc_match_e_kernel<true"), ("f16", "single", "sc_match_e_kernel<false, 8, 8, false>")):
     bench = f"python {ROOT}/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra --sc-arith {arith}"
     d = os.path.join(out, f"{tag}_tr_{arith}")
     sh(f"rm -rf {d}; rocprofv3 --kernel-trace --stats -d {d} -o sc -- {bench}")
