@@ -460,15 +460,54 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
 #else
 #define TOUCH_OPS(P)
 #endif
+// (split-f16 form) what goes behind the four MFMAs of a position: the six requests and the six VALU slots
+#ifndef E_LDD
+#define E_LDD 0
+#endif
+#ifndef E_VSD
+#define E_VSD 0
+#endif
+#if E_LDD == 0
+#define G0_REQ(P) LDA((P) + AD - 1, A_H)
+#define G1_REQ(P) LDA((P) + AD - 1, A_L)
+#define G2_REQ(P) { LDB((P) + BD - 1, B_REH); LDB((P) + BD - 1, B_IMH); }
+#define G3_REQ(P) { LDB((P) + BD - 1, B_REL); LDB((P) + BD - 1, B_IML); }
+#else
+#define G0_REQ(P) { LDA((P) + AD - 1, A_H); LDB((P) + BD - 1, B_REH); }
+#define G1_REQ(P) { LDA((P) + AD - 1, A_L); LDB((P) + BD - 1, B_IMH); }
+#define G2_REQ(P) LDB((P) + BD - 1, B_REL)
+#define G3_REQ(P) LDB((P) + BD - 1, B_IML)
+#endif
+#if E_VSD == 0
+#define G0_VS(P) VS(P, 0)
+#define G1_VS(P) { VS(P, 1); VS(P, 2); }
+#define G2_VS(P) VS(P, 3)
+#define G3_VS(P) { VS(P, 4); VS(P, 5); }
+#elif E_VSD == 1
+#define G0_VS(P) { VS(P, 0); VS(P, 1); }
+#define G1_VS(P) VS(P, 2)
+#define G2_VS(P) { VS(P, 3); VS(P, 4); }
+#define G3_VS(P) VS(P, 5)
+#elif E_VSD == 2
+#define G0_VS(P) VS(P, 0)
+#define G1_VS(P) VS(P, 1)
+#define G2_VS(P) { VS(P, 2); VS(P, 3); }
+#define G3_VS(P) { VS(P, 4); VS(P, 5); }
+#else
+#define G0_VS(P) { VS(P, 0); VS(P, 1); }
+#define G1_VS(P) { VS(P, 2); VS(P, 3); }
+#define G2_VS(P) VS(P, 4)
+#define G3_VS(P) VS(P, 5)
+#endif
 #define FREQ(P)                                                                                                  \
   {                                                                                                              \
     f32x4& t1 = T[((P) >> 2) & 1][2 * ((P) & 3)];                                                                \
     f32x4& t2 = T[((P) >> 2) & 1][2 * ((P) & 3) + 1];                                                            \
     if constexpr (seqf(P) < SC_NF && LO) {            /* operand pair 1, then pair 2, into T1 (Re tiles) and T2' (Im tiles) */ \
-      SB(); TOUCH_OPS(P); MF0(t1, At[(P) % AD].h, Bt[(P) % BD].reh); SB(); LDA((P) + AD - 1, A_H); VS(P, 0);      \
-      SB(); MF0(t2, At[(P) % AD].h, Bt[(P) % BD].imh); SB(); LDA((P) + AD - 1, A_L); VS(P, 1); VS(P, 2);         \
-      SB(); MFA(t1, At[(P) % AD].l, Bt[(P) % BD].rel); SB(); LDB((P) + BD - 1, B_REH); LDB((P) + BD - 1, B_IMH); VS(P, 3); \
-      SB(); MFA(t2, At[(P) % AD].l, Bt[(P) % BD].iml); SB(); LDB((P) + BD - 1, B_REL); LDB((P) + BD - 1, B_IML); VS(P, 4); VS(P, 5); \
+      SB(); TOUCH_OPS(P); MF0(t1, At[(P) % AD].h, Bt[(P) % BD].reh); SB(); G0_REQ(P); G0_VS(P);                  \
+      SB(); MF0(t2, At[(P) % AD].h, Bt[(P) % BD].imh); SB(); G1_REQ(P); G1_VS(P);                                \
+      SB(); MFA(t1, At[(P) % AD].l, Bt[(P) % BD].rel); SB(); G2_REQ(P); G2_VS(P);                                \
+      SB(); MFA(t2, At[(P) % AD].l, Bt[(P) % BD].iml); SB(); G3_REQ(P); G3_VS(P);                                \
       SB();                                                                                                      \
     } else if constexpr (seqf(P) < SC_NF) {                                                                      \
       SB(); TOUCH_OPS(P); MF0(t1, At[(P) % AD].h, Bt[(P) % BD].reh); SB(); LDA((P) + AD - 1, A_H); VS(P, 0);      \

@@ -356,7 +356,7 @@ class Matcher(_Base):
 
     def take_warnings(self) -> int:
         """PR_WARN_* bits of the context since the last call (synchronises its stream): WARN_ORDER_RESOLVED after a match() whose order
-        needed fp64 row statistics, WARN_ORDER_UNRESOLVED when more than 64 queries of one call did."""
+        needed fp64 row statistics, WARN_ORDER_UNRESOLVED when more than 64 queries of one match(..., exact_order="async") call did."""
         return self.ctx.take_warnings()
 
     def _split_twin(self):

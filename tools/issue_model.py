@@ -200,11 +200,11 @@ def main():
     ap.add_argument("--measured-ms", type=float, default=None)
     ap.add_argument("--ghz", type=float, default=None, help="sustained shader clock under this kernel (GRBM_GUI_ACTIVE / 8 / duration)")
     ap.add_argument("--json", action="store_true")
-    ap.add_argument("--hypothetical", default=None, choices=["coarse-stage2", "kconcat"],
+    ap.add_argument("--hypothetical", default=None, choices=["coarse-stage2"],
                     help="price a variant that was NOT built: coarse-stage2 = stage 2 with ONE f16 product per term (32 instead of 96 32x32x16 MFMAs) "
                          "+ exact refinement of the shifts within its error bound from the packed hi + lo stage-2 operands (VERDICT r04 item 4b); "
-                         "kconcat = the three split products of stage 1 concatenated along K (60 of 2 x 32 slots instead of 3 x 20 of 32): 4 instead of 6 "
-                         "16x16x32 MFMAs per frequency, same operand requests (DESIGN.md section 11)")
+                         "(round 5 also priced `kconcat`, the three split products of stage 1 as two full operand pairs, by dropping every third "
+                         "16x16x32 MFMA of the stream: profiles/r05_issue_model_kconcat.json - the kernel in the tree IS that variant now)")
     ap.add_argument("--refine-candidates", type=float, default=1.5, help="coarse-stage2: shifts per pair inside the coarse pass's error bound (>= 1)")
     a = ap.parse_args()
     if a.fit:
@@ -218,17 +218,6 @@ def main():
         assert a.kernel == "split"
         base_chain = simulate(st, c)[0]
         st = coarse_stage2(st, a.refine_candidates)
-    if a.hypothetical == "kconcat":
-        assert a.kernel == "split"
-        base_chain = simulate(st, c)[0]
-        out, seen = [], 0
-        for ins in st:                                   # every third stage-1 MFMA goes; requests, VALU and stage 2 stay
-            if ins[0] == "mfma16":
-                seen += 1
-                if seen % 3 == 0:
-                    continue
-            out.append(ins)
-        st = out
     chain, pipe, hist = simulate(st, c)
     waves_per_simd = 1 if a.kernel == "split" else 2
     waves_per_cu = 4 * waves_per_simd
