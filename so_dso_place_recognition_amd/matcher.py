@@ -668,6 +668,8 @@ def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None,
     mark("finish+checks")
     if resolve is not None:                              # step 7: the flagged queries from their exact rows (moments, per-shard k best, merge),
         passes = resolve[3]() if len(resolve) > 3 else 1   # 64 per pass; the same number of passes on every rank
+        if len(resolve) > 3:
+            mark("flagged count")                        # (calls above 64 queries: one read-back of the count; none flagged - no pass)
         for p in range(passes):
             off = p * RESOLVE_SLOTS
             ex = resolve[0](off) if p else resolve[0]()

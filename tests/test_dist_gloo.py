@@ -155,10 +155,19 @@ def test_bench_two_ranks_on_one_gpu(tmp_path, arith):
         assert {"pack(db)", "pack+distances+moments", "all_gather A (moments)", "select", "all_gather B (candidates)", "merge+rerank",
                 "all_gather C (evaluations)", "finish+checks"} <= set(ph)
         if arith != "f16":      # (the single-product arithmetic hands its flagged queries to a split-f16 twin instead of the exact-row exchange)
-            assert {"exact rows", "all_gather D (exact moments)", "exact select", "all_gather E (exact lists)", "exact merge"} <= set(ph)
+            assert "flagged count" in ph       # 130 queries > 64: the count is read back; nothing flagged - no exact-row pass, no all-gather D / E
+            assert not ({"exact rows", "all_gather D (exact moments)", "exact select", "all_gather E (exact lists)", "exact merge"} & set(ph))
         assert all(v >= 0 for v in ph.values()) and abs(r["collective_ms"] + r["compute_ms"] - sum(ph.values())) < 1e-6
         assert 0.49 < r["shard_fraction"] < 0.51 and r["matcher_ns_per_pair"] > 0 and r["step_ms"] >= sum(ph.values()) * 0.99
     assert d["collective"]["world"] == 2
+    if arith != "f16":          # every query flagged (PR_FORCE_ORDER_FLAGS): three passes of the exact-row exchange, each phase on the line
+        r = subprocess.run(cmd, capture_output=True, text=True, env=dict(env, PR_FORCE_ORDER_FLAGS="1"), timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        df = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert df["parity"]["planted_top1_correct"] == 130
+        for r_ in df["per_rank"]:
+            assert {"flagged count", "exact rows", "all_gather D (exact moments)", "exact select", "all_gather E (exact lists)",
+                    "exact merge"} <= set(r_["phases_ms"])
     one = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0", "--db", "6001",
                           "--queries", "130", "--no-cpu-baseline", "--no-extra", "--sc-arith", arith], capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stderr[-2000:]
