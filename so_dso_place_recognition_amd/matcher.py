@@ -62,6 +62,8 @@ def _stream_context(device: int, **kw) -> Context:
 
 
 class _Base:
+    resolved = None       # queries the last single-shard match() of more than 64 queries answered from their exact rows (it reads the count back)
+
     def _init_ctx(self, ctx, device):
         if device is None:
             device = ctx.device if ctx is not None else torch.cuda.current_device()
@@ -390,15 +392,17 @@ class Matcher(_Base):
         (online use: one keyframe per call - the ~10 kernel launches of a call replay as one graph launch).  Returns a
         CapturedMatch: `.run(new_queries)` copies them into the static input and replays ON THE MATCHER'S STREAM (a replay
         on another stream would not be ordered with the copy), `.idx` / `.score` are the static outputs.  The matcher must
-        come from on_new_stream()."""
+        come from on_new_stream().  A graph cannot read a count back: calls above 64 queries are captured with exact_order="async" (one
+        pass of 64 flagged queries; PR_WARN_ORDER_UNRESOLVED at take_warnings() if a replay flagged more)."""
         st = self.stream
+        eo = True if queries.shape[0] // self.rows_per_sig <= RESOLVE_SLOTS else "async"
         with torch.cuda.stream(st):
             assert self.ctx.stream == int(st.cuda_stream)
-            self.match(queries, mask_width, p_weight, k)            # warm-up: allocates every buffer the call uses
+            self.match(queries, mask_width, p_weight, k, exact_order=eo)            # warm-up: allocates every buffer the call uses
             st.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g, stream=st):
-                idx, score = self.match(queries, mask_width, p_weight, k)
+                idx, score = self.match(queries, mask_width, p_weight, k, exact_order=eo)
         return CapturedMatch(g, st, queries, idx, score)
 
 

@@ -686,7 +686,7 @@ def test_matcher_float32_signatures_and_larger_k(api):
     mt.close()
 
 
-@pytest.mark.parametrize("m", [4, 32])
+@pytest.mark.parametrize("m", [4, 32, 80])
 def test_match_as_hipgraph_replay(api, m):
     """One match() call captured into a hipGraph (online use: a keyframe per call): replays with new signatures in the static
     input give what the eager call gives."""
