@@ -92,7 +92,11 @@ __device__ __forceinline__ void load_b(BOps& b, __amdgpu_buffer_rsrc_t rs, int v
 #ifdef E_ABL_ONE_B        // ablation (wrong results): the single-product form without its Im tile requests
   if (!LO && T == B_IMH) { b.imh = b.reh; return; }
 #endif
+#ifdef E_ABL_B_HOT        // ablation (wrong results): every DB tile request reads the first tile pair of the group - the same requests, all of them L1 hits
+  const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ioff, 0, 0);
+#else
   const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff + ioff, soff, 0);
+#endif
   if (T == B_REH) b.reh = v; else if (T == B_REL) b.rel = v; else if (T == B_IMH) b.imh = v; else b.iml = v;
 }
 

@@ -1,1 +1,2 @@
-timeout 1200 python -m pytest tests/test_dist_gloo.py -m gpu -x -q 2>&1 | tail -5
+bash tools/ab.sh hot 2
+timeout 600 python -m pytest tests/test_gpu_parity.py -q -k "hipgraph" 2>&1 | tail -2
