@@ -225,7 +225,14 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
 #pragma unroll
       for (int k = 0; k < 4; k++) xq[(it + 2) % 3][k] = src[((it + 2) * 4 + k) * 20];
     }
-    const double* tp = twc + it * 32;
+    // (the 32 twiddles of a round are addressed through an opaque zero that the empty asm redefines together with the accumulators: the scalar
+    //  loads of round it cannot start before round it - 1 has finished.  hipcc otherwise requests three rounds' worth ahead - 192 SGPRs, of
+    //  which it spills ~100 through v_writelane / v_readlane: ~70 VALU instructions per round beside the 32 multiply-adds, 1.36 ms per 100k
+    //  signatures.  The other workgroups of the CU cover the scalar cache's latency.)
+    int tz = 0;
+    asm volatile("" : "+s"(tz), "+v"(ce[0]), "+v"(ce[1]), "+v"(ce[2]), "+v"(ce[3]), "+v"(co[0]), "+v"(co[1]), "+v"(co[2]), "+v"(co[3]),
+                      "+v"(se[0]), "+v"(se[1]), "+v"(se[2]), "+v"(se[3]), "+v"(so[0]), "+v"(so[1]), "+v"(so[2]), "+v"(so[3]));
+    const double* tp = twc + it * 32 + tz;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const double x0 = (double)xq[it % 3][2 * h], x1 = (double)xq[it % 3][2 * h + 1];

@@ -1,2 +1,3 @@
-bash tools/ab.sh hot 2
-timeout 600 python -m pytest tests/test_gpu_parity.py -q -k "hipgraph" 2>&1 | tail -2
+mkdir -p gpurun_out
+timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/r05_gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r05_gputest.log
+grep -E "passed|failed|rc=" gpurun_out/r05_gputest.log
