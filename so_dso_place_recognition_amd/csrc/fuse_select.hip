@@ -393,14 +393,30 @@ __device__ __forceinline__ void select_row(const float* __restrict__ d_p, const 
     // four 16-byte loads per channel in flight (the kernel runs at ~3 workgroups per CU - its LDS list - so a thread has to cover the
     // latency of its loads by itself); same elements, same order per thread as the plain loop.  The fused form's second channel pair
     // comes the same way (its element-wise 4-byte loads were most of that form's 2.65 ms sweep)
-    for (; j + 768 < nv; j += 1024) {
-      const f32x4 a0 = rp4[j], a1 = rp4[j + 256], a2 = rp4[j + 512], a3 = rp4[j + 768];
-      const f32x4 b0 = ri4[j], b1 = ri4[j + 256], b2 = ri4[j + 512], b3 = ri4[j + 768];
-      if (two) {
+    if (two) {
+      for (; j + 768 < nv; j += 1024) {
+        const f32x4 a0 = rp4[j], a1 = rp4[j + 256], a2 = rp4[j + 512], a3 = rp4[j + 768];
+        const f32x4 b0 = ri4[j], b1 = ri4[j + 256], b2 = ri4[j + 512], b3 = ri4[j + 768];
         const f32x4 c0 = ep4[j], c1 = ep4[j + 256], c2 = ep4[j + 512], c3 = ep4[j + 768];
         const f32x4 d0 = ei4[j], d1 = ei4[j + 256], d2 = ei4[j + 512], d3 = ei4[j + 768];
         four(a0, b0, c0, d0, j); four(a1, b1, c1, d1, j + 256); four(a2, b2, c2, d2, j + 512); four(a3, b3, c3, d3, j + 768);
-      } else { four(a0, b0, z4, z4, j); four(a1, b1, z4, z4, j + 256); four(a2, b2, z4, z4, j + 512); four(a3, b3, z4, z4, j + 768); }
+      }
+    } else if (j + 768 < nv) {
+      // the round's eight loads are requested while the previous round's 32 scores are evaluated (the kernel spent two thirds of its wave
+      // cycles in s_waitcnt with the loads of a round issued only after the arithmetic of the one before)
+      f32x4 a0 = rp4[j], a1 = rp4[j + 256], a2 = rp4[j + 512], a3 = rp4[j + 768];
+      f32x4 b0 = ri4[j], b1 = ri4[j + 256], b2 = ri4[j + 512], b3 = ri4[j + 768];
+      for (;;) {
+        const int jn = j + 1024;
+        const bool more = jn + 768 < nv;
+        const int jl = more ? jn : j;                                  // (the last round re-requests its own lines: no branch around the loads)
+        const f32x4 n0 = rp4[jl], n1 = rp4[jl + 256], n2 = rp4[jl + 512], n3 = rp4[jl + 768];
+        const f32x4 m0 = ri4[jl], m1 = ri4[jl + 256], m2 = ri4[jl + 512], m3 = ri4[jl + 768];
+        four(a0, b0, z4, z4, j); four(a1, b1, z4, z4, j + 256); four(a2, b2, z4, z4, j + 512); four(a3, b3, z4, z4, j + 768);
+        j = jn;
+        if (!more) break;
+        a0 = n0; a1 = n1; a2 = n2; a3 = n3; b0 = m0; b1 = m1; b2 = m2; b3 = m3;
+      }
     }
     for (; j < nv; j += 256) {
       const f32x4 a = rp4[j], b = ri4[j];
@@ -828,7 +844,12 @@ __global__ __launch_bounds__(256) void slice_merge_kernel(const int32_t* __restr
 //  the fence, the ticket and the agent-scope re-reads cost what a launch costs, and the finishing workgroup starts later than a fresh
 //  kernel would.  tools/experiments/README.md.)
 template <int CAP>
-__global__ __launch_bounds__(256) void fuse_select_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i,
+#ifdef FS_NOLB
+#define FS_BOUNDS __launch_bounds__(256)
+#else
+#define FS_BOUNDS __launch_bounds__(256, 3)
+#endif
+__global__ FS_BOUNDS void fuse_select_kernel(const float* __restrict__ d_p, const float* __restrict__ d_i,
                                                            const float* __restrict__ e_p, const float* __restrict__ e_i,
                                                            const double* __restrict__ mom2_all,
                                                            int m, int n, const double* __restrict__ mom_all, int G,
