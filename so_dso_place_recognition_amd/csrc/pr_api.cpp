@@ -37,6 +37,7 @@ struct pr_ctx {
   std::string err;
   int* d_svd_rows = nullptr;     // [1 + M2DP_SVD_ROWS_CAP] rows of the last pr_m2dp_generate* call whose leading singular pair did not converge
   int* d_flags = nullptr;        // [4] deferred bits: [0] zero-norm row at pack time, [1] M2DP singular pair not converged, [2] a query was answered with fp64 row statistics, [3] more flagged queries than one stream-ordered pass resolves
+  bool sc_online_h = false;      // PR_SC_ONLINE=h: calls of up to 8 queries through sc_match_h.hip's one-group form (the default until round 5)
   double* d_twiddle = nullptr;   // cos[60], sin[60] of 2*pi*t/60
   float* d_cst = nullptr;        // SC stage-2 constants [31][2][64]
   int32_t* d_margin = nullptr;    // [1] count of margin flags (PR_SC_ARITH_F16)
@@ -315,6 +316,7 @@ static int create_common(int device_id, hipStream_t external, bool use_external,
   if (const char* s = getenv("PR_SC_BINARY")) ctx->sc_binary = atoi(s) != 0;
   if (const char* s = getenv("PR_SC_BINARY_PAIR_SCALE")) ctx->sc_pair_scale = (float)atof(s);
   if (const char* s = getenv("PR_XROW")) ctx->xrow_direct = strcmp(s, "direct") == 0;
+  if (const char* s = getenv("PR_SC_ONLINE")) ctx->sc_online_h = strcmp(s, "h") == 0;
   *out = ctx;
   return PR_OK;
 }
@@ -703,7 +705,7 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
                               ctx->timing ? ctx->ev_t : nullptr);
     if (ctx->timing) ctx->timing_valid = 3;
   }
-  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && q->count > 8)
+  else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && (q->count > 8 || !ctx->sc_online_h))
     pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 0);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0)
     pr::launch_sc_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit);

@@ -21,6 +21,9 @@
 //  * single product (LO = false): the unit fits 256 registers, so the workgroup has EIGHT waves - two per SIMD, which do overlap - over
 //    8 query groups of the compact image (SCF_*: 64 queries in 160 KB of LDS); for m <= 8 (an online call) all eight waves share ONE query
 //    group and split the DB groups (NQG = 1: 20 KB of LDS, several workgroups per CU, 0.11 ms per 100k-entry DB = 5.3 TB/s).
+#include <cstdlib>
+#include <cstring>
+
 #include "kernels.hpp"
 // Split-f16 form, register placement (round 3): one wave per SIMD owns 256 ArchVGPRs + 256 AccVGPRs, and everything an MFMA only READS can
 // live in the AccVGPR half without ever passing through a VALU instruction: vector-memory and LDS loads write AccVGPRs directly and MFMAs
@@ -611,7 +614,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
 
 }  // namespace
 
-size_t sc_match_e_lds_bytes(int single, int nqg) { return (single ? (size_t)nqg * SCF_QIMG : (size_t)4 * SCH_QIMG) + 64 + (single ? 64 * nqg : 0); }
+size_t sc_match_e_lds_bytes(int single, int nqg) { return (single ? (size_t)nqg * SCF_QIMG : (size_t)nqg * SCH_QIMG) + 64 + (single ? 64 * nqg : 0); }
 
 void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
                        int nsplit_override, int single) {
@@ -633,6 +636,14 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
   };
   if (single && m <= 8) go(sc_match_e_kernel<false, 8, 1>, 8);
   else if (single) go(sc_match_e_kernel<false, 8, 8>, 8);
+  else if (m <= 8) {   // an online call in split-f16, both channels: one query group per workgroup (see launch_sc_match_e_bin); 8 x nsplit = one workgroup per CU
+    int ns = DG / 32 < 32 ? (DG / 32 > 0 ? DG / 32 : 1) : 32;
+    if (nsplit_override > 0) ns = nsplit_override * 4 <= DG ? nsplit_override : (DG >= 4 ? DG / 4 : 1);
+    auto kern = sc_match_e_kernel<true, 4, 1>;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(0, 1));
+    hipLaunchKernelGGL(kern, dim3(8 * ns), dim3(256), sc_match_e_lds_bytes(0, 1), st, static_cast<const char*>(qpk), static_cast<const char*>(dpk),
+                       static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, ns, none);
+  }
   else go(sc_match_e_kernel<true, 4, 4>, 4);
 }
 
@@ -664,9 +675,22 @@ void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* d
   };
   if (m <= 8) {      // an online call: sc_match_h.hip's one-group form for the split-f16 launches, all eight waves on one query group here
     ScBin b = bin;
+    // the split-f16 launches of an online call: this file's kernel with ONE query group per workgroup - its four waves split the DB groups,
+    // the DB operand ring five positions deep in AccVGPRs (0.303 -> 0.278 ms per call at m = 1, 0.317 -> 0.300 at m = 8 against
+    // sc_match_h.hip's one-group form, which PR_SC_ONLINE=h brings back)
+    static const bool online_e = !(getenv("PR_SC_ONLINE") && !strcmp(getenv("PR_SC_ONLINE"), "h"));
+    auto split1 = [&](int chsel, int gate) {
+      b.chsel = chsel; b.gate = gate;
+      if (!online_e) { launch_sc_match_h(st, qpk, m, dpk, n, cst, d_p, d_i, nsplit_override, &b); return; }
+      int nsplit = DG / 64 < 32 ? (DG / 64 > 0 ? DG / 64 : 1) : 32;          // 8 x nsplit workgroups = one per CU, >= 8 units per wave
+      if (nsplit_override > 0) nsplit = nsplit_override * 8 <= DG ? nsplit_override : (DG >= 8 ? DG / 8 : 1);
+      auto kern = sc_match_e_kernel<true, 4, 1>;
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(0, 1));
+      hipLaunchKernelGGL(kern, dim3(8 * nsplit), dim3(256), sc_match_e_lds_bytes(0, 1), st, static_cast<const char*>(qpk),
+                         static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, b);
+    };
     if (ev) (void)hipEventRecord(ev[0], st);
-    b.chsel = 0; b.gate = 0;
-    launch_sc_match_h(st, qpk, m, dpk, n, cst, d_p, d_i, nsplit_override, &b);
+    split1(0, 0);
     if (ev) (void)hipEventRecord(ev[1], st);
     {
       int nsplit = DG / 256 > 0 ? DG / 256 : 1;                      // ~32 DB groups per workgroup, 4 per wave (launch_sc_match_e: DG / 128 with four XCDs per channel)
@@ -678,8 +702,7 @@ void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* d
                          static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, b);
     }
     if (ev) (void)hipEventRecord(ev[2], st);
-    b.chsel = 1; b.gate = 2;
-    launch_sc_match_h(st, qpk, m, dpk, n, cst, d_p, d_i, nsplit_override, &b);
+    split1(1, 2);
     if (ev) (void)hipEventRecord(ev[3], st);
     return;
   }
