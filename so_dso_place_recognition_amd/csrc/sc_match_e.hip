@@ -666,7 +666,8 @@ void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* d
     return nsplit;
   };
   auto go = [&](auto kern, int nw, int nqg, int single, int chsel, int gate) {
-    const int QGW = (QG8 + nqg - 1) / nqg, nsplit = grid(QGW);
+    const int QGr = (m + 7) / 8;                                       // query groups that hold queries (the image is padded to fours)
+    const int QGW = ((QGr < QG8 ? QGr : QG8) + nqg - 1) / nqg, nsplit = grid(QGW);
     ScBin b = bin;
     b.chsel = chsel; b.gate = gate;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(single, nqg));
@@ -703,6 +704,16 @@ void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* d
     }
     if (ev) (void)hipEventRecord(ev[2], st);
     split1(1, 2);
+    if (ev) (void)hipEventRecord(ev[3], st);
+    return;
+  }
+  if (m <= 16) {     // 9 .. 16 queries: two query groups per workgroup, the other two (four) wave pairs take other DB groups instead of multiplying padding
+    if (ev) (void)hipEventRecord(ev[0], st);
+    go(sc_match_e_kernel<true, 4, 2>, 4, 2, 0, 0, 0);
+    if (ev) (void)hipEventRecord(ev[1], st);
+    go(sc_match_e_kernel<false, 8, 2, true>, 8, 2, 1, 1, 1);
+    if (ev) (void)hipEventRecord(ev[2], st);
+    go(sc_match_e_kernel<true, 4, 2>, 4, 2, 0, 1, 2);
     if (ev) (void)hipEventRecord(ev[3], st);
     return;
   }

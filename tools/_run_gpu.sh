@@ -1,6 +1,3 @@
-mkdir -p gpurun_out
-timeout 2400 python -m pytest tests -m gpu -q > gpurun_out/r05_gputest.log 2>&1; echo "pytest rc=$?" >> gpurun_out/r05_gputest.log
-grep -E "passed|failed|rc=" gpurun_out/r05_gputest.log
-for m in 1 8; do echo "m=$m: $(python tools/latency_probe.py $m 2>/dev/null | tail -1)"; done
-PR_SC_BINARY=0 python tools/latency_probe.py 1 2>/dev/null | tail -1
-PR_SC_BINARY=0 PR_SC_ONLINE=h python tools/latency_probe.py 1 2>/dev/null | tail -1
+for m in 9 12 16 24 32; do echo "m=$m: $(python tools/latency_probe.py $m 2>/dev/null | tail -1)"; done
+timeout 900 python tools/fuzz_all.py 61 30 match,matcher,group 2>&1 | grep -E "^BAD|fuzz_all"
+timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_binary.py -q 2>&1 | grep -E "passed|failed"
