@@ -108,3 +108,17 @@ def test_torch_finds_its_gpu_after_the_library_was_used_first():
                 "assert np.array_equal(i2.cpu().numpy(), idx), (i2, idx)\n"
                 "print('ok')")
     assert r.returncode == 0, r.stdout + r.stderr
+
+
+def test_split_f16_operand_pairs_cover_the_three_products_once(tmp_path):
+    """The SC matchers run the three split products of a frequency (q_hi d_hi + q_hi d_lo + q_lo d_hi, 20 rings each) as two 16x16x32 MFMAs
+    whose 16-byte lane pieces come from fixed places of the packed query rows and DB tiles (csrc/kernels.hpp).  tests/sch_layout_check.cpp
+    walks those places with the header's own functions and the pack's layout rules: 60 products, each once, nothing else."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "sch_layout_check")
+    r = subprocess.run(["/opt/rocm/bin/hipcc", "-x", "hip", "--cuda-host-only", "-std=c++17", "-I", os.path.join(root, "so_dso_place_recognition_amd", "csrc"),
+                        os.path.join(root, "tests", "sch_layout_check.cpp"), "-o", exe], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.stdout
