@@ -25,21 +25,35 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TB = M2_TILE * 4;            // bytes per (channel, tile)
 constexpr int TV = TB / 16;                // 16-byte vectors per tile: [step 12][hi|lo][64]
 
+// One thread per 8 consecutive values of a variant row: they are 8 consecutive halves of the image (16 bytes of the hi tile, 16 of the lo
+// tile), so the image leaves as two 16-byte stores per thread (round 5; the first form stored every half by itself - 2-byte scattered
+// stores, 0.94 ms per 50 000 signatures at ~1 TB/s).  The arithmetic per value is unchanged: the same image, bit for bit.
 template <typename T>
-__global__ __launch_bounds__(256) void m2dp_pack_h_kernel(const T* __restrict__ sig, int sigs, unsigned short* __restrict__ packed,
+__global__ __launch_bounds__(192) void m2dp_pack_h_kernel(const T* __restrict__ sig, int sigs, unsigned short* __restrict__ packed,
                                                            int tiles) {
-  const int sg = blockIdx.x, tid = threadIdx.x;      // one workgroup per signature (4 variant rows x 384)
+  const int sg = blockIdx.x, tid = threadIdx.x;      // one workgroup per signature (4 variant rows x 384 = 192 runs of 8)
   const int tile = sg >> 3, e = sg & 7;
-  for (int o = tid; o < 4 * 384; o += 256) {
-    const int var = o / 384, c = o - var * 384, ch = c / 192, k = c - ch * 192;
-    const double v = (double)sig[((size_t)sg * 4 + var) * 384 + c] * 256.0;
+  const int var = tid / 48, c = (tid - var * 48) * 8, ch = c / 192, k = c - ch * 192;
+  const T* src = sig + ((size_t)sg * 4 + var) * 384 + c;
+  T x[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) x[i] = src[i];
+  unsigned short h[8], l[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const double v = (double)x[i] * 256.0;
     const _Float16 hi = (_Float16)v;
     const _Float16 lo = (_Float16)(v - (double)hi);
-    const int row = e * 4 + var, step = k >> 4, lane = (((k >> 3) & 1) << 5) | row;
-    const size_t base = ((size_t)ch * tiles + tile) * (TB / 2) + ((size_t)(step * 2) * 64 + lane) * 8 + (k & 7);
-    packed[base] = __builtin_bit_cast(unsigned short, hi);
-    packed[base + 64 * 8] = __builtin_bit_cast(unsigned short, lo);
+    h[i] = __builtin_bit_cast(unsigned short, hi);
+    l[i] = __builtin_bit_cast(unsigned short, lo);
   }
+  const int row = e * 4 + var, step = k >> 4, lane = (((k >> 3) & 1) << 5) | row;
+  const size_t base = ((size_t)ch * tiles + tile) * (TB / 2) + ((size_t)(step * 2) * 64 + lane) * 8;      // (k & 7 = 0: a 16-byte boundary)
+  u32x4 hv, lv;
+#pragma unroll
+  for (int i = 0; i < 4; i++) { hv[i] = h[2 * i] | ((unsigned)h[2 * i + 1] << 16); lv[i] = l[2 * i] | ((unsigned)l[2 * i + 1] << 16); }
+  *reinterpret_cast<u32x4*>(packed + base) = hv;
+  *reinterpret_cast<u32x4*>(packed + base + 64 * 8) = lv;
 }
 
 struct HL { u32x4 h, l; };
@@ -269,9 +283,9 @@ __global__ __launch_bounds__(512, 2) void m2dp_match_h8_kernel(const u32x4* __re
 void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, void* packed, int tiles) {
   if (sigs <= 0) return;
   if (dtype == 0)
-    hipLaunchKernelGGL(m2dp_pack_h_kernel<double>, dim3(sigs), dim3(256), 0, st, (const double*)sig, sigs, (unsigned short*)packed, tiles);
+    hipLaunchKernelGGL(m2dp_pack_h_kernel<double>, dim3(sigs), dim3(192), 0, st, (const double*)sig, sigs, (unsigned short*)packed, tiles);
   else
-    hipLaunchKernelGGL(m2dp_pack_h_kernel<float>, dim3(sigs), dim3(256), 0, st, (const float*)sig, sigs, (unsigned short*)packed, tiles);
+    hipLaunchKernelGGL(m2dp_pack_h_kernel<float>, dim3(sigs), dim3(192), 0, st, (const float*)sig, sigs, (unsigned short*)packed, tiles);
 }
 
 void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i, int single) {
