@@ -620,8 +620,11 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
                        int nsplit_override, int single) {
   if (m <= 0 || n <= 0) return;
   const int QG8 = single ? sc_qgroups8_f16(m) : sc_qgroups8(m), DG = sc_dgroups(n);
-  const int nqg = single ? (m <= 8 ? 1 : 8) : 4;
-  const int QGW = (single && m <= 8) ? 1 : QG8 / nqg;   // workgroups along the queries (8 nqg queries each)
+  // query groups per workgroup: as many as hold queries (an online batch of 9 .. 16 | .. 32 keyframes: the waves a group would leave to the
+  // padding of the image take other DB groups instead)
+  const int QGr = (m + 7) / 8;
+  const int nqg = single ? (m <= 8 ? 1 : m <= 16 ? 2 : m <= 32 ? 4 : 8) : (m <= 16 && m > 8 ? 2 : 4);
+  const int QGW = (single && m <= 8) ? 1 : ((QGr < QG8 ? QGr : QG8) + nqg - 1) / nqg;   // workgroups along the queries (8 nqg queries each)
   int nsplit = (128 + QGW - 1) / QGW;
   if (QGW <= 2) nsplit = 32 / QGW;                      // a few query groups (an online batch of 9 .. 64 keyframes): exactly one workgroup per CU, see launch_sc_match_e_bin
   if (nsplit > DG / 32) nsplit = DG / 32;
@@ -635,6 +638,8 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
                        static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, none);
   };
   if (single && m <= 8) go(sc_match_e_kernel<false, 8, 1>, 8);
+  else if (single && nqg == 2) go(sc_match_e_kernel<false, 8, 2>, 8);
+  else if (single && nqg == 4) go(sc_match_e_kernel<false, 8, 4>, 8);
   else if (single) go(sc_match_e_kernel<false, 8, 8>, 8);
   else if (m <= 8) {   // an online call in split-f16, both channels: one query group per workgroup (see launch_sc_match_e_bin); 8 x nsplit = one workgroup per CU
     int ns = DG / 32 < 32 ? (DG / 32 > 0 ? DG / 32 : 1) : 32;
@@ -644,6 +649,7 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
     hipLaunchKernelGGL(kern, dim3(8 * ns), dim3(256), sc_match_e_lds_bytes(0, 1), st, static_cast<const char*>(qpk), static_cast<const char*>(dpk),
                        static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, ns, none);
   }
+  else if (nqg == 2) go(sc_match_e_kernel<true, 4, 2>, 4);
   else go(sc_match_e_kernel<true, 4, 4>, 4);
 }
 
