@@ -1,4 +1,2 @@
-for m in 12 16 24 32; do echo "f16 m=$m: $(python tools/latency_probe.py $m f16 2>/dev/null | tail -1)"; done
-PR_SC_BINARY=0 python tools/latency_probe.py 16 2>/dev/null | tail -1
-timeout 1500 python -m pytest tests/test_gpu_f16.py tests/test_gpu_parity.py tests/test_gpu_binary.py -q 2>&1 | grep -E "passed|failed"
-timeout 600 python tools/fuzz_all.py 95 30 match,matcher,fused 2>&1 | grep -E "^BAD|fuzz_all:"
+bash tools/abn.sh 2 nopf | sed 's/select.*//'
+for m in 1 8 16 32 64; do echo "m=$m new: $(python tools/latency_probe.py $m 2>/dev/null | tail -1)   old: $(PR_AMD_LIB=tools/expbuild/libpr_amd_nopf.so python tools/latency_probe.py $m 2>/dev/null | tail -1)"; done
