@@ -1,2 +1,9 @@
-bash tools/abn.sh 2 nopf | sed 's/select.*//'
-for m in 1 8 16 32 64; do echo "m=$m new: $(python tools/latency_probe.py $m 2>/dev/null | tail -1)   old: $(PR_AMD_LIB=tools/expbuild/libpr_amd_nopf.so python tools/latency_probe.py $m 2>/dev/null | tail -1)"; done
+mkdir -p gpurun_out
+: > gpurun_out/r05_fuzz5.txt
+for s in 101 102 103 104; do
+  echo "## seed $s" >> gpurun_out/r05_fuzz5.txt
+  timeout 700 python tools/fuzz_all.py $s 30 2>&1 | grep -E "^BAD|fuzz_all:" >> gpurun_out/r05_fuzz5.txt
+done
+echo "## big seed 111" >> gpurun_out/r05_fuzz5.txt
+timeout 900 python tools/fuzz_all.py 111 12 match,group,matcher,big 2>&1 | grep -E "^BAD|fuzz_all:" >> gpurun_out/r05_fuzz5.txt
+cat gpurun_out/r05_fuzz5.txt
