@@ -1,9 +1,5 @@
-mkdir -p gpurun_out
-: > gpurun_out/r05_fuzz5.txt
-for s in 101 102 103 104; do
-  echo "## seed $s" >> gpurun_out/r05_fuzz5.txt
-  timeout 700 python tools/fuzz_all.py $s 30 2>&1 | grep -E "^BAD|fuzz_all:" >> gpurun_out/r05_fuzz5.txt
-done
-echo "## big seed 111" >> gpurun_out/r05_fuzz5.txt
-timeout 900 python tools/fuzz_all.py 111 12 match,group,matcher,big 2>&1 | grep -E "^BAD|fuzz_all:" >> gpurun_out/r05_fuzz5.txt
-cat gpurun_out/r05_fuzz5.txt
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/tcp
+rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum -d /tmp/tcp -o sc -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /tmp/tcp.log 2>&1
+python $GRAFT_REPO_ROOT/profiles/summarize.py $(find /tmp/tcp -name "*_results.db") | grep -E "sc_match_e" | cut -c1-200
+tail -3 /tmp/tcp.log | cut -c1-200
