@@ -102,6 +102,26 @@ def blas_baseline(q_host, db_host, S):
     return time.perf_counter() - t0, top1, nthr
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks here (torch.distributed.run, one rank per GPU,
+    rendezvous on 127.0.0.1 at a free port) with the same command line.  The ranks inherit stdout / stderr, so rank 0's single JSON line is
+    this command's JSON line; the exit code is the launcher's."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")               # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    rc = subprocess.call(cmd, env=env)
+    if rc != 0:
+        raise SystemExit(rc)
+
+
 def via_group(args):
     """--via-group: the same metric through the C ABI's own sharding (pr_group: one process drives all GPUs, RCCL in-process).  The call takes
     HOST query buffers (it is the drop-in form of run_test.m:25-57), so the 39 MB of queries cross PCIe in every step: reported as its own
@@ -405,6 +425,8 @@ def main():
 
     if args.via_group:
         return via_group(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return self_launch(args)
 
     import numpy as np
     import torch
@@ -420,6 +442,8 @@ def main():
         local = 0                                              # all ranks share cuda:0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    if args.backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit(f"bench.py --gpus {world}: only {torch.cuda.device_count()} HIP device(s) visible (one rank per GPU)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:

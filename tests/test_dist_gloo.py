@@ -129,6 +129,22 @@ def test_merge_topk_ties_and_padding():
     assert i.tolist()[0][:5] == [2, 5, 7, 9, 11] and i.tolist()[0][5] == -1
 
 
+def test_bench_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (the shape of the driver's command) must start two ranks itself.  Without a GPU
+    every rank refuses loudly (there is no CPU path): the refusal - not an assertion about WORLD_SIZE - is what comes back."""
+    import subprocess
+    import torch as _t
+    if _t.cuda.is_available():
+        pytest.skip("CPU-only check; the GPU form is test_bench_two_ranks_on_one_gpu")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--backend", "gloo",
+                        "--no-cpu-baseline", "--no-extra"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode != 0
+    # (the launcher ends the other rank as soon as one has failed: one or two refusals)
+    assert (r.stdout + r.stderr).count("bench.py needs an MI355X") >= 1 and "AssertionError" not in r.stderr
+    assert "local_rank" in r.stderr                                  # the launcher's failure report: ranks were started
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("arith", ["f16x2", "f16"])
 def test_bench_two_ranks_on_one_gpu(tmp_path, arith):
@@ -137,10 +153,13 @@ def test_bench_two_ranks_on_one_gpu(tmp_path, arith):
     same exchanges (k + 56 candidates per shard, margin check on the merged list)."""
     import json
     import subprocess
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(29600 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    # the driver's plain command: no launcher around it, bench.py starts its own ranks (bench.py::self_launch)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1",
            "--warmup", "0", "--db", "6001", "--queries", "130", "--backend", "gloo", "--no-cpu-baseline", "--no-extra", "--sc-arith", arith]
+    if arith == "f16":   # and the driver's launcher form (python -m torch.distributed.run ... bench.py --gpus 2) for the other arithmetic
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(29600 + os.getpid() % 300)] + cmd[1:]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
