@@ -52,8 +52,8 @@ enum { PR_SC_ARITH_F16X2 = 0, PR_SC_ARITH_F32 = 1, PR_SC_ARITH_F16 = 2 };
 enum { PR_NAN_EXCLUDE = 0, PR_NAN_FAIL = 1 };
 enum { PR_WARN_NAN_ROWS = 1, PR_WARN_M2DP_SVD = 2, PR_WARN_F16_FALLBACK = 4, PR_WARN_ORDER_RESOLVED = 8,
        PR_WARN_ORDER_UNRESOLVED = 16 };   /* bits of pr_take_warnings; ORDER_RESOLVED: a query was answered from its exact fp64 row (order or containment
-                                            check, below); the last one: a stream-ordered call met more than 64 such queries - those beyond the 64th keep
-                                            the answer of the re-evaluated candidate list */
+                                            check, below); the last one: a caller of the sharded per-pass form stopped (last_pass != 0) with flagged queries left -
+                                            those keep the answer of the re-evaluated candidate list.  The library's own calls, stream-ordered or not, run every pass */
 
 #define PR_SC_SIG_LEN 2400    /* 2 x numS*numR = 2 x 60*20, SC/SC.h:7-8, test_sc.cpp:37-38 */
 #define PR_M2DP_SIG_LEN 384   /* 2 x (numP*numQ + numS*numR) = 2 x 192, M2DP/M2DP.h:7-10, test_m2dp.cpp:37-39 */
@@ -78,8 +78,8 @@ int pr_set_nan_policy(pr_ctx* ctx, int policy);      /* PR_NAN_EXCLUDE | PR_NAN_
 int pr_get_nan_policy(const pr_ctx* ctx);
 /* on != 0: EVERY query of a top-k call is treated as flagged, i.e. answered from its exact fp64 row (DESIGN.md section 2 "Returned order"):
  * returned scores are then the reference's doubles to rounding (|score - oracle| < 1e-9 whatever |z|; by default they carry the fp32 pass's
- * ~2e-7 relative error of the row sigma, 3e-5 absolute at z = -160).  The host calls and pr_group resolve all queries (passes of 64); a
- * stream-ordered call its first 64 (PR_WARN_ORDER_UNRESOLVED beyond).  Off by default; the environment variable PR_FORCE_ORDER_FLAGS=1 sets it
+ * ~2e-7 relative error of the row sigma, 3e-5 absolute at z = -160).  The host calls, pr_group and stream-ordered calls resolve all queries (passes of 64;
+ * a stream-ordered call of m queries chains ceil(m / 64) of them).  Off by default; the environment variable PR_FORCE_ORDER_FLAGS=1 sets it
  * at creation (tests). */
 int pr_set_exact_statistics(pr_ctx* ctx, int on);
 /* Binary intensity channel (no reference counterpart as a switch; the arithmetic is processSC.m:15-33 on the values SC/SC.cpp:67-72 writes:
@@ -276,14 +276,16 @@ int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2
  * mask, the k smallest by (score, index): indices and scores of that query are then those of fp64 arithmetic throughout (run_test.m:38-57),
  * whatever the all-pairs pass made of it.  Three forms, all in passes of 64 flagged queries (ascending):
  *   pr_order_resolve_async_dev  single shard, right after pr_rerank_dev; STREAM-ORDERED, no host synchronisation (fixed-grid kernels that
- *                               leave at once when nothing is flagged; hipGraph-capturable).  One pass: up to 64 flagged queries per call;
- *                               beyond that PR_WARN_ORDER_UNRESOLVED.  mom_sc / mom_m2 rows of resolved queries are overwritten with the
- *                               exact ones.  PR_WARN_ORDER_RESOLVED is raised (at pr_take_warnings) when a query was.
+ *                               leave at once when nothing is flagged; hipGraph-capturable).  ceil(m / 64) passes are chained on the
+ *                               stream, so ALL flagged queries are resolved whatever their number (an empty pass costs its launches,
+ *                               ~10 us).  mom_sc / mom_m2 rows of resolved queries are overwritten with the exact ones.
+ *                               PR_WARN_ORDER_RESOLVED is raised (at pr_take_warnings) when a query was.
  *   pr_order_resolve_dev        the same with a host round trip (reads the count back): ALL flagged queries, *resolved (may be NULL)
  *                               = their number.  The host top-k calls use this one.
  *   sharded                     after pr_rerank_finish_dev, per pass (offset = 0, 64, ...; pr_order_flagged_count gives the total, with a host
- *                               synchronisation - a stream-ordered caller runs pass 0 only and finds PR_WARN_ORDER_UNRESOLVED when that was
- *                               not all; a caller that runs every pass does not): pr_order_exact_moments_dev = this shard's rows of
+ *                               synchronisation; a stream-ordered caller chains ceil(m / 64) passes - empty ones leave at once).  The pass
+ *                               called with last_pass != 0 raises PR_WARN_ORDER_UNRESOLVED when flagged queries remain behind it (a
+ *                               caller that stops early); no pass ever clears that bit: pr_order_exact_moments_dev = this shard's rows of
  *                               the flagged queries (kept in the context) and their exact (count, mean, M2), exact DEVICE f64 [m][4][3] (rows
  *                               of other queries: unspecified) -> all-gather -> exact_all [G][m][4][3] -> pr_order_exact_select_dev = this
  *                               shard's k best under the statistics of all shards (Chan combination in rank order), sel DEVICE f64 [64][2][k]
@@ -298,7 +300,8 @@ int pr_order_resolve_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int s
                          int32_t* idx, double* score, int32_t* resolved);
 int pr_order_flagged_count(pr_ctx* ctx, int32_t m, int32_t* count);   /* flagged queries of the last m-query pr_rerank_dev / pr_rerank_finish_dev (synchronises) */
 int pr_order_exact_moments_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
-                               const double* mom_sc, const double* mom_m2, int32_t G_mom, int32_t m, int32_t n_local, int32_t offset, double* exact);
+                               const double* mom_sc, const double* mom_m2, int32_t G_mom, int32_t m, int32_t n_local, int32_t offset,
+                               int32_t last_pass /* non-zero: the caller runs no pass behind this one */, double* exact);
 int pr_order_exact_select_dev(pr_ctx* ctx, const double* exact_all, int32_t G, int32_t m, int32_t n_local, int32_t q_row0, int32_t db_row0,
                               int32_t mask_width, double p_weight, int has_sc, int has_m2, int32_t k, int32_t offset, double* sel);
 int pr_order_exact_merge_dev(pr_ctx* ctx, const double* sel_all, int32_t G, int32_t m, int32_t k, int32_t offset, int32_t* idx, double* score);

@@ -45,7 +45,7 @@ SYMBOLS = {
     "pr_order_resolve_async_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_order_resolve_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp, _vp]),
     "pr_order_flagged_count": (C.c_int, [_vp, _i32, _vp]),
-    "pr_order_exact_moments_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "pr_order_exact_moments_dev": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "pr_order_exact_select_dev": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _dbl, C.c_int, C.c_int, _i32, _i32, _vp]),
     "pr_order_exact_merge_dev": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "pr_widen_scores_dev": (C.c_int, [_vp, _vp, C.c_int64, _vp]),

@@ -9,6 +9,7 @@ Arrays are numpy on the host; the device-resident path used by bench.py / dist.p
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -45,6 +46,7 @@ class Context:
             self.check(self.lib.pr_set_sc_arith(h, {"f16x2": _lib.SC_ARITH_F16X2, "f32": _lib.SC_ARITH_F32, "f16": _lib.SC_ARITH_F16}[sc_arith]))
         if nan_policy is not None:
             self.check(self.lib.pr_set_nan_policy(h, {"exclude": _lib.NAN_EXCLUDE, "fail": _lib.NAN_FAIL}[nan_policy]))
+        self.exact_statistics = bool(exact_statistics) if exact_statistics is not None else os.environ.get("PR_FORCE_ORDER_FLAGS") == "1"
         if exact_statistics is not None:
             self.check(self.lib.pr_set_exact_statistics(h, int(bool(exact_statistics))))
         if sc_binary is not None:      # False: a binary intensity channel goes through the split-f16 kernel like any other (pr_set_sc_binary)
@@ -180,14 +182,19 @@ def default_context() -> Context:
     return _default_ctx
 
 
-_exact_ctx = None
+class _exact_statistics:
+    """`with _exact_statistics(ctx):` - pr_set_exact_statistics(ctx, 1) around a call, the context's own setting back afterwards."""
 
+    def __init__(self, ctx: Context):
+        self.ctx, self.prev = ctx, ctx.exact_statistics
 
-def _exact_context() -> Context:
-    global _exact_ctx
-    if _exact_ctx is None:
-        _exact_ctx = Context(0, exact_statistics=True)
-    return _exact_ctx
+    def __enter__(self):
+        self.ctx.check(self.ctx.lib.pr_set_exact_statistics(self.ctx.h, 1))
+        return self.ctx
+
+    def __exit__(self, *exc):
+        self.ctx.check(self.ctx.lib.pr_set_exact_statistics(self.ctx.h, int(self.prev)))
+        return False
 
 
 def _csr(pts_list):
@@ -406,8 +413,10 @@ def run_test(type_, hist1, hist2, gt1=None, gt2=None, loop_diff=None, mask_width
     best score (run_test.m:58), so every query is then answered from its exact fp64 row unless the caller brings a context of its own
     (pr_set_exact_statistics: scores are the reference's doubles to rounding, two queries whose scores agree to 1e-5 keep their places)."""
     if gt1 is not None and ctx is None and type_ in ("sc", "m2dp", TYPE_SC, TYPE_M2DP):
-        ctx = _exact_context()
-    idx, sc = match_topk(type_, hist1, hist2, mask_width, 2.0, 1, ctx)
+        with _exact_statistics(default_context()) as c:            # the default context (its device, its arithmetic), exact statistics for this call
+            idx, sc = match_topk(type_, hist1, hist2, mask_width, 2.0, 1, c)
+    else:
+        idx, sc = match_topk(type_, hist1, hist2, mask_width, 2.0, 1, ctx)
     if gt1 is None:
         return sc[:, 0], idx[:, 0]
     from . import eval as _eval

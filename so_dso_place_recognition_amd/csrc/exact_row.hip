@@ -113,15 +113,16 @@ struct XrowArgs {
   double* exact;                                                // [m][4][3]
   double* rows;                                                 // [RESOLVE_SLOTS][4][n_local]
   unsigned* tick;                                               // [1] zero between launches
-  int* dflags;                                                  // deferred warning bits of the context ([2] resolved, [3] more flagged than one pass)
+  int* dflags;                                                  // deferred warning bits of the context ([2] resolved, [3] flagged queries left unresolved)
+  int last_pass;                                                // the caller runs no pass behind this one: what it leaves is reported in dflags[3]
 };
 
 // partial [slot][NB][4][3] of this pass -> exact [q][4][3]; run by the last workgroup of a rows kernel (all of its threads)
 __device__ void xrow_finish(const XrowArgs& A, const int* s_list, int ns, int total, double* red, int tid) {
   if (tid == 0) {
     *A.tick = 0u;                                               // ready for the next launch
-    // (a caller that runs every pass leaves [3] clear: the pass that reaches the end of the list takes back what the earlier ones announced)
-    if (A.dflags) { A.dflags[2] = 1; if (total - A.offset > RESOLVE_SLOTS) A.dflags[3] = 1; else if (A.offset > 0) A.dflags[3] = 0; }
+    // ([3] is only ever SET here - an earlier call's bit stays until pr_take_warnings reads it - and only by a pass its caller declares its last)
+    if (A.dflags) { A.dflags[2] = 1; if (A.last_pass && total - A.offset > RESOLVE_SLOTS) A.dflags[3] = 1; }
   }
   auto part_at = [&](size_t i) {                                 // written by other workgroups: agent-scope loads (L2), no copy of this CU's L1
     return __longlong_as_double(__hip_atomic_load(reinterpret_cast<const long long*>(A.partial + i), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -733,20 +734,25 @@ hipError_t xrow_set_twiddles(const double* cos60, const double* sin60) {
 
 void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                  const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* flags, int32_t* list, int32_t* cnt,
-                 int offset, bool compacted, double* partial, double* exact, double* rows, unsigned* tick, int* dflags, double* qspec,
-                 const double* tw, int direct) {
+                 int offset, bool compacted, double* partial, double* exact, double* rows, unsigned* tick, int* dflags, int last_pass,
+                 double* qspec, const double* tw, int direct) {
   if (m <= 0 || n_local <= 0) return;
+  if (!direct) {                           // the spectral kernels ask for more dynamic LDS than a launch gets by default: if the device refuses, the direct form
+    static const bool lds_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_sc_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_SC_LDS) == hipSuccess &&
+                               hipFuncSetAttribute(reinterpret_cast<const void*>(xrow_sc_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)XROW_SC_LDS) == hipSuccess;
+    if (!lds_ok) direct = 1;
+  }
   const int32_t* fl = compacted ? nullptr : resolve_list(st, flags, m, list, cnt);
   if (direct) {                            // PR_XROW=direct: the reference's own formulation (the cross-check of the spectral form)
     int NB = exact_partial_blocks(n_local);
     if (m <= 64 && NB > 256) NB = 256;      // an online call pays for the launch every time and for the resolution once in 10^5 calls: a small grid
-    XrowArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, fl, list, cnt, offset, NB, partial, exact, rows, tick, dflags};
+    XrowArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, fl, list, cnt, offset, NB, partial, exact, rows, tick, dflags, last_pass};
     hipLaunchKernelGGL(xrow_valu_kernel, dim3(NB), dim3(256), 0, st, A);
     return;
   }
   const int ntile = (n_local + XE - 1) / XE;
   const int NB = ntile < 256 ? ntile : 256;                     // one workgroup per CU (its LDS), each walking tiles b, b + NB, ...
-  XrowArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, fl, list, cnt, offset, NB, partial, exact, rows, tick, dflags};
+  XrowArgs A{q_sc, db_sc, sc_dt, q_m2, db_m2, m2_dt, mom_sc, mom_m2, G, m, n_local, fl, list, cnt, offset, NB, partial, exact, rows, tick, dflags, last_pass};
   const int slots = m < RESOLVE_SLOTS ? m : RESOLVE_SLOTS;
   if (q_sc) {
     hipLaunchKernelGGL(xrow_qspec_kernel, dim3(slots, 2), dim3(256), 0, st, A, tw, qspec);

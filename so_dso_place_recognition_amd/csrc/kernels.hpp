@@ -35,7 +35,9 @@ __host__ __device__ constexpr int sch_a2_byte(int k) { return k == 0 ? 48 : k ==
 __host__ __device__ constexpr int sch_b1_byte(int lane) { return lane < 48 ? lane * 16 : SCH_DTILE + (lane - 48) * 16; }   // from the hi tile's first byte
 __host__ __device__ constexpr int sch_b2_byte(int lane) { return lane < 32 ? lane * 16 : lane < 48 ? SCH_DTILE + lane * 16 : SCH_DTILE + (lane - 32) * 16; }
 // single-product f16 images (PR_SC_ARITH_F16, sc_match_e.hip): the hi halves only
-constexpr int SCF_QBLK = 648;                   // (8-query group, frequency): 16 rows x 40 B, rows 8..15 shifted by 8 B
+constexpr int SCF_QBLK = 640;                   // (8-query group, frequency): 16 rows x 40 B, NO shift of rows 8..15: the rows are read with ds_read2_b64
+                                                // (banks = dword mod 32, 16 consecutive lanes per access) and 10 r mod 32 is distinct for r = 0..15 - the 8-byte shift
+                                                // the 80-byte rows of the split image need made rows 8, 9, 10 collide with rows 5, 6, 7 here (round 6: SQ_LDS_BANK_CONFLICT)
 constexpr int SCF_QIMG = SC_NF * SCF_QBLK;      // 20 088 per (channel, 8-query group); a workgroup holds 8 groups = 64 queries
 constexpr int SCF_DFREQ = 2 * SCH_DTILE;        // Re, Im
 constexpr int SCF_DIMG = SC_NF * SCF_DFREQ;     // 47 616 per (channel, 16-entry DB group) = 2976 B per entry and channel
@@ -111,7 +113,7 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
 // (Measured and dropped: the channel-0 launch of an online call and the binary pass on two streams at once - 0.302 -> 0.308 ms at m = 1,
 // 0.310 -> 0.337 at m = 8: sc_match_h's workgroups fill the LDS of their CUs, the two kernels do not run side by side, and the event hand-offs cost.)
 void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
-                           int nsplit_override, ScBin bin, hipEvent_t* ev);
+                           int nsplit_override, ScBin bin, hipEvent_t* ev, int online_h = 0 /* m <= 8: sc_match_h.hip's one-group form (PR_SC_ONLINE=h, read once at pr_create) */);
 
 // m2dp_match.hip — processM2DP.m:12-22 for both channels.
 void launch_m2dp_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed, int tiles);
@@ -147,7 +149,7 @@ void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, 
 // PR_SC_ARITH_F16: flags[q] = 1 where the candidate list does not provably contain the exact top-k (rerank.hip), count += number of flags
 void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,
                          const double* cand_sc, int k, const double* score, double eps_d, int32_t* flags, int32_t* count,
-                         const int32_t* order_flags = nullptr);
+                         const int32_t* order_flags, double eps_floor, double noise /* the order check's constants of this arithmetic: sigma slack of the containment test */);
 // flags[q] = 1 where the order of the re-evaluated candidates (the selected k and the best one left out) could change under the sigma error
 // of the all-pairs pass (per channel eps_floor + noise / sigma: noise = the largest error of one distance; statistics from mom_* [Gmom][m][2][3])
 // + bit 1 where the candidate list (cand_sc [m][kin]: its all-pairs-pass scores, ascending; score_sel [m][k]: the exact scores of the k selected;
@@ -172,7 +174,7 @@ void launch_flag_compact(hipStream_t st, const int32_t* flags, int m, int32_t* l
 void launch_xrow(hipStream_t st, const void* q_sc, const void* db_sc, int sc_dt, const void* q_m2, const void* db_m2, int m2_dt,
                  const double* mom_sc, const double* mom_m2, int G, int m, int n_local, const int32_t* flags, int32_t* list, int32_t* cnt,
                  int offset, bool compacted, double* partial, double* exact, double* rows, unsigned* tick, int* dflags,
-                 double* qspec /* [xrow_qspec_doubles()] scratch: the slots' query spectra */, const double* tw /* cos | sin of 2 pi t / 60 */,
+                 int last_pass /* no pass follows: flagged queries beyond this pass's 64 are reported in dflags[3] */, double* qspec /* [xrow_qspec_doubles()] scratch: the slots' query spectra */, const double* tw /* cos | sin of 2 pi t / 60 */,
                  int direct /* 1: the reference's own formulation instead of the spectral form */);
 size_t xrow_qspec_doubles();
 hipError_t xrow_set_twiddles(const double* cos60, const double* sin60);   // once per device, before the first launch_xrow (constant memory of exact_row.hip)

@@ -702,7 +702,7 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
     ctx->bin_gen = ctx->bin_gen == 0x7fffffff ? 1 : ctx->bin_gen + 1;
     const pr::ScBin bin = {sigset_bstat(q), sigset_bstat(db), q->binfo, db->binfo, ctx->d_flags + 4, ctx->bin_gen, ctx->sc_bconst, ctx->sc_pair_scale, 0, -1};
     pr::launch_sc_match_e_bin(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, bin,
-                              ctx->timing ? ctx->ev_t : nullptr);
+                              ctx->timing ? ctx->ev_t : nullptr, ctx->sc_online_h ? 1 : 0);
     if (ctx->timing) ctx->timing_valid = 3;
   }
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && (q->count > 8 || !ctx->sc_online_h))
@@ -825,7 +825,7 @@ int pr_f16_margin_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2, i
   if (int rc = set_device(ctx)) return rc;
   pr::launch_zero_ints(ctx->stream, count, 1);
   pr::launch_margin_check(ctx->stream, mom_sc, mom_m2, G, m, p_weight, k_in, cand_score, k, score, PR_F16_DISTANCE_BOUND, flags, count,
-                          ctx->order_m == m ? ctx->d_order : nullptr);
+                          ctx->order_m == m ? ctx->d_order : nullptr, PR_F16_SIGMA_REL, PR_F16_DIST_ERR);
   ctx->order_m = -1;
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
@@ -859,25 +859,34 @@ static int rerank_ticks(pr_ctx* ctx, size_t pairs) {
 static int32_t* res_list(pr_ctx* ctx) { return ctx->d_order + ctx->order_cap; }
 static int32_t* res_cnt(pr_ctx* ctx) { return ctx->d_order + 2 * ctx->order_cap; }
 static unsigned* res_tick(pr_ctx* ctx) { return reinterpret_cast<unsigned*>(ctx->res_partial + (size_t)pr::RESOLVE_SLOTS * pr::RESOLVE_NB * 12); }
-// scratch of the exact-row resolution: the workgroup partials of one pass, exact [m][4][3] (single-shard calls) and the rows of one pass
-static int resolve_scratch(pr_ctx* ctx, int32_t m_exact, int32_t m, int32_t n_local) {
+// scratch of the exact-row resolution: the workgroup partials of one pass, exact [m][4][3] (single-shard calls) ...
+static int resolve_scratch_base(pr_ctx* ctx, int32_t m_exact) {
   if (!ctx->res_partial) {                                    // (+ the ticket of the last-workgroup hand-off, zero between launches)
     PR_HIP(ctx, hipMalloc((void**)&ctx->res_partial, ((size_t)pr::RESOLVE_SLOTS * pr::RESOLVE_NB * 12 + 1) * sizeof(double)));
     PR_HIP(ctx, hipMemsetAsync(ctx->res_partial + (size_t)pr::RESOLVE_SLOTS * pr::RESOLVE_NB * 12, 0, sizeof(double), ctx->stream));
-    PR_HIP(ctx, hipMalloc((void**)&ctx->xqspec, pr::xrow_qspec_doubles() * sizeof(double)));
   }
+  if (!ctx->xqspec) PR_HIP(ctx, hipMalloc((void**)&ctx->xqspec, pr::xrow_qspec_doubles() * sizeof(double)));   // (its own check: a failed allocation is retried, never launched on)
   if ((size_t)m_exact > ctx->res_exact_cap) {
     if (ctx->res_exact) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->res_exact)); ctx->res_exact = nullptr; ctx->res_exact_cap = 0; }
     PR_HIP(ctx, hipMalloc((void**)&ctx->res_exact, (size_t)m_exact * 12 * sizeof(double)));
     ctx->res_exact_cap = (size_t)m_exact;
   }
-  const size_t need = (size_t)(m < pr::RESOLVE_SLOTS ? m : pr::RESOLVE_SLOTS) * 4 * (size_t)n_local;
+  return PR_OK;
+}
+// ... and the rows of one pass, [slots][4][n_local] doubles: `slots` = the queries the pass can hold (a stream-ordered call cannot know how many
+// are flagged: min(m, 64); a call that has read the count back: min(count, 64), and nothing at all when nothing is flagged - the usual case)
+static int resolve_scratch_rows(pr_ctx* ctx, int32_t slots, int32_t n_local) {
+  const size_t need = (size_t)(slots < pr::RESOLVE_SLOTS ? slots : pr::RESOLVE_SLOTS) * 4 * (size_t)n_local;
   if (need > ctx->xrows_cap) {
     if (ctx->xrows) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->xrows)); ctx->xrows = nullptr; ctx->xrows_cap = 0; }
     PR_HIP(ctx, hipMalloc((void**)&ctx->xrows, need * sizeof(double)));
     ctx->xrows_cap = need;
   }
   return PR_OK;
+}
+static int resolve_scratch(pr_ctx* ctx, int32_t m_exact, int32_t m, int32_t n_local) {
+  if (int rc = resolve_scratch_base(ctx, m_exact)) return rc;
+  return resolve_scratch_rows(ctx, m, n_local);
 }
 
 static int select_scratch_x(pr_ctx* ctx, int32_t m, int32_t k) {
@@ -929,9 +938,10 @@ int pr_rerank_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype
 // selection straight into idx / score (+ the compaction of the flags for calls of more than RESOLVE_SMALL_M queries)
 static void resolve_pass(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
                          double* mom_sc, double* mom_m2, int32_t m, int32_t n, int32_t q_row0, int32_t mask_width, double p_weight, int32_t k,
-                         int32_t* idx, double* score, int offset, bool compacted, int* dflags) {
+                         int32_t* idx, double* score, int offset, bool compacted, int* dflags, int last_pass) {
   pr::launch_xrow(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, 1, m, n, ctx->d_order, res_list(ctx), res_cnt(ctx),
-                  offset, compacted, ctx->res_partial, ctx->res_exact, ctx->xrows, res_tick(ctx), dflags, ctx->xqspec, ctx->d_twiddle, ctx->xrow_direct);
+                  offset, compacted, ctx->res_partial, ctx->res_exact, ctx->xrows, res_tick(ctx), dflags, last_pass, ctx->xqspec, ctx->d_twiddle,
+                  ctx->xrow_direct);
   pr::launch_xrow_select(ctx->stream, ctx->d_order, res_list(ctx), res_cnt(ctx), offset, ctx->res_exact, 1, m, n, q_row0, 0, mask_width, p_weight,
                          q_sc != nullptr, q_m2 != nullptr, k, ctx->xrows, ctx->xpart, nullptr, idx, score, q_sc ? mom_sc : nullptr, q_m2 ? mom_m2 : nullptr);
 }
@@ -956,7 +966,13 @@ int pr_order_resolve_async_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc,
   if (int rc = resolve_scratch(ctx, m, m, n)) return rc;
   if (int rc = select_scratch_x(ctx, m, k)) return rc;
   ctx->order_m = -1;
-  resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, k, idx, score, 0, false, ctx->d_flags);
+  // every pass the call could need, chained on the stream: ceil(m / 64) fixed-grid passes, each of whose kernels leaves at once when the
+  // flagged list ends before its offset (the usual case: nothing flagged at all) - a captured graph resolves ALL flagged queries, whatever
+  // their number (round 6; until then one pass, and PR_WARN_ORDER_UNRESOLVED beyond 64).  The first pass compacts the flags of a large call.
+  const int passes = (m + pr::RESOLVE_SLOTS - 1) / pr::RESOLVE_SLOTS;
+  for (int p = 0; p < passes; p++)
+    resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, k, idx, score,
+                 p * pr::RESOLVE_SLOTS, p > 0 && m > pr::RESOLVE_SMALL_M, ctx->d_flags, p == passes - 1);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -969,15 +985,18 @@ int pr_order_resolve_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int s
   if (resolved) *resolved = 0;
   if (m == 0 || ctx->order_m != m) { ctx->order_m = -1; return PR_OK; }
   if (int rc = set_device(ctx)) return rc;
-  if (int rc = resolve_scratch(ctx, m, m, n)) return rc;
-  if (int rc = select_scratch_x(ctx, m, k)) return rc;
   ctx->order_m = -1;
   pr::launch_flag_compact(ctx->stream, ctx->d_order, m, res_list(ctx), res_cnt(ctx));
   int32_t cnt = 0;
   PR_HIP(ctx, hipMemcpyAsync(&cnt, res_cnt(ctx), 4, hipMemcpyDeviceToHost, ctx->stream));
   PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (cnt > 0) {      // the scratch only when something is flagged, and rows for min(count, 64) queries (4 x n doubles each: 3.2 MB per query at n = 100k)
+    if (int rc = resolve_scratch_base(ctx, m)) return rc;
+    if (int rc = resolve_scratch_rows(ctx, cnt, n)) return rc;
+    if (int rc = select_scratch_x(ctx, m, k)) return rc;
+  }
   for (int off = 0; off < cnt; off += pr::RESOLVE_SLOTS)
-    resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, k, idx, score, off, true, nullptr);
+    resolve_pass(ctx, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, m, n, q_row0, mask_width, p_weight, k, idx, score, off, true, nullptr, 0);
   PR_HIP(ctx, hipGetLastError());
   if (cnt > 0) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); ctx->warnings |= PR_WARN_ORDER_RESOLVED; }
   if (resolved) *resolved = cnt;
@@ -1035,7 +1054,8 @@ int pr_rerank_finish_dev(pr_ctx* ctx, const double* mom_sc, const double* mom_m2
 }
 
 int pr_order_exact_moments_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc, int sc_dtype, const void* q_m2, const void* db_m2, int m2_dtype,
-                               const double* mom_sc, const double* mom_m2, int32_t G_mom, int32_t m, int32_t n_local, int32_t offset, double* exact) {
+                               const double* mom_sc, const double* mom_m2, int32_t G_mom, int32_t m, int32_t n_local, int32_t offset, int32_t last_pass,
+                               double* exact) {
   if (!ctx) return PR_EINVAL;
   const bool sc = q_sc || db_sc, m2 = q_m2 || db_m2;
   if ((!sc && !m2) || (sc && (!q_sc || !db_sc || !mom_sc)) || (m2 && (!q_m2 || !db_m2 || !mom_m2)) || !exact || m < 0 || n_local < 1 || G_mom < 1 ||
@@ -1046,7 +1066,8 @@ int pr_order_exact_moments_dev(pr_ctx* ctx, const void* q_sc, const void* db_sc,
   if (int rc = set_device(ctx)) return rc;
   if (int rc = resolve_scratch(ctx, 0, m, n_local)) return rc;
   pr::launch_xrow(ctx->stream, q_sc, db_sc, sc_dtype, q_m2, db_m2, m2_dtype, mom_sc, mom_m2, G_mom, m, n_local, ctx->d_order, res_list(ctx),
-                  res_cnt(ctx), offset, false, ctx->res_partial, exact, ctx->xrows, res_tick(ctx), ctx->d_flags, ctx->xqspec, ctx->d_twiddle, ctx->xrow_direct);
+                  res_cnt(ctx), offset, false, ctx->res_partial, exact, ctx->xrows, res_tick(ctx), ctx->d_flags, last_pass != 0, ctx->xqspec, ctx->d_twiddle,
+                  ctx->xrow_direct);
   PR_HIP(ctx, hipGetLastError());
   return PR_OK;
 }
@@ -1146,30 +1167,52 @@ static int f16_fallback(pr_ctx* ctx, const double* hq_sc, const double* hq_m2, c
           (rc = pr_row_moments_dev(ctx, d[2 * t].as<float>(), d[2 * t + 1].as<float>(), mf, n, mo[t].as<double>()))) break;
     }
     if (rc) break;
-    if (didx.alloc((size_t)kin2 * 4) != hipSuccess || dsc.alloc((size_t)kin2 * 4) != hipSuccess || dsw.alloc((size_t)kin2 * 8) != hipSuccess) { ctx->err = "out of device memory"; rc = PR_ENOMEM; break; }
+    // the flagged queries in RUNS: a query's own row number only enters through the mask (run_test.m:47-53), so without a mask the whole list
+    // is one batch, and with one every maximal run of consecutive row numbers is (a vehicle standing still flags its frames in a row) - one
+    // selection, one re-evaluation and one order resolution per run instead of per query (round 6; until then one query at a time, each
+    // with its own host synchronisation in pr_order_resolve_dev)
+    std::vector<int32_t> run_end;                                // run r = list positions [run_end[r - 1], run_end[r])
+    for (int32_t i = 1; i <= mf; i++)
+      if (i == mf || (mask_width > 0 && F[i] != F[i - 1] + 1)) run_end.push_back(i);
+    int32_t longest = 0;
+    for (size_t r = 0, a0 = 0; r < run_end.size(); a0 = run_end[r++]) longest = std::max<int32_t>(longest, run_end[r] - (int32_t)a0);
+    DevBuf oidx, osc;                                            // a run's results [len][k] (the list is ascending, not contiguous, without a mask)
+    if (didx.alloc((size_t)longest * kin2 * 4) != hipSuccess || dsc.alloc((size_t)longest * kin2 * 4) != hipSuccess ||
+        dsw.alloc((size_t)longest * kin2 * 8) != hipSuccess || oidx.alloc((size_t)longest * k * 4) != hipSuccess ||
+        osc.alloc((size_t)longest * k * 8) != hipSuccess) { ctx->err = "out of device memory"; rc = PR_ENOMEM; break; }
     const bool both = hq_sc && hq_m2;
-    for (int32_t i = 0; i < mf && rc == PR_OK; i++) {           // one row at a time: every flagged query has its own row number for the mask
-      const size_t o = (size_t)i * n;
-      const int32_t q0 = F[i];
+    for (size_t r = 0, a0 = 0; r < run_end.size() && rc == PR_OK; a0 = run_end[r++]) {
+      const int32_t i0 = (int32_t)a0, len = run_end[r] - i0;
+      const size_t o = (size_t)i0 * n;
+      const int32_t q0 = mask_width > 0 ? F[i0] : 0;             // (without a mask the row numbers are not read)
       if (both)
-        rc = pr_fuse_select2_dev(ctx, d[0].as<float>() + o, d[1].as<float>() + o, d[2].as<float>() + o, d[3].as<float>() + o, 1, n,
-                                 mo[0].as<double>() + (size_t)i * 6, mo[1].as<double>() + (size_t)i * 6, 1, q0, 0, mask_width, p_weight, kin2,
+        rc = pr_fuse_select2_dev(ctx, d[0].as<float>() + o, d[1].as<float>() + o, d[2].as<float>() + o, d[3].as<float>() + o, len, n,
+                                 mo[0].as<double>() + (size_t)i0 * 6, mo[1].as<double>() + (size_t)i0 * 6, 1, q0, 0, mask_width, p_weight, kin2,
                                  didx.as<int32_t>(), dsc.as<float>());
       else {
         const int t = hq_sc ? 0 : 1;
-        rc = pr_fuse_select_dev(ctx, d[2 * t].as<float>() + o, d[2 * t + 1].as<float>() + o, 1, n, mo[t].as<double>() + (size_t)i * 6, 1, q0, 0,
+        rc = pr_fuse_select_dev(ctx, d[2 * t].as<float>() + o, d[2 * t + 1].as<float>() + o, len, n, mo[t].as<double>() + (size_t)i0 * 6, 1, q0, 0,
                                 mask_width, p_weight, kin2, didx.as<int32_t>(), dsc.as<float>());
       }
-      if (rc || (rc = pr_widen_scores_dev(ctx, dsc.as<float>(), kin2, dsw.as<double>()))) break;
-      rc = pr_rerank_dev(ctx, hq_sc ? rq[0].as<double>() + (size_t)i * 2400 : nullptr, hq_sc ? ddb_sc : nullptr, PR_F64,
-                         hq_m2 ? rq[1].as<double>() + (size_t)i * 4 * 384 : nullptr, hq_m2 ? ddb_m2 : nullptr, PR_F64,
-                         hq_sc ? mo[0].as<double>() + (size_t)i * 6 : nullptr, hq_m2 ? mo[1].as<double>() + (size_t)i * 6 : nullptr, 1, n, 1, q0, 0,
-                         mask_width, p_weight, kin2, didx.as<int32_t>(), dsw.as<double>(), k, dcand + (size_t)q0 * k, dsc64 + (size_t)q0 * k);
+      if (rc || (rc = pr_widen_scores_dev(ctx, dsc.as<float>(), (int64_t)len * kin2, dsw.as<double>()))) break;
+      rc = pr_rerank_dev(ctx, hq_sc ? rq[0].as<double>() + (size_t)i0 * 2400 : nullptr, hq_sc ? ddb_sc : nullptr, PR_F64,
+                         hq_m2 ? rq[1].as<double>() + (size_t)i0 * 4 * 384 : nullptr, hq_m2 ? ddb_m2 : nullptr, PR_F64,
+                         hq_sc ? mo[0].as<double>() + (size_t)i0 * 6 : nullptr, hq_m2 ? mo[1].as<double>() + (size_t)i0 * 6 : nullptr, len, n, 1, q0, 0,
+                         mask_width, p_weight, kin2, didx.as<int32_t>(), dsw.as<double>(), k, oidx.as<int32_t>(), osc.as<double>());
       if (rc == PR_OK)                                            // (the split pass's own order check: exact row statistics if it fails)
-        rc = pr_order_resolve_dev(ctx, hq_sc ? rq[0].as<double>() + (size_t)i * 2400 : nullptr, hq_sc ? ddb_sc : nullptr, PR_F64,
-                                  hq_m2 ? rq[1].as<double>() + (size_t)i * 4 * 384 : nullptr, hq_m2 ? ddb_m2 : nullptr, PR_F64,
-                                  hq_sc ? mo[0].as<double>() + (size_t)i * 6 : nullptr, hq_m2 ? mo[1].as<double>() + (size_t)i * 6 : nullptr, 1, n, q0,
-                                  mask_width, p_weight, k, dcand + (size_t)q0 * k, dsc64 + (size_t)q0 * k, nullptr);
+        rc = pr_order_resolve_dev(ctx, hq_sc ? rq[0].as<double>() + (size_t)i0 * 2400 : nullptr, hq_sc ? ddb_sc : nullptr, PR_F64,
+                                  hq_m2 ? rq[1].as<double>() + (size_t)i0 * 4 * 384 : nullptr, hq_m2 ? ddb_m2 : nullptr, PR_F64,
+                                  hq_sc ? mo[0].as<double>() + (size_t)i0 * 6 : nullptr, hq_m2 ? mo[1].as<double>() + (size_t)i0 * 6 : nullptr, len, n, q0,
+                                  mask_width, p_weight, k, oidx.as<int32_t>(), osc.as<double>(), nullptr);
+      for (int32_t i = 0; i < len && rc == PR_OK; ) {            // results -> the flagged queries' rows of dcand / dsc64, one copy per stretch of consecutive rows
+        int32_t j = i + 1;
+        while (j < len && F[i0 + j] == F[i0 + j - 1] + 1) j++;
+        if (hipMemcpyAsync(dcand + (size_t)F[i0 + i] * k, oidx.as<int32_t>() + (size_t)i * k, (size_t)(j - i) * k * 4, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess ||
+            hipMemcpyAsync(dsc64 + (size_t)F[i0 + i] * k, osc.as<double>() + (size_t)i * k, (size_t)(j - i) * k * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+          ctx->err = "f16 fallback: device copy failed"; rc = PR_EHIP;
+        }
+        i = j;
+      }
     }
     if (rc == PR_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) { ctx->err = "f16 fallback failed"; rc = PR_EHIP; }
   } while (0);

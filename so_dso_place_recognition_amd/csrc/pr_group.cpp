@@ -472,7 +472,7 @@ static int match_topk_impl(pr_group* g, const double* h1, int32_t m, int32_t mas
       G_HIP(g, hipSetDevice(sh.device));
       G_PR(g, sh, pr_order_exact_moments_dev(sh.ctx, sc ? sh.raw_q : nullptr, sc ? sh.raw_db : nullptr, PR_F64, sc ? nullptr : sh.raw_q,
                                              sc ? nullptr : sh.raw_db, PR_F64, sc ? sh.mom_all : nullptr, sc ? nullptr : sh.mom_all, G, m, sh.rows,
-                                             off, sh.exact));
+                                             off, off + 64 >= flagged, sh.exact));
     }
     for (int r = 0; r < G; r++) { src[r] = g->s[r].exact; dst[r] = g->s[r].exact_all; }
     if (int rc = exchange(g, src, dst, (size_t)m * 12 * 8)) return rc;

@@ -226,31 +226,6 @@ __device__ double row_weight(const double* mom_sc, const double* mom_m2, int G, 
   return w;
 }
 
-// PR_SC_ARITH_F16: is the exact top-k of the candidates provably the exact top-k of ALL entries?  cand_sc = the all-pairs-pass scores of
-// the k_in candidates (ascending: every entry that is NOT a candidate has a pass score >= the last one, T), score = the exact scores of
-// the k selected.  Every non-candidate's exact score is >= T - err(T); if the exact k-th best is below that, nothing outside the list can
-// enter the top-k (pruned candidates: rerank_kernel).  Otherwise - or when statistics / scores are not finite - the query is flagged.
-__global__ __launch_bounds__(64) void margin_check_kernel(const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int G, int m,
-                                                           double p_weight, int kin, const double* __restrict__ cand_sc, int k,
-                                                           const double* __restrict__ score, double eps_d, int32_t* __restrict__ flags,
-                                                           int32_t* __restrict__ count, const int32_t* __restrict__ order_flags) {
-  const int q = blockIdx.x * 64 + threadIdx.x;
-  if (q >= m) return;
-  const double* cs = cand_sc + (size_t)q * kin;
-  int flag = order_flags ? (order_flags[q] != 0) : 0;          // order_check_kernel: the re-evaluated order hangs on the pass's sigmas
-  const double T = cs[kin - 1];
-  if (T == T) {                                       // a full candidate list (NaN = fewer than k_in entries exist: nothing is outside it)
-    double cn = 2.0;
-    const double w = row_weight(mom_sc, mom_m2, G, m, q, p_weight, &cn);
-    const double sk = score[(size_t)q * k + k - 1];
-    const double lim = T - score_err_bound(eps_d, w, T, cn);
-    if (T < __builtin_inf() && !(sk < lim)) flag = 1;   // (T = +Inf: everything left is masked)
-  }
-  flags[q] = flag;
-  if (flag) atomicAdd(count, 1);
-}
-
-
 // one thread per query: selection of the k best of `cnt` candidates laid out with the given strides
 __device__ void select_k(const int32_t* idx, const double* sc, int cnt, int k, int32_t* oidx, double* osc, float* osc32) {
   unsigned long long taken_lo = 0, taken_hi = 0;                // cnt <= 128
@@ -316,6 +291,32 @@ __device__ __forceinline__ int not_contained(const RowStats& S, double eps_d, do
   }
   return !(sk < T - score_err_bound(eps_d, w, T, S.cn) - slack) ? 1 : 0;
 }
+// PR_SC_ARITH_F16: is the exact top-k of the candidates provably the exact top-k of ALL entries?  cand_sc = the all-pairs-pass scores of
+// the k_in candidates (ascending: every entry that is NOT a candidate has a pass score >= the last one, T), score = the exact scores of
+// the k selected.  Every non-candidate's exact score is >= T - err(T); if the exact k-th best is below that, nothing outside the list can
+// enter the top-k (pruned candidates: rerank_kernel).  Otherwise - or when statistics / scores are not finite - the query is flagged.
+// Round 6: the same sigma slack as not_contained() above - under the TRUE sigmas an outside entry moves against a listed one by at most
+// sum_c eps_c w_c R_c / sigma_c (eps_c = eps_floor + noise / sigma_c: the relative sigma error the order check allows in this arithmetic).
+__global__ __launch_bounds__(64) void margin_check_kernel(const double* __restrict__ mom_sc, const double* __restrict__ mom_m2, int G, int m,
+                                                           double p_weight, int kin, const double* __restrict__ cand_sc, int k,
+                                                           const double* __restrict__ score, double eps_d, int32_t* __restrict__ flags,
+                                                           int32_t* __restrict__ count, const int32_t* __restrict__ order_flags,
+                                                           double eps_floor, double noise) {
+  const int q = blockIdx.x * 64 + threadIdx.x;
+  if (q >= m) return;
+  const double* cs = cand_sc + (size_t)q * kin;
+  int flag = order_flags ? (order_flags[q] != 0) : 0;          // order_check_kernel: the re-evaluated order hangs on the pass's sigmas
+  const double T = cs[kin - 1];
+  if (T == T) {                                       // a full candidate list (NaN = fewer than k_in entries exist: nothing is outside it)
+    RowStats S;
+    row_stats(mom_sc, mom_m2, G, m, q, p_weight, eps_floor, noise, S);
+    if (not_contained(S, eps_d, T, score[(size_t)q * k + k - 1])) flag = 1;   // (T = +Inf: everything left is masked)
+  }
+  flags[q] = flag;
+  if (flag) atomicAdd(count, 1);
+}
+
+
 // the weighted channel z-score exactly as rerank_kernel forms it (run_test.m:40)
 __device__ __forceinline__ double chan_z(const RowStats& S, int c, double d) { return S.w[c] == 0.0 ? 0.0 : S.w[c] * ((d - S.mean[c]) / S.sd[c]); }
 
@@ -617,10 +618,10 @@ void launch_rerank_partial(hipStream_t st, const void* q_sc, const void* db_sc, 
 
 void launch_margin_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int G, int m, double p_weight, int kin,
                          const double* cand_sc, int k, const double* score, double eps_d, int32_t* flags, int32_t* count,
-                         const int32_t* order_flags) {
+                         const int32_t* order_flags, double eps_floor, double noise) {
   if (m <= 0) return;
   hipLaunchKernelGGL(margin_check_kernel, dim3((m + 63) / 64), dim3(64), 0, st, mom_sc, mom_m2, G, m, p_weight, kin, cand_sc, k, score, eps_d,
-                     flags, count, order_flags);
+                     flags, count, order_flags, eps_floor, noise);
 }
 
 void launch_order_check(hipStream_t st, const double* mom_sc, const double* mom_m2, int Gmom, const int32_t* cand_idx, const double* p5_all,

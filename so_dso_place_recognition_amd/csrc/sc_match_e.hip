@@ -355,15 +355,15 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   constexpr int QROW = LO ? 80 : 40;
   static_assert(NW == 4 || !LO, "two waves per SIMD: single-product form only (a split-f16 unit needs all 512 registers)");
   if constexpr (SV) {  // the hi halves of this workgroup's query groups of the split image -> the compact LDS image, 8 bytes at a time:
-    // compact block (group, f) = 81 words: rows 0..7 (5 words each), one pad word, rows 8..15; split block = 1288 B, row = 80 B (hi | lo)
-    constexpr int WPG = SC_NF * 81;
+    // compact block (group, f) = 80 words: 16 rows of 5 words; split block = 1288 B, row = 80 B (hi | lo), rows 8..15 shifted by 8 B
+    constexpr int WPG = SC_NF * 80;
     unsigned long long* dst = reinterpret_cast<unsigned long long*>(lds);
     for (int i = tid; i < NQG * WPG + 8; i += 64 * NW) {
-      const int grp = i / WPG, rem = i - grp * WPG, f = rem / 81, j = rem - f * 81;
+      const int grp = i / WPG, rem = i - grp * WPG, f = rem / 80, j = rem - f * 80;
       const int gq = qg32 * NQG + grp;
-      const int jj = j > 40 ? j - 41 : j, rr = (j > 40 ? 8 : 0) + jj / 5, c = jj - (jj / 5) * 5;
+      const int rr = j / 5, c = j - rr * 5;
       unsigned long long v = 0ull;
-      if (i < NQG * WPG && gq < QG8 && j != 40)
+      if (i < NQG * WPG && gq < QG8)
         v = *reinterpret_cast<const unsigned long long*>(qpk + ((size_t)ch * QG8 + gq) * SCH_QIMG + (size_t)f * SCH_QBLK + rr * 80 + (rr >= 8 ? 8 : 0) + c * 8);
       dst[i] = v;
     }
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   constexpr int BD = LO ? E_BD : E_BD1;            // depth of the DB operand ring: the tiles of BD - 1 walk positions are in flight
   constexpr int AD = LO ? E_AD : 3;                // the same for the query tiles
   // split-f16 form: the two operand pairs of a frequency (kernels.hpp) - this lane's 16 bytes of its query row, and of the DB tiles below
-  const unsigned natr = lds0 + wq * QIMG + row * QROW + (row >= 8 ? 8 : 0);
+  const unsigned natr = lds0 + wq * QIMG + row * QROW + ((LO && row >= 8) ? 8 : 0);
   const unsigned nat0 = natr + (LO ? sch_a1_byte(kg) : kg * 16);
   [[maybe_unused]] const unsigned nat1 = natr + sch_a2_byte(kg);
   const int voff = LO ? sch_b1_byte(lane) : ((lane < 48) ? lane * 16 : (int)0x80000000);     // single product, lanes 48-63: out of range -> zeros (K = 24..31)
@@ -657,7 +657,7 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
 // the single-product kernel on the hi halves with integer rounding (leaves at once when the bound does not hold), then the split-f16 kernel
 // (leaves at once when that pass ran and every pair passed its rounding test)
 void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
-                           int nsplit_override, ScBin bin, hipEvent_t* ev) {
+                           int nsplit_override, ScBin bin, hipEvent_t* ev, int online_h) {
   if (m <= 0 || n <= 0) return;
   const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n);
   auto grid = [&](int QGW) {     // ranges per XCD: >= ~4 workgroups per CU in total, >= 8 DB groups per workgroup (an eighth of the ranges per XCD)
@@ -685,7 +685,7 @@ void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* d
     // the split-f16 launches of an online call: this file's kernel with ONE query group per workgroup - its four waves split the DB groups,
     // the DB operand ring five positions deep in AccVGPRs (0.303 -> 0.278 ms per call at m = 1, 0.317 -> 0.300 at m = 8 against
     // sc_match_h.hip's one-group form, which PR_SC_ONLINE=h brings back)
-    static const bool online_e = !(getenv("PR_SC_ONLINE") && !strcmp(getenv("PR_SC_ONLINE"), "h"));
+    const bool online_e = !online_h;
     auto split1 = [&](int chsel, int gate) {
       b.chsel = chsel; b.gate = gate;
       if (!online_e) { launch_sc_match_h(st, qpk, m, dpk, n, cst, d_p, d_i, nsplit_override, &b); return; }

@@ -311,7 +311,7 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
     int bh, bl;   // byte offsets of hi and lo in the LDS copy
     if (ROLE == 0) {
       const int rr = (im << 3) | (lrow & 7);
-      bh = ((lrow >> 3) * 8 + slice) * SL + rr * QROW + (rr >= 8 ? 8 : 0) + ring * 2;
+      bh = ((lrow >> 3) * 8 + slice) * SL + rr * QROW + ((LO && rr >= 8) ? 8 : 0) + ring * 2;
       bl = bh - ring * 2 + sch_qlo_byte(ring);
     } else {
       bh = slice * SL + im * (LO ? 2 : 1) * SCH_DTILE + (((ring >> 3) << 4) | lrow) * 16 + (ring & 7) * 2;
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict_
     size_t bh;
     if (ROLE == 0) {
       const int g = row >> 3, rr = (im << 3) | (row & 7);
-      bh = ((size_t)ch * groups + g) * IMGB + (size_t)ff * SL + rr * QROW + (rr >= 8 ? 8 : 0) + ring * 2;
+      bh = ((size_t)ch * groups + g) * IMGB + (size_t)ff * SL + rr * QROW + ((LO && rr >= 8) ? 8 : 0) + ring * 2;
       *reinterpret_cast<_Float16*>(out + bh) = hi;
       if (LO) *reinterpret_cast<_Float16*>(out + bh - ring * 2 + sch_qlo_byte(ring)) = lo;
     } else {

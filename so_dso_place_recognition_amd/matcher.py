@@ -116,8 +116,8 @@ class _Base:
         """After a single-shard pr_rerank_dev: queries whose re-evaluated order hangs on the fp32 pass's sigmas, or whose candidate list does
         not provably hold the top-k, are answered from their exact fp64 rows; idx / score (and the moments rows) are patched in place.
         One pass takes RESOLVE_SLOTS flagged queries.  Calls of up to that many queries (and exact_order == "async"): pr_order_resolve_async_dev,
-        one stream-ordered pass without host synchronisation (PR_WARN_ORDER_RESOLVED at ctx.take_warnings() tells whether it happened,
-        PR_WARN_ORDER_UNRESOLVED that more queries were flagged than it took).  Larger calls: pr_order_resolve_dev - reads the number of
+        ceil(m / 64) stream-ordered passes without host synchronisation - all flagged queries, empty passes leave at once
+        (PR_WARN_ORDER_RESOLVED at ctx.take_warnings() tells whether it happened).  Larger calls: pr_order_resolve_dev - reads the number of
         flagged queries back (ONE synchronisation of the stream per call) and runs as many passes as it takes."""
         self._enter()
         if m <= RESOLVE_SLOTS or exact_order == "async":
@@ -132,10 +132,13 @@ class _Base:
 
     def _exact_passes(self, m, exact_order=True):
         """Passes of RESOLVE_SLOTS flagged queries step 7 of the sharded protocol needs (the same number on every rank: the flags are a
-        function of the gathered evaluations).  Up to RESOLVE_SLOTS queries (or exact_order == "async"): one, unconditionally and without
-        synchronisation; more: the flagged count is read back (one synchronisation) - none flagged, no pass and no all-gather."""
-        if m <= RESOLVE_SLOTS or exact_order == "async":
+        function of the gathered evaluations).  Up to RESOLVE_SLOTS queries: one, unconditionally and without synchronisation; exact_order ==
+        "async" (a captured graph): ceil(m / 64), every one of them with its two all-gathers, whatever was flagged - empty passes leave at once;
+        otherwise the flagged count is read back (one synchronisation) - none flagged, no pass and no all-gather."""
+        if m <= RESOLVE_SLOTS:
             return 1
+        if exact_order == "async":
+            return (m + RESOLVE_SLOTS - 1) // RESOLVE_SLOTS
         return (self.flagged_count() + RESOLVE_SLOTS - 1) // RESOLVE_SLOTS
 
     def _fallback_rows(self, run_rows, idx, score, mask_width, q_row0):
@@ -287,10 +290,10 @@ class Matcher(_Base):
     def finish(self, cand_idx: torch.Tensor, cand_sc: torch.Tensor, part_all: torch.Tensor, k: int):
         return _finish_dev(self, cand_idx, cand_sc, part_all, k, (*self._moms(), self._args[0]), self._args[4])
 
-    def exact_moments(self, offset: int = 0):
+    def exact_moments(self, offset: int = 0, last: bool = True):
         """Step 7, first local part: this shard's exact rows of flagged queries offset .. offset + 63 of the last finish() (kept in the
-        context) and their moments -> [m, 4, 3] f64."""
-        return _exact_moments_dev(self, self._raw_args()[:6], *self._moms(), self._args[0], self._m, self.n, offset)
+        context) and their moments -> [m, 4, 3] f64.  last: no pass follows (flagged queries behind it raise WARN_ORDER_UNRESOLVED)."""
+        return _exact_moments_dev(self, self._raw_args()[:6], *self._moms(), self._args[0], self._m, self.n, offset, last)
 
     def exact_select(self, exact_all: torch.Tensor, k: int, offset: int = 0):
         """Step 7, second local part: this shard's k best of the flagged queries' exact rows under the statistics of all shards
@@ -321,8 +324,8 @@ class Matcher(_Base):
         do not provably hold the top-k of the whole row, are answered from their exact fp64 rows, sharded or not (run_test.m:38-57 are fp64
         over the whole row), 64 flagged queries per pass: a call of up to 64 queries runs one pass of stream-ordered kernels that leave at
         once when nothing is flagged (no host synchronisation: such a call can be captured in a hipGraph); a larger call reads the
-        number of flagged queries back (one synchronisation) and runs the passes it takes.  "async": one such pass whatever the call's size
-        (PR_WARN_ORDER_UNRESOLVED at take_warnings() when more than 64 queries were flagged: their answers are the candidate list's);
+        number of flagged queries back (one synchronisation) and runs the passes it takes.  "async": ceil(m / 64) such passes chained on the
+        stream whatever was flagged (no read-back: what a captured graph of a large call uses; empty passes leave at once);
         False skips the resolution (the answer of the re-evaluated candidate list; the flags are simply dropped)."""
         G = _world(group)
         f16 = self.f16 and not self.plain
@@ -358,7 +361,7 @@ class Matcher(_Base):
 
     def take_warnings(self) -> int:
         """PR_WARN_* bits of the context since the last call (synchronises its stream): WARN_ORDER_RESOLVED after a match() whose order
-        needed fp64 row statistics, WARN_ORDER_UNRESOLVED when more than 64 queries of one match(..., exact_order="async") call did."""
+        needed fp64 row statistics (WARN_ORDER_UNRESOLVED: only when exact_moments(.., last=True) was called with flagged queries left)."""
         return self.ctx.take_warnings()
 
     def _split_twin(self):
@@ -392,8 +395,8 @@ class Matcher(_Base):
         (online use: one keyframe per call - the ~10 kernel launches of a call replay as one graph launch).  Returns a
         CapturedMatch: `.run(new_queries)` copies them into the static input and replays ON THE MATCHER'S STREAM (a replay
         on another stream would not be ordered with the copy), `.idx` / `.score` are the static outputs.  The matcher must
-        come from on_new_stream().  A graph cannot read a count back: calls above 64 queries are captured with exact_order="async" (one
-        pass of 64 flagged queries; PR_WARN_ORDER_UNRESOLVED at take_warnings() if a replay flagged more)."""
+        come from on_new_stream().  A graph cannot read a count back: calls above 64 queries are captured with exact_order="async" (ceil(m / 64)
+        chained passes: every flagged query of every replay is resolved)."""
         st = self.stream
         eo = True if queries.shape[0] // self.rows_per_sig <= RESOLVE_SLOTS else "async"
         with torch.cuda.stream(st):
@@ -503,8 +506,8 @@ class FusedMatcher(_Base):
         return (_dptr(self.sc._q_sig), _dptr(self.sc.db_sig), _torch_dt(self.sc.db_sig), _dptr(self.m2._q_sig), _dptr(self.m2.db_sig),
                 _torch_dt(self.m2.db_sig))
 
-    def exact_moments(self, offset=0):
-        return _exact_moments_dev(self, self._raw6(), self._m1, self._m2, self._args[0], self.sc._m, self.sc.n, offset)
+    def exact_moments(self, offset=0, last=True):
+        return _exact_moments_dev(self, self._raw6(), self._m1, self._m2, self._args[0], self.sc._m, self.sc.n, offset, last)
 
     def exact_select(self, exact_all, k, offset=0):
         G, q_row0, db_row0, mask_width, p_weight = self._args
@@ -593,11 +596,11 @@ def _finish_dev(owner, cand_idx: torch.Tensor, cand_sc: torch.Tensor | None, par
 RESOLVE_SLOTS = 64      # flagged queries one pass of the exact-row resolution serves (kernels.hpp)
 
 
-def _exact_moments_dev(owner, raw6, mom_sc, mom_m2, g_mom: int, m: int, n_local: int, offset: int = 0):
+def _exact_moments_dev(owner, raw6, mom_sc, mom_m2, g_mom: int, m: int, n_local: int, offset: int = 0, last: bool = True):
     exact = torch.empty((m, 4, 3), dtype=torch.float64, device=owner.dev)
     owner._enter()
     owner.ctx.check(owner.lib.pr_order_exact_moments_dev(owner.ctx.h, *raw6, _dptr(mom_sc), _dptr(mom_m2), int(g_mom), m, n_local, int(offset),
-                                                         _dptr(exact)))
+                                                         int(bool(last)), _dptr(exact)))
     owner._leave()
     return exact
 
@@ -676,7 +679,7 @@ def sharded_topk(local_moments, local_select, k: int, group, G: int, merge=None,
             mark("flagged count")                        # (calls above 64 queries: one read-back of the count; none flagged - no pass)
         for p in range(passes):
             off = p * RESOLVE_SLOTS
-            ex = resolve[0](off) if p else resolve[0]()
+            ex = resolve[0](off, p == passes - 1) if len(resolve) > 3 else (resolve[0](off) if p else resolve[0]())
             mark("exact rows")
             exact_all = gather(ex)
             mark("all_gather D (exact moments)")

@@ -537,8 +537,8 @@ def test_fp64_statistics_for_every_query_give_the_oracles_scores(api, monkeypatc
     """PR_FORCE_ORDER_FLAGS=1 makes the order check flag every query, so the fp64-statistics resolution - normally a 1-in-10^5 path - answers
     all of them: every returned score must then be the oracle's to fp64 rounding (exact pair distances AND exact row statistics,
     run_test.m:38-57), on every path: the host calls (all queries: several passes of 64), the device-resident call (150 flagged queries: it
-    reads the count back and runs three passes; with exact_order="async" one stream-ordered pass - its first 64 flagged queries,
-    PR_WARN_ORDER_UNRESOLVED for the rest), pr_group with virtual shards, two torch.distributed ranks (three passes of the exchange), and the
+    reads the count back and runs three passes; with exact_order="async" the same three passes chained on the stream without a read-back -
+    PR_WARN_ORDER_UNRESOLVED never appears; a C caller that stops after one pass of the sharded form and says so gets it), pr_group with virtual shards, two torch.distributed ranks (three passes of the exchange), and the
     fused SC + M2DP form."""
     import json
     import subprocess
@@ -575,12 +575,26 @@ def test_fp64_statistics_for_every_query_give_the_oracles_scores(api, monkeypatc
     assert np.array_equal(i1.cpu().numpy(), oidx) and np.abs(s1.cpu().numpy() - osc).max() < 1e-9
     i1, s1 = mt.match(torch.from_numpy(q).to(dev), 5, 2.0, k, exact_order="async")
     w = mt.take_warnings()
-    assert (w & _lib.WARN_ORDER_RESOLVED) and (w & _lib.WARN_ORDER_UNRESOLVED)          # 150 flagged, one stream-ordered pass resolves 64
+    assert (w & _lib.WARN_ORDER_RESOLVED) and not (w & _lib.WARN_ORDER_UNRESOLVED)      # 150 flagged: three stream-ordered passes, no read-back
     i1, s1 = i1.cpu().numpy(), s1.cpu().numpy()
-    assert np.array_equal(i1, oidx)
-    assert np.abs(s1[:64] - osc[:64]).max() < 1e-9                                       # the resolved ones: fp64 throughout
+    assert np.array_equal(i1, oidx) and np.abs(s1 - osc).max() < 1e-9                    # every query: fp64 throughout
+    # the sharded form, driven like a C caller that stops after ONE pass and declares it its last: queries 64.. keep the candidate list's
+    # answer and the context says so (and a later complete call does not take the bit back before pr_take_warnings has reported it)
+    qd = torch.from_numpy(q).to(dev)
+    mom = mt.local_phase1(qd)
+    ci, cs = mt.local_select(mom.unsqueeze(0), 1, 5, 2.0, k, 0, 0)
+    part = mt.local_rerank(ci, k, True, cs)
+    i3, s3 = mt.finish(ci, cs, part.unsqueeze(0), k)
+    ex = mt.exact_moments(0, last=True)
+    sel = mt.exact_select(ex.unsqueeze(0), k, 0)
+    i3, s3 = mt.exact_merge(sel.unsqueeze(0), k, i3, s3, 0)
+    i3, s3 = i3.cpu().numpy().copy(), s3.cpu().numpy().copy()
+    i2, s2 = mt.match(qd[:40].contiguous(), 5, 2.0, k)                                   # (a complete call in between)
+    w = mt.take_warnings()
+    assert (w & _lib.WARN_ORDER_RESOLVED) and (w & _lib.WARN_ORDER_UNRESOLVED)
+    assert np.array_equal(i3, oidx) and np.abs(s3[:64] - osc[:64]).max() < 1e-9          # the resolved ones: fp64 throughout
     rc, odp, odi = oracle_lib.sc_distance(q[64:], db)
-    assert (np.abs(s1[64:] - osc[64:]) <= helpers.score_tol(osc[64:], helpers.row_sigmas(odp, odi))).all()   # the others: the fp32-statistics model
+    assert (np.abs(s3[64:] - osc[64:]) <= helpers.score_tol(osc[64:], helpers.row_sigmas(odp, odi))).all()   # the others: the fp32-statistics model
     i2, s2 = mt.match(torch.from_numpy(q[:40]).to(dev), 5, 2.0, k)                       # an online-sized call: everything resolved
     assert not (mt.take_warnings() & _lib.WARN_ORDER_UNRESOLVED)
     assert np.array_equal(i2.cpu().numpy(), oidx[:40]) and np.abs(s2.cpu().numpy() - osc[:40]).max() < 1e-9
