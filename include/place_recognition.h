@@ -188,6 +188,20 @@ void pr_sigset_destroy(pr_ctx* ctx, pr_sigset* s);
  * run without the fill it then needs.  (Packing other sets, or this one with the captured count, is fine.) */
 int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int where, int32_t n_sigs);
 int32_t pr_sigset_count(const pr_sigset* s);
+/* A DB that grows by one signature per keyframe (SC/test_sc.cpp:40-56 appends a row per cloud; run_test.m:57 matches a query against
+ * everything before it).  The operand image is [channel][group][...]; pr_sigset_pack lays it out for the COUNT it is given, so a larger count
+ * means a full re-pack.  pr_sigset_reserve fixes the layout at the CAPACITY (max_sigs of pr_sigset_create) instead: the set is emptied, and from
+ * then on pr_sigset_pack (bulk: rows 0 .. n_sigs - 1, the set's new count) and pr_sigset_append (rows count .. count + n_new - 1, everything else
+ * untouched) write into that one layout - an appended image is bit for bit the image a bulk pack of all rows writes, and the binary-channel
+ * statistics of an SC set are folded in, not recomputed.  pr_sigset_append on an EMPTY set reserves by itself.  DB sets of SC
+ * or M2DP signatures in the f16 arithmetics (the defaults); such a set is matched by the default kernels only (PR_EINVAL from
+ * pr_distances_dev under PR_SC_KERNEL / PR_SC_ONLINE=h).  sig: n_new signatures, [n_new][2400] (SC) or [4 n_new][384] (M2DP), as for
+ * pr_sigset_pack.  Stream-ordered (one kernel; PR_HOST buffers are staged and the call then waits).  The raw rows the fp64 re-evaluation reads
+ * (pr_rerank_dev's db_sc / db_m2) are the caller's: append them to that buffer too. */
+int pr_sigset_reserve(pr_ctx* ctx, pr_sigset* s);
+int pr_sigset_append(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int where, int32_t n_new);
+/* the packed operand image (DEVICE pointer, read-only), its size and its channel stride in groups / tiles: for tests and for saving a packed DB */
+int pr_sigset_image(const pr_sigset* s, const void** image, size_t* bytes, int32_t* channel_stride_groups);
 
 /* processSC.m:22-33 / processM2DP.m:15-21 / processDELIGHT.m:7-37 on packed sets.  d_p, d_i: DEVICE f32 [m][n]
  * (row stride n); DELIGHT writes d_p only (d_i may be NULL). */

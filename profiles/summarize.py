@@ -38,11 +38,25 @@ def main():
                     for g in cl:
                         print("%-72s n=%-3d avg=%9.3f min=%9.3f max=%9.3f" % (r[0][:72], len(g), sum(g) / len(g), g[0], g[-1]))
         if has_pmc:
-            print("-- PMC (rocprofv3 --pmc ...): kernel, counter, sum over dispatches, dispatches")
-            q = ("select kernel_name, counter_name, sum(value), count(*) from counters_collection"
-                 " group by kernel_name, counter_name order by kernel_name, counter_name")
-            for r in c.execute(q):
-                print("%-72s %-28s %.6g (n=%d)" % (r[0][:72], r[1], r[2], r[3]))
+            # one line per (kernel, grid size, counter): the same kernel runs the timed step's launches beside the small online / test launches,
+            # and gated launches that leave at once beside the ones that run - `per launch` is the average over the dispatches
+            # above a tenth of the largest (`big` of them), `sum` / `n` are over all
+            print("-- PMC (rocprofv3 --pmc ...): kernel, grid, counter, per launch (over `big` dispatches above a tenth of the largest), sum over all n dispatches")
+            cols = [r[1] for r in c.execute("pragma table_info(counters_collection)")]
+            grid = "grid_size" if "grid_size" in cols else "0"
+            disp = next((x for x in ("dispatch_id", "correlation_id") if x in cols), None)
+            per = {}
+            if disp:
+                q = (f"select kernel_name, {grid}, counter_name, {disp}, sum(value) from counters_collection"
+                     f" group by kernel_name, {grid}, counter_name, {disp}")
+                for name, g, ctr, d, v in c.execute(q):
+                    per.setdefault((name, g, ctr), []).append(v)
+            else:
+                for name, g, ctr, v, n_ in c.execute(f"select kernel_name, {grid}, counter_name, sum(value), count(*) from counters_collection group by 1, 2, 3"):
+                    per[(name, g, ctr)] = [v / n_] * n_
+            for (name, g, ctr), vals in sorted(per.items(), key=lambda kv: (kv[0][0], kv[0][1], kv[0][2])):
+                big = [v for v in vals if v > 0.1 * max(vals)] or vals
+                print("%-72s grid=%-9s %-28s per launch %.6g (big=%d)  sum %.6g (n=%d)" % (name[:72], g, ctr, sum(big) / len(big), len(big), sum(vals), len(vals)))
 
 
 if __name__ == "__main__":

@@ -90,6 +90,9 @@ SYMBOLS = {
     "pr_sigset_destroy": (None, [_vp, _vp]),
     "pr_sigset_pack": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _i32]),
     "pr_sigset_count": (_i32, [_vp]),
+    "pr_sigset_reserve": (C.c_int, [_vp, _vp]),
+    "pr_sigset_append": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, _i32]),
+    "pr_sigset_image": (C.c_int, [_vp, C.POINTER(_vp), C.POINTER(C.c_size_t), C.POINTER(_i32)]),
     "pr_distances_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "pr_row_moments_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "pr_fuse_select_dev": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _dbl, _i32, _vp, _vp]),

@@ -99,13 +99,15 @@ void launch_fill_ints(hipStream_t st, int* p, int n, int v);
 void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int role, void* packed, int groups,
                       const double* twiddle, int* flags, int* bad, int single = 0,   // single: hi halves only (SCF_* layout)
                       float* binfo = nullptr, int* bstat = nullptr);                 // binary-channel statistics (ScBin above)
+void launch_sc_pack_h_rows(hipStream_t st, const void* sig, int dtype, int rows, int row0, void* packed, int groups, const double* twiddle,
+                           int* flags, int* bad, int single, float* binfo, int* bstat);   // rows [row0, row0 + rows) of a DB image (pr_sigset_append)
 void launch_sc_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p,
                        float* d_i, int nsplit_override, const struct ScBin* bin = nullptr);   // bin: channel selection / gate of a binary-channel call
 size_t sc_match_h_lds_bytes();
 // sc_match_e.hip — the pair-walk form (no row-exchanged query operand; see the file): single = 0: split-f16 (three products, 4 waves),
 // single = 1: one f16 product per term (PR_SC_ARITH_F16), 8 waves = two per SIMD; same packed images and constants as sc_match_h.hip
 void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
-                       int nsplit_override, int single);
+                       int nsplit_override, int single, int dgs = 0 /* channel stride of the DB image in 16-entry groups when it is not sc_dgroups(n): an appendable set */);
 // split-f16 images whose channel 1 may be binary (ScBin above): channel 0 in split-f16; channel 1 by the single-product kernel on the hi
 // halves with integer rounding when the sets' statistics allow it, in split-f16 otherwise - the decision is taken ON THE DEVICE by every
 // workgroup from the same numbers (no host round trip: the two channel-1 launches are both issued, one of them leaves at once).
@@ -113,14 +115,15 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
 // (Measured and dropped: the channel-0 launch of an online call and the binary pass on two streams at once - 0.302 -> 0.308 ms at m = 1,
 // 0.310 -> 0.337 at m = 8: sc_match_h's workgroups fill the LDS of their CUs, the two kernels do not run side by side, and the event hand-offs cost.)
 void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
-                           int nsplit_override, ScBin bin, hipEvent_t* ev, int online_h = 0 /* m <= 8: sc_match_h.hip's one-group form (PR_SC_ONLINE=h, read once at pr_create) */);
+                           int nsplit_override, ScBin bin, hipEvent_t* ev, int online_h = 0 /* m <= 8: sc_match_h.hip's one-group form (PR_SC_ONLINE=h, read once at pr_create) */, int dgs = 0 /* as in launch_sc_match_e */);
 
 // m2dp_match.hip — processM2DP.m:12-22 for both channels.
 void launch_m2dp_pack(hipStream_t st, const void* sig, int dtype, int sigs, float* packed, int tiles);
 void launch_m2dp_match(hipStream_t st, const float* qpk, int m, const float* dpk, int n, float* d_p, float* d_i);
 // m2dp_match_h.hip — the same with split-f16 operands on the f16 matrix cores (tiles of the same size, packed by launch_m2dp_pack_h)
-void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, void* packed, int tiles);
-void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i, int single = 0);   // single: hi halves only
+void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, void* packed, int tiles, int sg0 = 0 /* first signature's place in the image */);
+void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i, int single = 0 /* hi halves only */,
+                         int dts = 0 /* channel stride of the DB image in tiles when it is not m2_tiles(n): an appendable set */);
 
 // fuse_select.hip — run_test.m:38-41,47-53,57
 // scratch (select_scratch_bytes(), or null): lets a call with few query rows cut every row into slices (grid m x P) instead of one workgroup per row

@@ -30,11 +30,11 @@ constexpr int TV = TB / 16;                // 16-byte vectors per tile: [step 12
 // stores, 0.94 ms per 50 000 signatures at ~1 TB/s).  The arithmetic per value is unchanged: the same image, bit for bit.
 template <typename T>
 __global__ __launch_bounds__(192) void m2dp_pack_h_kernel(const T* __restrict__ sig, int sigs, unsigned short* __restrict__ packed,
-                                                           int tiles) {
-  const int sg = blockIdx.x, tid = threadIdx.x;      // one workgroup per signature (4 variant rows x 384 = 192 runs of 8)
+                                                           int tiles, int sg0 /* place of sig's first signature in the image (an append) */) {
+  const int sg = sg0 + blockIdx.x, tid = threadIdx.x;      // one workgroup per signature (4 variant rows x 384 = 192 runs of 8)
   const int tile = sg >> 3, e = sg & 7;
   const int var = tid / 48, c = (tid - var * 48) * 8, ch = c / 192, k = c - ch * 192;
-  const T* src = sig + ((size_t)sg * 4 + var) * 384 + c;
+  const T* src = sig + ((size_t)blockIdx.x * 4 + var) * 384 + c;
   T x[8];
 #pragma unroll
   for (int i = 0; i < 8; i++) x[i] = src[i];
@@ -63,7 +63,7 @@ struct HL { u32x4 h, l; };
 template <int QTB, bool LO>
 __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __restrict__ qpk, const u32x4* __restrict__ dpk,
                                                               float* __restrict__ dist_p, float* __restrict__ dist_i,
-                                                              int m, int n, int QT, int DT, int nsplit) {
+                                                              int m, int n, int QT, int DT, int nsplit, int DTS /* channel stride of the DB image in tiles */) {
   extern __shared__ __attribute__((aligned(16))) u32x4 ldsv[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
   // the query tiles come from LDS one tile at a time, each reloaded for the next K-step right behind its own six MFMAs.
   // launch_bounds(256, 2) caps the wave at 256 unified registers, which keeps the 128 accumulators in ArchVGPRs (no
   // v_accvgpr_read in the epilogue).  The packed buffer has a readable tail for the requests past the last sweep step.
-  const u32x4* pb = dpk + ((size_t)ch * DT + (size_t)s0 * 8 + w * 2) * TV + lane;
+  const u32x4* pb = dpk + ((size_t)ch * DTS + (size_t)s0 * 8 + w * 2) * TV + lane;
   struct BSet { HL b0, b1; };
   BSet bs[3];               // K-steps st, st + 1, st + 2 (period 3 divides the 12 K-steps of a sweep step)
   HL a[QTB];                // the 4 query tiles of the current K-step; tile t is reloaded for the next K-step behind its own MFMAs
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256, 2) void m2dp_match_h_kernel(const u32x4* __res
 template <bool LO>
 __global__ __launch_bounds__(512, 2) void m2dp_match_h8_kernel(const u32x4* __restrict__ qpk, const u32x4* __restrict__ dpk,
                                                                float* __restrict__ dist_p, float* __restrict__ dist_i,
-                                                               int m, int n, int QT, int DT, int nsplit) {
+                                                               int m, int n, int QT, int DT, int nsplit, int DTS /* channel stride of the DB image in tiles */) {
   constexpr int QTB = 4;
   extern __shared__ __attribute__((aligned(16))) u32x4 ldsv[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(512, 2) void m2dp_match_h8_kernel(const u32x4* __re
   const unsigned st_lane = (unsigned)((2 * (lane & 3) + (lane >> 5)) * n + ((lane & 31) >> 2)) * 4u;
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (s0 >= s1) return;
-  const u32x4* pb = dpk + ((size_t)ch * DT + (size_t)s0 * 8 + w) * TV + lane;
+  const u32x4* pb = dpk + ((size_t)ch * DTS + (size_t)s0 * 8 + w) * TV + lane;
   HL bs[3];                 // DB operands of K-steps st, st + 1, st + 2
   HL a[QTB];
 #define MF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
@@ -280,17 +280,17 @@ __global__ __launch_bounds__(512, 2) void m2dp_match_h8_kernel(const u32x4* __re
 
 }  // namespace
 
-void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, void* packed, int tiles) {
+void launch_m2dp_pack_h(hipStream_t st, const void* sig, int dtype, int sigs, void* packed, int tiles, int sg0) {
   if (sigs <= 0) return;
   if (dtype == 0)
-    hipLaunchKernelGGL(m2dp_pack_h_kernel<double>, dim3(sigs), dim3(192), 0, st, (const double*)sig, sigs, (unsigned short*)packed, tiles);
+    hipLaunchKernelGGL(m2dp_pack_h_kernel<double>, dim3(sigs), dim3(192), 0, st, (const double*)sig, sigs, (unsigned short*)packed, tiles, sg0);
   else
-    hipLaunchKernelGGL(m2dp_pack_h_kernel<float>, dim3(sigs), dim3(192), 0, st, (const float*)sig, sigs, (unsigned short*)packed, tiles);
+    hipLaunchKernelGGL(m2dp_pack_h_kernel<float>, dim3(sigs), dim3(192), 0, st, (const float*)sig, sigs, (unsigned short*)packed, tiles, sg0);
 }
 
-void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i, int single) {
+void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk, int n, float* d_p, float* d_i, int single, int dts) {
   if (m <= 0 || n <= 0) return;
-  const int QT = m2_qtiles(m), DT = m2_tiles(n);
+  const int QT = m2_qtiles(m), DT = m2_tiles(n), DTS = dts > 0 ? dts : DT;
   // 4 query tiles per workgroup; PR_M2_QTB=3 selects the two-workgroups-per-CU variant for A/B runs (measured 6.4 ms against
   // 5.55 ms at 4096 x 50k: the overlap of two workgroups does not pay for a third more DB operand traffic per MFMA)
   static const int qtb = (getenv("PR_M2_QTB") && atoi(getenv("PR_M2_QTB")) == 3) ? 3 : 4;
@@ -318,25 +318,25 @@ void launch_m2dp_match_h(hipStream_t st, const void* qpk, int m, const void* dpk
       auto* k1 = m2dp_match_h_kernel<4, false>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k1), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * TB));
       hipLaunchKernelGGL(k1, dim3(base4 * nsplit), dim3(256), (size_t)4 * TB, st, static_cast<const u32x4*>(qpk),
-                         static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
+                         static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit, DTS);
     } else {
       auto* k8 = m2dp_match_h8_kernel<false>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)4 * TB));
       hipLaunchKernelGGL(k8, dim3(base4 * nsplit), dim3(512), (size_t)4 * TB, st, static_cast<const u32x4*>(qpk),
-                         static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
+                         static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit, DTS);
     }
     return;
   }
   if (eight && qtb == 4) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(m2dp_match_h8_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(m2dp_match_h8_kernel<true>, dim3(base * nsplit), dim3(512), lds, st, static_cast<const u32x4*>(qpk),
-                       static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
+                       static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit, DTS);
     return;
   }
   auto* k = qtb == 4 ? m2dp_match_h_kernel<4, true> : m2dp_match_h_kernel<3, true>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k, dim3(base * nsplit), dim3(256), lds, st, static_cast<const u32x4*>(qpk),
-                     static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit);
+                     static_cast<const u32x4*>(dpk), d_p, d_i, m, n, QT, DT, nsplit, DTS);
 }
 
 }  // namespace pr

@@ -81,6 +81,7 @@ struct pr_sigset {
   float* binfo = nullptr;        // SC split-f16 sets: [max_sigs + 1][2] {sqrt(ones), 1/sqrt(ones)} of channel 1, then SC_BSTAT_INTS ints of set statistics (kernels.hpp: ScBin)
   int32_t hw = 0;                // rows ever written since the image was last all-zero, and the group count (= channel stride) they were written for
   int packed_groups = -1;        // -1: the image is all-zero
+  bool cap_geom = false;         // the channel stride is the CAPACITY's group count whatever the row count (pr_sigset_reserve: what pr_sigset_append needs)
 };
 
 static thread_local std::string g_err;   // errors without a context
@@ -657,7 +658,7 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
   }
   // the channel stride must match the matcher's view of THIS count (not the capacity)
   int groups;
-  (void)sigset_floats(s->type, s->role, n_sigs, &groups, s->sc_mode);
+  (void)sigset_floats(s->type, s->role, s->cap_geom ? s->max_sigs : n_sigs, &groups, s->sc_mode);   // (an appendable set: the capacity's, pr_sigset_reserve)
   s->groups = groups;
   // Padding rows / tiles must be zero: they yield dot = 0 and are masked on store.  The image is zeroed at creation and a pack writes
   // only its own rows (the throughput kernels: whole groups, their padding rows as zeros), so a re-pack of at least as many rows in the
@@ -687,6 +688,71 @@ int pr_sigset_pack(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int wh
   return PR_OK;
 }
 
+// Appendable sets (SC/test_sc.cpp:40-56 produces one signature per keyframe; run_test.m:57 matches against everything seen so far): the
+// operand image of a DB set is [channel][groups][...] with the channel stride = the group count, which pr_sigset_pack takes from the ROW
+// COUNT - so one more row can move the second channel.  pr_sigset_reserve fixes the stride at the CAPACITY's group count (the matchers get
+// it beside the count); rows are then added in place.
+static bool appendable_kind(const pr_sigset* s) {
+  return s->role == PR_ROLE_DB && ((s->type == PR_TYPE_SC && (s->sc_mode == PR_SC_ARITH_F16X2 || s->sc_mode == PR_SC_ARITH_F16)) ||
+                                   (s->type == PR_TYPE_M2DP && s->sc_mode != PR_SC_ARITH_F32));
+}
+int pr_sigset_reserve(pr_ctx* ctx, pr_sigset* s) {
+  if (!ctx || !s) return PR_EINVAL;
+  if (!appendable_kind(s)) PR_FAIL(ctx, PR_EINVAL, "pr_sigset_reserve: DB sets of SC or M2DP signatures in the f16 arithmetics only");
+  if (s->cap_geom) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  if (s->packed_groups >= 0) { PR_HIP(ctx, hipMemsetAsync(s->packed, 0, s->floats * sizeof(float), ctx->stream)); s->packed_groups = -1; s->hw = 0; }
+  s->cap_geom = true;
+  s->count = 0;                                                 // (rows packed in the count's geometry are gone: pack or append again)
+  (void)sigset_floats(s->type, s->role, s->max_sigs, &s->groups, s->sc_mode);
+  if (s->binfo) pr::launch_zero_ints(ctx->stream, sigset_bstat(s), pr::SC_BSTAT_INTS);
+  PR_HIP(ctx, hipGetLastError());
+  return PR_OK;
+}
+
+int pr_sigset_append(pr_ctx* ctx, pr_sigset* s, const void* sig, int dtype, int where, int32_t n_new) {
+  if (!ctx || !s) return PR_EINVAL;
+  if (n_new < 0 || (n_new > 0 && !sig) || (dtype != PR_F64 && dtype != PR_F32) || (where != PR_HOST && where != PR_DEVICE))
+    PR_FAIL(ctx, PR_EINVAL, "pr_sigset_append: bad arguments (n_new=%d)", n_new);
+  if (!appendable_kind(s)) PR_FAIL(ctx, PR_EINVAL, "pr_sigset_append: DB sets of SC or M2DP signatures in the f16 arithmetics only");
+  if (!s->cap_geom) {
+    if (s->count != 0) PR_FAIL(ctx, PR_EINVAL, "pr_sigset_append: the set holds %d rows in the geometry of that count; pr_sigset_reserve it first (before packing)", s->count);
+    if (int rc = pr_sigset_reserve(ctx, s)) return rc;
+  }
+  if ((int64_t)s->count + n_new > s->max_sigs) PR_FAIL(ctx, PR_EINVAL, "pr_sigset_append: %d + %d rows exceed the capacity %d", s->count, n_new, s->max_sigs);
+  if (n_new == 0) return PR_OK;
+  if (int rc = set_device(ctx)) return rc;
+  const size_t rows = s->type == PR_TYPE_SC ? (size_t)n_new : (size_t)4 * n_new, cols = s->type == PR_TYPE_SC ? PR_SC_SIG_LEN : PR_M2DP_SIG_LEN;
+  const size_t esz = dtype == PR_F64 ? 8 : 4;
+  DevScope scope_(ctx);
+  DevBuf stage;
+  const void* dsig = sig;
+  if (where == PR_HOST) {
+    PR_HIP(ctx, stage.alloc(rows * cols * esz));
+    PR_HIP(ctx, hipMemcpyAsync(stage.p, sig, rows * cols * esz, hipMemcpyHostToDevice, ctx->stream));
+    dsig = stage.p;
+  }
+  if (s->type == PR_TYPE_SC)       // the row-wise pack kernel: bit for bit the rows a pack of the whole set writes; statistics folded in, not restarted
+    pr::launch_sc_pack_h_rows(ctx->stream, dsig, dtype, n_new, s->count, s->packed, s->groups, ctx->d_twiddle, ctx->d_flags, s->bad,
+                              s->sc_mode == PR_SC_ARITH_F16, s->binfo, s->binfo ? sigset_bstat(s) : nullptr);
+  else
+    pr::launch_m2dp_pack_h(ctx->stream, dsig, dtype, n_new, s->packed, s->groups, s->count);
+  PR_HIP(ctx, hipGetLastError());
+  s->count += n_new;
+  s->packed_groups = s->groups;
+  if (s->count > s->hw) s->hw = s->count;
+  if (stage.p) PR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return PR_OK;
+}
+
+int pr_sigset_image(const pr_sigset* s, const void** image, size_t* bytes, int32_t* channel_stride_groups) {
+  if (!s) return PR_EINVAL;
+  if (image) *image = s->packed;
+  if (bytes) *bytes = s->floats * sizeof(float);
+  if (channel_stride_groups) *channel_stride_groups = s->groups;
+  return PR_OK;
+}
+
 // ------------------------------------------------------------------------------------------- device path
 int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float* d_p, float* d_i) {
   if (!ctx || !q || !db || !d_p || (!d_i && q->type != PR_TYPE_DELIGHT)) return PR_EINVAL;
@@ -695,24 +761,28 @@ int pr_distances_dev(pr_ctx* ctx, const pr_sigset* q, const pr_sigset* db, float
   if (int rc = set_device(ctx)) return rc;
   if (q->type != PR_TYPE_DELIGHT && q->sc_mode != db->sc_mode)
     PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: the two sets were packed for different arithmetic modes");
+  // an appendable DB set: the channel stride is the capacity's, which only the default matchers take beside the count
+  const int dgs = db->cap_geom ? db->groups : 0;
+  if (dgs && db->type == PR_TYPE_SC && db->sc_mode == PR_SC_ARITH_F16X2 && (ctx->sc_kernel != 2 || (q->count <= 8 && ctx->sc_online_h)))
+    PR_FAIL(ctx, PR_EINVAL, "pr_distances_dev: an appendable (pr_sigset_reserve) SC set needs the default matcher (not PR_SC_KERNEL / PR_SC_ONLINE=h)");
   if (ctx->timing) { ctx->timing_valid = 1; PR_HIP(ctx, hipEventRecord(ctx->ev_t[0], ctx->stream)); }
   if (q->type == PR_TYPE_SC && q->sc_mode == PR_SC_ARITH_F16)
-    pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 1);
+    pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 1, dgs);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && ctx->sc_binary && q->binfo && db->binfo) {
     ctx->bin_gen = ctx->bin_gen == 0x7fffffff ? 1 : ctx->bin_gen + 1;
     const pr::ScBin bin = {sigset_bstat(q), sigset_bstat(db), q->binfo, db->binfo, ctx->d_flags + 4, ctx->bin_gen, ctx->sc_bconst, ctx->sc_pair_scale, 0, -1};
     pr::launch_sc_match_e_bin(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, bin,
-                              ctx->timing ? ctx->ev_t : nullptr, ctx->sc_online_h ? 1 : 0);
+                              ctx->timing ? ctx->ev_t : nullptr, ctx->sc_online_h ? 1 : 0, dgs);
     if (ctx->timing) ctx->timing_valid = 3;
   }
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0 && ctx->sc_kernel == 2 && (q->count > 8 || !ctx->sc_online_h))
-    pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 0);
+    pr::launch_sc_match_e(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit, 0, dgs);
   else if (q->type == PR_TYPE_SC && q->sc_mode == 0)
     pr::launch_sc_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst_h, d_p, d_i, ctx->sc_nsplit);
   else if (q->type == PR_TYPE_SC)
     pr::launch_sc_match(ctx->stream, q->packed, q->count, db->packed, db->count, ctx->d_cst, d_p, d_i, ctx->sc_nsplit);
   else if (q->type == PR_TYPE_M2DP)
-    if (q->sc_mode != PR_SC_ARITH_F32) pr::launch_m2dp_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i, q->sc_mode == PR_SC_ARITH_F16);
+    if (q->sc_mode != PR_SC_ARITH_F32) pr::launch_m2dp_match_h(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i, q->sc_mode == PR_SC_ARITH_F16, dgs);
     else pr::launch_m2dp_match(ctx->stream, q->packed, q->count, db->packed, db->count, d_p, d_i);
   else
     pr::launch_delight_match(ctx->stream, q->packed, q->count, db->packed, delight_masks(db), db->count, d_p);
@@ -879,8 +949,11 @@ static int resolve_scratch_rows(pr_ctx* ctx, int32_t slots, int32_t n_local) {
   const size_t need = (size_t)(slots < pr::RESOLVE_SLOTS ? slots : pr::RESOLVE_SLOTS) * 4 * (size_t)n_local;
   if (need > ctx->xrows_cap) {
     if (ctx->xrows) { PR_HIP(ctx, hipStreamSynchronize(ctx->stream)); PR_HIP(ctx, hipFree(ctx->xrows)); ctx->xrows = nullptr; ctx->xrows_cap = 0; }
-    PR_HIP(ctx, hipMalloc((void**)&ctx->xrows, need * sizeof(double)));
-    ctx->xrows_cap = need;
+    // a DB that grows by a row per call (pr_sigset_append) must not pay a free + malloc (~0.3 ms) per call: an eighth of headroom; the exact
+    // size when the device cannot give that much
+    size_t cap = need + need / 8;
+    if (hipMalloc((void**)&ctx->xrows, cap * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); cap = need; PR_HIP(ctx, hipMalloc((void**)&ctx->xrows, cap * sizeof(double))); }
+    ctx->xrows_cap = cap;
   }
   return PR_OK;
 }

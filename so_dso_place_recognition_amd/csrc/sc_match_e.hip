@@ -326,7 +326,8 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
                                                             const char* __restrict__ dpk,   // [2][DG][31][4][768 B] + zero groups
                                                             const u32x4* __restrict__ cst,  // [2][2][2][64] x 16 B
                                                             float* __restrict__ dist_p, float* __restrict__ dist_i,
-                                                            int m, int n, int QG8, int DG, int nsplit, ScBin bin) {
+                                                            int m, int n, int QG8, int DG, int nsplit, ScBin bin,
+                                                            int DGS /* channel stride of the DB image in groups: DG, or the capacity's of an appendable set */) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   static_assert(!SV || !LO, "SV: single-product form");
   float bbound = 0.f;
@@ -397,7 +398,7 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
   const int voff = LO ? sch_b1_byte(lane) : ((lane < 48) ? lane * 16 : (int)0x80000000);     // single product, lanes 48-63: out of range -> zeros (K = 24..31)
   [[maybe_unused]] const int voff2 = sch_b2_byte(lane);
   float* dist = ch ? dist_i : dist_p;
-  const char* dbase = dpk + ((size_t)ch * DG) * DIMG;
+  const char* dbase = dpk + ((size_t)ch * DGS) * DIMG;
   const int qrow0 = qg32 * (8 * NQG) + wq * 8;
   const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
       dist + (size_t)qrow0 * n, 0, (qrow0 < m ? (m - qrow0 < 8 ? m - qrow0 : 8) : 0) * n * 4, 0x00020000);
@@ -617,9 +618,9 @@ __global__ __launch_bounds__(64 * NW, NW / 4) void sc_match_e_kernel(const char*
 size_t sc_match_e_lds_bytes(int single, int nqg) { return (single ? (size_t)nqg * SCF_QIMG : (size_t)nqg * SCH_QIMG) + 64 + (single ? 64 * nqg : 0); }
 
 void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
-                       int nsplit_override, int single) {
+                       int nsplit_override, int single, int dgs) {
   if (m <= 0 || n <= 0) return;
-  const int QG8 = single ? sc_qgroups8_f16(m) : sc_qgroups8(m), DG = sc_dgroups(n);
+  const int QG8 = single ? sc_qgroups8_f16(m) : sc_qgroups8(m), DG = sc_dgroups(n), DGS = dgs > 0 ? dgs : DG;
   // query groups per workgroup: as many as hold queries (an online batch of 9 .. 16 | .. 32 keyframes: the waves a group would leave to the
   // padding of the image take other DB groups instead)
   const int QGr = (m + 7) / 8;
@@ -635,7 +636,7 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
   auto go = [&](auto kern, int nw) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(single, nqg));
     hipLaunchKernelGGL(kern, dim3(8 * QGW * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(single, nqg), st, static_cast<const char*>(qpk),
-                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, none);
+                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, none, DGS);
   };
   if (single && m <= 8) go(sc_match_e_kernel<false, 8, 1>, 8);
   else if (single && nqg == 2) go(sc_match_e_kernel<false, 8, 2>, 8);
@@ -647,7 +648,7 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
     auto kern = sc_match_e_kernel<true, 4, 1>;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(0, 1));
     hipLaunchKernelGGL(kern, dim3(8 * ns), dim3(256), sc_match_e_lds_bytes(0, 1), st, static_cast<const char*>(qpk), static_cast<const char*>(dpk),
-                       static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, ns, none);
+                       static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, ns, none, DGS);
   }
   else if (nqg == 2) go(sc_match_e_kernel<true, 4, 2>, 4);
   else go(sc_match_e_kernel<true, 4, 4>, 4);
@@ -657,9 +658,9 @@ void launch_sc_match_e(hipStream_t st, const void* qpk, int m, const void* dpk, 
 // the single-product kernel on the hi halves with integer rounding (leaves at once when the bound does not hold), then the split-f16 kernel
 // (leaves at once when that pass ran and every pair passed its rounding test)
 void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* dpk, int n, const void* cst, float* d_p, float* d_i,
-                           int nsplit_override, ScBin bin, hipEvent_t* ev, int online_h) {
+                           int nsplit_override, ScBin bin, hipEvent_t* ev, int online_h, int dgs) {
   if (m <= 0 || n <= 0) return;
-  const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n);
+  const int QG8 = sc_qgroups8(m), DG = sc_dgroups(n), DGS = dgs > 0 ? dgs : DG;
   auto grid = [&](int QGW) {     // ranges per XCD: >= ~4 workgroups per CU in total, >= 8 DB groups per workgroup (an eighth of the ranges per XCD)
     int nsplit = (128 + QGW - 1) / QGW;
     // one or two workgroups along the queries (m <= 64: an online batch): 8 QGW nsplit = 256 workgroups = ONE per CU (a workgroup fills its
@@ -678,7 +679,7 @@ void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* d
     b.chsel = chsel; b.gate = gate;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(single, nqg));
     hipLaunchKernelGGL(kern, dim3(8 * QGW * nsplit), dim3(64 * nw), sc_match_e_lds_bytes(single, nqg), st, static_cast<const char*>(qpk),
-                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, b);
+                       static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, b, DGS);
   };
   if (m <= 8) {      // an online call: sc_match_h.hip's one-group form for the split-f16 launches, all eight waves on one query group here
     ScBin b = bin;
@@ -694,7 +695,7 @@ void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* d
       auto kern = sc_match_e_kernel<true, 4, 1>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(0, 1));
       hipLaunchKernelGGL(kern, dim3(8 * nsplit), dim3(256), sc_match_e_lds_bytes(0, 1), st, static_cast<const char*>(qpk),
-                         static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, b);
+                         static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, b, DGS);
     };
     if (ev) (void)hipEventRecord(ev[0], st);
     split1(0, 0);
@@ -706,7 +707,7 @@ void launch_sc_match_e_bin(hipStream_t st, const void* qpk, int m, const void* d
       auto kern = sc_match_e_kernel<false, 8, 1, true>;
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc_match_e_lds_bytes(1, 1));
       hipLaunchKernelGGL(kern, dim3(8 * nsplit), dim3(512), sc_match_e_lds_bytes(1, 1), st, static_cast<const char*>(qpk),
-                         static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, b);
+                         static_cast<const char*>(dpk), static_cast<const u32x4*>(cst), d_p, d_i, m, n, QG8, DG, nsplit, b, DGS);
     }
     if (ev) (void)hipEventRecord(ev[2], st);
     split1(1, 2);

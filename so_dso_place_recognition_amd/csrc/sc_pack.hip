@@ -376,7 +376,8 @@ __device__ __forceinline__ double wave_sum(double v) {
 template <typename T, int ROLE, bool LO>
 __global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict__ sig, int rows, unsigned short* __restrict__ packed, int groups,
                                                              const double* __restrict__ tw, int* __restrict__ flags, int* __restrict__ bad,
-                                                             float* __restrict__ binfo, int* __restrict__ bstat) {
+                                                             float* __restrict__ binfo, int* __restrict__ bstat,
+                                                             int row0 /* place of sig's first row in the image, bad and binfo (an append; 0 otherwise) */) {
   constexpr int SL = ROLE == 0 ? (LO ? SCH_QBLK : SCF_QBLK) : (LO ? SCH_DFREQ : SCF_DFREQ);
   constexpr int IMGB = ROLE == 0 ? (LO ? SCH_QIMG : SCF_QIMG) : (LO ? SCH_DIMG : SCF_DIMG);
   constexpr int QROW = LO ? 80 : 40;
@@ -385,8 +386,8 @@ __global__ __launch_bounds__(320) void sc_pack_h_few_kernel(const T* __restrict_
   __shared__ double part[20];
   __shared__ double wred[5][3];
   const int tid = threadIdx.x, f = tid / 20, ring = tid - 20 * f;
-  const int row = blockIdx.x >> 1, ch = blockIdx.x & 1;
-  const T* src = sig + (size_t)row * 2400 + ch * 1200;
+  const int row = row0 + (blockIdx.x >> 1), ch = blockIdx.x & 1;
+  const T* src = sig + (size_t)(blockIdx.x >> 1) * 2400 + ch * 1200;
   const bool do_bin = LO && binfo != nullptr && ch == 1;    // binary-channel statistics, as in sc_pack_h_col_kernel (the row's whole residual
   double bz = 0.0, bmn_ = __builtin_inf(), bmx_ = -__builtin_inf();   // sum goes to bstat[2])
   for (int i = tid; i < 1200; i += 320) {
@@ -509,7 +510,7 @@ void launch_pack_col(hipStream_t st, const T* sig, int rows, unsigned short* pac
                      float* binfo = nullptr, int* bstat = nullptr) {
   if (rows <= SC_PACK_FEW) {
     hipLaunchKernelGGL((sc_pack_h_few_kernel<T, ROLE, LO>), dim3((unsigned)rows * 2), dim3(320), 0, st, sig, rows, packed, groups, tw, flags, bad,
-                       binfo, bstat);
+                       binfo, bstat, 0);
     return;
   }
   hipLaunchKernelGGL((sc_pack_h_col_kernel<T, ROLE, LO>), dim3((unsigned)(((rows + 15) / 16 + 7) / 8) * 64), dim3(320), 0, st, sig, rows, packed,
@@ -558,6 +559,23 @@ void launch_sc_pack_h(hipStream_t st, const void* sig, int dtype, int rows, int 
   else if (dtype == 0) launch_pack_col<double, 1>(st, (const double*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad, binfo, bstat);
   else if (role == 0) launch_pack_col<float, 0>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad, binfo, bstat);
   else launch_pack_col<float, 1>(st, (const float*)sig, rows, (unsigned short*)packed, groups, twiddle, flags, bad, binfo, bstat);
+}
+
+// rows [row0, row0 + rows) of a DB image whose other rows stay as they are (pr_sigset_append): one workgroup per (row, channel) of the
+// few-rows kernel, whatever the count - bit for bit what a pack of the whole set writes for these rows.  The binary-channel statistics are
+// FOLDED into bstat (or / max; the row's whole residual sum into slot [2], whose sum with [3..5] keeps bounding every row).
+void launch_sc_pack_h_rows(hipStream_t st, const void* sig, int dtype, int rows, int row0, void* packed, int groups, const double* twiddle,
+                           int* flags, int* bad, int single, float* binfo, int* bstat) {
+  if (rows <= 0) return;
+  unsigned short* pk = (unsigned short*)packed;
+  const dim3 grid((unsigned)rows * 2), blk(320);
+  if (single) {
+    if (dtype == 0) hipLaunchKernelGGL((sc_pack_h_few_kernel<double, 1, false>), grid, blk, 0, st, (const double*)sig, rows, pk, groups, twiddle, flags, bad, nullptr, nullptr, row0);
+    else hipLaunchKernelGGL((sc_pack_h_few_kernel<float, 1, false>), grid, blk, 0, st, (const float*)sig, rows, pk, groups, twiddle, flags, bad, nullptr, nullptr, row0);
+  } else {
+    if (dtype == 0) hipLaunchKernelGGL((sc_pack_h_few_kernel<double, 1, true>), grid, blk, 0, st, (const double*)sig, rows, pk, groups, twiddle, flags, bad, binfo, bstat, row0);
+    else hipLaunchKernelGGL((sc_pack_h_few_kernel<float, 1, true>), grid, blk, 0, st, (const float*)sig, rows, pk, groups, twiddle, flags, bad, binfo, bstat, row0);
+  }
 }
 
 void launch_sc_pack(hipStream_t st, const void* sig, int dtype, int rows, int role, float* packed, int groups,

@@ -175,6 +175,7 @@ class Matcher(_Base):
         self.n = 0
         self.db_sig = None             # the raw DB shard (the fp64 re-evaluation reads it)
         self._bufs = {}
+        self._flat = {}
         self.pre_distances = None      # optional callables (e.g. HIP event records) around the distance launch
         self.post_distances = None
 
@@ -188,9 +189,18 @@ class Matcher(_Base):
             self.q = self.db = None
 
     def _buf(self, name, shape, dtype):
+        """The call's working tensors, kept between calls.  A shape that grows a little per call (a DB that gains a row per keyframe: the
+        [m, n] distance matrices) is served as a view of flat storage with an eighth of headroom instead of a new allocation per call."""
         t = self._bufs.get(name)
         if t is None or tuple(t.shape) != tuple(shape) or t.dtype != dtype:
-            t = torch.empty(shape, dtype=dtype, device=self.dev)
+            need = 1
+            for d in shape:
+                need *= int(d)
+            flat = self._flat.get(name)
+            if flat is None or flat.dtype != dtype or flat.numel() < need:
+                flat = torch.empty(need + (need >> 3 if getattr(self, "_raw", None) is not None else 0), dtype=dtype, device=self.dev)
+                self._flat[name] = flat
+            t = flat[:need].view(shape)
             self._bufs[name] = t
         return t
 
@@ -207,6 +217,38 @@ class Matcher(_Base):
         self._enter()
         self.n = self._pack(self.db, sig)
         self.db_sig = sig
+        self._raw = None
+
+    def reserve_database(self, sig: torch.Tensor | None = None):
+        """A DB that grows (SC/test_sc.cpp:40-56: one signature per keyframe): the operand image is laid out for the matcher's CAPACITY
+        (pr_sigset_reserve) and the raw rows live in a capacity-sized buffer of the matcher, so append_database() adds rows in place - no
+        re-pack, no re-upload.  sig (optional): the rows to start with, device [n(*4), sig_len] f64."""
+        assert self.type in (_lib.TYPE_SC, _lib.TYPE_M2DP)
+        self._enter()
+        self.ctx.check(self.lib.pr_sigset_reserve(self.ctx.h, self.db))
+        self._raw = torch.empty((self._max_db * self.rows_per_sig, self.sig_len), dtype=torch.float64, device=self.dev)
+        self.n = 0
+        if sig is not None and sig.shape[0]:
+            assert sig.dtype == torch.float64
+            r = sig.shape[0]
+            self._raw[:r].copy_(sig)
+            self._enter()
+            self.n = self._pack(self.db, self._raw[:r])
+        self.db_sig = self._raw[:self.n * self.rows_per_sig]       # (a view: the same storage as the rows appended later)
+
+    def append_database(self, sig: torch.Tensor):
+        """Rows [n, n + n_new) of the growing DB: the raw rows into the matcher's buffer, their operand rows into the image
+        (pr_sigset_append: one kernel, bit for bit what a pack of all rows would write there)."""
+        assert getattr(self, "_raw", None) is not None, "reserve_database() first"
+        assert sig.is_cuda and sig.dim() == 2 and sig.shape[1] == self.sig_len and sig.dtype == torch.float64 and sig.shape[0] % self.rows_per_sig == 0
+        k, r0 = sig.shape[0] // self.rows_per_sig, self.n * self.rows_per_sig
+        assert self.n + k <= self._max_db
+        dst = self._raw[r0:r0 + sig.shape[0]]
+        dst.copy_(sig)
+        self._enter()                                              # (the copy above is torch's: ordered in front of the library's kernel)
+        self.ctx.check(self.lib.pr_sigset_append(self.ctx.h, self.db, _dptr(dst), 0, _lib.DEVICE, k))
+        self.n += k
+        self.db_sig = self._raw[:self.n * self.rows_per_sig]       # (a new view object: a split-f16 twin of the f16 arithmetic is re-packed when next needed)
 
     def local_phase1(self, queries: torch.Tensor):
         """pack(q) + distances + row moments of this shard -> moments [m, 2, 3] f64 (zeros for DELIGHT)."""
@@ -438,6 +480,7 @@ class FusedMatcher(_Base):
         self.sc = Matcher("sc", max_queries, max_db, self.ctx)
         self.m2 = Matcher("m2dp", max_queries, max_db, self.ctx)
         self._bufs = {}
+        self._flat = {}
 
     _buf = Matcher._buf
 

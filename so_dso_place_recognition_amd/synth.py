@@ -279,3 +279,60 @@ def scene_clouds_torch(seed: int, N: int, P: int, max_rho: float = 45.0, first: 
             xyz[(c0 + c) * P:(c0 + c + 1) * P] = torch.from_numpy(a).to(device)
             it[(c0 + c) * P:(c0 + c + 1) * P] = torch.from_numpy(b).to(device)
     return xyz, it, torch.arange(N + 1, dtype=torch.int64, device=device) * P
+
+
+def drive_clouds_torch(frames=2000, per_cloud=6000, seed=5, stops=(), device="cuda", positions=False):
+    """Two laps of a closed circuit through a static world: consecutive clouds overlap almost completely, frame i and
+    frame i + frames/2 see the same place from slightly different poses.  Returns CSR clouds in the camera frame
+    (x right, y down, z forward) and the lap length.  stops: (first frame, frames) stretches where the vehicle stands still - the pose
+    of `first frame` is kept for that many frames (the frame-dependent subsample still differs: near-copies, the clusters the matcher's
+    containment check exists for); the laps are then measured in MOVING frames.  positions: also return the sensor positions [frames, 3]
+    (the ground truth of run_test.m:62-85).  (tests/test_gpu_configs.py::test_drive_2000_frames_mask_100 and bench.py's
+    extra.kitti_shape share this sampler.)"""
+    import torch
+    g = torch.Generator(device=device); g.manual_seed(seed)
+    R0 = 160.0                                                        # circuit radius [m]
+    # world: ground strip + boxes along the circuit (y down: ground at y = +1.6)
+    nb = 900
+    ang = torch.rand(nb, generator=g, device=device, dtype=torch.float64) * 2 * np.pi
+    rad = R0 + (torch.rand(nb, generator=g, device=device, dtype=torch.float64) - 0.5) * 70
+    cx, cz = rad * torch.cos(ang), rad * torch.sin(ang)
+    half = 0.5 + 3.5 * torch.rand((nb, 3), generator=g, device=device, dtype=torch.float64)
+    base_i = 20 + 215 * torch.rand(nb, generator=g, device=device, dtype=torch.float64)
+    ppb = 700
+    u = torch.rand((nb, ppb, 3), generator=g, device=device, dtype=torch.float64) * 2 - 1
+    bx = torch.stack([cx[:, None] + half[:, None, 0] * u[..., 0], (1.6 - half[:, None, 1]) + half[:, None, 1] * u[..., 1] * 0.999,
+                      cz[:, None] + half[:, None, 2] * u[..., 2]], -1).reshape(-1, 3)
+    bi = (base_i[:, None] + 40 * (torch.rand((nb, ppb), generator=g, device=device, dtype=torch.float64) - 0.5)).reshape(-1)
+    ng = 500_000
+    ga = torch.rand(ng, generator=g, device=device, dtype=torch.float64) * 2 * np.pi
+    gr = R0 + (torch.rand(ng, generator=g, device=device, dtype=torch.float64) - 0.5) * 100
+    gx = torch.stack([gr * torch.cos(ga), 1.6 + 0.1 * (torch.rand(ng, generator=g, device=device, dtype=torch.float64) - 0.5), gr * torch.sin(ga)], -1)
+    gi_ = 60 + 40 * (torch.rand(ng, generator=g, device=device, dtype=torch.float64) - 0.5)
+    W = torch.cat([bx, gx]); WI = torch.cat([bi, gi_])
+    still = np.zeros(frames, bool)
+    for f0, cnt in stops:
+        still[f0 + 1: f0 + cnt] = True                                                # frames that repeat their predecessor's pose
+    step = np.cumsum(~still) - 1                                                      # the pose index of every frame (frame 0 moves)
+    moving = int((~still).sum())
+    lap = moving // 2
+    xyz, inten, offs, poss = [], [], [0], []
+    for f in range(frames):
+        s = int(step[f])
+        th = 2 * np.pi * (s % lap) / lap + (0.002 if s >= lap else 0.0)              # second lap: 0.3 m along-track offset
+        r = R0 + (0.4 if s >= lap else 0.0)                                           # ... and 0.4 m lateral
+        pos = torch.tensor([r * np.cos(th), 0.0, r * np.sin(th)], dtype=torch.float64, device=device)
+        fwd = torch.tensor([-np.sin(th), 0.0, np.cos(th)], dtype=torch.float64, device=device)
+        right = torch.tensor([np.cos(th), 0.0, np.sin(th)], dtype=torch.float64, device=device)
+        poss.append([r * np.cos(th), 0.0, r * np.sin(th)])
+        rel = W - pos
+        a, b = rel @ right, rel @ fwd
+        near = (a / 26.0) ** 2 + (b / 44.0) ** 2 < 1.0                               # a road corridor: keeps the three PCA eigenvalues apart (N3)
+        it = WI[near]
+        cam = torch.stack([a[near], rel[near, 1], b[near]], 1)
+        if cam.shape[0] > per_cloud:                                                  # frame-dependent subsample (a moving sensor never
+            sel = torch.randperm(cam.shape[0], generator=g, device=device)[:per_cloud]   # sees the same points twice)
+            cam, it = cam[sel], it[sel]
+        xyz.append(cam); inten.append(it.to(torch.float32)); offs.append(offs[-1] + cam.shape[0])
+    res = (torch.cat(xyz).cpu().numpy(), torch.cat(inten).cpu().numpy(), np.array(offs, np.int64), lap)
+    return res + (np.array(poss),) if positions else res

@@ -294,47 +294,7 @@ def test_pruned_reevaluation_gives_the_unpruned_result(api):
 
 # ------------------------------------------------------------------------------------------------ a drive
 def _drive(frames=2000, per_cloud=6000, seed=5):
-    """Two laps of a closed circuit through a static world: consecutive clouds overlap almost completely, frame i and
-    frame i + frames/2 see the same place from slightly different poses.  Returns CSR clouds in the camera frame
-    (x right, y down, z forward) and the lap length."""
-    g = torch.Generator(device="cuda"); g.manual_seed(seed)
-    R0 = 160.0                                                        # circuit radius [m]
-    # world: ground strip + boxes along the circuit (y down: ground at y = +1.6)
-    nb = 900
-    ang = torch.rand(nb, generator=g, device="cuda", dtype=torch.float64) * 2 * np.pi
-    rad = R0 + (torch.rand(nb, generator=g, device="cuda", dtype=torch.float64) - 0.5) * 70
-    cx, cz = rad * torch.cos(ang), rad * torch.sin(ang)
-    half = 0.5 + 3.5 * torch.rand((nb, 3), generator=g, device="cuda", dtype=torch.float64)
-    base_i = 20 + 215 * torch.rand(nb, generator=g, device="cuda", dtype=torch.float64)
-    ppb = 700
-    u = torch.rand((nb, ppb, 3), generator=g, device="cuda", dtype=torch.float64) * 2 - 1
-    bx = torch.stack([cx[:, None] + half[:, None, 0] * u[..., 0], (1.6 - half[:, None, 1]) + half[:, None, 1] * u[..., 1] * 0.999,
-                      cz[:, None] + half[:, None, 2] * u[..., 2]], -1).reshape(-1, 3)
-    bi = (base_i[:, None] + 40 * (torch.rand((nb, ppb), generator=g, device="cuda", dtype=torch.float64) - 0.5)).reshape(-1)
-    ng = 500_000
-    ga = torch.rand(ng, generator=g, device="cuda", dtype=torch.float64) * 2 * np.pi
-    gr = R0 + (torch.rand(ng, generator=g, device="cuda", dtype=torch.float64) - 0.5) * 100
-    gx = torch.stack([gr * torch.cos(ga), 1.6 + 0.1 * (torch.rand(ng, generator=g, device="cuda", dtype=torch.float64) - 0.5), gr * torch.sin(ga)], -1)
-    gi_ = 60 + 40 * (torch.rand(ng, generator=g, device="cuda", dtype=torch.float64) - 0.5)
-    W = torch.cat([bx, gx]); WI = torch.cat([bi, gi_])
-    lap = frames // 2
-    xyz, inten, offs = [], [], [0]
-    for f in range(frames):
-        th = 2 * np.pi * (f % lap) / lap + (0.002 if f >= lap else 0.0)              # second lap: 0.3 m along-track offset
-        r = R0 + (0.4 if f >= lap else 0.0)                                           # ... and 0.4 m lateral
-        pos = torch.tensor([r * np.cos(th), 0.0, r * np.sin(th)], dtype=torch.float64, device="cuda")
-        fwd = torch.tensor([-np.sin(th), 0.0, np.cos(th)], dtype=torch.float64, device="cuda")
-        right = torch.tensor([np.cos(th), 0.0, np.sin(th)], dtype=torch.float64, device="cuda")
-        rel = W - pos
-        a, b = rel @ right, rel @ fwd
-        near = (a / 26.0) ** 2 + (b / 44.0) ** 2 < 1.0                               # a road corridor: keeps the three PCA eigenvalues apart (N3)
-        it = WI[near]
-        cam = torch.stack([a[near], rel[near, 1], b[near]], 1)
-        if cam.shape[0] > per_cloud:                                                  # frame-dependent subsample (a moving sensor never
-            sel = torch.randperm(cam.shape[0], generator=g, device="cuda")[:per_cloud]   # sees the same points twice)
-            cam, it = cam[sel], it[sel]
-        xyz.append(cam); inten.append(it.to(torch.float32)); offs.append(offs[-1] + cam.shape[0])
-    return torch.cat(xyz).cpu().numpy(), torch.cat(inten).cpu().numpy(), np.array(offs, np.int64), lap
+    return synth.drive_clouds_torch(frames, per_cloud, seed)
 
 
 def test_drive_2000_frames_mask_100(api):
