@@ -322,7 +322,11 @@ def extra_workloads(dev, ev, args):
     out["m2dp_match_50k"] = {"queries_per_s": m / dt, "ms_per_step": 1e3 * dt, "kernel": "m2dp_match_h_kernel" if f16 else "m2dp_match_kernel",
                              "ms_per_launch": k, "flop_per_pair": fpp, "achieved_TFLOPs": m * n * fpp / (k * 1e-3) / 1e12,
                              "frac_of_mfma_peak": m * n * fpp / (k * 1e-3) / 1e12 / (MFMA_F16_PEAK_TFLOPS if f16 else MFMA_F32_PEAK_TFLOPS),
-                             "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == planted).sum()), "queries": m}
+                             "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == planted).sum()), "queries": m,
+                             # what a loop of nothing but v_mfma_f32_32x32x16_f16 sustains with split-f16-like operands on this chip (power-limited
+                             # clock): tools/ubench/mfma_power.hip, profiles/r06_mfma_power_box{A,B}.txt - a committed measurement, DESIGN.md section 4
+                             "sustained_mfma_ceiling_frac_of_peak": 0.67 if f16 else None,
+                             "frac_of_sustained_mfma_ceiling": (m * n * fpp / (k * 1e-3) / 1e12 / (0.67 * MFMA_F16_PEAK_TFLOPS)) if f16 else None}
     mt.close(); del db, q, mt
     torch.cuda.empty_cache()
     # config 2: SC / M2DP generation from 50 000-point clouds resident in HBM
@@ -352,12 +356,28 @@ def extra_workloads(dev, ev, args):
     Nm = 128
     sigm = torch.empty((4 * Nm, 384), dtype=torch.float64, device=dev)
     ms = timed(ctx, lambda: ctx.check(ctx.lib.pr_m2dp_generate_dev(ctx.h, P(xyz), P(it), P(offs), Nm, 45.0, P(sigm))), reps=2)
-    out["m2dp_generate_50k_pts"] = {"clouds": Nm, "points_per_cloud": PTS, "ms": ms, "clouds_per_s": Nm / (ms * 1e-3),
-                                    "plane_projections_per_s": Nm * 256 * PTS / (ms * 1e-3), "bound": "valu (fp64 dots + polar classification), not HBM"}
+    # "report projections/s and % VALUBusy".  VALU lane-instructions per plane projection from the committed PMC passes of this command
+    # (profiles/r06_final_derived.json: SQ_INSTS_VALU of m2dp_bin_kernel per launch of 256 clouds x 64 lanes / its projections), priced against the
+    # chip's VALU issue peak: 1024 SIMDs x 16 lanes x 2.4 GHz = 39.3 T lane-instructions/s
+    ipp = busy = None
+    try:
+        dk = json.load(open(os.path.join(ROOT, "profiles", "r06_final_derived.json")))["kernels"]
+        e_ = next(v for kk, v in dk.items() if kk.startswith("m2dp_bin_kernel<16> @ 1048576"))
+        ipp, busy = e_["insts_valu"] * 64.0 / (256.0 * PTS * 256.0), e_.get("valu_busy")
+    except Exception:
+        pass
+    VALU_PEAK = 1024 * 16 * 2.4e9
+
+    def m2gen(clouds, ms_):
+        pps = clouds * 256 * PTS / (ms_ * 1e-3)
+        return {"clouds": clouds, "points_per_cloud": PTS, "ms": ms_, "clouds_per_s": clouds / (ms_ * 1e-3), "plane_projections_per_s": pps,
+                "bound": "valu (fp64 dots + polar classification), not HBM", "valu_lane_instructions_per_projection": ipp,
+                "frac_of_valu_issue_peak": (pps * ipp / VALU_PEAK) if ipp else None, "valu_busy_of_m2dp_bin_kernel": busy,
+                "frac_source": "profiles/r06_final_derived.json (a committed PMC measurement of one box, not a live counter); whole call = m2dp_bin + m2dp_svd + frames"}
+    out["m2dp_generate_50k_pts"] = m2gen(Nm, ms)
     sigm = torch.empty((4 * N, 384), dtype=torch.float64, device=dev)
     ms = timed(ctx, lambda: ctx.check(ctx.lib.pr_m2dp_generate_dev(ctx.h, P(xyz), P(it), P(offs), N, 45.0, P(sigm))), reps=2)
-    out["m2dp_generate_50k_pts_1024_clouds"] = {"clouds": N, "points_per_cloud": PTS, "ms": ms, "clouds_per_s": N / (ms * 1e-3),
-                                                "plane_projections_per_s": N * 256 * PTS / (ms * 1e-3)}
+    out["m2dp_generate_50k_pts_1024_clouds"] = m2gen(N, ms)
     ctx.close(); del xyz, it, offs, sig, sigm
     torch.cuda.empty_cache()
     # the fp32-MFMA arithmetic of the SC matcher on the metric workload (one launch)
@@ -561,6 +581,7 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="N = 1 only: run the two all-gathers (RCCL, one-rank group) and the device merge of the sharded protocol anyway")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads reported under `extra`")
+    ap.add_argument("--no-kitti-shape", action="store_true", help="skip extra.kitti_shape (its drive sampler is ~70 000 torch launches: slow under rocprofv3 --pmc)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo: several ranks on ONE GPU, tests only)")
     args = ap.parse_args()
 
@@ -753,6 +774,10 @@ def main():
                          "flop_per_pair": fpp, "pairs_per_launch": pairs, "ms_per_launch": kms,
                          "matcher_ms_per_step": kms_all, "launches": launches,
                          "binary_channel_state": (int(st_bin.value) if launch_ms is not None else None),
+                         # a loop of nothing but f16 MFMAs on split-f16-like operands sustains 0.66 - 0.68 of `peak` on this chip (it clocks against its
+                         # power limit; zeros reach 0.98): tools/ubench/mfma_power.hip, profiles/r06_mfma_power_box{A,B}.txt (committed, not live)
+                         "sustained_mfma_ceiling_frac_of_peak": 0.67 if f16 else None,
+                         "frac_of_sustained_mfma_ceiling": (ach / peak / 0.67) if f16 else None,
                          # the same launch priced as the fp32 formulation it replaces (what an fp32-MFMA kernel would need)
                          "fp32_formulation_tflops": pairs * FLOP_PER_PAIR / (kms_all * 1e-3) / 1e12,
                          "fp32_formulation_frac_of_157.3": pairs * FLOP_PER_PAIR / (kms_all * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS,
@@ -818,7 +843,8 @@ def main():
             torch.cuda.empty_cache()
             out["extra"] = extra_workloads(dev, ev, args)
             try:
-                out["extra"]["kitti_shape"] = kitti_shape(dev, ev, args, not args.no_cpu_baseline)
+                if not args.no_kitti_shape:
+                    out["extra"]["kitti_shape"] = kitti_shape(dev, ev, args, not args.no_cpu_baseline)
             except Exception as e:    # an extra, never a reason to lose the bench line
                 out["extra"]["kitti_shape"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)

@@ -46,17 +46,31 @@ def main():
             grid = "grid_size" if "grid_size" in cols else "0"
             disp = next((x for x in ("dispatch_id", "correlation_id") if x in cols), None)
             per = {}
+            has_t = "start" in cols and "end" in cols
             if disp:
-                q = (f"select kernel_name, {grid}, counter_name, {disp}, sum(value) from counters_collection"
+                q = (f"select kernel_name, {grid}, counter_name, {disp}, sum(value)" + (", min(end - start)" if has_t else ", 0") + " from counters_collection"
                      f" group by kernel_name, {grid}, counter_name, {disp}")
-                for name, g, ctr, d, v in c.execute(q):
-                    per.setdefault((name, g, ctr), []).append(v)
+                for name, g, ctr, d, v, dur in c.execute(q):
+                    per.setdefault((name, g, ctr), []).append((dur or 0, v))
             else:
                 for name, g, ctr, v, n_ in c.execute(f"select kernel_name, {grid}, counter_name, sum(value), count(*) from counters_collection group by 1, 2, 3"):
-                    per[(name, g, ctr)] = [v / n_] * n_
-            for (name, g, ctr), vals in sorted(per.items(), key=lambda kv: (kv[0][0], kv[0][1], kv[0][2])):
-                big = [v for v in vals if v > 0.1 * max(vals)] or vals
-                print("%-72s grid=%-9s %-28s per launch %.6g (big=%d)  sum %.6g (n=%d)" % (name[:72], g, ctr, sum(big) / len(big), len(big), sum(vals), len(vals)))
+                    per[(name, g, ctr)] = [(0, v / n_)] * n_
+            for (name, g, ctr), dv in sorted(per.items(), key=lambda kv: (kv[0][0], kv[0][1], kv[0][2])):
+                # dispatches of one (kernel, grid) whose durations differ widely are different launches (one channel | both channels of the SC
+                # matcher; gated launches that leave at once): one line per duration cluster (sorted, a new cluster where the next is > 1.5x),
+                # labelled with the cluster's mean duration UNDER THE PROFILER (ms) - match it with the kernel trace's clusters by rank
+                dv.sort()
+                cl = [[dv[0]]]
+                for x in dv[1:]:
+                    if has_t and x[0] > 1.5 * cl[-1][-1][0] and x[0] > 20000:
+                        cl.append([])
+                    cl[-1].append(x)
+                allv = [v for _, v in dv]
+                for ci, gcl in enumerate(cl):
+                    vals = [v for _, v in gcl]
+                    big = [v for v in vals if v > 0.1 * max(vals)] or vals
+                    tag = ("cluster %d/%d ~%.3f ms" % (ci + 1, len(cl), sum(d for d, _ in gcl) / len(gcl) / 1e6)) if len(cl) > 1 else "-"
+                    print("%-72s grid=%-9s %-28s per launch %.6g (big=%d)  sum %.6g (n=%d)  [%s]" % (name[:72], g, ctr, sum(big) / len(big), len(big), sum(vals), len(vals), tag))
 
 
 if __name__ == "__main__":

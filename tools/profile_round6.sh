@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 f=$out/$tag.txt
 keep="^==|^--|pr::"
 {
-  echo "# $tag: python bench.py --steps 5 --warmup 2 (un-profiled); kernel trace: --steps 3 --warmup 1 --no-cpu-baseline; PMC passes: --steps 1 --warmup 0 --no-cpu-baseline - all WITH the extra workloads"
+  echo "# $tag: python bench.py --steps 5 --warmup 2 (un-profiled); kernel trace: --steps 3 --warmup 1 --no-cpu-baseline; PMC passes: --steps 1 --warmup 0 --no-cpu-baseline --no-kitti-shape - all WITH the extra workloads (the PMC passes without the drive sampler's ~70 000 torch launches)"
   echo "# MI355X, rocprofv3 --kernel-trace --stats, then one --pmc group per run"
   echo
   echo "## bench.py JSON line (un-profiled run, with the CPU baseline)"
@@ -32,7 +32,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE
   i=$((i+1))
   d=$out/${tag}_p$i
   rm -rf $d
-  rocprofv3 --pmc $grp -d $d -o sc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline ${PMC_BENCH_ARGS:-} > $d.log 2>&1
+  rocprofv3 --pmc $grp -d $d -o sc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kitti-shape ${PMC_BENCH_ARGS:-} > $d.log 2>&1
   echo >> $f
   python $root/profiles/summarize.py $(find $d -name "*_results.db") | grep -E "$keep" >> $f
 done
