@@ -69,12 +69,14 @@ def main():
                 if ci[0] == ci[1]:
                     c.update(cs)
             tt = dict(t, **tcl[-1]) if tcl else t
-            items.append(("%s @ %d" % key, tt, c))
+            items.append(("%s @ %d" % key, dict(tt, mixed=bool(tcl)), c))
     out = {"source": path, "note": "per (kernel, grid size in threads); counters are per launch (dispatches above a tenth of the largest)", "kernels": {}}
     for label, t, c in sorted(items, key=lambda it: -it[1]["ms_avg"] * it[1]["n"]):
         if not c or t["ms_avg"] < min_ms:
             continue
         e = {"ms_per_launch": t["ms_avg"], "launches_in_trace": t["n"], "vgpr": t["vgpr"], "lds_bytes": t["lds"]}
+        if t.get("mixed"):      # launches of several sizes under one (kernel, grid) that the two runs did not cluster alike: rates below mix them
+            e["caveat"] = "launches of different durations under this (kernel, grid) could not be matched between the trace and the PMC passes: ratios are over a mixture"
         cyc = c.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
         if cyc > 0:
             e["gpu_cycles"] = cyc

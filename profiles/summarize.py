@@ -27,7 +27,7 @@ def main():
             # (sorted durations, a new cluster wherever the next one is more than 1.5x the last)
             print("-- duration clusters of the kernels above whose launches differ widely (same name and grid): n, avg / min / max ms")
             for r in rows:
-                if r[4] > 4 * r[3] and r[4] > 1.0:
+                if r[4] > 1.5 * r[3] and r[4] > 0.05:
                     cond = " and %s = %d" % (grid, r[9]) if grid else ""
                     ds = sorted(x[0] / 1e6 for x in c.execute("select end-start from kernels where name = ?" + cond, (r[0],)))
                     cl = [[ds[0]]]

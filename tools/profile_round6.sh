@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 f=$out/$tag.txt
 keep="^==|^--|pr::"
 {
-  echo "# $tag: python bench.py --steps 5 --warmup 2 (un-profiled); kernel trace: --steps 3 --warmup 1 --no-cpu-baseline; PMC passes: --steps 1 --warmup 0 --no-cpu-baseline --no-kitti-shape - all WITH the extra workloads (the PMC passes without the drive sampler's ~70 000 torch launches)"
+  echo "# $tag: python bench.py --steps 5 --warmup 2 (un-profiled); kernel trace AND PMC passes: --steps 3 --warmup 1 --no-cpu-baseline --no-kitti-shape (the same launches in every pass) - all WITH the extra workloads (the PMC passes without the drive sampler's ~70 000 torch launches)"
   echo "# MI355X, rocprofv3 --kernel-trace --stats, then one --pmc group per run"
   echo
   echo "## bench.py JSON line (un-profiled run, with the CPU baseline)"
@@ -23,7 +23,7 @@ keep="^==|^--|pr::"
 } > $f
 tail -n 1 $f > /dev/null
 rm -rf $out/${tag}_trace
-rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o sc -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $out/${tag}_trace -o sc -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kitti-shape > $out/${tag}_trace.log 2>&1
 python $root/profiles/summarize.py $(find $out/${tag}_trace -name "*_results.db") | grep -E "$keep|rocclr" >> $f
 i=0
 for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY" \
@@ -32,14 +32,14 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE
   i=$((i+1))
   d=$out/${tag}_p$i
   rm -rf $d
-  rocprofv3 --pmc $grp -d $d -o sc -- python $root/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-kitti-shape ${PMC_BENCH_ARGS:-} > $d.log 2>&1
+  rocprofv3 --pmc $grp -d $d -o sc -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kitti-shape ${PMC_BENCH_ARGS:-} > $d.log 2>&1
   echo >> $f
   python $root/profiles/summarize.py $(find $d -name "*_results.db") | grep -E "$keep" >> $f
 done
 python - $out $tag <<'PY'
 import glob, json, re, sqlite3, sys
 out, tag = sys.argv[1], sys.argv[2]
-res = {"source": f"gpurun_out/{tag}.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `python bench.py --steps 1 --warmup 0 --no-cpu-baseline` (with the extra "
+res = {"source": f"gpurun_out/{tag}.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-kitti-shape` (with the extra "
                  "workloads); KiB per launch; FETCH_SIZE x2 (gfx950 wide-read correction, MI355X_MICROARCH.md); keys: kernel @ grid size",
        "workload": {"db": 100000, "queries": 4096, "n_gpus": 1}}
 for db in glob.glob(f"{out}/{tag}_p*/**/*_results.db", recursive=True):
