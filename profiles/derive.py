@@ -19,7 +19,7 @@ def short(name):
 def main():
     path = sys.argv[1]
     min_ms = float(sys.argv[sys.argv.index("--min-ms") + 1]) if "--min-ms" in sys.argv else 0.2
-    trace, clusters, pmc = {}, {}, {}
+    trace, clusters, pmc, order = {}, {}, {}, []
     mode = None
     for l in open(path):
         if l.startswith("-- kernel trace"):
@@ -31,17 +31,24 @@ def main():
         if mode == "trace":
             m = re.match(r"^(.*?)\s+n=(\d+)\s+avg=\s*([\d.]+) min=\s*([\d.]+) max=\s*([\d.]+) total=\s*([\d.]+) vgpr=(\d+) agpr=(\d+) lds=(\d+) grid=(\d+)", l)
             if m and "pr::" in m.group(1):
+                order.append((short(m.group(1)), int(m.group(10))))
                 trace[(short(m.group(1)), int(m.group(10)))] = {"n": int(m.group(2)), "ms_avg": float(m.group(3)), "ms_min": float(m.group(4)), "ms_max": float(m.group(5)),
                                                                "vgpr": int(m.group(7)), "lds": int(m.group(9))}
         elif mode == "clusters":
             # launches of one (kernel, grid) that differ widely (one channel | both channels; gated launches that leave at once): the trace's
-            # duration clusters, ascending - matched by rank with the PMC passes' clusters of the same (kernel, grid)
-            m = re.match(r"^(.*?)\s+n=(\d+)\s+avg=\s*([\d.]+) min=\s*([\d.]+) max=\s*([\d.]+)\s*$", l)
+            # duration clusters, ascending - matched by rank with the PMC passes' clusters of the same (kernel, grid).  The cluster lines follow
+            # the trace rows' order; a row's clusters are complete when their launch counts add up to the row's
+            m = re.match(r"^(.*?)\s+n=(\d+)\s+avg=\s*([\d.]+) min=\s*([\d.]+) max=\s*([\d.]+)(?: grid=(\d+))?\s*$", l)
             if m and "pr::" in m.group(1):
                 k = short(m.group(1))
-                cands = [key for key, t in trace.items() if key[0] == k and t["ms_min"] - 1e-9 <= float(m.group(4)) and float(m.group(5)) <= t["ms_max"] + 1e-9]
-                if cands:
-                    clusters.setdefault(cands[0], []).append({"n": int(m.group(2)), "ms_avg": float(m.group(3)), "ms_min": float(m.group(4)), "ms_max": float(m.group(5))})
+                rec = {"n": int(m.group(2)), "ms_avg": float(m.group(3)), "ms_min": float(m.group(4)), "ms_max": float(m.group(5))}
+                if m.group(6):
+                    key = (k, int(m.group(6)))
+                else:
+                    key = next((kk for kk in order if kk[0] == k and sum(c["n"] for c in clusters.get(kk, [])) < trace[kk]["n"]
+                                and trace[kk]["ms_min"] - 1e-9 <= rec["ms_min"] and rec["ms_max"] <= trace[kk]["ms_max"] + 1e-9), None)
+                if key is not None:
+                    clusters.setdefault(key, []).append(rec)
         elif mode == "pmc":
             m = re.match(r"^(.*?)\s+grid=(\d+)\s+(\S+)\s+per launch ([\d.e+-]+) \(big=(\d+)\).*?(?:\[cluster (\d+)/(\d+) ~([\d.]+) ms\])?\s*$", l)
             if m and "pr::" in m.group(1):

@@ -36,7 +36,7 @@ def main():
                             cl.append([])
                         cl[-1].append(d)
                     for g in cl:
-                        print("%-72s n=%-3d avg=%9.3f min=%9.3f max=%9.3f" % (r[0][:72], len(g), sum(g) / len(g), g[0], g[-1]))
+                        print("%-72s n=%-3d avg=%9.3f min=%9.3f max=%9.3f grid=%s" % (r[0][:72], len(g), sum(g) / len(g), g[0], g[-1], r[9]))
         if has_pmc:
             # one line per (kernel, grid size, counter): the same kernel runs the timed step's launches beside the small online / test launches,
             # and gated launches that leave at once beside the ones that run - `per launch` is the average over the dispatches
