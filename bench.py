@@ -447,6 +447,19 @@ def extra_workloads(dev, ev, args):
                                       "frac_of_f16_mfma_peak": m * n * FLOP_PER_PAIR / (k * 1e-3) / 1e12 / MFMA_F16_PEAK_TFLOPS,
                                       "packed_db_bytes_per_entry": 2 * 2976, "queries_recomputed_in_split_f16": int(mt.f16_fallbacks),
                                       "planted_top1_correct": int((idx.cpu().numpy()[:, 0] == planted).sum()), "queries": m}
+    # the same arithmetic at k = 5 (what the margin / order checks of the f16 pass hand to the split-f16 twin when the list reaches
+    # into a row's dense part, and what that costs a step - the twin's DB pack is part of the first such step only)
+    try:
+        f16_step(); mt.match(q, 0, 2.0, 5); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            mt.pack_database(db)
+            idx5, _ = mt.match(q, 0, 2.0, 5)
+        torch.cuda.synchronize()
+        out["sc_match_100k_f16_arith"]["k=5"] = {"ms_per_step": 1e3 * (time.perf_counter() - t0) / 3, "queries_recomputed_in_split_f16_per_step": int(mt.f16_fallbacks),
+                                                  "planted_top1_correct": int((idx5.cpu().numpy()[:, 0] == planted).sum())}
+    except Exception as e:
+        out["sc_match_100k_f16_arith"]["k=5"] = {"error": repr(e)[:200]}
     mt.close(); del mt
     torch.cuda.empty_cache()
     # BASELINE config 5, one GPU's share: fused SC + M2DP scoring, 125 000 of the 1 M signatures (an 8-GPU shard), f16 descriptors
