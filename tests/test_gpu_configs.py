@@ -582,3 +582,34 @@ def test_fp64_statistics_for_every_query_give_the_oracles_scores(api, monkeypatc
     i3, s3 = fm.match(torch.from_numpy(q[:48]).to(dev), torch.from_numpy(mq).to(dev), 5, 2.0, k)
     assert np.array_equal(i3.cpu().numpy(), fidx) and np.abs(s3.cpu().numpy() - fsc).max() < 1e-9
     fm.close()
+
+
+def test_stream_ordered_resolution_chains_every_pass_of_a_large_call(api, monkeypatch):
+    """pr_order_resolve_async_dev above RESOLVE_SMALL_M = 1024 queries: the first pass compacts the flags into a list, the passes behind it
+    read the list; every query flagged (PR_FORCE_ORDER_FLAGS) -> ceil(1100 / 64) = 18 passes chained on the stream without a read-back, all
+    scores the oracle's doubles, no PR_WARN_ORDER_UNRESOLVED; also as a captured hipGraph (what such a call is for)."""
+    import torch
+    from so_dso_place_recognition_amd.matcher import Matcher
+    monkeypatch.setenv("PR_FORCE_ORDER_FLAGS", "1")
+    m, n, k = 1100, 260, 2
+    db = synth.sc_database(83, n)
+    q = np.concatenate([synth.sc_queries(183 + i, db, 220)[0] for i in range(5)])
+    rc, oidx, osc = oracle_lib.match_topk(0, q, db, 3, 2.0, k)
+    assert rc == 0
+    dev = torch.device("cuda", 0)
+    mt = Matcher("sc", m, n, ctx=api.Context(0, stream=int(torch.cuda.current_stream(dev).cuda_stream)))
+    mt.pack_database(torch.from_numpy(db).to(dev))
+    i1, s1 = mt.match(torch.from_numpy(q).to(dev), 3, 2.0, k, exact_order="async")
+    w = mt.take_warnings()
+    assert (w & _lib.WARN_ORDER_RESOLVED) and not (w & _lib.WARN_ORDER_UNRESOLVED)
+    assert np.array_equal(i1.cpu().numpy(), oidx) and np.abs(s1.cpu().numpy() - osc).max() < 1e-9
+    mt.close()
+    mg = Matcher.on_new_stream("sc", m, n, device=0)
+    with torch.cuda.stream(mg.stream):
+        mg.pack_database(torch.from_numpy(db).to(dev))
+    cap = mg.capture(torch.from_numpy(q).to(dev), 3, 2.0, k)
+    cap.run(); cap.run()
+    w = mg.take_warnings()
+    assert (w & _lib.WARN_ORDER_RESOLVED) and not (w & _lib.WARN_ORDER_UNRESOLVED)
+    assert np.array_equal(cap.idx.cpu().numpy(), oidx) and np.abs(cap.score.cpu().numpy() - osc).max() < 1e-9
+    mg.close()
