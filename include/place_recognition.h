@@ -358,6 +358,14 @@ int32_t pr_group_last_flagged(const pr_group* g);       /* queries of the last p
 int pr_group_set_timing(pr_group* g, int on);
 int pr_group_last_timing(pr_group* g, float* ms, int32_t cap);
 int pr_group_set_database(pr_group* g, int type, const double* h2, int32_t n);
+/* A database that grows (SC/test_sc.cpp:40-56 adds one signature row per keyframe; run_test.m:57 matches a frame against all earlier ones):
+ * pr_group_set_database_growable = pr_group_set_database with room for extra_capacity more signatures on the LAST shard (whose rows end the
+ * global numbering; its operand image is laid out for that capacity, pr_sigset_reserve); pr_group_append_database adds hist_new ([n_new][2400]
+ * SC or [4 n_new][384] M2DP, host f64) there in place - no re-pack, no re-upload of what is resident - and the next pr_group_match_topk
+ * sees n + n_new rows.  With one device this is the online loop of a single GPU through host buffers only. */
+int pr_group_set_database_growable(pr_group* g, int type, const double* h2, int32_t n, int32_t extra_capacity);
+int pr_group_append_database(pr_group* g, const double* hist_new, int32_t n_new);
+int32_t pr_group_database_rows(const pr_group* g);
 int pr_group_take_warnings(pr_group* g);                /* OR of the shards' pr_take_warnings (PR_WARN_* bits), then cleared */
 int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,
                         double* score);

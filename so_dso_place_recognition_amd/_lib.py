@@ -61,6 +61,9 @@ SYMBOLS = {
     "pr_group_set_timing": (C.c_int, [_vp, C.c_int]),
     "pr_group_last_timing": (C.c_int, [_vp, _vp, _i32]),
     "pr_group_set_database": (C.c_int, [_vp, C.c_int, _vp, _i32]),
+    "pr_group_set_database_growable": (C.c_int, [_vp, C.c_int, _vp, _i32, _i32]),
+    "pr_group_append_database": (C.c_int, [_vp, _vp, _i32]),
+    "pr_group_database_rows": (_i32, [_vp]),
     "pr_group_take_warnings": (C.c_int, [_vp]),
     "pr_group_match_topk": (C.c_int, [_vp, _vp, _i32, _i32, _dbl, _i32, _vp, _vp]),
     "pr_destroy": (None, [_vp]),

@@ -138,13 +138,28 @@ class Group:
         if rc != 0:
             raise PRError(rc, self.lib.pr_group_last_error(self.h).decode())
 
-    def set_database(self, type_: str, hist2):
+    def set_database(self, type_: str, hist2, extra_capacity: int = 0):
+        """extra_capacity > 0: room for that many more signatures, added later in place by append_database (the online loop of
+        SC/test_sc.cpp:40-56 + run_test.m:57 through host buffers)."""
         t = {"sc": TYPE_SC, "m2dp": TYPE_M2DP}[type_]
         self.div, self.width = {TYPE_SC: (1, 2400), TYPE_M2DP: (4, 384)}[t]
         h2 = np.ascontiguousarray(hist2, np.float64)
         if h2.ndim != 2 or h2.shape[1] != self.width or h2.shape[0] % self.div:
             raise ValueError(f"expected a [{self.div}*n, {self.width}] signature matrix")
-        self._check(self.lib.pr_group_set_database(self.h, t, _ptr(h2), h2.shape[0] // self.div))
+        if extra_capacity:
+            self._check(self.lib.pr_group_set_database_growable(self.h, t, _ptr(h2), h2.shape[0] // self.div, int(extra_capacity)))
+        else:
+            self._check(self.lib.pr_group_set_database(self.h, t, _ptr(h2), h2.shape[0] // self.div))
+
+    def append_database(self, hist_new):
+        h = np.ascontiguousarray(hist_new, np.float64)
+        if h.ndim != 2 or h.shape[1] != self.width or h.shape[0] % self.div:
+            raise ValueError(f"expected a [{self.div}*n_new, {self.width}] signature matrix")
+        self._check(self.lib.pr_group_append_database(self.h, _ptr(h), h.shape[0] // self.div))
+
+    @property
+    def database_rows(self) -> int:
+        return int(self.lib.pr_group_database_rows(self.h))
 
     def match_topk(self, hist1, mask_width=0, p_weight=2.0, k=1):
         """run_test.m:26-57 against the sharded database -> (idx int32 [m,k] global rows, score float64 [m,k])."""

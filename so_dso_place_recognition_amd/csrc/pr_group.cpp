@@ -76,6 +76,7 @@ struct Shard {
   hipEvent_t ph[PR_GROUP_PHASES + 1] = {};      // pr_group_set_timing: events between the phases of a call
   pr_sigset *q = nullptr, *db = nullptr;
   int32_t row0 = 0, rows = 0;                 // this shard's global DB rows
+  int32_t cap_rows = 0;                       // rows its buffers are sized for: rows, or rows + the growth reserve of the last shard (pr_group_set_database_growable)
   void *raw_db = nullptr, *raw_q = nullptr;   // f64 signatures (the re-evaluation reads them)
   float *d_p = nullptr, *d_i = nullptr;
   double *mom = nullptr, *mom_all = nullptr, *score = nullptr, *score_all = nullptr, *sc64 = nullptr, *part = nullptr, *dump = nullptr;
@@ -334,9 +335,9 @@ int pr_group_last_timing(pr_group* g, float* ms, int32_t cap) {
 }
 
 // hist2 of run_test.m:1, host f64: [n][2400] (SC) or [4n][384] (M2DP); rows [g n/G, (g+1) n/G) go to shard g
-static int set_database_impl(pr_group* g, int type, const double* h2, int32_t n) {
+static int set_database_impl(pr_group* g, int type, const double* h2, int32_t n, int32_t extra) {
   g->type = -1; g->q_cap = 0; g->k_cap = 0;               // nothing usable until this call has succeeded
-  if ((type != PR_TYPE_SC && type != PR_TYPE_M2DP) || n < 2 || !h2) G_FAIL(g, PR_EINVAL, "pr_group_set_database: type must be SC or M2DP, n >= 2");
+  if ((type != PR_TYPE_SC && type != PR_TYPE_M2DP) || n < 2 || !h2 || extra < 0) G_FAIL(g, PR_EINVAL, "pr_group_set_database: type must be SC or M2DP, n >= 2, extra >= 0");
   const size_t row_doubles = type == PR_TYPE_SC ? PR_SC_SIG_LEN : (size_t)4 * PR_M2DP_SIG_LEN;
   for (int r = 0; r < g->G; r++) {
     Shard& sh = g->s[r];
@@ -347,10 +348,14 @@ static int set_database_impl(pr_group* g, int type, const double* h2, int32_t n)
     sh.row0 = (int32_t)((int64_t)n * r / g->G);
     sh.rows = (int32_t)((int64_t)n * (r + 1) / g->G) - sh.row0;
     if (sh.rows < 1) G_FAIL(g, PR_EINVAL, "pr_group_set_database: fewer signatures (%d) than shards (%d)", n, g->G);
+    // a growable database: the LAST shard (whose rows end the global numbering) gets `extra` rows of room - raw rows, operand image in the
+    // layout of that capacity (pr_sigset_reserve), distance matrices - and pr_group_append_database adds rows there in place
+    sh.cap_rows = sh.rows + (r == g->G - 1 ? extra : 0);
     const size_t bytes = (size_t)sh.rows * row_doubles * 8;
-    G_HIP(g, hipMalloc(&sh.raw_db, bytes));
+    G_HIP(g, hipMalloc(&sh.raw_db, (size_t)sh.cap_rows * row_doubles * 8));
     G_HIP(g, hipMemcpyAsync(sh.raw_db, h2 + (size_t)sh.row0 * row_doubles, bytes, hipMemcpyHostToDevice, sh.stream));
-    G_PR(g, sh, pr_sigset_create(sh.ctx, type, PR_ROLE_DB, sh.rows, &sh.db));
+    G_PR(g, sh, pr_sigset_create(sh.ctx, type, PR_ROLE_DB, sh.cap_rows, &sh.db));
+    if (sh.cap_rows > sh.rows) G_PR(g, sh, pr_sigset_reserve(sh.ctx, sh.db));
     G_PR(g, sh, pr_sigset_pack(sh.ctx, sh.db, sh.raw_db, PR_F64, PR_DEVICE, sh.rows));
   }
   for (auto& sh : g->s) { G_HIP(g, hipSetDevice(sh.device)); G_PR(g, sh, pr_sync(sh.ctx)); }   // h2 may be released by the caller
@@ -379,8 +384,8 @@ static int match_topk_impl(pr_group* g, const double* h1, int32_t m, int32_t mas
       G_HIP(g, hipSetDevice(sh.device));
       G_PR(g, sh, pr_sigset_create(sh.ctx, type, PR_ROLE_QUERY, qc, &sh.q));
       G_HIP(g, hipMalloc(&sh.raw_q, (size_t)qc * row_doubles * 8));
-      G_HIP(g, hipMalloc((void**)&sh.d_p, (size_t)qc * sh.rows * 4));
-      G_HIP(g, hipMalloc((void**)&sh.d_i, (size_t)qc * sh.rows * 4));
+      G_HIP(g, hipMalloc((void**)&sh.d_p, (size_t)qc * sh.cap_rows * 4));
+      G_HIP(g, hipMalloc((void**)&sh.d_i, (size_t)qc * sh.cap_rows * 4));
       G_HIP(g, hipMalloc((void**)&sh.mom, (size_t)qc * 6 * 8));
       G_HIP(g, hipMalloc((void**)&sh.mom_all, (size_t)G * qc * 6 * 8));
       G_HIP(g, hipMalloc((void**)&sh.idx_in, (size_t)qc * kinc * 4));
@@ -508,8 +513,40 @@ static int settle(pr_group* g, int rc) {
 
 int pr_group_set_database(pr_group* g, int type, const double* h2, int32_t n) {
   if (!g) return PR_EINVAL;
-  return settle(g, set_database_impl(g, type, h2, n));
+  return settle(g, set_database_impl(g, type, h2, n, 0));
 }
+
+int pr_group_set_database_growable(pr_group* g, int type, const double* h2, int32_t n, int32_t extra_capacity) {
+  if (!g) return PR_EINVAL;
+  return settle(g, set_database_impl(g, type, h2, n, extra_capacity));
+}
+
+// rows [n, n + n_new) of the database: onto the last shard, in place (raw rows + operand rows: pr_sigset_append) - SC/test_sc.cpp:40-56 adds a
+// row per keyframe, run_test.m:57 matches the next one against all of them
+static int append_database_impl(pr_group* g, const double* h_new, int32_t n_new) {
+  if (g->type < 0) G_FAIL(g, PR_EINVAL, "pr_group_append_database: no database (pr_group_set_database_growable)");
+  if (n_new < 0 || (n_new > 0 && !h_new)) G_FAIL(g, PR_EINVAL, "pr_group_append_database: bad arguments (n_new=%d)", n_new);
+  if (n_new == 0) return PR_OK;
+  Shard& sh = g->s[g->G - 1];
+  if ((int64_t)sh.rows + n_new > sh.cap_rows)
+    G_FAIL(g, PR_EINVAL, "pr_group_append_database: %d + %d rows exceed the last shard's capacity %d (pr_group_set_database_growable's extra_capacity)", sh.rows, n_new, sh.cap_rows);
+  const size_t row_doubles = g->type == PR_TYPE_SC ? PR_SC_SIG_LEN : (size_t)4 * PR_M2DP_SIG_LEN;
+  G_HIP(g, hipSetDevice(sh.device));
+  double* dst = static_cast<double*>(sh.raw_db) + (size_t)sh.rows * row_doubles;
+  G_HIP(g, hipMemcpyAsync(dst, h_new, (size_t)n_new * row_doubles * 8, hipMemcpyHostToDevice, sh.stream));
+  G_PR(g, sh, pr_sigset_append(sh.ctx, sh.db, dst, PR_F64, PR_DEVICE, n_new));
+  G_PR(g, sh, pr_sync(sh.ctx));                               // h_new may be released by the caller
+  sh.rows += n_new;
+  g->n += n_new;
+  return PR_OK;
+}
+
+int pr_group_append_database(pr_group* g, const double* h_new, int32_t n_new) {
+  if (!g) return PR_EINVAL;
+  return settle(g, append_database_impl(g, h_new, n_new));
+}
+
+int32_t pr_group_database_rows(const pr_group* g) { return g ? g->n : 0; }
 
 int pr_group_match_topk(pr_group* g, const double* h1, int32_t m, int32_t mask_width, double p_weight, int32_t k, int32_t* idx,
                         double* score) {

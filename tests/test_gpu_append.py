@@ -115,3 +115,32 @@ def test_appendable_set_needs_the_default_matcher(monkeypatch):
     assert ctx.lib.pr_distances_dev(ctx.h, q, d, dummy, dummy) == -1 and b"default matcher" in ctx.lib.pr_last_error(ctx.h)
     ctx.lib.pr_sigset_destroy(ctx.h, q); ctx.lib.pr_sigset_destroy(ctx.h, d)
     ctx.close()
+
+
+@pytest.mark.parametrize("shards,type_", [(1, "sc"), (3, "sc"), (2, "m2dp")])
+def test_pr_group_database_grows_in_place(shards, type_):
+    """The host-buffer form of the online loop (pr_group: what `match_signatures` and a MATLAB caller see): a database with room to grow on its
+    last shard, every keyframe matched against the rows so far (mask 3, k 2) and then appended; answers = the oracle's on the database of that moment."""
+    n0, extra = 250, 120
+    tcode = 0 if type_ == "sc" else 1
+    rows = 1 if type_ == "sc" else 4
+    full = synth.sc_database(91, n0 + extra) if type_ == "sc" else synth.m2dp_database(92, n0 + extra)
+    g = api.Group([0] * shards)
+    g.set_database(type_, full[:n0 * rows], extra_capacity=extra)
+    n = n0
+    for step, k_new in enumerate((1, 1, 2, 17, 1, 60)):
+        q = (synth.sc_queries(200 + step, full[:n], 6)[0] if type_ == "sc" else synth.m2dp_queries(200 + step, full[:n * rows], 6)[0])
+        idx, sc = g.match_topk(q, 3, 2.0, 2)
+        rc, oidx, osc = oracle_lib.match_topk(tcode, q, full[:n * rows], 3, 2.0, 2)
+        assert rc == 0 and np.array_equal(idx, oidx), (step, n)
+        g.append_database(full[n * rows:(n + k_new) * rows])
+        n += k_new
+        assert g.database_rows == n
+    with pytest.raises(api.PRError):
+        g.append_database(full[:(extra + 1) * rows])                 # past the reserve
+    g.close()
+    g = api.Group([0])
+    g.set_database(type_, full[:n0 * rows])                          # not growable: no room
+    with pytest.raises(api.PRError):
+        g.append_database(full[:rows])
+    g.close()
