@@ -13,7 +13,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // NA x NB accumulator tiles per wave (4 x 2 = the register tile of m2dp_match_h_kernel), PROD products per tile and K-step:
 // PROD = 3: a_hi b_hi + a_hi b_lo + a_lo b_hi (split-f16), PROD = 1: a_hi b_hi only
-template <int PROD>
+// ORDER 0: the matcher's order (A operand fixed over the NB tiles of a product, B changes with every MFMA); ORDER 1: a B operand fixed over all
+// NA tiles and the products that use it (B changes every 4 - 8 MFMAs, A with every MFMA) - does the operand-reuse pattern change the clock?
+template <int PROD, int ORDER = 0>
 __global__ __launch_bounds__(256, 2) void k(const f16x8* __restrict__ src, float* out, int iters) {
   constexpr int NA = 4, NB = 2;
   const int lane = threadIdx.x & 63;
@@ -24,6 +26,20 @@ __global__ __launch_bounds__(256, 2) void k(const f16x8* __restrict__ src, float
   f32x16 acc[NA][NB];
   for (int i = 0; i < NA; i++) for (int j = 0; j < NB; j++) for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
   for (int it = 0; it < iters; it++) {
+    if constexpr (ORDER == 1) {
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+        if (PROD == 3) {
+#pragma unroll
+          for (int i = 0; i < NA; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+          for (int i = 0; i < NA; i++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int i = 0; i < NA; i++) {
 #pragma unroll
@@ -84,10 +100,12 @@ int main(int argc, char** argv) {
       }
     }
     hipMemcpy(d, h.data(), h.size() * 2, hipMemcpyHostToDevice);
-    for (int prod = 3; prod >= (data >= 4 ? 3 : 1); prod -= 2)
-      for (int wg = 256; wg <= (data >= 4 ? 256 : 512); wg *= 2) {           // 256 workgroups = one wave per SIMD; 512 = two
+    for (int order = 0; order <= (data == 2 ? 1 : 0); order++)
+    for (int prod = 3; prod >= ((data >= 4 || order) ? 3 : 1); prod -= 2)
+      for (int wg = 256; wg <= ((data >= 4 || order) ? 256 : 512); wg *= 2) {           // 256 workgroups = one wave per SIMD; 512 = two
         auto go = [&](int iters) {
-          if (prod == 3) hipLaunchKernelGGL(k<3>, dim3(wg), dim3(256), 0, 0, d, o, iters);
+          if (prod == 3 && order) hipLaunchKernelGGL((k<3, 1>), dim3(wg), dim3(256), 0, 0, d, o, iters);
+          else if (prod == 3) hipLaunchKernelGGL(k<3>, dim3(wg), dim3(256), 0, 0, d, o, iters);
           else hipLaunchKernelGGL(k<1>, dim3(wg), dim3(256), 0, 0, d, o, iters);
         };
         const int mf = (prod == 3 ? 24 : 8);
@@ -103,7 +121,7 @@ int main(int argc, char** argv) {
           last = (double)wg * 4 * iters * mf * 32768.0 / (ms * 1e-3) / 1e12;
           if (last > best) best = last;
         }
-        printf("%-90s products=%d waves/SIMD=%d : %7.1f TFLOP/s (last of three %.0f ms launches; best %7.1f) = %.3f of 2500 = %.3f busy-GHz\n", names[data], prod,
+        printf("%-90s order=%d products=%d waves/SIMD=%d : %7.1f TFLOP/s (last of three %.0f ms launches; best %7.1f) = %.3f of 2500 = %.3f busy-GHz\n", names[data], order, prod,
                wg / 256, last, target_ms, best, last / 2500.0, last / 2500.0 * 2.4);
       }
   }
