@@ -219,12 +219,19 @@ __global__ __launch_bounds__(512, 2) void m2dp_match_h8_kernel(const u32x4* __re
   const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (s0 >= s1) return;
   const u32x4* pb = dpk + ((size_t)ch * DTS + (size_t)s0 * 8 + w) * TV + lane;
-  HL bs[3];                 // DB operands of K-steps st, st + 1, st + 2
+  // DB operands of K-steps st .. st + RD - 1.  Split-f16: a K-step is 12 MFMAs per wave (~770 cycles with the SIMD's other wave), two ahead cover an L2
+  // hit.  Single product: 4 MFMAs (~260 cycles) - two ahead were 500 cycles, LESS than the L2's latency under load, and the matrix pipe sat 37 %
+  // busy waiting for operands (round 6 counters); eleven ahead (RD = 12: the whole K loop of the next DB tile is in flight; 12 K-steps advance the rotation by 0 for RD in {3, 4, 6, 12}).  4096 x 50k: RD 3: 2.93 ms, 4: 2.55, 6: 2.34, 12: 2.27 = 0.34 -> 0.445 of 2.5 PF (alternating runs, tools/exp_m2dp_single.py)
+#ifndef M2_RD1
+#define M2_RD1 12
+#endif
+  constexpr int RD = LO ? 3 : M2_RD1;
+  HL bs[RD];
   HL a[QTB];
 #define MF(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, A), __builtin_bit_cast(f16x8, B), C, 0, 0, 0)
 #define SBAR() __builtin_amdgcn_sched_barrier(0)
-  bs[0].h = pb[0]; bs[1].h = pb[128];
-  if constexpr (LO) { bs[0].l = pb[64]; bs[1].l = pb[128 + 64]; }
+#pragma unroll
+  for (int r = 0; r < RD - 1; r++) { bs[r].h = pb[r * 128]; if constexpr (LO) bs[r].l = pb[r * 128 + 64]; }
 #pragma unroll
   for (int t = 0; t < QTB; t++) { a[t].h = la[t * TV]; if constexpr (LO) a[t].l = la[t * TV + 64]; }
   for (int s = s0; s < s1; s++) {
@@ -233,9 +240,9 @@ __global__ __launch_bounds__(512, 2) void m2dp_match_h8_kernel(const u32x4* __re
     f32x16 acc[QTB];
 #pragma unroll
     for (int st = 0; st < 12; st++) {
-      const HL& c = bs[st % 3];
-      HL& nx = bs[(st + 2) % 3];
-      const u32x4* pq = (st + 2 < 12) ? pb + (st + 2) * 128 : pn + (st + 2 - 12) * 128;
+      const HL& c = bs[st % RD];
+      HL& nx = bs[(st + RD - 1) % RD];
+      const u32x4* pq = (st + RD - 1 < 12) ? pb + (st + RD - 1) * 128 : pn + (st + RD - 1 - 12) * 128;
       const bool first = st == 0;
 #pragma unroll
       for (int t = 0; t < QTB; t++) {

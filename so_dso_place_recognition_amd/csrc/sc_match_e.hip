@@ -55,7 +55,8 @@
 #define E_BD 4          // depth of the DB operand ring, split-f16 form
 #endif
 #ifndef E_BD1
-#define E_BD1 6         // the same, single-product form (a position is only two MFMAs long)
+#define E_BD1 8         // the same, single-product form (a position is only two MFMAs long); round 6: 6 -> 8, binary launch 9.06 -> 8.90 ms (-1.8 %, alternating
+                        // runs); 252 of the 256 registers a wave has at two per SIMD - 9 spills
 #endif
 
 namespace pr {
