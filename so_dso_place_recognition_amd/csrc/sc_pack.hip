@@ -216,14 +216,21 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
   float e2 = 0.f;
   const double* twc = tw + 120 + (size_t)fb * 60 * 8;           // [sector][j]{cos, sin}, wave-uniform
   // rolled loop over 4 sectors at a time, the column values requested two rounds (8 sectors) ahead of their use
-  T xq[3][4];
+#ifndef SCP_AHEAD
+#define SCP_AHEAD 2     // rounds the column values are requested ahead of their use (the ring holds SCP_AHEAD + 1 rounds; 15 rounds: the ring size divides 15)
+#endif
+  constexpr int XR = SCP_AHEAD + 1;
+  static_assert(15 % XR == 0, "the ring size must divide the 15 rounds");
+  T xq[XR][4];
 #pragma unroll
-  for (int k = 0; k < 4; k++) { xq[0][k] = src[k * 20]; xq[1][k] = src[(4 + k) * 20]; }
-#pragma unroll 3
+  for (int r = 0; r < SCP_AHEAD; r++)
+#pragma unroll
+    for (int k = 0; k < 4; k++) xq[r][k] = src[(r * 4 + k) * 20];
+#pragma unroll XR
   for (int it = 0; it < 15; it++) {
-    if (it + 2 < 15) {
+    if (it + SCP_AHEAD < 15) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) xq[(it + 2) % 3][k] = src[((it + 2) * 4 + k) * 20];
+      for (int k = 0; k < 4; k++) xq[(it + SCP_AHEAD) % XR][k] = src[((it + SCP_AHEAD) * 4 + k) * 20];
     }
     // (the 32 twiddles of a round are addressed through an opaque zero that the empty asm redefines together with the accumulators: the scalar
     //  loads of round it cannot start before round it - 1 has finished.  hipcc otherwise requests three rounds' worth ahead - 192 SGPRs, of
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(320) void sc_pack_h_col_kernel(const T* __restrict_
     const double* tp = twc + it * 32 + tz;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-      const double x0 = (double)xq[it % 3][2 * h], x1 = (double)xq[it % 3][2 * h + 1];
+      const double x0 = (double)xq[it % XR][2 * h], x1 = (double)xq[it % XR][2 * h + 1];
       nsq += x0 * x0;
       nsq += x1 * x1;
       if (do_bin) {
