@@ -260,13 +260,16 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
   }
   // G = A A^T / fro.  Every thread owns a 4 x 4 block of the 64 x 64 result: 8 LDS reads per 16 multiply-adds instead
   // of 32 (the kernel is LDS-bound); every entry is summed over k in ascending order.
-  const int i0 = (tid >> 4) * 4, j0 = (tid & 15) * 4;
+  // rows i0 .. i0 + 3 (four values per wave: broadcasts) x rows jl, jl + 16, jl + 32, jl + 48: the 16 lanes that differ in jl read 16 CONSECUTIVE
+  // rows (pitch 129 | 65 doubles = bank step 2: conflict-free); round 6 - they owned 4 jl .. 4 jl + 3 before (bank step 8: two lanes per bank pair,
+  // SQ_LDS_BANK_CONFLICT 0.42 per CU cycle).  Every entry is still the same sum over k in the same order: the result is bit for bit the old one.
+  const int i0 = (tid >> 4) * 4, jl = tid & 15;
   {
     double acc[4][4] = {};
     for (int k = 0; k < 128; k++) {
       double ai[4], aj[4];
 #pragma unroll
-      for (int a = 0; a < 4; a++) { ai[a] = A[(i0 + a) * 129 + k]; aj[a] = A[(j0 + a) * 129 + k]; }
+      for (int a = 0; a < 4; a++) { ai[a] = A[(i0 + a) * 129 + k]; aj[a] = A[(jl + 16 * a) * 129 + k]; }
 #pragma unroll
       for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -276,7 +279,7 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-      for (int b = 0; b < 4; b++) G[(i0 + a) * 65 + j0 + b] = acc[a][b] / fro;
+      for (int b = 0; b < 4; b++) G[(i0 + a) * 65 + jl + 16 * b] = acc[a][b] / fro;
   }
   __syncthreads();
   for (int it = 0; it < 8; it++) {     // G <- G*G / ||G*G||_F   (G symmetric)
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
     for (int k = 0; k < 64; k++) {
       double gi[4], gj[4];
 #pragma unroll
-      for (int a = 0; a < 4; a++) { gi[a] = G[(i0 + a) * 65 + k]; gj[a] = G[(j0 + a) * 65 + k]; }
+      for (int a = 0; a < 4; a++) { gi[a] = G[(i0 + a) * 65 + k]; gj[a] = G[(jl + 16 * a) * 65 + k]; }
 #pragma unroll
       for (int a = 0; a < 4; a++)
 #pragma unroll
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(256) void m2dp_svd_kernel(const double* __restrict_
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
-      for (int b = 0; b < 4; b++) G[(i0 + a) * 65 + j0 + b] = acc[a][b] / nf;
+      for (int b = 0; b < 4; b++) G[(i0 + a) * 65 + jl + 16 * b] = acc[a][b] / nf;
     __syncthreads();
   }
   // start vector: G * ones (non-negative matrices keep it in the Perron cone), normalised
