@@ -7,9 +7,15 @@
 //   [--exact_statistics 0|1]          every query answered from its exact fp64 row (scores = the reference's doubles to rounding).  Default: 1
 //                                     with --gt1 / --gt2 - the sweep ranks the QUERIES by score (run_test.m:58), and two queries whose scores
 //                                     agree to 1e-5 must not change places -, else 0
+//   [--online 1]                      the causal form of the same match (what a running SLAM front end asks: SC/test_sc.cpp:40-56 produces one row per
+//                                     keyframe): row t of hist1 is matched against rows 0 .. t - mask_width of hist1 ITSELF (hist2 is not read; the
+//                                     mask of run_test.m:47-53 restricted to the past), then joins the database - resident on the GPU and grown IN
+//                                     PLACE (pr_group_set_database_growable / pr_group_append_database), one pr_group_match_topk per keyframe.
+//                                     Rows with fewer than two candidates come out as -1 NaN.  sc | m2dp; --devices optional (default: device 0)
 // Output: one line per query: K pairs "index score" (0-based indices unless --one_based 1), and the reference's
 // console lines `type` / `tm` (ms per query, run_test.m:42-44).  Scores are doubles, as MATLAB holds them.
 #include <chrono>
+#include <cmath>
 #include <vector>
 
 #include "../../../include/place_recognition.h"
@@ -64,9 +70,33 @@ int main(int argc, char** argv) {
     if (exact && ctx) (void)pr_set_exact_statistics(ctx, 1);
     if (exact && grp) (void)pr_group_set_exact_statistics(grp, 1);
   }
+  const bool online = prm.num("online", 0) != 0;
+  if (online && t != PR_TYPE_SC && t != PR_TYPE_M2DP) { fprintf(stderr, "--online needs --type sc|m2dp\n"); return 1; }
+  if (online && !grp) {                                                  // the growing database lives in a pr_group (one device unless --devices)
+    const int32_t d0 = (int32_t)prm.num("device", 0);
+    if (pr_group_create(&d0, 1, &grp) != PR_OK) { fprintf(stderr, "%s\n", pr_group_last_error(nullptr)); return 3; }
+  }
   const auto t0 = std::chrono::steady_clock::now();
   int rc;
-  if (grp) {
+  if (online) {
+    const int32_t mask = (int32_t)prm.num("mask_width", 0), lag = mask > 1 ? mask - 1 : 0;
+    const size_t rowd = (size_t)div * (size_t)width;                    // doubles per signature
+    int32_t have = 0;                                                   // rows of hist1 in the database: rows 0 .. have - 1
+    rc = PR_OK;
+    for (int32_t q = 0; q < m && rc == PR_OK; q++) {
+      const int32_t want = q - lag;                                     // rows the mask admits for keyframe q: 0 .. q - lag - 1
+      if (want >= 2 && have == 0) {                                     // two rows: the first database (N - 1 standard deviation)
+        rc = pr_group_set_database_growable(grp, t, h1, 2, m);
+        have = 2;
+      }
+      if (rc == PR_OK && have > 0 && want > have) { rc = pr_group_append_database(grp, h1 + (size_t)have * rowd, want - have); have = want; }
+      if (rc != PR_OK) break;
+      if (have < 2) { for (int32_t j = 0; j < k; j++) { idx[(size_t)q * k + j] = -1; score[(size_t)q * k + j] = NAN; } continue; }
+      rc = pr_group_match_topk(grp, h1 + (size_t)q * rowd, 1, 0, prm.num("p_weight", 2.0), k, idx.data() + (size_t)q * k, score.data() + (size_t)q * k);
+    }
+    if (rc != PR_OK) { fprintf(stderr, "online match failed (%d): %s\n", rc, pr_group_last_error(grp)); return 4; }
+    printf("online = 1 (database rows at the end: %d)\n", (int)pr_group_database_rows(grp));
+  } else if (grp) {
     rc = pr_group_match_topk(grp, h1, m, (int32_t)prm.num("mask_width", 0), prm.num("p_weight", 2.0), k, idx.data(), score.data());
     if (rc != PR_OK) { fprintf(stderr, "match failed (%d): %s\n", rc, pr_group_last_error(grp)); return 4; }
   } else if (cols_type) {

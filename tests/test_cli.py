@@ -206,3 +206,52 @@ def test_match_signatures_devices_and_ground_truth(tmp_path):
     line = {l.split(" = ")[0]: l.split(" = ")[1] for l in outs[0][1].splitlines() if " = " in l}
     assert abs(float(line["AUC"]) - auc) < 1e-9 or (np.isnan(auc) and line["AUC"].strip() == "nan")
     assert abs(float(line["top_recall"]) - tr) < 1e-9 and int(line["lp_detected"]) == len(det)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("type_,mask,devices", [("sc", 12, None), ("sc", 0, "0,0"), ("m2dp", 5, None)])
+def test_match_signatures_online_mode(tmp_path, type_, mask, devices):
+    """match_signatures --online 1: keyframe t against rows 0 .. t - mask of the same file, the database grown in place on the GPU
+    (pr_group_set_database_growable / pr_group_append_database).  Every answered row equals the oracle on the database of that moment (binary file:
+    the signatures reach the executable bit for bit)."""
+    from so_dso_place_recognition_amd import synth
+    N, k = 90, 2
+    rows = 1 if type_ == "sc" else 4
+    sig = synth.sc_database(301, N) if type_ == "sc" else synth.m2dp_database(302, N)
+    for t in (40, 55, 70):                                   # revisits: near-copies of earlier frames
+        src = t - 30
+        sig[t * rows:(t + 1) * rows] = sig[src * rows:(src + 1) * rows] * (1.0 + 1e-3 * np.random.default_rng(t).standard_normal((rows, sig.shape[1])))
+    f = str(tmp_path / "hist.bin")
+    from so_dso_place_recognition_amd import _lib
+    import ctypes as C
+    sig = np.ascontiguousarray(sig, np.float64)
+    assert _lib.load().pr_write_signatures_bin(f.encode(), sig.ctypes.data_as(C.c_void_p), sig.shape[0], sig.shape[1], _lib.F64) == 0
+    out = str(tmp_path / "online.txt")
+    cmd = [os.path.join(BIN, "match_signatures"), "--type", type_, "--hist1", f, "--hist2", f, "--online", "1", "--mask_width", str(mask),
+           "--topk", str(k), "--out", out]
+    if devices:
+        cmd += ["--devices", devices]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lag = max(mask - 1, 0)
+    assert f"database rows at the end: {N - 1 - lag}" in r.stdout
+    got = [l.split() for l in open(out).read().strip().split("\n")]
+    assert len(got) == N
+    tcode = 0 if type_ == "sc" else 1
+    for t in range(N):
+        have = t - lag
+        if have < 2:
+            assert got[t][0] == "-1"
+            continue
+        rc, oidx, osc = oracle_lib.match_topk(tcode, sig[t * rows:(t + 1) * rows], sig[:have * rows], 0, 2.0, k)
+        assert rc == 0
+        gi = [int(got[t][0]), int(got[t][2])]
+        assert gi == list(oidx[0]), (t, gi, oidx)
+        gs = np.array([float(got[t][1]), float(got[t][3])])
+        ok = np.isfinite(osc[0])
+        rc, odp, odi = (oracle_lib.sc_distance if type_ == "sc" else oracle_lib.m2dp_distance)(sig[t * rows:(t + 1) * rows], sig[:have * rows])
+        tol = helpers.score_tol(osc[0], helpers.row_sigmas(odp, odi), eps=1e-7)[0]          # short rows of a toy database: the fp32-statistics model
+        assert (np.abs(gs[ok] - osc[0][ok]) <= tol[ok]).all(), (t, gs, osc[0], tol)
+    for t, src in ((40, 10), (55, 25), (70, 40)):            # the revisits find their places
+        if src < t - lag:
+            assert int(got[t][0]) == src
