@@ -81,6 +81,27 @@ def _worker(rank, world, port, n, m, k, mask, q):
     assert seen["exact"].shape == (world, m, 4, 3) and all((seen["exact"][g] == g + 1).all() for g in range(world))
     assert seen["sel"].shape == (world, 64, 2, k) and all((seen["sel"][g] == 10 * (g + 1)).all() for g in range(world))
     assert torch.equal(idx2, idx) and np.abs(sc2.numpy() - sc.numpy()).max() == 0.0
+    # the Matcher's form of step 7: a fourth entry gives the number of passes (a stream-ordered call: ceil(m / 64), whatever is flagged); every
+    # pass runs both exchanges with its offset, and only the LAST one is declared last (what may raise PR_WARN_ORDER_UNRESOLVED in the library)
+    calls = []
+
+    def exact_p(off, last):
+        calls.append(("exact", off, last))
+        return torch.full((m, 4, 3), float(rank + 1), dtype=torch.float64)
+
+    def select_p(exact_all, kk, off=0):
+        calls.append(("select", off))
+        return torch.full((64, 2, kk), float(off), dtype=torch.float64)
+
+    def merge_p(sel_all, kk, i_, s_, off=0):
+        assert (sel_all.numpy() == float(off)).all() and sel_all.shape[0] == world
+        calls.append(("merge", off))
+        return i_, s_
+
+    idx3, sc3 = sharded_topk(local_moments, local_select, k, None, world, rerank=rerank, finish=finish, resolve=(exact_p, select_p, merge_p, lambda: 3))
+    assert calls == [("exact", 0, False), ("select", 0), ("merge", 0), ("exact", 64, False), ("select", 64), ("merge", 64),
+                     ("exact", 128, True), ("select", 128), ("merge", 128)]
+    assert torch.equal(idx3, idx)
     if rank == 0:
         q.put((idx.numpy(), sc.numpy()))
     dist.barrier()
