@@ -179,7 +179,17 @@ for it in range(cases):
             if "group" in what and n >= 8 * div:
                 G = int(rng.integers(2, 9 if BIG else 5))
                 g = api.Group([0] * G)
-                g.set_database(type_, db)
+                rg = np.random.default_rng([seed, it, 11])
+                n0 = int(rg.integers(max(G, 2), n + 1))                # a growable database: rows n0 .. n - 1 appended in place on the last shard
+                if n0 < n and rg.random() < 0.5:
+                    g.set_database(type_, db[:n0 * div], extra_capacity=n - n0)
+                    at = n0
+                    while at < n:
+                        c = int(min(n - at, rg.choice([1, 2, 9, 40])))
+                        g.append_database(db[at * div:(at + c) * div])
+                        at += c
+                else:
+                    g.set_database(type_, db)
                 idx, sc = g.match_topk(q, mask, 2.0, k)
                 ok = check((it, type_, "group", G, m, n, k, mask, note), idx, sc, oidx, osc, near_tol)   # (since round 4 the sharded protocol resolves too)
                 g.close()
@@ -196,12 +206,25 @@ for it in range(cases):
                         rc, oidx2, osc2 = oracle_lib.match_topk(t, qt.double().cpu().numpy(), dbt.double().cpu().numpy(), mask, 2.0, k)
                     else:
                         oidx2, osc2 = oidx, osc
-                    mt.pack_database(dbt)
+                    rg = np.random.default_rng([seed, it, 7])        # (its own stream: FUZZ_ONLY replays the main one draw for draw)
+                    grown = ""
+                    if dtype == torch.float64 and n >= 4 and rg.random() < 0.5:
+                        # the same database built IN PLACE: a reserved set, a bulk start and appends of random sizes (pr_sigset_reserve / _append)
+                        n0 = int(rg.integers(0, n))
+                        mt.reserve_database(dbt[:n0 * div] if n0 else None)
+                        at = n0
+                        while at < n:
+                            c = int(min(n - at, rg.choice([1, 1, 2, 7, 16, 33, 200])))
+                            mt.append_database(dbt[at * div:(at + c) * div].contiguous())
+                            at += c
+                        grown = "+grown"
+                    else:
+                        mt.pack_database(dbt)
                     idx, sc = mt.match(qt, mask, 2.0, k)
                     ok = check((it, type_, arith, "Matcher", str(dtype), m, n, k, mask, note), idx.cpu().numpy(), sc.cpu().numpy(), oidx2, osc2,
                                f16_tol(osc2, n, note) if arith == "f16" else near_tol)
                     mt.close()
-                    line.append(f"{type_}/Matcher/{arith}:{'ok' if ok else 'BAD'}")
+                    line.append(f"{type_}/Matcher/{arith}{grown}:{'ok' if ok else 'BAD'}")
         if "fused" in what and n >= 4:        # (n = 2, 3: the four z-scores are +-0.707 each and sum to EXACT ties, which no arithmetic orders reproducibly)
             sq, sdb, _, _, _ = sigs("sc", it, m, n); mq, mdb, _, _, _ = sigs("m2dp", it, m, n)
             rc, oidx, osc = oracle_lib.match_topk_fused(sq, mq, sdb, mdb, mask, 2.0, k)
